@@ -1,0 +1,155 @@
+/*
+ * svdd_hip.h — C ABI of libsvdd_hip.so, the MI355X (gfx950) implementation of the
+ * SVDD per-step propose / score-select / resample hot path.
+ *
+ * The reference (masa-ue/SVDD) is pure Python and has no FFI layer; its boundary for
+ * this path is the Python object protocol of `diffusion_gosai.Diffusion`. The entry
+ * points below are what a binding for that path replaces, each citing the reference
+ * lines whose tensor program it fuses (paths relative to the reference root).
+ * INTEGRATION.md shows the ctypes stub a reference maintainer would add.
+ *
+ * Conventions
+ *  - All pointers are DEVICE pointers unless marked "host". Caller owns every buffer;
+ *    nothing is allocated, freed or synchronised inside. Launches go to `stream`
+ *    (a hipStream_t passed as void*; NULL = the legacy default stream). Every entry
+ *    point is capturable in a hipGraph.
+ *  - Tokens are uint8: 0..3 = A,C,G,T; 4 = MASK (diffusion_gosai.py:85,94-95). The
+ *    reference's int64 token tensors carry the same values; the Python host mirror
+ *    converts at the API edge.
+ *  - Return value: 0 on success, a negative SVDD_E_* code otherwise. Launch failures
+ *    are reported as SVDD_E_LAUNCH (query hipGetLastError for detail).
+ *  - Arithmetic is fp32 in the reference's operation order; exp/log are evaluated
+ *    correctly rounded to fp32 (see DESIGN.md "Arithmetic contract").
+ */
+#ifndef SVDD_HIP_H
+#define SVDD_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SVDD_VOCAB 5      /* A,C,G,T,MASK */
+#define SVDD_MASK 4
+#define SVDD_MAX_M 1024   /* candidates per sample supported by svdd_select */
+
+enum {
+  SVDD_OK = 0,
+  SVDD_E_ARG = -1,      /* null pointer / non-positive size / M out of range */
+  SVDD_E_LAUNCH = -2,   /* hipLaunchKernel failed */
+  SVDD_E_NODEVICE = -3  /* no HIP device / wrong architecture */
+};
+
+/* Uniform source for the categorical draws. */
+enum {
+  SVDD_RNG_REPLAY = 0,  /* uniforms supplied by the caller (bit-exact replay of the
+                           reference's torch-CPU mt19937 stream, diffusion_gosai.py:33) */
+  SVDD_RNG_PHILOX = 1   /* counter-based Philox4x32-10 generated in-kernel; keyed by
+                           (seed, step, global row, candidate, position) so output is
+                           invariant to how rows are sharded over GPUs */
+};
+
+typedef struct svdd_rng {
+  int32_t kind;            /* SVDD_RNG_REPLAY | SVDD_RNG_PHILOX */
+  uint32_t step;           /* PHILOX: diffusion step index (0..S-1) */
+  const float* uniforms;   /* REPLAY: [M][B][L][5] fp32 in [0,1), candidate-major — the
+                              order M consecutive rand_like([B,L,5]) calls consume */
+  uint64_t seed;           /* PHILOX: 64-bit key */
+  uint64_t row_offset;     /* PHILOX: global index of this shard's row 0 */
+} svdd_rng_t;
+
+/* Selection rule of svdd_select. */
+enum {
+  SVDD_SELECT_ARGMAX = 0,      /* reference behaviour: argmax(softmax(scores)) (diffusion_gosai.py:1220,1225) */
+  SVDD_SELECT_MULTINOMIAL = 1  /* the commented-out torch.multinomial variant (:1223); PHILOX only */
+};
+
+/*
+ * svdd_propose — replaces, per diffusion step:
+ *   Diffusion._subs_parameterization               diffusion_gosai.py:286-304
+ *   q_xs construction                               diffusion_gosai.py:1194-1196
+ *   copy_flag                                       diffusion_gosai.py:1199
+ *   M x _sample_categorical + copy-flag merge       diffusion_gosai.py:30-34, 1203
+ *   M x transform_samples(...).float()              diffusion_gosai.py:1462-1470, 1208
+ *
+ *  logits  [B,L,5] fp32  raw backbone output (NOT modified; the reference edits it in place)
+ *  x       [B,L]   u8    current tokens x_t
+ *  dm      = fl32(move_chance_t - move_chance_s),  mcs = move_chance_s   (:1184-1187)
+ *  cand    [B,M,L] u8    out: the M proposals per sample
+ *  onehot  [B*M,L,4] fp32 out: value-net input, row (b*M+m); MASK rows all-zero
+ *  q_xs    [B,L,5] fp32  out, may be NULL (only the per-step API returns it, :1228)
+ */
+int svdd_propose(const float* logits, const uint8_t* x, float dm, float mcs,
+                 int B, int L, int M, const svdd_rng_t* rng,
+                 uint8_t* cand, float* onehot, float* q_xs, void* stream);
+
+/*
+ * svdd_select — replaces torch.stack(scores,1) -> softmax(dim=1) -> argmax(dim=1) ->
+ * per-row Python gather + stack                     diffusion_gosai.py:1219-1227 (= :1451-1459)
+ *
+ *  scores [B,M] fp32 (row b, candidate m) ; cand [B,M,L] u8
+ *  x_next [B,L] u8 out ; soft [B,M] fp32 out (softmax, may be NULL) ; idx [B] i32 out (may be NULL)
+ *  rng is read only for SVDD_SELECT_MULTINOMIAL (must be PHILOX).
+ */
+int svdd_select(const float* scores, const uint8_t* cand, int B, int L, int M, int mode,
+                const svdd_rng_t* rng, uint8_t* x_next, float* soft, int32_t* idx,
+                void* stream);
+
+/*
+ * svdd_x0hat — SVDD-PM / TDS posterior-mean candidate (Tweedie):
+ *   forward()'s _subs_parameterization + argmax(dim=2) + one_hot + keep-unmasked merge +
+ *   .float().transpose(1,2)                         diffusion_gosai.py:1415-1419,1430 ; :1263-1269
+ *  logits [R,L,5] raw backbone output for tokens xt [R,L] ; out onehot_t [R,4,L] fp32 ;
+ *  x0hat [R,L] u8 out (may be NULL).
+ */
+int svdd_x0hat(const float* logits, const uint8_t* xt, int R, int L,
+               float* onehot_t, uint8_t* x0hat, void* stream);
+
+/*
+ * svdd_finalize — noise-removal step: forward() then logits[:,:,:-1].argmax(-1)
+ *                                                   diffusion_gosai.py:1049-1060
+ *  out_i64 [B,L] int64 (the API's LongTensor) and/or out_u8 [B,L]; either may be NULL.
+ */
+int svdd_finalize(const float* logits, const uint8_t* x, int B, int L,
+                  int64_t* out_i64, uint8_t* out_u8, void* stream);
+
+/*
+ * svdd_transform_samples — tokens -> one-hot(4) with MASK rows zero
+ *                                                   diffusion_gosai.py:1462-1470 ≡ Enformer.py:269-277
+ *  transposed == 0: out [R,L,4] (value-net layout) ; != 0: out [R,4,L] (reward-model layout, Enformer.py:447)
+ */
+int svdd_transform_samples(const uint8_t* tok, int R, int L, int transposed, float* out,
+                           void* stream);
+
+/*
+ * svdd_subs_logp — Diffusion.forward()'s SUBS re-parameterisation alone
+ *                                                   diffusion_gosai.py:286-304
+ *  logp [B,L,5] out. (Used by the per-step API mirror and the DPS baseline.)
+ */
+int svdd_subs_logp(const float* logits, const uint8_t* x, int B, int L, float* logp,
+                   void* stream);
+
+/*
+ * svdd_tds_resample — SMC/TDS baseline resampling step
+ *   ratio = exp((num-den)/alpha); p = ratio/ratio.sum(); idx = np.random.choice(B,B,p=p);
+ *   return sample[idx]                              diffusion_gosai.py:1280-1284
+ *  reward_num, reward_den [B] fp32 ; sample [B,L] u8 ; u [B] fp64 uniforms in [0,1)
+ *  (REPLAY of numpy's RandomState.random_sample, supplied by the host) ;
+ *  out x_next [B,L] u8 ; idx [B] i32 (may be NULL) ; work [B] fp64 scratch (cdf).
+ */
+int svdd_tds_resample(const float* reward_num, const float* reward_den, float alpha,
+                      const uint8_t* sample, const double* u, int B, int L,
+                      uint8_t* x_next, int32_t* idx, double* work, void* stream);
+
+/* Library / device probe (host). Returns SVDD_OK and fills arch (e.g. "gfx950") and CU count. */
+int svdd_device_info(char* arch, int arch_len, int* num_cu);
+
+/* ABI version of this header: bumped on any signature change. */
+int svdd_abi_version(void);
+#define SVDD_ABI_VERSION 1
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVDD_HIP_H */

@@ -1,0 +1,372 @@
+"""Generate the golden vectors under tests/golden/ by RUNNING THE REFERENCE on CPU.
+
+Run in the build container only (needs /root/reference):   python tests/golden/make_golden.py
+The reference is imported from where it lies (tests/golden/_ref_import.py); only inputs and
+outputs are stored. Fixtures:
+
+  g1_sample_categorical.npz   _sample_categorical                 diffusion_gosai.py:30-34
+  g2_subs.npz                 Diffusion._subs_parameterization    :286-304
+  g3_schedule.npz             noise/move-chance prologue           :1036-1038,1176-1187
+  g4_transform.npz            transform_samples                    :1462-1470
+  g5_step_mc.npz              one _ddpm_update_finetune_controlled :1174-1228 (adversarial score ties)
+  g5_step_mc_bvl.npz          same, backbone output laid out [B,5,L] like the reference CNN's
+  g6_traj_mc_c1.npz           controlled_sample, C1 (B=4,L=200,M=2,S=128), tiny nets, per-step record
+  g6_traj_mc_s16.npz          controlled_sample, S=16, B=3, L=50, M=5
+  g7_traj_pm.npz              controlled_sample_tweedie, S=8, B=3, L=50, M=3
+  g8_traj_tds.npz             controlled_sample_TDS, S=8, B=6, L=50 (np.random.seed)
+  g9_rng.npz                  torch / numpy mt19937 streams
+  g10_decode_sample.npz       decode_sample (un-guided), S=16, B=3, L=50
+  nets_tiny.npz               state_dicts of the tiny nets used above (for net-parity tests)
+"""
+import os
+import sys
+import warnings
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+warnings.filterwarnings("ignore")
+from _ref_import import import_reference, make_cfg  # noqa: E402
+
+dg, En = import_reference()
+torch.set_num_threads(1)
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **{k: (v.numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in arrs.items()})
+    print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def tiny_diffusion(length, steps, seed=44):
+    torch.manual_seed(seed)
+    return dg.Diffusion(make_cfg(length=length, hidden_dim=16, num_cnn_stacks=1, steps=steps)).eval()
+
+
+def tiny_value(seed=45):
+    torch.manual_seed(seed)
+    emb = En.ConvGRUTrunk(stem_in_channels=4, stem_channels=8, stem_kernel_size=15, n_conv=3, channel_init=8,
+                          channel_mult=1, kernel_size=5, act_func="relu", conv_norm=True, pool_func=None,
+                          pool_size=None, residual=True, crop_len=0, n_gru=1, dropout=0.1, gru_norm=True).eval()
+    head = En.ConvHead(n_tasks=1, in_channels=8, act_func=None, pool_func="avg", norm=False).eval()
+    # non-trivial BatchNorm statistics so eval-mode BN is exercised
+    g = torch.Generator().manual_seed(seed)
+    for m in emb.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.running_mean.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+            m.running_var.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+    return emb, head
+
+
+def sd_np(prefix, module):
+    return {f"{prefix}.{k}": v.detach().numpy() for k, v in module.state_dict().items()}
+
+
+# ----------------------------------------------------------------------------- G9
+def g9():
+    out = {}
+    for seed, n in [(0, 140), (44, 5000), (123456789, 256000)]:
+        torch.manual_seed(seed)
+        r = torch.rand(n)
+        out[f"torch_s{seed}_n{n}_head"] = r[:256]
+        out[f"torch_s{seed}_n{n}_tail"] = r[-256:]
+        out[f"torch_s{seed}_n{n}_sum"] = np.float64(r.double().sum().item())
+    # rand_like on a [B,L,5] tensor consumes the same row-major stream
+    torch.manual_seed(7)
+    a = torch.rand_like(torch.empty(3, 50, 5))
+    torch.manual_seed(7)
+    b = torch.rand(3 * 50 * 5).view(3, 50, 5)
+    assert torch.equal(a, b)
+    out["torch_s7_randlike_3_50_5"] = a
+    for seed, n in [(0, 10), (44, 1000)]:
+        np.random.seed(seed)
+        out[f"numpy_s{seed}_n{n}"] = np.random.random_sample(n)
+    save("g9_rng.npz", **out)
+
+
+# ----------------------------------------------------------------------------- G1
+def g1():
+    torch.manual_seed(1)
+    B, L = 4, 200
+    p = torch.softmax(torch.randn(B, L, 4) * 2.0, -1) * 0.0078
+    q = torch.cat([p, torch.full((B, L, 1), 0.91)], -1)
+    # rows with the unmasked pattern (all zero except own token + MASK entry)
+    un = torch.rand(B, L) < 0.4
+    tok = torch.randint(0, 4, (B, L))
+    qz = torch.zeros_like(q)
+    qz.scatter_(2, tok[..., None], 0.0078)
+    qz[..., 4] = 0.91
+    q = torch.where(un[..., None], qz, q).contiguous()
+    torch.manual_seed(11)
+    u = torch.rand_like(q)
+    torch.manual_seed(11)
+    tokens = dg._sample_categorical(q)
+    save("g1_sample_categorical.npz", q=q, u=u, tokens=tokens, seed=11)
+
+
+# ----------------------------------------------------------------------------- G2 / G4
+def g2_g4(d):
+    torch.manual_seed(2)
+    B, L = 4, 200
+    logits = torch.randn(B, L, 5) * 3.0
+    logits[0, :10] = 0.0                     # exact ties
+    logits[1, :10, :4] = torch.tensor([1.0, 1.0, 0.5, 1.0])
+    xt = torch.where(torch.rand(B, L) < 0.5, torch.randint(0, 4, (B, L)), torch.full((B, L), 4))
+    logp = d._subs_parameterization(logits.clone(), xt)
+    save("g2_subs.npz", logits=logits, xt=xt, logp=logp)
+    oh = d.transform_samples(xt)
+    save("g4_transform.npz", tokens=xt, onehot=oh)
+
+
+# ----------------------------------------------------------------------------- G3
+def g3(d):
+    out = {}
+    for S in (128, 16, 8):
+        eps = 1e-5
+        timesteps = torch.linspace(1, eps, S + 1)
+        dt = (1 - eps) / S
+        rows = []
+        for i in range(S):
+            t = timesteps[i] * torch.ones(2, 1)
+            sigma_t, _ = d.noise(t)
+            sigma_s, _ = d.noise(t - dt)
+            mct = 1 - torch.exp(-sigma_t.squeeze(-1))
+            mcs = 1 - torch.exp(-sigma_s.squeeze(-1))
+            rows.append([t[0, 0].item(), sigma_t[0, 0].item(), sigma_s[0, 0].item(), mct[0].item(), mcs[0].item(),
+                         (mct - mcs)[0].item()])
+        out[f"S{S}"] = np.asarray(rows, dtype=np.float32)
+        out[f"S{S}_t_last"] = np.float32(timesteps[-1].item())
+        out[f"S{S}_sigma_last"] = np.float32(d.noise(timesteps[-1] * torch.ones(1, 1))[0].item())
+    save("g3_schedule.npz", **out)
+
+
+# ------------------------------------------------------------- recording wrappers
+class RecBackbone(torch.nn.Module):
+    """Wraps the reference backbone; records (x, raw logits) of every call."""
+
+    def __init__(self, inner):
+        super().__init__()
+        self.inner = inner
+        self.calls = []
+
+    def forward(self, x, sigma, *a, **k):
+        out = self.inner(x, sigma, *a, **k)
+        self.calls.append((x.clone(), out.detach().clone()))
+        return out
+
+
+class FixedBackbone(torch.nn.Module):
+    def __init__(self, logits):
+        super().__init__()
+        self.logits = logits
+
+    def forward(self, x, sigma):
+        return self.logits.clone()
+
+
+class RecCallable:
+    def __init__(self, fn):
+        self.fn = fn
+        self.inputs, self.outputs = [], []
+
+    def __call__(self, x):
+        self.inputs.append(x.detach().clone())
+        y = self.fn(x)
+        self.outputs.append(y.detach().clone())
+        return y
+
+    def eval(self):
+        return self
+
+
+# ----------------------------------------------------------------------------- G5
+def g5(d, bvl=False):
+    """bvl=False: backbone output contiguous [B,L,5] (stream order [m][b][l][v]);
+    bvl=True: backbone output is a permuted view of a [B,5,L] buffer, as the reference's CNNModel
+    returns (models/dnaconv.py:201) -> rand_like fills in memory order [m][b][v][l]."""
+    torch.manual_seed(6 if bvl else 5)
+    B, L, M = 8, 200, 6
+    logits = torch.randn(B, L, 5) * 1.5
+    x = torch.where(torch.rand(B, L) < 0.45, torch.randint(0, 4, (B, L)), torch.full((B, L), 4))
+    x[7] = 4
+    scores = torch.randn(B, M) * 0.3
+    scores[1] = 0.25                                  # all tied -> index 0
+    scores[2, 4] = scores[2].max() + 0.5              # clear winner
+    scores[3, 2] = scores[3, 5] = scores[3].max() + 1.0   # exact two-way tie -> lowest index
+    scores[4] = torch.tensor([0.1, 0.1 + 2 ** -27, 0.1, 0.1 + 2 ** -27, 0.1, 0.1])  # 1-ulp near tie
+    scores[5] = scores[5] * 50.0                      # large spread
+    scores[6] = -30.0 + torch.arange(M) * 1e-3        # offset
+    inner = d.backbone
+    if bvl:
+        logits = logits.permute(0, 2, 1).contiguous().permute(0, 2, 1)
+        assert logits.stride() == (5 * L, 1, L)
+    d.backbone = FixedBackbone(logits)
+    emb = RecCallable(lambda t: t)
+    calls = {"n": 0}
+
+    def head_fn(t):
+        m = calls["n"]
+        calls["n"] += 1
+        return scores[:, m].clone().view(B, 1, 1)
+
+    head = RecCallable(head_fn)
+    S, eps = 128, 1e-5
+    i = 40
+    t = torch.linspace(1, eps, S + 1)[i] * torch.ones(B, 1)
+    dt = (1 - eps) / S
+    torch.manual_seed(55)
+    uniforms = torch.rand(M, B, 5, L) if bvl else torch.rand(M, B, L, 5)   # stream (= memory) order
+    torch.manual_seed(55)
+    x_next, x_in, q_xs, copy_flag = d._ddpm_update_finetune_controlled(x, t, dt, emb, head, repeats=M)
+    assert q_xs.stride() == logits.stride()
+    cand = torch.stack([oh.argmax(-1) * (oh.sum(-1) > 0) + 4 * (oh.sum(-1) == 0) for oh in emb.inputs], 1)
+    soft = torch.softmax(scores, 1)
+    idx = torch.argmax(soft, 1)
+    sigma_t, _ = d.noise(t)
+    sigma_s, _ = d.noise(t - dt)
+    mct = (1 - torch.exp(-sigma_t.squeeze(-1)))[0]
+    mcs = (1 - torch.exp(-sigma_s.squeeze(-1)))[0]
+    d.backbone = inner
+    save("g5_step_mc_bvl.npz" if bvl else "g5_step_mc.npz", logits=logits, x=x, scores=scores, uniforms=uniforms, seed=55, mct=mct, mcs=mcs,
+         dm=(mct - mcs), q_xs=q_xs, copy_flag=copy_flag, cand=cand.to(torch.uint8),
+         onehot=torch.stack(emb.inputs, 1), soft=soft, idx=idx, x_next=x_next)
+
+
+# ----------------------------------------------------------------------------- G6
+def traj_mc(name, L, S, B, M, seed):
+    d = tiny_diffusion(L, S)
+    emb_m, head_m = tiny_value()
+    rec = RecBackbone(d.backbone)
+    d.backbone = rec
+    emb, head = RecCallable(emb_m), RecCallable(head_m)
+    torch.manual_seed(seed)
+    x0 = d.controlled_sample(emb, head, eval_sp_size=B, sample_M=M)
+    xs = torch.stack([c[0] for c in rec.calls])                 # [S+1,B,L]
+    logits = torch.stack([c[1] for c in rec.calls])             # [S+1,B,L,5]
+    onehots = torch.stack(emb.inputs).view(S, M, B, L, 4)
+    scores = torch.stack([o.squeeze() for o in head.outputs]).view(S, M, B).permute(0, 2, 1).contiguous()
+    d.backbone = rec.inner
+    save(name, xs=xs.to(torch.uint8), logits=logits, scores=scores,
+         cand=(onehots.argmax(-1) * (onehots.sum(-1) > 0) + 4 * (onehots.sum(-1) == 0)).permute(0, 2, 1, 3).to(torch.uint8),
+         x0=x0, seed=seed, B=B, L=L, M=M, S=S)
+    return d, emb_m, head_m
+
+
+# ----------------------------------------------------------------------------- G7
+class RewardWrap(torch.nn.Module):
+    """reward_model(x[B,4,L]) -> [B, n_tasks, 1] built from the reference's own OriBaseModel."""
+
+    def __init__(self, emb, head):
+        super().__init__()
+        self.m = En.OriBaseModel(embedding=emb, head=head)
+
+    def forward(self, x):
+        return self.m(x)
+
+
+def traj_pm(seed=3):
+    L, S, B, M = 50, 8, 3, 3
+    d = tiny_diffusion(L, S)
+    emb_m, head_m = tiny_value()
+    reward = RewardWrap(emb_m, head_m).eval()
+    rec = RecBackbone(d.backbone)
+    d.backbone = rec
+    rr = RecCallable(reward)
+    torch.manual_seed(seed)
+    x0 = d.controlled_sample_tweedie(rr, eval_sp_size=B, sample_M=M, options="True", task="dna")
+    # per step: 1 + M backbone calls; final: 1
+    calls = rec.calls
+    xs, logits, cx, cl = [], [], [], []
+    k = 0
+    for _ in range(S):
+        xs.append(calls[k][0]); logits.append(calls[k][1]); k += 1
+        cx.append(torch.stack([calls[k + m][0] for m in range(M)], 1))
+        cl.append(torch.stack([calls[k + m][1] for m in range(M)], 1))
+        k += M
+    xs.append(calls[k][0]); logits.append(calls[k][1])
+    scores = torch.stack([o[:, 0].squeeze() for o in rr.outputs]).view(S, M, B).permute(0, 2, 1).contiguous()
+    x0hat_oh = torch.stack(rr.inputs).view(S, M, B, 4, L).permute(0, 2, 1, 3, 4).contiguous()
+    d.backbone = rec.inner
+    save("g7_traj_pm.npz", xs=torch.stack(xs).to(torch.uint8), logits=torch.stack(logits),
+         cand=torch.stack(cx).to(torch.uint8), cand_logits=torch.stack(cl), x0hat_onehot_t=x0hat_oh,
+         scores=scores, x0=x0, seed=seed, B=B, L=L, M=M, S=S)
+
+
+# ----------------------------------------------------------------------------- G8
+def traj_tds(seed=4, np_seed=9, alpha=0.5):
+    L, S, B = 50, 8, 6
+    d = tiny_diffusion(L, S)
+    emb_m, head_m = tiny_value()
+    reward = RewardWrap(emb_m, head_m).eval()
+    rec = RecBackbone(d.backbone)
+    d.backbone = rec
+    rr = RecCallable(reward)
+    torch.manual_seed(seed)
+    np.random.seed(np_seed)
+    x0 = d.controlled_sample_TDS(rr, alpha, eval_sp_size=B)
+    calls = rec.calls
+    xs, logits, samples, s_logits, den_logits = [], [], [], [], []
+    for i in range(S):
+        xs.append(calls[3 * i][0]); logits.append(calls[3 * i][1])
+        samples.append(calls[3 * i + 1][0]); s_logits.append(calls[3 * i + 1][1])
+        den_logits.append(calls[3 * i + 2][1])
+    xs.append(calls[3 * S][0]); logits.append(calls[3 * S][1])
+    num = torch.stack([rr.outputs[2 * i][:, 0][:, 0] for i in range(S)])
+    den = torch.stack([rr.outputs[2 * i + 1][:, 0][:, 0] for i in range(S)])
+    np.random.seed(np_seed)
+    choice_u = np.random.random_sample(S * B).reshape(S, B)
+    d.backbone = rec.inner
+    save("g8_traj_tds.npz", xs=torch.stack(xs).to(torch.uint8), logits=torch.stack(logits),
+         samples=torch.stack(samples).to(torch.uint8), sample_logits=torch.stack(s_logits),
+         den_logits=torch.stack(den_logits), num=num, den=den, choice_u=choice_u, x0=x0, alpha=alpha,
+         seed=seed, np_seed=np_seed, B=B, L=L, S=S)
+
+
+# ----------------------------------------------------------------------------- G10
+def g10(seed=6):
+    L, S, B = 50, 16, 3
+    d = tiny_diffusion(L, S)
+    rec = RecBackbone(d.backbone)
+    d.backbone = rec
+    torch.manual_seed(seed)
+    x0 = d.decode_sample(eval_sp_size=B)
+    save("g10_decode_sample.npz", xs=torch.stack([c[0] for c in rec.calls]).to(torch.uint8),
+         logits=torch.stack([c[1] for c in rec.calls]), x0=x0, seed=seed, B=B, L=L, S=S)
+    d.backbone = rec.inner
+
+
+def nets():
+    d200 = tiny_diffusion(200, 128)
+    emb_m, head_m = tiny_value()
+    arrs = {}
+    arrs.update(sd_np("backbone", d200.backbone))
+    arrs.update(sd_np("embedding", emb_m))
+    arrs.update(sd_np("head", head_m))
+    # one forward of each for net-parity tests
+    torch.manual_seed(8)
+    x = torch.where(torch.rand(3, 200) < 0.5, torch.randint(0, 4, (3, 200)), torch.full((3, 200), 4))
+    with torch.no_grad():
+        arrs["probe_x"] = x.numpy()
+        arrs["probe_logits"] = d200.backbone(x, torch.zeros(3)).numpy()
+        oh = d200.transform_samples(x).float()
+        arrs["probe_value"] = head_m(emb_m(oh)).numpy()
+        arrs["probe_reward"] = RewardWrap(emb_m, head_m).eval()(oh.transpose(1, 2)).numpy()
+    save("nets_tiny.npz", **arrs)
+
+
+if __name__ == "__main__":
+    d = tiny_diffusion(200, 128)
+    g9()
+    g1()
+    g2_g4(d)
+    g3(d)
+    g5(d)
+    g5(d, bvl=True)
+    traj_mc("g6_traj_mc_c1.npz", L=200, S=128, B=4, M=2, seed=0)
+    traj_mc("g6_traj_mc_s16.npz", L=50, S=16, B=3, M=5, seed=1)
+    traj_pm()
+    traj_tds()
+    g10()
+    nets()
