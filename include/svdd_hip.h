@@ -41,6 +41,15 @@ enum {
   SVDD_E_NODEVICE = -3  /* no HIP device / wrong architecture */
 };
 
+/* Memory layout of the [B,L,5] tensors (logits, q_xs, logp, replay uniforms).
+ * The reference's CNN backbone returns `feat.permute(0, 2, 1)` (models/dnaconv.py:201), a view of a
+ * [B,5,L] buffer; log_p_x0, q_xs and rand_like(q_xs) inherit those strides and torch fills
+ * rand_like in MEMORY order. A drop-in must therefore accept both images. */
+enum {
+  SVDD_LAYOUT_BLV = 0,  /* element (b,l,v) at (b*L + l)*5 + v   — contiguous [B,L,5] (e.g. DiT) */
+  SVDD_LAYOUT_BVL = 1   /* element (b,l,v) at (b*5 + v)*L + l   — [B,5,L], the conv-native image */
+};
+
 /* Uniform source for the categorical draws. */
 enum {
   SVDD_RNG_REPLAY = 0,  /* uniforms supplied by the caller (bit-exact replay of the
@@ -53,8 +62,8 @@ enum {
 typedef struct svdd_rng {
   int32_t kind;            /* SVDD_RNG_REPLAY | SVDD_RNG_PHILOX */
   uint32_t step;           /* PHILOX: diffusion step index (0..S-1) */
-  const float* uniforms;   /* REPLAY: [M][B][L][5] fp32 in [0,1), candidate-major — the
-                              order M consecutive rand_like([B,L,5]) calls consume */
+  const float* uniforms;   /* REPLAY: M consecutive blocks of B*L*5 fp32 in [0,1), each in the
+                              SAME layout as `logits` — the order M rand_like(q_xs) calls consume */
   uint64_t seed;           /* PHILOX: 64-bit key */
   uint64_t row_offset;     /* PHILOX: global index of this shard's row 0 */
 } svdd_rng_t;
@@ -73,15 +82,15 @@ enum {
  *   M x _sample_categorical + copy-flag merge       diffusion_gosai.py:30-34, 1203
  *   M x transform_samples(...).float()              diffusion_gosai.py:1462-1470, 1208
  *
- *  logits  [B,L,5] fp32  raw backbone output (NOT modified; the reference edits it in place)
+ *  logits  [B,L,5] fp32  raw backbone output in `layout` (NOT modified; the reference edits it in place)
  *  x       [B,L]   u8    current tokens x_t
  *  dm      = fl32(move_chance_t - move_chance_s),  mcs = move_chance_s   (:1184-1187)
  *  cand    [B,M,L] u8    out: the M proposals per sample
  *  onehot  [B*M,L,4] fp32 out: value-net input, row (b*M+m); MASK rows all-zero
- *  q_xs    [B,L,5] fp32  out, may be NULL (only the per-step API returns it, :1228)
+ *  q_xs    [B,L,5] fp32  out in `layout`, may be NULL (only the per-step API returns it, :1228)
  */
 int svdd_propose(const float* logits, const uint8_t* x, float dm, float mcs,
-                 int B, int L, int M, const svdd_rng_t* rng,
+                 int B, int L, int M, int layout, const svdd_rng_t* rng,
                  uint8_t* cand, float* onehot, float* q_xs, void* stream);
 
 /*
@@ -103,7 +112,7 @@ int svdd_select(const float* scores, const uint8_t* cand, int B, int L, int M, i
  *  logits [R,L,5] raw backbone output for tokens xt [R,L] ; out onehot_t [R,4,L] fp32 ;
  *  x0hat [R,L] u8 out (may be NULL).
  */
-int svdd_x0hat(const float* logits, const uint8_t* xt, int R, int L,
+int svdd_x0hat(const float* logits, const uint8_t* xt, int R, int L, int layout,
                float* onehot_t, uint8_t* x0hat, void* stream);
 
 /*
@@ -111,7 +120,7 @@ int svdd_x0hat(const float* logits, const uint8_t* xt, int R, int L,
  *                                                   diffusion_gosai.py:1049-1060
  *  out_i64 [B,L] int64 (the API's LongTensor) and/or out_u8 [B,L]; either may be NULL.
  */
-int svdd_finalize(const float* logits, const uint8_t* x, int B, int L,
+int svdd_finalize(const float* logits, const uint8_t* x, int B, int L, int layout,
                   int64_t* out_i64, uint8_t* out_u8, void* stream);
 
 /*
@@ -127,7 +136,7 @@ int svdd_transform_samples(const uint8_t* tok, int R, int L, int transposed, flo
  *                                                   diffusion_gosai.py:286-304
  *  logp [B,L,5] out. (Used by the per-step API mirror and the DPS baseline.)
  */
-int svdd_subs_logp(const float* logits, const uint8_t* x, int B, int L, float* logp,
+int svdd_subs_logp(const float* logits, const uint8_t* x, int B, int L, int layout, float* logp,
                    void* stream);
 
 /*
@@ -136,7 +145,8 @@ int svdd_subs_logp(const float* logits, const uint8_t* x, int B, int L, float* l
  *   return sample[idx]                              diffusion_gosai.py:1280-1284
  *  reward_num, reward_den [B] fp32 ; sample [B,L] u8 ; u [B] fp64 uniforms in [0,1)
  *  (REPLAY of numpy's RandomState.random_sample, supplied by the host) ;
- *  out x_next [B,L] u8 ; idx [B] i32 (may be NULL) ; work [B] fp64 scratch (cdf).
+ *  out x_next [B,L] u8 ; idx [B] i32 (may be NULL) ; work [2*B] fp64 scratch (cdf + ratio).
+ *  One shard's B particles are resampled by one workgroup (B <= ~64k).
  */
 int svdd_tds_resample(const float* reward_num, const float* reward_den, float alpha,
                       const uint8_t* sample, const double* u, int B, int L,

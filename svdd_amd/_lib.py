@@ -1,0 +1,97 @@
+"""ctypes binding of libsvdd_hip.so (include/svdd_hip.h).
+
+The HIP library is the product: there is NO CPU or PyTorch fallback for the hot-path
+operators. Importing this module without the built library, or calling an operator
+without a gfx950 device, raises.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+SO_PATH = os.path.join(CSRC, "libsvdd_hip.so")
+ABI_VERSION = 1
+
+OK, E_ARG, E_LAUNCH, E_NODEVICE = 0, -1, -2, -3
+LAYOUT_BLV, LAYOUT_BVL = 0, 1
+RNG_REPLAY, RNG_PHILOX = 0, 1
+SELECT_ARGMAX, SELECT_MULTINOMIAL = 0, 1
+MAX_M = 1024
+
+EXPORTS = (
+    "svdd_abi_version", "svdd_device_info", "svdd_propose", "svdd_select", "svdd_x0hat",
+    "svdd_finalize", "svdd_transform_samples", "svdd_subs_logp", "svdd_tds_resample",
+)
+
+
+class SvddRng(ctypes.Structure):
+    """struct svdd_rng (include/svdd_hip.h)."""
+    _fields_ = [("kind", ctypes.c_int32), ("step", ctypes.c_uint32), ("uniforms", ctypes.c_void_p),
+                ("seed", ctypes.c_uint64), ("row_offset", ctypes.c_uint64)]
+
+
+class SvddError(RuntimeError):
+    pass
+
+
+def build(force=False):
+    """Compile csrc/svdd_kernels.hip for gfx950 (hipcc cross-compiles without a GPU)."""
+    src = os.path.join(CSRC, "svdd_kernels.hip")
+    hdr = os.path.join(os.path.dirname(_HERE), "include", "svdd_hip.h")
+    stale = (not os.path.exists(SO_PATH)
+             or os.path.getmtime(SO_PATH) < max(os.path.getmtime(src), os.path.getmtime(hdr)))
+    if force or stale:
+        subprocess.check_call(["make", "-C", CSRC, "-B"])
+    return SO_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load libsvdd_hip.so. torch is imported first so that the library binds to the HIP
+    runtime already resident in the process (same libamdhip64 SONAME) instead of a second copy."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    import torch  # noqa: F401  (loads torch's bundled libamdhip64.so.7 first)
+    if not os.path.exists(SO_PATH):
+        raise SvddError(f"{SO_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "or `make -C svdd_amd/csrc`. There is no CPU fallback for the SVDD hot path.")
+    L = ctypes.CDLL(SO_PATH)
+    for name in EXPORTS:
+        if not hasattr(L, name):
+            raise SvddError(f"libsvdd_hip.so does not export {name}")
+    if L.svdd_abi_version() != ABI_VERSION:
+        raise SvddError(f"libsvdd_hip.so ABI {L.svdd_abi_version()} != binding ABI {ABI_VERSION}; rebuild")
+    vp, f32, i32 = ctypes.c_void_p, ctypes.c_float, ctypes.c_int
+    L.svdd_propose.argtypes = [vp, vp, f32, f32, i32, i32, i32, i32, ctypes.POINTER(SvddRng), vp, vp, vp, vp]
+    L.svdd_select.argtypes = [vp, vp, i32, i32, i32, i32, ctypes.POINTER(SvddRng), vp, vp, vp, vp]
+    L.svdd_x0hat.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp]
+    L.svdd_finalize.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp]
+    L.svdd_transform_samples.argtypes = [vp, i32, i32, i32, vp, vp]
+    L.svdd_subs_logp.argtypes = [vp, vp, i32, i32, i32, vp, vp]
+    L.svdd_tds_resample.argtypes = [vp, vp, f32, vp, vp, i32, i32, vp, vp, vp, vp]
+    L.svdd_device_info.argtypes = [ctypes.c_char_p, i32, ctypes.POINTER(ctypes.c_int)]
+    for name in EXPORTS:
+        getattr(L, name).restype = ctypes.c_int
+    _lib = L
+    return L
+
+
+def device_info():
+    buf = ctypes.create_string_buffer(64)
+    ncu = ctypes.c_int(0)
+    rc = lib().svdd_device_info(buf, 64, ctypes.byref(ncu))
+    if rc != OK:
+        raise SvddError("no HIP device visible to libsvdd_hip.so")
+    return buf.value.decode().split(":")[0], ncu.value
+
+
+_ERR = {E_ARG: "invalid argument", E_LAUNCH: "kernel launch failed", E_NODEVICE: "no HIP device"}
+
+
+def check(rc, what):
+    if rc != OK:
+        raise SvddError(f"{what}: {_ERR.get(rc, rc)}")

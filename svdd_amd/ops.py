@@ -1,0 +1,172 @@
+"""Torch-tensor front end of the C ABI (include/svdd_hip.h): raw pointers of CUDA(HIP) tensors
+are handed to libsvdd_hip.so on torch's current stream. No fallbacks: tensors must live on the
+GPU, and the library must be present.
+
+Token tensors are uint8 (0..3 = A,C,G,T; 4 = MASK). `[B,L,5]` float tensors may be contiguous
+(layout BLV) or a permuted view of a `[B,5,L]` buffer (layout BVL, what a Conv1d backbone
+returns after `.permute(0, 2, 1)`, reference models/dnaconv.py:201); both are consumed in place.
+"""
+import ctypes
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import (LAYOUT_BLV, LAYOUT_BVL, RNG_PHILOX, RNG_REPLAY, SELECT_ARGMAX,  # noqa: F401
+                   SELECT_MULTINOMIAL, SvddError, SvddRng)
+
+MASK = 4
+
+
+@dataclass
+class Rng:
+    """Uniform source for the categorical draws.
+
+    replay : uniforms tensor = M consecutive blocks in the same memory layout as the logits
+             (the bytes `M x rand_like(q_xs)` produce from torch's CPU mt19937 stream).
+    philox : counter-based, keyed by (seed, step, row_offset + b, m, l)."""
+    uniforms: Optional[torch.Tensor] = None
+    seed: int = 0
+    row_offset: int = 0
+    step: int = 0
+
+    def c_struct(self):
+        if self.uniforms is not None:
+            return SvddRng(RNG_REPLAY, 0, self.uniforms.data_ptr(), 0, 0)
+        return SvddRng(RNG_PHILOX, self.step, None, self.seed & 0xFFFFFFFFFFFFFFFF, self.row_offset)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need(t, dtype, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise SvddError(f"{name} must be a GPU tensor (the SVDD hot path has no CPU fallback)")
+    if t.dtype != dtype:
+        raise SvddError(f"{name} must be {dtype}, got {t.dtype}")
+    return t
+
+
+def layout_of(t):
+    """(tensor-to-pass, layout) for a logical [R,L,5] fp32 tensor."""
+    assert t.dim() == 3 and t.shape[2] == 5, t.shape
+    if t.is_contiguous():
+        return t, LAYOUT_BLV
+    if t.transpose(1, 2).is_contiguous():
+        return t, LAYOUT_BVL
+    return t.contiguous(), LAYOUT_BLV
+
+
+def _empty_like_layout(t, layout):
+    if layout == LAYOUT_BLV:
+        return torch.empty(t.shape, dtype=torch.float32, device=t.device)
+    R, L, V = t.shape
+    return torch.empty((R, V, L), dtype=torch.float32, device=t.device).transpose(1, 2)
+
+
+def propose(logits, x, dm, mcs, M, rng, want_q=False, cand=None, onehot=None):
+    """-> (cand u8 [B,M,L], onehot f32 [B*M,L,4], q_xs f32 [B,L,5] (same strides as logits) | None)."""
+    logits = _need(logits, torch.float32, "logits")
+    x = _need(x, torch.uint8, "x").contiguous()
+    B, L = x.shape
+    logits, layout = layout_of(logits)
+    assert logits.shape == (B, L, 5), (logits.shape, x.shape)
+    if cand is None:
+        cand = torch.empty((B, M, L), dtype=torch.uint8, device=x.device)
+    if onehot is None:
+        onehot = torch.empty((B * M, L, 4), dtype=torch.float32, device=x.device)
+    q = _empty_like_layout(logits, layout) if want_q else None
+    if rng.uniforms is not None:
+        u = _need(rng.uniforms, torch.float32, "uniforms")
+        assert u.is_contiguous() and u.numel() == M * B * L * 5, (u.shape, M, B, L)
+    rs = rng.c_struct()
+    rc = _lib.lib().svdd_propose(logits.data_ptr(), x.data_ptr(), float(dm), float(mcs), B, L, M, layout,
+                                 ctypes.byref(rs), cand.data_ptr(), onehot.data_ptr(),
+                                 q.data_ptr() if q is not None else None, _stream())
+    _lib.check(rc, "svdd_propose")
+    return cand, onehot, q
+
+
+def select(scores, cand, mode=SELECT_ARGMAX, rng=None, want_soft=True, x_next=None):
+    """-> (x_next u8 [B,L], soft f32 [B,M] | None, idx i32 [B])."""
+    cand = _need(cand, torch.uint8, "cand").contiguous()
+    B, M, L = cand.shape
+    scores = _need(scores, torch.float32, "scores").contiguous()
+    assert scores.numel() == B * M, (scores.shape, cand.shape)
+    if x_next is None:
+        x_next = torch.empty((B, L), dtype=torch.uint8, device=cand.device)
+    soft = torch.empty((B, M), dtype=torch.float32, device=cand.device) if want_soft else None
+    idx = torch.empty((B,), dtype=torch.int32, device=cand.device)
+    rs = rng.c_struct() if rng is not None else None
+    rc = _lib.lib().svdd_select(scores.data_ptr(), cand.data_ptr(), B, L, M, mode,
+                                ctypes.byref(rs) if rs is not None else None, x_next.data_ptr(),
+                                soft.data_ptr() if soft is not None else None, idx.data_ptr(), _stream())
+    _lib.check(rc, "svdd_select")
+    return x_next, soft, idx
+
+
+def x0hat(logits, xt, want_tokens=False):
+    """-> (onehot_t f32 [R,4,L], x0hat u8 [R,L] | None)."""
+    logits = _need(logits, torch.float32, "logits")
+    xt = _need(xt, torch.uint8, "xt").contiguous()
+    R, L = xt.shape
+    logits, layout = layout_of(logits)
+    oh = torch.empty((R, 4, L), dtype=torch.float32, device=xt.device)
+    xh = torch.empty((R, L), dtype=torch.uint8, device=xt.device) if want_tokens else None
+    rc = _lib.lib().svdd_x0hat(logits.data_ptr(), xt.data_ptr(), R, L, layout, oh.data_ptr(),
+                               xh.data_ptr() if xh is not None else None, _stream())
+    _lib.check(rc, "svdd_x0hat")
+    return oh, xh
+
+
+def finalize(logits, x):
+    """Noise-removal argmax -> int64 [B,L] (the API's LongTensor)."""
+    logits = _need(logits, torch.float32, "logits")
+    x = _need(x, torch.uint8, "x").contiguous()
+    B, L = x.shape
+    logits, layout = layout_of(logits)
+    out = torch.empty((B, L), dtype=torch.int64, device=x.device)
+    rc = _lib.lib().svdd_finalize(logits.data_ptr(), x.data_ptr(), B, L, layout, out.data_ptr(), None, _stream())
+    _lib.check(rc, "svdd_finalize")
+    return out
+
+
+def transform_samples(tok, transposed=False):
+    """tokens u8 [R,L] -> one-hot f32 [R,L,4] (or [R,4,L]); MASK rows are zero."""
+    tok = _need(tok, torch.uint8, "tok").contiguous()
+    R, L = tok.shape
+    out = torch.empty((R, 4, L) if transposed else (R, L, 4), dtype=torch.float32, device=tok.device)
+    rc = _lib.lib().svdd_transform_samples(tok.data_ptr(), R, L, int(bool(transposed)), out.data_ptr(), _stream())
+    _lib.check(rc, "svdd_transform_samples")
+    return out
+
+
+def subs_logp(logits, x):
+    """Diffusion.forward()'s SUBS re-parameterisation -> log p(x0|xt), same strides as logits."""
+    logits = _need(logits, torch.float32, "logits")
+    x = _need(x, torch.uint8, "x").contiguous()
+    B, L = x.shape
+    logits, layout = layout_of(logits)
+    out = _empty_like_layout(logits, layout)
+    rc = _lib.lib().svdd_subs_logp(logits.data_ptr(), x.data_ptr(), B, L, layout, out.data_ptr(), _stream())
+    _lib.check(rc, "svdd_subs_logp")
+    return out
+
+
+def tds_resample(reward_num, reward_den, alpha, sample, u):
+    """-> (x_next u8 [B,L], idx i32 [B]); u = the B float64 uniforms np.random.choice consumes."""
+    num = _need(reward_num, torch.float32, "reward_num").contiguous()
+    den = _need(reward_den, torch.float32, "reward_den").contiguous()
+    sample = _need(sample, torch.uint8, "sample").contiguous()
+    u = _need(u, torch.float64, "u").contiguous()
+    B, L = sample.shape
+    assert num.numel() == B and den.numel() == B and u.numel() == B
+    x_next = torch.empty_like(sample)
+    idx = torch.empty((B,), dtype=torch.int32, device=sample.device)
+    work = torch.empty((2 * B,), dtype=torch.float64, device=sample.device)
+    rc = _lib.lib().svdd_tds_resample(num.data_ptr(), den.data_ptr(), float(alpha), sample.data_ptr(), u.data_ptr(),
+                                      B, L, x_next.data_ptr(), idx.data_ptr(), work.data_ptr(), _stream())
+    _lib.check(rc, "svdd_tds_resample")
+    return x_next, idx

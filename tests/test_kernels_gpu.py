@@ -1,0 +1,272 @@
+"""-m gpu parity tests: the HIP kernels, called through the C ABI, against the CPU oracle on the
+same seeded inputs, against the golden fixtures captured from the reference, and — at
+BASELINE.json's full sizes — through size-independent properties.
+
+Bar: bit-exact for tokens / indices / one-hots; floats (q_xs, log-probs, soft values) equal to the
+oracle up to 1 ulp (both sides evaluate exp/log correctly rounded; spec tolerance is 1e-4)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import svdd_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU")
+    from svdd_amd import ops as _ops
+    from svdd_amd import _lib
+    arch, ncu = _lib.device_info()
+    assert arch.startswith("gfx950"), arch
+    return _ops
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(DEV)
+
+
+def bvl_view(logits_np):
+    """numpy logical [R,L,5] -> GPU tensor with logical shape [R,L,5] and [R,5,L] memory."""
+    return dev(np.ascontiguousarray(np.swapaxes(logits_np, 1, 2))).transpose(1, 2)
+
+
+def ulp_diff(a, b):
+    a = np.ascontiguousarray(a, dtype=np.float32).view(np.int32).astype(np.int64)
+    b = np.ascontiguousarray(b, dtype=np.float32).view(np.int32).astype(np.int64)
+    return np.abs(a - b)
+
+
+def rand_case(rng, B, L, frac_unmasked=0.5, scale=2.0):
+    logits = (rng.standard_normal((B, L, 5)) * scale).astype(np.float32)
+    x = np.where(rng.random((B, L)) < frac_unmasked, rng.integers(0, 4, (B, L)), 4).astype(np.uint8)
+    return logits, x
+
+
+@pytest.mark.parametrize("B,L,M", [(8, 200, 6), (3, 50, 5), (1, 7, 1), (5, 64, 4), (2, 129, 13)])
+@pytest.mark.parametrize("layout", [orc.BLV, orc.BVL])
+def test_propose_replay_vs_oracle(ops, B, L, M, layout):
+    rng = np.random.default_rng(100 + B * L + M)
+    logits, x = rand_case(rng, B, L)
+    logits[0, : min(L, 4)] = 0.0                       # exact ties between categories
+    dm, mcs = np.float32(0.0078), np.float32(0.61)
+    shape = (M, B, L, 5) if layout == orc.BLV else (M, B, 5, L)
+    uni = rng.random(shape, dtype=np.float32)
+    uni.flat[:3] = [0.0, (2 ** 24 - 1) / 2 ** 24, 2.0 ** -24]    # extremes of the 24-bit grid
+    lg_np = logits if layout == orc.BLV else np.ascontiguousarray(np.swapaxes(logits, 1, 2))
+    c_ref, oh_ref, q_ref = orc.propose(lg_np, x, dm, mcs, M, uniforms=uni, layout=layout)
+    lg = dev(logits) if layout == orc.BLV else bvl_view(logits)
+    cand, onehot, q = ops.propose(lg, dev(x), dm, mcs, M, ops.Rng(uniforms=dev(uni)), want_q=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(cand.cpu().numpy(), c_ref)
+    assert np.array_equal(onehot.cpu().numpy(), oh_ref)
+    q_log = q.cpu().numpy()                            # logical [B,L,5]
+    q_ref_log = q_ref if layout == orc.BLV else np.swapaxes(q_ref, 1, 2)
+    assert ulp_diff(q_log, q_ref_log).max() <= 1
+    # and without q_xs (the fast path that skips unmasked positions)
+    cand2, onehot2, _ = ops.propose(lg, dev(x), dm, mcs, M, ops.Rng(uniforms=dev(uni)))
+    assert torch.equal(cand2, cand) and torch.equal(onehot2, onehot)
+
+
+@pytest.mark.parametrize("B,L,M", [(8, 200, 10), (3, 50, 3)])
+def test_propose_philox_vs_oracle(ops, B, L, M):
+    rng = np.random.default_rng(7)
+    logits, x = rand_case(rng, B, L, frac_unmasked=0.3)
+    dm, mcs = np.float32(0.0078), np.float32(0.2)
+    for step, seed, off in [(0, 1234, 0), (77, 2 ** 63 + 5, 1000)]:
+        c_ref, oh_ref, _ = orc.propose(logits, x, dm, mcs, M, seed=seed, row_offset=off, step=step, want_q=False)
+        cand, onehot, _ = ops.propose(dev(logits), dev(x), dm, mcs, M, ops.Rng(seed=seed, row_offset=off, step=step))
+        assert np.array_equal(cand.cpu().numpy(), c_ref)
+        assert np.array_equal(onehot.cpu().numpy(), oh_ref)
+
+
+def test_propose_philox_shard_invariance(ops):
+    """Rows keyed by global index: decoding a shard with row_offset equals slicing the full batch."""
+    rng = np.random.default_rng(8)
+    B, L, M = 16, 200, 10
+    logits, x = rand_case(rng, B, L, frac_unmasked=0.2)
+    full, _, _ = ops.propose(dev(logits), dev(x), 0.0078, 0.5, M, ops.Rng(seed=9, step=3))
+    for lo, hi in [(0, 8), (8, 16), (4, 5)]:
+        part, _, _ = ops.propose(dev(logits[lo:hi]), dev(x[lo:hi]), 0.0078, 0.5, M, ops.Rng(seed=9, step=3, row_offset=lo))
+        assert torch.equal(part, full[lo:hi])
+
+
+@pytest.mark.parametrize("name,layout", [("g5_step_mc.npz", orc.BLV), ("g5_step_mc_bvl.npz", orc.BVL)])
+def test_golden_g5_step(ops, golden, name, layout):
+    g = golden(name)
+    x = g["x"].astype(np.uint8)
+    M = g["scores"].shape[1]
+    lg = dev(g["logits"]) if layout == orc.BLV else bvl_view(g["logits"])
+    cand, onehot, q = ops.propose(lg, dev(x), float(g["dm"]), float(g["mcs"]), M, ops.Rng(uniforms=dev(g["uniforms"])), want_q=True)
+    assert np.array_equal(cand.cpu().numpy(), g["cand"])
+    B, L = x.shape
+    assert np.array_equal(onehot.cpu().numpy().reshape(B, M, L, 4), g["onehot"])
+    assert np.allclose(q.cpu().numpy(), g["q_xs"], rtol=2e-6, atol=0)
+    x_next, soft, idx = ops.select(dev(g["scores"]), cand)
+    assert np.array_equal(idx.cpu().numpy(), g["idx"])
+    assert np.array_equal(x_next.cpu().numpy(), g["x_next"])
+    assert np.abs(soft.cpu().numpy() - g["soft"]).max() <= 1e-6        # spec: 1e-4
+
+
+@pytest.mark.parametrize("M", [1, 2, 10, 20, 63, 64, 65, 200, 1024])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_select_vs_oracle(ops, M, mode):
+    rng = np.random.default_rng(M)
+    B, L = 37, 50 if M > 100 else 200
+    scores = (rng.standard_normal((B, M)) * 0.3).astype(np.float32)
+    scores[1] = 0.25                                   # all tied -> first index
+    if M > 2:
+        scores[2, M - 1] = scores[2, 1] = scores[2].max() + 1.0   # exact tie -> lower index
+        scores[3] = np.float32(0.1) + (rng.integers(0, 3, M) * 2.0 ** -27).astype(np.float32)  # ulp near-ties
+    scores[4] *= 100.0
+    cand = rng.integers(0, 5, (B, M, L)).astype(np.uint8)
+    x_ref, soft_ref, idx_ref = orc.select(scores, cand, mode=mode, seed=11, row_offset=5, step=9)
+    x_next, soft, idx = ops.select(dev(scores), dev(cand), mode=mode, rng=ops.Rng(seed=11, row_offset=5, step=9))
+    assert np.array_equal(idx.cpu().numpy(), idx_ref)
+    assert np.array_equal(x_next.cpu().numpy(), x_ref)
+    assert ulp_diff(soft.cpu().numpy(), soft_ref).max() <= 1
+
+
+@pytest.mark.parametrize("layout", [orc.BLV, orc.BVL])
+def test_pointwise_kernels_vs_oracle(ops, layout):
+    rng = np.random.default_rng(21)
+    R, L = 9, 200
+    logits, x = rand_case(rng, R, L)
+    logits[0, :8, :4] = 1.5                            # ties among the 4 real tokens
+    lg_np = logits if layout == orc.BLV else np.ascontiguousarray(np.swapaxes(logits, 1, 2))
+    lg = dev(logits) if layout == orc.BLV else bvl_view(logits)
+    oh_ref, xh_ref = orc.x0hat(lg_np, x, layout=layout)
+    oh, xh = ops.x0hat(lg, dev(x), want_tokens=True)
+    assert np.array_equal(oh.cpu().numpy(), oh_ref) and np.array_equal(xh.cpu().numpy(), xh_ref)
+    assert np.array_equal(ops.finalize(lg, dev(x)).cpu().numpy(), orc.finalize(lg_np, x, layout=layout))
+    lp = ops.subs_logp(lg, dev(x)).cpu().numpy()
+    lp_ref = orc.subs_logp(lg_np, x, layout=layout)
+    lp_ref = lp_ref if layout == orc.BLV else np.swapaxes(lp_ref, 1, 2)
+    assert ulp_diff(lp, lp_ref).max() <= 1
+    for tr in (False, True):
+        assert np.array_equal(ops.transform_samples(dev(x), transposed=tr).cpu().numpy(), orc.transform_samples(x, transposed=tr))
+
+
+def _sched(golden, S):
+    return golden("g3_schedule.npz")[f"S{S}"]
+
+
+@pytest.mark.parametrize("name", ["g6_traj_mc_c1.npz", "g6_traj_mc_s16.npz"])
+def test_golden_g6_trajectory(ops, golden, name):
+    """The reference's own controlled_sample run (recorded logits + scores per step) replayed
+    through the HIP kernels: every x_t and the final x_0 bit-exact."""
+    g = golden(name)
+    S, B, L, M = int(g["S"]), int(g["B"]), int(g["L"]), int(g["M"])
+    sched = _sched(golden, S)
+    torch.manual_seed(int(g["seed"]))
+    x = torch.full((B, L), 4, dtype=torch.uint8, device=DEV)
+    for i in range(S):
+        assert np.array_equal(x.cpu().numpy(), g["xs"][i]), f"x_t step {i}"
+        uni = torch.rand(M, B, 5, L)                   # torch CPU generator == the reference's stream
+        cand, _, _ = ops.propose(bvl_view(g["logits"][i]), x, sched[i, 5], sched[i, 4], M, ops.Rng(uniforms=uni.to(DEV)))
+        assert np.array_equal(cand.cpu().numpy(), g["cand"][i]), f"cand step {i}"
+        x, _, _ = ops.select(dev(g["scores"][i]), cand)
+    assert np.array_equal(ops.finalize(bvl_view(g["logits"][S]), x).cpu().numpy(), g["x0"])
+
+
+def test_golden_g7_tweedie_trajectory(ops, golden):
+    g = golden("g7_traj_pm.npz")
+    S, B, L, M = int(g["S"]), int(g["B"]), int(g["L"]), int(g["M"])
+    sched = _sched(golden, S)
+    torch.manual_seed(int(g["seed"]))
+    x = torch.full((B, L), 4, dtype=torch.uint8, device=DEV)
+    for i in range(S):
+        uni = torch.rand(M, B, 5, L)
+        cand, _, _ = ops.propose(bvl_view(g["logits"][i]), x, sched[i, 5], sched[i, 4], M, ops.Rng(uniforms=uni.to(DEV)))
+        assert np.array_equal(cand.cpu().numpy(), g["cand"][i])
+        cl = g["cand_logits"][i].reshape(B * M, L, 5)
+        oh, _ = ops.x0hat(bvl_view(cl), cand.reshape(B * M, L))
+        assert np.array_equal(oh.cpu().numpy().reshape(B, M, 4, L), g["x0hat_onehot_t"][i].astype(np.float32))
+        x, _, _ = ops.select(dev(g["scores"][i]), cand)
+        assert np.array_equal(x.cpu().numpy(), g["xs"][i + 1])
+    assert np.array_equal(ops.finalize(bvl_view(g["logits"][S]), x).cpu().numpy(), g["x0"])
+
+
+def test_golden_g8_tds_trajectory(ops, golden):
+    g = golden("g8_traj_tds.npz")
+    S, B, L = int(g["S"]), int(g["B"]), int(g["L"])
+    sched = _sched(golden, S)
+    torch.manual_seed(int(g["seed"]))
+    np.random.seed(int(g["np_seed"]))
+    x = torch.full((B, L), 4, dtype=torch.uint8, device=DEV)
+    for i in range(S):
+        uni = torch.rand(1, B, 5, L)
+        cand, _, _ = ops.propose(bvl_view(g["logits"][i]), x, sched[i, 5], sched[i, 4], 1, ops.Rng(uniforms=uni.to(DEV)))
+        sample = cand[:, 0].contiguous()
+        assert np.array_equal(sample.cpu().numpy(), g["samples"][i])
+        u = np.random.random_sample(B)
+        x, idx = ops.tds_resample(dev(g["num"][i]), dev(g["den"][i]), float(g["alpha"]), sample, dev(u))
+        assert np.array_equal(x.cpu().numpy(), g["xs"][i + 1])
+    assert np.array_equal(ops.finalize(bvl_view(g["logits"][S]), x).cpu().numpy(), g["x0"])
+
+
+def test_golden_g10_decode_sample(ops, golden):
+    g = golden("g10_decode_sample.npz")
+    S, B, L = int(g["S"]), int(g["B"]), int(g["L"])
+    sched = _sched(golden, S)
+    torch.manual_seed(int(g["seed"]))
+    x = torch.full((B, L), 4, dtype=torch.uint8, device=DEV)
+    for i in range(S):
+        assert np.array_equal(x.cpu().numpy(), g["xs"][i])
+        cand, _, _ = ops.propose(bvl_view(g["logits"][i]), x, sched[i, 5], sched[i, 4], 1, ops.Rng(uniforms=torch.rand(1, B, 5, L).to(DEV)))
+        x = cand[:, 0].contiguous()
+    assert np.array_equal(ops.finalize(bvl_view(g["logits"][S]), x).cpu().numpy(), g["x0"])
+
+
+@pytest.mark.parametrize("B", [1, 6, 130, 2048])
+def test_tds_resample_vs_oracle(ops, B):
+    rng = np.random.default_rng(B)
+    L = 200
+    num = rng.standard_normal(B).astype(np.float32)
+    den = rng.standard_normal(B).astype(np.float32)
+    sample = rng.integers(0, 5, (B, L)).astype(np.uint8)
+    u = rng.random(B)
+    u[0] = 0.0
+    x_ref, idx_ref, _, _ = orc.tds_resample(num, den, 0.5, sample, u)
+    x, idx = ops.tds_resample(dev(num), dev(den), 0.5, dev(sample), dev(u))
+    assert np.array_equal(idx.cpu().numpy(), idx_ref)
+    assert np.array_equal(x.cpu().numpy(), x_ref)
+
+
+def test_full_size_properties_c2(ops):
+    """BASELINE config 2 sizes (B=256, L=200, M=10): size-independent invariants + a sampled
+    oracle comparison on a row subset (Philox makes rows independent of the batch they sit in)."""
+    rng = np.random.default_rng(2)
+    B, L, M = 256, 200, 10
+    logits, x = rand_case(rng, B, L, frac_unmasked=0.5)
+    lg, xd = bvl_view(logits), dev(x)
+    cand, onehot, _ = ops.propose(lg, xd, 0.0078, 0.5, M, ops.Rng(seed=3, step=64))
+    c = cand.cpu().numpy()
+    assert c.max() <= 4
+    un = x != 4
+    assert np.array_equal(c[un[:, None, :].repeat(M, 1)], x[:, None, :].repeat(M, 1)[un[:, None, :].repeat(M, 1)])  # copy_flag
+    oh = onehot.cpu().numpy().reshape(B, M, L, 4)
+    assert np.array_equal(oh.sum(-1), (c != 4).astype(np.float32))           # MASK rows are zero rows
+    assert np.array_equal(oh.argmax(-1)[c != 4], c[c != 4])
+    rows = [0, 17, 255]
+    for r in rows:
+        lg_r = np.ascontiguousarray(np.swapaxes(logits[r:r + 1], 1, 2))
+        c_ref, _, _ = orc.propose(lg_r, x[r:r + 1], np.float32(0.0078), np.float32(0.5), M, seed=3, row_offset=r, step=64, want_q=False, layout=orc.BVL)
+        assert np.array_equal(c[r:r + 1], c_ref)
+    scores = rng.standard_normal((B, M)).astype(np.float32)
+    x_next, soft, idx = ops.select(dev(scores), cand)
+    i = idx.cpu().numpy()
+    assert np.array_equal(i, scores.argmax(1))                               # no ties in this draw
+    assert np.array_equal(x_next.cpu().numpy(), c[np.arange(B), i])
+    assert np.allclose(soft.cpu().numpy().sum(1), 1.0, atol=1e-6)
+    # idempotence: proposing from a fully unmasked state changes nothing
+    xf = dev(rng.integers(0, 4, (B, L)).astype(np.uint8))
+    cand2, _, _ = ops.propose(lg, xf, 0.0078, 0.5, M, ops.Rng(seed=3, step=65))
+    assert torch.equal(cand2, xf[:, None, :].expand(B, M, L))
