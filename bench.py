@@ -1,0 +1,161 @@
+"""bench.py — decoded sequences/sec of the SVDD-MC hot path on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One bench "step" = one full `Diffusion.controlled_sample` decode of one batch (config 2 of
+BASELINE.json: DNA enhancer SVDD-MC, batch=256 per GPU, L=200, M=10, 128 diffusion steps,
+random-init dilated-CNN backbone + ConvGRU value net, synthetic all-MASK prior), from the prior to
+the final x_0 including the noise-removal forward and, for N>1, the one all-gather of the decoded
+tokens. Inputs are generated on the device (nothing crosses PCIe in the timed region).
+Weak scaling: every rank decodes its own 256 rows (global rows rank*256 .. rank*256+255).
+
+Prints ONE JSON line (rank 0). Extra objects:
+  roofline      the dominant hand-written kernel, K1 propose: algorithmic bytes per launch
+                B*L*(21 + 17*M) / its mean launch duration measured with HIP events on the
+                launch stream inside the timed region, against the 8 TB/s HBM peak.
+  cpu_baseline  the CPU oracle port of the same workload, timed on this box's host cores on a bounded
+                sample (a few diffusion steps at full batch), extrapolated to a whole decode.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec
+FP32_PEAK_TFLOPS = 157.3
+
+
+def cpu_baseline(B, L, M, S, sample_steps, seed=44):
+    """Oracle (CPU port of the reference path: M value-net calls of batch B per step, like
+    diffusion_gosai.py:1207-1209) on `sample_steps` diffusion steps of the same workload."""
+    from oracle import svdd_oracle as orc
+    from svdd_amd import synthetic
+    model, emb, head, _ = synthetic.build("dna" if L == 200 else "rna", "cpu", seed=seed)
+    sched = model._schedule(S, 1e-5)[0]
+    bb = lambda x: model.backbone(x, torch.zeros(x.shape[0]))                               # noqa: E731
+    val = lambda oh: head(emb(oh)).reshape(-1)                                              # noqa: E731
+    picks = np.linspace(0, S - 1, sample_steps).astype(int)
+    x = np.full((B, L), orc.MASK, np.uint8)
+    rng = np.random.default_rng(0)
+    t_steps = []
+    for i in picks:
+        # a state with the masked fraction step i would see (move chance ~ t_i)
+        frac = 1.0 - i / S
+        x = np.where(rng.random((B, L)) < frac, orc.MASK, rng.integers(0, 4, (B, L))).astype(np.uint8)
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            logits = bb(torch.from_numpy(x.astype(np.int64))).contiguous().numpy()
+        cand, onehot, _ = orc.propose(logits, x, sched[i, 2], sched[i, 1], M, seed=1, step=int(i), want_q=False)
+        oh = onehot.reshape(B, M, L, 4)
+        with torch.no_grad():
+            sc = np.stack([val(torch.from_numpy(np.ascontiguousarray(oh[:, m]))).numpy() for m in range(M)], 1)
+        orc.select(sc, cand)
+        t_steps.append(time.perf_counter() - t0)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        logits = bb(torch.from_numpy(x.astype(np.int64))).contiguous().numpy()
+    orc.finalize(logits, x)
+    t_final = time.perf_counter() - t0
+    per_decode = float(np.mean(t_steps)) * S + t_final
+    return {
+        "value": round(B / per_decode, 4), "unit": "sequences/s", "cores": torch.get_num_threads(),
+        "kind": "port",
+        "sample": f"{sample_steps} of {S} diffusion steps at full batch (B={B}, L={L}, M={M}) + the noise-removal "
+                  f"forward, extrapolated to one decode; {sum(t_steps) + t_final:.1f} s of CPU work",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=256, help="rows per GPU")
+    ap.add_argument("--length", type=int, default=200)
+    ap.add_argument("--sample-M", type=int, default=10)
+    ap.add_argument("--diffusion-steps", type=int, default=128)
+    ap.add_argument("--cpu-steps", type=int, default=4, help="diffusion steps timed for cpu_baseline (0 = skip)")
+    ap.add_argument("--rng", default="philox", choices=["philox", "replay"])
+    args = ap.parse_args()
+
+    from svdd_amd import distributed, ops, synthetic
+    from svdd_amd.backbone import CNNModel
+    from svdd_amd.value_nets import ConvGRUTrunk
+    import torch.distributed as dist
+
+    rank, world, local = distributed.init_from_env()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    torch.cuda.set_device(local)
+    dev = f"cuda:{local}"
+    B, L, M, S = args.batch, args.length, args.sample_M, args.diffusion_steps
+
+    model, emb, head, _ = synthetic.build("dna" if L == 200 else "rna", dev)
+    model.rng_mode, model.philox_seed, model.row_offset = args.rng, 0, rank * B
+
+    def one_decode():
+        x0 = model.controlled_sample(emb, head, num_steps=S, eval_sp_size=B, sample_M=M)
+        return distributed.gather_tokens(x0, B * world)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_decode()
+    fence()
+    ops.PROPOSE_EVENTS = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = one_decode()
+    fence()
+    elapsed = time.perf_counter() - t0
+    events, ops.PROPOSE_EVENTS = ops.PROPOSE_EVENTS, None
+    assert out.shape == (B * world, L) and int(out.max()) <= 3
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    if rank == 0:
+        k1_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
+        k1_bytes = B * L * (21 + 17 * M)
+        achieved = k1_bytes / (k1_ms * 1e-3) / 1e9
+        seqs = B * world * args.steps
+        flops_seq = (CNNModel.flops_per_position() * L * (S + 1) + ConvGRUTrunk.flops_per_position() * L * S * M)
+        line = {
+            "metric": "decoded sequences/sec (whole node), L=200 M=10 128-step SVDD-MC",
+            "value": round(seqs / elapsed, 3), "unit": "sequences/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic (random-init nets, all-MASK prior)",
+            "config": {"workload": f"DNA enhancer SVDD-MC, batch={B}/GPU, L={L}, M={M}, {S} steps "
+                                   f"(BASELINE.json configs[1]); dilated-CNN backbone 3.3M params + ConvGRU value net",
+                       "global_batch": B * world, "rng": args.rng, "sharding": f"rows x{world}, 1 all-gather"},
+            "roofline": {"bound": "hbm", "kernel": "propose_kernel (K1)", "achieved": round(achieved, 2),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                         "traffic": None, "bytes_per_launch": k1_bytes, "avg_launch_us": round(k1_ms * 1e3, 3),
+                         "launches": len(events)},
+            "e2e_fp32_frac": round(flops_seq * seqs / elapsed / 1e12 / (FP32_PEAK_TFLOPS * world), 5),
+        }
+        if args.cpu_steps > 0 and world == 1:
+            line["cpu_baseline"] = cpu_baseline(B, L, M, S, args.cpu_steps)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

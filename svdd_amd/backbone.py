@@ -1,0 +1,116 @@
+"""Masked-diffusion backbone: the dilated 1-D CNN that is live in the reference
+(`models/dnaconv.py:135-210`, `backbone: cnn`), as a PyTorch-ROCm module.
+
+Same computation and the same parameter names/creation order as the reference's `CNNModel`, so
+reference checkpoints (`state_dict`) load unchanged and a given `torch.manual_seed` yields the
+same random-init network. Differences, all value-preserving:
+  * tokens may be uint8 or int64; the `F.one_hot(seq, 5)` front end (:177) is an index into an
+    identity table;
+  * with `time_conditioning=False` the sampler zeroes sigma (`diffusion_gosai.py:334-335`), so
+    the time embedding and the 20 per-layer time biases are constants: they are computed once per
+    distinct `t` vector and cached;
+  * the output is returned exactly like the reference's: `feat.permute(0, 2, 1)`, a [B,L,5] view
+    of a [B,5,L] buffer (:201,210) — the HIP propose kernel reads that image in place.
+"""
+import copy
+import math
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+
+class GaussianFourierProjection(nn.Module):
+    """Random Fourier features of the time step (reference models/dnaconv.py:8-21)."""
+
+    def __init__(self, embed_dim, scale=30.0):
+        super().__init__()
+        self.W = nn.Parameter(torch.randn(embed_dim // 2) * scale, requires_grad=False)
+
+    def forward(self, t):
+        proj = t[:, None] * self.W[None, :] * 2 * math.pi
+        return torch.cat([torch.sin(proj), torch.cos(proj)], dim=-1)
+
+
+class Dense(nn.Module):
+    """Linear layer kept under `.dense` for checkpoint-name compatibility (dnaconv.py:24-34)."""
+
+    def __init__(self, input_dim, output_dim):
+        super().__init__()
+        self.dense = nn.Linear(input_dim, output_dim)
+
+    def forward(self, x):
+        return self.dense(x)
+
+
+DILATIONS = (1, 1, 4, 16, 64)   # dnaconv.py:151-155; each repeated num_cnn_stacks times (:156)
+
+
+class CNNModel(nn.Module):
+    def __init__(self, args, alphabet_size=5, num_cls=3):
+        super().__init__()
+        if args.clean_data or args.cls_free_guidance:
+            raise NotImplementedError("clean_data / cls_free_guidance are off in every reference config "
+                                      "(configs_gosai/model/dnaconv.yaml:14-15)")
+        H = args.hidden_dim
+        self.alphabet_size = alphabet_size
+        self.args = args
+        self.linear = nn.Conv1d(alphabet_size, H, kernel_size=9, padding=4)
+        self.time_embedder = nn.Sequential(GaussianFourierProjection(embed_dim=H), nn.Linear(H, H))
+        self.num_layers = 5 * args.num_cnn_stacks
+        base = [nn.Conv1d(H, H, kernel_size=9, dilation=d, padding=4 * d) for d in DILATIONS]
+        # each base conv is deep-copied num_cnn_stacks times, consecutively (dnaconv.py:156)
+        self.convs = nn.ModuleList([copy.deepcopy(c) for c in base for _ in range(args.num_cnn_stacks)])
+        self.time_layers = nn.ModuleList([Dense(H, H) for _ in range(self.num_layers)])
+        self.norms = nn.ModuleList([nn.LayerNorm(H) for _ in range(self.num_layers)])
+        self.final_conv = nn.Sequential(nn.Conv1d(H, H, kernel_size=1), nn.ReLU(),
+                                        nn.Conv1d(H, alphabet_size, kernel_size=1))
+        self.dropout = nn.Dropout(args.dropout)
+        self.register_buffer("_eye", torch.eye(alphabet_size), persistent=False)
+        self._tb_key = None
+        self._tb = None
+
+    def _time_biases(self, t):
+        """[num_layers] list of [B,H,1] biases `time_layers[i](relu(time_embedder(t)))` (:182,190)."""
+        emb = F.relu(self.time_embedder(t))
+        return [layer(emb)[:, :, None] for layer in self.time_layers]
+
+    def zero_time_biases(self, batch, device):
+        """Pre-computes (and pins in the cache) the time biases for sigma == 0, so that the hot loop
+        never re-evaluates the time embedder (and never syncs to check t)."""
+        with torch.no_grad():
+            self._tb = self._time_biases(torch.zeros(batch, device=device))
+            self._tb_key = ("zero", batch, torch.device(device))
+        return self._tb
+
+    def trunk(self, onehot_cl, time_biases):
+        """onehot_cl: [B,5,L] fp32. Returns [B,5,L] logits (channel-first)."""
+        feat = F.relu(self.linear(onehot_cl))
+        for i in range(self.num_layers):
+            h = self.dropout(feat) + time_biases[i]
+            h = self.norms[i](h.permute(0, 2, 1)).permute(0, 2, 1)
+            h = F.relu(self.convs[i](h))
+            feat = h + feat if h.shape == feat.shape else h
+        return self.final_conv(feat)
+
+    def forward(self, seq, t, zero_sigma=False):
+        """seq: tokens [B,L] (uint8/int64) ; t: [B] conditioning (all zeros from the sampler).
+        zero_sigma=True promises t == 0 and uses the pinned bias cache without touching t."""
+        onehot = self._eye[seq.long()]                     # F.one_hot(seq, 5).float()   (:177)
+        if zero_sigma and self._tb_key == ("zero", seq.shape[0], seq.device):
+            tb = self._tb
+        elif zero_sigma:
+            tb = self.zero_time_biases(seq.shape[0], seq.device)
+        else:
+            tb = self._time_biases(t)
+        return self.trunk(onehot.permute(0, 2, 1), tb).permute(0, 2, 1)
+
+    def forward2(self, seq_onehot, t):
+        """Differentiable entry on a one-hot/relaxed input [B,L,5] (reference dnaconv.py:212-247; DPS)."""
+        return self.trunk(seq_onehot.permute(0, 2, 1), self._time_biases(t)).permute(0, 2, 1)
+
+    @staticmethod
+    def flops_per_position(hidden_dim=128, num_cnn_stacks=4, alphabet=5):
+        """MACs*2 per sequence position (5,943,808 for the default config)."""
+        H, n = hidden_dim, 5 * num_cnn_stacks
+        return 2 * (alphabet * H * 9 + n * H * H * 9 + H * H + H * alphabet)

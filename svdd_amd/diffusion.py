@@ -1,0 +1,340 @@
+"""`Diffusion` — host-side mirror of the reference sampler `diffusion_gosai.Diffusion` for the
+decode hot path (reference diffusion_gosai.py:74-175, 286-377, 751-753, 820-1496).
+
+Same method names, keyword arguments, return types and error behaviour as the reference for the
+methods on the SVDD decode path, so `BaseModel`/`decode.py`-style callers work unchanged:
+
+    forward, _process_sigma, _sample_prior, _sample, decode_sample, controlled_sample,
+    controlled_sample_tweedie, controlled_sample_TDS, controlled_sample_DPS,
+    _ddpm_update_finetune[_controlled[_twedie|_TDS|_DPS]], transform_samples
+
+What differs is where the work runs: everything between "backbone logits" and "next x_t" is one
+or two launches of the hand-written HIP kernels (svdd_amd/csrc, C ABI include/svdd_hip.h) instead
+of ~16*M+20 tiny tensor ops and B host syncs per step; the nets stay PyTorch-ROCm modules.
+There is no CPU fallback: the sampler methods need a gfx950 GPU and raise otherwise.
+
+Engine knobs (attributes; defaults reproduce the reference's observable behaviour):
+  rng_mode         "replay": the categorical uniforms are drawn from torch's global CPU mt19937
+                   generator in exactly the order the reference's CPU path consumes them
+                   (M x rand_like(q_xs), in q_xs' memory order) and uploaded — token-exact parity.
+                   "philox": generated in-kernel from (seed, step, global row, m, l) — no host
+                   traffic, identical results for any sharding of the batch over GPUs.
+  value_batching   "batched": one value-net forward over all B*M candidates (default);
+                   "reference": M forwards of batch B like diffusion_gosai.py:1207-1209.
+  select_mode      "argmax" (reference, :1225) or "multinomial" (the commented-out :1223; philox only).
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import noise_schedule, ops
+from .backbone import CNNModel
+
+
+class Diffusion(nn.Module):
+    def __init__(self, config, backbone=None):
+        super().__init__()
+        self.config = config
+        self.vocab_size = 4                                   # diffusion_gosai.py:85
+        self.sampler = config.sampling.predictor
+        self.mask_index = self.vocab_size                     # :94
+        self.vocab_size += 1                                  # :95
+        self.parameterization = config.parameterization
+        if backbone is not None:
+            self.backbone = backbone
+        elif config.backbone == "cnn":
+            self.backbone = CNNModel(config.model, alphabet_size=self.vocab_size, num_cls=3)   # :100-101
+        else:
+            # `dit` is dead in the reference snapshot (models/__init__.py:1); pass a module via backbone=
+            raise ValueError(f"Unknown backbone: {config.backbone}")
+        if self.parameterization != "subs":
+            raise ValueError("only the `subs` parameterization is on the reference's decode path "
+                             "(configs_gosai/config_gosai.yaml:13)")
+        self.T = config.T
+        self.subs_masking = config.subs_masking
+        self.noise = noise_schedule.get_noise(config)
+        self.time_conditioning = config.time_conditioning
+        self.neg_infinity = -1000000.0
+        self.sampling_eps = config.training.sampling_eps
+        # engine knobs
+        self.rng_mode = "replay"
+        self.value_batching = "batched"
+        self.select_mode = "argmax"
+        self.philox_seed = 0
+        self.row_offset = 0
+        self._sched_cache = {}
+
+    # ------------------------------------------------------------------ plumbing ----
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    def _require_gpu(self):
+        if self.device.type != "cuda":
+            raise ops.SvddError("the SVDD sampler runs on the GPU only (move the model with .cuda()); "
+                                "there is no CPU fallback for the hot path")
+
+    def _schedule(self, num_steps, eps):
+        key = (num_steps, eps)
+        if key not in self._sched_cache:
+            tab, timesteps, dt = noise_schedule.move_chance_table(self.noise, num_steps, eps)
+            self._sched_cache[key] = (tab.numpy().copy(), timesteps, dt)
+        return self._sched_cache[key]
+
+    def _tokens_u8(self, x):
+        return x if x.dtype == torch.uint8 else x.to(torch.uint8)
+
+    def _backbone_logits(self, x_u8):
+        """Raw backbone output for tokens x (sigma is zeroed when time_conditioning is False, :334-335)."""
+        if isinstance(self.backbone, CNNModel) and not self.time_conditioning:
+            return self.backbone(x_u8, None, zero_sigma=True)
+        sigma = torch.zeros(x_u8.shape[0], device=x_u8.device)
+        return self.backbone(x_u8.long(), sigma).float()
+
+    def _step_scalars(self, t, dt):
+        """(mct, mcs, mct - mcs) for an explicit (t, dt) as the per-step API receives them
+        (:1176-1187), evaluated on the host with the reference's fp32 ops."""
+        t0 = t.reshape(-1)[:1].detach().float().cpu().view(1, 1)
+        sigma_t, _ = self.noise(t0)
+        sigma_s, _ = self.noise(t0 - dt)
+        mct = 1 - torch.exp(-sigma_t.squeeze(-1))
+        mcs = 1 - torch.exp(-sigma_s.squeeze(-1))
+        return float(mct), float(mcs), float(mct - mcs)
+
+    def _uniforms(self, M, B, L, logits):
+        """Replay mode: the next M*B*L*5 draws of torch's CPU generator, laid out like `logits`."""
+        _, layout = ops.layout_of(logits)
+        shape = (M, B, L, 5) if layout == ops.LAYOUT_BLV else (M, B, 5, L)
+        return torch.rand(shape).to(logits.device, non_blocking=True)
+
+    def _rng(self, step, M, B, L, logits):
+        if self.rng_mode == "replay":
+            return ops.Rng(uniforms=self._uniforms(M, B, L, logits))
+        if self.rng_mode == "philox":
+            return ops.Rng(seed=self.philox_seed, row_offset=self.row_offset, step=step)
+        raise ValueError(f"rng_mode {self.rng_mode!r}")
+
+    def _select(self, scores, cand, step):
+        mode = {"argmax": ops.SELECT_ARGMAX, "multinomial": ops.SELECT_MULTINOMIAL}[self.select_mode]
+        rng = None
+        if mode == ops.SELECT_MULTINOMIAL:
+            if self.rng_mode != "philox":
+                raise ValueError("select_mode='multinomial' needs rng_mode='philox'")
+            rng = ops.Rng(seed=self.philox_seed, row_offset=self.row_offset, step=step)
+        x_next, _, _ = ops.select(scores, cand, mode=mode, rng=rng, want_soft=False)
+        return x_next
+
+    def _value_scores(self, embedding, head, onehot, B, M):
+        """scores[b, m] = head(embedding(onehot of candidate m of sample b)) (:1207-1209,1219)."""
+        if self.value_batching == "batched":
+            return head(embedding(onehot)).reshape(B, M).float()
+        oh = onehot.view(B, M, onehot.shape[1], 4)
+        return torch.stack([head(embedding(oh[:, m].contiguous())).reshape(B) for m in range(M)], dim=1).float()
+
+    def _batch_size(self, eval_sp_size):
+        return self.config.loader.eval_batch_size if eval_sp_size is None else eval_sp_size
+
+    def _num_steps(self, num_steps):
+        return self.config.sampling.steps if num_steps is None else num_steps
+
+    def _noise_removal(self, x_u8):
+        """:1049-1060 — x = forward(x, sigma(t_last))[:, :, :-1].argmax(-1) ; returns int64."""
+        if self.config.sampling.noise_removal:
+            if self.sampler == "analytic":
+                raise NotImplementedError("analytic sampler is not on the reference's decode path")
+            return ops.finalize(self._backbone_logits(x_u8), x_u8)
+        return x_u8.long()
+
+    # ---------------------------------------------------------- reference API: basics ----
+    def _process_sigma(self, sigma):
+        if sigma.ndim > 1:
+            sigma = sigma.squeeze(-1)
+        if not self.time_conditioning:
+            sigma = torch.zeros_like(sigma)
+        assert sigma.ndim == 1, sigma.shape
+        return sigma
+
+    def forward(self, x, sigma):
+        """Returns log score: backbone logits under the SUBS parameterization (:339-357)."""
+        self._require_gpu()
+        sigma = self._process_sigma(sigma)
+        x_u8 = self._tokens_u8(x)
+        if isinstance(self.backbone, CNNModel) and not self.time_conditioning:
+            logits = self.backbone(x_u8, None, zero_sigma=True)
+        else:
+            logits = self.backbone(x if x.dtype == torch.int64 else x.long(), sigma).float()
+        return ops.subs_logp(logits, x_u8)
+
+    def forward2(self, x_onehot, x, sigma):
+        """Differentiable log score on a one-hot input (:359-377), used by the DPS baseline. Autograd
+        must see every op, so the SUBS step is expressed in torch here."""
+        sigma = self._process_sigma(sigma)
+        logits = self.backbone.forward2(x_onehot, sigma)
+        neg = torch.zeros(self.vocab_size, device=logits.device)
+        neg[self.mask_index] = self.neg_infinity
+        logits = logits + neg
+        logits = logits - torch.logsumexp(logits, dim=-1, keepdim=True)
+        unmasked = (x != self.mask_index)
+        fixed = torch.full_like(logits, self.neg_infinity).scatter(-1, x.clamp(max=self.vocab_size - 1)[..., None], 0.0)
+        return torch.where(unmasked[..., None], fixed, logits)
+
+    def _sample_prior(self, *batch_dims):
+        return self.mask_index * torch.ones(*batch_dims, dtype=torch.int64)          # :751-753
+
+    def transform_samples(self, samples, num_classes=4):
+        """tokens -> one-hot(4), MASK rows zero; int64 like the reference's F.one_hot (:1462-1470)."""
+        if samples.is_cuda and num_classes == 4:
+            return ops.transform_samples(self._tokens_u8(samples)).long()
+        mask = samples != 4
+        return F.one_hot((samples * mask).long(), num_classes=num_classes) * mask.unsqueeze(-1)
+
+    # --------------------------------------------------------------- per-step updates ----
+    @torch.no_grad()
+    def _ddpm_update_finetune(self, x, t, dt):
+        """Un-guided ancestral step (:1147-1172) -> (x_next, x, q_xs, copy_flag)."""
+        self._require_gpu()
+        mct, mcs, dm = self._step_scalars(t, dt)
+        x_u8 = self._tokens_u8(x)
+        logits = self._backbone_logits(x_u8)
+        B, L = x_u8.shape
+        cand, _, q = ops.propose(logits, x_u8, dm, mcs, 1, self._rng(0, 1, B, L, logits), want_q=True)
+        return cand[:, 0].long(), x, q, (x != self.mask_index).to(x.dtype)
+
+    @torch.no_grad()
+    def _ddpm_update_finetune_controlled(self, x, t, dt, pre_scorer_embedding, pre_scorer_head, repeats=10):
+        """One SVDD-MC step (:1174-1228) -> (final_samples, x, q_xs, copy_flag)."""
+        self._require_gpu()
+        mct, mcs, dm = self._step_scalars(t, dt)
+        x_u8 = self._tokens_u8(x)
+        logits = self._backbone_logits(x_u8)
+        B, L = x_u8.shape
+        cand, onehot, q = ops.propose(logits, x_u8, dm, mcs, repeats, self._rng(0, repeats, B, L, logits), want_q=True)
+        scores = self._value_scores(pre_scorer_embedding, pre_scorer_head, onehot, B, repeats)
+        x_next = self._select(scores, cand, 0)
+        return x_next.long(), x, q, (x != self.mask_index).to(x.dtype)
+
+    @torch.no_grad()
+    def _ddpm_update_finetune_controlled_twedie(self, x, t, dt, reward_model, repeats=10, options="True", task="dna"):
+        """One SVDD-PM step (:1373-1460) -> (final_samples, x, q_xs, copy_flag)."""
+        self._require_gpu()
+        mct, mcs, dm = self._step_scalars(t, dt)
+        x_u8 = self._tokens_u8(x)
+        logits = self._backbone_logits(x_u8)
+        B, L = x_u8.shape
+        cand, _, q = ops.propose(logits, x_u8, dm, mcs, repeats, self._rng(0, repeats, B, L, logits), want_q=True)
+        scores = self._tweedie_scores(cand, reward_model, options, task)
+        x_next = self._select(scores, cand, 0)
+        return x_next.long(), x, q, (x != self.mask_index).to(x.dtype)
+
+    def _tweedie_scores(self, cand, reward_model, options, task):
+        """scores[b,m] = reward_model(x0hat(candidate))[:, 0] (:1413-1436)."""
+        if task == "rna_saluki":
+            raise NotImplementedError("rna_saluki needs a data file the reference hard-codes by absolute path "
+                                      "(diffusion_gosai.py:1478); unsupported offline")
+        B, M, L = cand.shape
+        flat = cand.reshape(B * M, L)
+        if options == "True":
+            oh, _ = ops.x0hat(self._backbone_logits(flat), flat)          # :1415-1419
+        else:
+            oh = ops.transform_samples(flat, transposed=True)             # heuristic branch :1420-1424
+        return reward_model(oh)[:, 0].reshape(B, M).float()               # :1430,1436
+
+    @torch.no_grad()
+    def _ddpm_update_finetune_controlled_TDS(self, x, t, dt, reward_model, alpha=1.0):
+        """One SMC/TDS step (:1230-1284) -> x_next. Consumes B doubles of numpy's global RandomState,
+        like the reference's np.random.choice."""
+        self._require_gpu()
+        mct, mcs, dm = self._step_scalars(t, dt)
+        x_u8 = self._tokens_u8(x)
+        return self._tds_step(x_u8, dm, mcs, reward_model, alpha, 0).long()
+
+    def _tds_step(self, x_u8, dm, mcs, reward_model, alpha, step):
+        B, L = x_u8.shape
+        logits = self._backbone_logits(x_u8)
+        cand, _, _ = ops.propose(logits, x_u8, dm, mcs, 1, self._rng(step, 1, B, L, logits))
+        sample = cand[:, 0].contiguous()
+        oh_num, _ = ops.x0hat(self._backbone_logits(sample), sample)      # :1263-1268
+        reward_num = reward_model(oh_num)[:, 0][:, 0].float()             # :1269
+        # forward(x, sigma_s) == forward(x, sigma_t): sigma is zeroed (:334-335), so `logits` is reused (:1273)
+        oh_den, _ = ops.x0hat(logits, x_u8)
+        reward_den = reward_model(oh_den)[:, 0][:, 0].float()             # :1277
+        u = torch.from_numpy(np.random.random_sample(B)).to(x_u8.device)   # what np.random.choice draws (:1282)
+        x_next, _ = ops.tds_resample(reward_num, reward_den, alpha, sample, u)
+        return x_next
+
+    # ------------------------------------------------------------------ outer loops ----
+    @torch.no_grad()
+    def decode_sample(self, num_steps=None, eps=1e-5, eval_sp_size=None, cdq=False):
+        """Un-guided decode (:888-936) -> LongTensor[B,L]."""
+        self._require_gpu()
+        B, L, S = self._batch_size(eval_sp_size), self.config.model.length, self._num_steps(num_steps)
+        sched, _, _ = self._schedule(S, eps)
+        x = torch.full((B, L), self.mask_index, dtype=torch.uint8, device=self.device)
+        for i in range(S):
+            logits = self._backbone_logits(x)
+            cand, _, _ = ops.propose(logits, x, sched[i, 2], sched[i, 1], 1, self._rng(i, 1, B, L, logits))
+            x = cand.view(B, L)
+        return self._noise_removal(x)
+
+    @torch.no_grad()
+    def _sample(self, num_steps=None, eps=1e-5, eval_sp_size=None, cdq=False):
+        """Un-guided decode that also returns the S-1 intermediate states (:820-886)."""
+        self._require_gpu()
+        if cdq:
+            raise NotImplementedError("cdq=True is a value-function *training* data path (Enformer.py:163-267)")
+        B, L, S = self._batch_size(eval_sp_size), self.config.model.length, self._num_steps(num_steps)
+        sched, _, _ = self._schedule(S, eps)
+        x = torch.full((B, L), self.mask_index, dtype=torch.uint8, device=self.device)
+        mid_x = []
+        for i in range(S):
+            logits = self._backbone_logits(x)
+            cand, _, _ = ops.propose(logits, x, sched[i, 2], sched[i, 1], 1, self._rng(i, 1, B, L, logits))
+            x = cand.view(B, L)
+            if i != S - 1:
+                mid_x.append(x.long())
+        return self._noise_removal(x), mid_x
+
+    @torch.no_grad()
+    def controlled_sample(self, pre_scorer_embedding, pre_scorer_head, num_steps=None, eps=1e-5,
+                          eval_sp_size=None, sample_M=10):
+        """SVDD-MC decode (:1021-1061): S x [backbone -> propose -> value net -> select], then noise removal."""
+        self._require_gpu()
+        B, L, S, M = self._batch_size(eval_sp_size), self.config.model.length, self._num_steps(num_steps), sample_M
+        sched, _, _ = self._schedule(S, eps)
+        x = torch.full((B, L), self.mask_index, dtype=torch.uint8, device=self.device)   # _sample_prior
+        cand = torch.empty((B, M, L), dtype=torch.uint8, device=self.device)
+        onehot = torch.empty((B * M, L, 4), dtype=torch.float32, device=self.device)
+        for i in range(S):
+            logits = self._backbone_logits(x)
+            ops.propose(logits, x, sched[i, 2], sched[i, 1], M, self._rng(i, M, B, L, logits), cand=cand, onehot=onehot)
+            scores = self._value_scores(pre_scorer_embedding, pre_scorer_head, onehot, B, M)
+            x = self._select(scores, cand, i)
+        return self._noise_removal(x)
+
+    @torch.no_grad()
+    def controlled_sample_tweedie(self, reward_model, num_steps=None, eps=1e-5, eval_sp_size=None, sample_M=10,
+                                  options=True, task="dna"):
+        """SVDD-PM decode (:1105-1145). NB the reference compares `options == "True"` (a string, :1414):
+        the default `options=True` therefore takes the heuristic branch there too."""
+        self._require_gpu()
+        B, L, S, M = self._batch_size(eval_sp_size), self.config.model.length, self._num_steps(num_steps), sample_M
+        sched, _, _ = self._schedule(S, eps)
+        x = torch.full((B, L), self.mask_index, dtype=torch.uint8, device=self.device)
+        for i in range(S):
+            logits = self._backbone_logits(x)
+            cand, _, _ = ops.propose(logits, x, sched[i, 2], sched[i, 1], M, self._rng(i, M, B, L, logits))
+            scores = self._tweedie_scores(cand, reward_model, options, task)
+            x = self._select(scores, cand, i)
+        return self._noise_removal(x)
+
+    @torch.no_grad()
+    def controlled_sample_TDS(self, reward_model, alpha, num_steps=None, eps=1e-5, eval_sp_size=None, sample_M=10):
+        """SMC/TDS baseline decode (:938-978)."""
+        self._require_gpu()
+        B, L, S = self._batch_size(eval_sp_size), self.config.model.length, self._num_steps(num_steps)
+        sched, _, _ = self._schedule(S, eps)
+        x = torch.full((B, L), self.mask_index, dtype=torch.uint8, device=self.device)
+        for i in range(S):
+            x = self._tds_step(x, sched[i, 2], sched[i, 1], reward_model, alpha, i)
+        return self._noise_removal(x)

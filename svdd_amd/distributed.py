@@ -1,0 +1,66 @@
+"""Batch-sharded decode over the GPUs of one node: one process per GPU, RCCL only for the single
+all-gather of the final decoded tokens. Rows of the batch are independent in
+SVDD-MC / SVDD-PM / un-guided decode, so nothing is exchanged per step; Philox draws are keyed by
+the GLOBAL row index, so the decoded batch is identical for any number of GPUs."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """(rank, world_size, local_rank). Initialises torch.distributed when launched by torchrun."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"      # "nccl" is RCCL on ROCm
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_rows(total_rows, rank, world):
+    """Contiguous row range [lo, hi) of `rank` (the first total_rows % world ranks get one extra row)."""
+    base, rem = divmod(total_rows, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def gather_tokens(local_tokens, total_rows=None):
+    """All-gather of the final decoded tokens [B_local, L] -> [B_total, L] on every rank.
+    Tokens travel as uint8 (B_total*L bytes: 0.4 MB at B=2048, L=200 — latency-bound over xGMI, so it is
+    issued exactly once, after the last step); ragged shards are padded to the largest."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return local_tokens
+    world = dist.get_world_size()
+    out_dtype = local_tokens.dtype
+    t = local_tokens.to(torch.uint8).contiguous()
+    if total_rows is None:
+        total_rows = t.shape[0] * world
+    sizes = [shard_rows(total_rows, r, world) for r in range(world)]
+    maxrows = max(hi - lo for lo, hi in sizes)
+    if t.shape[0] < maxrows:
+        t = torch.cat([t, t.new_zeros(maxrows - t.shape[0], t.shape[1])], dim=0)
+    out = t.new_empty((world * maxrows, t.shape[1]))
+    dist.all_gather_into_tensor(out, t)
+    parts = [out[r * maxrows: r * maxrows + (hi - lo)] for r, (lo, hi) in enumerate(sizes)]
+    return torch.cat(parts, dim=0).to(out_dtype)
+
+
+def sharded_sample(model, total_rows, sampler, rank=None, world=None):
+    """Runs `sampler(eval_sp_size=<rows of this rank>)` with the model's Philox row offset set to this
+    rank's first global row, then gathers. `sampler` is e.g.
+    `lambda **kw: model.controlled_sample(emb, head, sample_M=M, **kw)`."""
+    if rank is None:
+        rank = dist.get_rank() if dist.is_initialized() else 0
+        world = dist.get_world_size() if dist.is_initialized() else 1
+    lo, hi = shard_rows(total_rows, rank, world)
+    prev = model.row_offset
+    model.row_offset = lo
+    try:
+        local = sampler(eval_sp_size=hi - lo)
+    finally:
+        model.row_offset = prev
+    return gather_tokens(local, total_rows)
