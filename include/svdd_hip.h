@@ -152,6 +152,26 @@ int svdd_tds_resample(const float* reward_num, const float* reward_den, float al
                       const uint8_t* sample, const double* u, int B, int L,
                       uint8_t* x_next, int32_t* idx, double* work, void* stream);
 
+/* Process-wide options (host). SVDD_OPT_FORCE_EXACT != 0 makes svdd_propose evaluate every draw in the
+ * exact (fp64, correctly rounded) arithmetic instead of the filtered fast path — same results, used
+ * to A/B the filter. */
+enum { SVDD_OPT_FORCE_EXACT = 0,
+       SVDD_OPT_MSPLIT = 1 /* tuning: waves per 64-position tile in svdd_propose, 0 = auto */ };
+int svdd_set_option(int key, int value);
+
+/* Per-launch kernel timing (host). While enabled, svdd_propose (kernel 0) and svdd_select (kernel 1)
+ * are dispatched with HIP start/stop events bound to the dispatch on its launch stream
+ * (hipExtLaunchKernelGGL); svdd_profile_collect waits for the recorded launches, returns the summed
+ * hipEventElapsedTime and their count, and clears the record. Not for use during graph capture. */
+int svdd_profile_enable(int on);
+int svdd_profile_collect(int kernel, double* total_ms, int* launches);
+
+/* Self-test of the fast-math error bounds the K1 filter relies on (host; synchronous; allocates).
+ * out3[0] = max relative error of the fast Gumbel-norm g over ALL 2^24 possible uniforms,
+ * out3[1] = max relative error of the fast exp over 2^24 points of [-80,0],
+ * out3[2] = max relative error of the fast log over 2^24 points of (1,4]. */
+int svdd_selftest_fastmath(double* out3);
+
 /* Library / device probe (host). Returns SVDD_OK and fills arch (e.g. "gfx950") and CU count. */
 int svdd_device_info(char* arch, int arch_len, int* num_cu);
 

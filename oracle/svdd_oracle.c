@@ -80,8 +80,9 @@ void orc_numpy_random_sample(orc_mt_t* s, double* out, int64_t n) {
 /* ----------------------------------------------------------------- philox ---- */
 /* Philox4x32-10 (Salmon et al. 2011). Counter layout shared with the HIP kernels:
  *   ctr = { lo32(pos), hi32(pos), (step<<16)|m, stream }   key = { lo32(seed), hi32(seed) }
- *   pos = (row_offset + b) * L + l ; stream 0 -> uniforms of categories 0..3,
- *   stream 1 -> word 0 = category 4 ; stream 2 (pos = global row, m = 0) -> word 0 = select draw. */
+ *   pos = (row_offset + b) * L + l ; stream 0 -> the 5 uniforms of one draw: categories 0..3 take the
+ *   top 24 bits of words 0..3, MASK the low bytes of words 0..2 ; stream 2 (pos = global row, m = 0)
+ *   -> word 0 = select draw. */
 static void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
   for (int r = 0; r < 10; ++r) {
     uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
@@ -101,9 +102,8 @@ void orc_philox_uniform5(uint64_t seed, uint64_t pos, uint32_t step, uint32_t m,
   uint32_t c[4] = {(uint32_t)pos, (uint32_t)(pos >> 32), (step << 16) | m, 0u};
   philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
   u[0] = u24(c[0]); u[1] = u24(c[1]); u[2] = u24(c[2]); u[3] = u24(c[3]);
-  uint32_t d[4] = {(uint32_t)pos, (uint32_t)(pos >> 32), (step << 16) | m, 1u};
-  philox4x32_10(d, (uint32_t)seed, (uint32_t)(seed >> 32));
-  u[4] = u24(d[0]);
+  uint32_t low = (c[0] & 0xFFu) | ((c[1] & 0xFFu) << 8) | ((c[2] & 0xFFu) << 16);
+  u[4] = (float)low * (1.0f / 16777216.0f);
 }
 
 float orc_philox_select_uniform(uint64_t seed, uint64_t row, uint32_t step) {

@@ -22,7 +22,9 @@ MAX_M = 1024
 EXPORTS = (
     "svdd_abi_version", "svdd_device_info", "svdd_propose", "svdd_select", "svdd_x0hat",
     "svdd_finalize", "svdd_transform_samples", "svdd_subs_logp", "svdd_tds_resample",
+    "svdd_set_option", "svdd_selftest_fastmath", "svdd_profile_enable", "svdd_profile_collect",
 )
+OPT_FORCE_EXACT = 0
 
 
 class SvddRng(ctypes.Structure):
@@ -73,6 +75,10 @@ def lib():
     L.svdd_transform_samples.argtypes = [vp, i32, i32, i32, vp, vp]
     L.svdd_subs_logp.argtypes = [vp, vp, i32, i32, i32, vp, vp]
     L.svdd_tds_resample.argtypes = [vp, vp, f32, vp, vp, i32, i32, vp, vp, vp, vp]
+    L.svdd_set_option.argtypes = [i32, i32]
+    L.svdd_selftest_fastmath.argtypes = [ctypes.POINTER(ctypes.c_double)]
+    L.svdd_profile_enable.argtypes = [i32]
+    L.svdd_profile_collect.argtypes = [i32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]
     L.svdd_device_info.argtypes = [ctypes.c_char_p, i32, ctypes.POINTER(ctypes.c_int)]
     for name in EXPORTS:
         getattr(L, name).restype = ctypes.c_int
@@ -87,6 +93,29 @@ def device_info():
     if rc != OK:
         raise SvddError("no HIP device visible to libsvdd_hip.so")
     return buf.value.decode().split(":")[0], ncu.value
+
+
+def set_force_exact(on):
+    """A/B switch: K1 evaluates every draw in the exact arithmetic (same results, slower)."""
+    check(lib().svdd_set_option(OPT_FORCE_EXACT, int(bool(on))), "svdd_set_option")
+
+
+def profile_enable(on=True):
+    check(lib().svdd_profile_enable(int(bool(on))), "svdd_profile_enable")
+
+
+def profile_collect(kernel):
+    """(total_ms, launches) of kernel 0 = propose / 1 = select since profiling was enabled."""
+    tot, n = ctypes.c_double(0.0), ctypes.c_int(0)
+    check(lib().svdd_profile_collect(kernel, ctypes.byref(tot), ctypes.byref(n)), "svdd_profile_collect")
+    return tot.value, n.value
+
+
+def selftest_fastmath():
+    """(max rel err of fast g over all 2^24 uniforms, of fast exp on [-80,0], of fast log on (1,4])."""
+    out = (ctypes.c_double * 3)()
+    check(lib().svdd_selftest_fastmath(out), "svdd_selftest_fastmath")
+    return tuple(out)
 
 
 _ERR = {E_ARG: "invalid argument", E_LAUNCH: "kernel launch failed", E_NODEVICE: "no HIP device"}

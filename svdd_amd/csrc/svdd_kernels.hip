@@ -14,7 +14,9 @@
 //   K7 subs_logp_kernel  SUBS re-parameterisation alone
 //   K4 tds_resample_kernel  SMC/TDS resampling (baseline)
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "svdd_hip.h"
@@ -74,14 +76,15 @@ __device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uin
 }
 __device__ __forceinline__ float u24(uint32_t r) { return (float)(r >> 8) * (1.0f / 16777216.0f); }
 
+// One Philox block (128 bits) feeds the 5 uniforms of a draw (5 x 24 = 120 bits): categories 0..3
+// take the top 24 bits of the four words, MASK takes the low bytes of words 0..2.
 __device__ __forceinline__ void philox_uniform5(uint64_t seed, uint64_t pos, uint32_t step, uint32_t m,
                                                 float (&u)[V]) {
   uint32_t c[4] = {(uint32_t)pos, (uint32_t)(pos >> 32), (step << 16) | m, 0u};
   philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
   u[0] = u24(c[0]); u[1] = u24(c[1]); u[2] = u24(c[2]); u[3] = u24(c[3]);
-  uint32_t d[4] = {(uint32_t)pos, (uint32_t)(pos >> 32), (step << 16) | m, 1u};
-  philox4x32_10(d, (uint32_t)seed, (uint32_t)(seed >> 32));
-  u[4] = u24(d[0]);
+  const uint32_t low = (c[0] & 0xFFu) | ((c[1] & 0xFFu) << 8) | ((c[2] & 0xFFu) << 16);
+  u[4] = (float)low * (1.0f / 16777216.0f);
 }
 
 // _sample_categorical for one position (diffusion_gosai.py:30-34): exponential race, first max wins.
@@ -99,78 +102,173 @@ __device__ __forceinline__ int sample_categorical_1(const float (&q)[V], const f
 }
 
 // ------------------------------------------------------------------------- K1 propose ----
-// Block = 256 threads = 4 waves over one tile of 64 consecutive (b,l) positions; wave 0 builds
-// q_xs for the tile into LDS (once, not per candidate), then the 4 waves split the M candidates.
-// Stores: cand 1 B/lane (64 B per wave-store), one-hot float4/lane (1 KiB per wave-store).
+// The exact semantics (oracle) evaluate exp/log correctly rounded, which on the GPU means fp64
+// (ocml) — ~100 quarter-rate instructions per transcendental, 5 per draw: compute-bound far below
+// the HBM roofline. The only OUTPUT that depends on them in the hot loop is an argmax, so K1 uses an
+// exact-arithmetic *filter*: a fast fp32 path (v_exp_f32 / v_log_f32 / v_rcp_f32, a few ulps off)
+// decides every draw whose winner leads the runner-up by more than a proven error margin; the rare
+// ambiguous lane (~1e-5 of draws) re-evaluates in the exact arithmetic. Results are identical to
+// the exact path by construction (DESIGN.md "K1 filter"; bound checked exhaustively over all 2^24
+// possible uniforms by svdd_selftest_fastmath and A/B-tested against the forced-exact path).
+//
+// Block = 256 threads = 4 waves over one tile of 64 consecutive (b,l) positions; every wave rebuilds
+// the tile's (cheap, fast-path) q in registers — no LDS, no barrier — and the waves split the M
+// candidates. Stores: cand 1 B/lane (64 B per wave-store), one-hot float4/lane (1 KiB per wave-store).
 struct ProposeArgs {
   const float* logits; const uint8_t* x; float dm, mcs; int B, L, M, layout;
   int rng_kind; uint32_t step; const float* uniforms; uint64_t seed, row_offset;
-  uint8_t* cand; float* onehot; float* q_xs;
+  uint8_t* cand; float* onehot; float* q_xs; int force_exact; int msplit;
 };
 
-__global__ __launch_bounds__(256) void propose_kernel(ProposeArgs a) {
-  __shared__ float sq[V][WAVE];
-  __shared__ int sx[WAVE];
-  const int lane = threadIdx.x & (WAVE - 1);
-  const int wave = threadIdx.x >> 6;
-  const int64_t N = (int64_t)a.B * a.L;
-  const int64_t n = (int64_t)blockIdx.x * WAVE + lane;
-  const bool valid = n < N;
-  const int64_t b = valid ? n / a.L : 0;
-  const int64_t l = valid ? n - b * a.L : 0;
+constexpr float LOG2E_HI = 1.44269502162933349609375f;        // fl32(log2 e)
+constexpr float LOG2E_LO = 1.925963033500011e-08f;             // log2 e - LOG2E_HI
+constexpr float LN2 = 0.693147182464599609375f;
 
-  if (wave == 0 && valid) {
-    float z[V], lp[V], q[V];
+// exp(x), relative error <= ~2^-21 for -80 < x <= 0 (hardware exp2 is 1 ulp; the product rounding
+// of x*log2e is compensated with an fma residual).
+__device__ __forceinline__ float exp_fast(float x) {
+  const float t = x * LOG2E_HI;
+  const float r = __fmaf_rn(x, LOG2E_HI, -t) + x * LOG2E_LO;   // x*log2e - t
+  const float e = __builtin_amdgcn_exp2f(t);
+  return __fmaf_rn(e, r * LN2, e);
+}
+__device__ __forceinline__ float log_fast(float a) { return __builtin_amdgcn_logf(a) * LN2; }   // rel err <= ~2^-22
+
+// exact q for one position (oracle arithmetic)
+__device__ __forceinline__ void q_exact(const float (&z)[V], int xt, float dm, float mcs, float (&q)[V]) {
+  if (xt != MASK) {               // exp(0)*dm and exp(-1e6)*dm: constants, no transcendental needed
+#pragma unroll
+    for (int v = 0; v < V; ++v) q[v] = (v == xt) ? dm : 0.0f;
+  } else {
+    float lp[V];
+    subs_logp_1(z, xt, lp);
+#pragma unroll
+    for (int v = 0; v < V; ++v) q[v] = expf_cr(lp[v]) * dm;     // diffusion_gosai.py:1194
+  }
+  q[MASK] = mcs;                                                 // :1196
+}
+
+// Work decomposition: a *unit* = (tile of 64 consecutive (b,l) positions, candidate group s of
+// `msplit`): the wave that owns a unit rebuilds the tile's cheap fast-path q in registers (no LDS, no
+// barrier) and draws candidates m = s, s + msplit, ... Waves take units in a grid-stride loop, so a
+// large launch runs as <= 2048 persistent blocks instead of one short-lived wave per unit (wave
+// dispatch was the bottleneck of the one-wave-per-unit version). msplit is chosen by the host: 1 when
+// there are enough tiles to fill the chip, up to 4 for small batches where latency dominates.
+template <bool REPLAY>
+__global__ __launch_bounds__(256) void propose_kernel(ProposeArgs a) {
+  const int lane = threadIdx.x & (WAVE - 1);
+  const uint32_t N = (uint32_t)a.B * (uint32_t)a.L;            // host guarantees B*L*5*M < 2^31-ish for 32-bit tiles
+  const uint32_t ntiles = (N + WAVE - 1) / WAVE;
+  const uint32_t nunits = ntiles * (uint32_t)a.msplit;
+  const uint32_t wave_global = blockIdx.x * 4u + (threadIdx.x >> 6);
+  const uint32_t nwaves = gridDim.x * 4u;
+
+  for (uint32_t unit = wave_global; unit < nunits; unit += nwaves) {
+    const uint32_t tile = unit / (uint32_t)a.msplit;
+    const int s0 = (int)(unit - tile * (uint32_t)a.msplit);
+    const uint32_t n = tile * WAVE + lane;
+    if (n >= N) continue;
+    const uint32_t b = n / (uint32_t)a.L;
+    const uint32_t l = n - b * (uint32_t)a.L;
+
+    // issue the token and logit loads together (the logits of an unmasked position are simply unused)
+    const int xt = a.x[n];
+    float z[V];
 #pragma unroll
     for (int v = 0; v < V; ++v) z[v] = a.logits[at(a.layout, b, l, v, a.L)];
-    const int xt = a.x[n];
-    if (xt != MASK && a.q_xs == nullptr) {
-      // q is never read for an unmasked position (copy_flag wins); skip the transcendental work
+    const bool masked = xt == MASK;
+
+    if (a.q_xs && s0 == 0) {                  // per-step API only: q_xs is returned to the caller (:1228)
+      float q[V];
+      q_exact(z, xt, a.dm, a.mcs, q);
 #pragma unroll
-      for (int v = 0; v < V; ++v) q[v] = 0.0f;
-    } else {
-      subs_logp_1(z, xt, lp);
+      for (int v = 0; v < V; ++v) a.q_xs[at(a.layout, b, l, v, a.L)] = q[v];
+    }
+
+    // fast-path q~ and the decision margin for this position
+    float qf[V];
+    float margin = 0.0f;                      // a draw is decided when second < best * margin
+    bool fast_ok = false;
+    if (masked) {
+      const float mx = fmaxf(fmaxf(z[0], z[1]), fmaxf(z[2], z[3]));
+      fast_ok = !a.force_exact && (fabsf(mx) < 60.0f) && (fabsf(z[MASK]) < 1e5f);   // also false on NaN
+      if (fast_ok) {
+        const float sum = (exp_fast(z[0] - mx) + exp_fast(z[1] - mx)) + (exp_fast(z[2] - mx) + exp_fast(z[3] - mx));
+        const float lse = log_fast(sum) + mx;
 #pragma unroll
-      for (int v = 0; v < V; ++v) q[v] = expf_cr(lp[v]) * a.dm;   // diffusion_gosai.py:1194
-      q[MASK] = a.mcs;                                             // :1196
-      if (a.q_xs) {
-#pragma unroll
-        for (int v = 0; v < V; ++v) a.q_xs[at(a.layout, b, l, v, a.L)] = q[v];
+        for (int v = 0; v < 4; ++v) qf[v] = exp_fast(z[v] - lse) * a.dm;
+        qf[MASK] = a.mcs;
+        // relative error budget of r~ = q~ * rcp(g~) against the exact quotient (DESIGN.md "K1 filter"):
+        //   q~: 2^-19 + 2^-21 |lse| ; g~: 2^-21 (selftest: 2^-22.5) ; rcp+mul: 2^-22 ; x2 for the pair,
+        //   + 2^-21 for the exact side's own rounding, x2 safety  =>  2^-16 + 2^-18 |lse|.
+        margin = 1.0f - (1.52587890625e-05f + 3.814697265625e-06f * fabsf(lse));
       }
     }
-#pragma unroll
-    for (int v = 0; v < V; ++v) sq[v][lane] = q[v];
-    sx[lane] = xt;
-  }
-  __syncthreads();
-  if (!valid) return;
+    const uint64_t pos = (a.row_offset + (uint64_t)b) * (uint64_t)a.L + (uint64_t)l;
+    const uint64_t obase = (uint64_t)b * (uint64_t)a.M * (uint64_t)a.L + l;
 
-  float q[V];
+    for (int m = s0; m < a.M; m += a.msplit) {
+      int c = xt;
+      if (masked) {
+        float u[V];
+        if (REPLAY) {
+          const float* ub = a.uniforms + (uint64_t)m * N * V;
 #pragma unroll
-  for (int v = 0; v < V; ++v) q[v] = sq[v][lane];
-  const int xt = sx[lane];
-  const uint64_t pos = (a.row_offset + (uint64_t)b) * (uint64_t)a.L + (uint64_t)l;
-
-  for (int m = wave; m < a.M; m += 4) {
-    int c = xt;
-    if (xt == MASK) {
-      float u[V];
-      if (a.rng_kind == SVDD_RNG_REPLAY) {
-        const float* ub = a.uniforms + (int64_t)m * N * V;
+          for (int v = 0; v < V; ++v) u[v] = ub[at(a.layout, b, l, v, a.L)];
+        } else {
+          philox_uniform5(a.seed, pos, a.step, (uint32_t)m, u);
+        }
+        bool decided = false;
+        if (fast_ok) {
+          float best = -1.0f, second = -1.0f;
+          int bi = 0;
 #pragma unroll
-        for (int v = 0; v < V; ++v) u[v] = ub[at(a.layout, b, l, v, a.L)];
-      } else {
-        philox_uniform5(a.seed, pos, a.step, (uint32_t)m, u);
+          for (int v = 0; v < V; ++v) {
+            const float g = 1e-10f - log_fast(u[v] + 1e-10f);
+            const float r = qf[v] * __builtin_amdgcn_rcpf(g);
+            if (r > best) { second = best; best = r; bi = v; }
+            else if (r > second) second = r;
+          }
+          decided = (best > 1e-30f) && (second < best * margin);
+          c = bi;
+        }
+        if (!decided) {                        // rare (~1e-6 of draws): exact arithmetic for this lane
+          float q[V];
+          q_exact(z, xt, a.dm, a.mcs, q);
+          c = sample_categorical_1(q, u);
+        }
       }
-      c = sample_categorical_1(q, u);
+      const uint64_t o = obase + (uint64_t)m * (uint64_t)a.L;
+      a.cand[o] = (uint8_t)c;
+      float4 oh;
+      oh.x = (c == 0) ? 1.0f : 0.0f; oh.y = (c == 1) ? 1.0f : 0.0f;
+      oh.z = (c == 2) ? 1.0f : 0.0f; oh.w = (c == 3) ? 1.0f : 0.0f;
+      reinterpret_cast<float4*>(a.onehot)[o] = oh;                 // transform_samples, :1462-1470
     }
-    const int64_t o = ((int64_t)b * a.M + m) * a.L + l;
-    a.cand[o] = (uint8_t)c;
-    float4 oh;
-    oh.x = (c == 0) ? 1.0f : 0.0f; oh.y = (c == 1) ? 1.0f : 0.0f;
-    oh.z = (c == 2) ? 1.0f : 0.0f; oh.w = (c == 3) ? 1.0f : 0.0f;
-    reinterpret_cast<float4*>(a.onehot)[o] = oh;                   // transform_samples, :1462-1470
   }
+}
+
+// Self-test of the fast-math error bounds K1's filter relies on. Thread t sweeps a strided subset:
+//  out[0][t] max relative error of g~ = 1e-10 - log_fast(u + 1e-10) vs the exact g over ALL 2^24 uniforms
+//  out[1][t] max relative error of exp_fast(x) vs correctly-rounded exp over 2^24 points of [-80, 0]
+//  out[2][t] max relative error of log_fast(s) vs correctly-rounded log over 2^24 points of [1, 4]
+__global__ void selftest_kernel(double* out, int nthreads) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  double e0 = 0.0, e1 = 0.0, e2 = 0.0;
+  for (uint32_t k = (uint32_t)t; k < (1u << 24); k += (uint32_t)nthreads) {
+    const float u = (float)k * (1.0f / 16777216.0f);
+    const float a = u + 1e-10f;
+    const float gx = 1e-10f - logf_cr(a);
+    const float gf = 1e-10f - log_fast(a);
+    e0 = fmax(e0, fabs((double)gf - (double)gx) / (double)gx);
+    const float x = -80.0f * u;
+    const double ex = exp((double)x);
+    e1 = fmax(e1, fabs((double)exp_fast(x) - ex) / ex);
+    const float s = 1.0f + 3.0f * u;
+    const double lx = log((double)s);
+    if (k) e2 = fmax(e2, fabs((double)log_fast(s) - lx) / lx);
+  }
+  out[t] = e0; out[nthreads + t] = e1; out[2 * nthreads + t] = e2;
 }
 
 // -------------------------------------------------------------------------- K2 select ----
@@ -456,6 +554,33 @@ __global__ __launch_bounds__(1024) void tds_resample_kernel(TdsArgs a) {
   }
 }
 
+// Optional per-launch timing (bench.py's roofline leg): when enabled, K1/K2 are launched with
+// hipExtLaunchKernelGGL start/stop events, i.e. HIP events bound to the dispatch itself on the launch
+// stream; svdd_profile_collect() sums hipEventElapsedTime over the recorded launches.
+struct TimedLaunch { hipEvent_t start, stop; };
+constexpr int PROFILE_KERNELS = 2;            // 0 = propose (K1), 1 = select (K2)
+bool g_profile = false;
+TimedLaunch* g_timed[PROFILE_KERNELS] = {nullptr, nullptr};
+int g_timed_n[PROFILE_KERNELS] = {0, 0}, g_timed_cap[PROFILE_KERNELS] = {0, 0};
+
+TimedLaunch* timed_slot(int k) {
+  if (!g_profile) return nullptr;
+  if (g_timed_n[k] == g_timed_cap[k]) {
+    const int cap = g_timed_cap[k] ? g_timed_cap[k] * 2 : 1024;
+    TimedLaunch* p = (TimedLaunch*)realloc(g_timed[k], sizeof(TimedLaunch) * (size_t)cap);
+    if (!p) return nullptr;
+    g_timed[k] = p; g_timed_cap[k] = cap;
+  }
+  TimedLaunch* t = &g_timed[k][g_timed_n[k]];
+  if (hipEventCreate(&t->start) != hipSuccess) return nullptr;
+  if (hipEventCreate(&t->stop) != hipSuccess) { (void)hipEventDestroy(t->start); return nullptr; }
+  ++g_timed_n[k];
+  return t;
+}
+
+int g_msplit = 0;        // svdd_set_option(SVDD_OPT_MSPLIT, k): override K1's candidate split (0 = auto)
+int g_force_exact = 0;   // svdd_set_option(SVDD_OPT_FORCE_EXACT, 1): K1 takes the exact path for every draw
+
 inline int check_launch() { return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH; }
 inline bool bad_layout(int layout) { return layout != SVDD_LAYOUT_BLV && layout != SVDD_LAYOUT_BVL; }
 
@@ -465,6 +590,55 @@ inline bool bad_layout(int layout) { return layout != SVDD_LAYOUT_BLV && layout 
 extern "C" {
 
 int svdd_abi_version(void) { return SVDD_ABI_VERSION; }
+
+int svdd_set_option(int key, int value) {
+  if (key == SVDD_OPT_FORCE_EXACT) { g_force_exact = value ? 1 : 0; return SVDD_OK; }
+  if (key == SVDD_OPT_MSPLIT && value >= 0 && value <= 64) { g_msplit = value; return SVDD_OK; }
+  return SVDD_E_ARG;
+}
+
+int svdd_profile_enable(int on) {
+  g_profile = on != 0;
+  return SVDD_OK;
+}
+
+int svdd_profile_collect(int kernel, double* total_ms, int* launches) {
+  if (kernel < 0 || kernel >= PROFILE_KERNELS || !total_ms || !launches) return SVDD_E_ARG;
+  double tot = 0.0;
+  int n = 0;
+  for (int i = 0; i < g_timed_n[kernel]; ++i) {
+    TimedLaunch& t = g_timed[kernel][i];
+    float ms = 0.0f;
+    if (hipEventSynchronize(t.stop) == hipSuccess && hipEventElapsedTime(&ms, t.start, t.stop) == hipSuccess) {
+      tot += ms; ++n;
+    }
+    (void)hipEventDestroy(t.start);
+    (void)hipEventDestroy(t.stop);
+  }
+  g_timed_n[kernel] = 0;
+  *total_ms = tot;
+  *launches = n;
+  return SVDD_OK;
+}
+
+int svdd_selftest_fastmath(double* out3) {
+  if (!out3) return SVDD_E_ARG;
+  const int nthreads = 256 * 1024;
+  double* d = nullptr;
+  if (hipMalloc(&d, sizeof(double) * 3 * nthreads) != hipSuccess) return SVDD_E_NODEVICE;
+  hipLaunchKernelGGL(selftest_kernel, dim3(1024), dim3(256), 0, 0, d, nthreads);
+  double* h = (double*)malloc(sizeof(double) * 3 * nthreads);
+  const bool ok = hipMemcpy(h, d, sizeof(double) * 3 * nthreads, hipMemcpyDeviceToHost) == hipSuccess;
+  if (ok)
+    for (int j = 0; j < 3; ++j) {
+      double m = 0.0;
+      for (int i = 0; i < nthreads; ++i) m = h[j * nthreads + i] > m ? h[j * nthreads + i] : m;
+      out3[j] = m;
+    }
+  free(h);
+  (void)hipFree(d);
+  return ok ? SVDD_OK : SVDD_E_LAUNCH;
+}
 
 int svdd_device_info(char* arch, int arch_len, int* num_cu) {
   int dev = 0;
@@ -484,11 +658,22 @@ int svdd_propose(const float* logits, const uint8_t* x, float dm, float mcs, int
   if (!logits || !x || !rng || !cand || !onehot || B <= 0 || L <= 0 || M <= 0 || M > 65535 || bad_layout(layout))
     return SVDD_E_ARG;
   if (rng->kind == SVDD_RNG_REPLAY ? rng->uniforms == nullptr : rng->kind != SVDD_RNG_PHILOX) return SVDD_E_ARG;
-  ProposeArgs a{logits, x, dm, mcs, B, L, M, layout, rng->kind, rng->step, rng->uniforms, rng->seed,
-                rng->row_offset, cand, onehot, q_xs};
   const int64_t N = (int64_t)B * L;
-  const unsigned grid = (unsigned)((N + WAVE - 1) / WAVE);
-  hipLaunchKernelGGL(propose_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  if (N >= (int64_t)1 << 31) return SVDD_E_ARG;
+  const int64_t ntiles = (N + WAVE - 1) / WAVE;
+  // split the M candidates of a tile over up to 4 waves only while the chip (256 CUs x 4 SIMDs) is underfilled
+  int msplit = g_msplit > 0 ? g_msplit : (ntiles >= 4096 ? 1 : ntiles >= 256 ? 2 : 4);   // measured: tools/k1_microbench.py
+  if (msplit > M) msplit = M;
+  ProposeArgs a{logits, x, dm, mcs, B, L, M, layout, rng->kind, rng->step, rng->uniforms, rng->seed,
+                rng->row_offset, cand, onehot, q_xs, g_force_exact, msplit};
+  const int64_t nblocks = (ntiles * msplit + 3) / 4;
+  const unsigned grid = (unsigned)(nblocks < 2048 ? nblocks : 2048);
+  TimedLaunch* t = timed_slot(0);
+  hipEvent_t e0 = t ? t->start : nullptr, e1 = t ? t->stop : nullptr;
+  if (rng->kind == SVDD_RNG_REPLAY)
+    hipExtLaunchKernelGGL(propose_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, e0, e1, 0, a);
+  else
+    hipExtLaunchKernelGGL(propose_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, e0, e1, 0, a);
   return check_launch();
 }
 
@@ -499,7 +684,9 @@ int svdd_select(const float* scores, const uint8_t* cand, int B, int L, int M, i
   if (mode == SVDD_SELECT_MULTINOMIAL && (!rng || rng->kind != SVDD_RNG_PHILOX)) return SVDD_E_ARG;
   SelectArgs a{scores, cand, B, L, M, mode, rng ? rng->step : 0u, rng ? rng->seed : 0ull,
                rng ? rng->row_offset : 0ull, x_next, soft, idx};
-  hipLaunchKernelGGL(select_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
+  TimedLaunch* t = timed_slot(1);
+  hipExtLaunchKernelGGL(select_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                        t ? t->start : nullptr, t ? t->stop : nullptr, 0, a);
   return check_launch();
 }
 

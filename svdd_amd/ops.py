@@ -18,10 +18,6 @@ from ._lib import (LAYOUT_BLV, LAYOUT_BVL, RNG_PHILOX, RNG_REPLAY, SELECT_ARGMAX
 
 MASK = 4
 
-# bench.py sets this to a list to time every propose launch with HIP events recorded on the launch
-# stream (torch's current stream); each entry is a (start, end) torch.cuda.Event pair.
-PROPOSE_EVENTS = None
-
 
 @dataclass
 class Rng:
@@ -86,16 +82,9 @@ def propose(logits, x, dm, mcs, M, rng, want_q=False, cand=None, onehot=None):
         u = _need(rng.uniforms, torch.float32, "uniforms")
         assert u.is_contiguous() and u.numel() == M * B * L * 5, (u.shape, M, B, L)
     rs = rng.c_struct()
-    ev = None
-    if PROPOSE_EVENTS is not None:
-        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-        ev[0].record()
     rc = _lib.lib().svdd_propose(logits.data_ptr(), x.data_ptr(), float(dm), float(mcs), B, L, M, layout,
                                  ctypes.byref(rs), cand.data_ptr(), onehot.data_ptr(),
                                  q.data_ptr() if q is not None else None, _stream())
-    if ev is not None:
-        ev[1].record()
-        PROPOSE_EVENTS.append(ev)
     _lib.check(rc, "svdd_propose")
     return cand, onehot, q
 

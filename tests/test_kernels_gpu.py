@@ -270,3 +270,61 @@ def test_full_size_properties_c2(ops):
     xf = dev(rng.integers(0, 4, (B, L)).astype(np.uint8))
     cand2, _, _ = ops.propose(lg, xf, 0.0078, 0.5, M, ops.Rng(seed=3, step=65))
     assert torch.equal(cand2, xf[:, None, :].expand(B, M, L))
+
+
+# ------------------------------------------------------------------ K1 filter (fast exact path)
+def test_fastmath_bounds_exhaustive(ops):
+    """The error bounds K1's filter assumes, measured on the device: the fast Gumbel-norm over ALL 2^24
+    possible uniforms, fast exp on [-80,0], fast log on (1,4]. Margins in the kernel: 2^-21, 2^-21, 2^-22."""
+    from svdd_amd import _lib
+    eg, ee, el = _lib.selftest_fastmath()
+    print(f"max rel err: g~ {eg:.3e} (2^{np.log2(eg):.2f}), exp {ee:.3e} (2^{np.log2(ee):.2f}), log {el:.3e} (2^{np.log2(el):.2f})")
+    assert eg <= 2.0 ** -21
+    assert ee <= 2.0 ** -21
+    assert el <= 2.0 ** -22
+
+
+@pytest.mark.parametrize("layout", [orc.BLV, orc.BVL])
+def test_filter_equals_forced_exact_large(ops, layout):
+    """A/B: the filtered fast path and the forced-exact path produce identical candidates on 2.5M draws
+    (Philox) incl. large-magnitude logits that must take the guard."""
+    from svdd_amd import _lib
+    rng = np.random.default_rng(31)
+    B, L, M = 128, 200, 20
+    logits, x = rand_case(rng, B, L, frac_unmasked=0.1, scale=3.0)
+    logits[0] *= 40.0                                   # |z| > 60: guard -> exact path
+    logits[1, :, :4] = 0.5                              # uniform q: many near-ties between categories
+    lg = dev(logits) if layout == orc.BLV else bvl_view(logits)
+    outs = []
+    for force in (False, True):
+        _lib.set_force_exact(force)
+        try:
+            cand, onehot, _ = ops.propose(lg, dev(x), 0.0078, 0.0021, M, ops.Rng(seed=5, step=100))
+            torch.cuda.synchronize()
+        finally:
+            _lib.set_force_exact(False)
+        outs.append((cand.clone(), onehot.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+def test_filter_adversarial_ties_vs_oracle(ops):
+    """Replay uniforms crafted so that categories tie exactly or within an ulp (equal q, equal or
+    adjacent u): the filter must hand these lanes to the exact path and reproduce the oracle's
+    first-index rule."""
+    rng = np.random.default_rng(32)
+    B, L, M = 4, 192, 8
+    logits = np.zeros((B, L, 5), np.float32)
+    logits[..., :4] = rng.integers(-2, 3, (B, L, 1)).astype(np.float32)      # z0=z1=z2=z3 -> equal q
+    x = np.full((B, L), 4, np.uint8)
+    k = rng.integers(1, 2 ** 24 - 2, (M, B, L, 1))
+    jitter = rng.integers(-1, 2, (M, B, L, 5))
+    jitter[..., 4] = 0
+    u = ((k + jitter) / 2.0 ** 24).astype(np.float32)                         # equal / adjacent uniforms
+    dm = np.float32(0.0078)
+    mcs = np.float32(dm * 0.25)                                               # MASK ties with the tokens too
+    u[:, 1] = u[:, 1, :, :1]                                                  # row 1: all five uniforms equal
+    c_ref, oh_ref, _ = orc.propose(logits, x, dm, mcs, M, uniforms=u, want_q=False)
+    cand, onehot, _ = ops.propose(dev(logits), dev(x), dm, mcs, M, ops.Rng(uniforms=dev(u)))
+    assert np.array_equal(cand.cpu().numpy(), c_ref)
+    assert np.array_equal(onehot.cpu().numpy(), oh_ref)
+    assert len(np.unique(c_ref)) >= 3                                         # the ties do exercise several outcomes

@@ -164,12 +164,11 @@ def test_g10_decode_sample_stepwise(golden):
 
 
 def test_philox_known_answer():
-    """Philox4x32-10 known-answer vectors from the Random123 distribution (kat_vectors):
-    ctr=0,key=0 ; ctr=ff..,key=ff.. ; ctr/key = digits of pi."""
-    import ctypes
-    lib = orc.lib()
-    # exposed through orc_philox_uniform5 only as floats; check via a raw call on the static
-    # function's public twin instead: uniforms are (word >> 8) * 2^-24
+    """Philox4x32-10 known-answer vector from the Random123 distribution (kat_vectors, ctr=0, key=0):
+    6627e8d5 e169c58d bc57ac4c 9b00dbd8. One block feeds the 5 uniforms of a draw: categories 0..3 take the
+    top 24 bits of the four words, MASK the low bytes of words 0..2."""
     u = orc.philox_uniform5(0, 0, 0, 0)
     words = [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
-    assert np.array_equal(u[:4], np.array([(w >> 8) / 16777216.0 for w in words], dtype=np.float32))
+    want = [(w >> 8) / 16777216.0 for w in words]
+    want.append(((words[0] & 0xFF) | ((words[1] & 0xFF) << 8) | ((words[2] & 0xFF) << 16)) / 16777216.0)
+    assert np.array_equal(u, np.array(want, dtype=np.float32))
