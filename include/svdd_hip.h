@@ -62,10 +62,13 @@ enum {
 typedef struct svdd_rng {
   int32_t kind;            /* SVDD_RNG_REPLAY | SVDD_RNG_PHILOX */
   uint32_t step;           /* PHILOX: diffusion step index (0..S-1) */
-  const float* uniforms;   /* REPLAY: M consecutive blocks of B*L*5 fp32 in [0,1), each in the
-                              SAME layout as `logits` — the order M rand_like(q_xs) calls consume */
+  const float* uniforms;   /* REPLAY: M consecutive blocks of B*L*5 fp32 in [0,1), each laid out as
+                              `uniforms_layout` — the order M rand_like(q_xs) calls consume, i.e. the
+                              memory order of the REFERENCE backbone's output (BVL for its CNN) */
   uint64_t seed;           /* PHILOX: 64-bit key */
   uint64_t row_offset;     /* PHILOX: global index of this shard's row 0 */
+  int32_t uniforms_layout; /* REPLAY: SVDD_LAYOUT_* of each uniforms block (independent of `layout`) */
+  int32_t reserved;
 } svdd_rng_t;
 
 /* Selection rule of svdd_select. */
@@ -152,6 +155,17 @@ int svdd_tds_resample(const float* reward_num, const float* reward_den, float al
                       const uint8_t* sample, const double* u, int B, int L,
                       uint8_t* x_next, int32_t* idx, double* work, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Net kernels — internals of the value network (reference Enformer.py), not of the sampler. They are
+ * optional accelerations of PyTorch modules (svdd_amd/fused.py); the sampler API above never needs them.
+ *
+ * svdd_gru_bidir_f32 — bidirectional single-layer GRU, input = hidden = 64, fp32
+ *   (reference Enformer.py:1595-1602 nn.GRU(64, 64, bidirectional=True, batch_first=True), gate order r,z,n).
+ *   x [n,L,64] ; out [2,n,L,64] = per-direction hidden states (the caller sums them, Enformer.py:1617).
+ *   wpack [2][4][64][96], bpack [2][4][64]: weights repacked per MFMA lane, see svdd_amd/fused.py:pack_gru. */
+int svdd_gru_bidir_f32(const float* x, const float* wpack, const float* bpack, float* out, int n, int L,
+                       void* stream);
+
 /* Process-wide options (host). SVDD_OPT_FORCE_EXACT != 0 makes svdd_propose evaluate every draw in the
  * exact (fp64, correctly rounded) arithmetic instead of the filtered fast path — same results, used
  * to A/B the filter. */
@@ -177,7 +191,7 @@ int svdd_device_info(char* arch, int arch_len, int* num_cu);
 
 /* ABI version of this header: bumped on any signature change. */
 int svdd_abi_version(void);
-#define SVDD_ABI_VERSION 1
+#define SVDD_ABI_VERSION 2
 
 #ifdef __cplusplus
 }

@@ -310,3 +310,21 @@ def controlled_sample_tds(backbone, reward_fn, schedule, alpha, B, L, uniform_fn
     with torch.no_grad():
         logits = backbone(torch.from_numpy(x.astype(np.int64))).float().numpy()
     return finalize(logits, x)
+
+
+def replay_controlled_sample(trace, schedule, B, L, M, uniform_fn=None, seed=0, row_offset=0, mode=0, layout=BLV):
+    """SVDD-MC / SVDD-PM outer loop on RECORDED per-step (logits, scores): `trace` is a list of S
+    (logits, scores[B,M]) pairs followed by the (logits, None) of the noise-removal forward. Everything
+    but the nets is recomputed here, so the result is independent of whether the nets are run-to-run
+    deterministic."""
+    S = schedule.shape[0]
+    assert len(trace) == S + 1, (len(trace), S)
+    x = np.full((B, L), MASK, dtype=np.uint8)
+    for i in range(S):
+        logits, scores = trace[i]
+        mct, mcs, dm = (float(v) for v in schedule[i])
+        uni = uniform_fn(i, M, B, L) if uniform_fn is not None else None
+        cand, _, _ = propose(logits, x, dm, mcs, M, uniforms=uni, seed=seed, row_offset=row_offset, step=i,
+                             want_q=False, layout=layout)
+        x, _, _ = select(scores, cand, mode=mode, seed=seed, row_offset=row_offset, step=i)
+    return finalize(trace[S][0], x, layout=layout)

@@ -11,7 +11,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 SO_PATH = os.path.join(CSRC, "libsvdd_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 OK, E_ARG, E_LAUNCH, E_NODEVICE = 0, -1, -2, -3
 LAYOUT_BLV, LAYOUT_BVL = 0, 1
@@ -23,6 +23,7 @@ EXPORTS = (
     "svdd_abi_version", "svdd_device_info", "svdd_propose", "svdd_select", "svdd_x0hat",
     "svdd_finalize", "svdd_transform_samples", "svdd_subs_logp", "svdd_tds_resample",
     "svdd_set_option", "svdd_selftest_fastmath", "svdd_profile_enable", "svdd_profile_collect",
+    "svdd_gru_bidir_f32",
 )
 OPT_FORCE_EXACT = 0
 
@@ -30,7 +31,8 @@ OPT_FORCE_EXACT = 0
 class SvddRng(ctypes.Structure):
     """struct svdd_rng (include/svdd_hip.h)."""
     _fields_ = [("kind", ctypes.c_int32), ("step", ctypes.c_uint32), ("uniforms", ctypes.c_void_p),
-                ("seed", ctypes.c_uint64), ("row_offset", ctypes.c_uint64)]
+                ("seed", ctypes.c_uint64), ("row_offset", ctypes.c_uint64),
+                ("uniforms_layout", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 class SvddError(RuntimeError):
@@ -39,10 +41,9 @@ class SvddError(RuntimeError):
 
 def build(force=False):
     """Compile csrc/svdd_kernels.hip for gfx950 (hipcc cross-compiles without a GPU)."""
-    src = os.path.join(CSRC, "svdd_kernels.hip")
-    hdr = os.path.join(os.path.dirname(_HERE), "include", "svdd_hip.h")
-    stale = (not os.path.exists(SO_PATH)
-             or os.path.getmtime(SO_PATH) < max(os.path.getmtime(src), os.path.getmtime(hdr)))
+    srcs = [os.path.join(CSRC, "svdd_kernels.hip"), os.path.join(CSRC, "svdd_nets.hip"),
+            os.path.join(os.path.dirname(_HERE), "include", "svdd_hip.h")]
+    stale = not os.path.exists(SO_PATH) or os.path.getmtime(SO_PATH) < max(os.path.getmtime(f) for f in srcs)
     if force or stale:
         subprocess.check_call(["make", "-C", CSRC, "-B"])
     return SO_PATH
@@ -77,6 +78,7 @@ def lib():
     L.svdd_tds_resample.argtypes = [vp, vp, f32, vp, vp, i32, i32, vp, vp, vp, vp]
     L.svdd_set_option.argtypes = [i32, i32]
     L.svdd_selftest_fastmath.argtypes = [ctypes.POINTER(ctypes.c_double)]
+    L.svdd_gru_bidir_f32.argtypes = [vp, vp, vp, vp, i32, i32, vp]
     L.svdd_profile_enable.argtypes = [i32]
     L.svdd_profile_collect.argtypes = [i32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]
     L.svdd_device_info.argtypes = [ctypes.c_char_p, i32, ctypes.POINTER(ctypes.c_int)]

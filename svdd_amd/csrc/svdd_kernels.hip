@@ -117,7 +117,7 @@ __device__ __forceinline__ int sample_categorical_1(const float (&q)[V], const f
 struct ProposeArgs {
   const float* logits; const uint8_t* x; float dm, mcs; int B, L, M, layout;
   int rng_kind; uint32_t step; const float* uniforms; uint64_t seed, row_offset;
-  uint8_t* cand; float* onehot; float* q_xs; int force_exact; int msplit;
+  uint8_t* cand; float* onehot; float* q_xs; int force_exact; int msplit; int ulayout;
 };
 
 constexpr float LOG2E_HI = 1.44269502162933349609375f;        // fl32(log2 e)
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void propose_kernel(ProposeArgs a) {
         if (REPLAY) {
           const float* ub = a.uniforms + (uint64_t)m * N * V;
 #pragma unroll
-          for (int v = 0; v < V; ++v) u[v] = ub[at(a.layout, b, l, v, a.L)];
+          for (int v = 0; v < V; ++v) u[v] = ub[at(a.ulayout, b, l, v, a.L)];
         } else {
           philox_uniform5(a.seed, pos, a.step, (uint32_t)m, u);
         }
@@ -657,7 +657,8 @@ int svdd_propose(const float* logits, const uint8_t* x, float dm, float mcs, int
                  const svdd_rng_t* rng, uint8_t* cand, float* onehot, float* q_xs, void* stream) {
   if (!logits || !x || !rng || !cand || !onehot || B <= 0 || L <= 0 || M <= 0 || M > 65535 || bad_layout(layout))
     return SVDD_E_ARG;
-  if (rng->kind == SVDD_RNG_REPLAY ? rng->uniforms == nullptr : rng->kind != SVDD_RNG_PHILOX) return SVDD_E_ARG;
+  if (rng->kind == SVDD_RNG_REPLAY ? (rng->uniforms == nullptr || bad_layout(rng->uniforms_layout))
+                                   : rng->kind != SVDD_RNG_PHILOX) return SVDD_E_ARG;
   const int64_t N = (int64_t)B * L;
   if (N >= (int64_t)1 << 31) return SVDD_E_ARG;
   const int64_t ntiles = (N + WAVE - 1) / WAVE;
@@ -665,7 +666,7 @@ int svdd_propose(const float* logits, const uint8_t* x, float dm, float mcs, int
   int msplit = g_msplit > 0 ? g_msplit : (ntiles >= 4096 ? 1 : ntiles >= 256 ? 2 : 4);   // measured: tools/k1_microbench.py
   if (msplit > M) msplit = M;
   ProposeArgs a{logits, x, dm, mcs, B, L, M, layout, rng->kind, rng->step, rng->uniforms, rng->seed,
-                rng->row_offset, cand, onehot, q_xs, g_force_exact, msplit};
+                rng->row_offset, cand, onehot, q_xs, g_force_exact, msplit, rng->uniforms_layout};
   const int64_t nblocks = (ntiles * msplit + 3) / 4;
   const unsigned grid = (unsigned)(nblocks < 2048 ? nblocks : 2048);
   TimedLaunch* t = timed_slot(0);

@@ -22,6 +22,9 @@ Engine knobs (attributes; defaults reproduce the reference's observable behaviou
   value_batching   "batched": one value-net forward over all B*M candidates (default);
                    "reference": M forwards of batch B like diffusion_gosai.py:1207-1209.
   select_mode      "argmax" (reference, :1225) or "multinomial" (the commented-out :1223; philox only).
+  fuse_nets        True: nets of known architecture (CNNModel backbone; ConvGRUTrunk+ConvHead value /
+                   reward nets) are run through their MI355X formulations in svdd_amd/fused.py (same
+                   weights, fp32, channels-last, folded BN, HIP GRU kernel). False: call the modules as given.
 """
 import numpy as np
 import torch
@@ -63,7 +66,10 @@ class Diffusion(nn.Module):
         self.select_mode = "argmax"
         self.philox_seed = 0
         self.row_offset = 0
+        self.fuse_nets = True
+        self.trace = None          # set to a list to record (logits, scores) of every step (tests / smoke)
         self._sched_cache = {}
+        self._fused = {}
 
     # ------------------------------------------------------------------ plumbing ----
     @property
@@ -85,9 +91,47 @@ class Diffusion(nn.Module):
     def _tokens_u8(self, x):
         return x if x.dtype == torch.uint8 else x.to(torch.uint8)
 
+    def clear_fused(self):
+        """Drop the cached fused formulations (call after changing any net's weights)."""
+        self._fused = {}
+
+    def _fused_backbone(self):
+        fb = self._fused.get("backbone")
+        if fb is None:
+            from .fused import FusedBackbone
+            fb = FusedBackbone(self.backbone).to(self.device).eval()
+            self._fused["backbone"] = fb
+        return fb
+
+    def value_callable(self, embedding, head):
+        """The callable the engine uses for `head(embedding(onehot))`: onehot fp32 [n,L,4] -> [n,1,1]."""
+        from .value_nets import ConvGRUTrunk, ConvHead
+        if (self.fuse_nets and isinstance(embedding, ConvGRUTrunk) and isinstance(head, ConvHead)
+                and embedding.gru_tower.gru.hidden_size == 64 and embedding.gru_tower.gru.input_size == 64
+                and embedding.gru_tower.gru.num_layers == 1 and next(embedding.parameters()).is_cuda):
+            key = ("value", id(embedding), id(head))
+            fv = self._fused.get(key)
+            if fv is None:
+                from .fused import FusedValueNet
+                fv = FusedValueNet(embedding, head).to(self.device).eval()
+                self._fused[key] = fv
+            return fv
+        return lambda onehot: head(embedding(onehot))
+
+    def reward_callable(self, reward_model):
+        """The callable the engine uses for `reward_model(onehot_t [n,4,L])` -> [n,n_tasks,1]."""
+        from .value_nets import RewardModel
+        if self.fuse_nets and isinstance(reward_model, RewardModel):
+            fused = self.value_callable(reward_model.embedding, reward_model.head)
+            if isinstance(fused, nn.Module):
+                return fused
+        return reward_model
+
     def _backbone_logits(self, x_u8):
         """Raw backbone output for tokens x (sigma is zeroed when time_conditioning is False, :334-335)."""
         if isinstance(self.backbone, CNNModel) and not self.time_conditioning:
+            if self.fuse_nets and x_u8.is_cuda:
+                return self._fused_backbone()(x_u8)
             return self.backbone(x_u8, None, zero_sigma=True)
         sigma = torch.zeros(x_u8.shape[0], device=x_u8.device)
         return self.backbone(x_u8.long(), sigma).float()
@@ -102,15 +146,20 @@ class Diffusion(nn.Module):
         mcs = 1 - torch.exp(-sigma_s.squeeze(-1))
         return float(mct), float(mcs), float(mct - mcs)
 
-    def _uniforms(self, M, B, L, logits):
-        """Replay mode: the next M*B*L*5 draws of torch's CPU generator, laid out like `logits`."""
-        _, layout = ops.layout_of(logits)
-        shape = (M, B, L, 5) if layout == ops.LAYOUT_BLV else (M, B, 5, L)
-        return torch.rand(shape).to(logits.device, non_blocking=True)
+    def _replay_layout(self, logits):
+        """Memory order in which the REFERENCE consumes its uniforms: rand_like(q_xs) fills in the
+        memory order of the reference backbone's output — [b][v][l] for its CNN, whose output is a
+        permuted view (models/dnaconv.py:201) — whatever layout this engine's backbone emits."""
+        if self.config.backbone == "cnn":
+            return ops.LAYOUT_BVL
+        return ops.layout_of(logits)[1]
 
     def _rng(self, step, M, B, L, logits):
         if self.rng_mode == "replay":
-            return ops.Rng(uniforms=self._uniforms(M, B, L, logits))
+            ul = self._replay_layout(logits)
+            shape = (M, B, L, 5) if ul == ops.LAYOUT_BLV else (M, B, 5, L)
+            u = torch.rand(shape).to(logits.device, non_blocking=True)   # torch's global CPU generator
+            return ops.Rng(uniforms=u, uniforms_layout=ul)
         if self.rng_mode == "philox":
             return ops.Rng(seed=self.philox_seed, row_offset=self.row_offset, step=step)
         raise ValueError(f"rng_mode {self.rng_mode!r}")
@@ -127,10 +176,11 @@ class Diffusion(nn.Module):
 
     def _value_scores(self, embedding, head, onehot, B, M):
         """scores[b, m] = head(embedding(onehot of candidate m of sample b)) (:1207-1209,1219)."""
+        fn = self.value_callable(embedding, head)
         if self.value_batching == "batched":
-            return head(embedding(onehot)).reshape(B, M).float()
+            return fn(onehot).reshape(B, M).float()
         oh = onehot.view(B, M, onehot.shape[1], 4)
-        return torch.stack([head(embedding(oh[:, m].contiguous())).reshape(B) for m in range(M)], dim=1).float()
+        return torch.stack([fn(oh[:, m].contiguous()).reshape(B) for m in range(M)], dim=1).float()
 
     def _batch_size(self, eval_sp_size):
         return self.config.loader.eval_batch_size if eval_sp_size is None else eval_sp_size
@@ -143,8 +193,14 @@ class Diffusion(nn.Module):
         if self.config.sampling.noise_removal:
             if self.sampler == "analytic":
                 raise NotImplementedError("analytic sampler is not on the reference's decode path")
-            return ops.finalize(self._backbone_logits(x_u8), x_u8)
+            logits = self._backbone_logits(x_u8)
+            self._record(logits, None)
+            return ops.finalize(logits, x_u8)
         return x_u8.long()
+
+    def _record(self, logits, scores):
+        if self.trace is not None:
+            self.trace.append((logits.detach().clone(), None if scores is None else scores.detach().clone()))
 
     # ---------------------------------------------------------- reference API: basics ----
     def _process_sigma(self, sigma):
@@ -160,11 +216,7 @@ class Diffusion(nn.Module):
         self._require_gpu()
         sigma = self._process_sigma(sigma)
         x_u8 = self._tokens_u8(x)
-        if isinstance(self.backbone, CNNModel) and not self.time_conditioning:
-            logits = self.backbone(x_u8, None, zero_sigma=True)
-        else:
-            logits = self.backbone(x if x.dtype == torch.int64 else x.long(), sigma).float()
-        return ops.subs_logp(logits, x_u8)
+        return ops.subs_logp(self._backbone_logits(x_u8), x_u8)
 
     def forward2(self, x_onehot, x, sigma):
         """Differentiable log score on a one-hot input (:359-377), used by the DPS baseline. Autograd
@@ -238,7 +290,7 @@ class Diffusion(nn.Module):
             oh, _ = ops.x0hat(self._backbone_logits(flat), flat)          # :1415-1419
         else:
             oh = ops.transform_samples(flat, transposed=True)             # heuristic branch :1420-1424
-        return reward_model(oh)[:, 0].reshape(B, M).float()               # :1430,1436
+        return self.reward_callable(reward_model)(oh)[:, 0].reshape(B, M).float()   # :1430,1436
 
     @torch.no_grad()
     def _ddpm_update_finetune_controlled_TDS(self, x, t, dt, reward_model, alpha=1.0):
@@ -255,10 +307,11 @@ class Diffusion(nn.Module):
         cand, _, _ = ops.propose(logits, x_u8, dm, mcs, 1, self._rng(step, 1, B, L, logits))
         sample = cand[:, 0].contiguous()
         oh_num, _ = ops.x0hat(self._backbone_logits(sample), sample)      # :1263-1268
-        reward_num = reward_model(oh_num)[:, 0][:, 0].float()             # :1269
+        reward_fn = self.reward_callable(reward_model)
+        reward_num = reward_fn(oh_num)[:, 0][:, 0].float()                # :1269
         # forward(x, sigma_s) == forward(x, sigma_t): sigma is zeroed (:334-335), so `logits` is reused (:1273)
         oh_den, _ = ops.x0hat(logits, x_u8)
-        reward_den = reward_model(oh_den)[:, 0][:, 0].float()             # :1277
+        reward_den = reward_fn(oh_den)[:, 0][:, 0].float()                # :1277
         u = torch.from_numpy(np.random.random_sample(B)).to(x_u8.device)   # what np.random.choice draws (:1282)
         x_next, _ = ops.tds_resample(reward_num, reward_den, alpha, sample, u)
         return x_next
@@ -309,6 +362,7 @@ class Diffusion(nn.Module):
             logits = self._backbone_logits(x)
             ops.propose(logits, x, sched[i, 2], sched[i, 1], M, self._rng(i, M, B, L, logits), cand=cand, onehot=onehot)
             scores = self._value_scores(pre_scorer_embedding, pre_scorer_head, onehot, B, M)
+            self._record(logits, scores)
             x = self._select(scores, cand, i)
         return self._noise_removal(x)
 
@@ -325,6 +379,7 @@ class Diffusion(nn.Module):
             logits = self._backbone_logits(x)
             cand, _, _ = ops.propose(logits, x, sched[i, 2], sched[i, 1], M, self._rng(i, M, B, L, logits))
             scores = self._tweedie_scores(cand, reward_model, options, task)
+            self._record(logits, scores)
             x = self._select(scores, cand, i)
         return self._noise_removal(x)
 

@@ -1,0 +1,154 @@
+"""Inference-time re-formulations of the nets for MI355X.
+
+The sampler treats the nets as opaque callables; these wrappers compute the SAME functions as
+`backbone.CNNModel` and `value_nets.ConvGRUTrunk + ConvHead` (same weights, fp32) but laid out
+for the hardware:
+
+  * activations stay channels-last ([n, L, C] in memory) end to end, so MIOpen's NHWC implicit-GEMM
+    convolutions run without the NCHW<->NHWC `batched_transpose` kernels PyTorch otherwise inserts
+    around every Conv1d, and LayerNorm normalises the contiguous last dimension;
+  * eval-mode BatchNorm is folded into the preceding convolution (rocprof r01_v0: MIOpen's
+    BatchNormFwdInfer took 0.72 ms per call, 12.5 % of the step);
+  * the bidirectional GRU — ~2900 MIOpen launches and 11.7 ms per call at n=2560, L=200 — is ONE
+    launch of the hand-written MFMA kernel `svdd_gru_bidir_f32` (csrc/svdd_nets.hip).
+
+Numerics: fp32 throughout; results differ from the plain modules only by fp32 re-association
+(BN folding, GEMM tiling) and the GRU's hardware exp/rcp — observed <= 1e-5 on the scores,
+well inside the 1e-4 soft-value tolerance of the north star (tests/test_fused_gpu.py).
+"""
+import ctypes
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import _lib
+from .backbone import CNNModel
+from .value_nets import ConvGRUTrunk, ConvHead
+
+
+def _cl(w):
+    """Conv1d weight [O,I,k] -> Conv2d weight [O,I,1,k] in channels_last memory."""
+    return w.detach().unsqueeze(2).contiguous(memory_format=torch.channels_last)
+
+
+def pack_gru(gru):
+    """nn.GRU(64, 64, bidirectional) -> (wpack [2,4,64,96], bpack [2,4,64]) for svdd_gru_bidir_f32.
+
+    Lane (j = lane & 15, g = lane >> 4) of wave w holds, for hidden unit u = 16 w + j and input
+    k = 16 g + s (s = 0..15): W_ir, W_hr, W_iz, W_hz, W_in, W_hn rows — the B operands of
+    v_mfma_f32_16x16x4_f32 with the k axis permuted so that each lane's A operand is 16 contiguous floats."""
+    H = gru.hidden_size
+    assert H == 64 and gru.input_size == 64 and gru.bidirectional and gru.num_layers == 1 and gru.bias
+    packs, biases = [], []
+    for sfx in ("", "_reverse"):
+        w_ih = getattr(gru, "weight_ih_l0" + sfx).detach().float()     # [3H, I] rows r,z,n
+        w_hh = getattr(gru, "weight_hh_l0" + sfx).detach().float()
+        b_ih = getattr(gru, "bias_ih_l0" + sfx).detach().float()
+        b_hh = getattr(gru, "bias_hh_l0" + sfx).detach().float()
+        mats = [w_ih[0:H], w_hh[0:H], w_ih[H:2 * H], w_hh[H:2 * H], w_ih[2 * H:], w_hh[2 * H:]]   # each [u, k]
+        # [6, u=(w,j), k=(g,s)] -> [w, g, j, 6, s] -> lanes = g*16 + j
+        t = torch.stack(mats).view(6, 4, 16, 4, 16).permute(1, 3, 2, 0, 4).reshape(4, 64, 96)
+        packs.append(t)
+        biases.append(torch.stack([b_ih[0:H] + b_hh[0:H], b_ih[H:2 * H] + b_hh[H:2 * H], b_ih[2 * H:], b_hh[2 * H:]]))
+    return torch.stack(packs).contiguous(), torch.stack(biases).contiguous()
+
+
+def gru_bidir(x_nlc, wpack, bpack):
+    """x [n, L, 64] fp32 (contiguous) -> [2, n, L, 64] per-direction hidden states (HIP kernel)."""
+    assert x_nlc.is_cuda and x_nlc.dtype == torch.float32 and x_nlc.is_contiguous() and x_nlc.shape[2] == 64
+    n, L, _ = x_nlc.shape
+    out = torch.empty((2, n, L, 64), dtype=torch.float32, device=x_nlc.device)
+    rc = _lib.lib().svdd_gru_bidir_f32(x_nlc.data_ptr(), wpack.data_ptr(), bpack.data_ptr(), out.data_ptr(), n, L,
+                                       ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    _lib.check(rc, "svdd_gru_bidir_f32")
+    return out
+
+
+class FusedValueNet(nn.Module):
+    """`head(embedding(onehot))` of a ConvGRUTrunk + ConvHead pair in one module:
+    forward(onehot fp32 [n, L, 4]) -> scores [n, n_tasks, 1]   (the reference call at diffusion_gosai.py:1208-1209).
+    Also accepts the reward-model layout [n, 4, L] (Enformer.py:1422-1423)."""
+
+    def __init__(self, embedding: ConvGRUTrunk, head: ConvHead):
+        super().__init__()
+        blocks = embedding.conv_tower.blocks
+        self.in_channels = embedding.in_channels
+        self.stem_w = nn.Parameter(_cl(blocks[0].conv.weight), requires_grad=False)
+        self.stem_b = nn.Parameter(blocks[0].conv.bias.detach().clone(), requires_grad=False)
+        self.stem_pad = blocks[0].conv.kernel_size[0] // 2
+        ws, bs, self.pads, self.residual = [], [], [], []
+        for blk in blocks[1:]:
+            w, b = blk.conv.weight.detach(), blk.conv.bias.detach()
+            bn = blk.norm.layer
+            if isinstance(bn, nn.BatchNorm1d):                       # fold eval-mode BN into the conv
+                s = bn.weight.detach() / torch.sqrt(bn.running_var + bn.eps)
+                w = w * s[:, None, None]
+                b = (b - bn.running_mean) * s + bn.bias.detach()
+            assert not blk.residual or isinstance(blk.channel_transform.layer, nn.Identity)
+            ws.append(nn.Parameter(_cl(w), requires_grad=False))
+            bs.append(nn.Parameter(b.clone(), requires_grad=False))
+            self.pads.append(blk.conv.kernel_size[0] // 2 * blk.conv.dilation[0])
+            self.residual.append(blk.residual)
+        self.ws, self.bs = nn.ParameterList(ws), nn.ParameterList(bs)
+        gt = embedding.gru_tower
+        wpack, bpack = pack_gru(gt.gru)
+        self.register_buffer("wpack", wpack)
+        self.register_buffer("bpack", bpack)
+        self.ffn = gt.ffn                                           # LayerNorm/Linear on the last dim: already channels-last
+        hw = head.channel_transform.conv.layer
+        self.head_w = nn.Parameter(hw.weight.detach()[:, :, 0].clone(), requires_grad=False)   # [n_tasks, C]
+        self.head_b = nn.Parameter(hw.bias.detach().clone(), requires_grad=False)
+
+    def forward(self, x):
+        if x.shape[1] == self.in_channels and x.shape[2] != self.in_channels:
+            x = x.transpose(1, 2)                                   # reward-model layout [n,4,L] -> [n,L,4]
+        n, L, C = x.shape
+        f = x.contiguous().view(n, 1, L, C).permute(0, 3, 1, 2)     # [n,4,1,L] view with channels_last strides
+        f = F.relu(F.conv2d(f, self.stem_w, self.stem_b, padding=(0, self.stem_pad)))
+        for w, b, pad, res in zip(self.ws, self.bs, self.pads, self.residual):
+            y = F.conv2d(f, w, b, padding=(0, pad))
+            f = F.relu(y + f) if res else F.relu(y)
+        seq = f.permute(0, 2, 3, 1).reshape(n, L, f.shape[1])       # [n,L,64] — a view, memory is already NLC
+        h = gru_bidir(seq.contiguous(), self.wpack, self.bpack)
+        y = self.ffn(h[0] + h[1])                                   # [n,L,64]
+        # ConvHead: 1x1 conv to n_tasks then mean over length (mean and the linear map commute)
+        return (F.linear(y, self.head_w, self.head_b)).mean(dim=1)[:, :, None]
+
+
+class FusedBackbone(nn.Module):
+    """CNNModel.forward for the sampler's zero-sigma case, channels-last. forward(tokens [B,L]) ->
+    raw logits fp32 [B, L, 5] (contiguous, layout BLV)."""
+
+    def __init__(self, cnn: CNNModel):
+        super().__init__()
+        self.H = cnn.args.hidden_dim
+        self.first_w = nn.Parameter(_cl(cnn.linear.weight), requires_grad=False)
+        self.first_b = nn.Parameter(cnn.linear.bias.detach().clone(), requires_grad=False)
+        self.ws = nn.ParameterList([nn.Parameter(_cl(c.weight), requires_grad=False) for c in cnn.convs])
+        self.bs = nn.ParameterList([nn.Parameter(c.bias.detach().clone(), requires_grad=False) for c in cnn.convs])
+        self.dil = [c.dilation[0] for c in cnn.convs]
+        self.norms = cnn.norms
+        with torch.no_grad():                                       # time biases at sigma == 0 (diffusion_gosai.py:334-335)
+            dev = cnn.linear.weight.device
+            tb = cnn._time_biases(torch.zeros(1, device=dev))
+        self.tb = nn.ParameterList([nn.Parameter(t.reshape(1, 1, 1, self.H).clone(), requires_grad=False) for t in tb])
+        self.f1_w = nn.Parameter(_cl(cnn.final_conv[0].weight), requires_grad=False)
+        self.f1_b = nn.Parameter(cnn.final_conv[0].bias.detach().clone(), requires_grad=False)
+        self.f2_w = nn.Parameter(_cl(cnn.final_conv[2].weight), requires_grad=False)
+        self.f2_b = nn.Parameter(cnn.final_conv[2].bias.detach().clone(), requires_grad=False)
+        self.register_buffer("eye", torch.eye(cnn.alphabet_size), persistent=False)
+
+    def forward(self, seq, sigma=None):
+        B, L = seq.shape
+        onehot = self.eye[seq.long()]                               # [B,L,5]
+        f = onehot.view(B, 1, L, onehot.shape[2]).permute(0, 3, 1, 2)
+        f = F.relu(F.conv2d(f, self.first_w, self.first_b, padding=(0, 4)))
+        H = self.H
+        for i, (w, b) in enumerate(zip(self.ws, self.bs)):
+            hn = f.permute(0, 2, 3, 1)                              # [B,1,L,H] contiguous view
+            hn = F.layer_norm(hn + self.tb[i], (H,), self.norms[i].weight, self.norms[i].bias)
+            d = self.dil[i]
+            f = F.relu(F.conv2d(hn.permute(0, 3, 1, 2), w, b, padding=(0, 4 * d), dilation=(1, d))) + f
+        f = F.conv2d(F.relu(F.conv2d(f, self.f1_w, self.f1_b)), self.f2_w, self.f2_b)   # [B,5,1,L] channels_last
+        return f.permute(0, 2, 3, 1).reshape(B, L, f.shape[1])      # [B,L,5] contiguous view

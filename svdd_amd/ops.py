@@ -30,11 +30,13 @@ class Rng:
     seed: int = 0
     row_offset: int = 0
     step: int = 0
+    uniforms_layout: Optional[int] = None      # None: same layout as the logits passed to propose()
 
-    def c_struct(self):
+    def c_struct(self, logits_layout=LAYOUT_BLV):
         if self.uniforms is not None:
-            return SvddRng(RNG_REPLAY, 0, self.uniforms.data_ptr(), 0, 0)
-        return SvddRng(RNG_PHILOX, self.step, None, self.seed & 0xFFFFFFFFFFFFFFFF, self.row_offset)
+            ul = logits_layout if self.uniforms_layout is None else self.uniforms_layout
+            return SvddRng(RNG_REPLAY, 0, self.uniforms.data_ptr(), 0, 0, ul, 0)
+        return SvddRng(RNG_PHILOX, self.step, None, self.seed & 0xFFFFFFFFFFFFFFFF, self.row_offset, 0, 0)
 
 
 def _stream():
@@ -81,7 +83,7 @@ def propose(logits, x, dm, mcs, M, rng, want_q=False, cand=None, onehot=None):
     if rng.uniforms is not None:
         u = _need(rng.uniforms, torch.float32, "uniforms")
         assert u.is_contiguous() and u.numel() == M * B * L * 5, (u.shape, M, B, L)
-    rs = rng.c_struct()
+    rs = rng.c_struct(layout)
     rc = _lib.lib().svdd_propose(logits.data_ptr(), x.data_ptr(), float(dm), float(mcs), B, L, M, layout,
                                  ctypes.byref(rs), cand.data_ptr(), onehot.data_ptr(),
                                  q.data_ptr() if q is not None else None, _stream())

@@ -1,0 +1,96 @@
+"""-m gpu: the MI355X formulations of the nets (svdd_amd/fused.py: channels-last convs, folded BN,
+hand-written MFMA GRU kernel) compute the same functions as the plain PyTorch modules.
+fp32 vs fp32: tolerance 2e-5 absolute on O(1) activations (re-association + hardware exp/rcp in the
+GRU gates); the north-star tolerance for soft values is 1e-4."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def nets():
+    from svdd_amd import synthetic
+    return synthetic.build("dna", DEV)
+
+
+@pytest.mark.parametrize("n,L", [(16, 200), (37, 50), (2560, 200), (1, 7)])
+def test_gru_kernel_vs_torch(n, L):
+    from svdd_amd.fused import gru_bidir, pack_gru
+    torch.manual_seed(n)
+    gru = torch.nn.GRU(64, 64, bidirectional=True, batch_first=True).to(DEV).eval()
+    with torch.no_grad():
+        for p in gru.parameters():
+            p.mul_(2.0)                                  # larger gates: exercise saturation
+    x = torch.randn(n, L, 64, device=DEV)
+    wpack, bpack = pack_gru(gru)
+    with torch.no_grad():
+        ref = gru(x)[0]
+    out = gru_bidir(x, wpack.to(DEV), bpack.to(DEV))
+    torch.cuda.synchronize()
+    assert (out[0] - ref[:, :, :64]).abs().max().item() <= 2e-5
+    assert (out[1] - ref[:, :, 64:]).abs().max().item() <= 2e-5
+    # the recurrence itself, independently of MIOpen: fp64 on the CPU
+    g64 = torch.nn.GRU(64, 64, bidirectional=True, batch_first=True).double()
+    g64.load_state_dict({k: v.double().cpu() for k, v in gru.state_dict().items()})
+    nn_ = min(n, 8)
+    with torch.no_grad():
+        ref64 = g64(x[:nn_].double().cpu())[0]
+    assert (out[0, :nn_].double().cpu() - ref64[:, :, :64]).abs().max().item() <= 2e-5
+    assert (out[1, :nn_].double().cpu() - ref64[:, :, 64:]).abs().max().item() <= 2e-5
+
+
+def test_fused_value_net_vs_plain(nets):
+    from svdd_amd.fused import FusedValueNet
+    model, emb, head, reward = nets
+    # non-trivial BatchNorm statistics
+    g = torch.Generator().manual_seed(3)
+    for m in emb.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.running_mean.copy_(torch.randn(m.num_features, generator=g).to(DEV) * 0.1)
+            m.running_var.copy_((torch.rand(m.num_features, generator=g) + 0.5).to(DEV))
+    fv = FusedValueNet(emb, head).to(DEV).eval()
+    tok = torch.randint(0, 5, (96, 200), device=DEV)
+    oh = (torch.nn.functional.one_hot(tok.clamp(max=3), 4) * (tok != 4)[..., None]).float()
+    with torch.no_grad():
+        ref = head(emb(oh))
+        fv(oh)                                          # warm-up (MIOpen solver search on first use)
+        out = fv(oh)
+        out2 = fv(oh)
+        out_t = fv(oh.transpose(1, 2).contiguous())     # reward-model layout
+    assert out.shape == ref.shape == (96, 1, 1)
+    assert (out - ref).abs().max().item() <= 2e-5
+    print("repeat-call max diff", (out - out2).abs().max().item(), "layout max diff", (out - out_t).abs().max().item())
+    # MIOpen's split-K convolutions use atomics at small batch: call-to-call noise at the 1e-8 level
+    assert (out - out2).abs().max().item() <= 1e-6
+    assert (out - out_t).abs().max().item() <= 2e-6
+    model.clear_fused()
+
+
+def test_fused_backbone_vs_plain(nets):
+    from svdd_amd.fused import FusedBackbone
+    model = nets[0]
+    fb = FusedBackbone(model.backbone).to(DEV).eval()
+    x = torch.randint(0, 5, (32, 200), device=DEV).to(torch.uint8)
+    with torch.no_grad():
+        ref = model.backbone(x, None, zero_sigma=True)
+        out = fb(x)
+    assert out.shape == (32, 200, 5) and out.is_contiguous()
+    assert (out - ref).abs().max().item() <= 2e-5
+
+
+def test_engine_uses_fused_nets_and_rows_are_batch_invariant(nets):
+    """Row independence of the fused value net: scoring rows in one [B*M] call or in chunks gives
+    the same scores bit-for-bit (needed for the batched-vs-per-candidate deviation to be exact)."""
+    model, emb, head, _ = nets
+    model.fuse_nets = True
+    fn = model.value_callable(emb, head)
+    assert isinstance(fn, torch.nn.Module)
+    oh = torch.zeros(64, 200, 4, device=DEV)
+    oh.scatter_(2, torch.randint(0, 4, (64, 200, 1), device=DEV), 1.0)
+    with torch.no_grad():
+        full = fn(oh)
+        parts = torch.cat([fn(oh[:16]), fn(oh[16:48]), fn(oh[48:])])
+    assert (full - parts).abs().max().item() <= 1e-6

@@ -36,7 +36,7 @@ def test_argument_validation_without_gpu():
     """Entry points reject bad arguments before touching the device."""
     from svdd_amd import _lib
     L = _lib.lib()
-    rs = _lib.SvddRng(_lib.RNG_PHILOX, 0, None, 0, 0)
+    rs = _lib.SvddRng(_lib.RNG_PHILOX, 0, None, 0, 0, 0, 0)
     assert L.svdd_propose(None, None, 0.0, 0.0, 1, 1, 1, 0, ctypes.byref(rs), None, None, None, None) == _lib.E_ARG
     assert L.svdd_select(None, None, 1, 1, 1, 0, None, None, None, None, None) == _lib.E_ARG
     assert L.svdd_finalize(None, None, 1, 1, 0, None, None, None) == _lib.E_ARG
