@@ -35,11 +35,15 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec
 FP32_PEAK_TFLOPS = 157.3
 
 
-def cpu_baseline(B, L, M, S, sample_steps, seed=44):
+def cpu_baseline(B, L, M, S, sample_steps, seed=44, threads=16):
     """Oracle (CPU port of the reference path: M value-net calls of batch B per step, like
-    diffusion_gosai.py:1207-1209) on `sample_steps` diffusion steps of the same workload."""
+    diffusion_gosai.py:1207-1209) on `sample_steps` diffusion steps of the same workload.
+    16 torch threads: the fastest setting on the GPU box's host (2 x EPYC 9575F; 8/16/32/64/128 threads
+    measured 0.63/0.36/0.53/0.73/1.68 s per backbone forward, tools/exp_cpu_threads.py)."""
     from oracle import svdd_oracle as orc
     from svdd_amd import synthetic
+    threads = max(1, min(threads, os.cpu_count() or 1))
+    torch.set_num_threads(threads)
     model, emb, head, _ = synthetic.build("dna" if L == 200 else "rna", "cpu", seed=seed)
     sched = model._schedule(S, 1e-5)[0]
     bb = lambda x: model.backbone(x, torch.zeros(x.shape[0]))                               # noqa: E731
@@ -68,7 +72,7 @@ def cpu_baseline(B, L, M, S, sample_steps, seed=44):
     t_final = time.perf_counter() - t0
     per_decode = float(np.mean(t_steps)) * S + t_final
     return {
-        "value": round(B / per_decode, 4), "unit": "sequences/s", "cores": torch.get_num_threads(),
+        "value": round(B / per_decode, 4), "unit": "sequences/s", "cores": threads,
         "kind": "port",
         "sample": f"{sample_steps} of {S} diffusion steps at full batch (B={B}, L={L}, M={M}) + the noise-removal "
                   f"forward, extrapolated to one decode; {sum(t_steps) + t_final:.1f} s of CPU work",
@@ -84,7 +88,7 @@ def main():
     ap.add_argument("--length", type=int, default=200)
     ap.add_argument("--sample-M", type=int, default=10)
     ap.add_argument("--diffusion-steps", type=int, default=128)
-    ap.add_argument("--cpu-steps", type=int, default=4, help="diffusion steps timed for cpu_baseline (0 = skip)")
+    ap.add_argument("--cpu-steps", type=int, default=8, help="diffusion steps timed for cpu_baseline (0 = skip)")
     ap.add_argument("--rng", default="philox", choices=["philox", "replay"])
     args = ap.parse_args()
 
@@ -132,6 +136,10 @@ def main():
     if rank == 0:
         k1_ms = k1_total_ms / max(k1_launches, 1)
         k1_bytes = B * L * (21 + 17 * M)
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_k1_pmc.json")
+        if os.path.exists(pmc) and (B, L, M) == (256, 200, 10):
+            traffic = json.load(open(pmc))["traffic_bytes_per_launch"]     # separate --pmc passes, see the file
         achieved = k1_bytes / (k1_ms * 1e-3) / 1e9
         seqs = B * world * args.steps
         flops_seq = (CNNModel.flops_per_position() * L * (S + 1) + ConvGRUTrunk.flops_per_position() * L * S * M)
@@ -146,7 +154,7 @@ def main():
                        "global_batch": B * world, "rng": args.rng, "sharding": f"rows x{world}, 1 all-gather"},
             "roofline": {"bound": "hbm", "kernel": "propose_kernel (K1)", "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "traffic": None, "bytes_per_launch": k1_bytes, "avg_launch_us": round(k1_ms * 1e3, 3),
+                         "traffic": traffic, "bytes_per_launch": k1_bytes, "avg_launch_us": round(k1_ms * 1e3, 3),
                          "launches": k1_launches,
                          "select_kernel_avg_launch_us": round(k2_total_ms / max(k2_launches, 1) * 1e3, 3)},
             "e2e_fp32_frac": round(flops_seq * seqs / elapsed / 1e12 / (FP32_PEAK_TFLOPS * world), 5),

@@ -166,6 +166,16 @@ int svdd_tds_resample(const float* reward_num, const float* reward_den, float al
 int svdd_gru_bidir_f32(const float* x, const float* wpack, const float* bpack, float* out, int n, int L,
                        void* stream);
 
+/* svdd_epilogue_ln_f32 — fused convolution epilogue (+ next layer's LayerNorm) on channels-last rows [rows, C],
+ *   C in {64,128,256}: t = y + bias ; f_out = relu(t) + f_prev (act 0) | relu(t + f_prev) (act 1) | t + f_prev (act 2);
+ *   hn = LayerNorm(f_out + tb) * gamma + beta (eps 1e-5).  bias, f_prev, tb may be NULL; hn NULL skips the norm;
+ *   f_out NULL skips storing the pre-norm sum.
+ *   Replaces the bias/ReLU/residual/LayerNorm tensor ops between two convolutions of the dilated-CNN backbone
+ *   (reference models/dnaconv.py:188-197) and of the value net's conv tower (Enformer.py:2269-2285). */
+int svdd_epilogue_ln_f32(const float* y, const float* bias, const float* f_prev, const float* tb,
+                         const float* gamma, const float* beta, float* f_out, float* hn, int64_t rows,
+                         int channels, int act, void* stream);
+
 /* Process-wide options (host). SVDD_OPT_FORCE_EXACT != 0 makes svdd_propose evaluate every draw in the
  * exact (fp64, correctly rounded) arithmetic instead of the filtered fast path — same results, used
  * to A/B the filter. */

@@ -121,6 +121,67 @@ __global__ __launch_bounds__(256) void gru_bidir_kernel(const float* __restrict_
   }
 }
 
+// ------------------------------------------------------------------ fused conv epilogue + LayerNorm ----
+// Channels-last rows [R, C]. One pass replaces the bias-add, ReLU, residual-add, time-bias-add and
+// LayerNorm kernels PyTorch launches between two convolutions of the dilated-CNN backbone
+// (reference models/dnaconv.py:188-197) and of the value net's conv tower (Enformer.py:2269-2285):
+//     t     = y + bias
+//     f_out = act 0: relu(t) + f_prev | act 1: relu(t + f_prev) | act 2: t + f_prev      (f_prev optional)
+//     hn    = LayerNorm(f_out + tb) * gamma + beta                    (optional; eps = 1e-5, biased variance)
+// One wave per row, lane owns VPL = C/64 consecutive channels (8-16 B vector loads), mean/variance by
+// xor-shuffle wave reduction (two-pass, like ATen's RowwiseMoments). HBM-bound: 2 reads + 1-2 writes.
+struct EpiArgs {
+  const float* y; const float* bias; const float* f_prev; const float* tb; const float* gamma; const float* beta;
+  float* f_out; float* hn; int64_t R; int act;
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+template <int VPL>
+__global__ __launch_bounds__(256) void epilogue_ln_kernel(EpiArgs a) {
+  constexpr int C = 64 * VPL;
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  const int c0 = lane * VPL;
+  float bias[VPL], tb[VPL], gm[VPL], bt[VPL];
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    bias[i] = a.bias ? a.bias[c0 + i] : 0.0f;
+    tb[i] = (a.hn && a.tb) ? a.tb[c0 + i] : 0.0f;
+    gm[i] = a.hn ? a.gamma[c0 + i] : 1.0f;
+    bt[i] = a.hn ? a.beta[c0 + i] : 0.0f;
+  }
+  for (int64_t r = wave; r < a.R; r += nwaves) {
+    const int64_t base = r * C + c0;
+    float v[VPL], p[VPL];
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) { v[i] = a.y[base + i]; p[i] = a.f_prev ? a.f_prev[base + i] : 0.0f; }
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const float t = v[i] + bias[i];
+      v[i] = a.act == 0 ? fmaxf(t, 0.0f) + p[i] : a.act == 1 ? fmaxf(t + p[i], 0.0f) : t + p[i];
+      if (a.f_out) a.f_out[base + i] = v[i];
+      v[i] += tb[i];
+      s += v[i];
+    }
+    if (a.hn) {
+      const float mean = wave_sum(s) * (1.0f / C);
+      float q = 0.0f;
+#pragma unroll
+      for (int i = 0; i < VPL; ++i) { const float d = v[i] - mean; q += d * d; }
+      const float rstd = rsqrtf(wave_sum(q) * (1.0f / C) + 1e-5f);
+#pragma unroll
+      for (int i = 0; i < VPL; ++i) a.hn[base + i] = (v[i] - mean) * rstd * gm[i] + bt[i];
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int svdd_gru_bidir_f32(const float* x, const float* wpack, const float* bpack, float* out, int n, int L,
@@ -128,5 +189,19 @@ extern "C" int svdd_gru_bidir_f32(const float* x, const float* wpack, const floa
   if (!x || !wpack || !bpack || !out || n <= 0 || L <= 0) return SVDD_E_ARG;
   hipLaunchKernelGGL(gru_bidir_kernel, dim3((unsigned)((n + TS - 1) / TS), 2), dim3(256), 0, (hipStream_t)stream,
                      x, wpack, bpack, out, n, L);
+  return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
+}
+
+extern "C" int svdd_epilogue_ln_f32(const float* y, const float* bias, const float* f_prev, const float* tb,
+                                    const float* gamma, const float* beta, float* f_out, float* hn, int64_t rows,
+                                    int channels, int act, void* stream) {
+  if (!y || (!f_out && !hn) || rows <= 0 || (hn && (!gamma || !beta)) || act < 0 || act > 2) return SVDD_E_ARG;
+  EpiArgs a{y, bias, f_prev, tb, gamma, beta, f_out, hn, rows, act};
+  const int64_t nblocks = (rows + 3) / 4;
+  const unsigned grid = (unsigned)(nblocks < 4096 ? nblocks : 4096);
+  if (channels == 64) hipLaunchKernelGGL(epilogue_ln_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  else if (channels == 128) hipLaunchKernelGGL(epilogue_ln_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  else if (channels == 256) hipLaunchKernelGGL(epilogue_ln_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  else return SVDD_E_ARG;
   return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
 }

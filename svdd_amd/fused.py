@@ -65,6 +65,31 @@ def gru_bidir(x_nlc, wpack, bpack):
     return out
 
 
+def _ptr(t):
+    return t.data_ptr() if t is not None else None
+
+
+ACT_RELU_THEN_ADD, ACT_ADD_THEN_RELU, ACT_NONE = 0, 1, 2
+
+
+def epilogue_ln(y, bias=None, f_prev=None, tb=None, gamma=None, beta=None, act=ACT_RELU_THEN_ADD, want_norm=True,
+                want_sum=True):
+    """Fused conv epilogue on channels-last rows (HIP kernel svdd_epilogue_ln_f32):
+    f = relu(y + bias) + f_prev | relu(y + bias + f_prev) | y + bias + f_prev ; hn = LayerNorm(f + tb)*gamma + beta.
+    y: any tensor whose memory is [rows, C] contiguous (e.g. a channels_last conv2d output). -> (f | None, hn | None),
+    both with y's shape/strides."""
+    C = bias.numel() if bias is not None else gamma.numel()
+    rows = y.numel() // C
+    f = torch.empty_like(y) if want_sum else None
+    hn = torch.empty_like(y) if want_norm else None
+    assert y.dtype == torch.float32 and (f if f is not None else hn).stride() == y.stride()
+    rc = _lib.lib().svdd_epilogue_ln_f32(y.data_ptr(), _ptr(bias), _ptr(f_prev), _ptr(tb), _ptr(gamma), _ptr(beta),
+                                         _ptr(f), _ptr(hn), rows, C, int(act),
+                                         ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    _lib.check(rc, "svdd_epilogue_ln_f32")
+    return f, hn
+
+
 class FusedValueNet(nn.Module):
     """`head(embedding(onehot))` of a ConvGRUTrunk + ConvHead pair in one module:
     forward(onehot fp32 [n, L, 4]) -> scores [n, n_tasks, 1]   (the reference call at diffusion_gosai.py:1208-1209).
@@ -95,25 +120,35 @@ class FusedValueNet(nn.Module):
         wpack, bpack = pack_gru(gt.gru)
         self.register_buffer("wpack", wpack)
         self.register_buffer("bpack", bpack)
-        self.ffn = gt.ffn                                           # LayerNorm/Linear on the last dim: already channels-last
+        # FFN (LayerNorm -> Linear 64->128 -> ReLU -> Linear 128->64, Enformer.py:2010-2047) and the head
+        # (1x1 conv 64->n_tasks + mean over length, :2131-2173). The last two maps are linear with nothing in
+        # between, so they collapse into one 128->n_tasks map; the mean over length commutes with it.
+        d1, d2 = gt.ffn.dense1, gt.ffn.dense2
+        self.ln_w = nn.Parameter(d1.norm.layer.weight.detach().clone(), requires_grad=False)
+        self.ln_b = nn.Parameter(d1.norm.layer.bias.detach().clone(), requires_grad=False)
+        self.w1 = nn.Parameter(d1.linear.weight.detach().clone(), requires_grad=False)          # [128, 64]
+        self.b1 = nn.Parameter(d1.linear.bias.detach().clone(), requires_grad=False)
         hw = head.channel_transform.conv.layer
-        self.head_w = nn.Parameter(hw.weight.detach()[:, :, 0].clone(), requires_grad=False)   # [n_tasks, C]
-        self.head_b = nn.Parameter(hw.bias.detach().clone(), requires_grad=False)
+        wh, bh = hw.weight.detach()[:, :, 0].double(), hw.bias.detach().double()                  # [T,64], [T]
+        w2, b2 = d2.linear.weight.detach().double(), d2.linear.bias.detach().double()            # [64,128], [64]
+        self.w_eff = nn.Parameter((wh @ w2).float().t().contiguous(), requires_grad=False)       # [128, T]
+        self.b_eff = nn.Parameter((wh @ b2 + bh).float(), requires_grad=False)                   # [T]
 
     def forward(self, x):
         if x.shape[1] == self.in_channels and x.shape[2] != self.in_channels:
             x = x.transpose(1, 2)                                   # reward-model layout [n,4,L] -> [n,L,4]
         n, L, C = x.shape
         f = x.contiguous().view(n, 1, L, C).permute(0, 3, 1, 2)     # [n,4,1,L] view with channels_last strides
-        f = F.relu(F.conv2d(f, self.stem_w, self.stem_b, padding=(0, self.stem_pad)))
+        f, _ = epilogue_ln(F.conv2d(f, self.stem_w, None, padding=(0, self.stem_pad)), self.stem_b, want_norm=False)
         for w, b, pad, res in zip(self.ws, self.bs, self.pads, self.residual):
-            y = F.conv2d(f, w, b, padding=(0, pad))
-            f = F.relu(y + f) if res else F.relu(y)
+            y = F.conv2d(f, w, None, padding=(0, pad))
+            f, _ = epilogue_ln(y, b, f if res else None, act=ACT_ADD_THEN_RELU, want_norm=False)   # relu(conv + b + f)
         seq = f.permute(0, 2, 3, 1).reshape(n, L, f.shape[1])       # [n,L,64] — a view, memory is already NLC
         h = gru_bidir(seq.contiguous(), self.wpack, self.bpack)
-        y = self.ffn(h[0] + h[1])                                   # [n,L,64]
-        # ConvHead: 1x1 conv to n_tasks then mean over length (mean and the linear map commute)
-        return (F.linear(y, self.head_w, self.head_b)).mean(dim=1)[:, :, None]
+        # LayerNorm(h_fwd + h_bwd) in one pass (the direction sum of Enformer.py:1617 + dense1.norm)
+        _, hn = epilogue_ln(h[0], None, h[1], None, self.ln_w, self.ln_b, act=ACT_NONE, want_sum=False)
+        z = F.relu(F.linear(hn, self.w1, self.b1))                  # [n,L,128]
+        return ((z @ self.w_eff).mean(dim=1) + self.b_eff)[:, :, None]
 
 
 class FusedBackbone(nn.Module):
@@ -143,12 +178,17 @@ class FusedBackbone(nn.Module):
         B, L = seq.shape
         onehot = self.eye[seq.long()]                               # [B,L,5]
         f = onehot.view(B, 1, L, onehot.shape[2]).permute(0, 3, 1, 2)
-        f = F.relu(F.conv2d(f, self.first_w, self.first_b, padding=(0, 4)))
-        H = self.H
+        n = len(self.ws)
+        # f_0 = relu(conv(onehot) + b) ; hn_0 = LN(f_0 + tb_0)                          (dnaconv.py:184,188-194)
+        f, hn = epilogue_ln(F.conv2d(f, self.first_w, None, padding=(0, 4)), self.first_b, None,
+                            self.tb[0], self.norms[0].weight, self.norms[0].bias)
         for i, (w, b) in enumerate(zip(self.ws, self.bs)):
-            hn = f.permute(0, 2, 3, 1)                              # [B,1,L,H] contiguous view
-            hn = F.layer_norm(hn + self.tb[i], (H,), self.norms[i].weight, self.norms[i].bias)
             d = self.dil[i]
-            f = F.relu(F.conv2d(hn.permute(0, 3, 1, 2), w, b, padding=(0, 4 * d), dilation=(1, d))) + f
+            y = F.conv2d(hn, w, None, padding=(0, 4 * d), dilation=(1, d))
+            last = i + 1 == n
+            # f_{i+1} = relu(y + b) + f_i ; hn_{i+1} = LN(f_{i+1} + tb_{i+1})           (:195-197, then :188-194)
+            f, hn = epilogue_ln(y, b, f, None if last else self.tb[i + 1],
+                                None if last else self.norms[i + 1].weight, None if last else self.norms[i + 1].bias,
+                                want_norm=not last)
         f = F.conv2d(F.relu(F.conv2d(f, self.f1_w, self.f1_b)), self.f2_w, self.f2_b)   # [B,5,1,L] channels_last
         return f.permute(0, 2, 3, 1).reshape(B, L, f.shape[1])      # [B,L,5] contiguous view
