@@ -97,6 +97,14 @@ int svdd_propose(const float* logits, const uint8_t* x, float dm, float mcs,
                  uint8_t* cand, float* onehot, float* q_xs, void* stream);
 
 /*
+ * svdd_sample_categorical — M x (_sample_categorical(q) merged with copy_flag) + one-hot, for a caller-built
+ * q (e.g. the DPS baseline's guided q_xs * exp(guidance), diffusion_gosai.py:1311-1318; :30-34).
+ *  q [B,L,5] fp32 in `layout`, all entries >= 0; other arguments as svdd_propose.
+ */
+int svdd_sample_categorical(const float* q, const uint8_t* x, int B, int L, int M, int layout,
+                            const svdd_rng_t* rng, uint8_t* cand, float* onehot, void* stream);
+
+/*
  * svdd_select — replaces torch.stack(scores,1) -> softmax(dim=1) -> argmax(dim=1) ->
  * per-row Python gather + stack                     diffusion_gosai.py:1219-1227 (= :1451-1459)
  *

@@ -109,6 +109,22 @@ def sample_categorical(q, u):
     return tok
 
 
+def sample_categorical_merged(q, x, uniforms, layout=BLV):
+    """M x (copy_flag * x + (1 - copy_flag) * _sample_categorical(q)) for a caller-built q
+    (DPS, diffusion_gosai.py:1316-1319). q: [B,L,5] (BLV) or [B,5,L] (BVL); uniforms [M, *q.shape]. -> cand u8 [B,M,L]."""
+    q = _f32(q); x = _u8(x); uniforms = _f32(uniforms)
+    B, L = x.shape
+    _layout_of(q, x.shape, layout)
+    M = uniforms.shape[0]
+    ql = q if layout == BLV else np.ascontiguousarray(np.swapaxes(q, 1, 2))
+    out = np.empty((B, M, L), dtype=np.uint8)
+    for m in range(M):
+        ul = uniforms[m] if layout == BLV else np.ascontiguousarray(np.swapaxes(uniforms[m], 1, 2))
+        tok = sample_categorical(ql, ul)
+        out[:, m] = np.where(x != MASK, x, tok)
+    return out
+
+
 def propose(logits, x, dm, mcs, M, uniforms=None, seed=0, row_offset=0, step=0, want_q=True, layout=BLV):
     """-> (cand u8 [B,M,L], onehot f32 [B*M,L,4], q_xs f32 (same layout as logits) | None).
 

@@ -20,7 +20,7 @@ SELECT_ARGMAX, SELECT_MULTINOMIAL = 0, 1
 MAX_M = 1024
 
 EXPORTS = (
-    "svdd_abi_version", "svdd_device_info", "svdd_propose", "svdd_select", "svdd_x0hat",
+    "svdd_abi_version", "svdd_device_info", "svdd_propose", "svdd_sample_categorical", "svdd_select", "svdd_x0hat",
     "svdd_finalize", "svdd_transform_samples", "svdd_subs_logp", "svdd_tds_resample",
     "svdd_set_option", "svdd_selftest_fastmath", "svdd_profile_enable", "svdd_profile_collect",
     "svdd_gru_bidir_f32", "svdd_epilogue_ln_f32",
@@ -70,6 +70,7 @@ def lib():
         raise SvddError(f"libsvdd_hip.so ABI {L.svdd_abi_version()} != binding ABI {ABI_VERSION}; rebuild")
     vp, f32, i32 = ctypes.c_void_p, ctypes.c_float, ctypes.c_int
     L.svdd_propose.argtypes = [vp, vp, f32, f32, i32, i32, i32, i32, ctypes.POINTER(SvddRng), vp, vp, vp, vp]
+    L.svdd_sample_categorical.argtypes = [vp, vp, i32, i32, i32, i32, ctypes.POINTER(SvddRng), vp, vp, vp]
     L.svdd_select.argtypes = [vp, vp, i32, i32, i32, i32, ctypes.POINTER(SvddRng), vp, vp, vp, vp]
     L.svdd_x0hat.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp]
     L.svdd_finalize.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp]

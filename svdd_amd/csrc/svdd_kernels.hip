@@ -154,7 +154,7 @@ __device__ __forceinline__ void q_exact(const float (&z)[V], int xt, float dm, f
 // large launch runs as <= 2048 persistent blocks instead of one short-lived wave per unit (wave
 // dispatch was the bottleneck of the one-wave-per-unit version). msplit is chosen by the host: 1 when
 // there are enough tiles to fill the chip, up to 4 for small batches where latency dominates.
-template <bool REPLAY>
+template <bool REPLAY, bool QGIVEN>
 __global__ __launch_bounds__(256) void propose_kernel(ProposeArgs a) {
   const int lane = threadIdx.x & (WAVE - 1);
   const uint32_t N = (uint32_t)a.B * (uint32_t)a.L;            // host guarantees B*L*5*M < 2^31-ish for 32-bit tiles
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void propose_kernel(ProposeArgs a) {
     for (int v = 0; v < V; ++v) z[v] = a.logits[at(a.layout, b, l, v, a.L)];
     const bool masked = xt == MASK;
 
-    if (a.q_xs && s0 == 0) {                  // per-step API only: q_xs is returned to the caller (:1228)
+    if (!QGIVEN && a.q_xs && s0 == 0) {       // per-step API only: q_xs is returned to the caller (:1228)
       float q[V];
       q_exact(z, xt, a.dm, a.mcs, q);
 #pragma unroll
@@ -189,7 +189,12 @@ __global__ __launch_bounds__(256) void propose_kernel(ProposeArgs a) {
     float qf[V];
     float margin = 0.0f;                      // a draw is decided when second < best * margin
     bool fast_ok = false;
-    if (masked) {
+    if (QGIVEN) {                             // svdd_sample_categorical: `logits` already holds q (e.g. DPS-guided)
+      fast_ok = !a.force_exact;
+#pragma unroll
+      for (int v = 0; v < V; ++v) { qf[v] = z[v]; fast_ok = fast_ok && (z[v] >= 0.0f) && (z[v] < 1e30f); }
+      margin = 1.0f - 7.62939453125e-06f;     // 2^-17: only g~, rcp and the product carry error
+    } else if (masked) {
       const float mx = fmaxf(fmaxf(z[0], z[1]), fmaxf(z[2], z[3]));
       fast_ok = !a.force_exact && (fabsf(mx) < 60.0f) && (fabsf(z[MASK]) < 1e5f);   // also false on NaN
       if (fast_ok) {
@@ -233,9 +238,13 @@ __global__ __launch_bounds__(256) void propose_kernel(ProposeArgs a) {
           c = bi;
         }
         if (!decided) {                        // rare (~1e-6 of draws): exact arithmetic for this lane
-          float q[V];
-          q_exact(z, xt, a.dm, a.mcs, q);
-          c = sample_categorical_1(q, u);
+          if (QGIVEN) {
+            c = sample_categorical_1(z, u);
+          } else {
+            float q[V];
+            q_exact(z, xt, a.dm, a.mcs, q);
+            c = sample_categorical_1(q, u);
+          }
         }
       }
       const uint64_t o = obase + (uint64_t)m * (uint64_t)a.L;
@@ -653,8 +662,21 @@ int svdd_device_info(char* arch, int arch_len, int* num_cu) {
   return SVDD_OK;
 }
 
+static int launch_propose(bool q_given, const float* logits, const uint8_t* x, float dm, float mcs, int B, int L, int M,
+                          int layout, const svdd_rng_t* rng, uint8_t* cand, float* onehot, float* q_xs, void* stream);
+
 int svdd_propose(const float* logits, const uint8_t* x, float dm, float mcs, int B, int L, int M, int layout,
                  const svdd_rng_t* rng, uint8_t* cand, float* onehot, float* q_xs, void* stream) {
+  return launch_propose(false, logits, x, dm, mcs, B, L, M, layout, rng, cand, onehot, q_xs, stream);
+}
+
+int svdd_sample_categorical(const float* q, const uint8_t* x, int B, int L, int M, int layout, const svdd_rng_t* rng,
+                            uint8_t* cand, float* onehot, void* stream) {
+  return launch_propose(true, q, x, 0.0f, 0.0f, B, L, M, layout, rng, cand, onehot, nullptr, stream);
+}
+
+static int launch_propose(bool q_given, const float* logits, const uint8_t* x, float dm, float mcs, int B, int L, int M,
+                          int layout, const svdd_rng_t* rng, uint8_t* cand, float* onehot, float* q_xs, void* stream) {
   if (!logits || !x || !rng || !cand || !onehot || B <= 0 || L <= 0 || M <= 0 || M > 65535 || bad_layout(layout))
     return SVDD_E_ARG;
   if (rng->kind == SVDD_RNG_REPLAY ? (rng->uniforms == nullptr || bad_layout(rng->uniforms_layout))
@@ -671,10 +693,10 @@ int svdd_propose(const float* logits, const uint8_t* x, float dm, float mcs, int
   const unsigned grid = (unsigned)(nblocks < 2048 ? nblocks : 2048);
   TimedLaunch* t = timed_slot(0);
   hipEvent_t e0 = t ? t->start : nullptr, e1 = t ? t->stop : nullptr;
-  if (rng->kind == SVDD_RNG_REPLAY)
-    hipExtLaunchKernelGGL(propose_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, e0, e1, 0, a);
-  else
-    hipExtLaunchKernelGGL(propose_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, e0, e1, 0, a);
+  const bool replay = rng->kind == SVDD_RNG_REPLAY;
+  auto k = q_given ? (replay ? propose_kernel<true, true> : propose_kernel<false, true>)
+                   : (replay ? propose_kernel<true, false> : propose_kernel<false, false>);
+  hipExtLaunchKernelGGL(k, dim3(grid), dim3(256), 0, (hipStream_t)stream, e0, e1, 0, a);
   return check_launch();
 }
 

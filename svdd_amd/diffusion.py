@@ -316,6 +316,54 @@ class Diffusion(nn.Module):
         x_next, _ = ops.tds_resample(reward_num, reward_den, alpha, sample, u)
         return x_next
 
+    # ------------------------------------------------------------------ DPS baseline ----
+    def compute_gradient_DPS(self, x_onehot, x, reward_model, sigma_s, copy_flag):
+        """d mean(reward(softmax(E[x0|x_t]))) / d onehot(x_t)  (reference :1321-1330). Pure autograd: the
+        differentiable backbone entry `forward2` and the reward net are run as plain torch modules."""
+        x_onehot.requires_grad_(True)
+        keep = copy_flag[:, :, None]
+        expected_x0 = keep * x_onehot + (1 - keep) * self.forward2(x_onehot, x, sigma_s)
+        probs = torch.softmax(expected_x0, dim=2)
+        with torch.backends.cudnn.flags(enabled=False):        # MIOpen's RNN backward needs train(); the native GRU does not
+            scores = reward_model(probs.transpose(1, 2)[:, 0:4, :])[:, 0]
+        scores.mean().backward()
+        return x_onehot.grad.clone()
+
+    def _dps_step(self, x_u8, mct, mcs, dm, reward_model, guidance_scale, step):
+        B, L = x_u8.shape
+        with torch.no_grad():
+            q_xs = torch.exp(ops.subs_logp(self._backbone_logits(x_u8), x_u8)) * float(dm)   # :1306-1307
+        x = x_u8.long()
+        copy_flag = (x != self.mask_index).to(x.dtype)
+        x_onehot = F.one_hot(x, num_classes=self.vocab_size).float()                          # :1308
+        sigma = torch.zeros(B, device=x.device)
+        with torch.enable_grad():
+            x_grad = self.compute_gradient_DPS(x_onehot, x, reward_model, sigma, copy_flag)   # :1310
+        with torch.no_grad():
+            guidance = guidance_scale * (x_grad - x_grad[:, :, self.mask_index][:, :, None])   # :1311
+            q_xs[:, :, self.mask_index] = float(mcs)                                          # :1312
+            q_xs = q_xs * guidance.exp()                                                      # :1314
+            cand, _ = ops.sample_categorical(q_xs, x_u8, 1, self._rng(step, 1, B, L, q_xs))   # :1316-1319
+        return cand.view(B, L)
+
+    def _ddpm_update_finetune_controlled_DPS(self, x, t, dt, reward_model, guidance_scale):
+        """One DPS (gradient-guidance) step (:1286-1319) -> x_next."""
+        self._require_gpu()
+        mct, mcs, dm = self._step_scalars(t, dt)
+        return self._dps_step(self._tokens_u8(x), mct, mcs, dm, reward_model, guidance_scale, 0).long()
+
+    def controlled_sample_DPS(self, reward_model, guidance_scale, num_steps=None, eps=1e-5, eval_sp_size=None,
+                              sample_M=10):
+        """DPS baseline decode (:980-1019). Not under no_grad in the reference either: it back-propagates."""
+        self._require_gpu()
+        B, L, S = self._batch_size(eval_sp_size), self.config.model.length, self._num_steps(num_steps)
+        sched, _, _ = self._schedule(S, eps)
+        x = torch.full((B, L), self.mask_index, dtype=torch.uint8, device=self.device)
+        for i in range(S):
+            x = self._dps_step(x, sched[i, 0], sched[i, 1], sched[i, 2], reward_model, guidance_scale, i)
+        with torch.no_grad():
+            return self._noise_removal(x)
+
     # ------------------------------------------------------------------ outer loops ----
     @torch.no_grad()
     def decode_sample(self, num_steps=None, eps=1e-5, eval_sp_size=None, cdq=False):

@@ -104,3 +104,13 @@ class BaseModel(nn.Module):
         """SMC/TDS baseline (reference Enformer.py:479-557)."""
         return self._decode(gen_batch_num, sample_M, lambda: self.ref_model.controlled_sample_TDS(
             self.reward_model, alpha, eval_sp_size=self.NUM_SAMPLES_PER_BATCH, sample_M=sample_M))
+
+    def controlled_decode_DPS(self, gen_batch_num, sample_M, guidance_scale):
+        """DPS baseline (reference Enformer.py:560-637). The guided decodes back-propagate through the backbone
+        and the reward net, so they run with autograd on; the evaluation / baseline part runs under no_grad.
+        (Scoring consumes no RNG, so decoding all guided batches first keeps the reference's RNG order.)"""
+        batches = iter([self.ref_model.controlled_sample_DPS(self.reward_model, guidance_scale,
+                                                             eval_sp_size=self.NUM_SAMPLES_PER_BATCH, sample_M=sample_M)
+                        for _ in range(gen_batch_num)])
+        with torch.no_grad():
+            return self._decode(gen_batch_num, sample_M, lambda: next(batches))

@@ -91,6 +91,21 @@ def propose(logits, x, dm, mcs, M, rng, want_q=False, cand=None, onehot=None):
     return cand, onehot, q
 
 
+def sample_categorical(q, x, M, rng):
+    """M categorical draws from a caller-built q [B,L,5] (>= 0), merged with copy_flag -> (cand, onehot)."""
+    q = _need(q, torch.float32, "q")
+    x = _need(x, torch.uint8, "x").contiguous()
+    B, L = x.shape
+    q, layout = layout_of(q)
+    cand = torch.empty((B, M, L), dtype=torch.uint8, device=x.device)
+    onehot = torch.empty((B * M, L, 4), dtype=torch.float32, device=x.device)
+    rs = rng.c_struct(layout)
+    rc = _lib.lib().svdd_sample_categorical(q.data_ptr(), x.data_ptr(), B, L, M, layout, ctypes.byref(rs),
+                                            cand.data_ptr(), onehot.data_ptr(), _stream())
+    _lib.check(rc, "svdd_sample_categorical")
+    return cand, onehot
+
+
 def select(scores, cand, mode=SELECT_ARGMAX, rng=None, want_soft=True, x_next=None):
     """-> (x_next u8 [B,L], soft f32 [B,M] | None, idx i32 [B])."""
     cand = _need(cand, torch.uint8, "cand").contiguous()

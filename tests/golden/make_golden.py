@@ -16,6 +16,7 @@ outputs are stored. Fixtures:
   g8_traj_tds.npz             controlled_sample_TDS, S=8, B=6, L=50 (np.random.seed)
   g9_rng.npz                  torch / numpy mt19937 streams
   g10_decode_sample.npz       decode_sample (un-guided), S=16, B=3, L=50
+  g11_traj_dps.npz            controlled_sample_DPS, S=6, B=3, L=50: guided q_xs, uniforms, gradients per step
   nets_tiny.npz               state_dicts of the tiny nets used above (for net-parity tests)
 """
 import os
@@ -337,6 +338,44 @@ def g10(seed=6):
     d.backbone = rec.inner
 
 
+# ----------------------------------------------------------------------------- G11
+def traj_dps(seed=12, scale=50.0):
+    """controlled_sample_DPS (diffusion_gosai.py:980-1019, 1286-1330), S=6, B=3, L=50: per step the guided
+    q_xs handed to _sample_categorical, the uniforms it drew and the result."""
+    L, S, B = 50, 6, 3
+    d = tiny_diffusion(L, S)
+    emb_m, head_m = tiny_value()
+    reward = RewardWrap(emb_m, head_m).eval()
+    rec = {"q": [], "u": [], "x": [], "grad": []}
+    orig_sc, orig_rl, orig_grad = dg._sample_categorical, torch.rand_like, d.compute_gradient_DPS
+
+    def rl(t, *a, **k):
+        r = orig_rl(t, *a, **k)
+        rec["u"].append(r.detach().clone())
+        return r
+
+    def sc(q):
+        rec["q"].append(q.detach().clone())
+        return orig_sc(q)
+
+    def grad(x_onehot, x, reward_model, sigma_s, copy_flag):
+        g = orig_grad(x_onehot, x, reward_model, sigma_s, copy_flag)
+        rec["x"].append(x.clone())
+        rec["grad"].append(g.clone())
+        return g
+
+    dg._sample_categorical, torch.rand_like, d.compute_gradient_DPS = sc, rl, grad
+    try:
+        torch.manual_seed(seed)
+        x0 = d.controlled_sample_DPS(reward, scale, eval_sp_size=B)
+    finally:
+        dg._sample_categorical, torch.rand_like, d.compute_gradient_DPS = orig_sc, orig_rl, orig_grad
+    q = torch.stack(rec["q"])
+    print("DPS q_xs strides", rec["q"][0].stride(), "u strides", rec["u"][0].stride())
+    save("g11_traj_dps.npz", xs=torch.stack(rec["x"]).to(torch.uint8), q=q, q_is_bvl=int(rec["q"][0].stride()[1] == 1),
+         u=torch.stack(rec["u"]), grad=torch.stack(rec["grad"]), x0=x0, seed=seed, scale=scale, B=B, L=L, S=S)
+
+
 def nets():
     d200 = tiny_diffusion(200, 128)
     emb_m, head_m = tiny_value()
@@ -369,4 +408,5 @@ if __name__ == "__main__":
     traj_pm()
     traj_tds()
     g10()
+    traj_dps()
     nets()

@@ -74,6 +74,10 @@ def test_sampler_api_surface():
         "_ddpm_update_finetune_controlled": ["x", "t", "dt", "pre_scorer_embedding", "pre_scorer_head", "repeats"],
         "_ddpm_update_finetune_controlled_twedie": ["x", "t", "dt", "reward_model", "repeats", "options", "task"],
         "_ddpm_update_finetune_controlled_TDS": ["x", "t", "dt", "reward_model", "alpha"],
+        "_ddpm_update_finetune_controlled_DPS": ["x", "t", "dt", "reward_model", "guidance_scale"],
+        "controlled_sample_DPS": ["reward_model", "guidance_scale", "num_steps", "eps", "eval_sp_size", "sample_M"],
+        "compute_gradient_DPS": ["x_onehot", "x", "reward_model", "sigma_s", "copy_flag"],
+        "forward2": ["x_onehot", "x", "sigma"],
         "transform_samples": ["samples", "num_classes"],
     }
     for name, params in want.items():
@@ -142,3 +146,23 @@ def test_sharded_decode_two_ranks_gloo(tmp_path, total):
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     assert res.stdout.count("ok") == 2
+
+
+def test_dps_gradient_matches_reference(golden):
+    """compute_gradient_DPS (autograd through forward2 + reward net, pure torch) against the gradients the
+    reference computed in its own controlled_sample_DPS run (fixture g11), same weights, CPU fp32."""
+    from svdd_amd.config import Config, ModelConfig
+    from svdd_amd.diffusion import Diffusion
+    from svdd_amd.value_nets import RewardModel
+    from tests.test_nets_cpu import tiny_nets
+    g = golden("g11_traj_dps.npz")
+    bb, emb, head = tiny_nets(golden("nets_tiny.npz"))
+    d = Diffusion(Config(model=ModelConfig(hidden_dim=16, num_cnn_stacks=1, length=int(g["L"]))), backbone=bb).eval()
+    reward = RewardModel(emb, head).eval()
+    for i in range(int(g["S"])):
+        x = torch.from_numpy(g["xs"][i].astype(np.int64))
+        onehot = torch.nn.functional.one_hot(x, 5).float()
+        copy = (x != 4).to(x.dtype)
+        grad = d.compute_gradient_DPS(onehot, x, reward, torch.zeros(x.shape[0]), copy)
+        ref = torch.from_numpy(g["grad"][i])
+        assert torch.allclose(grad, ref, rtol=1e-4, atol=1e-9), (i, (grad - ref).abs().max())

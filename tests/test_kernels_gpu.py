@@ -328,3 +328,42 @@ def test_filter_adversarial_ties_vs_oracle(ops):
     assert np.array_equal(cand.cpu().numpy(), c_ref)
     assert np.array_equal(onehot.cpu().numpy(), oh_ref)
     assert len(np.unique(c_ref)) >= 3                                         # the ties do exercise several outcomes
+
+
+def test_golden_g11_dps_sampling(ops, golden):
+    """DPS baseline: the reference's guided q_xs and the uniforms it drew (fixture g11, q laid out [B,5,L]
+    like the reference's) through svdd_sample_categorical: next states bit-exact."""
+    g = golden("g11_traj_dps.npz")
+    S, B, L = int(g["S"]), int(g["B"]), int(g["L"])
+    assert int(g["q_is_bvl"]) == 1
+    for i in range(S):
+        x = g["xs"][i]
+        u_stream = np.ascontiguousarray(np.swapaxes(g["u"][i], 1, 2))[None]          # [1,B,5,L] = the stream order
+        cand, onehot = ops.sample_categorical(bvl_view(g["q"][i]), dev(x), 1, ops.Rng(uniforms=dev(u_stream)))
+        ref = orc.sample_categorical_merged(np.ascontiguousarray(np.swapaxes(g["q"][i], 1, 2)), x, u_stream, layout=orc.BVL)
+        assert np.array_equal(cand.cpu().numpy(), ref)
+        if i + 1 < S:
+            assert np.array_equal(cand.cpu().numpy()[:, 0], g["xs"][i + 1])
+        assert np.array_equal(onehot.cpu().numpy(), orc.transform_samples(ref[:, 0]))
+
+
+def test_sample_categorical_philox_vs_forced_exact(ops):
+    from svdd_amd import _lib
+    rng = np.random.default_rng(41)
+    B, L, M = 32, 200, 8
+    q = rng.random((B, L, 5)).astype(np.float32) * np.float32(0.01)
+    q[..., 4] = 0.5
+    q[0, :, :4] = 0.0                                   # zeros: ties at 0 among losers
+    x = np.where(rng.random((B, L)) < 0.3, rng.integers(0, 4, (B, L)), 4).astype(np.uint8)
+    outs = []
+    for force in (False, True):
+        _lib.set_force_exact(force)
+        try:
+            cand, _ = ops.sample_categorical(dev(q), dev(x), M, ops.Rng(seed=3, step=1))
+            torch.cuda.synchronize()
+        finally:
+            _lib.set_force_exact(False)
+        outs.append(cand.clone())
+    assert torch.equal(outs[0], outs[1])
+    un = x != 4
+    assert np.array_equal(outs[0].cpu().numpy()[un[:, None, :].repeat(M, 1)], x[:, None, :].repeat(M, 1)[un[:, None, :].repeat(M, 1)])
