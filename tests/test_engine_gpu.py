@@ -206,3 +206,30 @@ def test_dps_decode_runs_and_samples_from_guided_q(small_nets):
     agree = (a == b).float().mean().item()
     assert agree >= 0.98                                # MIOpen backward kernels may use atomics
     assert torch.equal(c, d)                            # zero guidance == un-guided ancestral sampling (same Philox draws)
+
+
+@pytest.mark.parametrize("method,suffix", [("mc", ""), ("tweedie", "_tw"), ("tds", "_TDS")])
+def test_cli_writes_reference_npz(tmp_path, method, suffix):
+    """decode*.py contract: ./log/{task}-{reward_name}{suffix}.npz with arrays `decoding`, `baseline`
+    of length val_batch_num*batch_size (reference decode.py:112-117)."""
+    from svdd_amd import cli
+    from svdd_amd.config import SamplingConfig
+    import svdd_amd.synthetic as syn
+    orig = syn.build
+
+    def small_build(task, device, seed=44, **kw):       # shrink the nets and the step count for test speed
+        m = orig(task, device, seed=seed)
+        m[0].config.sampling = SamplingConfig(steps=6)
+        return m
+
+    syn.build = small_build
+    try:
+        path, out = cli.main(method, ["--task", "rna", "--batch_size", "4", "--sample_M", "3", "--val_batch_num", "2",
+                                      "--out_dir", str(tmp_path), "--rng", "philox"])
+    finally:
+        syn.build = orig
+    assert path.endswith(f"rna-MRL{suffix}.npz")
+    z = np.load(path)
+    assert set(z.files) == {"decoding", "baseline"} and z["decoding"].shape == (8,) and z["baseline"].shape == (8,)
+    samples, vpred, rpred, topk, base = out
+    assert len(samples) == 2 and samples[0].shape == (4, 50) and vpred.shape == (8,) and topk.shape == (8,)
