@@ -184,6 +184,17 @@ int svdd_epilogue_ln_f32(const float* y, const float* bias, const float* f_prev,
                          const float* gamma, const float* beta, float* f_out, float* hn, int64_t rows,
                          int channels, int act, void* stream);
 
+/* svdd_conv1d_cl_f32 — dilated Conv1d with "same" zero padding on channels-last activations, fp32 on the
+ *   exact-fp32 matrix cores, NO bias (the epilogue kernel adds it):
+ *     y[n,l,co] = sum_{t,ci} x[n, l + (t - taps/2)*dilation, ci] * W[co,ci,t]
+ *   x [n,L,cin], y [n,L,cout], cin/cout in {64,128}, taps odd, L <= 224.
+ *   wpack [taps][cin/32][cout][32] = W[co][32c + k][t]   (svdd_amd/fused.py:pack_conv).
+ *   Replaces the nn.Conv1d calls of reference models/dnaconv.py:151-156,196 and Enformer.py:2245-2253,2271. */
+int svdd_conv1d_cl_f32(const float* x, const float* wpack, float* y, int n, int L, int cin, int cout,
+                       int taps, int dilation, void* stream);
+/* tests only: != 0 forces the dynamically scheduled kernel instead of the per-(dilation,L) specialisations */
+int svdd_conv1d_set_dynamic(int on);
+
 /* Process-wide options (host). SVDD_OPT_FORCE_EXACT != 0 makes svdd_propose evaluate every draw in the
  * exact (fp64, correctly rounded) arithmetic instead of the filtered fast path — same results, used
  * to A/B the filter. */

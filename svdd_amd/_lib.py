@@ -23,7 +23,8 @@ EXPORTS = (
     "svdd_abi_version", "svdd_device_info", "svdd_propose", "svdd_sample_categorical", "svdd_select", "svdd_x0hat",
     "svdd_finalize", "svdd_transform_samples", "svdd_subs_logp", "svdd_tds_resample",
     "svdd_set_option", "svdd_selftest_fastmath", "svdd_profile_enable", "svdd_profile_collect",
-    "svdd_gru_bidir_f32", "svdd_epilogue_ln_f32",
+    "svdd_gru_bidir_f32", "svdd_epilogue_ln_f32", "svdd_conv1d_cl_f32",
+    "svdd_conv1d_set_dynamic",
 )
 OPT_FORCE_EXACT = 0
 
@@ -80,6 +81,8 @@ def lib():
     L.svdd_set_option.argtypes = [i32, i32]
     L.svdd_selftest_fastmath.argtypes = [ctypes.POINTER(ctypes.c_double)]
     L.svdd_gru_bidir_f32.argtypes = [vp, vp, vp, vp, i32, i32, vp]
+    L.svdd_conv1d_set_dynamic.argtypes = [i32]
+    L.svdd_conv1d_cl_f32.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
     L.svdd_epilogue_ln_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_int64, i32, i32, vp]
     L.svdd_profile_enable.argtypes = [i32]
     L.svdd_profile_collect.argtypes = [i32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]

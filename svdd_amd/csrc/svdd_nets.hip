@@ -182,6 +182,350 @@ __global__ __launch_bounds__(256) void epilogue_ln_kernel(EpiArgs a) {
   }
 }
 
+// ------------------------------------------------------------- dilated Conv1d, channels-last, fp32 MFMA ----
+// y[n, l, co] = sum_{t, ci} x[n, l + (t - T/2) * dil, ci] * W[co, ci, t]      ("same" zero padding, no bias)
+// as an implicit GEMM on the exact-fp32 matrix cores (v_mfma_f32_32x32x2_f32). One workgroup owns a tile
+// of whole sequences (<= 224 rows: one L=200 sequence, four L=50 sequences), so that
+//   * the activations of the tile are staged into LDS ONCE per 32-channel chunk and re-used by all T taps
+//     (a tap is just a row offset into the LDS image; out-of-range rows read a zero row);
+//   * taps whose receptive rows are all padding are skipped, per 32-row MFMA tile — at L=200 the
+//     dilation-64 layers only do 35 % of the nominal work, dilation-16 82 %;
+//   * B = 256 sequences is exactly one workgroup per CU (no tail).
+// Wave w owns output channels [32 (w % NCT), +32) and row tiles w / NCT, w / NCT + 4 / NCT, ...;
+// accumulators stay in registers across the whole K loop (Cin * T).
+constexpr int CONV_RT = 7;                 // 32-row MFMA tiles per workgroup tile
+constexpr int CONV_ROWS = 32 * CONV_RT;    // 224
+constexpr int CH = 32;                     // input-channel chunk
+constexpr int CHP = CH + 4;                // padded LDS row stride (floats): conflict-free ds_read_b128
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ConvArgs {
+  const float* x; const float* wpack; float* y;
+  int n, L, spt /*sequences per tile*/, T, dil;
+};
+
+// 16 MFMAs of one 32-row tile: A = 4 float4 (16 consecutive input channels of this lane's row), B = bf[16]
+#define CONV_MMA16(ACC, A0, A1, A2, A3)                                                    \
+  ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(A0.x, bf[0], ACC, 0, 0, 0);                   \
+  ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(A0.y, bf[1], ACC, 0, 0, 0);                   \
+  ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(A0.z, bf[2], ACC, 0, 0, 0);                   \
+  ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(A0.w, bf[3], ACC, 0, 0, 0);                   \
+  ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(A1.x, bf[4], ACC, 0, 0, 0);                   \
+  ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(A1.y, bf[5], ACC, 0, 0, 0);                   \
+  ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(A1.z, bf[6], ACC, 0, 0, 0);                   \
+  ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(A1.w, bf[7], ACC, 0, 0, 0);                   \
+  ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(A2.x, bf[8], ACC, 0, 0, 0);                   \
+  ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(A2.y, bf[9], ACC, 0, 0, 0);                   \
+  ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(A2.z, bf[10], ACC, 0, 0, 0);                  \
+  ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(A2.w, bf[11], ACC, 0, 0, 0);                  \
+  ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(A3.x, bf[12], ACC, 0, 0, 0);                  \
+  ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(A3.y, bf[13], ACC, 0, 0, 0);                  \
+  ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(A3.z, bf[14], ACC, 0, 0, 0);                  \
+  ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(A3.w, bf[15], ACC, 0, 0, 0);
+
+// two row tiles interleaved: consecutive MFMAs never share an accumulator (a dependent back-to-back pair
+// stalls ~43 cycles as soon as ANY other instruction is scheduled between them)
+#define CONV_MMA2(K, AV, BV)                                                               \
+  acc[ra] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV, bf[K], acc[ra], 0, 0, 0);            \
+  acc[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(BV, bf[K], acc[rb], 0, 0, 0);
+#define CONV_MMA32(X0, X1, X2, X3, Y0, Y1, Y2, Y3)                                         \
+  CONV_MMA2(0, X0.x, Y0.x) CONV_MMA2(1, X0.y, Y0.y) CONV_MMA2(2, X0.z, Y0.z) CONV_MMA2(3, X0.w, Y0.w)       \
+  CONV_MMA2(4, X1.x, Y1.x) CONV_MMA2(5, X1.y, Y1.y) CONV_MMA2(6, X1.z, Y1.z) CONV_MMA2(7, X1.w, Y1.w)       \
+  CONV_MMA2(8, X2.x, Y2.x) CONV_MMA2(9, X2.y, Y2.y) CONV_MMA2(10, X2.z, Y2.z) CONV_MMA2(11, X2.w, Y2.w)     \
+  CONV_MMA2(12, X3.x, Y3.x) CONV_MMA2(13, X3.y, Y3.y) CONV_MMA2(14, X3.z, Y3.z) CONV_MMA2(15, X3.w, Y3.w)
+
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void conv1d_cl_kernel(ConvArgs a) {
+  constexpr int NCHUNK = CIN / CH;
+  constexpr int NCT = COUT / 32;                 // column tiles (2 or 4)
+  constexpr int RGROUPS = 4 / NCT;               // waves sharing a column tile split the row tiles
+  constexpr int MAXRT = (CONV_RT + RGROUPS - 1) / RGROUPS;
+  constexpr int BLD = COUT * 8 / 256;            // float4 per thread to stage one W[t][c] tile (2 or 4)
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                                      // [CONV_ROWS + 1][CHP]   (+1: the zero row)
+  float* Bs = smem + (CONV_ROWS + 1) * CHP;              // [2][COUT][CHP]
+
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave-uniform (SGPR): keeps the tile-liveness branches scalar
+  const int i = lane & 31, h = lane >> 5;
+  const int ct = w % NCT, rg = w / NCT;
+  const int L = a.L, T = a.T;
+  const int tile_rows = a.spt * L;
+  const int64_t row0 = (int64_t)blockIdx.x * tile_rows;   // first flattened (n*L) row of this tile
+  const int64_t total_rows = (int64_t)a.n * L;
+  const int half_t = T / 2;
+  const int NIT = NCHUNK * T;
+
+  f32x16 acc[MAXRT];
+#pragma unroll
+  for (int r = 0; r < MAXRT; ++r)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[r][e] = 0.0f;
+
+  // this lane's A row per owned row tile: LDS byte-free offsets and the position inside its sequence
+  int arow[MAXRT], apos[MAXRT];
+#pragma unroll
+  for (int r = 0; r < MAXRT; ++r) {
+    const int rt = rg + r * RGROUPS;
+    const int tr = 32 * rt + i;
+    arow[r] = tr;
+    apos[r] = (rt < CONV_RT && tr < tile_rows) ? tr % L : -(1 << 20);   // padding rows never match a tap
+  }
+  for (int e = threadIdx.x; e < CHP; e += 256) As[CONV_ROWS * CHP + e] = 0.0f;   // zero row
+
+  // staging coordinates of this thread for the weight tile W[t][c] ([COUT][32] contiguous in wpack)
+  const int b_r = threadIdx.x >> 3, b_q = threadIdx.x & 7;             // rows b_r + 32 k, 16-B column b_q
+  float4 bp0, bp1, bp2, bp3;                                            // prefetched tile (named: must stay in VGPRs)
+  bp0 = bp1 = bp2 = bp3 = float4{0.0f, 0.0f, 0.0f, 0.0f};
+
+  // first live tap
+  int it = 0;
+  while (it < NIT) { const int d = (it % T - half_t) * a.dil; if (max(0, -d) < min(L, L - d)) break; ++it; }
+  if (it < NIT) {
+    const float* wsrc = a.wpack + ((size_t)((it % T) * NCHUNK + it / T) * COUT) * CH + b_r * CH + 4 * b_q;
+    bp0 = *reinterpret_cast<const float4*>(wsrc);
+    bp1 = *reinterpret_cast<const float4*>(wsrc + 32 * CH);
+    if (BLD > 2) { bp2 = *reinterpret_cast<const float4*>(wsrc + 64 * CH); bp3 = *reinterpret_cast<const float4*>(wsrc + 96 * CH); }
+    float* Bt = Bs + b_r * CHP + 4 * b_q;
+    *reinterpret_cast<float4*>(Bt) = bp0;
+    *reinterpret_cast<float4*>(Bt + 32 * CHP) = bp1;
+    if (BLD > 2) { *reinterpret_cast<float4*>(Bt + 64 * CHP) = bp2; *reinterpret_cast<float4*>(Bt + 96 * CHP) = bp3; }
+  }
+  int par = 0, cur_c = -1;
+  while (it < NIT) {
+    const int c = it / T, t = it % T;
+    if (c != cur_c) {                                        // new input-channel chunk: restage the activations
+      __syncthreads();                                       // previous chunk's readers are done with As
+      for (int e = threadIdx.x; e < CONV_ROWS * 8; e += 256) {
+        const int r = e >> 3, q = e & 7;
+        float4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (r < tile_rows && row0 + r < total_rows)
+          v = *reinterpret_cast<const float4*>(a.x + (row0 + r) * CIN + c * CH + 4 * q);
+        *reinterpret_cast<float4*>(As + r * CHP + 4 * q) = v;
+      }
+      cur_c = c;
+    }
+    // next live tap; its weight tile is fetched now and flies under this tap's MFMAs
+    int nxt = it + 1;
+    while (nxt < NIT) { const int d = (nxt % T - half_t) * a.dil; if (max(0, -d) < min(L, L - d)) break; ++nxt; }
+    if (nxt < NIT) {
+      const float* wsrc = a.wpack + ((size_t)((nxt % T) * NCHUNK + nxt / T) * COUT) * CH + b_r * CH + 4 * b_q;
+      bp0 = *reinterpret_cast<const float4*>(wsrc);
+      bp1 = *reinterpret_cast<const float4*>(wsrc + 32 * CH);
+      if (BLD > 2) { bp2 = *reinterpret_cast<const float4*>(wsrc + 64 * CH); bp3 = *reinterpret_cast<const float4*>(wsrc + 96 * CH); }
+    }
+    __syncthreads();                                         // Bs[par] (and As) visible to every wave
+    float bf[16];
+    {
+      const float4* bq = reinterpret_cast<const float4*>(Bs + par * COUT * CHP + (32 * ct + i) * CHP + 16 * h);
+      const float4 v0 = bq[0], v1 = bq[1], v2 = bq[2], v3 = bq[3];
+      bf[0] = v0.x; bf[1] = v0.y; bf[2] = v0.z; bf[3] = v0.w; bf[4] = v1.x; bf[5] = v1.y; bf[6] = v1.z; bf[7] = v1.w;
+      bf[8] = v2.x; bf[9] = v2.y; bf[10] = v2.z; bf[11] = v2.w; bf[12] = v3.x; bf[13] = v3.y; bf[14] = v3.z; bf[15] = v3.w;
+    }
+    const int delta = (t - half_t) * a.dil;
+    const int lo = max(0, -delta), hi = min(L, L - delta);   // rows l with 0 <= l + delta < L are live
+    const float* Ah = As + 16 * h;
+    // software pipeline over the row tiles: the 4 ds_read_b128 of tile r+1 are issued before the 16 MFMAs of tile r
+    float4 x0, x1, x2, x3, y0, y1, y2, y3;
+    x0 = x1 = x2 = x3 = y0 = y1 = y2 = y3 = float4{0.0f, 0.0f, 0.0f, 0.0f};
+#define CONV_LIVE(R) ((rg + (R) * RGROUPS) < CONV_RT && (a.spt == 1 ? (lo < 32 * (rg + (R) * RGROUPS) + 32 && hi > 32 * (rg + (R) * RGROUPS)) \
+                                                                      : 32 * (rg + (R) * RGROUPS) < tile_rows))
+#define CONV_ALOAD(R, V0, V1, V2, V3)                                                                    \
+  {                                                                                                       \
+    const int p_ = apos[R] + delta;                                                                       \
+    const float4* ap_ = reinterpret_cast<const float4*>(Ah + ((p_ >= 0 && p_ < L) ? arow[R] + delta : CONV_ROWS) * CHP); \
+    V0 = ap_[0]; V1 = ap_[1]; V2 = ap_[2]; V3 = ap_[3];                                                    \
+  }
+    // row tiles in pairs (2 independent accumulator chains interleaved); dead tiles of a dilated tap are skipped
+#pragma unroll
+    for (int r = 0; r < MAXRT; r += 2) {
+      const int ra = r, rb = (r + 1 < MAXRT) ? r + 1 : r;
+      const bool la = CONV_LIVE(ra), lb = (r + 1 < MAXRT) && CONV_LIVE(rb);
+      if (la && lb) {
+        CONV_ALOAD(ra, x0, x1, x2, x3)
+        CONV_ALOAD(rb, y0, y1, y2, y3)
+        CONV_MMA32(x0, x1, x2, x3, y0, y1, y2, y3)
+      } else if (la) {
+        CONV_ALOAD(ra, x0, x1, x2, x3)
+        CONV_MMA16(acc[ra], x0, x1, x2, x3)
+      } else if (lb) {
+        CONV_ALOAD(rb, y0, y1, y2, y3)
+        CONV_MMA16(acc[rb], y0, y1, y2, y3)
+      }
+    }
+    if (nxt < NIT) {                                        // other buffer: its last readers passed this tap's barrier
+      float* Bt = Bs + (par ^ 1) * COUT * CHP + b_r * CHP + 4 * b_q;
+      *reinterpret_cast<float4*>(Bt) = bp0;
+      *reinterpret_cast<float4*>(Bt + 32 * CHP) = bp1;
+      if (BLD > 2) { *reinterpret_cast<float4*>(Bt + 64 * CHP) = bp2; *reinterpret_cast<float4*>(Bt + 96 * CHP) = bp3; }
+    }
+    par ^= 1;
+    it = nxt;
+  }
+#undef CONV_LIVE
+#undef CONV_ALOAD
+  // C/D layout of 32x32: reg e -> row (e & 3) + 8 (e >> 2) + 4 h, column i
+#pragma unroll
+  for (int r = 0; r < MAXRT; ++r) {
+    const int rt = rg + r * RGROUPS;
+    if (rt >= CONV_RT) continue;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int tr = 32 * rt + (e & 3) + 8 * (e >> 2) + 4 * h;
+      if (tr < tile_rows && row0 + tr < total_rows) a.y[(row0 + tr) * COUT + 32 * ct + i] = acc[r][e];
+    }
+  }
+}
+
+// ---- statically scheduled variant: taps, dilation and sequence length are template parameters, so which
+// (tap, 32-row tile) pairs touch only padding is known at compile time: no branch surrounds any MFMA, the
+// accumulators stay in place, and the compiler software-pipelines the straight-line tap bodies.
+constexpr bool conv_tap_live(int t, int T, int dil, int L) {
+  const int d = (t - T / 2) * dil;
+  const int lo = d < 0 ? -d : 0, hi = d > 0 ? L - d : L;
+  return lo < hi;
+}
+constexpr bool conv_tile_live(int t, int rt, int T, int dil, int L, int spt) {
+  const int d = (t - T / 2) * dil;
+  const int lo = d < 0 ? -d : 0, hi = d > 0 ? L - d : L;
+  if (lo >= hi) return false;
+  if (32 * rt >= spt * L) return false;                       // pure padding tile
+  if (spt != 1) return true;
+  return lo < 32 * rt + 32 && hi > 32 * rt;
+}
+
+template <int CIN, int T, int DIL, int LSEQ>
+__global__ __launch_bounds__(256) void conv1d_cl_static_kernel(ConvArgs a) {
+  constexpr int COUT = 128;
+  constexpr int NCHUNK = CIN / CH;
+  constexpr int SPT = CONV_ROWS / LSEQ;
+  constexpr int TILE_ROWS = SPT * LSEQ;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                                      // [CONV_ROWS + 1][CHP]
+  float* Bs = smem + (CONV_ROWS + 1) * CHP;              // [2][COUT][CHP]
+
+  const int lane = threadIdx.x & 63;
+  const int ct = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);    // this wave's 32 output channels
+  const int i = lane & 31, h = lane >> 5;
+  const int64_t row0 = (int64_t)blockIdx.x * TILE_ROWS;
+  const int64_t total_rows = (int64_t)a.n * LSEQ;
+
+  f32x16 acc[CONV_RT];
+#pragma unroll
+  for (int r = 0; r < CONV_RT; ++r)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[r][e] = 0.0f;
+
+  int apos[CONV_RT];                                     // position of this lane's row inside its sequence
+#pragma unroll
+  for (int r = 0; r < CONV_RT; ++r) apos[r] = (32 * r + i < TILE_ROWS) ? (32 * r + i) % LSEQ : -(1 << 20);
+  for (int e = threadIdx.x; e < CHP; e += 256) As[CONV_ROWS * CHP + e] = 0.0f;   // zero row
+
+  const int b_r = threadIdx.x >> 3, b_q = threadIdx.x & 7;
+  const float* wbase = a.wpack + b_r * CH + 4 * b_q;
+  float* bdst = Bs + b_r * CHP + 4 * b_q;
+  float4 bp0, bp1, bp2, bp3;
+  int par = 0;
+  {                                                      // first live tap of chunk 0
+    int t0 = 0;
+#pragma unroll
+    for (int t = T - 1; t >= 0; --t) if (conv_tap_live(t, T, DIL, LSEQ)) t0 = t;
+    const float* wsrc = wbase + ((size_t)(t0 * NCHUNK) * COUT) * CH;
+    bp0 = *reinterpret_cast<const float4*>(wsrc);
+    bp1 = *reinterpret_cast<const float4*>(wsrc + 32 * CH);
+    bp2 = *reinterpret_cast<const float4*>(wsrc + 64 * CH);
+    bp3 = *reinterpret_cast<const float4*>(wsrc + 96 * CH);
+    *reinterpret_cast<float4*>(bdst) = bp0;
+    *reinterpret_cast<float4*>(bdst + 32 * CHP) = bp1;
+    *reinterpret_cast<float4*>(bdst + 64 * CHP) = bp2;
+    *reinterpret_cast<float4*>(bdst + 96 * CHP) = bp3;
+  }
+  const float* Ah = As + 16 * h;
+  for (int c = 0; c < NCHUNK; ++c) {
+    __syncthreads();                                       // previous chunk's readers are done with As
+    for (int e = threadIdx.x; e < CONV_ROWS * 8; e += 256) {
+      const int r = e >> 3, q = e & 7;
+      float4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (r < TILE_ROWS && row0 + r < total_rows)
+        v = *reinterpret_cast<const float4*>(a.x + (row0 + r) * CIN + c * CH + 4 * q);
+      *reinterpret_cast<float4*>(As + r * CHP + 4 * q) = v;
+    }
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      if (!conv_tap_live(t, T, DIL, LSEQ)) continue;       // compile-time
+      // weight tile of the next live tap (next chunk's first live tap after the last one) flies under the MFMAs
+      int tn = -1;
+#pragma unroll
+      for (int u = T - 1; u > t; --u) if (conv_tap_live(u, T, DIL, LSEQ)) tn = u;
+      int cn = c;
+      if (tn < 0) {
+        cn = c + 1;
+#pragma unroll
+        for (int u = T - 1; u >= 0; --u) if (conv_tap_live(u, T, DIL, LSEQ)) tn = u;
+      }
+      const bool have_next = cn < NCHUNK;
+      if (have_next) {
+        const float* wsrc = wbase + ((size_t)(tn * NCHUNK + cn) * COUT) * CH;
+        bp0 = *reinterpret_cast<const float4*>(wsrc);
+        bp1 = *reinterpret_cast<const float4*>(wsrc + 32 * CH);
+        bp2 = *reinterpret_cast<const float4*>(wsrc + 64 * CH);
+        bp3 = *reinterpret_cast<const float4*>(wsrc + 96 * CH);
+      }
+      __syncthreads();                                     // Bs[par] (and As) visible to every wave
+      float bf[16];
+      {
+        const float4* bq = reinterpret_cast<const float4*>(Bs + par * COUT * CHP + (32 * ct + i) * CHP + 16 * h);
+        const float4 v0 = bq[0], v1 = bq[1], v2 = bq[2], v3 = bq[3];
+        bf[0] = v0.x; bf[1] = v0.y; bf[2] = v0.z; bf[3] = v0.w; bf[4] = v1.x; bf[5] = v1.y; bf[6] = v1.z; bf[7] = v1.w;
+        bf[8] = v2.x; bf[9] = v2.y; bf[10] = v2.z; bf[11] = v2.w; bf[12] = v3.x; bf[13] = v3.y; bf[14] = v3.z; bf[15] = v3.w;
+      }
+      constexpr int dummy = 0; (void)dummy;
+      const int delta = (t - T / 2) * DIL;
+      float4 af[CONV_RT][4];
+#pragma unroll
+      for (int r = 0; r < CONV_RT; ++r) {
+        if (!conv_tile_live(t, r, T, DIL, LSEQ, SPT)) continue;
+        const int p = apos[r] + delta;
+        const float4* ap = reinterpret_cast<const float4*>(Ah + ((p >= 0 && p < LSEQ) ? 32 * r + i + delta : CONV_ROWS) * CHP);
+        af[r][0] = ap[0]; af[r][1] = ap[1]; af[r][2] = ap[2]; af[r][3] = ap[3];
+      }
+      // k-step outer, row tile inner: consecutive MFMAs never share an accumulator
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int r = 0; r < CONV_RT; ++r)
+          if (conv_tile_live(t, r, T, DIL, LSEQ, SPT)) acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[r][q].x, bf[4 * q], acc[r], 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < CONV_RT; ++r)
+          if (conv_tile_live(t, r, T, DIL, LSEQ, SPT)) acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[r][q].y, bf[4 * q + 1], acc[r], 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < CONV_RT; ++r)
+          if (conv_tile_live(t, r, T, DIL, LSEQ, SPT)) acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[r][q].z, bf[4 * q + 2], acc[r], 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < CONV_RT; ++r)
+          if (conv_tile_live(t, r, T, DIL, LSEQ, SPT)) acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[r][q].w, bf[4 * q + 3], acc[r], 0, 0, 0);
+      }
+      if (have_next) {                                    // other buffer: its last readers passed this tap's barrier
+        float* bd = bdst + (par ^ 1) * COUT * CHP;
+        *reinterpret_cast<float4*>(bd) = bp0;
+        *reinterpret_cast<float4*>(bd + 32 * CHP) = bp1;
+        *reinterpret_cast<float4*>(bd + 64 * CHP) = bp2;
+        *reinterpret_cast<float4*>(bd + 96 * CHP) = bp3;
+      }
+      par ^= 1;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < CONV_RT; ++r) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int tr = 32 * r + (e & 3) + 8 * (e >> 2) + 4 * h;
+      if (tr < TILE_ROWS && row0 + tr < total_rows) a.y[(row0 + tr) * COUT + 32 * ct + i] = acc[r][e];
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int svdd_gru_bidir_f32(const float* x, const float* wpack, const float* bpack, float* out, int n, int L,
@@ -202,6 +546,36 @@ extern "C" int svdd_epilogue_ln_f32(const float* y, const float* bias, const flo
   if (channels == 64) hipLaunchKernelGGL(epilogue_ln_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
   else if (channels == 128) hipLaunchKernelGGL(epilogue_ln_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
   else if (channels == 256) hipLaunchKernelGGL(epilogue_ln_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  else return SVDD_E_ARG;
+  return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
+}
+
+static int g_conv_dynamic = 0;     // tests: force the dynamically scheduled kernel
+extern "C" int svdd_conv1d_set_dynamic(int on) { g_conv_dynamic = on; return SVDD_OK; }
+
+extern "C" int svdd_conv1d_cl_f32(const float* x, const float* wpack, float* y, int n, int L, int cin, int cout,
+                                  int taps, int dilation, void* stream) {
+  if (!x || !wpack || !y || n <= 0 || L <= 0 || L > CONV_ROWS || taps <= 0 || !(taps & 1) || dilation <= 0)
+    return SVDD_E_ARG;
+  const int spt = CONV_ROWS / L;                               // whole sequences per workgroup tile
+  ConvArgs a{x, wpack, y, n, L, spt, taps, dilation};
+  const unsigned grid = (unsigned)((n + spt - 1) / spt);
+  auto launch = [&](auto kern, int co) {
+    const size_t lds = sizeof(float) * ((size_t)(CONV_ROWS + 1) * CHP + 2 * (size_t)co * CHP);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, (hipStream_t)stream, a);
+  };
+  const bool dyn = g_conv_dynamic != 0;
+  if (!dyn && cin == 128 && cout == 128 && taps == 9 && (L == 200 || L == 50)) {
+#define SVDD_CONV_CASE(D, LL) if (dilation == D && L == LL) { launch(conv1d_cl_static_kernel<128, 9, D, LL>, 128); return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH; }
+    SVDD_CONV_CASE(1, 200) SVDD_CONV_CASE(4, 200) SVDD_CONV_CASE(16, 200) SVDD_CONV_CASE(64, 200)
+    SVDD_CONV_CASE(1, 50) SVDD_CONV_CASE(4, 50) SVDD_CONV_CASE(16, 50) SVDD_CONV_CASE(64, 50)
+#undef SVDD_CONV_CASE
+  }
+  if (cin == 128 && cout == 128) launch(conv1d_cl_kernel<128, 128>, 128);
+  else if (cin == 64 && cout == 64) launch(conv1d_cl_kernel<64, 64>, 64);
+  else if (cin == 64 && cout == 128) launch(conv1d_cl_kernel<64, 128>, 128);
+  else if (cin == 128 && cout == 64) launch(conv1d_cl_kernel<128, 64>, 64);
   else return SVDD_E_ARG;
   return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
 }

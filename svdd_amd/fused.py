@@ -65,6 +65,24 @@ def gru_bidir(x_nlc, wpack, bpack):
     return out
 
 
+def pack_conv(weight):
+    """Conv1d weight [cout, cin, taps] -> [taps][cin/32][cout][32] for svdd_conv1d_cl_f32."""
+    co, ci, T = weight.shape
+    assert ci % 32 == 0
+    return weight.detach().float().permute(2, 1, 0).reshape(T, ci // 32, 32, co).permute(0, 1, 3, 2).contiguous()
+
+
+def conv1d_cl(x_nlc, wpack, cout, taps, dilation):
+    """x [n, L, cin] fp32 contiguous -> y [n, L, cout] (no bias), HIP kernel svdd_conv1d_cl_f32."""
+    assert x_nlc.is_cuda and x_nlc.dtype == torch.float32 and x_nlc.is_contiguous()
+    n, L, cin = x_nlc.shape
+    y = torch.empty((n, L, cout), dtype=torch.float32, device=x_nlc.device)
+    rc = _lib.lib().svdd_conv1d_cl_f32(x_nlc.data_ptr(), wpack.data_ptr(), y.data_ptr(), n, L, cin, cout, taps, dilation,
+                                       ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    _lib.check(rc, "svdd_conv1d_cl_f32")
+    return y
+
+
 def _ptr(t):
     return t.data_ptr() if t is not None else None
 
@@ -161,6 +179,11 @@ class FusedBackbone(nn.Module):
         self.first_w = nn.Parameter(_cl(cnn.linear.weight), requires_grad=False)
         self.first_b = nn.Parameter(cnn.linear.bias.detach().clone(), requires_grad=False)
         self.ws = nn.ParameterList([nn.Parameter(_cl(c.weight), requires_grad=False) for c in cnn.convs])
+        # hand-written fp32-MFMA conv (csrc/svdd_nets.hip) for the 128->128, 9-tap layers
+        self.wpacks = nn.ParameterList([nn.Parameter(pack_conv(c.weight), requires_grad=False) if self.H == 128 and
+                                        c.kernel_size[0] == 9 else nn.Parameter(torch.zeros(0), requires_grad=False)
+                                        for c in cnn.convs])
+        self.use_hip_conv = True
         self.bs = nn.ParameterList([nn.Parameter(c.bias.detach().clone(), requires_grad=False) for c in cnn.convs])
         self.dil = [c.dilation[0] for c in cnn.convs]
         self.norms = cnn.norms
@@ -182,9 +205,15 @@ class FusedBackbone(nn.Module):
         # f_0 = relu(conv(onehot) + b) ; hn_0 = LN(f_0 + tb_0)                          (dnaconv.py:184,188-194)
         f, hn = epilogue_ln(F.conv2d(f, self.first_w, None, padding=(0, 4)), self.first_b, None,
                             self.tb[0], self.norms[0].weight, self.norms[0].bias)
+        # one workgroup per 224-row tile of whole sequences: worth it once the tiles fill most of the 256 CUs
+        hip_conv = self.use_hip_conv and self.H == 128 and L in (200, 50) and B * L >= 192 * 200
         for i, (w, b) in enumerate(zip(self.ws, self.bs)):
             d = self.dil[i]
-            y = F.conv2d(hn, w, None, padding=(0, 4 * d), dilation=(1, d))
+            if hip_conv and self.wpacks[i].numel():
+                y = conv1d_cl(hn.permute(0, 2, 3, 1).reshape(B, L, self.H), self.wpacks[i], self.H, 9, d)
+                y = y.view(B, 1, L, self.H).permute(0, 3, 1, 2)
+            else:
+                y = F.conv2d(hn, w, None, padding=(0, 4 * d), dilation=(1, d))
             last = i + 1 == n
             # f_{i+1} = relu(y + b) + f_i ; hn_{i+1} = LN(f_{i+1} + tb_{i+1})           (:195-197, then :188-194)
             f, hn = epilogue_ln(y, b, f, None if last else self.tb[i + 1],

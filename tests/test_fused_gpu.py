@@ -69,16 +69,19 @@ def test_fused_value_net_vs_plain(nets):
     model.clear_fused()
 
 
-def test_fused_backbone_vs_plain(nets):
+@pytest.mark.parametrize("B", [32, 256])          # 256: the hand-written conv path; 32: MIOpen convs
+def test_fused_backbone_vs_plain(nets, B):
     from svdd_amd.fused import FusedBackbone
     model = nets[0]
     fb = FusedBackbone(model.backbone).to(DEV).eval()
-    x = torch.randint(0, 5, (32, 200), device=DEV).to(torch.uint8)
+    x = torch.randint(0, 5, (B, 200), device=DEV).to(torch.uint8)
     with torch.no_grad():
         ref = model.backbone(x, None, zero_sigma=True)
         out = fb(x)
-    assert out.shape == (32, 200, 5) and out.is_contiguous()
+    assert out.shape == (B, 200, 5) and out.is_contiguous()
     assert (out - ref).abs().max().item() <= 2e-5
+    if B >= 192:
+        assert torch.equal(out, fb(x))                  # our kernels are run-to-run deterministic (MIOpen's split-K is not)
 
 
 def test_engine_uses_fused_nets_and_rows_are_batch_invariant(nets):
@@ -94,3 +97,25 @@ def test_engine_uses_fused_nets_and_rows_are_batch_invariant(nets):
         full = fn(oh)
         parts = torch.cat([fn(oh[:16]), fn(oh[16:48]), fn(oh[48:])])
     assert (full - parts).abs().max().item() <= 1e-6
+
+
+@pytest.mark.parametrize("n,L,cin,cout,T,dil", [
+    (8, 200, 128, 128, 9, 1), (8, 200, 128, 128, 9, 4), (5, 200, 128, 128, 9, 16), (5, 200, 128, 128, 9, 64),
+    (9, 50, 128, 128, 9, 64), (7, 50, 128, 128, 9, 4), (33, 200, 64, 64, 5, 1), (6, 50, 64, 64, 5, 1),
+    (3, 37, 64, 128, 3, 2), (3, 224, 128, 64, 1, 1)])
+def test_conv1d_cl_kernel_vs_torch(n, L, cin, cout, T, dil):
+    from svdd_amd import _lib
+    from svdd_amd.fused import conv1d_cl, pack_conv
+    torch.manual_seed(n * L + T)
+    x = torch.randn(n, L, cin, device=DEV)
+    w = torch.randn(cout, cin, T, device=DEV) / (cin * T) ** 0.5
+    y = conv1d_cl(x, pack_conv(w), cout, T, dil)
+    ref = torch.nn.functional.conv1d(x.double().transpose(1, 2), w.double(), padding=(T // 2) * dil, dilation=dil).transpose(1, 2)
+    err = (y.double() - ref).abs().max().item()
+    assert y.shape == (n, L, cout) and err <= 2e-5, err
+    _lib.lib().svdd_conv1d_set_dynamic(1)              # the generic (runtime-scheduled) kernel on the same problem
+    try:
+        y2 = conv1d_cl(x, pack_conv(w), cout, T, dil)
+    finally:
+        _lib.lib().svdd_conv1d_set_dynamic(0)
+    assert (y2.double() - ref).abs().max().item() <= 2e-5
