@@ -191,7 +191,10 @@ int svdd_epilogue_ln_f32(const float* y, const float* bias, const float* f_prev,
  *   wpack [taps][cin/32][cout][32] = W[co][32c + k][t]   (svdd_amd/fused.py:pack_conv).
  *   Replaces the nn.Conv1d calls of reference models/dnaconv.py:151-156,196 and Enformer.py:2245-2253,2271. */
 int svdd_conv1d_cl_f32(const float* x, const float* wpack, float* y, int n, int L, int cin, int cout,
-                       int taps, int dilation, void* stream);
+                       int taps, int dilation, const float* bias, const float* f_prev, int act, void* stream);
+/*   fused epilogue (specialised shapes only: 128->128 x 9 taps x dilation {1,4,16,64}, 64->64 x 5 taps; L in {200,50}):
+ *   act -1: y = conv ; 0: y = relu(conv + bias) + f_prev ; 1: y = relu(conv + bias + f_prev) ; 2: y = conv + bias + f_prev
+ *   (bias, f_prev may be NULL).  Other shapes take the generic kernel and require act = -1. */
 /* tests only: != 0 forces the dynamically scheduled kernel instead of the per-(dilation,L) specialisations */
 int svdd_conv1d_set_dynamic(int on);
 

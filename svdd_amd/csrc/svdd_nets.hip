@@ -203,6 +203,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 struct ConvArgs {
   const float* x; const float* wpack; float* y;
   int n, L, spt /*sequences per tile*/, T, dil;
+  const float* bias; const float* f_prev; int act;      // fused epilogue (static kernels): act -1 = raw conv output
 };
 
 // 16 MFMAs of one 32-row tile: A = 4 float4 (16 consecutive input channels of this lane's row), B = bf[16]
@@ -395,10 +396,13 @@ constexpr bool conv_tile_live(int t, int rt, int T, int dil, int L, int spt) {
   return lo < 32 * rt + 32 && hi > 32 * rt;
 }
 
-template <int CIN, int T, int DIL, int LSEQ>
+template <int CIN, int COUT, int T, int DIL, int LSEQ>
 __global__ __launch_bounds__(256) void conv1d_cl_static_kernel(ConvArgs a) {
-  constexpr int COUT = 128;
   constexpr int NCHUNK = CIN / CH;
+  constexpr int NCT = COUT / 32;                 // 4 (128 channels) or 2 (64)
+  constexpr int RGROUPS = 4 / NCT;               // waves sharing a column tile take interleaved row tiles
+  constexpr int NRT = (CONV_RT + RGROUPS - 1) / RGROUPS;   // row tiles per wave (the last one of group 1 is padding)
+  constexpr int BLD = COUT * 8 / 256;            // float4 per thread per weight tile
   constexpr int SPT = CONV_ROWS / LSEQ;
   constexpr int TILE_ROWS = SPT * LSEQ;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -406,26 +410,32 @@ __global__ __launch_bounds__(256) void conv1d_cl_static_kernel(ConvArgs a) {
   float* Bs = smem + (CONV_ROWS + 1) * CHP;              // [2][COUT][CHP]
 
   const int lane = threadIdx.x & 63;
-  const int ct = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);    // this wave's 32 output channels
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int ct = w % NCT, rg = w / NCT;                  // this wave's 32 output channels / row-tile group
   const int i = lane & 31, h = lane >> 5;
   const int64_t row0 = (int64_t)blockIdx.x * TILE_ROWS;
   const int64_t total_rows = (int64_t)a.n * LSEQ;
 
-  f32x16 acc[CONV_RT];
+  f32x16 acc[NRT];
 #pragma unroll
-  for (int r = 0; r < CONV_RT; ++r)
+  for (int r = 0; r < NRT; ++r)
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[r][e] = 0.0f;
 
-  int apos[CONV_RT];                                     // position of this lane's row inside its sequence
+  // row tile r of this wave is tile rt = rg + r * RGROUPS; arow = its row for this lane, apos = position in its sequence
+  int arow[NRT], apos[NRT];
 #pragma unroll
-  for (int r = 0; r < CONV_RT; ++r) apos[r] = (32 * r + i < TILE_ROWS) ? (32 * r + i) % LSEQ : -(1 << 20);
+  for (int r = 0; r < NRT; ++r) {
+    arow[r] = 32 * (rg + r * RGROUPS) + i;
+    apos[r] = (arow[r] < TILE_ROWS) ? arow[r] % LSEQ : -(1 << 20);      // padding rows read the zero row
+  }
   for (int e = threadIdx.x; e < CHP; e += 256) As[CONV_ROWS * CHP + e] = 0.0f;   // zero row
 
   const int b_r = threadIdx.x >> 3, b_q = threadIdx.x & 7;
   const float* wbase = a.wpack + b_r * CH + 4 * b_q;
   float* bdst = Bs + b_r * CHP + 4 * b_q;
   float4 bp0, bp1, bp2, bp3;
+  bp2 = bp3 = float4{0.0f, 0.0f, 0.0f, 0.0f};
   int par = 0;
   {                                                      // first live tap of chunk 0
     int t0 = 0;
@@ -434,12 +444,10 @@ __global__ __launch_bounds__(256) void conv1d_cl_static_kernel(ConvArgs a) {
     const float* wsrc = wbase + ((size_t)(t0 * NCHUNK) * COUT) * CH;
     bp0 = *reinterpret_cast<const float4*>(wsrc);
     bp1 = *reinterpret_cast<const float4*>(wsrc + 32 * CH);
-    bp2 = *reinterpret_cast<const float4*>(wsrc + 64 * CH);
-    bp3 = *reinterpret_cast<const float4*>(wsrc + 96 * CH);
+    if (BLD > 2) { bp2 = *reinterpret_cast<const float4*>(wsrc + 64 * CH); bp3 = *reinterpret_cast<const float4*>(wsrc + 96 * CH); }
     *reinterpret_cast<float4*>(bdst) = bp0;
     *reinterpret_cast<float4*>(bdst + 32 * CHP) = bp1;
-    *reinterpret_cast<float4*>(bdst + 64 * CHP) = bp2;
-    *reinterpret_cast<float4*>(bdst + 96 * CHP) = bp3;
+    if (BLD > 2) { *reinterpret_cast<float4*>(bdst + 64 * CHP) = bp2; *reinterpret_cast<float4*>(bdst + 96 * CHP) = bp3; }
   }
   const float* Ah = As + 16 * h;
   for (int c = 0; c < NCHUNK; ++c) {
@@ -469,8 +477,7 @@ __global__ __launch_bounds__(256) void conv1d_cl_static_kernel(ConvArgs a) {
         const float* wsrc = wbase + ((size_t)(tn * NCHUNK + cn) * COUT) * CH;
         bp0 = *reinterpret_cast<const float4*>(wsrc);
         bp1 = *reinterpret_cast<const float4*>(wsrc + 32 * CH);
-        bp2 = *reinterpret_cast<const float4*>(wsrc + 64 * CH);
-        bp3 = *reinterpret_cast<const float4*>(wsrc + 96 * CH);
+        if (BLD > 2) { bp2 = *reinterpret_cast<const float4*>(wsrc + 64 * CH); bp3 = *reinterpret_cast<const float4*>(wsrc + 96 * CH); }
       }
       __syncthreads();                                     // Bs[par] (and As) visible to every wave
       float bf[16];
@@ -482,46 +489,60 @@ __global__ __launch_bounds__(256) void conv1d_cl_static_kernel(ConvArgs a) {
       }
       constexpr int dummy = 0; (void)dummy;
       const int delta = (t - T / 2) * DIL;
-      float4 af[CONV_RT][4];
+      // Tile liveness is a compile-time fact when every wave owns all row tiles (RGROUPS == 1); with two row
+      // groups a tile's index depends on the wave, so only whole-tap skipping is static there.
+#define SCONV_LIVE(R) (RGROUPS == 1 ? conv_tile_live(t, R, T, DIL, LSEQ, SPT) : true)
+      float4 af[NRT][4];
 #pragma unroll
-      for (int r = 0; r < CONV_RT; ++r) {
-        if (!conv_tile_live(t, r, T, DIL, LSEQ, SPT)) continue;
+      for (int r = 0; r < NRT; ++r) {
+        if (!SCONV_LIVE(r)) continue;
         const int p = apos[r] + delta;
-        const float4* ap = reinterpret_cast<const float4*>(Ah + ((p >= 0 && p < LSEQ) ? 32 * r + i + delta : CONV_ROWS) * CHP);
+        const float4* ap = reinterpret_cast<const float4*>(Ah + ((p >= 0 && p < LSEQ) ? arow[r] + delta : CONV_ROWS) * CHP);
         af[r][0] = ap[0]; af[r][1] = ap[1]; af[r][2] = ap[2]; af[r][3] = ap[3];
       }
       // k-step outer, row tile inner: consecutive MFMAs never share an accumulator
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
 #pragma unroll
-        for (int r = 0; r < CONV_RT; ++r)
-          if (conv_tile_live(t, r, T, DIL, LSEQ, SPT)) acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[r][q].x, bf[4 * q], acc[r], 0, 0, 0);
+        for (int r = 0; r < NRT; ++r)
+          if (SCONV_LIVE(r)) acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[r][q].x, bf[4 * q], acc[r], 0, 0, 0);
 #pragma unroll
-        for (int r = 0; r < CONV_RT; ++r)
-          if (conv_tile_live(t, r, T, DIL, LSEQ, SPT)) acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[r][q].y, bf[4 * q + 1], acc[r], 0, 0, 0);
+        for (int r = 0; r < NRT; ++r)
+          if (SCONV_LIVE(r)) acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[r][q].y, bf[4 * q + 1], acc[r], 0, 0, 0);
 #pragma unroll
-        for (int r = 0; r < CONV_RT; ++r)
-          if (conv_tile_live(t, r, T, DIL, LSEQ, SPT)) acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[r][q].z, bf[4 * q + 2], acc[r], 0, 0, 0);
+        for (int r = 0; r < NRT; ++r)
+          if (SCONV_LIVE(r)) acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[r][q].z, bf[4 * q + 2], acc[r], 0, 0, 0);
 #pragma unroll
-        for (int r = 0; r < CONV_RT; ++r)
-          if (conv_tile_live(t, r, T, DIL, LSEQ, SPT)) acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[r][q].w, bf[4 * q + 3], acc[r], 0, 0, 0);
+        for (int r = 0; r < NRT; ++r)
+          if (SCONV_LIVE(r)) acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[r][q].w, bf[4 * q + 3], acc[r], 0, 0, 0);
       }
+#undef SCONV_LIVE
       if (have_next) {                                    // other buffer: its last readers passed this tap's barrier
         float* bd = bdst + (par ^ 1) * COUT * CHP;
         *reinterpret_cast<float4*>(bd) = bp0;
         *reinterpret_cast<float4*>(bd + 32 * CHP) = bp1;
-        *reinterpret_cast<float4*>(bd + 64 * CHP) = bp2;
-        *reinterpret_cast<float4*>(bd + 96 * CHP) = bp3;
+        if (BLD > 2) { *reinterpret_cast<float4*>(bd + 64 * CHP) = bp2; *reinterpret_cast<float4*>(bd + 96 * CHP) = bp3; }
       }
       par ^= 1;
     }
   }
+  // epilogue: act -1 raw conv output ; 0 relu(v + bias) + f_prev ; 1 relu(v + bias + f_prev) ; 2 v + bias + f_prev
+  const float bias = (a.act >= 0 && a.bias) ? a.bias[32 * ct + i] : 0.0f;
 #pragma unroll
-  for (int r = 0; r < CONV_RT; ++r) {
+  for (int r = 0; r < NRT; ++r) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      const int tr = 32 * r + (e & 3) + 8 * (e >> 2) + 4 * h;
-      if (tr < TILE_ROWS && row0 + tr < total_rows) a.y[(row0 + tr) * COUT + 32 * ct + i] = acc[r][e];
+      const int tr = 32 * (rg + r * RGROUPS) + (e & 3) + 8 * (e >> 2) + 4 * h;
+      if (tr < TILE_ROWS && row0 + tr < total_rows) {
+        const int64_t o = (row0 + tr) * COUT + 32 * ct + i;
+        float v = acc[r][e];
+        if (a.act >= 0) {
+          v += bias;
+          const float p = a.f_prev ? a.f_prev[o] : 0.0f;
+          v = a.act == 0 ? fmaxf(v, 0.0f) + p : a.act == 1 ? fmaxf(v + p, 0.0f) : v + p;
+        }
+        a.y[o] = v;
+      }
     }
   }
 }
@@ -554,11 +575,13 @@ static int g_conv_dynamic = 0;     // tests: force the dynamically scheduled ker
 extern "C" int svdd_conv1d_set_dynamic(int on) { g_conv_dynamic = on; return SVDD_OK; }
 
 extern "C" int svdd_conv1d_cl_f32(const float* x, const float* wpack, float* y, int n, int L, int cin, int cout,
-                                  int taps, int dilation, void* stream) {
-  if (!x || !wpack || !y || n <= 0 || L <= 0 || L > CONV_ROWS || taps <= 0 || !(taps & 1) || dilation <= 0)
+                                  int taps, int dilation, const float* bias, const float* f_prev, int act,
+                                  void* stream) {
+  if (!x || !wpack || !y || n <= 0 || L <= 0 || L > CONV_ROWS || taps <= 0 || !(taps & 1) || dilation <= 0 ||
+      act < -1 || act > 2)
     return SVDD_E_ARG;
   const int spt = CONV_ROWS / L;                               // whole sequences per workgroup tile
-  ConvArgs a{x, wpack, y, n, L, spt, taps, dilation};
+  ConvArgs a{x, wpack, y, n, L, spt, taps, dilation, bias, f_prev, act};
   const unsigned grid = (unsigned)((n + spt - 1) / spt);
   auto launch = [&](auto kern, int co) {
     const size_t lds = sizeof(float) * ((size_t)(CONV_ROWS + 1) * CHP + 2 * (size_t)co * CHP);
@@ -567,11 +590,17 @@ extern "C" int svdd_conv1d_cl_f32(const float* x, const float* wpack, float* y, 
   };
   const bool dyn = g_conv_dynamic != 0;
   if (!dyn && cin == 128 && cout == 128 && taps == 9 && (L == 200 || L == 50)) {
-#define SVDD_CONV_CASE(D, LL) if (dilation == D && L == LL) { launch(conv1d_cl_static_kernel<128, 9, D, LL>, 128); return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH; }
+#define SVDD_CONV_CASE(D, LL) if (dilation == D && L == LL) { launch(conv1d_cl_static_kernel<128, 128, 9, D, LL>, 128); return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH; }
     SVDD_CONV_CASE(1, 200) SVDD_CONV_CASE(4, 200) SVDD_CONV_CASE(16, 200) SVDD_CONV_CASE(64, 200)
     SVDD_CONV_CASE(1, 50) SVDD_CONV_CASE(4, 50) SVDD_CONV_CASE(16, 50) SVDD_CONV_CASE(64, 50)
 #undef SVDD_CONV_CASE
   }
+  if (!dyn && cin == 64 && cout == 64 && taps == 5 && dilation == 1 && (L == 200 || L == 50)) {
+    if (L == 200) launch(conv1d_cl_static_kernel<64, 64, 5, 1, 200>, 64);
+    else launch(conv1d_cl_static_kernel<64, 64, 5, 1, 50>, 64);
+    return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
+  }
+  if (act >= 0) return SVDD_E_ARG;                             // the generic kernel has no fused epilogue
   if (cin == 128 && cout == 128) launch(conv1d_cl_kernel<128, 128>, 128);
   else if (cin == 64 && cout == 64) launch(conv1d_cl_kernel<64, 64>, 64);
   else if (cin == 64 && cout == 128) launch(conv1d_cl_kernel<64, 128>, 128);

@@ -72,12 +72,15 @@ def pack_conv(weight):
     return weight.detach().float().permute(2, 1, 0).reshape(T, ci // 32, 32, co).permute(0, 1, 3, 2).contiguous()
 
 
-def conv1d_cl(x_nlc, wpack, cout, taps, dilation):
-    """x [n, L, cin] fp32 contiguous -> y [n, L, cout] (no bias), HIP kernel svdd_conv1d_cl_f32."""
+def conv1d_cl(x_nlc, wpack, cout, taps, dilation, bias=None, f_prev=None, act=-1):
+    """x [n, L, cin] fp32 contiguous -> y [n, L, cout], HIP kernel svdd_conv1d_cl_f32.
+    act -1: raw conv (no bias); 0: relu(conv + bias) + f_prev; 1: relu(conv + bias + f_prev); 2: conv + bias + f_prev."""
     assert x_nlc.is_cuda and x_nlc.dtype == torch.float32 and x_nlc.is_contiguous()
     n, L, cin = x_nlc.shape
     y = torch.empty((n, L, cout), dtype=torch.float32, device=x_nlc.device)
     rc = _lib.lib().svdd_conv1d_cl_f32(x_nlc.data_ptr(), wpack.data_ptr(), y.data_ptr(), n, L, cin, cout, taps, dilation,
+                                       bias.data_ptr() if bias is not None else None,
+                                       f_prev.data_ptr() if f_prev is not None else None, int(act),
                                        ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     _lib.check(rc, "svdd_conv1d_cl_f32")
     return y
@@ -120,7 +123,7 @@ class FusedValueNet(nn.Module):
         self.stem_w = nn.Parameter(_cl(blocks[0].conv.weight), requires_grad=False)
         self.stem_b = nn.Parameter(blocks[0].conv.bias.detach().clone(), requires_grad=False)
         self.stem_pad = blocks[0].conv.kernel_size[0] // 2
-        ws, bs, self.pads, self.residual = [], [], [], []
+        ws, bs, wpacks, self.pads, self.residual = [], [], [], [], []
         for blk in blocks[1:]:
             w, b = blk.conv.weight.detach(), blk.conv.bias.detach()
             bn = blk.norm.layer
@@ -131,9 +134,12 @@ class FusedValueNet(nn.Module):
             assert not blk.residual or isinstance(blk.channel_transform.layer, nn.Identity)
             ws.append(nn.Parameter(_cl(w), requires_grad=False))
             bs.append(nn.Parameter(b.clone(), requires_grad=False))
+            wpacks.append(nn.Parameter(pack_conv(w) if tuple(w.shape) == (64, 64, 5) and blk.conv.dilation[0] == 1
+                                       else torch.zeros(0), requires_grad=False))
             self.pads.append(blk.conv.kernel_size[0] // 2 * blk.conv.dilation[0])
             self.residual.append(blk.residual)
-        self.ws, self.bs = nn.ParameterList(ws), nn.ParameterList(bs)
+        self.ws, self.bs, self.wpacks = nn.ParameterList(ws), nn.ParameterList(bs), nn.ParameterList(wpacks)
+        self.use_hip_conv = False
         gt = embedding.gru_tower
         wpack, bpack = pack_gru(gt.gru)
         self.register_buffer("wpack", wpack)
@@ -158,9 +164,17 @@ class FusedValueNet(nn.Module):
         n, L, C = x.shape
         f = x.contiguous().view(n, 1, L, C).permute(0, 3, 1, 2)     # [n,4,1,L] view with channels_last strides
         f, _ = epilogue_ln(F.conv2d(f, self.stem_w, None, padding=(0, self.stem_pad)), self.stem_b, want_norm=False)
-        for w, b, pad, res in zip(self.ws, self.bs, self.pads, self.residual):
-            y = F.conv2d(f, w, None, padding=(0, pad))
-            f, _ = epilogue_ln(y, b, f if res else None, act=ACT_ADD_THEN_RELU, want_norm=False)   # relu(conv + b + f)
+        # measured (tools/conv_microbench.py): at 64->64 x 5 taps MIOpen's igemm (216 us) still beats our kernel
+        # (246 us), so the hand-written conv is opt-in for the tower
+        hip_conv = self.use_hip_conv and L in (200, 50) and n * L >= 192 * 200
+        for w, b, wp, pad, res in zip(self.ws, self.bs, self.wpacks, self.pads, self.residual):
+            if hip_conv and wp.numel():                               # conv + bias + residual + ReLU in one kernel
+                seq = f.permute(0, 2, 3, 1).reshape(n, L, 64)
+                f = conv1d_cl(seq, wp, 64, 5, 1, bias=b, f_prev=seq if res else None, act=ACT_ADD_THEN_RELU)
+                f = f.view(n, 1, L, 64).permute(0, 3, 1, 2)
+            else:
+                y = F.conv2d(f, w, None, padding=(0, pad))
+                f, _ = epilogue_ln(y, b, f if res else None, act=ACT_ADD_THEN_RELU, want_norm=False)   # relu(conv + b + f)
         seq = f.permute(0, 2, 3, 1).reshape(n, L, f.shape[1])       # [n,L,64] — a view, memory is already NLC
         h = gru_bidir(seq.contiguous(), self.wpack, self.bpack)
         # LayerNorm(h_fwd + h_bwd) in one pass (the direction sum of Enformer.py:1617 + dense1.norm)
@@ -184,6 +198,9 @@ class FusedBackbone(nn.Module):
                                         c.kernel_size[0] == 9 else nn.Parameter(torch.zeros(0), requires_grad=False)
                                         for c in cnn.convs])
         self.use_hip_conv = True
+        # in-kernel bias/ReLU/residual epilogue: fewer HBM passes but measured slower (its per-element residual
+        # loads sit on the tail of a 1-wave-per-SIMD kernel): 3.29 vs 2.93 ms per backbone forward. Off.
+        self.fuse_conv_epilogue = False
         self.bs = nn.ParameterList([nn.Parameter(c.bias.detach().clone(), requires_grad=False) for c in cnn.convs])
         self.dil = [c.dilation[0] for c in cnn.convs]
         self.norms = cnn.norms
@@ -209,12 +226,21 @@ class FusedBackbone(nn.Module):
         hip_conv = self.use_hip_conv and self.H == 128 and L in (200, 50) and B * L >= 192 * 200
         for i, (w, b) in enumerate(zip(self.ws, self.bs)):
             d = self.dil[i]
+            last = i + 1 == n
+            if hip_conv and self.fuse_conv_epilogue and self.wpacks[i].numel():
+                # f_{i+1} = relu(conv + b) + f_i inside the conv kernel; then hn_{i+1} = LN(f_{i+1} + tb_{i+1})
+                f = conv1d_cl(hn.permute(0, 2, 3, 1).reshape(B, L, self.H), self.wpacks[i], self.H, 9, d, bias=b,
+                              f_prev=f.permute(0, 2, 3, 1).reshape(B, L, self.H), act=ACT_RELU_THEN_ADD)
+                f = f.view(B, 1, L, self.H).permute(0, 3, 1, 2)
+                if not last:
+                    _, hn = epilogue_ln(f, None, None, self.tb[i + 1], self.norms[i + 1].weight, self.norms[i + 1].bias,
+                                        act=ACT_NONE, want_sum=False)
+                continue
             if hip_conv and self.wpacks[i].numel():
                 y = conv1d_cl(hn.permute(0, 2, 3, 1).reshape(B, L, self.H), self.wpacks[i], self.H, 9, d)
                 y = y.view(B, 1, L, self.H).permute(0, 3, 1, 2)
             else:
                 y = F.conv2d(hn, w, None, padding=(0, 4 * d), dilation=(1, d))
-            last = i + 1 == n
             # f_{i+1} = relu(y + b) + f_i ; hn_{i+1} = LN(f_{i+1} + tb_{i+1})           (:195-197, then :188-194)
             f, hn = epilogue_ln(y, b, f, None if last else self.tb[i + 1],
                                 None if last else self.norms[i + 1].weight, None if last else self.norms[i + 1].bias,

@@ -119,3 +119,18 @@ def test_conv1d_cl_kernel_vs_torch(n, L, cin, cout, T, dil):
     finally:
         _lib.lib().svdd_conv1d_set_dynamic(0)
     assert (y2.double() - ref).abs().max().item() <= 2e-5
+
+
+@pytest.mark.parametrize("n,L,cin,cout,T,dil,act", [(6, 200, 128, 128, 9, 4, 0), (6, 200, 128, 128, 9, 64, 0),
+                                                    (9, 200, 64, 64, 5, 1, 1), (9, 50, 64, 64, 5, 1, 1), (5, 200, 64, 64, 5, 1, 2)])
+def test_conv1d_cl_fused_epilogue(n, L, cin, cout, T, dil, act):
+    from svdd_amd.fused import conv1d_cl, pack_conv
+    torch.manual_seed(act + n)
+    x = torch.randn(n, L, cin, device=DEV)
+    w = torch.randn(cout, cin, T, device=DEV) / (cin * T) ** 0.5
+    b = torch.randn(cout, device=DEV)
+    fp = torch.randn(n, L, cout, device=DEV)
+    y = conv1d_cl(x, pack_conv(w), cout, T, dil, bias=b, f_prev=fp, act=act)
+    c = torch.nn.functional.conv1d(x.double().transpose(1, 2), w.double(), b.double(), padding=(T // 2) * dil, dilation=dil).transpose(1, 2)
+    ref = {0: torch.relu(c) + fp.double(), 1: torch.relu(c + fp.double()), 2: c + fp.double()}[act]
+    assert (y.double() - ref).abs().max().item() <= 2e-5
