@@ -11,10 +11,14 @@ tokens. Inputs are generated on the device (nothing crosses PCIe in the timed re
 Weak scaling: every rank decodes its own 256 rows (global rows rank*256 .. rank*256+255).
 
 Prints ONE JSON line (rank 0). Extra objects:
-  roofline      the dominant hand-written kernel, K1 propose: algorithmic bytes per launch
-                B*L*(21 + 17*M) / its mean launch duration, measured inside the timed region
-                with HIP start/stop events bound to each dispatch on its launch stream
-                (hipExtLaunchKernelGGL, svdd_profile_*), against the 8 TB/s HBM peak.
+  roofline      the dominant kernel of the job by time, the hand-written fp32-MFMA dilated conv of the
+                backbone (conv1d_cl_static_kernel, 20 launches per backbone forward): useful FLOPs per launch
+                (2*B*Cin*Cout*sum_t max(0, L-|t-4|*dil): multiplications with zero padding are not counted) /
+                its mean launch duration, against the 157.3 TFLOP/s dense fp32-MFMA peak.
+  roofline_sampler  the dominant kernel of the sampler itself, K1 propose: algorithmic bytes per launch
+                B*L*(21 + 17*M) / mean launch duration, against the 8 TB/s HBM peak.
+                All durations are measured inside the timed region with HIP start/stop events bound to each
+                dispatch on its launch stream (hipExtLaunchKernelGGL, svdd_profile_*).
   cpu_baseline  the CPU oracle port of the same workload, timed on this box's host cores on a bounded
                 sample (a few diffusion steps at full batch), extrapolated to a whole decode.
 """
@@ -118,15 +122,19 @@ def main():
     for _ in range(args.warmup):
         one_decode()
     fence()
-    _lib.profile_enable(True)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for k in range(args.steps):
+        if k == args.steps - 1:
+            _lib.profile_enable(True)      # per-dispatch HIP events on the LAST timed decode (a few us of host time per launch)
         out = one_decode()
     fence()
     elapsed = time.perf_counter() - t0
     _lib.profile_enable(False)
     k1_total_ms, k1_launches = _lib.profile_collect(0)
     k2_total_ms, k2_launches = _lib.profile_collect(1)
+    conv_total_ms, conv_launches = _lib.profile_collect(2)
+    gru_total_ms, gru_launches = _lib.profile_collect(3)
+    epi_total_ms, epi_launches = _lib.profile_collect(4)
     assert out.shape == (B * world, L) and int(out.max()) <= 3
     if world > 1:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -143,6 +151,16 @@ def main():
         achieved = k1_bytes / (k1_ms * 1e-3) / 1e9
         seqs = B * world * args.steps
         flops_seq = (CNNModel.flops_per_position() * L * (S + 1) + ConvGRUTrunk.flops_per_position() * L * S * M)
+        # useful FLOPs of the 20 dilated 128->128 x 9-tap convs of one backbone forward (dnaconv.py:151-156)
+        H = 128
+        conv_flops_fwd = sum(2.0 * B * H * H * sum(max(0, L - abs(t - 4) * d) for t in range(9))
+                             for d in (1, 1, 4, 16, 64) for _ in range(4))
+        conv_ms = conv_total_ms / max(conv_launches, 1)
+        conv_tf = (conv_flops_fwd / 20.0) / (conv_ms * 1e-3) / 1e12 if conv_launches else 0.0
+        pmc = {}
+        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc.json")
+        if os.path.exists(pmc_path) and (B, L, M) == (256, 200, 10):
+            pmc = json.load(open(pmc_path))                    # separate --pmc passes, see the file
         line = {
             "metric": "decoded sequences/sec (whole node), L=200 M=10 128-step SVDD-MC",
             "value": round(seqs / elapsed, 3), "unit": "sequences/s", "n_gpus": world,
@@ -152,11 +170,20 @@ def main():
             "config": {"workload": f"DNA enhancer SVDD-MC, batch={B}/GPU, L={L}, M={M}, {S} steps "
                                    f"(BASELINE.json configs[1]); dilated-CNN backbone 3.3M params + ConvGRU value net",
                        "global_batch": B * world, "rng": args.rng, "sharding": f"rows x{world}, 1 all-gather"},
-            "roofline": {"bound": "hbm", "kernel": "propose_kernel (K1)", "achieved": round(achieved, 2),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "traffic": traffic, "bytes_per_launch": k1_bytes, "avg_launch_us": round(k1_ms * 1e3, 3),
-                         "launches": k1_launches,
-                         "select_kernel_avg_launch_us": round(k2_total_ms / max(k2_launches, 1) * 1e3, 3)},
+            "roofline": {"bound": "mfma", "kernel": "conv1d_cl_static_kernel<128,128,9,dil,200> (backbone dilated conv, "
+                                                     "dil 1,1,4,16,64 x4 per forward)",
+                         "achieved": round(conv_tf, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(conv_tf / FP32_PEAK_TFLOPS, 5), "traffic": pmc.get("conv_traffic_bytes_per_launch"),
+                         "flops_per_launch": round(conv_flops_fwd / 20.0), "avg_launch_us": round(conv_ms * 1e3, 3),
+                         "launches": conv_launches},
+            "roofline_sampler": {"bound": "hbm", "kernel": "propose_kernel (K1)", "achieved": round(achieved, 2),
+                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                                 "traffic": pmc.get("k1_traffic_bytes_per_launch", traffic), "bytes_per_launch": k1_bytes,
+                                 "avg_launch_us": round(k1_ms * 1e3, 3), "launches": k1_launches,
+                                 "select_kernel_avg_launch_us": round(k2_total_ms / max(k2_launches, 1) * 1e3, 3)},
+            "own_kernels_ms_per_decode": {"conv1d": round(conv_total_ms, 2), "gru": round(gru_total_ms, 2),
+                                          "epilogue_ln": round(epi_total_ms, 2),
+                                          "propose": round(k1_total_ms, 3), "select": round(k2_total_ms, 3)},
             "e2e_fp32_frac": round(flops_seq * seqs / elapsed / 1e12 / (FP32_PEAK_TFLOPS * world), 5),
         }
         if args.cpu_steps > 0 and world == 1:

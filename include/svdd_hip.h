@@ -191,10 +191,12 @@ int svdd_epilogue_ln_f32(const float* y, const float* bias, const float* f_prev,
  *   wpack [taps][cin/32][cout][32] = W[co][32c + k][t]   (svdd_amd/fused.py:pack_conv).
  *   Replaces the nn.Conv1d calls of reference models/dnaconv.py:151-156,196 and Enformer.py:2245-2253,2271. */
 int svdd_conv1d_cl_f32(const float* x, const float* wpack, float* y, int n, int L, int cin, int cout,
-                       int taps, int dilation, const float* bias, const float* f_prev, int act, void* stream);
+                       int taps, int dilation, const float* bias, const float* f_prev, int act,
+                       const float* tb, const float* gamma, const float* beta, float* hn, void* stream);
 /*   fused epilogue (specialised shapes only: 128->128 x 9 taps x dilation {1,4,16,64}, 64->64 x 5 taps; L in {200,50}):
  *   act -1: y = conv ; 0: y = relu(conv + bias) + f_prev ; 1: y = relu(conv + bias + f_prev) ; 2: y = conv + bias + f_prev
- *   (bias, f_prev may be NULL).  Other shapes take the generic kernel and require act = -1. */
+ *   (bias, f_prev may be NULL); with hn != NULL additionally hn = LayerNorm(y + tb) * gamma + beta (eps 1e-5), the
+ *   next layer's normalised input (tb may be NULL).  Other shapes take the generic kernel and require act = -1. */
 /* tests only: != 0 forces the dynamically scheduled kernel instead of the per-(dilation,L) specialisations */
 int svdd_conv1d_set_dynamic(int on);
 
@@ -205,8 +207,8 @@ enum { SVDD_OPT_FORCE_EXACT = 0,
        SVDD_OPT_MSPLIT = 1 /* tuning: waves per 64-position tile in svdd_propose, 0 = auto */ };
 int svdd_set_option(int key, int value);
 
-/* Per-launch kernel timing (host). While enabled, svdd_propose (kernel 0) and svdd_select (kernel 1)
- * are dispatched with HIP start/stop events bound to the dispatch on its launch stream
+/* Per-launch kernel timing (host). While enabled, svdd_propose (kernel 0), svdd_select (1), svdd_conv1d_cl_f32 (2),
+ * svdd_gru_bidir_f32 (3) and svdd_epilogue_ln_f32 (4) are dispatched with HIP start/stop events bound to the dispatch on its launch stream
  * (hipExtLaunchKernelGGL); svdd_profile_collect waits for the recorded launches, returns the summed
  * hipEventElapsedTime and their count, and clears the record. Not for use during graph capture. */
 int svdd_profile_enable(int on);

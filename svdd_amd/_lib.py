@@ -82,7 +82,7 @@ def lib():
     L.svdd_selftest_fastmath.argtypes = [ctypes.POINTER(ctypes.c_double)]
     L.svdd_gru_bidir_f32.argtypes = [vp, vp, vp, vp, i32, i32, vp]
     L.svdd_conv1d_set_dynamic.argtypes = [i32]
-    L.svdd_conv1d_cl_f32.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, i32, vp]
+    L.svdd_conv1d_cl_f32.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp]
     L.svdd_epilogue_ln_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_int64, i32, i32, vp]
     L.svdd_profile_enable.argtypes = [i32]
     L.svdd_profile_collect.argtypes = [i32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]

@@ -567,10 +567,10 @@ __global__ __launch_bounds__(1024) void tds_resample_kernel(TdsArgs a) {
 // hipExtLaunchKernelGGL start/stop events, i.e. HIP events bound to the dispatch itself on the launch
 // stream; svdd_profile_collect() sums hipEventElapsedTime over the recorded launches.
 struct TimedLaunch { hipEvent_t start, stop; };
-constexpr int PROFILE_KERNELS = 2;            // 0 = propose (K1), 1 = select (K2)
+constexpr int PROFILE_KERNELS = 5;            // 0 propose (K1), 1 select (K2), 2 conv1d, 3 gru, 4 epilogue_ln
 bool g_profile = false;
-TimedLaunch* g_timed[PROFILE_KERNELS] = {nullptr, nullptr};
-int g_timed_n[PROFILE_KERNELS] = {0, 0}, g_timed_cap[PROFILE_KERNELS] = {0, 0};
+TimedLaunch* g_timed[PROFILE_KERNELS] = {};
+int g_timed_n[PROFILE_KERNELS] = {}, g_timed_cap[PROFILE_KERNELS] = {};
 
 TimedLaunch* timed_slot(int k) {
   if (!g_profile) return nullptr;
@@ -604,6 +604,13 @@ int svdd_set_option(int key, int value) {
   if (key == SVDD_OPT_FORCE_EXACT) { g_force_exact = value ? 1 : 0; return SVDD_OK; }
   if (key == SVDD_OPT_MSPLIT && value >= 0 && value <= 64) { g_msplit = value; return SVDD_OK; }
   return SVDD_E_ARG;
+}
+
+// used by svdd_nets.hip: start/stop events for a timed launch of net kernel k (nullptrs when profiling is off)
+void svdd_internal_timed_events(int k, hipEvent_t* e0, hipEvent_t* e1) {
+  TimedLaunch* t = timed_slot(k);
+  *e0 = t ? t->start : nullptr;
+  *e1 = t ? t->stop : nullptr;
 }
 
 int svdd_profile_enable(int on) {

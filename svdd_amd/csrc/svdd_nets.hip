@@ -10,13 +10,23 @@
 //                      operands), the hidden state in LDS, and runs the recurrence on the exact-fp32
 //                      matrix cores (v_mfma_f32_16x16x4_f32, 96 per wave-step).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include "svdd_hip.h"
 
+extern "C" void svdd_internal_timed_events(int k, hipEvent_t* e0, hipEvent_t* e1);   // svdd_kernels.hip (profiling)
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
 
 constexpr int H = 64;          // hidden = input width
 constexpr int TS = 16;         // sequences per workgroup (MFMA M)
@@ -135,11 +145,6 @@ struct EpiArgs {
   float* f_out; float* hn; int64_t R; int act;
 };
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
-}
 
 template <int VPL>
 __global__ __launch_bounds__(256) void epilogue_ln_kernel(EpiArgs a) {
@@ -204,6 +209,7 @@ struct ConvArgs {
   const float* x; const float* wpack; float* y;
   int n, L, spt /*sequences per tile*/, T, dil;
   const float* bias; const float* f_prev; int act;      // fused epilogue (static kernels): act -1 = raw conv output
+  const float* tb; const float* gamma; const float* beta; float* hn;   // + LayerNorm(y + tb) of the next layer (hn != NULL)
 };
 
 // 16 MFMAs of one 32-row tile: A = 4 float4 (16 consecutive input channels of this lane's row), B = bf[16]
@@ -526,22 +532,83 @@ __global__ __launch_bounds__(256) void conv1d_cl_static_kernel(ConvArgs a) {
       par ^= 1;
     }
   }
-  // epilogue: act -1 raw conv output ; 0 relu(v + bias) + f_prev ; 1 relu(v + bias + f_prev) ; 2 v + bias + f_prev
-  const float bias = (a.act >= 0 && a.bias) ? a.bias[32 * ct + i] : 0.0f;
+  // ---- epilogue ----
+  if (a.act < 0) {                                        // raw conv output straight from the accumulators
 #pragma unroll
-  for (int r = 0; r < NRT; ++r) {
+    for (int r = 0; r < NRT; ++r) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int tr = 32 * (rg + r * RGROUPS) + (e & 3) + 8 * (e >> 2) + 4 * h;
-      if (tr < TILE_ROWS && row0 + tr < total_rows) {
-        const int64_t o = (row0 + tr) * COUT + 32 * ct + i;
-        float v = acc[r][e];
-        if (a.act >= 0) {
-          v += bias;
-          const float p = a.f_prev ? a.f_prev[o] : 0.0f;
-          v = a.act == 0 ? fmaxf(v, 0.0f) + p : a.act == 1 ? fmaxf(v + p, 0.0f) : v + p;
+      for (int e = 0; e < 16; ++e) {
+        const int tr = 32 * (rg + r * RGROUPS) + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (tr < TILE_ROWS && row0 + tr < total_rows) a.y[(row0 + tr) * COUT + 32 * ct + i] = acc[r][e];
+      }
+    }
+    return;
+  }
+  // Fused: the accumulator tile goes through LDS (two halves of 128 rows: it does not fit at once) so that the
+  // residual read, the f store and the LayerNorm run row-wise with fully coalesced 256/512-B rows:
+  //   t = conv + bias ; f = act 0: relu(t) + f_prev | 1: relu(t + f_prev) | 2: t + f_prev ; hn = LN(f + tb)*gamma + beta
+  constexpr int EP = COUT + 4;                            // LDS row stride of the epilogue tile
+  constexpr int VPL = COUT / 64;                          // channels per lane in the row-wise pass
+  float* Es = smem;
+  const float bias_c = a.bias ? a.bias[32 * ct + i] : 0.0f;
+  float tbv[VPL], gmv[VPL], btv[VPL];
+#pragma unroll
+  for (int k = 0; k < VPL; ++k) {
+    tbv[k] = (a.hn && a.tb) ? a.tb[lane * VPL + k] : 0.0f;
+    gmv[k] = a.hn ? a.gamma[lane * VPL + k] : 1.0f;
+    btv[k] = a.hn ? a.beta[lane * VPL + k] : 0.0f;
+  }
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    __syncthreads();                                      // main loop / previous half is done with this LDS
+#pragma unroll
+    for (int r = 0; r < NRT; ++r) {
+      const int rt = rg + r * RGROUPS;
+      if (rt / 4 != half || rt >= CONV_RT) continue;      // scalar-uniform
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int lr = 32 * (rt - 4 * half) + (e & 3) + 8 * (e >> 2) + 4 * h;
+        Es[lr * EP + 32 * ct + i] = acc[r][e] + bias_c;
+      }
+    }
+    __syncthreads();
+    const int nrows = min(128, TILE_ROWS - 128 * half);
+    constexpr int RB = 8;                                 // rows in flight per wave: the residual loads are issued together
+    for (int base = 0; base < nrows; base += 4 * RB) {
+      float p[RB][VPL];
+#pragma unroll
+      for (int j = 0; j < RB; ++j) {
+        const int lr = base + 4 * j + w;
+        const int64_t gr = row0 + 128 * half + lr;
+#pragma unroll
+        for (int k = 0; k < VPL; ++k)
+          p[j][k] = (a.f_prev && lr < nrows && gr < total_rows) ? a.f_prev[gr * COUT + lane * VPL + k] : 0.0f;
+      }
+#pragma unroll
+      for (int j = 0; j < RB; ++j) {
+        const int lr = base + 4 * j + w;
+        const int64_t gr = row0 + 128 * half + lr;
+        if (lr >= nrows || gr >= total_rows) continue;    // wave-uniform
+        const int64_t o = gr * COUT + lane * VPL;
+        float v[VPL];
+        float sum = 0.0f;
+#pragma unroll
+        for (int k = 0; k < VPL; ++k) {
+          const float t = Es[lr * EP + lane * VPL + k];
+          v[k] = a.act == 0 ? fmaxf(t, 0.0f) + p[j][k] : a.act == 1 ? fmaxf(t + p[j][k], 0.0f) : t + p[j][k];
+          a.y[o + k] = v[k];
+          v[k] += tbv[k];
+          sum += v[k];
         }
-        a.y[o] = v;
+        if (a.hn) {
+          const float mean = wave_sum(sum) * (1.0f / COUT);
+          float q = 0.0f;
+#pragma unroll
+          for (int k = 0; k < VPL; ++k) { const float d = v[k] - mean; q += d * d; }
+          const float rstd = rsqrtf(wave_sum(q) * (1.0f / COUT) + 1e-5f);
+#pragma unroll
+          for (int k = 0; k < VPL; ++k) a.hn[o + k] = (v[k] - mean) * rstd * gmv[k] + btv[k];
+        }
       }
     }
   }
@@ -552,8 +619,10 @@ __global__ __launch_bounds__(256) void conv1d_cl_static_kernel(ConvArgs a) {
 extern "C" int svdd_gru_bidir_f32(const float* x, const float* wpack, const float* bpack, float* out, int n, int L,
                                   void* stream) {
   if (!x || !wpack || !bpack || !out || n <= 0 || L <= 0) return SVDD_E_ARG;
-  hipLaunchKernelGGL(gru_bidir_kernel, dim3((unsigned)((n + TS - 1) / TS), 2), dim3(256), 0, (hipStream_t)stream,
-                     x, wpack, bpack, out, n, L);
+  hipEvent_t e0, e1;
+  svdd_internal_timed_events(3, &e0, &e1);
+  hipExtLaunchKernelGGL(gru_bidir_kernel, dim3((unsigned)((n + TS - 1) / TS), 2), dim3(256), 0, (hipStream_t)stream,
+                        e0, e1, 0, x, wpack, bpack, out, n, L);
   return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
 }
 
@@ -564,10 +633,12 @@ extern "C" int svdd_epilogue_ln_f32(const float* y, const float* bias, const flo
   EpiArgs a{y, bias, f_prev, tb, gamma, beta, f_out, hn, rows, act};
   const int64_t nblocks = (rows + 3) / 4;
   const unsigned grid = (unsigned)(nblocks < 4096 ? nblocks : 4096);
-  if (channels == 64) hipLaunchKernelGGL(epilogue_ln_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
-  else if (channels == 128) hipLaunchKernelGGL(epilogue_ln_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
-  else if (channels == 256) hipLaunchKernelGGL(epilogue_ln_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
-  else return SVDD_E_ARG;
+  hipEvent_t e0, e1;
+  if (channels != 64 && channels != 128 && channels != 256) return SVDD_E_ARG;
+  svdd_internal_timed_events(4, &e0, &e1);
+  if (channels == 64) hipExtLaunchKernelGGL(epilogue_ln_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, e0, e1, 0, a);
+  else if (channels == 128) hipExtLaunchKernelGGL(epilogue_ln_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, e0, e1, 0, a);
+  else hipExtLaunchKernelGGL(epilogue_ln_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, e0, e1, 0, a);
   return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
 }
 
@@ -576,17 +647,19 @@ extern "C" int svdd_conv1d_set_dynamic(int on) { g_conv_dynamic = on; return SVD
 
 extern "C" int svdd_conv1d_cl_f32(const float* x, const float* wpack, float* y, int n, int L, int cin, int cout,
                                   int taps, int dilation, const float* bias, const float* f_prev, int act,
-                                  void* stream) {
+                                  const float* tb, const float* gamma, const float* beta, float* hn, void* stream) {
   if (!x || !wpack || !y || n <= 0 || L <= 0 || L > CONV_ROWS || taps <= 0 || !(taps & 1) || dilation <= 0 ||
-      act < -1 || act > 2)
+      act < -1 || act > 2 || (hn && (act < 0 || !gamma || !beta)))
     return SVDD_E_ARG;
   const int spt = CONV_ROWS / L;                               // whole sequences per workgroup tile
-  ConvArgs a{x, wpack, y, n, L, spt, taps, dilation, bias, f_prev, act};
+  ConvArgs a{x, wpack, y, n, L, spt, taps, dilation, bias, f_prev, act, tb, gamma, beta, hn};
   const unsigned grid = (unsigned)((n + spt - 1) / spt);
   auto launch = [&](auto kern, int co) {
     const size_t lds = sizeof(float) * ((size_t)(CONV_ROWS + 1) * CHP + 2 * (size_t)co * CHP);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, (hipStream_t)stream, a);
+    hipEvent_t e0, e1;
+    svdd_internal_timed_events(2, &e0, &e1);
+    hipExtLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, (hipStream_t)stream, e0, e1, 0, a);
   };
   const bool dyn = g_conv_dynamic != 0;
   if (!dyn && cin == 128 && cout == 128 && taps == 9 && (L == 200 || L == 50)) {

@@ -65,6 +65,10 @@ def gru_bidir(x_nlc, wpack, bpack):
     return out
 
 
+def _ptr(t):
+    return t.data_ptr() if t is not None else None
+
+
 def pack_conv(weight):
     """Conv1d weight [cout, cin, taps] -> [taps][cin/32][cout][32] for svdd_conv1d_cl_f32."""
     co, ci, T = weight.shape
@@ -72,22 +76,20 @@ def pack_conv(weight):
     return weight.detach().float().permute(2, 1, 0).reshape(T, ci // 32, 32, co).permute(0, 1, 3, 2).contiguous()
 
 
-def conv1d_cl(x_nlc, wpack, cout, taps, dilation, bias=None, f_prev=None, act=-1):
+def conv1d_cl(x_nlc, wpack, cout, taps, dilation, bias=None, f_prev=None, act=-1, ln=None):
     """x [n, L, cin] fp32 contiguous -> y [n, L, cout], HIP kernel svdd_conv1d_cl_f32.
-    act -1: raw conv (no bias); 0: relu(conv + bias) + f_prev; 1: relu(conv + bias + f_prev); 2: conv + bias + f_prev."""
+    act -1: raw conv (no bias); 0: relu(conv + bias) + f_prev; 1: relu(conv + bias + f_prev); 2: conv + bias + f_prev.
+    ln = (tb | None, gamma, beta): also returns hn = LayerNorm(y + tb) * gamma + beta -> (y, hn)."""
     assert x_nlc.is_cuda and x_nlc.dtype == torch.float32 and x_nlc.is_contiguous()
     n, L, cin = x_nlc.shape
     y = torch.empty((n, L, cout), dtype=torch.float32, device=x_nlc.device)
+    hn = torch.empty_like(y) if ln is not None else None
+    tb, gamma, beta = ln if ln is not None else (None, None, None)
     rc = _lib.lib().svdd_conv1d_cl_f32(x_nlc.data_ptr(), wpack.data_ptr(), y.data_ptr(), n, L, cin, cout, taps, dilation,
-                                       bias.data_ptr() if bias is not None else None,
-                                       f_prev.data_ptr() if f_prev is not None else None, int(act),
+                                       _ptr(bias), _ptr(f_prev), int(act), _ptr(tb), _ptr(gamma), _ptr(beta), _ptr(hn),
                                        ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     _lib.check(rc, "svdd_conv1d_cl_f32")
-    return y
-
-
-def _ptr(t):
-    return t.data_ptr() if t is not None else None
+    return y if ln is None else (y, hn)
 
 
 ACT_RELU_THEN_ADD, ACT_ADD_THEN_RELU, ACT_NONE = 0, 1, 2
@@ -198,8 +200,10 @@ class FusedBackbone(nn.Module):
                                         c.kernel_size[0] == 9 else nn.Parameter(torch.zeros(0), requires_grad=False)
                                         for c in cnn.convs])
         self.use_hip_conv = True
-        # in-kernel bias/ReLU/residual epilogue: fewer HBM passes but measured slower (its per-element residual
-        # loads sit on the tail of a 1-wave-per-SIMD kernel): 3.29 vs 2.93 ms per backbone forward. Off.
+        # In-kernel epilogue (bias/ReLU/residual + the next layer's LayerNorm, row-wise through LDS): saves one HBM
+        # round trip of the activations but serialises a memory-bound tail behind the MFMA loop of a 1-workgroup-
+        # per-CU kernel; measured 3.29 ms vs 2.93 ms per backbone forward with the separate 19-us epilogue kernel
+        # (which runs at 5.5 TB/s chip-wide). Kept for testing, off by default.
         self.fuse_conv_epilogue = False
         self.bs = nn.ParameterList([nn.Parameter(c.bias.detach().clone(), requires_grad=False) for c in cnn.convs])
         self.dil = [c.dilation[0] for c in cnn.convs]
@@ -229,12 +233,15 @@ class FusedBackbone(nn.Module):
             last = i + 1 == n
             if hip_conv and self.fuse_conv_epilogue and self.wpacks[i].numel():
                 # f_{i+1} = relu(conv + b) + f_i inside the conv kernel; then hn_{i+1} = LN(f_{i+1} + tb_{i+1})
-                f = conv1d_cl(hn.permute(0, 2, 3, 1).reshape(B, L, self.H), self.wpacks[i], self.H, 9, d, bias=b,
-                              f_prev=f.permute(0, 2, 3, 1).reshape(B, L, self.H), act=ACT_RELU_THEN_ADD)
+                xin = hn.permute(0, 2, 3, 1).reshape(B, L, self.H)
+                fp = f.permute(0, 2, 3, 1).reshape(B, L, self.H)
+                if last:
+                    f = conv1d_cl(xin, self.wpacks[i], self.H, 9, d, bias=b, f_prev=fp, act=ACT_RELU_THEN_ADD)
+                else:
+                    f, hn = conv1d_cl(xin, self.wpacks[i], self.H, 9, d, bias=b, f_prev=fp, act=ACT_RELU_THEN_ADD,
+                                      ln=(self.tb[i + 1], self.norms[i + 1].weight, self.norms[i + 1].bias))
+                    hn = hn.view(B, 1, L, self.H).permute(0, 3, 1, 2)
                 f = f.view(B, 1, L, self.H).permute(0, 3, 1, 2)
-                if not last:
-                    _, hn = epilogue_ln(f, None, None, self.tb[i + 1], self.norms[i + 1].weight, self.norms[i + 1].bias,
-                                        act=ACT_NONE, want_sum=False)
                 continue
             if hip_conv and self.wpacks[i].numel():
                 y = conv1d_cl(hn.permute(0, 2, 3, 1).reshape(B, L, self.H), self.wpacks[i], self.H, 9, d)

@@ -134,3 +134,9 @@ def test_conv1d_cl_fused_epilogue(n, L, cin, cout, T, dil, act):
     c = torch.nn.functional.conv1d(x.double().transpose(1, 2), w.double(), b.double(), padding=(T // 2) * dil, dilation=dil).transpose(1, 2)
     ref = {0: torch.relu(c) + fp.double(), 1: torch.relu(c + fp.double()), 2: c + fp.double()}[act]
     assert (y.double() - ref).abs().max().item() <= 2e-5
+    # + the next layer's LayerNorm in the same kernel
+    tb, gm, bt = torch.randn(cout, device=DEV), torch.randn(cout, device=DEV), torch.randn(cout, device=DEV)
+    y2, hn = conv1d_cl(x, pack_conv(w), cout, T, dil, bias=b, f_prev=fp, act=act, ln=(tb, gm, bt))
+    ref_hn = torch.nn.functional.layer_norm(ref + tb.double(), (cout,), gm.double(), bt.double(), eps=1e-5)
+    assert torch.equal(y2, y)
+    assert (hn.double() - ref_hn).abs().max().item() <= 5e-5
