@@ -94,6 +94,8 @@ def main():
     ap.add_argument("--diffusion-steps", type=int, default=128)
     ap.add_argument("--cpu-steps", type=int, default=8, help="diffusion steps timed for cpu_baseline (0 = skip)")
     ap.add_argument("--rng", default="philox", choices=["philox", "replay"])
+    ap.add_argument("--value-net", default="convgru", choices=["convgru", "enformer"],
+                    help="enformer: the 230M-parameter Enformer-shaped value trunk of BASELINE config 4 (not the headline config)")
     args = ap.parse_args()
 
     from svdd_amd import _lib, distributed, synthetic
@@ -107,7 +109,7 @@ def main():
     dev = f"cuda:{local}"
     B, L, M, S = args.batch, args.length, args.sample_M, args.diffusion_steps
 
-    model, emb, head, _ = synthetic.build("dna" if L == 200 else "rna", dev)
+    model, emb, head, _ = synthetic.build("dna" if L == 200 else "rna", dev, value=args.value_net)
     model.rng_mode, model.philox_seed, model.row_offset = args.rng, 0, rank * B
 
     def one_decode():
@@ -186,7 +188,10 @@ def main():
                                           "propose": round(k1_total_ms, 3), "select": round(k2_total_ms, 3)},
             "e2e_fp32_frac": round(flops_seq * seqs / elapsed / 1e12 / (FP32_PEAK_TFLOPS * world), 5),
         }
-        if args.cpu_steps > 0 and world == 1:
+        if args.value_net != "convgru":
+            line["config"]["workload"] += " [value net: Enformer-shaped trunk, 230M params — BASELINE configs[3] shape]"
+            line["e2e_fp32_frac"] = None
+        if args.cpu_steps > 0 and world == 1 and args.value_net == "convgru":
             line["cpu_baseline"] = cpu_baseline(B, L, M, S, args.cpu_steps)
         else:
             line["cpu_baseline"] = None

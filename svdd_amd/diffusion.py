@@ -130,7 +130,7 @@ class Diffusion(nn.Module):
     def _backbone_logits(self, x_u8):
         """Raw backbone output for tokens x (sigma is zeroed when time_conditioning is False, :334-335)."""
         if isinstance(self.backbone, CNNModel) and not self.time_conditioning:
-            if self.fuse_nets and x_u8.is_cuda:
+            if self.fuse_nets and x_u8.is_cuda and self.backbone.args.hidden_dim in (64, 128, 256):
                 return self._fused_backbone()(x_u8)
             return self.backbone(x_u8, None, zero_sigma=True)
         sigma = torch.zeros(x_u8.shape[0], device=x_u8.device)

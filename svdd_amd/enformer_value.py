@@ -1,0 +1,214 @@
+"""Enformer-shaped value trunk — the value-function architecture of BASELINE.json config 4
+(`decode.py:78-80`: `EnformerTrunk(n_conv=7, channels=1536, n_transformers=11, n_heads=8, key_len=64)`
++ `ConvHead(1, 3072, pool_func='avg')`), as a self-contained PyTorch-ROCm module.
+
+Why self-contained: the reference builds this trunk from `enformer_pytorch` (lucidrains), an un-vendored,
+un-pinned dependency that is absent offline (`Enformer.py:8-9`) — its `Attention`,
+`AttentionPool`, `GELU`, `relative_shift`, `exponential_linspace_int` cannot be imported, so there is no
+reference output to pin against: **parity unpinned** for this module. It follows the layer structure of the
+reference wrapper (`Enformer.py:1271-1334` trunk, `:1807-1884` conv tower, `:1887-2007` transformer tower,
+`:2176-2292` ConvBlock order "NACDR") and the published Enformer design (Avsec et al. 2021: attention pooling,
+relative positional attention with exponential / central-mask / gamma basis functions). To the SVDD hot path
+it is an opaque callable with the value-function interface `fp32 [n, L, 4] -> [n, C, L']`.
+
+Attention runs through `F.scaled_dot_product_attention` with the relative-position logits as an additive
+bias, so ROCm's fused SDPA kernels are used where available.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+
+def exponential_linspace_int(start, end, num, divisible_by=1):
+    base = math.exp(math.log(end / start) / (num - 1))
+    return [int(round(start * base ** i / divisible_by) * divisible_by) for i in range(num)]
+
+
+class EnformerGELU(nn.Module):
+    """x * sigmoid(1.702 x) — the tanh-free GELU approximation Enformer uses ("gelu_enformer")."""
+
+    def forward(self, x):
+        return x * torch.sigmoid(1.702 * x)
+
+
+class AttentionPool(nn.Module):
+    """Softmax-weighted pooling over windows of `pool_size` positions with per-channel logits from a 1x1
+    projection (initialised to 2*identity, i.e. close to max-pooling). Pads to a multiple of the window."""
+
+    def __init__(self, dim, pool_size=2):
+        super().__init__()
+        self.pool_size = pool_size
+        self.to_attn_logits = nn.Conv2d(dim, dim, 1, bias=False)
+        nn.init.dirac_(self.to_attn_logits.weight)
+        with torch.no_grad():
+            self.to_attn_logits.weight.mul_(2)
+
+    def forward(self, x):                                   # [n, C, L]
+        n, c, length = x.shape
+        pad = (-length) % self.pool_size
+        if pad:
+            x = F.pad(x, (0, pad))
+        x = x.view(n, c, -1, self.pool_size)
+        logits = self.to_attn_logits(x)
+        if pad:
+            mask = torch.zeros(x.shape[2] * self.pool_size, dtype=torch.bool, device=x.device)
+            mask[-pad:] = True
+            logits = logits.masked_fill(mask.view(1, 1, -1, self.pool_size), -torch.finfo(logits.dtype).max)
+        return (x * logits.softmax(dim=-1)).sum(dim=-1)
+
+
+class ConvBlockNACDR(nn.Module):
+    """BatchNorm -> GELU -> Conv1d('same') -> dropout -> (+ input), optional attention pooling
+    (reference ConvBlock with order="NACDR", Enformer.py:2269-2292)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, residual=False, pool=False, dropout=0.0):
+        super().__init__()
+        self.norm = nn.BatchNorm1d(in_channels)
+        self.act = EnformerGELU()
+        self.conv = nn.Conv1d(in_channels, out_channels, kernel_size, padding="same")
+        self.dropout = nn.Dropout(dropout) if dropout > 0 else nn.Identity()
+        self.residual = residual
+        self.pool = AttentionPool(out_channels, 2) if pool else nn.Identity()
+
+    def forward(self, x):
+        y = self.dropout(self.conv(self.act(self.norm(x))))
+        if self.residual:
+            y = y + x
+        return self.pool(y)
+
+
+class EnformerConvTower(nn.Module):
+    """Stem (Conv 4 -> C/2, k=15; residual 1x1 block; pool) + n_blocks-1 x [k=5 block; residual 1x1 block; pool],
+    channels growing geometrically C/2 -> C in multiples of 128 (reference Enformer.py:1807-1884)."""
+
+    def __init__(self, n_blocks, out_channels):
+        super().__init__()
+        half = out_channels // 2
+        self.blocks = nn.ModuleList([nn.Sequential(nn.Conv1d(4, half, 15, padding="same"),
+                                                   ConvBlockNACDR(half, half, 1, residual=True, pool=True))])
+        filters = [half] + exponential_linspace_int(half, out_channels, num=n_blocks - 1, divisible_by=128)
+        for i in range(1, n_blocks):
+            self.blocks.append(nn.Sequential(ConvBlockNACDR(filters[i - 1], filters[i], 5),
+                                             ConvBlockNACDR(filters[i], filters[i], 1, residual=True, pool=True)))
+
+    def forward(self, x):
+        for blk in self.blocks:
+            x = blk(x)
+        return x
+
+
+def _positional_features(length, num_features, device):
+    """Enformer's relative-position basis over distances -(L-1)..(L-1): three families (exponential decay,
+    central mask, gamma pdf), each num_features/6 wide, concatenated with their sign-antisymmetric copies."""
+    assert num_features % 6 == 0
+    nb = num_features // 6
+    dist = torch.arange(-length + 1, length, device=device, dtype=torch.float32)
+    ad = dist.abs()[:, None]
+    # exponential: half-lives geometrically spaced between 3 and L
+    max_range = math.log2(length)
+    half_life = 2 ** torch.linspace(3.0, max_range, nb, device=device)[None, :]
+    f_exp = torch.exp(-math.log(2.0) / half_life * ad)
+    # central mask: |d| <= 2^(i+1) - 1
+    widths = (2 ** torch.arange(1, nb + 1, device=device, dtype=torch.float32) - 1)[None, :]
+    f_mask = (widths > ad).float()
+    # gamma pdf with means spread over the sequence
+    stddev = length / (2 * nb)
+    start_mean = length / nb
+    mean = torch.linspace(start_mean, float(length), nb, device=device)[None, :]
+    conc = (mean / stddev) ** 2
+    rate = mean / stddev ** 2
+    log_unnorm = torch.xlogy(conc - 1.0, ad) - rate * ad
+    log_norm = torch.lgamma(conc) - conc * torch.log(rate)
+    f_gamma = torch.exp(log_unnorm - log_norm) + 1e-8
+    f_gamma = f_gamma / f_gamma.amax()
+    feats = torch.cat([f_exp, f_mask, f_gamma], dim=-1)
+    return torch.cat([feats, torch.sign(dist)[:, None] * feats], dim=-1)        # [2L-1, num_features]
+
+
+def _relative_shift(x):
+    """[.., L, 2L-1] logits indexed by relative distance -> [.., L, L] indexed by key position."""
+    *lead, t1, t2 = x.shape
+    x = torch.cat([torch.zeros_like(x[..., :1]), x], dim=-1)
+    x = x.reshape(*lead, t2 + 1, t1)[..., 1:, :].reshape(*lead, t1, t2)
+    return x[..., : (t2 + 1) // 2]
+
+
+class RelPosAttention(nn.Module):
+    def __init__(self, dim, heads, dim_key, dim_value, num_rel_pos_features):
+        super().__init__()
+        self.heads, self.dim_key, self.dim_value = heads, dim_key, dim_value
+        self.num_rel_pos_features = num_rel_pos_features
+        self.to_q = nn.Linear(dim, dim_key * heads, bias=False)
+        self.to_k = nn.Linear(dim, dim_key * heads, bias=False)
+        self.to_v = nn.Linear(dim, dim_value * heads, bias=False)
+        self.to_out = nn.Linear(dim_value * heads, dim)
+        nn.init.zeros_(self.to_out.weight)
+        nn.init.zeros_(self.to_out.bias)
+        self.to_rel_k = nn.Linear(num_rel_pos_features, dim_key * heads, bias=False)
+        self.rel_content_bias = nn.Parameter(torch.randn(1, heads, 1, dim_key))
+        self.rel_pos_bias = nn.Parameter(torch.randn(1, heads, 1, dim_key))
+
+    def forward(self, x):                                   # [n, L, dim]
+        n, length, _ = x.shape
+        h = self.heads
+        q = self.to_q(x).view(n, length, h, self.dim_key).transpose(1, 2) * self.dim_key ** -0.5
+        k = self.to_k(x).view(n, length, h, self.dim_key).transpose(1, 2)
+        v = self.to_v(x).view(n, length, h, self.dim_value).transpose(1, 2)
+        pos = _positional_features(length, self.num_rel_pos_features, x.device)
+        rel_k = self.to_rel_k(pos).view(2 * length - 1, h, self.dim_key).transpose(0, 1)        # [h, 2L-1, dk]
+        rel_logits = _relative_shift(torch.einsum("bhid,hjd->bhij", q + self.rel_pos_bias, rel_k))
+        # content logits (q + content bias) k^T plus the positional logits as an additive bias; scale already in q
+        out = F.scaled_dot_product_attention(q + self.rel_content_bias, k, v, attn_mask=rel_logits, scale=1.0)
+        return self.to_out(out.transpose(1, 2).reshape(n, length, h * self.dim_value))
+
+
+class TransformerBlock(nn.Module):
+    """x + MHA(LN(x)); then x + FFN(x), FFN = LN -> Linear(C,2C) -> ReLU -> Linear(2C,C)
+    (reference Enformer.py:1887-1949 with the FeedForwardBlock of :2010-2047)."""
+
+    def __init__(self, dim, heads, key_len):
+        super().__init__()
+        self.norm = nn.LayerNorm(dim)
+        self.mha = RelPosAttention(dim, heads, key_len, dim // heads, dim // heads)
+        self.ffn_norm = nn.LayerNorm(dim)
+        self.ffn1 = nn.Linear(dim, 2 * dim)
+        self.ffn2 = nn.Linear(2 * dim, dim)
+
+    def forward(self, x):
+        x = x + self.mha(self.norm(x))
+        return x + self.ffn2(F.relu(self.ffn1(self.ffn_norm(x))))
+
+
+class EnformerTrunk(nn.Module):
+    def __init__(self, n_conv=7, channels=1536, n_transformers=11, n_heads=8, key_len=64):
+        super().__init__()
+        self.conv_tower = EnformerConvTower(n_conv, channels)
+        self.transformer_tower = nn.ModuleList([TransformerBlock(channels, n_heads, key_len) for _ in range(n_transformers)])
+        self.pointwise_conv = ConvBlockNACDR(channels, channels * 2, 1)
+        self.act = EnformerGELU()
+
+    def forward(self, x):                                   # [n, L, 4] (value-function call) -> [n, 2C, L']
+        x = self.conv_tower(x.transpose(1, 2))
+        x = x.transpose(1, 2)
+        for blk in self.transformer_tower:
+            x = blk(x)
+        return self.act(self.pointwise_conv(x.transpose(1, 2)))
+
+    @staticmethod
+    def flops_per_sequence(length=200, n_conv=7, channels=1536, n_transformers=11, n_heads=8, key_len=64):
+        """Approximate MAC*2 count of one forward (conv tower + transformer tower + pointwise)."""
+        half = channels // 2
+        filters = [half] + exponential_linspace_int(half, channels, num=n_conv - 1, divisible_by=128)
+        fl, cur = 0, length
+        fl += cur * (4 * half * 15 + half * half)
+        cur = (cur + 1) // 2
+        for i in range(1, n_conv):
+            fl += cur * (filters[i - 1] * filters[i] * 5 + filters[i] * filters[i])
+            cur = (cur + 1) // 2
+        dv = channels // n_heads
+        per_tok = channels * key_len * n_heads * 2 + channels * dv * n_heads * 2 + 4 * channels * channels
+        fl += n_transformers * (cur * per_tok + cur * cur * n_heads * (2 * key_len + dv))
+        fl += cur * channels * 2 * channels
+        return 2 * fl

@@ -8,7 +8,8 @@ from .diffusion import Diffusion
 from .value_nets import ConvGRUTrunk, ConvHead, RewardModel
 
 
-def build(task="dna", device="cuda", seed=44, hidden_dim=128, num_cnn_stacks=4, value_channels=64, n_conv=6):
+def build(task="dna", device="cuda", seed=44, hidden_dim=128, num_cnn_stacks=4, value_channels=64, n_conv=6,
+          value="convgru", enformer_kwargs=None):
     """-> (Diffusion, embedding, head, reward_model) in eval mode on `device`.
 
     task "dna": L=200 (configs_gosai) ; "rna": L=50 (configs_gosai_rna). The value function is the
@@ -17,9 +18,16 @@ def build(task="dna", device="cuda", seed=44, hidden_dim=128, num_cnn_stacks=4, 
     torch.manual_seed(seed)
     cfg = (dna_config if task == "dna" else rna_config)(hidden_dim=hidden_dim, num_cnn_stacks=num_cnn_stacks)
     model = Diffusion(cfg)
-    embedding = ConvGRUTrunk(stem_in_channels=4, stem_channels=value_channels, stem_kernel_size=15, n_conv=n_conv,
-                             channel_init=value_channels, kernel_size=5, dropout=0.1)
-    head = ConvHead(1, value_channels)
+    if value == "enformer":      # BASELINE config 4: decode.py:78-80 EnformerTrunk(7 conv, 1536 ch, 11 transformers) + ConvHead(1, 3072)
+        from .enformer_value import EnformerTrunk
+        kw = dict(n_conv=7, channels=1536, n_transformers=11, n_heads=8, key_len=64)
+        kw.update(enformer_kwargs or {})
+        embedding = EnformerTrunk(**kw)
+        head = ConvHead(1, 2 * kw["channels"])
+    else:
+        embedding = ConvGRUTrunk(stem_in_channels=4, stem_channels=value_channels, stem_kernel_size=15, n_conv=n_conv,
+                                 channel_init=value_channels, kernel_size=5, dropout=0.1)
+        head = ConvHead(1, value_channels)
     reward = RewardModel(ConvGRUTrunk(stem_in_channels=4, stem_channels=value_channels, stem_kernel_size=15,
                                       n_conv=n_conv, channel_init=value_channels, kernel_size=5, dropout=0.1),
                          ConvHead(1, value_channels))

@@ -233,3 +233,18 @@ def test_cli_writes_reference_npz(tmp_path, method, suffix):
     assert set(z.files) == {"decoding", "baseline"} and z["decoding"].shape == (8,) and z["baseline"].shape == (8,)
     samples, vpred, rpred, topk, base = out
     assert len(samples) == 2 and samples[0].shape == (4, 50) and vpred.shape == (8,) and topk.shape == (8,)
+
+
+def test_mc_decode_with_enformer_shaped_value_net():
+    """Config-4 shape in miniature: SVDD-MC with an Enformer-shaped value trunk (opaque nn.Module to the
+    sampler); the oracle recomputes every step from the recorded logits / scores."""
+    from svdd_amd import synthetic
+    model, emb, head, _ = synthetic.build("dna", DEV, hidden_dim=32, num_cnn_stacks=1, value="enformer",
+                                          enformer_kwargs=dict(n_conv=4, channels=384, n_transformers=2, n_heads=2, key_len=16))
+    B, L, M, S = 3, 200, 4, 6
+    sched = model._schedule(S, 1e-5)[0]
+    model.rng_mode, model.philox_seed, model.trace = "philox", 11, []
+    x_gpu = model.controlled_sample(emb, head, num_steps=S, eval_sp_size=B, sample_M=M).cpu().numpy()
+    trace = _trace_np(model)
+    x_orc = orc.replay_controlled_sample(trace, sched, B, L, M, seed=11)
+    assert np.array_equal(x_gpu, x_orc)

@@ -51,3 +51,30 @@ def test_value_and_reward_match_reference(golden):
 
 def test_flop_formulas():
     assert CNNModel.flops_per_position() == 5_943_808
+
+
+def test_enformer_shaped_value_trunk():
+    """Config-4 value function shape (decode.py:78-80): self-contained Enformer-shaped trunk + ConvHead; parity
+    unpinned (enformer_pytorch is absent offline) — interface, sizes and the relative-shift indexing are checked."""
+    from svdd_amd.enformer_value import EnformerTrunk, _relative_shift, exponential_linspace_int
+    from svdd_amd.value_nets import ConvHead
+    assert exponential_linspace_int(768, 1536, 6, 128) == [768, 896, 1024, 1152, 1280, 1536]
+    L = 5
+    r = torch.arange(2 * L - 1).float().repeat(L, 1)[None, None]
+    want = torch.tensor([[(j - i) + (L - 1) for j in range(L)] for i in range(L)]).float()
+    assert torch.equal(_relative_shift(r)[0, 0], want)            # logits indexed by (key - query) distance
+    torch.manual_seed(0)
+    trunk = EnformerTrunk(n_conv=4, channels=384, n_transformers=2, n_heads=2, key_len=16).eval()
+    head = ConvHead(1, 768).eval()
+    x = torch.zeros(3, 200, 4)
+    x.scatter_(2, torch.randint(0, 4, (3, 200, 1)), 1.0)
+    with torch.no_grad():
+        y = trunk(x)
+        s = head(y)
+        s2 = head(trunk(x[1:2]))
+    assert y.shape == (3, 768, 13) and s.shape == (3, 1, 1) and torch.isfinite(s).all()
+    assert torch.allclose(s[1:2], s2, atol=1e-5)                   # rows independent (eval-mode BN)
+    with torch.device("meta"):
+        full = EnformerTrunk()
+    n_params = sum(p.numel() for p in full.parameters())
+    assert 225e6 < n_params < 235e6                                # SURVEY: ~230 M parameters
