@@ -173,6 +173,8 @@ int svdd_tds_resample(const float* reward_num, const float* reward_den, float al
  *   wpack [2][4][64][96], bpack [2][4][64]: weights repacked per MFMA lane, see svdd_amd/fused.py:pack_gru. */
 int svdd_gru_bidir_f32(const float* x, const float* wpack, const float* bpack, float* out, int n, int L,
                        void* stream);
+/* tests / experiments: 2 selects the both-directions-per-workgroup scheduling (balanced but measured slower), else default */
+int svdd_gru_set_mode(int mode);
 
 /* svdd_epilogue_ln_f32 — fused convolution epilogue (+ next layer's LayerNorm) on channels-last rows [rows, C],
  *   C in {64,128,256}: t = y + bias ; f_out = relu(t) + f_prev (act 0) | relu(t + f_prev) (act 1) | t + f_prev (act 2);

@@ -45,16 +45,23 @@ __device__ __forceinline__ float tanh_fast(float a) {
 //        [0:16) W_ir[u][k]  [16:32) W_hr[u][k]  [32:48) W_iz  [48:64) W_hz  [64:80) W_in  [80:96) W_hn
 // bpack  [2 dirs][4][64] : b_ir+b_hr, b_iz+b_hz, b_in, b_hn
 // out    [2 dirs][n, L, 64] : hidden state of each direction at every timestep
-__global__ __launch_bounds__(256) void gru_bidir_kernel(const float* __restrict__ x, const float* __restrict__ wpack,
-                                                        const float* __restrict__ bpack, float* __restrict__ out,
-                                                        int n, int L) {
-  __shared__ __attribute__((aligned(16))) float hbuf[2][TS][HPAD];
+// BOTH = false: one workgroup (4 waves) per (16-sequence tile, direction), grid (tiles, 2).
+// BOTH = true : one workgroup (8 waves) per tile of `ts` <= 16 sequences runs BOTH directions, two waves per SIMD
+//               interleaving their MFMAs; with ts = ceil(n / 256) every CU gets exactly one workgroup (n = 2560:
+//               ts = 10), instead of 320 single-direction workgroups leaving 3/4 of the chip idle for the second
+//               half of the launch.
+template <bool BOTH>
+__global__ __launch_bounds__(BOTH ? 512 : 256) void gru_bidir_kernel(const float* __restrict__ x, const float* __restrict__ wpack,
+                                                                     const float* __restrict__ bpack, float* __restrict__ out,
+                                                                     int n, int L, int ts) {
+  __shared__ __attribute__((aligned(16))) float hbuf_all[BOTH ? 2 : 1][2][TS][HPAD];
   const int lane = threadIdx.x & 63;
-  const int w = threadIdx.x >> 6;
-  const int dir = blockIdx.y;
+  const int w = (threadIdx.x >> 6) & 3;
+  const int dir = BOTH ? (int)(threadIdx.x >> 8) : (int)blockIdx.y;
+  float (*hbuf)[TS][HPAD] = hbuf_all[BOTH ? dir : 0];
   const int j = lane & 15;            // hidden unit within the wave's 16 / sequence row for A operands
   const int g = lane >> 4;            // k-group of A/B operands ; row-group of C/D
-  const int seq0 = blockIdx.x * TS;
+  const int seq0 = blockIdx.x * ts;
 
   // B operands: this lane's 96 weights stay in registers for the whole sequence
   float wr[96];
@@ -71,12 +78,12 @@ __global__ __launch_bounds__(256) void gru_bidir_kernel(const float* __restrict_
   const float b_nx = bpack[(dir * 4 + 2) * H + u], b_nh = bpack[(dir * 4 + 3) * H + u];
 
   // A-operand source row for this lane (clamped for the ragged last tile)
-  const int arow = min(seq0 + j, n - 1);
+  const int arow = min(seq0 + min(j, ts - 1), n - 1);
   const float* xrow = x + (size_t)arow * L * H + 16 * g;
   float hprev[4] = {0.0f, 0.0f, 0.0f, 0.0f};   // h[seq = 4g + rho][u] of the previous step
 
   // h_0 = 0
-  for (int i = threadIdx.x; i < TS * HPAD; i += 256) (&hbuf[0][0][0])[i] = 0.0f;
+  for (int i = threadIdx.x & 255; i < TS * HPAD; i += 256) (&hbuf[0][0][0])[i] = 0.0f;
 
   const int t0 = dir == 0 ? 0 : L - 1;
   const int dt = dir == 0 ? 1 : -1;
@@ -123,7 +130,7 @@ __global__ __launch_bounds__(256) void gru_bidir_kernel(const float* __restrict_
       hprev[rho] = hn;
       const int srow = 4 * g + rho;
       hbuf[cur ^ 1][srow][u] = hn;
-      if (seq0 + srow < n) out[(((size_t)dir * n + seq0 + srow) * L + t) * H + u] = hn;
+      if (srow < ts && seq0 + srow < n) out[(((size_t)dir * n + seq0 + srow) * L + t) * H + u] = hn;
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i) xa[i] = xn[i];
@@ -616,13 +623,22 @@ __global__ __launch_bounds__(256) void conv1d_cl_static_kernel(ConvArgs a) {
 
 }  // namespace
 
+static int g_gru_mode = 0;         // 2 selects the both-directions-per-workgroup variant (tests / experiments)
+extern "C" int svdd_gru_set_mode(int mode) { g_gru_mode = mode; return SVDD_OK; }
+
 extern "C" int svdd_gru_bidir_f32(const float* x, const float* wpack, const float* bpack, float* out, int n, int L,
                                   void* stream) {
   if (!x || !wpack || !bpack || !out || n <= 0 || L <= 0) return SVDD_E_ARG;
   hipEvent_t e0, e1;
   svdd_internal_timed_events(3, &e0, &e1);
-  hipExtLaunchKernelGGL(gru_bidir_kernel, dim3((unsigned)((n + TS - 1) / TS), 2), dim3(256), 0, (hipStream_t)stream,
-                        e0, e1, 0, x, wpack, bpack, out, n, L);
+  // both directions per workgroup when that fills the chip evenly (<= 16 sequences per CU); else one direction each
+  const int per_cu = (n + 255) / 256;
+  if (g_gru_mode == 2 && per_cu <= TS && n >= 256)   // measured slower (841 vs 758 us at n=2560, L=200): opt-in only
+    hipExtLaunchKernelGGL(gru_bidir_kernel<true>, dim3((unsigned)((n + per_cu - 1) / per_cu)), dim3(512), 0,
+                          (hipStream_t)stream, e0, e1, 0, x, wpack, bpack, out, n, L, per_cu);
+  else
+    hipExtLaunchKernelGGL(gru_bidir_kernel<false>, dim3((unsigned)((n + TS - 1) / TS), 2), dim3(256), 0,
+                          (hipStream_t)stream, e0, e1, 0, x, wpack, bpack, out, n, L, TS);
   return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
 }
 

@@ -16,9 +16,12 @@ def nets():
     return synthetic.build("dna", DEV)
 
 
-@pytest.mark.parametrize("n,L", [(16, 200), (37, 50), (2560, 200), (1, 7)])
-def test_gru_kernel_vs_torch(n, L):
+@pytest.mark.parametrize("mode", [0, 2])            # 0: one direction per workgroup (default), 2: both directions per workgroup
+@pytest.mark.parametrize("n,L", [(16, 200), (37, 50), (2560, 200), (1, 7), (300, 50), (4000, 20)])
+def test_gru_kernel_vs_torch(n, L, mode):
+    from svdd_amd import _lib
     from svdd_amd.fused import gru_bidir, pack_gru
+    _lib.lib().svdd_gru_set_mode(mode)
     torch.manual_seed(n)
     gru = torch.nn.GRU(64, 64, bidirectional=True, batch_first=True).to(DEV).eval()
     with torch.no_grad():
@@ -30,6 +33,7 @@ def test_gru_kernel_vs_torch(n, L):
         ref = gru(x)[0]
     out = gru_bidir(x, wpack.to(DEV), bpack.to(DEV))
     torch.cuda.synchronize()
+    _lib.lib().svdd_gru_set_mode(0)
     assert (out[0] - ref[:, :, :64]).abs().max().item() <= 2e-5
     assert (out[1] - ref[:, :, 64:]).abs().max().item() <= 2e-5
     # the recurrence itself, independently of MIOpen: fp64 on the CPU
