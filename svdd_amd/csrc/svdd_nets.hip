@@ -93,12 +93,23 @@ __global__ __launch_bounds__(BOTH ? 512 : 256) void gru_bidir_kernel(const float
 #pragma unroll
     for (int i = 0; i < 4; ++i) { const float4 v = xp[i]; xa[4 * i] = v.x; xa[4 * i + 1] = v.y; xa[4 * i + 2] = v.z; xa[4 * i + 3] = v.w; }
   }
+  // input projections of step 0 (they do not depend on h): acc = bias + x_0 W_i*
+  f32x4 acc_r = {b_r, b_r, b_r, b_r}, acc_z = {b_z, b_z, b_z, b_z}, acc_nx = {b_nx, b_nx, b_nx, b_nx};
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    acc_r = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[s], wr[s], acc_r, 0, 0, 0);
+    acc_z = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[s], wr[32 + s], acc_z, 0, 0, 0);
+    acc_nx = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[s], wr[64 + s], acc_nx, 0, 0, 0);
+  }
   __syncthreads();
 
+  // Per step the only serial chain is  barrier -> read h -> 48 recurrent MFMAs -> gates -> write h.
+  // The 48 input-projection MFMAs of the NEXT step are issued between the h write and the barrier, so they cover
+  // the barrier skew and the LDS write latency instead of adding to the chain.
   for (int step = 0; step < L; ++step) {
     const int t = t0 + dt * step;
     const int cur = step & 1;
-    if (step + 1 < L) {             // prefetch x_{t+1} under the MFMAs
+    if (step + 1 < L) {             // prefetch x_{t+1}
       const float4* xp = reinterpret_cast<const float4*>(xrow + (size_t)(t + dt) * H);
 #pragma unroll
       for (int i = 0; i < 4; ++i) { const float4 v = xp[i]; xn[4 * i] = v.x; xn[4 * i + 1] = v.y; xn[4 * i + 2] = v.z; xn[4 * i + 3] = v.w; }
@@ -109,13 +120,9 @@ __global__ __launch_bounds__(BOTH ? 512 : 256) void gru_bidir_kernel(const float
 #pragma unroll
       for (int i = 0; i < 4; ++i) { const float4 v = hp[i]; ha[4 * i] = v.x; ha[4 * i + 1] = v.y; ha[4 * i + 2] = v.z; ha[4 * i + 3] = v.w; }
     }
-    f32x4 acc_r = {b_r, b_r, b_r, b_r}, acc_z = {b_z, b_z, b_z, b_z};
-    f32x4 acc_nx = {b_nx, b_nx, b_nx, b_nx}, acc_nh = {b_nh, b_nh, b_nh, b_nh};
+    f32x4 acc_nh = {b_nh, b_nh, b_nh, b_nh};
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
-      acc_r = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[s], wr[s], acc_r, 0, 0, 0);
-      acc_z = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[s], wr[32 + s], acc_z, 0, 0, 0);
-      acc_nx = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[s], wr[64 + s], acc_nx, 0, 0, 0);
       acc_nh = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[s], wr[80 + s], acc_nh, 0, 0, 0);
       acc_r = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[s], wr[16 + s], acc_r, 0, 0, 0);
       acc_z = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[s], wr[48 + s], acc_z, 0, 0, 0);
@@ -132,8 +139,16 @@ __global__ __launch_bounds__(BOTH ? 512 : 256) void gru_bidir_kernel(const float
       hbuf[cur ^ 1][srow][u] = hn;
       if (srow < ts && seq0 + srow < n) out[(((size_t)dir * n + seq0 + srow) * L + t) * H + u] = hn;
     }
+    // next step's input projections (independent of the barrier below)
+    acc_r = f32x4{b_r, b_r, b_r, b_r}; acc_z = f32x4{b_z, b_z, b_z, b_z}; acc_nx = f32x4{b_nx, b_nx, b_nx, b_nx};
+    if (step + 1 < L) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) xa[i] = xn[i];
+      for (int s = 0; s < 16; ++s) {
+        acc_r = __builtin_amdgcn_mfma_f32_16x16x4f32(xn[s], wr[s], acc_r, 0, 0, 0);
+        acc_z = __builtin_amdgcn_mfma_f32_16x16x4f32(xn[s], wr[32 + s], acc_z, 0, 0, 0);
+        acc_nx = __builtin_amdgcn_mfma_f32_16x16x4f32(xn[s], wr[64 + s], acc_nx, 0, 0, 0);
+      }
+    }
     __syncthreads();
   }
 }
