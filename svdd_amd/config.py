@@ -60,3 +60,11 @@ def dna_config(**model_overrides):
 
 def rna_config(**model_overrides):
     return Config(model=ModelConfig(length=50, **model_overrides))
+
+
+def dit_config(length=200, **dit_overrides):
+    """backbone: dit (configs_gosai/model/small.yaml shape by default)."""
+    from .dit import DiTModelConfig
+    cfg = Config(backbone="dit")
+    cfg.model = DiTModelConfig(length=length, **dit_overrides)
+    return cfg

@@ -48,8 +48,11 @@ class Diffusion(nn.Module):
             self.backbone = backbone
         elif config.backbone == "cnn":
             self.backbone = CNNModel(config.model, alphabet_size=self.vocab_size, num_cls=3)   # :100-101
+        elif config.backbone == "dit":
+            # dead in the reference snapshot (models/__init__.py:1, needs CUDA-only flash_attn); here via ROCm SDPA
+            from .dit import DIT
+            self.backbone = DIT(config.model, vocab_size=self.vocab_size)                      # :102-104
         else:
-            # `dit` is dead in the reference snapshot (models/__init__.py:1); pass a module via backbone=
             raise ValueError(f"Unknown backbone: {config.backbone}")
         if self.parameterization != "subs":
             raise ValueError("only the `subs` parameterization is on the reference's decode path "

@@ -248,3 +248,29 @@ def test_mc_decode_with_enformer_shaped_value_net():
     trace = _trace_np(model)
     x_orc = orc.replay_controlled_sample(trace, sched, B, L, M, seed=11)
     assert np.array_equal(x_gpu, x_orc)
+
+
+def test_mc_decode_with_dit_backbone(small_nets):
+    """SVDD-MC over the DiT backbone (contiguous [B,L,5] logits: layout BLV, replay order [m][b][l][v])."""
+    from svdd_amd.config import dit_config
+    from svdd_amd.diffusion import Diffusion
+    _, emb, head, _ = small_nets
+    torch.manual_seed(3)
+    model = Diffusion(dit_config(length=50, hidden_size=64, cond_dim=32, n_blocks=2, n_heads=4, dropout=0.0)).to(DEV).eval()
+    with torch.no_grad():
+        for p in model.backbone.parameters():
+            if float(p.abs().max()) == 0.0:
+                p.normal_(0, 0.2)
+    B, L, M, S = 4, 50, 3, 8
+    sched = model._schedule(S, 1e-5)[0]
+    for mode in ("replay", "philox"):
+        model.rng_mode, model.philox_seed, model.trace = mode, 21, []
+        torch.manual_seed(9)
+        x_gpu = model.controlled_sample(emb, head, num_steps=S, eval_sp_size=B, sample_M=M).cpu().numpy()
+        trace = _trace_np(model)
+        uf = None
+        if mode == "replay":
+            torch.manual_seed(9)
+            uf = lambda i, M_, B_, L_: torch.rand(M_, B_, L_, 5).numpy()      # noqa: E731  contiguous logits: row-major stream
+        x_orc = orc.replay_controlled_sample(trace, sched, B, L, M, uniform_fn=uf, seed=21)
+        assert np.array_equal(x_gpu, x_orc)

@@ -78,3 +78,43 @@ def test_enformer_shaped_value_trunk():
         full = EnformerTrunk()
     n_params = sum(p.numel() for p in full.parameters())
     assert 225e6 < n_params < 235e6                                # SURVEY: ~230 M parameters
+
+
+def test_dit_backbone_structure():
+    """DiT backbone (dead code in the reference: parity unpinned). Checks the reference's parameter names, the
+    adaLN-zero init (zero logits at init, like the reference's zero-initialised final layer), and the attention
+    block against an explicit softmax formulation."""
+    from svdd_amd.config import dit_config
+    from svdd_amd.diffusion import Diffusion
+    from svdd_amd import dit as D
+    torch.manual_seed(0)
+    d = Diffusion(dit_config(length=50, hidden_size=64, cond_dim=32, n_blocks=2, n_heads=4, dropout=0.0)).eval()
+    names = set(d.backbone.state_dict())
+    for k in ("vocab_embed.embedding", "sigma_map.mlp.0.weight", "blocks.0.norm1.weight", "blocks.0.attn_qkv.weight",
+              "blocks.0.attn_out.weight", "blocks.0.mlp.2.bias", "blocks.1.adaLN_modulation.weight",
+              "output_layer.norm_final.weight", "output_layer.linear.weight", "output_layer.adaLN_modulation.bias"):
+        assert k in names, k
+    x = torch.randint(0, 5, (3, 50))
+    with torch.no_grad():
+        out = d.backbone(x, torch.zeros(3))
+        assert out.shape == (3, 50, 5) and out.is_contiguous() and float(out.abs().max()) == 0.0
+        for p in d.backbone.parameters():                      # un-zero the adaLN / output layers
+            if float(p.abs().max()) == 0.0:
+                p.normal_(0, 0.05)
+        out = d.backbone(x, torch.zeros(3))
+        # explicit evaluation of block 0's attention path
+        blk = d.backbone.blocks[0]
+        h0 = d.backbone.vocab_embed(x)
+        c = torch.nn.functional.silu(d.backbone.sigma_map(torch.zeros(3)))
+        sa, sc, ga, _, _, _ = blk.adaLN_modulation(c)[:, None].chunk(6, dim=2)
+        h = blk.norm1(h0) * (1 + sc) + sa
+        q, k, v = blk.attn_qkv(h).view(3, 50, 3, 4, 16).permute(2, 0, 3, 1, 4)
+        q, k = D._rotary(q, k)
+        att = torch.softmax(q @ k.transpose(-1, -2) / 4.0, -1) @ v
+        ref = h0 + ga * blk.attn_out(att.transpose(1, 2).reshape(3, 50, 64))
+        mid = h0 + ga * blk.attn_out(torch.nn.functional.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(3, 50, 64))
+    assert torch.allclose(ref, mid, atol=1e-5) and torch.isfinite(out).all() and float(out.abs().max()) > 0
+    # rotary: position 0 is unrotated, norms are preserved
+    qq = torch.randn(1, 2, 7, 16)
+    r, _ = D._rotary(qq, qq)
+    assert torch.allclose(r[:, :, 0], qq[:, :, 0]) and torch.allclose(r.norm(dim=-1), qq.norm(dim=-1), atol=1e-5)
