@@ -202,6 +202,14 @@ int svdd_conv1d_cl_f32(const float* x, const float* wpack, float* y, int n, int 
 /* tests only: != 0 forces the dynamically scheduled kernel instead of the per-(dilation,L) specialisations */
 int svdd_conv1d_set_dynamic(int on);
 
+/* svdd_conv_tower_f32 — the whole conv tower of the ConvGRU value net in one launch, activations resident in LDS:
+ *   a0 = relu(conv15(onehot) + b0) ; a_{k+1} = relu(conv5(a_k) + b_k [+ a_k])  (k < nlayers, 64 channels, dilation 1)
+ *   (reference Enformer.py:1634-1751: Stem + ConvBlocks "CDNRA"; eval-mode BatchNorm folded by the caller).
+ *   onehot [n,L,4] ; tiles [2 + 10*nlayers][64][32] weight tiles in execution order (svdd_amd/fused.py:pack_tower) ;
+ *   bias [1 + nlayers][64] ; out [n,L,64] ; residual_mask bit k = layer k adds its input ; L <= 208. */
+int svdd_conv_tower_f32(const float* onehot, const float* tiles, const float* bias, float* out, int n, int L,
+                        int nlayers, int residual_mask, void* stream);
+
 /* Process-wide options (host). SVDD_OPT_FORCE_EXACT != 0 makes svdd_propose evaluate every draw in the
  * exact (fp64, correctly rounded) arithmetic instead of the filtered fast path — same results, used
  * to A/B the filter. */

@@ -636,6 +636,156 @@ __global__ __launch_bounds__(256) void conv1d_cl_static_kernel(ConvArgs a) {
   }
 }
 
+// ------------------------------------------------------------------- fused conv tower (value network) ----
+// The whole ConvTower of the ConvGRU value net (reference Enformer.py:1634-1751 with the Stem :1754-1804 and five
+// ConvBlocks "CDNRA" :2176-2292; eval-mode BatchNorm folded into the weights by the host):
+//     a0 = relu(conv15(onehot) + b0) ;  a_{k+1} = relu(conv5(a_k) + b_k + a_k)   (k = 0..4, 64 channels)
+// in ONE launch, one workgroup per tile of whole sequences (<= 208 rows). The activations never leave the CU:
+// they ping-pong between two LDS images [rows][64] and are the MFMA A operands directly (a tap is a row offset;
+// rows outside the sequence read a zero row), so there is no activation traffic to HBM between layers (5 x 2 x
+// 131 MB per value forward at n = 2560), no separate bias/residual/ReLU pass and no im2col staging. Only the
+// weights stream through LDS (one [64][32] tile per (layer, tap, 32-channel chunk), register-prefetched).
+// v_mfma_f32_16x16x4_f32 with 16-row tiles: 13 row tiles x 4 column tiles = 52 units = 13 per SIMD exactly
+// (200 rows pad to 208: 4 % waste instead of 12 % with 32-row tiles). 8 waves: wave w owns column tile w & 3 and
+// the row tiles of parity w >> 2, so the two waves of a SIMD interleave their MFMA streams.
+constexpr int TW_ROWS = 208;               // 13 row tiles of 16
+constexpr int TW_RT = 13;
+constexpr int TW_C = 64;
+constexpr int TW_AP = TW_C + 4;            // LDS row stride of the activation images (floats)
+constexpr int TW_MAXL = 8;                 // max conv layers after the stem
+
+struct TowerArgs {
+  const float* x;        // [n, L, 4] one-hot (value-function input)
+  const float* tiles;    // [2 + 10*nlayers][64 cout][32] weight tiles in execution order:
+                         //   stem: k = 4*tap + channel (60 real, 4 zero), chunks 0,1 ; then per layer, per 32-channel chunk, per tap
+  const float* bias;     // [1 + nlayers][64]   stem bias, then the (BatchNorm-folded) layer biases
+  float* out;            // [n, L, 64]
+  int n, L, spt, nlayers, residual_mask;
+};
+
+// One LDS activation image only: a layer's outputs wait in the accumulators until every wave has finished reading
+// the image, then each wave overwrites the positions it owns (reading its own residual first). 79 KB of LDS and
+// <= 128 VGPRs per wave => TWO workgroups (16 waves) per CU, which overlap each other's barriers, LDS latency and
+// global stores.
+__global__ __launch_bounds__(512, 4) void conv_tower_kernel(TowerArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* act = smem;                                    // [TW_ROWS + 1][TW_AP]  (+1: zero row)
+  float* Bs = act + (TW_ROWS + 1) * TW_AP;              // [2][64][CHP]  weight tiles
+  float* xs = Bs + 2 * TW_C * CHP;                      // [TW_ROWS + 1][4]  one-hot tile (+1: zero row)
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cs = w & 3, rh = w >> 2;                    // column tile (16 channels) ; row-tile parity
+  const int j = lane & 15, g = lane >> 4;
+  const int L = a.L;
+  const int tile_rows = a.spt * L;
+  const int64_t row0 = (int64_t)blockIdx.x * tile_rows;
+  const int64_t total_rows = (int64_t)a.n * L;
+
+  for (int e = tid; e < TW_ROWS + 1; e += 512) {
+    float4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (e < tile_rows && row0 + e < total_rows) v = *reinterpret_cast<const float4*>(a.x + (row0 + e) * 4);
+    *reinterpret_cast<float4*>(xs + 4 * e) = v;
+  }
+  for (int e = tid; e < TW_AP; e += 512) act[TW_ROWS * TW_AP + e] = 0.0f;
+  const int b_r = tid >> 3, b_q = tid & 7;              // one float4 of the [64][32] tile per thread
+  const float* tsrc = a.tiles + b_r * CH + 4 * b_q;
+  float* bdst = Bs + b_r * CHP + 4 * b_q;
+  float4 bp = *reinterpret_cast<const float4*>(tsrc);
+  *reinterpret_cast<float4*>(bdst) = bp;
+
+  int arow[7], apos[7];
+#pragma unroll
+  for (int r = 0; r < 7; ++r) {
+    arow[r] = 16 * (rh + 2 * r) + j;
+    apos[r] = (rh + 2 * r < TW_RT && arow[r] < tile_rows) ? arow[r] % L : -(1 << 20);
+  }
+  const int nit = 2 + 10 * a.nlayers;
+  int it = 0, par = 0;
+  f32x4 acc[7];
+
+#define TW_MMA(R0, R1)                                                                                        \
+  _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                             \
+    _Pragma("unroll") for (int r = R0; r < R1; ++r) if (!(r == 6 && rh == 1)) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r - R0][q].x, bf[4 * q], acc[r], 0, 0, 0);     \
+    _Pragma("unroll") for (int r = R0; r < R1; ++r) if (!(r == 6 && rh == 1)) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r - R0][q].y, bf[4 * q + 1], acc[r], 0, 0, 0); \
+    _Pragma("unroll") for (int r = R0; r < R1; ++r) if (!(r == 6 && rh == 1)) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r - R0][q].z, bf[4 * q + 2], acc[r], 0, 0, 0); \
+    _Pragma("unroll") for (int r = R0; r < R1; ++r) if (!(r == 6 && rh == 1)) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r - R0][q].w, bf[4 * q + 3], acc[r], 0, 0, 0); \
+  }
+
+  for (int layer = -1; layer < a.nlayers; ++layer) {     // layer -1 = the stem (15 taps x 4 channels as K = 64)
+    const float bl = a.bias[(layer + 1) * TW_C + 16 * cs + j];
+#pragma unroll
+    for (int r = 0; r < 7; ++r) acc[r] = f32x4{bl, bl, bl, bl};
+    const int niter = layer < 0 ? 2 : 10;
+    for (int ci = 0; ci < niter; ++ci, ++it) {
+      if (it + 1 < nit) bp = *reinterpret_cast<const float4*>(tsrc + (size_t)(it + 1) * TW_C * CH);   // flies under the MFMAs
+      __syncthreads();                                   // Bs[par] and the activation image are visible
+      float bf[8];
+      {
+        const float4* bq = reinterpret_cast<const float4*>(Bs + par * TW_C * CHP + (16 * cs + j) * CHP + 8 * g);
+        const float4 v0 = bq[0], v1 = bq[1];
+        bf[0] = v0.x; bf[1] = v0.y; bf[2] = v0.z; bf[3] = v0.w; bf[4] = v1.x; bf[5] = v1.y; bf[6] = v1.z; bf[7] = v1.w;
+      }
+      float4 af[4][2];
+      if (layer < 0) {
+        // k = 32 ci + 8 g + s covers taps t0 = 8 ci + 2 g and t0 + 1 (4 channels each): two float4 of the one-hot tile
+        const int t0 = 8 * ci + 2 * g;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          const int r0 = half ? 4 : 0, r1 = half ? 7 : 4;
+#pragma unroll
+          for (int r = r0; r < r1; ++r) {
+            if (r == 6 && rh == 1) continue;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+              const int p = apos[r] + t0 + q - 7;
+              af[r - r0][q] = *reinterpret_cast<const float4*>(xs + 4 * ((p >= 0 && p < L) ? arow[r] + t0 + q - 7 : TW_ROWS));
+            }
+          }
+          if (half == 0) { TW_MMA(0, 4) } else { TW_MMA(4, 7) }
+        }
+      } else {
+        const int c = ci / 5, delta = ci - 5 * c - 2;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          const int r0 = half ? 4 : 0, r1 = half ? 7 : 4;
+#pragma unroll
+          for (int r = r0; r < r1; ++r) {
+            if (r == 6 && rh == 1) continue;
+            const int p = apos[r] + delta;
+            const float4* ap = reinterpret_cast<const float4*>(act + ((p >= 0 && p < L) ? arow[r] + delta : TW_ROWS) * TW_AP + 32 * c + 8 * g);
+            af[r - r0][0] = ap[0]; af[r - r0][1] = ap[1];
+          }
+          if (half == 0) { TW_MMA(0, 4) } else { TW_MMA(4, 7) }
+        }
+      }
+      if (it + 1 < nit) *reinterpret_cast<float4*>(bdst + (par ^ 1) * TW_C * CHP) = bp;
+      par ^= 1;
+    }
+    // every wave must be done reading the image before its owners overwrite it (the stem reads xs, not the image)
+    if (layer >= 0) __syncthreads();
+    const bool res = layer >= 0 && ((a.residual_mask >> layer) & 1);
+#pragma unroll
+    for (int r = 0; r < 7; ++r) {
+      if (r == 6 && rh == 1) continue;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {                      // C/D layout: reg e -> row 4 g + e, column j
+        const int row = 16 * (rh + 2 * r) + 4 * g + e;
+        const int o = row * TW_AP + 16 * cs + j;
+        const float v = acc[r][e] + (res ? act[o] : 0.0f);
+        act[o] = row < tile_rows ? fmaxf(v, 0.0f) : 0.0f;
+      }
+    }
+  }
+#undef TW_MMA
+  __syncthreads();
+  for (int e = tid; e < tile_rows * 16; e += 512) {      // final image -> HBM, 16 B per thread, rows contiguous
+    const int row = e >> 4, q = e & 15;
+    if (row0 + row < total_rows)
+      *reinterpret_cast<float4*>(a.out + (row0 + row) * TW_C + 4 * q) = *reinterpret_cast<const float4*>(act + row * TW_AP + 4 * q);
+  }
+}
+
 }  // namespace
 
 static int g_gru_mode = 0;         // 2 selects the both-directions-per-workgroup variant (tests / experiments)
@@ -710,5 +860,20 @@ extern "C" int svdd_conv1d_cl_f32(const float* x, const float* wpack, float* y, 
   else if (cin == 64 && cout == 128) launch(conv1d_cl_kernel<64, 128>, 128);
   else if (cin == 128 && cout == 64) launch(conv1d_cl_kernel<128, 64>, 64);
   else return SVDD_E_ARG;
+  return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
+}
+
+extern "C" int svdd_conv_tower_f32(const float* onehot, const float* tiles, const float* bias, float* out, int n, int L,
+                                   int nlayers, int residual_mask, void* stream) {
+  if (!onehot || !tiles || !bias || !out || n <= 0 || L <= 0 || L > TW_ROWS || nlayers <= 0 || nlayers > TW_MAXL)
+    return SVDD_E_ARG;
+  const int spt = TW_ROWS / L;
+  TowerArgs a{onehot, tiles, bias, out, n, L, spt, nlayers, residual_mask};
+  const size_t lds = sizeof(float) * ((size_t)(TW_ROWS + 1) * TW_AP + 2 * (size_t)TW_C * CHP + (size_t)(TW_ROWS + 1) * 4);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_tower_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipEvent_t e0, e1;
+  svdd_internal_timed_events(2, &e0, &e1);
+  hipExtLaunchKernelGGL(conv_tower_kernel, dim3((unsigned)((n + spt - 1) / spt)), dim3(512), lds, (hipStream_t)stream,
+                        e0, e1, 0, a);
   return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
 }

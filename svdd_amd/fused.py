@@ -95,6 +95,35 @@ def conv1d_cl(x_nlc, wpack, cout, taps, dilation, bias=None, f_prev=None, act=-1
 ACT_RELU_THEN_ADD, ACT_ADD_THEN_RELU, ACT_NONE = 0, 1, 2
 
 
+def pack_tower(stem_weight, layer_weights):
+    """Weight tiles [2 + 10*nlayers][64][32] in the execution order of svdd_conv_tower_f32.
+    stem_weight [64,4,15]: K index k = 4*tap + channel (60 real + 4 zero), two 32-wide chunks;
+    each layer weight [64,64,5] (BatchNorm already folded): for chunk c in (0,1), for tap t in 0..4: W[:, 32c:32c+32, t]."""
+    co = stem_weight.shape[0]
+    k = stem_weight.detach().float().permute(0, 2, 1).reshape(co, 60)                  # [co][4*t + c]
+    k = torch.cat([k, k.new_zeros(co, 4)], dim=1)
+    tiles = [k[:, :32], k[:, 32:]]
+    for w in layer_weights:
+        w = w.detach().float()
+        for c in range(2):
+            for t in range(5):
+                tiles.append(w[:, 32 * c: 32 * c + 32, t])
+    return torch.stack([t.contiguous() for t in tiles]).contiguous()
+
+
+def conv_tower(onehot, tiles, bias, residual_mask):
+    """onehot [n, L, 4] fp32 -> [n, L, 64]: stem + (len(bias) - 1) residual conv layers in ONE launch
+    (HIP kernel svdd_conv_tower_f32, activations resident in LDS)."""
+    assert onehot.is_cuda and onehot.dtype == torch.float32 and onehot.is_contiguous() and onehot.shape[2] == 4
+    n, L, _ = onehot.shape
+    out = torch.empty((n, L, 64), dtype=torch.float32, device=onehot.device)
+    rc = _lib.lib().svdd_conv_tower_f32(onehot.data_ptr(), tiles.data_ptr(), bias.data_ptr(), out.data_ptr(), n, L,
+                                        bias.shape[0] - 1, int(residual_mask),
+                                        ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    _lib.check(rc, "svdd_conv_tower_f32")
+    return out
+
+
 def epilogue_ln(y, bias=None, f_prev=None, tb=None, gamma=None, beta=None, act=ACT_RELU_THEN_ADD, want_norm=True,
                 want_sum=True):
     """Fused conv epilogue on channels-last rows (HIP kernel svdd_epilogue_ln_f32):
@@ -125,7 +154,7 @@ class FusedValueNet(nn.Module):
         self.stem_w = nn.Parameter(_cl(blocks[0].conv.weight), requires_grad=False)
         self.stem_b = nn.Parameter(blocks[0].conv.bias.detach().clone(), requires_grad=False)
         self.stem_pad = blocks[0].conv.kernel_size[0] // 2
-        ws, bs, wpacks, self.pads, self.residual = [], [], [], [], []
+        ws, bs, wpacks, folded_ws, self.pads, self.residual = [], [], [], [], [], []
         for blk in blocks[1:]:
             w, b = blk.conv.weight.detach(), blk.conv.bias.detach()
             bn = blk.norm.layer
@@ -134,6 +163,7 @@ class FusedValueNet(nn.Module):
                 w = w * s[:, None, None]
                 b = (b - bn.running_mean) * s + bn.bias.detach()
             assert not blk.residual or isinstance(blk.channel_transform.layer, nn.Identity)
+            folded_ws.append(w)
             ws.append(nn.Parameter(_cl(w), requires_grad=False))
             bs.append(nn.Parameter(b.clone(), requires_grad=False))
             wpacks.append(nn.Parameter(pack_conv(w) if tuple(w.shape) == (64, 64, 5) and blk.conv.dilation[0] == 1
@@ -142,6 +172,17 @@ class FusedValueNet(nn.Module):
             self.residual.append(blk.residual)
         self.ws, self.bs, self.wpacks = nn.ParameterList(ws), nn.ParameterList(bs), nn.ParameterList(wpacks)
         self.use_hip_conv = False
+        # the whole tower as one LDS-resident kernel when it has the reference shape: stem 4->64 x 15, then 64->64 x 5
+        stem = blocks[0].conv
+        self.tower_ok = (tuple(stem.weight.shape) == (64, 4, 15) and 1 <= len(ws) <= 8 and
+                         all(tuple(w.shape) == (64, 64, 5) for w in folded_ws) and
+                         all(blk.conv.dilation[0] == 1 for blk in blocks[1:]))
+        if self.tower_ok:
+            self.tw_tiles = nn.Parameter(pack_tower(stem.weight, folded_ws), requires_grad=False)
+            self.tw_bias = nn.Parameter(torch.stack([stem.bias.detach()] + [b.detach() for b in bs]).contiguous(),
+                                        requires_grad=False)
+            self.tw_resmask = sum(1 << k for k, r in enumerate(self.residual) if r)
+        self.use_fused_tower = True
         gt = embedding.gru_tower
         wpack, bpack = pack_gru(gt.gru)
         self.register_buffer("wpack", wpack)
@@ -164,6 +205,9 @@ class FusedValueNet(nn.Module):
         if x.shape[1] == self.in_channels and x.shape[2] != self.in_channels:
             x = x.transpose(1, 2)                                   # reward-model layout [n,4,L] -> [n,L,4]
         n, L, C = x.shape
+        if self.use_fused_tower and self.tower_ok and L <= 208 and x.is_cuda:
+            seq = conv_tower(x.contiguous(), self.tw_tiles, self.tw_bias, self.tw_resmask)
+            return self._after_tower(seq, n, L)
         f = x.contiguous().view(n, 1, L, C).permute(0, 3, 1, 2)     # [n,4,1,L] view with channels_last strides
         f, _ = epilogue_ln(F.conv2d(f, self.stem_w, None, padding=(0, self.stem_pad)), self.stem_b, want_norm=False)
         # measured (tools/conv_microbench.py): at 64->64 x 5 taps MIOpen's igemm (216 us) still beats our kernel
@@ -178,7 +222,10 @@ class FusedValueNet(nn.Module):
                 y = F.conv2d(f, w, None, padding=(0, pad))
                 f, _ = epilogue_ln(y, b, f if res else None, act=ACT_ADD_THEN_RELU, want_norm=False)   # relu(conv + b + f)
         seq = f.permute(0, 2, 3, 1).reshape(n, L, f.shape[1])       # [n,L,64] — a view, memory is already NLC
-        h = gru_bidir(seq.contiguous(), self.wpack, self.bpack)
+        return self._after_tower(seq.contiguous(), n, L)
+
+    def _after_tower(self, seq, n, L):
+        h = gru_bidir(seq, self.wpack, self.bpack)
         # LayerNorm(h_fwd + h_bwd) in one pass (the direction sum of Enformer.py:1617 + dense1.norm)
         _, hn = epilogue_ln(h[0], None, h[1], None, self.ln_w, self.ln_b, act=ACT_NONE, want_sum=False)
         z = F.relu(F.linear(hn, self.w1, self.b1))                  # [n,L,128]

@@ -144,3 +144,31 @@ def test_conv1d_cl_fused_epilogue(n, L, cin, cout, T, dil, act):
     ref_hn = torch.nn.functional.layer_norm(ref + tb.double(), (cout,), gm.double(), bt.double(), eps=1e-5)
     assert torch.equal(y2, y)
     assert (hn.double() - ref_hn).abs().max().item() <= 5e-5
+
+
+@pytest.mark.parametrize("n,L", [(7, 200), (2560, 200), (9, 50), (3, 37), (5, 208)])
+def test_fused_conv_tower_vs_layerwise(nets, n, L):
+    """One-launch LDS-resident conv tower vs the layer-by-layer path (MIOpen convs + epilogue kernels) and vs the
+    plain PyTorch modules."""
+    from svdd_amd.fused import FusedValueNet
+    model, emb, head, _ = nets
+    g = torch.Generator().manual_seed(5)
+    for m in emb.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.running_mean.copy_(torch.randn(m.num_features, generator=g).to(DEV) * 0.1)
+            m.running_var.copy_((torch.rand(m.num_features, generator=g) + 0.5).to(DEV))
+    fv = FusedValueNet(emb, head).to(DEV).eval()
+    assert fv.tower_ok
+    tok = torch.randint(0, 5, (n, L), device=DEV)
+    oh = (torch.nn.functional.one_hot(tok.clamp(max=3), 4) * (tok != 4)[..., None]).float()
+    with torch.no_grad():
+        fv.use_fused_tower = True
+        a = fv(oh)
+        a2 = fv(oh)
+        fv.use_fused_tower = False
+        b = fv(oh)
+        ref = head(emb(oh[: min(n, 64)]))
+    assert torch.equal(a, a2)                                        # deterministic
+    assert (a - b).abs().max().item() <= 2e-5
+    assert (a[: min(n, 64)] - ref).abs().max().item() <= 2e-5
+    model.clear_fused()
