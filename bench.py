@@ -11,10 +11,12 @@ tokens. Inputs are generated on the device (nothing crosses PCIe in the timed re
 Weak scaling: every rank decodes its own 256 rows (global rows rank*256 .. rank*256+255).
 
 Prints ONE JSON line (rank 0). Extra objects:
-  roofline      the dominant kernel of the job by time, the hand-written fp32-MFMA dilated conv of the
-                backbone (conv1d_cl_static_kernel, 20 launches per backbone forward): useful FLOPs per launch
-                (2*B*Cin*Cout*sum_t max(0, L-|t-4|*dil): multiplications with zero padding are not counted) /
-                its mean launch duration, against the 157.3 TFLOP/s dense fp32-MFMA peak.
+  roofline      the dominant kernel of the job by time: backbone_kernel, the whole dilated-CNN backbone forward in
+                one launch (svdd_backbone_cnn_f32; exact-fp32 MFMA, activations in LDS/registers). Useful FLOPs per
+                launch (20 convs: 2*B*Cin*Cout*sum_t max(0, L-|t-4|*dil) - multiplications with zero padding are
+                not counted - plus the first 9-tap conv and the two 1x1 convs) / its mean launch duration, against
+                the 157.3 TFLOP/s dense fp32-MFMA peak. (When the batch is too small for that kernel the
+                layer-wise conv1d_cl_static_kernel is reported instead.)
   roofline_sampler  the dominant kernel of the sampler itself, K1 propose: algorithmic bytes per launch
                 B*L*(21 + 17*M) / mean launch duration, against the 8 TB/s HBM peak.
                 All durations are measured inside the timed region with HIP start/stop events bound to each
@@ -137,6 +139,8 @@ def main():
     conv_total_ms, conv_launches = _lib.profile_collect(2)
     gru_total_ms, gru_launches = _lib.profile_collect(3)
     epi_total_ms, epi_launches = _lib.profile_collect(4)
+    tower_total_ms, tower_launches = _lib.profile_collect(5)
+    bb_total_ms, bb_launches = _lib.profile_collect(6)
     assert out.shape == (B * world, L) and int(out.max()) <= 3
     if world > 1:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -163,6 +167,25 @@ def main():
         pmc_path = os.path.join(ROOT, "profiles", "r01_pmc.json")
         if os.path.exists(pmc_path) and (B, L, M) == (256, 200, 10):
             pmc = json.load(open(pmc_path))                    # separate --pmc passes, see the file
+        if bb_launches:
+            # the job's dominant kernel: the whole backbone forward in one launch. Algorithmic FLOPs per launch = the
+            # multiply-adds of one forward that touch real data (taps that fall into the zero padding excluded):
+            # 20 dilated convs + the 9-tap first conv on the one-hot + the two 1x1 convs.
+            bb_flops = conv_flops_fwd + 2.0 * B * L * (5 * H * 9 + H * H + H * 5)
+            bb_ms = bb_total_ms / bb_launches
+            bb_tf = bb_flops / (bb_ms * 1e-3) / 1e12
+            roofline = {"bound": "mfma", "kernel": "backbone_kernel (svdd_backbone_cnn_f32: first conv + 20 x [LayerNorm, "
+                                                   "dilated 9-tap conv 128->128, ReLU, residual] + 2 x 1x1 conv, one launch)",
+                        "achieved": round(bb_tf, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(bb_tf / FP32_PEAK_TFLOPS, 5), "traffic": pmc.get("backbone_traffic_bytes_per_launch"),
+                        "flops_per_launch": round(bb_flops), "avg_launch_us": round(bb_ms * 1e3, 3), "launches": bb_launches}
+        else:
+            roofline = {"bound": "mfma", "kernel": "conv1d_cl_static_kernel<128,128,9,dil,200> (backbone dilated conv, "
+                                                   "dil 1,1,4,16,64 x4 per forward)",
+                        "achieved": round(conv_tf, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(conv_tf / FP32_PEAK_TFLOPS, 5), "traffic": pmc.get("conv_traffic_bytes_per_launch"),
+                        "flops_per_launch": round(conv_flops_fwd / 20.0), "avg_launch_us": round(conv_ms * 1e3, 3),
+                        "launches": conv_launches}
         line = {
             "metric": "decoded sequences/sec (whole node), L=200 M=10 128-step SVDD-MC",
             "value": round(seqs / elapsed, 3), "unit": "sequences/s", "n_gpus": world,
@@ -172,18 +195,14 @@ def main():
             "config": {"workload": f"DNA enhancer SVDD-MC, batch={B}/GPU, L={L}, M={M}, {S} steps "
                                    f"(BASELINE.json configs[1]); dilated-CNN backbone 3.3M params + ConvGRU value net",
                        "global_batch": B * world, "rng": args.rng, "sharding": f"rows x{world}, 1 all-gather"},
-            "roofline": {"bound": "mfma", "kernel": "conv1d_cl_static_kernel<128,128,9,dil,200> (backbone dilated conv, "
-                                                     "dil 1,1,4,16,64 x4 per forward)",
-                         "achieved": round(conv_tf, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(conv_tf / FP32_PEAK_TFLOPS, 5), "traffic": pmc.get("conv_traffic_bytes_per_launch"),
-                         "flops_per_launch": round(conv_flops_fwd / 20.0), "avg_launch_us": round(conv_ms * 1e3, 3),
-                         "launches": conv_launches},
+            "roofline": roofline,
             "roofline_sampler": {"bound": "hbm", "kernel": "propose_kernel (K1)", "achieved": round(achieved, 2),
                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                                  "traffic": pmc.get("k1_traffic_bytes_per_launch", traffic), "bytes_per_launch": k1_bytes,
                                  "avg_launch_us": round(k1_ms * 1e3, 3), "launches": k1_launches,
                                  "select_kernel_avg_launch_us": round(k2_total_ms / max(k2_launches, 1) * 1e3, 3)},
-            "own_kernels_ms_per_decode": {"conv1d": round(conv_total_ms, 2), "gru": round(gru_total_ms, 2),
+            "own_kernels_ms_per_decode": {"backbone_cnn": round(bb_total_ms, 2), "conv_tower": round(tower_total_ms, 2),
+                                          "conv1d": round(conv_total_ms, 2), "gru": round(gru_total_ms, 2),
                                           "epilogue_ln": round(epi_total_ms, 2),
                                           "propose": round(k1_total_ms, 3), "select": round(k2_total_ms, 3)},
             "e2e_fp32_frac": round(flops_seq * seqs / elapsed / 1e12 / (FP32_PEAK_TFLOPS * world), 5),

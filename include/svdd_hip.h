@@ -210,6 +210,19 @@ int svdd_conv1d_set_dynamic(int on);
 int svdd_conv_tower_f32(const float* onehot, const float* tiles, const float* bias, float* out, int n, int L,
                         int nlayers, int residual_mask, void* stream);
 
+/* svdd_backbone_cnn_f32 — the whole dilated-CNN masked-diffusion backbone at sigma = 0 in ONE launch
+ *   (reference models/dnaconv.py:176-210 as called from diffusion_gosai.py:334-340): one-hot + 9-tap first conv,
+ *   nlayers x [LayerNorm(f + tb_i) -> dilated 9-tap conv 128->128 -> ReLU -> + f], then the two 1x1 convs of
+ *   final_conv. The residual stream stays in registers, the normalised activations in LDS; nothing but the tokens
+ *   and the logits touches HBM.  hidden_dim = 128, alphabet 5, L <= 208, nlayers <= 32.
+ *   x [n,L] u8 tokens ; table0 [9][5][128] = W_first[co][c][t] ; tiles [nlayers][4][9][128][32] = W_i[co][32c+k][t]
+ *   followed by [4][128][32] = W_f1[co][32c+k] ; vec [nlayers+2][4][128]: row 0 = {b_first}, row 1+i = {b_i, tb_i,
+ *   gamma_i, beta_i}, row nlayers+1 = {b_f1} ; w2 [5][128] then b2 [5] ; dilations: HOST int[nlayers] ;
+ *   out [n,L,5] raw logits (layout BLV).  Packing: svdd_amd/fused.py:pack_backbone. */
+int svdd_backbone_cnn_f32(const uint8_t* x, const float* table0, const float* tiles, const float* vec,
+                          const float* w2, float* out, int n, int L, int nlayers, const int* dilations,
+                          void* stream);
+
 /* Process-wide options (host). SVDD_OPT_FORCE_EXACT != 0 makes svdd_propose evaluate every draw in the
  * exact (fp64, correctly rounded) arithmetic instead of the filtered fast path — same results, used
  * to A/B the filter. */
@@ -218,7 +231,8 @@ enum { SVDD_OPT_FORCE_EXACT = 0,
 int svdd_set_option(int key, int value);
 
 /* Per-launch kernel timing (host). While enabled, svdd_propose (kernel 0), svdd_select (1), svdd_conv1d_cl_f32 (2),
- * svdd_gru_bidir_f32 (3) and svdd_epilogue_ln_f32 (4) are dispatched with HIP start/stop events bound to the dispatch on its launch stream
+ * svdd_gru_bidir_f32 (3), svdd_epilogue_ln_f32 (4), svdd_conv_tower_f32 (5) and svdd_backbone_cnn_f32 (6) are dispatched
+ * with HIP start/stop events bound to the dispatch on its launch stream
  * (hipExtLaunchKernelGGL); svdd_profile_collect waits for the recorded launches, returns the summed
  * hipEventElapsedTime and their count, and clears the record. Not for use during graph capture. */
 int svdd_profile_enable(int on);

@@ -786,6 +786,310 @@ __global__ __launch_bounds__(512, 4) void conv_tower_kernel(TowerArgs a) {
   }
 }
 
+// --------------------------------------------------------- fused dilated-CNN backbone (one launch per forward) ----
+// The whole masked-diffusion backbone of the reference (models/dnaconv.py:176-210, sigma = 0):
+//     f_0 = relu(conv9(onehot5(x)) + b)                      first layer as a 9-entry table lookup per output
+//     hn_i = LayerNorm(f_i + tb_i) ; f_{i+1} = relu(conv9_dil_i(hn_i) + b_i) + f_i          i = 0..nl-1
+//     logits = W2 relu(W1 f_nl + b1) + b2
+// One workgroup per tile of whole sequences (<= 208 rows), 8 waves; wave w owns output channels [16 w, 16 w + 16) of
+// EVERY row tile (13 x f32x4 accumulators) and keeps the residual stream f in registers in the same layout for the
+// whole forward. The only LDS-resident activation is the LayerNorm'd image hn [rows][128] that feeds the MFMA A
+// operands (a tap = a row offset; out-of-sequence rows read a zero row). No activation ever goes to HBM: per forward
+// the layer-wise path moved ~3 GB (conv in/out + the epilogue/LayerNorm pass per layer) and launched 41 kernels.
+// v_mfma_f32_16x16x4_f32, 16-row tiles (200 rows -> 13 tiles, 4 % padding); row tiles whose rows all fall into the
+// zero padding of a dilated tap are skipped in pairs (runtime, workgroup-uniform). Weights stream through LDS, one
+// [128][32] tile per (layer, chunk, tap), register-prefetched one tile ahead. LayerNorm statistics are two-pass
+// (mean, then centred variance) with a 16-lane shuffle reduction and an 8-wave LDS exchange.
+constexpr int BB_C = 128;
+constexpr int BB_AP = BB_C + 4;
+constexpr int BB_MAXL = 32;
+
+struct BackboneArgs {
+  const uint8_t* x;        // [n, L] tokens 0..4
+  const float* table0;     // [9][5][128]  W_first[co][c][t] -> [t][c][co]
+  const float* tiles;      // [nl][4 chunks][9 taps][128][32] then final-1x1 [4][128][32]
+  const float* vec;        // [nl + 2][4][128] : row 0: {b_first,-,-,-}; row 1+i: {bias_i, tb_i, gamma_i, beta_i}; last: {b_f1,-,-,-}
+  const float* w2;         // [5][128] , then b2 [5]
+  float* out;              // [n, L, 5]
+  int n, L, spt, nl;
+  int dil[BB_MAXL];
+};
+
+template <int N>
+__device__ __forceinline__ float row_ror(float v) {            // rotate right by N inside each 16-lane DPP row
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + N, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float group16_sum(float v) {        // sum over the 16 lanes sharing lane >> 4 (VALU DPP, no LDS)
+  v += row_ror<8>(v); v += row_ror<4>(v); v += row_ror<2>(v); v += row_ror<1>(v);
+  return v;
+}
+
+// LDS image rows: row -1 and rows >= L of a one-sequence tile are zero, so a tap is a clamped row offset.
+template <bool SPT1>
+__global__ __launch_bounds__(512, 2) void backbone_kernel(BackboneArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* img = smem + BB_AP;                              // rows -1 .. TW_ROWS ; [-1] and [TW_ROWS] stay zero
+  float* Bs = smem + (TW_ROWS + 2) * BB_AP;               // [9][5][128] the first layer's lookup table
+  float* psum = Bs + 9 * 5 * BB_C;                        // [8][TW_ROWS]
+  float* rstat = psum + 8 * TW_ROWS;                      // [TW_ROWS]
+  int* toks = reinterpret_cast<int*>(rstat + TW_ROWS);    // [TW_ROWS]
+  int* rpos = toks + TW_ROWS;                             // [TW_ROWS] position of a tile row inside its sequence
+  int* sdil = rpos + TW_ROWS;                             // [BB_MAXL + 1]
+  int* sched = sdil + BB_MAXL + 1;                        // [(nl + 1) * 36] schedule entries, see below
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, g = lane >> 4;
+  const int col = 16 * w + j;
+  const int L = a.L;
+  const int tile_rows = a.spt * L;
+  const int64_t row0 = (int64_t)blockIdx.x * tile_rows;
+  const int64_t total_rows = (int64_t)a.n * L;
+  const int nl = a.nl;
+  const int it_end = (nl + 1) * 36;
+
+  for (int e = tid; e < TW_ROWS; e += 512) {
+    toks[e] = (e < tile_rows && row0 + e < total_rows) ? a.x[row0 + e] : -1;
+    rpos[e] = e < tile_rows ? e % L : -(1 << 20);
+  }
+  for (int e = tid; e < BB_AP; e += 512) { smem[e] = 0.0f; img[TW_ROWS * BB_AP + e] = 0.0f; }
+  if (tid == 0) {
+#pragma unroll
+    for (int i = 0; i < BB_MAXL; ++i) sdil[i] = a.dil[i];
+    sdil[BB_MAXL] = 1;
+  }
+  for (int e = tid; e < 9 * 5 * BB_C; e += 512) Bs[e] = a.table0[e];
+  __syncthreads();
+  // Schedule: index k = (layer*4 + chunk)*9 + tap. sched[k] = 0 for a tap that only sees zero padding, else
+  //   bits 0-6: live row-tile pairs (0,1)(2,3)..(10,11)(12) ; 8-9 chunk ; 12-15 tap ; 16-25 index of the next live k.
+  for (int k = tid; k < it_end; k += 512) {
+    auto entry = [&](int kk) {
+      const int layer = kk / 36, t = kk % 9;
+      if (layer >= nl) return t == 4 ? 0x7f : 0;
+      const int d = (t - 4) * sdil[layer];
+      const int lo = d < 0 ? -d : 0, hi = d > 0 ? L - d : L;
+      if (lo >= hi) return 0;
+      if (!SPT1) return 0x7f;
+      int m = 0;
+      for (int p = 0; p < 7; ++p) if (lo < 32 * p + 32 && hi > 32 * p) m |= 1 << p;
+      return m;
+    };
+    const int m = entry(k);
+    int nx = k + 1;
+    while (nx < it_end && entry(nx) == 0) ++nx;
+    sched[k] = m ? (m | ((k % 36) / 9) << 8 | (k % 9) << 12 | nx << 16) : 0;
+  }
+
+  // ---- first layer: f[row][col] = relu(b + sum_t table[t][tok[row + t - 4]][col])   (dnaconv.py:177,184)
+  f32x4 f[TW_RT], acc[TW_RT];
+  {
+    const float b0 = a.vec[col];
+#pragma unroll
+    for (int r = 0; r < TW_RT; ++r)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int row = 16 * r + 4 * g + e;
+        float v = b0;
+        const int pos = rpos[row];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int p = pos + t - 4;
+          const int tk = (p >= 0 && p < L) ? toks[row + t - 4] : -1;
+          if (tk >= 0) v += Bs[(t * 5 + tk) * BB_C + col];
+        }
+        f[r][e] = row < tile_rows ? fmaxf(v, 0.0f) : 0.0f;
+      }
+  }
+  __syncthreads();                                        // sched is visible
+
+  // A operand addressing: this lane feeds row 16 rt + j of every tile, channels 32 c + 8 g .. + 8
+  const int arow0 = (j * BB_AP + 8 * g) * 4;              // byte offset of (row j, col 8 g) inside img
+  const int a_lo = arow0 - (j + 1) * BB_AP * 4;           // row -1
+  const int a_hi = arow0 + (TW_ROWS - j) * BB_AP * 4;     // row TW_ROWS
+  int apos[SPT1 ? 1 : TW_RT];
+  if (!SPT1) {
+#pragma unroll
+    for (int r = 0; r < TW_RT; ++r) apos[r] = rpos[16 * r + j];
+  }
+  const char* imgb = reinterpret_cast<const char*>(img);
+
+  // Weight stream: each wave reads ITS [16 cout][32 k] slice of the (layer, chunk, tap) tile straight from L2 into the
+  // B-operand registers (2 KB contiguous per wave, one tile ahead). No LDS staging and no per-tile barrier: inside a
+  // layer the 8 waves run unsynchronised, so the address/scalar phase of one wave of a SIMD hides behind its partner's
+  // MFMAs (with an LDS-staged tile + barrier per tap the two ran in lockstep and the matrix pipe idled 36 %).
+  const float* wsrc = a.tiles + col * CH + 8 * g;
+  auto tile_of = [&](int k) { return k < nl * 36 ? k : nl * 36 + (k - nl * 36) / 9; };
+  int it = 0;
+  while (it < it_end && sched[it] == 0) ++it;
+  it = __builtin_amdgcn_readfirstlane(it);
+  int en = __builtin_amdgcn_readfirstlane(sched[it]);      // current entry; the next one is fetched an iteration ahead
+  float4 bn0, bn1;
+  {
+    const float* src = wsrc + (size_t)tile_of(it) * BB_C * CH;
+    bn0 = *reinterpret_cast<const float4*>(src);
+    bn1 = *reinterpret_cast<const float4*>(src + 4);
+  }
+
+  for (int layer = 0; layer <= nl; ++layer) {             // layer == nl: the first 1x1 conv of final_conv
+    // ---- write the A image: LayerNorm(f + tb) for conv layers, f itself for the final 1x1 conv
+    const float* vl = a.vec + (size_t)(layer + 1) * 4 * BB_C;
+    if (layer < nl) {
+      const float tb = vl[BB_C + col], gm = vl[2 * BB_C + col], bt = vl[3 * BB_C + col];
+      // pass 1: row means
+#pragma unroll
+      for (int r = 0; r < TW_RT; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float sm = group16_sum(f[r][e] + tb);
+          if (j == 0) psum[w * TW_ROWS + 16 * r + 4 * g + e] = sm;
+        }
+      __syncthreads();
+      if (tid < TW_ROWS) {
+        float sm = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sm += psum[k * TW_ROWS + tid];
+        rstat[tid] = sm * (1.0f / BB_C);
+      }
+      __syncthreads();
+      // pass 2: centred second moment
+#pragma unroll
+      for (int r = 0; r < TW_RT; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float d = f[r][e] + tb - rstat[16 * r + 4 * g + e];
+          acc[r][e] = d;                                  // keep the centred value
+          const float sq = group16_sum(d * d);
+          if (j == 0) psum[w * TW_ROWS + 16 * r + 4 * g + e] = sq;
+        }
+      __syncthreads();
+      if (tid < TW_ROWS) {
+        float sq = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sq += psum[k * TW_ROWS + tid];
+        rstat[tid] = rsqrtf(sq * (1.0f / BB_C) + 1e-5f);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < TW_RT; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int row = 16 * r + 4 * g + e;
+          img[row * BB_AP + col] = row < tile_rows ? acc[r][e] * rstat[row] * gm + bt : 0.0f;
+        }
+    } else {
+#pragma unroll
+      for (int r = 0; r < TW_RT; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) img[(16 * r + 4 * g + e) * BB_AP + col] = f[r][e];
+    }
+    // ---- implicit GEMM over (chunk, live tap)
+    const float bl = vl[col];
+#pragma unroll
+    for (int r = 0; r < TW_RT; ++r) acc[r] = f32x4{bl, bl, bl, bl};
+    const int dil = __builtin_amdgcn_readfirstlane(sdil[layer < nl ? layer : BB_MAXL]);
+    const int layer_end = (layer + 1) * 36;
+    __syncthreads();                                      // the image is complete
+    while (it < layer_end) {
+      const int nxt = en >> 16;
+      const int en_next_v = sched[nxt < it_end ? nxt : it];
+      const float bf[8] = {bn0.x, bn0.y, bn0.z, bn0.w, bn1.x, bn1.y, bn1.z, bn1.w};
+      if (nxt < it_end) {
+        const float* src = wsrc + (size_t)tile_of(nxt) * BB_C * CH;
+        bn0 = *reinterpret_cast<const float4*>(src);
+        bn1 = *reinterpret_cast<const float4*>(src + 4);
+      }
+      const int delta = (((en >> 12) & 15) - 4) * dil;
+      const int coff = ((en >> 8) & 3) * (CH * 4);        // chunk byte offset inside a row
+      const int dbytes = delta * (BB_AP * 4) + coff;
+      // A fragments are loaded one tile pair ahead of the MFMAs that consume them: the waves of a workgroup leave the
+      // barrier in lockstep, so an LDS latency exposed between two MFMA groups is exposed on every wave at once.
+#define BB_ALOAD(R, V)                                                                                       \
+      { int o_;                                                                                              \
+        if (SPT1) { o_ = arow0 + (dbytes + (R) * 16 * BB_AP * 4);                                            \
+                    o_ = min(max(o_, a_lo + coff), a_hi + coff); }                                       \
+        else o_ = ((unsigned)(apos[SPT1 ? 0 : (R)] + delta) < (unsigned)L ? arow0 + dbytes + (R) * 16 * BB_AP * 4 \
+                                                                            : a_hi + coff);                  \
+        const float4* ap_ = reinterpret_cast<const float4*>(imgb + o_);                                      \
+        V[0] = ap_[0]; V[1] = ap_[1]; }
+      // Nothing but MFMAs inside a 16-MFMA group: an s_waitcnt or ds_read between two MFMAs costs tens of cycles of
+      // matrix-pipe time on gfx950, so each group is fenced and preceded by ONE explicit lgkmcnt wait that leaves
+      // exactly the next pair's reads (NOUT of them) in flight.
+#define BB_WAIT(NOUT) __builtin_amdgcn_s_waitcnt(0xC07F | ((NOUT) << 8));
+#define BB_MM2(P, R0, R1, U0, U1, NOUT)                                                                   \
+      __builtin_amdgcn_sched_barrier(0);                                                                  \
+      BB_WAIT(NOUT)                                                                                       \
+      if (en & (1 << (P))) {                                                                              \
+        _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                   \
+          acc[R0] = __builtin_amdgcn_mfma_f32_16x16x4f32(U0[q].x, bf[4 * q], acc[R0], 0, 0, 0);           \
+          acc[R1] = __builtin_amdgcn_mfma_f32_16x16x4f32(U1[q].x, bf[4 * q], acc[R1], 0, 0, 0);           \
+          acc[R0] = __builtin_amdgcn_mfma_f32_16x16x4f32(U0[q].y, bf[4 * q + 1], acc[R0], 0, 0, 0);       \
+          acc[R1] = __builtin_amdgcn_mfma_f32_16x16x4f32(U1[q].y, bf[4 * q + 1], acc[R1], 0, 0, 0);       \
+          acc[R0] = __builtin_amdgcn_mfma_f32_16x16x4f32(U0[q].z, bf[4 * q + 2], acc[R0], 0, 0, 0);       \
+          acc[R1] = __builtin_amdgcn_mfma_f32_16x16x4f32(U1[q].z, bf[4 * q + 2], acc[R1], 0, 0, 0);       \
+          acc[R0] = __builtin_amdgcn_mfma_f32_16x16x4f32(U0[q].w, bf[4 * q + 3], acc[R0], 0, 0, 0);       \
+          acc[R1] = __builtin_amdgcn_mfma_f32_16x16x4f32(U1[q].w, bf[4 * q + 3], acc[R1], 0, 0, 0);       \
+        }                                                                                                 \
+      }                                                                                                   \
+      __builtin_amdgcn_sched_barrier(0);
+      float4 ua0[2], ua1[2], ub0[2], ub1[2];
+      BB_ALOAD(0, ua0) BB_ALOAD(1, ua1)
+      BB_ALOAD(2, ub0) BB_ALOAD(3, ub1)
+      BB_MM2(0, 0, 1, ua0, ua1, 4)
+      BB_ALOAD(4, ua0) BB_ALOAD(5, ua1)
+      BB_MM2(1, 2, 3, ub0, ub1, 4)
+      BB_ALOAD(6, ub0) BB_ALOAD(7, ub1)
+      BB_MM2(2, 4, 5, ua0, ua1, 4)
+      BB_ALOAD(8, ua0) BB_ALOAD(9, ua1)
+      BB_MM2(3, 6, 7, ub0, ub1, 4)
+      BB_ALOAD(10, ub0) BB_ALOAD(11, ub1)
+      BB_MM2(4, 8, 9, ua0, ua1, 4)
+      BB_ALOAD(12, ua0)
+      BB_MM2(5, 10, 11, ub0, ub1, 2)
+      __builtin_amdgcn_sched_barrier(0);
+      BB_WAIT(0)
+      if (en & (1 << 6)) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          acc[12] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua0[q].x, bf[4 * q], acc[12], 0, 0, 0);
+          acc[12] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua0[q].y, bf[4 * q + 1], acc[12], 0, 0, 0);
+          acc[12] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua0[q].z, bf[4 * q + 2], acc[12], 0, 0, 0);
+          acc[12] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua0[q].w, bf[4 * q + 3], acc[12], 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#undef BB_WAIT
+#undef BB_MM2
+#undef BB_ALOAD
+      it = nxt;
+      en = __builtin_amdgcn_readfirstlane(en_next_v);
+    }
+    __syncthreads();                                      // every wave is done reading the image
+    if (layer < nl) {
+#pragma unroll
+      for (int r = 0; r < TW_RT; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) f[r][e] = fmaxf(acc[r][e], 0.0f) + f[r][e];       // relu(conv + b) + f  (:195-197)
+    } else {
+#pragma unroll
+      for (int r = 0; r < TW_RT; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) img[(16 * r + 4 * g + e) * BB_AP + col] = fmaxf(acc[r][e], 0.0f);   // relu(W1 f + b1)
+    }
+  }
+  __syncthreads();
+  // ---- last 1x1 conv 128 -> 5: one (row, class) dot product per thread iteration
+  for (int e = tid; e < tile_rows * 5; e += 512) {
+    const int row = e / 5, v = e - 5 * row;
+    if (row0 + row >= total_rows) continue;
+    const float* hr = img + row * BB_AP;
+    const float* wv = a.w2 + v * BB_C;
+    float sm = a.w2[5 * BB_C + v];
+#pragma unroll 8
+    for (int k = 0; k < BB_C; ++k) sm += hr[k] * wv[k];
+    a.out[(row0 + row) * 5 + v] = sm;
+  }
+}
+
 }  // namespace
 
 static int g_gru_mode = 0;         // 2 selects the both-directions-per-workgroup variant (tests / experiments)
@@ -872,8 +1176,34 @@ extern "C" int svdd_conv_tower_f32(const float* onehot, const float* tiles, cons
   const size_t lds = sizeof(float) * ((size_t)(TW_ROWS + 1) * TW_AP + 2 * (size_t)TW_C * CHP + (size_t)(TW_ROWS + 1) * 4);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_tower_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipEvent_t e0, e1;
-  svdd_internal_timed_events(2, &e0, &e1);
+  svdd_internal_timed_events(5, &e0, &e1);
   hipExtLaunchKernelGGL(conv_tower_kernel, dim3((unsigned)((n + spt - 1) / spt)), dim3(512), lds, (hipStream_t)stream,
                         e0, e1, 0, a);
+  return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
+}
+
+extern "C" int svdd_backbone_cnn_f32(const uint8_t* x, const float* table0, const float* tiles, const float* vec,
+                                     const float* w2, float* out, int n, int L, int nlayers, const int* dilations,
+                                     void* stream) {
+  if (!x || !table0 || !tiles || !vec || !w2 || !out || !dilations || n <= 0 || L <= 0 || L > TW_ROWS ||
+      nlayers <= 0 || nlayers > BB_MAXL)
+    return SVDD_E_ARG;
+  BackboneArgs a;
+  a.x = x; a.table0 = table0; a.tiles = tiles; a.vec = vec; a.w2 = w2; a.out = out;
+  a.n = n; a.L = L; a.spt = TW_ROWS / L; a.nl = nlayers;
+  for (int i = 0; i < BB_MAXL; ++i) a.dil[i] = i < nlayers ? dilations[i] : 1;
+  for (int i = 0; i < nlayers; ++i) if (dilations[i] <= 0) return SVDD_E_ARG;
+  const size_t lds = sizeof(float) * ((size_t)(TW_ROWS + 2) * BB_AP + 9 * 5 * (size_t)BB_C + 8 * (size_t)TW_ROWS +
+                                      3 * (size_t)TW_ROWS + BB_MAXL + 1 + (size_t)(nlayers + 1) * 36);
+  hipEvent_t e0, e1;
+  svdd_internal_timed_events(6, &e0, &e1);
+  const dim3 grid((unsigned)((n + a.spt - 1) / a.spt));
+  if (a.spt == 1) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(backbone_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipExtLaunchKernelGGL(backbone_kernel<true>, grid, dim3(512), lds, (hipStream_t)stream, e0, e1, 0, a);
+  } else {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(backbone_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipExtLaunchKernelGGL(backbone_kernel<false>, grid, dim3(512), lds, (hipStream_t)stream, e0, e1, 0, a);
+  }
   return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
 }

@@ -124,6 +124,50 @@ def conv_tower(onehot, tiles, bias, residual_mask):
     return out
 
 
+def pack_backbone(cnn):
+    """CNNModel (hidden_dim 128, alphabet 5) -> the operand images of svdd_backbone_cnn_f32 (include/svdd_hip.h):
+    dict(table0, tiles, vec, w2, dil). Time biases are those of sigma == 0 (diffusion_gosai.py:334-335)."""
+    H = cnn.args.hidden_dim
+    assert H == 128 and cnn.alphabet_size == 5 and cnn.linear.kernel_size[0] == 9
+    nl = len(cnn.convs)
+    with torch.no_grad():
+        dev = cnn.linear.weight.device
+        table0 = cnn.linear.weight.detach().float().permute(2, 1, 0).contiguous()       # [t][c][co]
+        tiles = []
+        for conv in cnn.convs:
+            assert conv.kernel_size[0] == 9 and conv.in_channels == H and conv.out_channels == H
+            w = conv.weight.detach().float()                                              # [co][ci][t]
+            tiles.append(w.view(H, 4, 32, 9).permute(1, 3, 0, 2))                        # [c][t][co][k]
+        wf1 = cnn.final_conv[0].weight.detach().float()[:, :, 0]                          # [co][ci]
+        tiles = torch.cat([torch.stack(tiles).reshape(-1), wf1.view(H, 4, 32).permute(1, 0, 2).reshape(-1)]).contiguous()
+        tb = cnn._time_biases(torch.zeros(1, device=dev))
+        vec = torch.zeros(nl + 2, 4, H, device=dev)
+        vec[0, 0] = cnn.linear.bias
+        for i in range(nl):
+            vec[1 + i, 0] = cnn.convs[i].bias
+            vec[1 + i, 1] = tb[i].reshape(H)
+            vec[1 + i, 2] = cnn.norms[i].weight
+            vec[1 + i, 3] = cnn.norms[i].bias
+        vec[nl + 1, 0] = cnn.final_conv[0].bias
+        w2 = torch.cat([cnn.final_conv[2].weight.detach().float()[:, :, 0].reshape(-1),
+                        cnn.final_conv[2].bias.detach().float()]).contiguous()
+    return dict(table0=table0, tiles=tiles, vec=vec.contiguous(), w2=w2, dil=[c.dilation[0] for c in cnn.convs])
+
+
+def backbone_cnn(tokens, pk):
+    """tokens [n, L] uint8 -> raw logits fp32 [n, L, 5]: the whole backbone forward in ONE launch
+    (HIP kernel svdd_backbone_cnn_f32)."""
+    assert tokens.is_cuda and tokens.dtype == torch.uint8 and tokens.is_contiguous()
+    n, L = tokens.shape
+    out = torch.empty((n, L, 5), dtype=torch.float32, device=tokens.device)
+    dil = (ctypes.c_int * len(pk["dil"]))(*pk["dil"])
+    rc = _lib.lib().svdd_backbone_cnn_f32(tokens.data_ptr(), pk["table0"].data_ptr(), pk["tiles"].data_ptr(),
+                                          pk["vec"].data_ptr(), pk["w2"].data_ptr(), out.data_ptr(), n, L,
+                                          len(pk["dil"]), dil, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    _lib.check(rc, "svdd_backbone_cnn_f32")
+    return out
+
+
 def epilogue_ln(y, bias=None, f_prev=None, tb=None, gamma=None, beta=None, act=ACT_RELU_THEN_ADD, want_norm=True,
                 want_sum=True):
     """Fused conv epilogue on channels-last rows (HIP kernel svdd_epilogue_ln_f32):
@@ -264,9 +308,23 @@ class FusedBackbone(nn.Module):
         self.f2_w = nn.Parameter(_cl(cnn.final_conv[2].weight), requires_grad=False)
         self.f2_b = nn.Parameter(cnn.final_conv[2].bias.detach().clone(), requires_grad=False)
         self.register_buffer("eye", torch.eye(cnn.alphabet_size), persistent=False)
+        # the whole forward in ONE launch (svdd_backbone_cnn_f32): residual stream in registers, activations in LDS
+        self.one_launch = self.H == 128 and cnn.alphabet_size == 5 and all(c.kernel_size[0] == 9 for c in cnn.convs)
+        self.use_one_launch = True
+        if self.one_launch:
+            pk = pack_backbone(cnn)
+            self.ol_dil = pk.pop("dil")
+            for k, v in pk.items():
+                self.register_buffer("ol_" + k, v, persistent=False)
 
     def forward(self, seq, sigma=None):
         B, L = seq.shape
+        # one workgroup per tile of whole sequences and ~2.3 ms per workgroup whatever the batch: worth it once the
+        # tiles fill most of the 256 CUs (below that the layer-wise path finishes sooner)
+        if self.one_launch and self.use_one_launch and L <= 208 and B // (208 // L) >= 192 and seq.is_cuda:
+            tok = seq if seq.dtype == torch.uint8 else seq.to(torch.uint8)
+            return backbone_cnn(tok.contiguous(), dict(table0=self.ol_table0, tiles=self.ol_tiles, vec=self.ol_vec,
+                                                       w2=self.ol_w2, dil=self.ol_dil))
         onehot = self.eye[seq.long()]                               # [B,L,5]
         f = onehot.view(B, 1, L, onehot.shape[2]).permute(0, 3, 1, 2)
         n = len(self.ws)

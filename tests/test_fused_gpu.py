@@ -172,3 +172,28 @@ def test_fused_conv_tower_vs_layerwise(nets, n, L):
     assert (a - b).abs().max().item() <= 2e-5
     assert (a[: min(n, 64)] - ref).abs().max().item() <= 2e-5
     model.clear_fused()
+
+
+@pytest.mark.parametrize("n,L", [(7, 200), (3, 187), (1, 208), (9, 50), (5, 33), (2, 9), (300, 200)])
+def test_one_launch_backbone_vs_plain(n, L):
+    """svdd_backbone_cnn_f32 (whole backbone in one launch) against the plain CNNModel on ragged shapes: L = 200
+    (one sequence per workgroup, clamped tap addressing, dead-tile skipping), several short sequences per tile,
+    L shorter than the widest dilation (dead taps), and more sequences than fit the tile grid evenly."""
+    from svdd_amd import backbone, config, fused
+    torch.manual_seed(5)
+    cnn = backbone.CNNModel(config.dna_config().model, alphabet_size=5).to(DEV).eval()
+    with torch.no_grad():
+        for nm in cnn.norms:
+            nm.weight.uniform_(0.5, 1.5)
+            nm.bias.uniform_(-0.3, 0.3)
+    x = torch.randint(0, 5, (n, L), device=DEV, dtype=torch.uint8)
+    pk = fused.pack_backbone(cnn)
+    with torch.no_grad():
+        ref = cnn(x, torch.zeros(n, device=DEV), zero_sigma=True).contiguous()
+        out = fused.backbone_cnn(x, pk)
+    assert out.shape == (n, L, 5)
+    assert (out - ref).abs().max().item() <= 2e-5
+    assert torch.equal(out, fused.backbone_cnn(x, pk))                # deterministic
+    # rows are independent: a sub-batch gives the same bits whatever tile it lands in
+    if n >= 5:
+        assert torch.equal(out[2:5], fused.backbone_cnn(x[2:5].contiguous(), pk))
