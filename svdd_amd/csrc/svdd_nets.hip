@@ -664,14 +664,19 @@ struct TowerArgs {
 };
 
 // One LDS activation image only: a layer's outputs wait in the accumulators until every wave has finished reading
-// the image, then each wave overwrites the positions it owns (reading its own residual first). 79 KB of LDS and
+// the image, then each wave overwrites the positions it owns (reading its own residual first). 57 KB of LDS and
 // <= 128 VGPRs per wave => TWO workgroups (16 waves) per CU, which overlap each other's barriers, LDS latency and
 // global stores.
+// Weight stream: each wave reads ITS [16 cout][32 k] slice of the (layer, chunk, tap) tile straight from L2 into the
+// B-operand registers, one tile ahead: no LDS staging and no barrier per tap, so the waves of a workgroup run
+// unsynchronised inside a layer. MFMA groups are fenced (sched_barrier) behind one explicit lgkmcnt wait: an
+// s_waitcnt or ds_read between two MFMAs costs tens of cycles of matrix-pipe time on gfx950.
+// SPT1 (one sequence per tile): image rows -1 and >= L are zero, so a tap is a clamped row offset.
+template <bool SPT1>
 __global__ __launch_bounds__(512, 4) void conv_tower_kernel(TowerArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* act = smem;                                    // [TW_ROWS + 1][TW_AP]  (+1: zero row)
-  float* Bs = act + (TW_ROWS + 1) * TW_AP;              // [2][64][CHP]  weight tiles
-  float* xs = Bs + 2 * TW_C * CHP;                      // [TW_ROWS + 1][4]  one-hot tile (+1: zero row)
+  float* act = smem + TW_AP;                            // rows -1 .. TW_ROWS ; [-1] and [TW_ROWS] stay zero
+  float* xs = smem + (TW_ROWS + 2) * TW_AP + 4;         // one-hot tile, rows -1 .. TW_ROWS ; [-1], [>= L], [TW_ROWS] zero
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -682,34 +687,38 @@ __global__ __launch_bounds__(512, 4) void conv_tower_kernel(TowerArgs a) {
   const int64_t row0 = (int64_t)blockIdx.x * tile_rows;
   const int64_t total_rows = (int64_t)a.n * L;
 
-  for (int e = tid; e < TW_ROWS + 1; e += 512) {
+  for (int e = tid - 1; e < TW_ROWS + 1; e += 512) {
     float4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-    if (e < tile_rows && row0 + e < total_rows) v = *reinterpret_cast<const float4*>(a.x + (row0 + e) * 4);
+    if (e >= 0 && e < tile_rows && row0 + e < total_rows) v = *reinterpret_cast<const float4*>(a.x + (row0 + e) * 4);
     *reinterpret_cast<float4*>(xs + 4 * e) = v;
   }
-  for (int e = tid; e < TW_AP; e += 512) act[TW_ROWS * TW_AP + e] = 0.0f;
-  const int b_r = tid >> 3, b_q = tid & 7;              // one float4 of the [64][32] tile per thread
-  const float* tsrc = a.tiles + b_r * CH + 4 * b_q;
-  float* bdst = Bs + b_r * CHP + 4 * b_q;
-  float4 bp = *reinterpret_cast<const float4*>(tsrc);
-  *reinterpret_cast<float4*>(bdst) = bp;
+  for (int e = tid; e < TW_AP; e += 512) { smem[e] = 0.0f; act[TW_ROWS * TW_AP + e] = 0.0f; }
+  const float* wsrc = a.tiles + (16 * cs + j) * CH + 8 * g;
+  float4 bn0 = *reinterpret_cast<const float4*>(wsrc), bn1 = *reinterpret_cast<const float4*>(wsrc + 4);
 
-  int arow[7], apos[7];
+  const int arow0 = 16 * rh + j;                        // this lane feeds rows arow0 + 32 r as the A operand
+  int apos[SPT1 ? 1 : 7];
+  if (!SPT1) {
 #pragma unroll
-  for (int r = 0; r < 7; ++r) {
-    arow[r] = 16 * (rh + 2 * r) + j;
-    apos[r] = (rh + 2 * r < TW_RT && arow[r] < tile_rows) ? arow[r] % L : -(1 << 20);
+    for (int r = 0; r < 7; ++r)
+      apos[r] = (rh + 2 * r < TW_RT && arow0 + 32 * r < tile_rows) ? (arow0 + 32 * r) % L : -(1 << 20);
   }
+  const int abase = ((16 * rh + j) * TW_AP + 8 * g) * 4;             // byte offset of (row 16 rh + j, col 8 g)
+  const int a_lo = abase - (16 * rh + j + 1) * TW_AP * 4;            // row -1
+  const int a_hi = abase + (TW_ROWS - 16 * rh - j) * TW_AP * 4;      // row TW_ROWS
+  const char* actb = reinterpret_cast<const char*>(act);
   const int nit = 2 + 10 * a.nlayers;
-  int it = 0, par = 0;
+  int it = 0;
   f32x4 acc[7];
+  __syncthreads();                                       // xs and the zero rows are visible
 
-#define TW_MMA(R0, R1)                                                                                        \
+#define TW_WAIT(NOUT) __builtin_amdgcn_s_waitcnt(0xC07F | ((NOUT) << 8));
+#define TW_MMA(AF, R0, R1)                                                                                    \
   _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                             \
-    _Pragma("unroll") for (int r = R0; r < R1; ++r) if (!(r == 6 && rh == 1)) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r - R0][q].x, bf[4 * q], acc[r], 0, 0, 0);     \
-    _Pragma("unroll") for (int r = R0; r < R1; ++r) if (!(r == 6 && rh == 1)) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r - R0][q].y, bf[4 * q + 1], acc[r], 0, 0, 0); \
-    _Pragma("unroll") for (int r = R0; r < R1; ++r) if (!(r == 6 && rh == 1)) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r - R0][q].z, bf[4 * q + 2], acc[r], 0, 0, 0); \
-    _Pragma("unroll") for (int r = R0; r < R1; ++r) if (!(r == 6 && rh == 1)) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r - R0][q].w, bf[4 * q + 3], acc[r], 0, 0, 0); \
+    _Pragma("unroll") for (int r = R0; r < R1; ++r) if (!(r == 6 && rh == 1)) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(AF[r - R0][q].x, bf[4 * q], acc[r], 0, 0, 0);     \
+    _Pragma("unroll") for (int r = R0; r < R1; ++r) if (!(r == 6 && rh == 1)) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(AF[r - R0][q].y, bf[4 * q + 1], acc[r], 0, 0, 0); \
+    _Pragma("unroll") for (int r = R0; r < R1; ++r) if (!(r == 6 && rh == 1)) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(AF[r - R0][q].z, bf[4 * q + 2], acc[r], 0, 0, 0); \
+    _Pragma("unroll") for (int r = R0; r < R1; ++r) if (!(r == 6 && rh == 1)) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(AF[r - R0][q].w, bf[4 * q + 3], acc[r], 0, 0, 0); \
   }
 
   for (int layer = -1; layer < a.nlayers; ++layer) {     // layer -1 = the stem (15 taps x 4 channels as K = 64)
@@ -718,18 +727,16 @@ __global__ __launch_bounds__(512, 4) void conv_tower_kernel(TowerArgs a) {
     for (int r = 0; r < 7; ++r) acc[r] = f32x4{bl, bl, bl, bl};
     const int niter = layer < 0 ? 2 : 10;
     for (int ci = 0; ci < niter; ++ci, ++it) {
-      if (it + 1 < nit) bp = *reinterpret_cast<const float4*>(tsrc + (size_t)(it + 1) * TW_C * CH);   // flies under the MFMAs
-      __syncthreads();                                   // Bs[par] and the activation image are visible
-      float bf[8];
-      {
-        const float4* bq = reinterpret_cast<const float4*>(Bs + par * TW_C * CHP + (16 * cs + j) * CHP + 8 * g);
-        const float4 v0 = bq[0], v1 = bq[1];
-        bf[0] = v0.x; bf[1] = v0.y; bf[2] = v0.z; bf[3] = v0.w; bf[4] = v1.x; bf[5] = v1.y; bf[6] = v1.z; bf[7] = v1.w;
+      const float bf[8] = {bn0.x, bn0.y, bn0.z, bn0.w, bn1.x, bn1.y, bn1.z, bn1.w};
+      if (it + 1 < nit) {                                // the next tile's slice flies under the MFMAs
+        const float* src = wsrc + (size_t)(it + 1) * TW_C * CH;
+        bn0 = *reinterpret_cast<const float4*>(src);
+        bn1 = *reinterpret_cast<const float4*>(src + 4);
       }
-      float4 af[4][2];
       if (layer < 0) {
         // k = 32 ci + 8 g + s covers taps t0 = 8 ci + 2 g and t0 + 1 (4 channels each): two float4 of the one-hot tile
         const int t0 = 8 * ci + 2 * g;
+        float4 af[4][2];
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
           const int r0 = half ? 4 : 0, r1 = half ? 7 : 4;
@@ -738,29 +745,45 @@ __global__ __launch_bounds__(512, 4) void conv_tower_kernel(TowerArgs a) {
             if (r == 6 && rh == 1) continue;
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-              const int p = apos[r] + t0 + q - 7;
-              af[r - r0][q] = *reinterpret_cast<const float4*>(xs + 4 * ((p >= 0 && p < L) ? arow[r] + t0 + q - 7 : TW_ROWS));
+              const int rr = arow0 + 32 * r + t0 + q - 7;
+              int idx;
+              if (SPT1) idx = min(max(rr, -1), TW_ROWS);
+              else idx = (unsigned)(apos[SPT1 ? 0 : r] + t0 + q - 7) < (unsigned)L ? rr : TW_ROWS;
+              af[r - r0][q] = *reinterpret_cast<const float4*>(xs + 4 * idx);
             }
           }
-          if (half == 0) { TW_MMA(0, 4) } else { TW_MMA(4, 7) }
+          if (half == 0) { TW_MMA(af, 0, 4) } else { TW_MMA(af, 4, 7) }
         }
       } else {
         const int c = ci / 5, delta = ci - 5 * c - 2;
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-          const int r0 = half ? 4 : 0, r1 = half ? 7 : 4;
-#pragma unroll
-          for (int r = r0; r < r1; ++r) {
-            if (r == 6 && rh == 1) continue;
-            const int p = apos[r] + delta;
-            const float4* ap = reinterpret_cast<const float4*>(act + ((p >= 0 && p < L) ? arow[r] + delta : TW_ROWS) * TW_AP + 32 * c + 8 * g);
-            af[r - r0][0] = ap[0]; af[r - r0][1] = ap[1];
-          }
-          if (half == 0) { TW_MMA(0, 4) } else { TW_MMA(4, 7) }
+        const int dbytes = delta * (TW_AP * 4) + c * (CH * 4);
+        // tile groups (0,1,2)(3,4)(5,6) through two register buffers, each group's reads one group ahead
+        float4 fa[3][2], fb[2][2];
+#define TW_ALOAD(R, V)                                                                                        \
+        if (!((R) == 6 && rh == 1)) {                                                                         \
+          int o_;                                                                                             \
+          if (SPT1) o_ = min(max(abase + dbytes + (R) * (32 * TW_AP * 4), a_lo + c * (CH * 4)), a_hi + c * (CH * 4)); \
+          else o_ = (unsigned)(apos[SPT1 ? 0 : (R)] + delta) < (unsigned)L ? abase + dbytes + (R) * (32 * TW_AP * 4) \
+                                                                         : a_hi + c * (CH * 4);               \
+          const float4* ap_ = reinterpret_cast<const float4*>(actb + o_);                                     \
+          V[0] = ap_[0]; V[1] = ap_[1];                                                                       \
         }
+        TW_ALOAD(0, fa[0]) TW_ALOAD(1, fa[1]) TW_ALOAD(2, fa[2])
+        TW_ALOAD(3, fb[0]) TW_ALOAD(4, fb[1])
+        __builtin_amdgcn_sched_barrier(0);
+        TW_WAIT(4)
+        TW_MMA(fa, 0, 3)
+        __builtin_amdgcn_sched_barrier(0);
+        TW_ALOAD(5, fa[0]) TW_ALOAD(6, fa[1])
+        __builtin_amdgcn_sched_barrier(0);
+        if (rh == 1) { TW_WAIT(2) } else { TW_WAIT(4) }
+        TW_MMA(fb, 3, 5)
+        __builtin_amdgcn_sched_barrier(0);
+        TW_WAIT(0)
+        TW_MMA(fa, 5, 7)
+        __builtin_amdgcn_sched_barrier(0);
+#undef TW_ALOAD
       }
-      if (it + 1 < nit) *reinterpret_cast<float4*>(bdst + (par ^ 1) * TW_C * CHP) = bp;
-      par ^= 1;
     }
     // every wave must be done reading the image before its owners overwrite it (the stem reads xs, not the image)
     if (layer >= 0) __syncthreads();
@@ -776,9 +799,10 @@ __global__ __launch_bounds__(512, 4) void conv_tower_kernel(TowerArgs a) {
         act[o] = row < tile_rows ? fmaxf(v, 0.0f) : 0.0f;
       }
     }
+    __syncthreads();                                     // the image is complete
   }
 #undef TW_MMA
-  __syncthreads();
+#undef TW_WAIT
   for (int e = tid; e < tile_rows * 16; e += 512) {      // final image -> HBM, 16 B per thread, rows contiguous
     const int row = e >> 4, q = e & 15;
     if (row0 + row < total_rows)
@@ -1173,12 +1197,17 @@ extern "C" int svdd_conv_tower_f32(const float* onehot, const float* tiles, cons
     return SVDD_E_ARG;
   const int spt = TW_ROWS / L;
   TowerArgs a{onehot, tiles, bias, out, n, L, spt, nlayers, residual_mask};
-  const size_t lds = sizeof(float) * ((size_t)(TW_ROWS + 1) * TW_AP + 2 * (size_t)TW_C * CHP + (size_t)(TW_ROWS + 1) * 4);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_tower_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const size_t lds = sizeof(float) * ((size_t)(TW_ROWS + 2) * TW_AP + (size_t)(TW_ROWS + 2) * 4);
   hipEvent_t e0, e1;
   svdd_internal_timed_events(5, &e0, &e1);
-  hipExtLaunchKernelGGL(conv_tower_kernel, dim3((unsigned)((n + spt - 1) / spt)), dim3(512), lds, (hipStream_t)stream,
-                        e0, e1, 0, a);
+  const dim3 grid((unsigned)((n + spt - 1) / spt));
+  if (spt == 1) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_tower_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipExtLaunchKernelGGL(conv_tower_kernel<true>, grid, dim3(512), lds, (hipStream_t)stream, e0, e1, 0, a);
+  } else {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_tower_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipExtLaunchKernelGGL(conv_tower_kernel<false>, grid, dim3(512), lds, (hipStream_t)stream, e0, e1, 0, a);
+  }
   return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
 }
 
