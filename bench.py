@@ -141,6 +141,7 @@ def main():
     epi_total_ms, epi_launches = _lib.profile_collect(4)
     tower_total_ms, tower_launches = _lib.profile_collect(5)
     bb_total_ms, bb_launches = _lib.profile_collect(6)
+    tail_total_ms, tail_launches = _lib.profile_collect(7)
     assert out.shape == (B * world, L) and int(out.max()) <= 3
     if world > 1:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -202,6 +203,7 @@ def main():
                                  "avg_launch_us": round(k1_ms * 1e3, 3), "launches": k1_launches,
                                  "select_kernel_avg_launch_us": round(k2_total_ms / max(k2_launches, 1) * 1e3, 3)},
             "own_kernels_ms_per_decode": {"backbone_cnn": round(bb_total_ms, 2), "conv_tower": round(tower_total_ms, 2),
+                                          "value_tail": round(tail_total_ms, 2),
                                           "conv1d": round(conv_total_ms, 2), "gru": round(gru_total_ms, 2),
                                           "epilogue_ln": round(epi_total_ms, 2),
                                           "propose": round(k1_total_ms, 3), "select": round(k2_total_ms, 3)},

@@ -173,6 +173,15 @@ int svdd_tds_resample(const float* reward_num, const float* reward_den, float al
  *   wpack [2][4][64][96], bpack [2][4][64]: weights repacked per MFMA lane, see svdd_amd/fused.py:pack_gru. */
 int svdd_gru_bidir_f32(const float* x, const float* wpack, const float* bpack, float* out, int n, int L,
                        void* stream);
+/* svdd_value_tail_f32 — everything of the ConvGRU value net after the GRU, in one pass over the two GRU outputs:
+ *   out[n][t] = b_eff[t] + mean_l sum_c w_eff[c][t] * relu(b1[c] + sum_k W1[c][k] * LayerNorm(h_fwd + h_bwd)[n][l][k])
+ *   (reference Enformer.py:1617 direction sum; :2010-2047 FeedForwardBlock; :2131-2173 ConvHead with pool "avg").
+ *   h_fwd, h_bwd [n,L,64] ; w1pack [64 lanes][128]: lane (j = lane & 15, g = lane >> 4) holds W1[16 ct + j][16 g + s] at
+ *   16 ct + s (svdd_amd/fused.py:pack_tail) ; b1 [128] ; gamma, beta [64] (LayerNorm, eps 1e-5) ;
+ *   w_eff [128][n_tasks] = (W_head W_2)^T, b_eff [n_tasks] = W_head b_2 + b_head ; out [n][n_tasks] ; n_tasks <= 4. */
+int svdd_value_tail_f32(const float* h_fwd, const float* h_bwd, const float* w1pack, const float* b1,
+                        const float* gamma, const float* beta, const float* w_eff, const float* b_eff,
+                        float* out, int n, int L, int n_tasks, void* stream);
 /* tests / experiments: 2 selects the both-directions-per-workgroup scheduling (balanced but measured slower), else default */
 int svdd_gru_set_mode(int mode);
 
@@ -231,7 +240,7 @@ enum { SVDD_OPT_FORCE_EXACT = 0,
 int svdd_set_option(int key, int value);
 
 /* Per-launch kernel timing (host). While enabled, svdd_propose (kernel 0), svdd_select (1), svdd_conv1d_cl_f32 (2),
- * svdd_gru_bidir_f32 (3), svdd_epilogue_ln_f32 (4), svdd_conv_tower_f32 (5) and svdd_backbone_cnn_f32 (6) are dispatched
+ * svdd_gru_bidir_f32 (3), svdd_epilogue_ln_f32 (4), svdd_conv_tower_f32 (5), svdd_backbone_cnn_f32 (6) and svdd_value_tail_f32 (7) are dispatched
  * with HIP start/stop events bound to the dispatch on its launch stream
  * (hipExtLaunchKernelGGL); svdd_profile_collect waits for the recorded launches, returns the summed
  * hipEventElapsedTime and their count, and clears the record. Not for use during graph capture. */

@@ -567,7 +567,7 @@ __global__ __launch_bounds__(1024) void tds_resample_kernel(TdsArgs a) {
 // hipExtLaunchKernelGGL start/stop events, i.e. HIP events bound to the dispatch itself on the launch
 // stream; svdd_profile_collect() sums hipEventElapsedTime over the recorded launches.
 struct TimedLaunch { hipEvent_t start, stop; };
-constexpr int PROFILE_KERNELS = 7;            // 0 propose (K1), 1 select (K2), 2 conv1d, 3 gru, 4 epilogue_ln, 5 conv_tower, 6 backbone_cnn
+constexpr int PROFILE_KERNELS = 8;            // 0 propose (K1), 1 select (K2), 2 conv1d, 3 gru, 4 epilogue_ln, 5 conv_tower, 6 backbone_cnn, 7 value_tail
 bool g_profile = false;
 TimedLaunch* g_timed[PROFILE_KERNELS] = {};
 int g_timed_n[PROFILE_KERNELS] = {}, g_timed_cap[PROFILE_KERNELS] = {};

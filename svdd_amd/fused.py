@@ -124,6 +124,27 @@ def conv_tower(onehot, tiles, bias, residual_mask):
     return out
 
 
+def pack_tail(w1):
+    """dense1 weight W1 [128, 64] -> [64 lanes][128] MFMA B-operand image of svdd_value_tail_f32:
+    lane (j = lane & 15, g = lane >> 4) holds W1[16 ct + j][16 g + s] at index 16 ct + s."""
+    w = w1.detach().float().view(8, 16, 4, 16)                     # [ct][j][g][s]
+    return w.permute(2, 1, 0, 3).reshape(64, 128).contiguous()     # [g][j] -> lane = 16 g + j ; [ct][s]
+
+
+def value_tail(h, w1pack, b1, gamma, beta, w_eff, b_eff):
+    """h [2, n, L, 64] (GRU output, both directions) -> scores [n, n_tasks]: direction sum + LayerNorm + dense1 + ReLU +
+    collapsed (dense2, head) + mean over length in one pass (HIP kernel svdd_value_tail_f32)."""
+    assert h.is_cuda and h.dtype == torch.float32 and h.is_contiguous() and h.shape[0] == 2 and h.shape[3] == 64
+    _, n, L, _ = h.shape
+    T = w_eff.shape[1]
+    out = torch.empty((n, T), dtype=torch.float32, device=h.device)
+    rc = _lib.lib().svdd_value_tail_f32(h[0].data_ptr(), h[1].data_ptr(), w1pack.data_ptr(), b1.data_ptr(),
+                                        gamma.data_ptr(), beta.data_ptr(), w_eff.data_ptr(), b_eff.data_ptr(),
+                                        out.data_ptr(), n, L, T, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    _lib.check(rc, "svdd_value_tail_f32")
+    return out
+
+
 def pack_backbone(cnn):
     """CNNModel (hidden_dim 128, alphabet 5) -> the operand images of svdd_backbone_cnn_f32 (include/svdd_hip.h):
     dict(table0, tiles, vec, w2, dil). Time biases are those of sigma == 0 (diffusion_gosai.py:334-335)."""
@@ -244,6 +265,10 @@ class FusedValueNet(nn.Module):
         w2, b2 = d2.linear.weight.detach().double(), d2.linear.bias.detach().double()            # [64,128], [64]
         self.w_eff = nn.Parameter((wh @ w2).float().t().contiguous(), requires_grad=False)       # [128, T]
         self.b_eff = nn.Parameter((wh @ b2 + bh).float(), requires_grad=False)                   # [T]
+        self.tail_ok = tuple(self.w1.shape) == (128, 64) and self.w_eff.shape[1] <= 4
+        if self.tail_ok:
+            self.w1pack = nn.Parameter(pack_tail(self.w1), requires_grad=False)
+        self.use_fused_tail = True
 
     def forward(self, x):
         if x.shape[1] == self.in_channels and x.shape[2] != self.in_channels:
@@ -270,6 +295,8 @@ class FusedValueNet(nn.Module):
 
     def _after_tower(self, seq, n, L):
         h = gru_bidir(seq, self.wpack, self.bpack)
+        if self.use_fused_tail and self.tail_ok:
+            return value_tail(h, self.w1pack, self.b1, self.ln_w, self.ln_b, self.w_eff, self.b_eff)[:, :, None]
         # LayerNorm(h_fwd + h_bwd) in one pass (the direction sum of Enformer.py:1617 + dense1.norm)
         _, hn = epilogue_ln(h[0], None, h[1], None, self.ln_w, self.ln_b, act=ACT_NONE, want_sum=False)
         z = F.relu(F.linear(hn, self.w1, self.b1))                  # [n,L,128]

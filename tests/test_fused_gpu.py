@@ -197,3 +197,24 @@ def test_one_launch_backbone_vs_plain(n, L):
     # rows are independent: a sub-batch gives the same bits whatever tile it lands in
     if n >= 5:
         assert torch.equal(out[2:5], fused.backbone_cnn(x[2:5].contiguous(), pk))
+
+
+@pytest.mark.parametrize("n,L,T", [(5, 200, 1), (64, 200, 1), (7, 50, 1), (3, 33, 2), (9, 17, 4), (2, 1, 3)])
+def test_value_tail_vs_torch(n, L, T):
+    """svdd_value_tail_f32 (direction sum + LayerNorm + dense1 + ReLU + collapsed dense2/head + mean over length)
+    against the same maps as plain torch ops, incl. ragged last row tiles and several tasks."""
+    from svdd_amd import fused
+    g = torch.Generator(device="cpu").manual_seed(11)
+    h = torch.randn(2, n, L, 64, generator=g).to(DEV)
+    w1 = (torch.randn(128, 64, generator=g) * 0.2).to(DEV)
+    b1 = (torch.randn(128, generator=g) * 0.1).to(DEV)
+    gamma = (torch.rand(64, generator=g) + 0.5).to(DEV)
+    beta = (torch.randn(64, generator=g) * 0.2).to(DEV)
+    w_eff = (torch.randn(128, T, generator=g) * 0.2).to(DEV)
+    b_eff = torch.randn(T, generator=g).to(DEV)
+    out = fused.value_tail(h, fused.pack_tail(w1), b1, gamma, beta, w_eff, b_eff)
+    hn = torch.nn.functional.layer_norm((h[0] + h[1]).double(), (64,), gamma.double(), beta.double(), 1e-5)
+    ref = (torch.relu(hn @ w1.double().t() + b1.double()) @ w_eff.double()).mean(dim=1) + b_eff.double()
+    assert out.shape == (n, T)
+    assert (out.double() - ref).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item())
+    assert torch.equal(out, fused.value_tail(h, fused.pack_tail(w1), b1, gamma, beta, w_eff, b_eff))

@@ -1,0 +1,28 @@
+#!/bin/bash
+# Collects the judged evidence of a round on the GPU box into gpurun_out/<tag>_*:
+#   bench JSON line, rocprofv3 --kernel-trace --stats summary of the same command, per-kernel trace summary of our
+#   kernels, and FETCH_SIZE / WRITE_SIZE PMC passes (separate runs, --kernel-trace only) for the two roofline kernels.
+TAG=${1:-r01_v4}
+OUT=/root/repo/gpurun_out
+cd /tmp && export TMPDIR=/tmp
+python3 /root/repo/bench.py --steps 3 --warmup 1 2>/dev/null | tail -1 > $OUT/${TAG}_bench.json
+rm -rf /tmp/prof_$TAG
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o $TAG -- python3 /root/repo/bench.py --steps 2 --warmup 1 --cpu-steps 0 > /tmp/prof_$TAG.log 2>&1
+cp $(find /tmp/prof_$TAG -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_bench_kernel_stats.csv
+python3 /root/repo/tools/trace_summary.py $(find /tmp/prof_$TAG -name "*kernel_trace.csv" | head -1) backbone_kernel conv_tower_kernel gru_bidir propose_kernel select_kernel epilogue_ln conv1d_cl > $OUT/${TAG}_own_kernels_trace_summary.txt
+: > $OUT/${TAG}_pmc.txt
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/pmc_$c
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -- python3 /root/repo/bench.py --steps 1 --warmup 0 --cpu-steps 0 > /tmp/pmc_$c.log 2>&1
+  python3 - $(find /tmp/pmc_$c -name "*counter_collection.csv" | head -1) $c >> $OUT/${TAG}_pmc.txt <<'PY'
+import csv, sys, collections
+agg = collections.defaultdict(list)
+for r in csv.DictReader(open(sys.argv[1])):
+    n = r["Kernel_Name"]
+    if any(p in n for p in ("backbone_kernel", "propose_kernel", "conv_tower_kernel", "gru_bidir")):
+        agg[n[:90]].append(float(r["Counter_Value"]))
+for k, v in sorted(agg.items()):
+    print("%s per dispatch (KB) %-92s n=%d mean=%.3f min=%.3f max=%.3f" % (sys.argv[2], k, len(v), sum(v) / len(v), min(v), max(v)))
+PY
+done
+cat $OUT/${TAG}_bench.json | cut -c1-400; cat $OUT/${TAG}_pmc.txt; cat $OUT/${TAG}_own_kernels_trace_summary.txt
