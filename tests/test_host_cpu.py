@@ -166,3 +166,14 @@ def test_dps_gradient_matches_reference(golden):
         grad = d.compute_gradient_DPS(onehot, x, reward, torch.zeros(x.shape[0]), copy)
         ref = torch.from_numpy(g["grad"][i])
         assert torch.allclose(grad, ref, rtol=1e-4, atol=1e-9), (i, (grad - ref).abs().max())
+
+
+def test_detokenizer_roundtrip():
+    """dataloader_gosai.py:13-32: ids 0..3 <-> ACGT; MASK prints as N."""
+    from svdd_amd import tokens
+    x = torch.tensor([[0, 1, 2, 3, 3, 0], [3, 3, 4, 0, 1, 2]])
+    assert tokens.batch_dna_detokenize(x) == ["ACGTTA", "TTNACG"]
+    assert tokens.batch_dna_detokenize(x.numpy().astype(np.uint8)) == ["ACGTTA", "TTNACG"]
+    assert tokens.dna_detokenize(x[0]) == "ACGTTA"
+    assert tokens.DNASequenceDetokenizer().detokenize(x)[1] == "TTNACG"
+    assert tokens.dna_tokenize("acgtn").tolist() == [0, 1, 2, 3, 4]
