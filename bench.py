@@ -120,7 +120,7 @@ def main():
 
     def fence():
         if world > 1:
-            dist.barrier()
+            dist.barrier(device_ids=[local])
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -218,7 +218,7 @@ def main():
             line["cpu_baseline"] = None
         print(json.dumps(line))
     if world > 1:
-        dist.barrier()
+        dist.barrier(device_ids=[local])
         dist.destroy_process_group()
 
 
