@@ -1,14 +1,16 @@
-// svdd_nets.hip — gfx950 kernels for the value-network internals that PyTorch-ROCm/MIOpen runs
-// badly at SVDD's shapes (B*M = 2560 short sequences, hidden 64). Exposed through the C ABI of
-// include/svdd_hip.h ("net kernels" section); used by svdd_amd/fused.py.
+// svdd_nets.hip — gfx950 kernels for the two networks of the SVDD step (the masked-diffusion backbone and the
+// ConvGRU value net), which are >99 % of a diffusion step and which PyTorch-ROCm/MIOpen runs badly at SVDD's
+// shapes (256 / 2560 short sequences, 64-128 channels). Exact fp32 on the matrix cores throughout. Exposed through
+// the C ABI of include/svdd_hip.h ("net kernels" section); used by svdd_amd/fused.py.
 //
-//   gru_bidir_kernel   bidirectional GRU layer (input 64 -> hidden 64), fp32, one launch for all
-//                      L timesteps. MIOpen's RNN path issues ~10 tiny kernels per timestep per
-//                      direction (~2900 launches and 11.7 ms per value forward at n=2560, L=200
-//                      [rocprof r01_v0]); here each workgroup owns 16 sequences of one direction,
-//                      keeps the 96 KB of gate weights in registers (96 VGPRs/lane as MFMA B
-//                      operands), the hidden state in LDS, and runs the recurrence on the exact-fp32
-//                      matrix cores (v_mfma_f32_16x16x4_f32, 96 per wave-step).
+//   backbone_kernel     the whole dilated-CNN backbone forward in one launch (residual stream in registers,
+//                       LayerNorm'd activations in LDS, weights from L2 straight into MFMA B operands)
+//   conv_tower_kernel   the value net's conv tower (stem + 5 residual blocks) in one launch, activations in LDS
+//   gru_bidir_kernel    bidirectional GRU 64 -> 64, one launch for all L timesteps (MIOpen: ~2900 launches, 11.7 ms
+//                       per value forward at n = 2560, L = 200 [rocprof r01_v0]); 16 sequences of one direction per
+//                       workgroup, gate weights in registers as MFMA B operands, hidden state in LDS
+//   value_tail_kernel   direction sum + LayerNorm + FFN dense1 + ReLU + (dense2 o head) + mean over length
+//   conv1d_cl_*_kernel  one dilated conv layer (layer-wise path, small batches) ; epilogue_ln_kernel its epilogue
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <stdint.h>
@@ -821,9 +823,11 @@ __global__ __launch_bounds__(512, 4) void conv_tower_kernel(TowerArgs a) {
 // operands (a tap = a row offset; out-of-sequence rows read a zero row). No activation ever goes to HBM: per forward
 // the layer-wise path moved ~3 GB (conv in/out + the epilogue/LayerNorm pass per layer) and launched 41 kernels.
 // v_mfma_f32_16x16x4_f32, 16-row tiles (200 rows -> 13 tiles, 4 % padding); row tiles whose rows all fall into the
-// zero padding of a dilated tap are skipped in pairs (runtime, workgroup-uniform). Weights stream through LDS, one
-// [128][32] tile per (layer, chunk, tap), register-prefetched one tile ahead. LayerNorm statistics are two-pass
-// (mean, then centred variance) with a 16-lane shuffle reduction and an 8-wave LDS exchange.
+// zero padding of a dilated tap are skipped in pairs (runtime, workgroup-uniform, from a schedule built once in LDS).
+// Weights are NOT staged through LDS: each wave reads its [16 cout][32 k] slice of the (layer, chunk, tap) tile
+// straight from L2 into the B-operand registers, one tile ahead, so there is no barrier inside a layer.
+// LayerNorm statistics are two-pass (mean, then centred variance) with a 16-lane DPP reduction and an 8-wave LDS
+// exchange. Measurements and the PMC-guided history of this kernel: DESIGN.md section 4.
 constexpr int BB_C = 128;
 constexpr int BB_AP = BB_C + 4;
 constexpr int BB_MAXL = 32;
