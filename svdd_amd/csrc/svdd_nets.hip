@@ -817,16 +817,16 @@ __global__ __launch_bounds__(512, 4) void conv_tower_kernel(TowerArgs a) {
 //     f_0 = relu(conv9(onehot5(x)) + b)                      first layer as a 9-entry table lookup per output
 //     hn_i = LayerNorm(f_i + tb_i) ; f_{i+1} = relu(conv9_dil_i(hn_i) + b_i) + f_i          i = 0..nl-1
 //     logits = W2 relu(W1 f_nl + b1) + b2
-// One workgroup per tile of whole sequences (<= 208 rows), 8 waves; wave w owns output channels [16 w, 16 w + 16) of
-// EVERY row tile (13 x f32x4 accumulators) and keeps the residual stream f in registers in the same layout for the
-// whole forward. The only LDS-resident activation is the LayerNorm'd image hn [rows][128] that feeds the MFMA A
-// operands (a tap = a row offset; out-of-sequence rows read a zero row). No activation ever goes to HBM: per forward
-// the layer-wise path moved ~3 GB (conv in/out + the epilogue/LayerNorm pass per layer) and launched 41 kernels.
+// One workgroup per tile of whole sequences (<= 208 rows), 8 waves; every wave keeps its part of the residual stream f
+// in registers, in the MFMA C/D layout, for the whole forward (work split: see the kernel). The only LDS-resident
+// activation is the LayerNorm'd image hn [rows][128] that feeds the MFMA A operands (a tap = a row offset;
+// out-of-sequence rows read a zero row). No activation ever goes to HBM: per forward the layer-wise path moved ~3 GB
+// (conv in/out + the epilogue/LayerNorm pass per layer) and launched 41 kernels.
 // v_mfma_f32_16x16x4_f32, 16-row tiles (200 rows -> 13 tiles, 4 % padding); row tiles whose rows all fall into the
-// zero padding of a dilated tap are skipped in pairs (runtime, workgroup-uniform, from a schedule built once in LDS).
-// Weights are NOT staged through LDS: each wave reads its [16 cout][32 k] slice of the (layer, chunk, tap) tile
+// zero padding of a dilated tap are skipped (runtime, workgroup-uniform, from a schedule built once in LDS).
+// Weights are NOT staged through LDS: each wave reads its [32 cout][32 k] slice of the (layer, chunk, tap) tile
 // straight from L2 into the B-operand registers, one tile ahead, so there is no barrier inside a layer.
-// LayerNorm statistics are two-pass (mean, then centred variance) with a 16-lane DPP reduction and an 8-wave LDS
+// LayerNorm statistics are two-pass (mean, then centred variance) with a 16-lane DPP reduction and a 4-way LDS
 // exchange. Measurements and the PMC-guided history of this kernel: DESIGN.md section 4.
 constexpr int BB_C = 128;
 constexpr int BB_AP = BB_C + 4;
@@ -852,29 +852,39 @@ __device__ __forceinline__ float group16_sum(float v) {        // sum over the 1
   return v;
 }
 
+// Work split: wave w owns 32 output channels (column group w & 3) of the row tiles of parity w >> 2 (7 / 6 tiles; the
+// two waves of a SIMD share a column group and split the rows). An MFMA group is ONE row tile x two column tiles x
+// 8 k-steps = 16 MFMAs alternating two accumulators, so
+//   * an A fragment (two ds_read_b128 + one clamped address) feeds two column tiles;
+//   * dead row tiles are skipped one by one;
+//   * a LayerNorm row has two of its values in the same lane (half the DPP reductions, 4 partials per row).
+// (A first version gave each wave 16 channels of all 13 row tiles and skipped tiles in pairs: twice the LDS reads and
+//  address VALU per MFMA, 6 % more MFMAs; 2.31 vs 2.17 ms.)
 // LDS image rows: row -1 and rows >= L of a one-sequence tile are zero, so a tap is a clamped row offset.
 template <bool SPT1>
 __global__ __launch_bounds__(512, 2) void backbone_kernel(BackboneArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* img = smem + BB_AP;                              // rows -1 .. TW_ROWS ; [-1] and [TW_ROWS] stay zero
   float* Bs = smem + (TW_ROWS + 2) * BB_AP;               // [9][5][128] the first layer's lookup table
-  float* psum = Bs + 9 * 5 * BB_C;                        // [8][TW_ROWS]
+  float* psum = Bs + 9 * 5 * BB_C;                        // [4][TW_ROWS]
   float* rstat = psum + 8 * TW_ROWS;                      // [TW_ROWS]
   int* toks = reinterpret_cast<int*>(rstat + TW_ROWS);    // [TW_ROWS]
   int* rpos = toks + TW_ROWS;                             // [TW_ROWS] position of a tile row inside its sequence
   int* sdil = rpos + TW_ROWS;                             // [BB_MAXL + 1]
-  int* sched = sdil + BB_MAXL + 1;                        // [(nl + 1) * 36] schedule entries, see below
+  int* sched = sdil + BB_MAXL + 1;                        // [(nl + 1) * 36]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cg = w & 3, rh = w >> 2;
   const int j = lane & 15, g = lane >> 4;
-  const int col = 16 * w + j;
+  const int col0 = 32 * cg + j;                           // this lane's columns: col0 and col0 + 16
   const int L = a.L;
   const int tile_rows = a.spt * L;
   const int64_t row0 = (int64_t)blockIdx.x * tile_rows;
   const int64_t total_rows = (int64_t)a.n * L;
   const int nl = a.nl;
   const int it_end = (nl + 1) * 36;
+  constexpr int NR = 7;                                   // owned row tiles rh + 2 r (r = 6 only for rh = 0)
 
   for (int e = tid; e < TW_ROWS; e += 512) {
     toks[e] = (e < tile_rows && row0 + e < total_rows) ? a.x[row0 + e] : -1;
@@ -889,219 +899,225 @@ __global__ __launch_bounds__(512, 2) void backbone_kernel(BackboneArgs a) {
   for (int e = tid; e < 9 * 5 * BB_C; e += 512) Bs[e] = a.table0[e];
   __syncthreads();
   // Schedule: index k = (layer*4 + chunk)*9 + tap. sched[k] = 0 for a tap that only sees zero padding, else
-  //   bits 0-6: live row-tile pairs (0,1)(2,3)..(10,11)(12) ; 8-9 chunk ; 12-15 tap ; 16-25 index of the next live k.
+  //   bits 0-12: live row tiles ; 13-14 chunk ; 15-18 tap ; 19-28 index of the next live k.
   for (int k = tid; k < it_end; k += 512) {
     auto entry = [&](int kk) {
       const int layer = kk / 36, t = kk % 9;
-      if (layer >= nl) return t == 4 ? 0x7f : 0;
+      if (layer >= nl) return t == 4 ? 0x1fff : 0;
       const int d = (t - 4) * sdil[layer];
       const int lo = d < 0 ? -d : 0, hi = d > 0 ? L - d : L;
       if (lo >= hi) return 0;
-      if (!SPT1) return 0x7f;
+      if (!SPT1) return 0x1fff;
       int m = 0;
-      for (int p = 0; p < 7; ++p) if (lo < 32 * p + 32 && hi > 32 * p) m |= 1 << p;
+      for (int r = 0; r < TW_RT; ++r) if (lo < 16 * r + 16 && hi > 16 * r) m |= 1 << r;
       return m;
     };
     const int m = entry(k);
     int nx = k + 1;
     while (nx < it_end && entry(nx) == 0) ++nx;
-    sched[k] = m ? (m | ((k % 36) / 9) << 8 | (k % 9) << 12 | nx << 16) : 0;
+    sched[k] = m ? (m | ((k % 36) / 9) << 13 | (k % 9) << 15 | nx << 19) : 0;
   }
 
   // ---- first layer: f[row][col] = relu(b + sum_t table[t][tok[row + t - 4]][col])   (dnaconv.py:177,184)
-  f32x4 f[TW_RT], acc[TW_RT];
-  {
+  f32x4 f[NR][2], acc[NR][2];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    const int col = col0 + 16 * ct;
     const float b0 = a.vec[col];
 #pragma unroll
-    for (int r = 0; r < TW_RT; ++r)
+    for (int r = 0; r < NR; ++r)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int row = 16 * r + 4 * g + e;
+        const int row = 16 * (rh + 2 * r) + 4 * g + e;
         float v = b0;
-        const int pos = rpos[row];
+        if (row < TW_ROWS) {
+          const int pos = rpos[row];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-          const int p = pos + t - 4;
-          const int tk = (p >= 0 && p < L) ? toks[row + t - 4] : -1;
-          if (tk >= 0) v += Bs[(t * 5 + tk) * BB_C + col];
+          for (int t = 0; t < 9; ++t) {
+            const int p = pos + t - 4;
+            const int tk = (p >= 0 && p < L) ? toks[row + t - 4] : -1;
+            if (tk >= 0) v += Bs[(t * 5 + tk) * BB_C + col];
+          }
         }
-        f[r][e] = row < tile_rows ? fmaxf(v, 0.0f) : 0.0f;
+        f[r][ct][e] = row < tile_rows ? fmaxf(v, 0.0f) : 0.0f;
       }
   }
   __syncthreads();                                        // sched is visible
 
-  // A operand addressing: this lane feeds row 16 rt + j of every tile, channels 32 c + 8 g .. + 8
-  const int arow0 = (j * BB_AP + 8 * g) * 4;              // byte offset of (row j, col 8 g) inside img
-  const int a_lo = arow0 - (j + 1) * BB_AP * 4;           // row -1
-  const int a_hi = arow0 + (TW_ROWS - j) * BB_AP * 4;     // row TW_ROWS
-  int apos[SPT1 ? 1 : TW_RT];
+  // A operand addressing: this lane feeds row 16 (rh + 2 r) + j of its tiles, channels 32 c + 8 g .. + 8
+  const int arow0 = ((16 * rh + j) * BB_AP + 8 * g) * 4;  // byte offset of (row 16 rh + j, col 8 g) inside img
+  const int a_lo = arow0 - (16 * rh + j + 1) * BB_AP * 4; // row -1
+  const int a_hi = arow0 + (TW_ROWS - 16 * rh - j) * BB_AP * 4;     // row TW_ROWS
+  int apos[SPT1 ? 1 : NR];
   if (!SPT1) {
 #pragma unroll
-    for (int r = 0; r < TW_RT; ++r) apos[r] = rpos[16 * r + j];
+    for (int r = 0; r < NR; ++r) apos[r] = 16 * (rh + 2 * r) + j < TW_ROWS ? rpos[16 * (rh + 2 * r) + j] : -(1 << 20);
   }
   const char* imgb = reinterpret_cast<const char*>(img);
 
-  // Weight stream: each wave reads ITS [16 cout][32 k] slice of the (layer, chunk, tap) tile straight from L2 into the
-  // B-operand registers (2 KB contiguous per wave, one tile ahead). No LDS staging and no per-tile barrier: inside a
-  // layer the 8 waves run unsynchronised, so the address/scalar phase of one wave of a SIMD hides behind its partner's
-  // MFMAs (with an LDS-staged tile + barrier per tap the two ran in lockstep and the matrix pipe idled 36 %).
-  const float* wsrc = a.tiles + col * CH + 8 * g;
+  // Weight stream: each lane reads W[col0][8 g ..] and W[col0 + 16][8 g ..] of the (layer, chunk, tap) tile straight
+  // from L2 into the B-operand registers, one tile ahead (no LDS staging, no barrier inside a layer).
+  const float* wsrc = a.tiles + col0 * CH + 8 * g;
   auto tile_of = [&](int k) { return k < nl * 36 ? k : nl * 36 + (k - nl * 36) / 9; };
   int it = 0;
   while (it < it_end && sched[it] == 0) ++it;
   it = __builtin_amdgcn_readfirstlane(it);
-  int en = __builtin_amdgcn_readfirstlane(sched[it]);      // current entry; the next one is fetched an iteration ahead
-  float4 bn0, bn1;
+  int en = __builtin_amdgcn_readfirstlane(sched[it]);
+  float4 bn[4];
   {
     const float* src = wsrc + (size_t)tile_of(it) * BB_C * CH;
-    bn0 = *reinterpret_cast<const float4*>(src);
-    bn1 = *reinterpret_cast<const float4*>(src + 4);
+    bn[0] = *reinterpret_cast<const float4*>(src);
+    bn[1] = *reinterpret_cast<const float4*>(src + 4);
+    bn[2] = *reinterpret_cast<const float4*>(src + 16 * CH);
+    bn[3] = *reinterpret_cast<const float4*>(src + 16 * CH + 4);
   }
 
   for (int layer = 0; layer <= nl; ++layer) {             // layer == nl: the first 1x1 conv of final_conv
-    // ---- write the A image: LayerNorm(f + tb) for conv layers, f itself for the final 1x1 conv
     const float* vl = a.vec + (size_t)(layer + 1) * 4 * BB_C;
     if (layer < nl) {
-      const float tb = vl[BB_C + col], gm = vl[2 * BB_C + col], bt = vl[3 * BB_C + col];
-      // pass 1: row means
+      const float tb0 = vl[BB_C + col0], tb1 = vl[BB_C + col0 + 16];
+      // pass 1: row means (this lane's two values of a row first, then the 16 lanes of the DPP row)
 #pragma unroll
-      for (int r = 0; r < TW_RT; ++r)
+      for (int r = 0; r < NR; ++r)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float sm = group16_sum(f[r][e] + tb);
-          if (j == 0) psum[w * TW_ROWS + 16 * r + 4 * g + e] = sm;
+          const int row = 16 * (rh + 2 * r) + 4 * g + e;
+          const float sm = group16_sum((f[r][0][e] + tb0) + (f[r][1][e] + tb1));
+          if (j == 0 && row < TW_ROWS) psum[cg * TW_ROWS + row] = sm;
         }
       __syncthreads();
-      if (tid < TW_ROWS) {
-        float sm = 0.0f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) sm += psum[k * TW_ROWS + tid];
-        rstat[tid] = sm * (1.0f / BB_C);
-      }
+      if (tid < TW_ROWS)
+        rstat[tid] = ((psum[tid] + psum[TW_ROWS + tid]) + (psum[2 * TW_ROWS + tid] + psum[3 * TW_ROWS + tid])) * (1.0f / BB_C);
       __syncthreads();
       // pass 2: centred second moment
 #pragma unroll
-      for (int r = 0; r < TW_RT; ++r)
+      for (int r = 0; r < NR; ++r)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float d = f[r][e] + tb - rstat[16 * r + 4 * g + e];
-          acc[r][e] = d;                                  // keep the centred value
-          const float sq = group16_sum(d * d);
-          if (j == 0) psum[w * TW_ROWS + 16 * r + 4 * g + e] = sq;
+          const int row = 16 * (rh + 2 * r) + 4 * g + e;
+          const float mean = row < TW_ROWS ? rstat[row] : 0.0f;
+          const float d0 = f[r][0][e] + tb0 - mean, d1 = f[r][1][e] + tb1 - mean;
+          acc[r][0][e] = d0; acc[r][1][e] = d1;           // keep the centred values
+          const float sq = group16_sum(d0 * d0 + d1 * d1);
+          if (j == 0 && row < TW_ROWS) psum[cg * TW_ROWS + row] = sq;
         }
       __syncthreads();
-      if (tid < TW_ROWS) {
-        float sq = 0.0f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) sq += psum[k * TW_ROWS + tid];
-        rstat[tid] = rsqrtf(sq * (1.0f / BB_C) + 1e-5f);
-      }
+      if (tid < TW_ROWS)
+        rstat[tid] = rsqrtf(((psum[tid] + psum[TW_ROWS + tid]) + (psum[2 * TW_ROWS + tid] + psum[3 * TW_ROWS + tid])) *
+                            (1.0f / BB_C) + 1e-5f);
       __syncthreads();
+      const float gm0 = vl[2 * BB_C + col0], gm1 = vl[2 * BB_C + col0 + 16];
+      const float bt0 = vl[3 * BB_C + col0], bt1 = vl[3 * BB_C + col0 + 16];
 #pragma unroll
-      for (int r = 0; r < TW_RT; ++r)
+      for (int r = 0; r < NR; ++r)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const int row = 16 * r + 4 * g + e;
-          img[row * BB_AP + col] = row < tile_rows ? acc[r][e] * rstat[row] * gm + bt : 0.0f;
+          const int row = 16 * (rh + 2 * r) + 4 * g + e;
+          if (row < TW_ROWS) {
+            const float rs = rstat[row];
+            img[row * BB_AP + col0] = row < tile_rows ? acc[r][0][e] * rs * gm0 + bt0 : 0.0f;
+            img[row * BB_AP + col0 + 16] = row < tile_rows ? acc[r][1][e] * rs * gm1 + bt1 : 0.0f;
+          }
         }
     } else {
 #pragma unroll
-      for (int r = 0; r < TW_RT; ++r)
+      for (int r = 0; r < NR; ++r)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) img[(16 * r + 4 * g + e) * BB_AP + col] = f[r][e];
+        for (int e = 0; e < 4; ++e) {
+          const int row = 16 * (rh + 2 * r) + 4 * g + e;
+          if (row < TW_ROWS) { img[row * BB_AP + col0] = f[r][0][e]; img[row * BB_AP + col0 + 16] = f[r][1][e]; }
+        }
     }
     // ---- implicit GEMM over (chunk, live tap)
-    const float bl = vl[col];
+    const float bl0 = vl[col0], bl1 = vl[col0 + 16];
 #pragma unroll
-    for (int r = 0; r < TW_RT; ++r) acc[r] = f32x4{bl, bl, bl, bl};
+    for (int r = 0; r < NR; ++r) { acc[r][0] = f32x4{bl0, bl0, bl0, bl0}; acc[r][1] = f32x4{bl1, bl1, bl1, bl1}; }
     const int dil = __builtin_amdgcn_readfirstlane(sdil[layer < nl ? layer : BB_MAXL]);
     const int layer_end = (layer + 1) * 36;
     __syncthreads();                                      // the image is complete
     while (it < layer_end) {
-      const int nxt = en >> 16;
+      const int nxt = en >> 19;
       const int en_next_v = sched[nxt < it_end ? nxt : it];
-      const float bf[8] = {bn0.x, bn0.y, bn0.z, bn0.w, bn1.x, bn1.y, bn1.z, bn1.w};
+      const float bf0[8] = {bn[0].x, bn[0].y, bn[0].z, bn[0].w, bn[1].x, bn[1].y, bn[1].z, bn[1].w};
+      const float bf1[8] = {bn[2].x, bn[2].y, bn[2].z, bn[2].w, bn[3].x, bn[3].y, bn[3].z, bn[3].w};
       if (nxt < it_end) {
         const float* src = wsrc + (size_t)tile_of(nxt) * BB_C * CH;
-        bn0 = *reinterpret_cast<const float4*>(src);
-        bn1 = *reinterpret_cast<const float4*>(src + 4);
+        bn[0] = *reinterpret_cast<const float4*>(src);
+        bn[1] = *reinterpret_cast<const float4*>(src + 4);
+        bn[2] = *reinterpret_cast<const float4*>(src + 16 * CH);
+        bn[3] = *reinterpret_cast<const float4*>(src + 16 * CH + 4);
       }
-      const int delta = (((en >> 12) & 15) - 4) * dil;
-      const int coff = ((en >> 8) & 3) * (CH * 4);        // chunk byte offset inside a row
+      const int delta = (((en >> 15) & 15) - 4) * dil;
+      const int coff = ((en >> 13) & 3) * (CH * 4);
       const int dbytes = delta * (BB_AP * 4) + coff;
-      // A fragments are loaded one tile pair ahead of the MFMAs that consume them: the waves of a workgroup leave the
-      // barrier in lockstep, so an LDS latency exposed between two MFMA groups is exposed on every wave at once.
-#define BB_ALOAD(R, V)                                                                                       \
+      const int live = en >> rh;                          // bit 2 r = owned tile r
+#define B2_ALOAD(R, V)                                                                                       \
       { int o_;                                                                                              \
-        if (SPT1) { o_ = arow0 + (dbytes + (R) * 16 * BB_AP * 4);                                            \
-                    o_ = min(max(o_, a_lo + coff), a_hi + coff); }                                       \
-        else o_ = ((unsigned)(apos[SPT1 ? 0 : (R)] + delta) < (unsigned)L ? arow0 + dbytes + (R) * 16 * BB_AP * 4 \
+        if (SPT1) o_ = min(max(arow0 + dbytes + (R) * (32 * BB_AP * 4), a_lo + coff), a_hi + coff);          \
+        else o_ = ((unsigned)(apos[SPT1 ? 0 : (R)] + delta) < (unsigned)L ? arow0 + dbytes + (R) * (32 * BB_AP * 4) \
                                                                             : a_hi + coff);                  \
         const float4* ap_ = reinterpret_cast<const float4*>(imgb + o_);                                      \
         V[0] = ap_[0]; V[1] = ap_[1]; }
-      // Nothing but MFMAs inside a 16-MFMA group: an s_waitcnt or ds_read between two MFMAs costs tens of cycles of
-      // matrix-pipe time on gfx950, so each group is fenced and preceded by ONE explicit lgkmcnt wait that leaves
-      // exactly the next pair's reads (NOUT of them) in flight.
-#define BB_WAIT(NOUT) __builtin_amdgcn_s_waitcnt(0xC07F | ((NOUT) << 8));
-#define BB_MM2(P, R0, R1, U0, U1, NOUT)                                                                   \
-      __builtin_amdgcn_sched_barrier(0);                                                                  \
-      BB_WAIT(NOUT)                                                                                       \
-      if (en & (1 << (P))) {                                                                              \
-        _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                   \
-          acc[R0] = __builtin_amdgcn_mfma_f32_16x16x4f32(U0[q].x, bf[4 * q], acc[R0], 0, 0, 0);           \
-          acc[R1] = __builtin_amdgcn_mfma_f32_16x16x4f32(U1[q].x, bf[4 * q], acc[R1], 0, 0, 0);           \
-          acc[R0] = __builtin_amdgcn_mfma_f32_16x16x4f32(U0[q].y, bf[4 * q + 1], acc[R0], 0, 0, 0);       \
-          acc[R1] = __builtin_amdgcn_mfma_f32_16x16x4f32(U1[q].y, bf[4 * q + 1], acc[R1], 0, 0, 0);       \
-          acc[R0] = __builtin_amdgcn_mfma_f32_16x16x4f32(U0[q].z, bf[4 * q + 2], acc[R0], 0, 0, 0);       \
-          acc[R1] = __builtin_amdgcn_mfma_f32_16x16x4f32(U1[q].z, bf[4 * q + 2], acc[R1], 0, 0, 0);       \
-          acc[R0] = __builtin_amdgcn_mfma_f32_16x16x4f32(U0[q].w, bf[4 * q + 3], acc[R0], 0, 0, 0);       \
-          acc[R1] = __builtin_amdgcn_mfma_f32_16x16x4f32(U1[q].w, bf[4 * q + 3], acc[R1], 0, 0, 0);       \
-        }                                                                                                 \
-      }                                                                                                   \
+#define B2_WAIT(NOUT) __builtin_amdgcn_s_waitcnt(0xC07F | ((NOUT) << 8));
+#define B2_MM(R, U, NOUT)                                                                                    \
+      __builtin_amdgcn_sched_barrier(0);                                                                     \
+      B2_WAIT(NOUT)                                                                                          \
+      if (live & (1 << (2 * (R)))) {                                                                         \
+        _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                      \
+          acc[R][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(U[q].x, bf0[4 * q], acc[R][0], 0, 0, 0);          \
+          acc[R][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(U[q].x, bf1[4 * q], acc[R][1], 0, 0, 0);          \
+          acc[R][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(U[q].y, bf0[4 * q + 1], acc[R][0], 0, 0, 0);      \
+          acc[R][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(U[q].y, bf1[4 * q + 1], acc[R][1], 0, 0, 0);      \
+          acc[R][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(U[q].z, bf0[4 * q + 2], acc[R][0], 0, 0, 0);      \
+          acc[R][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(U[q].z, bf1[4 * q + 2], acc[R][1], 0, 0, 0);      \
+          acc[R][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(U[q].w, bf0[4 * q + 3], acc[R][0], 0, 0, 0);      \
+          acc[R][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(U[q].w, bf1[4 * q + 3], acc[R][1], 0, 0, 0);      \
+        }                                                                                                    \
+      }                                                                                                      \
       __builtin_amdgcn_sched_barrier(0);
-      float4 ua0[2], ua1[2], ub0[2], ub1[2];
-      BB_ALOAD(0, ua0) BB_ALOAD(1, ua1)
-      BB_ALOAD(2, ub0) BB_ALOAD(3, ub1)
-      BB_MM2(0, 0, 1, ua0, ua1, 4)
-      BB_ALOAD(4, ua0) BB_ALOAD(5, ua1)
-      BB_MM2(1, 2, 3, ub0, ub1, 4)
-      BB_ALOAD(6, ub0) BB_ALOAD(7, ub1)
-      BB_MM2(2, 4, 5, ua0, ua1, 4)
-      BB_ALOAD(8, ua0) BB_ALOAD(9, ua1)
-      BB_MM2(3, 6, 7, ub0, ub1, 4)
-      BB_ALOAD(10, ub0) BB_ALOAD(11, ub1)
-      BB_MM2(4, 8, 9, ua0, ua1, 4)
-      BB_ALOAD(12, ua0)
-      BB_MM2(5, 10, 11, ub0, ub1, 2)
-      __builtin_amdgcn_sched_barrier(0);
-      BB_WAIT(0)
-      if (en & (1 << 6)) {
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          acc[12] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua0[q].x, bf[4 * q], acc[12], 0, 0, 0);
-          acc[12] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua0[q].y, bf[4 * q + 1], acc[12], 0, 0, 0);
-          acc[12] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua0[q].z, bf[4 * q + 2], acc[12], 0, 0, 0);
-          acc[12] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua0[q].w, bf[4 * q + 3], acc[12], 0, 0, 0);
-        }
+      float4 ua[2], ub[2];
+      B2_ALOAD(0, ua) B2_ALOAD(1, ub)
+      B2_MM(0, ua, 2)
+      B2_ALOAD(2, ua)
+      B2_MM(1, ub, 2)
+      B2_ALOAD(3, ub)
+      B2_MM(2, ua, 2)
+      B2_ALOAD(4, ua)
+      B2_MM(3, ub, 2)
+      B2_ALOAD(5, ub)
+      B2_MM(4, ua, 2)
+      if (rh == 0) {
+        B2_ALOAD(6, ua)
+        B2_MM(5, ub, 2)
+        B2_MM(6, ua, 0)
+      } else {
+        B2_MM(5, ub, 0)
       }
-      __builtin_amdgcn_sched_barrier(0);
-#undef BB_WAIT
-#undef BB_MM2
-#undef BB_ALOAD
+#undef B2_MM
+#undef B2_WAIT
+#undef B2_ALOAD
       it = nxt;
       en = __builtin_amdgcn_readfirstlane(en_next_v);
     }
     __syncthreads();                                      // every wave is done reading the image
     if (layer < nl) {
 #pragma unroll
-      for (int r = 0; r < TW_RT; ++r)
+      for (int r = 0; r < NR; ++r)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) f[r][e] = fmaxf(acc[r][e], 0.0f) + f[r][e];       // relu(conv + b) + f  (:195-197)
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) f[r][ct][e] = fmaxf(acc[r][ct][e], 0.0f) + f[r][ct][e];   // relu(conv + b) + f
     } else {
 #pragma unroll
-      for (int r = 0; r < TW_RT; ++r)
+      for (int r = 0; r < NR; ++r)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) img[(16 * r + 4 * g + e) * BB_AP + col] = fmaxf(acc[r][e], 0.0f);   // relu(W1 f + b1)
+        for (int e = 0; e < 4; ++e) {
+          const int row = 16 * (rh + 2 * r) + 4 * g + e;
+          if (row < TW_ROWS) {
+            img[row * BB_AP + col0] = fmaxf(acc[r][0][e], 0.0f);                                   // relu(W1 f + b1)
+            img[row * BB_AP + col0 + 16] = fmaxf(acc[r][1][e], 0.0f);
+          }
+        }
     }
   }
   __syncthreads();
