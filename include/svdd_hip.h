@@ -174,14 +174,15 @@ int svdd_tds_resample(const float* reward_num, const float* reward_den, float al
 int svdd_gru_bidir_f32(const float* x, const float* wpack, const float* bpack, float* out, int n, int L,
                        void* stream);
 /* svdd_value_tail_f32 — everything of the ConvGRU value net after the GRU, in one pass over the two GRU outputs:
- *   out[n][t] = b_eff[t] + mean_l sum_c w_eff[c][t] * relu(b1[c] + sum_k W1[c][k] * LayerNorm(h_fwd + h_bwd)[n][l][k])
+ *   out[n][t] = b_eff[t] + mean_l sum_c w_eff[c][t] * relu(b1'[c] + sum_k W1'[c][k] * norm(h_fwd + h_bwd)[n][l][k])
+ *   norm = LayerNorm over the 64 channels WITHOUT affine (eps 1e-5); the caller folds the LayerNorm affine into the
+ *   linear map: W1' = W1 diag(gamma), b1' = b1 + W1 beta
  *   (reference Enformer.py:1617 direction sum; :2010-2047 FeedForwardBlock; :2131-2173 ConvHead with pool "avg").
- *   h_fwd, h_bwd [n,L,64] ; w1pack [64 lanes][128]: lane (j = lane & 15, g = lane >> 4) holds W1[16 ct + j][16 g + s] at
- *   16 ct + s (svdd_amd/fused.py:pack_tail) ; b1 [128] ; gamma, beta [64] (LayerNorm, eps 1e-5) ;
+ *   h_fwd, h_bwd [n,L,64] ; w1pack [64 lanes][128]: lane (j = lane & 15, g = lane >> 4) holds
+ *   W1'[16 ct + j][16 (s / 4) + 4 g + s % 4] at 16 ct + s (svdd_amd/fused.py:pack_tail) ; b1 = b1' [128] ;
  *   w_eff [128][n_tasks] = (W_head W_2)^T, b_eff [n_tasks] = W_head b_2 + b_head ; out [n][n_tasks] ; n_tasks <= 4. */
 int svdd_value_tail_f32(const float* h_fwd, const float* h_bwd, const float* w1pack, const float* b1,
-                        const float* gamma, const float* beta, const float* w_eff, const float* b_eff,
-                        float* out, int n, int L, int n_tasks, void* stream);
+                        const float* w_eff, const float* b_eff, float* out, int n, int L, int n_tasks, void* stream);
 /* tests / experiments: 2 selects the both-directions-per-workgroup scheduling (balanced but measured slower), else default */
 int svdd_gru_set_mode(int mode);
 

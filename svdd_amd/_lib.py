@@ -84,7 +84,7 @@ def lib():
     L.svdd_conv1d_set_dynamic.argtypes = [i32]
     L.svdd_gru_set_mode.argtypes = [i32]
     L.svdd_conv_tower_f32.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp]
-    L.svdd_value_tail_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]
+    L.svdd_value_tail_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]
     L.svdd_backbone_cnn_f32.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, ctypes.POINTER(ctypes.c_int), vp]
     L.svdd_conv1d_cl_f32.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp]
     L.svdd_epilogue_ln_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_int64, i32, i32, vp]

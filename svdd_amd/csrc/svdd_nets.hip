@@ -1137,30 +1137,31 @@ __global__ __launch_bounds__(512, 2) void backbone_kernel(BackboneArgs a) {
 // ------------------------------------------------------- value-net tail: everything after the GRU in one pass ----
 // score[n][t] = b_eff[t] + mean_l sum_c w_eff[c][t] * relu(b1[c] + sum_k W1[c][k] * LayerNorm(h_fwd + h_bwd)[n][l][k])
 // (reference Enformer.py:1617 direction sum, :2010-2047 FeedForwardBlock LayerNorm -> Linear 64->128 -> ReLU ->
-//  Linear 128->64, :2131-2173 ConvHead 1x1 conv + mean over length; the last two linear maps are collapsed by the host).
+//  Linear 128->64, :2131-2173 ConvHead 1x1 conv + mean over length; the last two linear maps are collapsed and the
+//  LayerNorm affine is folded into (W1, b1) by the host).
 // Replaces epilogue_ln + 2 GEMMs + ReLU + mean: those moved 1.3 GB through HBM per value forward (n = 2560, L = 200);
 // this reads the two GRU outputs once (262 MB) and writes n*T floats. One wave per sequence; 16-row tiles; the
-// 64 -> 128 map runs on the exact-fp32 matrix cores with W1 held in registers as MFMA B operands (k axis permuted so a
-// lane's A operand is 16 contiguous channels of its row); LayerNorm statistics are two-pass across the 4 lanes of a row.
+// 64 -> 128 map runs on the exact-fp32 matrix cores with W1 held in registers as MFMA B operands; LayerNorm statistics
+// are two-pass across the 4 lanes of a row. The next tile's rows are loaded RAW into registers under the current
+// tile's MFMAs and only summed when their turn comes (summing at load time would park the wave on the loads).
 template <int T>
-__global__ __launch_bounds__(256, 1) void value_tail_kernel(const float* __restrict__ hf, const float* __restrict__ hb,
+__global__ __launch_bounds__(256, 2) void value_tail_kernel(const float* __restrict__ hf, const float* __restrict__ hb,
                                                             const float* __restrict__ w1pack, const float* __restrict__ b1,
-                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             const float* __restrict__ weff, const float* __restrict__ beff,
                                                             float* __restrict__ out, int n, int L) {
   const int lane = threadIdx.x & 63;
   const int seq = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (seq >= n) return;
   const int j = lane & 15, g = lane >> 4;
-  float wb[128];                                           // wb[16 ct + s] = W1[16 ct + j][16 g + s]
+  // channel of this lane's value i (= MFMA k-step i): ch(i) = 16 (i / 4) + 4 g + (i % 4) — four 16-byte pieces that,
+  // across the 4 lanes of a row, make each load instruction cover whole 64-byte segments
+  float wb[128];                                           // wb[16 ct + s] = W1'[16 ct + j][ch(s)]
   {
     const float4* wp = reinterpret_cast<const float4*>(w1pack + (size_t)lane * 128);
 #pragma unroll
     for (int i = 0; i < 32; ++i) { const float4 v = wp[i]; wb[4 * i] = v.x; wb[4 * i + 1] = v.y; wb[4 * i + 2] = v.z; wb[4 * i + 3] = v.w; }
   }
-  float gm[16], bt[16], bias1[8], we[8][T];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) { gm[i] = gamma[16 * g + i]; bt[i] = beta[16 * g + i]; }
+  float bias1[8], we[8][T];
 #pragma unroll
   for (int ct = 0; ct < 8; ++ct) {
     bias1[ct] = b1[16 * ct + j];
@@ -1170,28 +1171,27 @@ __global__ __launch_bounds__(256, 1) void value_tail_kernel(const float* __restr
   float part[T];
 #pragma unroll
   for (int t = 0; t < T; ++t) part[t] = 0.0f;
-  const float* pf = hf + (size_t)seq * L * 64 + 16 * g;
-  const float* pb = hb + (size_t)seq * L * 64 + 16 * g;
+  const float* pf = hf + (size_t)seq * L * 64 + 4 * g;
+  const float* pb = hb + (size_t)seq * L * 64 + 4 * g;
   const int ntiles = (L + 15) / 16;
-  float v[16];
+  float4 xa[4], xb[4];
   auto load_rows = [&](int tile) {
-    const int row = 16 * tile + j;
-    if (row < L) {
-      const float4* a4 = reinterpret_cast<const float4*>(pf + (size_t)row * 64);
-      const float4* b4 = reinterpret_cast<const float4*>(pb + (size_t)row * 64);
+    const int row = min(16 * tile + j, L - 1);            // rows past the end re-read the last row; masked below
+    const float4* a4 = reinterpret_cast<const float4*>(pf + (size_t)row * 64);
+    const float4* b4 = reinterpret_cast<const float4*>(pb + (size_t)row * 64);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float4 x = a4[i], y = b4[i];
-        v[4 * i] = x.x + y.x; v[4 * i + 1] = x.y + y.y; v[4 * i + 2] = x.z + y.z; v[4 * i + 3] = x.w + y.w;
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) v[i] = 0.0f;
-    }
+    for (int i = 0; i < 4; ++i) { xa[i] = a4[4 * i]; xb[i] = b4[4 * i]; }
   };
   load_rows(0);
   for (int tile = 0; tile < ntiles; ++tile) {
-    // LayerNorm over the 64 channels of row 16 tile + j (this lane holds 16 of them; lanes j, j+16, j+32, j+48 the rest)
+    float v[16];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[4 * i] = xa[i].x + xb[i].x; v[4 * i + 1] = xa[i].y + xb[i].y;
+      v[4 * i + 2] = xa[i].z + xb[i].z; v[4 * i + 3] = xa[i].w + xb[i].w;
+    }
+    if (tile + 1 < ntiles) load_rows(tile + 1);           // fly under the LayerNorm and the 128 MFMAs below
+    // LayerNorm (no affine: folded into W1', b1') over the 64 channels of row 16 tile + j: 16 here, 48 in lanes j + 16 g'
     float sm = 0.0f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) sm += v[i];
@@ -1202,17 +1202,15 @@ __global__ __launch_bounds__(256, 1) void value_tail_kernel(const float* __restr
     for (int i = 0; i < 16; ++i) { v[i] -= mean; sq += v[i] * v[i]; }
     sq += __shfl_xor(sq, 16, 64); sq += __shfl_xor(sq, 32, 64);
     const float rstd = rsqrtf(sq * (1.0f / 64.0f) + 1e-5f);
-    float hn[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) hn[i] = v[i] * rstd * gm[i] + bt[i];
-    if (tile + 1 < ntiles) load_rows(tile + 1);           // next tile's rows fly under the MFMAs
+    for (int i = 0; i < 16; ++i) v[i] *= rstd;
     f32x4 acc[8];
 #pragma unroll
     for (int ct = 0; ct < 8; ++ct) acc[ct] = f32x4{bias1[ct], bias1[ct], bias1[ct], bias1[ct]};
 #pragma unroll
     for (int sidx = 0; sidx < 16; ++sidx)
 #pragma unroll
-      for (int ct = 0; ct < 8; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(hn[sidx], wb[16 * ct + sidx], acc[ct], 0, 0, 0);
+      for (int ct = 0; ct < 8; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[sidx], wb[16 * ct + sidx], acc[ct], 0, 0, 0);
     // C/D layout: reg rho -> row 4 g + rho, column 16 ct + j
 #pragma unroll
     for (int rho = 0; rho < 4; ++rho) {
@@ -1357,17 +1355,16 @@ extern "C" int svdd_backbone_cnn_f32(const uint8_t* x, const float* table0, cons
 }
 
 extern "C" int svdd_value_tail_f32(const float* h_fwd, const float* h_bwd, const float* w1pack, const float* b1,
-                                   const float* gamma, const float* beta, const float* w_eff, const float* b_eff,
-                                   float* out, int n, int L, int n_tasks, void* stream) {
-  if (!h_fwd || !h_bwd || !w1pack || !b1 || !gamma || !beta || !w_eff || !b_eff || !out || n <= 0 || L <= 0 ||
-      n_tasks < 1 || n_tasks > 4)
+                                   const float* w_eff, const float* b_eff, float* out, int n, int L, int n_tasks,
+                                   void* stream) {
+  if (!h_fwd || !h_bwd || !w1pack || !b1 || !w_eff || !b_eff || !out || n <= 0 || L <= 0 || n_tasks < 1 || n_tasks > 4)
     return SVDD_E_ARG;
   hipEvent_t e0, e1;
   svdd_internal_timed_events(7, &e0, &e1);
   const dim3 grid((unsigned)((n + 3) / 4)), block(256);
 #define SVDD_TAIL(TT)                                                                                              \
   hipExtLaunchKernelGGL(value_tail_kernel<TT>, grid, block, 0, (hipStream_t)stream, e0, e1, 0, h_fwd, h_bwd, w1pack, b1, \
-                        gamma, beta, w_eff, b_eff, out, n, L)
+                        w_eff, b_eff, out, n, L)
   switch (n_tasks) {
     case 1: SVDD_TAIL(1); break;
     case 2: SVDD_TAIL(2); break;

@@ -124,23 +124,28 @@ def conv_tower(onehot, tiles, bias, residual_mask):
     return out
 
 
-def pack_tail(w1):
-    """dense1 weight W1 [128, 64] -> [64 lanes][128] MFMA B-operand image of svdd_value_tail_f32:
-    lane (j = lane & 15, g = lane >> 4) holds W1[16 ct + j][16 g + s] at index 16 ct + s."""
-    w = w1.detach().float().view(8, 16, 4, 16)                     # [ct][j][g][s]
-    return w.permute(2, 1, 0, 3).reshape(64, 128).contiguous()     # [g][j] -> lane = 16 g + j ; [ct][s]
+def pack_tail(w1, b1, gamma, beta):
+    """(dense1 weight W1 [128, 64], bias b1, LayerNorm gamma/beta [64]) -> (w1pack [64 lanes][128], b1' [128]) for
+    svdd_value_tail_f32. The LayerNorm affine is folded into the linear map: W1' = W1 diag(gamma), b1' = b1 + W1 beta.
+    Lane (j = lane & 15, g = lane >> 4) holds W1'[16 ct + j][ch(g, s)] at index 16 ct + s, with
+    ch(g, s) = 16 (s // 4) + 4 g + s % 4 (the channel order in which the kernel's lanes read a row)."""
+    w64 = w1.detach().double()
+    wf = (w64 * gamma.detach().double()[None, :]).float()
+    bf = (b1.detach().double() + w64 @ beta.detach().double()).float().contiguous()
+    w = wf.view(8, 16, 4, 4, 4)                                   # [ct][j][i = s // 4][g][c = s % 4]
+    return w.permute(3, 1, 0, 2, 4).reshape(64, 128).contiguous(), bf
 
 
-def value_tail(h, w1pack, b1, gamma, beta, w_eff, b_eff):
+def value_tail(h, w1pack, b1f, w_eff, b_eff):
     """h [2, n, L, 64] (GRU output, both directions) -> scores [n, n_tasks]: direction sum + LayerNorm + dense1 + ReLU +
-    collapsed (dense2, head) + mean over length in one pass (HIP kernel svdd_value_tail_f32)."""
+    collapsed (dense2, head) + mean over length in one pass (HIP kernel svdd_value_tail_f32); (w1pack, b1f) from pack_tail."""
     assert h.is_cuda and h.dtype == torch.float32 and h.is_contiguous() and h.shape[0] == 2 and h.shape[3] == 64
     _, n, L, _ = h.shape
     T = w_eff.shape[1]
     out = torch.empty((n, T), dtype=torch.float32, device=h.device)
-    rc = _lib.lib().svdd_value_tail_f32(h[0].data_ptr(), h[1].data_ptr(), w1pack.data_ptr(), b1.data_ptr(),
-                                        gamma.data_ptr(), beta.data_ptr(), w_eff.data_ptr(), b_eff.data_ptr(),
-                                        out.data_ptr(), n, L, T, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    rc = _lib.lib().svdd_value_tail_f32(h[0].data_ptr(), h[1].data_ptr(), w1pack.data_ptr(), b1f.data_ptr(),
+                                        w_eff.data_ptr(), b_eff.data_ptr(), out.data_ptr(), n, L, T,
+                                        ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     _lib.check(rc, "svdd_value_tail_f32")
     return out
 
@@ -267,7 +272,9 @@ class FusedValueNet(nn.Module):
         self.b_eff = nn.Parameter((wh @ b2 + bh).float(), requires_grad=False)                   # [T]
         self.tail_ok = tuple(self.w1.shape) == (128, 64) and self.w_eff.shape[1] <= 4
         if self.tail_ok:
-            self.w1pack = nn.Parameter(pack_tail(self.w1), requires_grad=False)
+            wp, bf = pack_tail(self.w1, self.b1, self.ln_w, self.ln_b)
+            self.w1pack = nn.Parameter(wp, requires_grad=False)
+            self.b1f = nn.Parameter(bf, requires_grad=False)
         self.use_fused_tail = True
 
     def forward(self, x):
@@ -296,7 +303,7 @@ class FusedValueNet(nn.Module):
     def _after_tower(self, seq, n, L):
         h = gru_bidir(seq, self.wpack, self.bpack)
         if self.use_fused_tail and self.tail_ok:
-            return value_tail(h, self.w1pack, self.b1, self.ln_w, self.ln_b, self.w_eff, self.b_eff)[:, :, None]
+            return value_tail(h, self.w1pack, self.b1f, self.w_eff, self.b_eff)[:, :, None]
         # LayerNorm(h_fwd + h_bwd) in one pass (the direction sum of Enformer.py:1617 + dense1.norm)
         _, hn = epilogue_ln(h[0], None, h[1], None, self.ln_w, self.ln_b, act=ACT_NONE, want_sum=False)
         z = F.relu(F.linear(hn, self.w1, self.b1))                  # [n,L,128]

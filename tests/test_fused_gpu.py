@@ -212,9 +212,10 @@ def test_value_tail_vs_torch(n, L, T):
     beta = (torch.randn(64, generator=g) * 0.2).to(DEV)
     w_eff = (torch.randn(128, T, generator=g) * 0.2).to(DEV)
     b_eff = torch.randn(T, generator=g).to(DEV)
-    out = fused.value_tail(h, fused.pack_tail(w1), b1, gamma, beta, w_eff, b_eff)
+    wp, bf = fused.pack_tail(w1, b1, gamma, beta)
+    out = fused.value_tail(h, wp, bf, w_eff, b_eff)
     hn = torch.nn.functional.layer_norm((h[0] + h[1]).double(), (64,), gamma.double(), beta.double(), 1e-5)
     ref = (torch.relu(hn @ w1.double().t() + b1.double()) @ w_eff.double()).mean(dim=1) + b_eff.double()
     assert out.shape == (n, T)
     assert (out.double() - ref).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item())
-    assert torch.equal(out, fused.value_tail(h, fused.pack_tail(w1), b1, gamma, beta, w_eff, b_eff))
+    assert torch.equal(out, fused.value_tail(h, wp, bf, w_eff, b_eff))
