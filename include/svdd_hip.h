@@ -220,6 +220,22 @@ int svdd_conv1d_set_dynamic(int on);
 int svdd_conv_tower_f32(const float* onehot, const float* tiles, const float* bias, float* out, int n, int L,
                         int nlayers, int residual_mask, void* stream);
 
+/* svdd_candidate_windows + svdd_conv_tower_windows_f32 — the conv tower on the M candidates of every sample, sharing
+ *   the work they have in common with their parent x_t (SVDD-MC scoring, reference diffusion_gosai.py:1203-1209: the
+ *   candidates are copies of x_t with a few MASKs replaced). The tower's receptive field is +-17 rows, so a
+ *   candidate's tower output differs from its parent's only near the replaced positions; only a row window around
+ *   them is computed, the other rows are copied from the parent's output. Bit-identical to svdd_conv_tower_f32 on
+ *   the candidates (tests/test_fused_gpu.py::test_tower_windows_equal_full_tower).
+ *   svdd_candidate_windows: cand [B,M,L] u8, x [B,L] u8 -> win [B*M][2] = (w0, w1), multiples of 16 covering the
+ *     positions where the candidate differs from its parent +- margin (27 for the 5-layer tower); (0, 0) if none.
+ *   svdd_conv_tower_windows_f32: onehot [n = B*M, L, 4] (row b*M + m), win from above, parent_out [B, L, 64] =
+ *     svdd_conv_tower_f32 of the parents' one-hot; out [n, L, 64]. 104 < L <= 208, nlayers = 5. */
+int svdd_candidate_windows(const uint8_t* cand, const uint8_t* x, int B, int L, int M, int margin, int32_t* win,
+                           void* stream);
+int svdd_conv_tower_windows_f32(const float* onehot, const float* tiles, const float* bias, const int32_t* win,
+                                const float* parent_out, float* out, int n, int L, int M, int nlayers,
+                                int residual_mask, void* stream);
+
 /* svdd_backbone_cnn_f32 — the whole dilated-CNN masked-diffusion backbone at sigma = 0 in ONE launch
  *   (reference models/dnaconv.py:176-210 as called from diffusion_gosai.py:334-340): one-hot + 9-tap first conv,
  *   nlayers x [LayerNorm(f + tb_i) -> dilated 9-tap conv 128->128 -> ReLU -> + f], then the two 1x1 convs of

@@ -25,6 +25,7 @@ EXPORTS = (
     "svdd_set_option", "svdd_selftest_fastmath", "svdd_profile_enable", "svdd_profile_collect",
     "svdd_gru_bidir_f32", "svdd_epilogue_ln_f32", "svdd_conv1d_cl_f32",
     "svdd_conv1d_set_dynamic", "svdd_gru_set_mode", "svdd_conv_tower_f32", "svdd_backbone_cnn_f32", "svdd_value_tail_f32",
+    "svdd_candidate_windows", "svdd_conv_tower_windows_f32",
 )
 OPT_FORCE_EXACT = 0
 
@@ -85,6 +86,8 @@ def lib():
     L.svdd_gru_set_mode.argtypes = [i32]
     L.svdd_conv_tower_f32.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp]
     L.svdd_value_tail_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]
+    L.svdd_candidate_windows.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp]
+    L.svdd_conv_tower_windows_f32.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
     L.svdd_backbone_cnn_f32.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, ctypes.POINTER(ctypes.c_int), vp]
     L.svdd_conv1d_cl_f32.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp]
     L.svdd_epilogue_ln_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_int64, i32, i32, vp]

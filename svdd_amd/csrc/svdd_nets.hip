@@ -812,6 +812,193 @@ __global__ __launch_bounds__(512, 4) void conv_tower_kernel(TowerArgs a) {
   }
 }
 
+// ---------------------------------------------- conv tower on candidate WINDOWS (SVDD-MC: M candidates per parent) ----
+// The M candidates of a sample differ from their parent x_t only where a MASK was replaced this step (~L/steps
+// positions), and the tower's receptive field is +-17 rows (stem 15 taps + 5 x 5 taps). So tower(candidate) equals
+// tower(parent) outside +-17 rows of the changed positions, bit for bit (every output element accumulates the same
+// products in the same order). This kernel computes, per candidate, only a contiguous row window [w0, w1) (multiples
+// of 16) that covers the changed positions +-27 rows: +-17 for the receptive field, +10 because rows next to a window
+// edge see zeros instead of their real neighbours and are wrong by up to 2 rows per conv layer (the stem reads the real
+// one-hot rows beyond the window). Rows [w0 + 10, w1 - 10) come from this computation (a window edge that is a
+// sequence end is exact), all other rows are copied from the parent's tower output (computed once per parent by
+// conv_tower_kernel). At L = 200, 128 steps, M = 10: 42 % of the row tiles, 21 % of the candidates need none at all.
+struct TowerWinArgs {
+  TowerArgs t;             // x = candidates' one-hot [n, L, 4], out [n, L, 64]
+  const int* win;          // [n][2]  (w0, w1) ; w0 == w1: the candidate equals its parent
+  const float* parent_out; // [n / M, L, 64]
+  int M;
+};
+
+__global__ __launch_bounds__(512, 4) void conv_tower_win_kernel(TowerWinArgs wa) {
+  const TowerArgs& a = wa.t;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* act = smem + TW_AP;                            // rows -1 .. TW_ROWS ; [-1] and [TW_ROWS] stay zero
+  float* xs = smem + (TW_ROWS + 2) * TW_AP + 8 * 4;     // one-hot rows -8 .. TW_ROWS + 8 (real data beyond the window)
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cs = w & 3, rh = w >> 2;
+  const int j = lane & 15, g = lane >> 4;
+  const int L = a.L;
+  const int cand = blockIdx.x;
+  const int w0 = __builtin_amdgcn_readfirstlane(wa.win[2 * cand]);
+  const int w1 = __builtin_amdgcn_readfirstlane(wa.win[2 * cand + 1]);
+  const int nt = (w1 - w0) >> 4;                        // live row tiles
+  const int lrows = min(L, w1) - w0;                    // valid local rows
+  const int keep_lo = nt == 0 ? 0 : (w0 == 0 ? 0 : w0 + 10);
+  const int keep_hi = nt == 0 ? 0 : (w1 >= L ? L : w1 - 10);
+  float* outc = a.out + (size_t)cand * L * TW_C;
+  const float* par = wa.parent_out + (size_t)(cand / wa.M) * L * TW_C;
+
+  for (int e = tid; e < L * 16; e += 512) {             // rows that are the parent's, straight from its output
+    const int row = e >> 4;
+    if (row < keep_lo || row >= keep_hi)
+      *reinterpret_cast<float4*>(outc + (size_t)row * TW_C + 4 * (e & 15)) = *reinterpret_cast<const float4*>(par + (size_t)row * TW_C + 4 * (e & 15));
+  }
+  if (nt == 0) return;
+
+  const float* xc = a.x + (size_t)cand * L * 4;
+  for (int e = tid - 8; e < TW_ROWS + 8; e += 512) {
+    const int gl = w0 + e;
+    float4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (gl >= 0 && gl < L) v = *reinterpret_cast<const float4*>(xc + (size_t)gl * 4);
+    *reinterpret_cast<float4*>(xs + 4 * e) = v;
+  }
+  for (int e = tid; e < (TW_ROWS + 2) * TW_AP; e += 512) smem[e] = 0.0f;     // rows beyond the window must read as zero
+  const float* wsrc = a.tiles + (16 * cs + j) * CH + 8 * g;
+  float4 bn0 = *reinterpret_cast<const float4*>(wsrc), bn1 = *reinterpret_cast<const float4*>(wsrc + 4);
+
+  const int arow0 = 16 * rh + j;
+  const int abase = ((16 * rh + j) * TW_AP + 8 * g) * 4;
+  const int a_lo = abase - (16 * rh + j + 1) * TW_AP * 4;
+  const int a_hi = abase + (TW_ROWS - 16 * rh - j) * TW_AP * 4;
+  const char* actb = reinterpret_cast<const char*>(act);
+  const int nlive = (nt - rh + 1) >> 1;                 // owned live tiles rh + 2 r, r < nlive (a prefix)
+  const int nit = 2 + 10 * a.nlayers;
+  int it = 0;
+  f32x4 acc[7];
+  __syncthreads();
+
+#define TW_WAIT(NOUT) __builtin_amdgcn_s_waitcnt(0xC07F | ((NOUT) << 8));
+#define TWW_MMA(AF, R0, CNT)                                                                                  \
+  _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                             \
+    _Pragma("unroll") for (int r = 0; r < CNT; ++r) acc[R0 + r] = __builtin_amdgcn_mfma_f32_16x16x4f32(AF[r][q].x, bf[4 * q], acc[R0 + r], 0, 0, 0);     \
+    _Pragma("unroll") for (int r = 0; r < CNT; ++r) acc[R0 + r] = __builtin_amdgcn_mfma_f32_16x16x4f32(AF[r][q].y, bf[4 * q + 1], acc[R0 + r], 0, 0, 0); \
+    _Pragma("unroll") for (int r = 0; r < CNT; ++r) acc[R0 + r] = __builtin_amdgcn_mfma_f32_16x16x4f32(AF[r][q].z, bf[4 * q + 2], acc[R0 + r], 0, 0, 0); \
+    _Pragma("unroll") for (int r = 0; r < CNT; ++r) acc[R0 + r] = __builtin_amdgcn_mfma_f32_16x16x4f32(AF[r][q].w, bf[4 * q + 3], acc[R0 + r], 0, 0, 0); \
+  }
+#define TWW_GROUP3(AF, R0) { const int c_ = nlive - (R0); if (c_ >= 3) { TWW_MMA(AF, R0, 3) } else if (c_ == 2) { TWW_MMA(AF, R0, 2) } else if (c_ == 1) { TWW_MMA(AF, R0, 1) } }
+#define TWW_GROUP2(AF, R0) { const int c_ = nlive - (R0); if (c_ >= 2) { TWW_MMA(AF, R0, 2) } else if (c_ == 1) { TWW_MMA(AF, R0, 1) } }
+
+  for (int layer = -1; layer < a.nlayers; ++layer) {
+    const float bl = a.bias[(layer + 1) * TW_C + 16 * cs + j];
+#pragma unroll
+    for (int r = 0; r < 7; ++r) acc[r] = f32x4{bl, bl, bl, bl};
+    const int niter = layer < 0 ? 2 : 10;
+    for (int ci = 0; ci < niter; ++ci, ++it) {
+      const float bf[8] = {bn0.x, bn0.y, bn0.z, bn0.w, bn1.x, bn1.y, bn1.z, bn1.w};
+      if (it + 1 < nit) {
+        const float* src = wsrc + (size_t)(it + 1) * TW_C * CH;
+        bn0 = *reinterpret_cast<const float4*>(src);
+        bn1 = *reinterpret_cast<const float4*>(src + 4);
+      }
+      if (layer < 0) {
+        const int t0 = 8 * ci + 2 * g;
+        float4 fa[3][2], fb[2][2];
+#define TWW_XLOAD(R, V)                                                                                       \
+        { const float* xp_ = xs + 4 * (arow0 + 32 * (R) + t0 - 7);                                            \
+          V[0] = *reinterpret_cast<const float4*>(xp_); V[1] = *reinterpret_cast<const float4*>(xp_ + 4); }
+        TWW_XLOAD(0, fa[0]) TWW_XLOAD(1, fa[1]) TWW_XLOAD(2, fa[2])
+        TWW_XLOAD(3, fb[0]) TWW_XLOAD(4, fb[1])
+        __builtin_amdgcn_sched_barrier(0);
+        TW_WAIT(4)
+        TWW_GROUP3(fa, 0)
+        __builtin_amdgcn_sched_barrier(0);
+        TWW_XLOAD(5, fa[0])
+        if (rh == 0) TWW_XLOAD(6, fa[1])
+        __builtin_amdgcn_sched_barrier(0);
+        if (rh == 1) { TW_WAIT(2) } else { TW_WAIT(4) }
+        TWW_GROUP2(fb, 3)
+        __builtin_amdgcn_sched_barrier(0);
+        TW_WAIT(0)
+        TWW_GROUP2(fa, 5)
+        __builtin_amdgcn_sched_barrier(0);
+#undef TWW_XLOAD
+      } else {
+        const int c = ci / 5, delta = ci - 5 * c - 2;
+        const int dbytes = delta * (TW_AP * 4) + c * (CH * 4);
+        float4 fa[3][2], fb[2][2];
+#define TWW_ALOAD(R, V)                                                                                       \
+        { const int o_ = min(max(abase + dbytes + (R) * (32 * TW_AP * 4), a_lo + c * (CH * 4)), a_hi + c * (CH * 4)); \
+          const float4* ap_ = reinterpret_cast<const float4*>(actb + o_);                                     \
+          V[0] = ap_[0]; V[1] = ap_[1]; }
+        TWW_ALOAD(0, fa[0]) TWW_ALOAD(1, fa[1]) TWW_ALOAD(2, fa[2])
+        TWW_ALOAD(3, fb[0]) TWW_ALOAD(4, fb[1])
+        __builtin_amdgcn_sched_barrier(0);
+        TW_WAIT(4)
+        TWW_GROUP3(fa, 0)
+        __builtin_amdgcn_sched_barrier(0);
+        TWW_ALOAD(5, fa[0])
+        if (rh == 0) TWW_ALOAD(6, fa[1])
+        __builtin_amdgcn_sched_barrier(0);
+        if (rh == 1) { TW_WAIT(2) } else { TW_WAIT(4) }
+        TWW_GROUP2(fb, 3)
+        __builtin_amdgcn_sched_barrier(0);
+        TW_WAIT(0)
+        TWW_GROUP2(fa, 5)
+        __builtin_amdgcn_sched_barrier(0);
+#undef TWW_ALOAD
+      }
+    }
+    if (layer >= 0) __syncthreads();
+    const bool res = layer >= 0 && ((a.residual_mask >> layer) & 1);
+#pragma unroll
+    for (int r = 0; r < 7; ++r) {
+      if (r >= nlive) continue;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int row = 16 * (rh + 2 * r) + 4 * g + e;
+        const int o = row * TW_AP + 16 * cs + j;
+        const float v = acc[r][e] + (res ? act[o] : 0.0f);
+        act[o] = row < lrows ? fmaxf(v, 0.0f) : 0.0f;
+      }
+    }
+    __syncthreads();
+  }
+#undef TWW_GROUP2
+#undef TWW_GROUP3
+#undef TWW_MMA
+#undef TW_WAIT
+  for (int e = tid; e < L * 16; e += 512) {
+    const int row = e >> 4, q = e & 15;
+    if (row >= keep_lo && row < keep_hi)
+      *reinterpret_cast<float4*>(outc + (size_t)row * TW_C + 4 * q) = *reinterpret_cast<const float4*>(act + (row - w0) * TW_AP + 4 * q);
+  }
+}
+
+// (w0, w1) of every candidate: one wave per candidate compares it with its parent.
+__global__ __launch_bounds__(256) void candidate_windows_kernel(const uint8_t* __restrict__ cand, const uint8_t* __restrict__ x,
+                                                               int n, int L, int M, int margin, int* __restrict__ win) {
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= n) return;
+  const int lane = threadIdx.x & 63;
+  const uint8_t* cp = cand + (size_t)c * L;
+  const uint8_t* xp = x + (size_t)(c / M) * L;
+  int lo = 1 << 30, hi = -1;
+  for (int l = lane; l < L; l += 64)
+    if (cp[l] != xp[l]) { lo = min(lo, l); hi = max(hi, l); }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { lo = min(lo, __shfl_xor(lo, off, 64)); hi = max(hi, __shfl_xor(hi, off, 64)); }
+  if (lane == 0) {
+    int w0 = 0, w1 = 0;
+    if (hi >= 0) {
+      w0 = max(0, lo - margin) & ~15;
+      w1 = min((L + 15) & ~15, (hi + margin + 1 + 15) & ~15);
+    }
+    win[2 * c] = w0; win[2 * c + 1] = w1;
+  }
+}
+
 // --------------------------------------------------------- fused dilated-CNN backbone (one launch per forward) ----
 // The whole masked-diffusion backbone of the reference (models/dnaconv.py:176-210, sigma = 0):
 //     f_0 = relu(conv9(onehot5(x)) + b)                      first layer as a 9-entry table lookup per output
@@ -1372,5 +1559,29 @@ extern "C" int svdd_value_tail_f32(const float* h_fwd, const float* h_bwd, const
     default: SVDD_TAIL(4); break;
   }
 #undef SVDD_TAIL
+  return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
+}
+
+extern "C" int svdd_candidate_windows(const uint8_t* cand, const uint8_t* x, int B, int L, int M, int margin, int32_t* win,
+                                      void* stream) {
+  if (!cand || !x || !win || B <= 0 || L <= 0 || M <= 0 || margin < 0) return SVDD_E_ARG;
+  const int n = B * M;
+  hipLaunchKernelGGL(candidate_windows_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, cand, x,
+                     n, L, M, margin, win);
+  return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
+}
+
+extern "C" int svdd_conv_tower_windows_f32(const float* onehot, const float* tiles, const float* bias, const int32_t* win,
+                                           const float* parent_out, float* out, int n, int L, int M, int nlayers,
+                                           int residual_mask, void* stream) {
+  if (!onehot || !tiles || !bias || !win || !parent_out || !out || n <= 0 || M <= 0 || n % M || L <= TW_ROWS / 2 ||
+      L > TW_ROWS || nlayers != 5)
+    return SVDD_E_ARG;                                   // one sequence per tile; margins below assume the 5-layer tower
+  TowerWinArgs wa{TowerArgs{onehot, tiles, bias, out, n, L, 1, nlayers, residual_mask}, win, parent_out, M};
+  const size_t lds = sizeof(float) * ((size_t)(TW_ROWS + 2) * TW_AP + (size_t)(TW_ROWS + 16) * 4);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_tower_win_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipEvent_t e0, e1;
+  svdd_internal_timed_events(5, &e0, &e1);
+  hipExtLaunchKernelGGL(conv_tower_win_kernel, dim3((unsigned)n), dim3(512), lds, (hipStream_t)stream, e0, e1, 0, wa);
   return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
 }

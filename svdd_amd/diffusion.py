@@ -177,10 +177,12 @@ class Diffusion(nn.Module):
         x_next, _, _ = ops.select(scores, cand, mode=mode, rng=rng, want_soft=False)
         return x_next
 
-    def _value_scores(self, embedding, head, onehot, B, M):
+    def _value_scores(self, embedding, head, onehot, B, M, cand=None, x_u8=None):
         """scores[b, m] = head(embedding(onehot of candidate m of sample b)) (:1207-1209,1219)."""
         fn = self.value_callable(embedding, head)
         if self.value_batching == "batched":
+            if cand is not None and hasattr(fn, "candidates_ok") and fn.candidates_ok(onehot.shape[1], M):
+                return fn.forward_candidates(onehot, cand, x_u8).reshape(B, M).float()
             return fn(onehot).reshape(B, M).float()
         oh = onehot.view(B, M, onehot.shape[1], 4)
         return torch.stack([fn(oh[:, m].contiguous()).reshape(B) for m in range(M)], dim=1).float()
@@ -265,7 +267,7 @@ class Diffusion(nn.Module):
         logits = self._backbone_logits(x_u8)
         B, L = x_u8.shape
         cand, onehot, q = ops.propose(logits, x_u8, dm, mcs, repeats, self._rng(0, repeats, B, L, logits), want_q=True)
-        scores = self._value_scores(pre_scorer_embedding, pre_scorer_head, onehot, B, repeats)
+        scores = self._value_scores(pre_scorer_embedding, pre_scorer_head, onehot, B, repeats, cand, x_u8)
         x_next = self._select(scores, cand, 0)
         return x_next.long(), x, q, (x != self.mask_index).to(x.dtype)
 
@@ -412,7 +414,7 @@ class Diffusion(nn.Module):
         for i in range(S):
             logits = self._backbone_logits(x)
             ops.propose(logits, x, sched[i, 2], sched[i, 1], M, self._rng(i, M, B, L, logits), cand=cand, onehot=onehot)
-            scores = self._value_scores(pre_scorer_embedding, pre_scorer_head, onehot, B, M)
+            scores = self._value_scores(pre_scorer_embedding, pre_scorer_head, onehot, B, M, cand, x)
             self._record(logits, scores)
             x = self._select(scores, cand, i)
         return self._noise_removal(x)

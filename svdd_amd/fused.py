@@ -194,6 +194,35 @@ def backbone_cnn(tokens, pk):
     return out
 
 
+TOWER_WINDOW_MARGIN = 27     # +-17 rows receptive field of the 5-layer tower + 10 rows of window-edge error
+
+
+def candidate_windows(cand, x, margin=TOWER_WINDOW_MARGIN):
+    """cand [B, M, L] u8, x [B, L] u8 -> int32 [B*M, 2]: the 16-aligned row window (w0, w1) around the positions where a
+    candidate differs from its parent, (0, 0) for an exact copy (HIP kernel svdd_candidate_windows)."""
+    assert cand.is_cuda and cand.dtype == torch.uint8 and cand.is_contiguous() and x.dtype == torch.uint8 and x.is_contiguous()
+    B, M, L = cand.shape
+    win = torch.empty((B * M, 2), dtype=torch.int32, device=cand.device)
+    rc = _lib.lib().svdd_candidate_windows(cand.data_ptr(), x.data_ptr(), B, L, M, margin, win.data_ptr(),
+                                           ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    _lib.check(rc, "svdd_candidate_windows")
+    return win
+
+
+def conv_tower_windows(onehot, win, parent_out, M, tiles, bias, residual_mask):
+    """Tower output [n, L, 64] of the candidates' one-hot [n = B*M, L, 4], computing only the row windows `win` and
+    copying the rest from the parents' tower output [B, L, 64] (HIP kernel svdd_conv_tower_windows_f32)."""
+    assert onehot.is_cuda and onehot.dtype == torch.float32 and onehot.is_contiguous() and onehot.shape[2] == 4
+    n, L, _ = onehot.shape
+    assert parent_out.is_contiguous() and parent_out.shape == (n // M, L, 64) and win.shape == (n, 2)
+    out = torch.empty((n, L, 64), dtype=torch.float32, device=onehot.device)
+    rc = _lib.lib().svdd_conv_tower_windows_f32(onehot.data_ptr(), tiles.data_ptr(), bias.data_ptr(), win.data_ptr(),
+                                                parent_out.data_ptr(), out.data_ptr(), n, L, M, bias.shape[0] - 1,
+                                                int(residual_mask), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    _lib.check(rc, "svdd_conv_tower_windows_f32")
+    return out
+
+
 def epilogue_ln(y, bias=None, f_prev=None, tb=None, gamma=None, beta=None, act=ACT_RELU_THEN_ADD, want_norm=True,
                 want_sum=True):
     """Fused conv epilogue on channels-last rows (HIP kernel svdd_epilogue_ln_f32):
@@ -276,6 +305,7 @@ class FusedValueNet(nn.Module):
             self.w1pack = nn.Parameter(wp, requires_grad=False)
             self.b1f = nn.Parameter(bf, requires_grad=False)
         self.use_fused_tail = True
+        self.share_parent_tower = True
 
     def forward(self, x):
         if x.shape[1] == self.in_channels and x.shape[2] != self.in_channels:
@@ -299,6 +329,23 @@ class FusedValueNet(nn.Module):
                 f, _ = epilogue_ln(y, b, f if res else None, act=ACT_ADD_THEN_RELU, want_norm=False)   # relu(conv + b + f)
         seq = f.permute(0, 2, 3, 1).reshape(n, L, f.shape[1])       # [n,L,64] — a view, memory is already NLC
         return self._after_tower(seq.contiguous(), n, L)
+
+    def candidates_ok(self, L, M):
+        """True when forward_candidates can share the parents' tower work (reference-shaped tower, one sequence per
+        tile)."""
+        return (self.use_fused_tower and self.tower_ok and self.share_parent_tower and M > 1 and 104 < L <= 208 and
+                self.tw_bias.shape[0] == 6)
+
+    def forward_candidates(self, onehot, cand, x):
+        """Scores of the B*M candidates (onehot [B*M, L, 4], row b*M + m; cand [B, M, L] u8) of the parents x [B, L] u8.
+        Same result as forward(onehot), bit for bit; the conv tower is evaluated once per parent and, per candidate,
+        only on the row window around the positions it changed (svdd_conv_tower_windows_f32)."""
+        from . import ops
+        B, M, L = cand.shape
+        parent_out = conv_tower(ops.transform_samples(x), self.tw_tiles, self.tw_bias, self.tw_resmask)
+        win = candidate_windows(cand, x)
+        seq = conv_tower_windows(onehot, win, parent_out, M, self.tw_tiles, self.tw_bias, self.tw_resmask)
+        return self._after_tower(seq, B * M, L)
 
     def _after_tower(self, seq, n, L):
         h = gru_bidir(seq, self.wpack, self.bpack)

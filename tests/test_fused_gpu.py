@@ -219,3 +219,42 @@ def test_value_tail_vs_torch(n, L, T):
     assert out.shape == (n, T)
     assert (out.double() - ref).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item())
     assert torch.equal(out, fused.value_tail(h, wp, bf, w_eff, b_eff))
+
+
+@pytest.mark.parametrize("B,M,L,nchg", [(6, 5, 200, 2), (3, 10, 200, 6), (4, 3, 187, 1), (2, 4, 120, 3), (5, 2, 208, 0)])
+def test_tower_windows_equal_full_tower(nets, B, M, L, nchg):
+    """svdd_conv_tower_windows_f32 (parent tower + per-candidate row windows) is bit-identical to the full tower on
+    every candidate: candidates that equal the parent, changes at the sequence ends, many scattered changes."""
+    from svdd_amd import fused, ops
+    model, emb, head, _ = nets
+    fv = fused.FusedValueNet(emb, head).to(DEV).eval()
+    g = torch.Generator(device="cpu").manual_seed(3 + nchg)
+    x = torch.randint(0, 5, (B, L), generator=g).to(torch.uint8)
+    x[:, ::3] = 4                                                   # plenty of MASKs to replace
+    cand = x[:, None, :].repeat(1, M, 1).clone()
+    for b in range(B):
+        for m in range(M):
+            if m == 0 and nchg:                                     # one candidate changes both sequence ends
+                pos = torch.tensor([0, L - 1])
+            else:
+                masked = (x[b] == 4).nonzero().flatten()
+                k = int(torch.randint(0, nchg + 1, (1,), generator=g))
+                pos = masked[torch.randperm(len(masked), generator=g)[:k]]
+            cand[b, m, pos] = torch.randint(0, 4, (len(pos),), generator=g).to(torch.uint8)
+    x, cand = x.to(DEV), cand.to(DEV).contiguous()
+    onehot = ops.transform_samples(cand.view(B * M, L))
+    full = fused.conv_tower(onehot, fv.tw_tiles, fv.tw_bias, fv.tw_resmask)
+    parent = fused.conv_tower(ops.transform_samples(x), fv.tw_tiles, fv.tw_bias, fv.tw_resmask)
+    win = fused.candidate_windows(cand, x)
+    out = fused.conv_tower_windows(onehot, win, parent, M, fv.tw_tiles, fv.tw_bias, fv.tw_resmask)
+    assert torch.equal(out, full)
+    w = win.cpu()
+    diff = (cand != x[:, None, :]).view(B * M, L).cpu()
+    for c in range(B * M):                                          # window = changed positions +- 27, 16-aligned
+        p = diff[c].nonzero().flatten()
+        if len(p) == 0:
+            assert w[c].tolist() == [0, 0]
+        else:
+            assert w[c, 0] == max(0, int(p.min()) - 27) // 16 * 16 and w[c, 1] >= min(L, int(p.max()) + 28)
+    with torch.no_grad():                                           # and the scores through the whole value net
+        assert torch.equal(fv.forward_candidates(onehot, cand, x), fv(onehot))
