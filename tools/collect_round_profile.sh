@@ -9,7 +9,7 @@ python3 /root/repo/bench.py --steps 3 --warmup 1 2>/dev/null | tail -1 > $OUT/${
 rm -rf /tmp/prof_$TAG
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o $TAG -- python3 /root/repo/bench.py --steps 2 --warmup 1 --cpu-steps 0 > /tmp/prof_$TAG.log 2>&1
 cp $(find /tmp/prof_$TAG -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_bench_kernel_stats.csv
-python3 /root/repo/tools/trace_summary.py $(find /tmp/prof_$TAG -name "*kernel_trace.csv" | head -1) backbone_kernel conv_tower_kernel gru_bidir value_tail propose_kernel select_kernel epilogue_ln conv1d_cl > $OUT/${TAG}_own_kernels_trace_summary.txt
+python3 /root/repo/tools/trace_summary.py $(find /tmp/prof_$TAG -name "*kernel_trace.csv" | head -1) backbone_kernel conv_tower gru_bidir value_tail candidate_windows propose_kernel select_kernel transform epilogue_ln conv1d_cl > $OUT/${TAG}_own_kernels_trace_summary.txt
 : > $OUT/${TAG}_pmc.txt
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
@@ -19,7 +19,7 @@ import csv, sys, collections
 agg = collections.defaultdict(list)
 for r in csv.DictReader(open(sys.argv[1])):
     n = r["Kernel_Name"]
-    if any(p in n for p in ("backbone_kernel", "propose_kernel", "conv_tower_kernel", "gru_bidir", "value_tail")):
+    if any(p in n for p in ("backbone_kernel", "propose_kernel", "conv_tower", "gru_bidir", "value_tail")):
         agg[n[:90]].append(float(r["Counter_Value"]))
 for k, v in sorted(agg.items()):
     print("%s per dispatch (KB) %-92s n=%d mean=%.3f min=%.3f max=%.3f" % (sys.argv[2], k, len(v), sum(v) / len(v), min(v), max(v)))
