@@ -24,7 +24,10 @@ Engine knobs (attributes; defaults reproduce the reference's observable behaviou
   select_mode      "argmax" (reference, :1225) or "multinomial" (the commented-out :1223; philox only).
   fuse_nets        True: nets of known architecture (CNNModel backbone; ConvGRUTrunk+ConvHead value /
                    reward nets) are run through their MI355X formulations in svdd_amd/fused.py (same
-                   weights, fp32, channels-last, folded BN, HIP GRU kernel). False: call the modules as given.
+                   weights, exact fp32: one-launch backbone kernel, conv-tower / GRU / value-tail kernels; in
+                   SVDD-MC the conv tower is evaluated once per parent x_t and per candidate only around the
+                   positions it changed — bit-identical, `FusedValueNet.share_parent_tower`).
+                   False: call the modules as given.
 """
 import numpy as np
 import torch

@@ -258,3 +258,27 @@ def test_tower_windows_equal_full_tower(nets, B, M, L, nchg):
             assert w[c, 0] == max(0, int(p.min()) - 27) // 16 * 16 and w[c, 1] >= min(L, int(p.max()) + 28)
     with torch.no_grad():                                           # and the scores through the whole value net
         assert torch.equal(fv.forward_candidates(onehot, cand, x), fv(onehot))
+
+
+def test_full_size_c2_net_paths(nets):
+    """Config-2 sizes (B=256, M=10, L=200): the kernels the benchmark actually runs — one-launch backbone, parent-sharing
+    tower, GRU, value tail — against the plain PyTorch modules on one real propose step."""
+    from svdd_amd import fused, ops
+    model, emb, head, _ = nets
+    B, M, L = 256, 10, 200
+    g = torch.Generator(device="cpu").manual_seed(17)
+    x = torch.randint(0, 4, (B, L), generator=g).to(torch.uint8)
+    x[torch.rand(B, L, generator=g) < 0.6] = 4
+    x = x.to(DEV)
+    fb = fused.FusedBackbone(model.backbone).to(DEV).eval()
+    fv = fused.FusedValueNet(emb, head).to(DEV).eval()
+    with torch.no_grad():
+        logits = fb(x)                                              # one-launch kernel (B >= 192)
+        ref_logits = model.backbone(x, None, zero_sigma=True)
+        assert (logits - ref_logits).abs().max().item() <= 2e-5
+        cand, onehot, _ = ops.propose(logits, x, 0.999 / 128, 0.5, M, ops.Rng(seed=5, step=3))
+        scores = fv.forward_candidates(onehot, cand, x)             # parent tower + windows + GRU + tail
+        assert torch.equal(scores, fv(onehot))                      # sharing the parent's tower changes no bit
+        ref = head(emb(onehot))
+        assert scores.shape == ref.shape == (B * M, 1, 1)
+        assert (scores - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
