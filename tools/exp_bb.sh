@@ -16,6 +16,11 @@ for e in sys.argv[1:]:
     if e=="noB":
         assert "      if (nxt < it_end) {\n        const float* src = wsrc + (size_t)tile_of(nxt) * BB_C * CH;" in k
         k=k.replace("      if (nxt < it_end) {\n        const float* src = wsrc + (size_t)tile_of(nxt) * BB_C * CH;","      if (nxt < it_end && a.n == 12345) {\n        const float* src = wsrc + (size_t)tile_of(nxt) * BB_C * CH;",1)
+    if e=="nobranch":
+        assert "      if (live & (1 << (2 * (R)))) {" in k
+        k=k.replace("      if (live & (1 << (2 * (R)))) {","      if (true) {",1)
+    if e=="nofence":
+        k=k.replace("      __builtin_amdgcn_sched_barrier(0);                                                                     \\\n      B2_WAIT(NOUT)","      /*nofence*/")
     if e=="noLN":
         assert "    if (layer < nl) {\n      const float tb0 = vl[BB_C + col0]" in k
         k=k.replace("    if (layer < nl) {\n      const float tb0 = vl[BB_C + col0]","    if (layer < nl && a.n == 12345) {\n      const float tb0 = vl[BB_C + col0]",1)
@@ -24,7 +29,7 @@ open(p,'w').write(s)
 PY
 }
 run baseline
-for v in noA noB noLN; do edit $v; run $v; cp /tmp/nets_orig.hip svdd_amd/csrc/svdd_nets.hip; done
-edit noA noB noLN; run all3; cp /tmp/nets_orig.hip svdd_amd/csrc/svdd_nets.hip
+for v in nobranch; do edit $v; run $v; cp /tmp/nets_orig.hip svdd_amd/csrc/svdd_nets.hip; done
+edit noA noB noLN nobranch; run all4; cp /tmp/nets_orig.hip svdd_amd/csrc/svdd_nets.hip
 make -C svdd_amd/csrc 2>&1 | grep -E " error"
 true
