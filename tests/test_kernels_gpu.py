@@ -367,3 +367,32 @@ def test_sample_categorical_philox_vs_forced_exact(ops):
     assert torch.equal(outs[0], outs[1])
     un = x != 4
     assert np.array_equal(outs[0].cpu().numpy()[un[:, None, :].repeat(M, 1)], x[:, None, :].repeat(M, 1)[un[:, None, :].repeat(M, 1)])
+
+
+def test_propose_select_fuzz_vs_oracle(ops):
+    """Random ragged shapes (L not a multiple of the 64-position tile, M = 1 .. 37, tiny and odd B, anything from
+    all-MASK to fully decoded rows, both logits layouts, extreme move chances): propose + select through the C ABI
+    equal the oracle token for token."""
+    rng = np.random.default_rng(2024)
+    for case in range(24):
+        B = int(rng.integers(1, 20)); L = int(rng.integers(1, 260)); M = int(rng.integers(1, 38))
+        frac = float(rng.choice([0.0, 0.05, 0.5, 0.95, 1.0]))
+        logits, x = rand_case(rng, B, L, frac_unmasked=frac)
+        logits *= np.float32(rng.choice([0.1, 1.0, 8.0]))            # flat to very peaked proposals
+        dm = np.float32(rng.choice([1e-6, 0.0078, 0.3])); mcs = np.float32(rng.choice([1e-5, 0.2, 0.69]))
+        seed, step, off = int(rng.integers(0, 2 ** 62)), int(rng.integers(0, 128)), int(rng.integers(0, 5000))
+        layout = orc.BLV if case % 2 == 0 else orc.BVL
+        lg_ref = logits if layout == orc.BLV else np.ascontiguousarray(np.swapaxes(logits, 1, 2))
+        c_ref, oh_ref, _ = orc.propose(lg_ref, x, dm, mcs, M, seed=seed, row_offset=off, step=step, want_q=False,
+                                       layout=layout)
+        lg = dev(logits) if layout == orc.BLV else bvl_view(logits)
+        cand, onehot, _ = ops.propose(lg, dev(x), float(dm), float(mcs), M, ops.Rng(seed=seed, row_offset=off, step=step))
+        assert np.array_equal(cand.cpu().numpy(), c_ref), (case, B, L, M)
+        assert np.array_equal(onehot.cpu().numpy(), oh_ref), (case, B, L, M)
+        scores = rng.standard_normal((B, M)).astype(np.float32)
+        if case % 3 == 0:
+            scores[:, rng.integers(0, M)] = scores.max()             # ties: the first maximum wins
+        x_ref, soft_ref, idx_ref = orc.select(scores, c_ref)
+        x_next, soft, idx = ops.select(dev(scores), cand)
+        assert np.array_equal(idx.cpu().numpy(), idx_ref) and np.array_equal(x_next.cpu().numpy(), x_ref), (case, B, L, M)
+        assert np.abs(soft.cpu().numpy() - soft_ref).max() <= 1e-6
