@@ -45,8 +45,12 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        build()
-        _lib = ctypes.CDLL(_SO)
+        override = os.environ.get("SVDD_ORACLE_LIB")     # e.g. the ASan/UBSan build (oracle/Makefile: asan)
+        if override:
+            _lib = ctypes.CDLL(os.path.abspath(override))
+        else:
+            build()
+            _lib = ctypes.CDLL(_SO)
         _lib.orc_philox_select_uniform.restype = ctypes.c_float
     return _lib
 
