@@ -1094,9 +1094,15 @@ __global__ __launch_bounds__(512, 2) void backbone_kernel(BackboneArgs a) {
       const int d = (t - 4) * sdil[layer];
       const int lo = d < 0 ? -d : 0, hi = d > 0 ? L - d : L;
       if (lo >= hi) return 0;
-      if (!SPT1) return 0x1fff;
       int m = 0;
-      for (int r = 0; r < TW_RT; ++r) if (lo < 16 * r + 16 && hi > 16 * r) m |= 1 << r;
+      if (SPT1) {
+        for (int r = 0; r < TW_RT; ++r) if (lo < 16 * r + 16 && hi > 16 * r) m |= 1 << r;
+      } else {                                            // several sequences per tile: a row tile is live if any of its rows is
+        for (int row = 0; row < TW_ROWS; ++row) {
+          const int pp = rpos[row];
+          if (pp >= lo && pp < hi) m |= 1 << (row >> 4);
+        }
+      }
       return m;
     };
     const int m = entry(k);
