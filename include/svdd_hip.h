@@ -249,12 +249,37 @@ int svdd_backbone_cnn_f32(const uint8_t* x, const float* table0, const float* ti
                           const float* w2, float* out, int n, int L, int nlayers, const int* dilations,
                           void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Split-precision net kernels (svdd_amd/csrc/svdd_nets_lp.hip) — the same functions as the *_f32 net kernels above
+ * with the matrix products on the 16-bit matrix cores (fp32 accumulate). An explicit opt-in of the caller
+ * (Diffusion.precision); the exact-fp32 kernels remain the default and the parity reference.
+ *   SVDD_PREC_F16X3 / BF16X3: fp32 operands split hi + lo on the fly, a*b = ahi*bhi + ahi*blo + alo*bhi (3 MFMAs):
+ *     fp32-class error (measured 1.5e-7 / 5.3e-7 of sum|a b| at K = 1152 vs 1.8e-7 for the fp32 MFMA chain);
+ *   SVDD_PREC_F16 / BF16: one pass on the 16-bit roundings of the operands (~3e-5 / ~3e-4 of sum|a b|).
+ * Everything that is not a matrix product stays fp32. */
+enum { SVDD_PREC_F32 = 0, SVDD_PREC_F16X3 = 1, SVDD_PREC_BF16X3 = 2, SVDD_PREC_F16 = 3, SVDD_PREC_BF16 = 4 };
+
+/* svdd_backbone_cnn_lp — svdd_backbone_cnn_f32 on the 16-bit matrix cores. x, table0, vec, w2, out, dilations as
+ *   there. tiles: [nlayers*36 + 4] weight tiles in the order (layer, chunk, tap) then the 4 chunks of W_f1, each
+ *   [4 cg][64 lanes][2 ct][P][8] 16-bit values, P = 2 (hi, lo) for the x3 modes and 1 otherwise: lane (j = lane & 15,
+ *   g = lane >> 4) of column group cg holds s_w * W[32 cg + 2 j + ct][32 c + 8 g + e][t], e = 0..7.
+ *   lscale [nlayers + 1][2] = {sa, 1 / (sa * s_w)}: power-of-two scales of the activations / weights of each stage
+ *   (1 for bf16).  Packing: svdd_amd/fused.py:pack_backbone_lp. */
+int svdd_backbone_cnn_lp(const uint8_t* x, const float* table0, const void* tiles, const float* vec,
+                         const float* lscale, const float* w2, float* out, int n, int L, int nlayers,
+                         const int* dilations, int prec, void* stream);
+
 /* Process-wide options (host). SVDD_OPT_FORCE_EXACT != 0 makes svdd_propose evaluate every draw in the
  * exact (fp64, correctly rounded) arithmetic instead of the filtered fast path — same results, used
  * to A/B the filter. */
 enum { SVDD_OPT_FORCE_EXACT = 0,
        SVDD_OPT_MSPLIT = 1 /* tuning: waves per 64-position tile in svdd_propose, 0 = auto */ };
 int svdd_set_option(int key, int value);
+
+/* Soak / profiling aid: while `device_counters2` (two zero-initialised uint64 on the device) is non-NULL, every
+ * svdd_propose / svdd_sample_categorical launch adds {draws at masked positions, draws the exact-arithmetic filter
+ * could not decide on the fast path} to it. NULL switches the counting off. */
+int svdd_k1_stats(unsigned long long* device_counters2);
 
 /* Per-launch kernel timing (host). While enabled, svdd_propose (kernel 0), svdd_select (1), svdd_conv1d_cl_f32 (2),
  * svdd_gru_bidir_f32 (3), svdd_epilogue_ln_f32 (4), svdd_conv_tower_f32 (5), svdd_backbone_cnn_f32 (6) and svdd_value_tail_f32 (7) are dispatched

@@ -17,6 +17,7 @@ OK, E_ARG, E_LAUNCH, E_NODEVICE = 0, -1, -2, -3
 LAYOUT_BLV, LAYOUT_BVL = 0, 1
 RNG_REPLAY, RNG_PHILOX = 0, 1
 SELECT_ARGMAX, SELECT_MULTINOMIAL = 0, 1
+PRECISIONS = {"f32": 0, "f16x3": 1, "bf16x3": 2, "f16": 3, "bf16": 4}      # enum SVDD_PREC_* of include/svdd_hip.h
 MAX_M = 1024
 
 EXPORTS = (
@@ -25,7 +26,8 @@ EXPORTS = (
     "svdd_set_option", "svdd_selftest_fastmath", "svdd_profile_enable", "svdd_profile_collect",
     "svdd_gru_bidir_f32", "svdd_epilogue_ln_f32", "svdd_conv1d_cl_f32",
     "svdd_conv1d_set_dynamic", "svdd_gru_set_mode", "svdd_conv_tower_f32", "svdd_backbone_cnn_f32", "svdd_value_tail_f32",
-    "svdd_candidate_windows", "svdd_conv_tower_windows_f32",
+    "svdd_candidate_windows", "svdd_conv_tower_windows_f32", "svdd_k1_stats",
+    "svdd_backbone_cnn_lp",
 )
 OPT_FORCE_EXACT = 0
 
@@ -44,6 +46,7 @@ class SvddError(RuntimeError):
 def build(force=False):
     """Compile csrc/svdd_kernels.hip for gfx950 (hipcc cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, "svdd_kernels.hip"), os.path.join(CSRC, "svdd_nets.hip"),
+            os.path.join(CSRC, "svdd_nets_lp.hip"),
             os.path.join(os.path.dirname(_HERE), "include", "svdd_hip.h")]
     stale = not os.path.exists(SO_PATH) or os.path.getmtime(SO_PATH) < max(os.path.getmtime(f) for f in srcs)
     if force or stale:
@@ -91,6 +94,8 @@ def lib():
     L.svdd_backbone_cnn_f32.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, ctypes.POINTER(ctypes.c_int), vp]
     L.svdd_conv1d_cl_f32.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp]
     L.svdd_epilogue_ln_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_int64, i32, i32, vp]
+    L.svdd_k1_stats.argtypes = [vp]
+    L.svdd_backbone_cnn_lp.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, ctypes.POINTER(ctypes.c_int), i32, vp]
     L.svdd_profile_enable.argtypes = [i32]
     L.svdd_profile_collect.argtypes = [i32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]
     L.svdd_device_info.argtypes = [ctypes.c_char_p, i32, ctypes.POINTER(ctypes.c_int)]

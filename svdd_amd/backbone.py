@@ -75,12 +75,21 @@ class CNNModel(nn.Module):
         emb = F.relu(self.time_embedder(t))
         return [layer(emb)[:, :, None] for layer in self.time_layers]
 
+    def _tb_fingerprint(self):
+        """(address, in-place version) of every weight the time biases depend on: a cached set is stale as soon as one
+        of them was replaced or modified (load_state_dict, training between decodes)."""
+        return tuple((p.data_ptr(), p._version) for m in (self.time_embedder, self.time_layers) for p in m.parameters())
+
+    def clear_time_bias_cache(self):
+        self._tb_key = None
+        self._tb = None
+
     def zero_time_biases(self, batch, device):
         """Pre-computes (and pins in the cache) the time biases for sigma == 0, so that the hot loop
         never re-evaluates the time embedder (and never syncs to check t)."""
         with torch.no_grad():
             self._tb = self._time_biases(torch.zeros(batch, device=device))
-            self._tb_key = ("zero", batch, torch.device(device))
+            self._tb_key = ("zero", batch, torch.device(device), self._tb_fingerprint())
         return self._tb
 
     def trunk(self, onehot_cl, time_biases):
@@ -97,7 +106,7 @@ class CNNModel(nn.Module):
         """seq: tokens [B,L] (uint8/int64) ; t: [B] conditioning (all zeros from the sampler).
         zero_sigma=True promises t == 0 and uses the pinned bias cache without touching t."""
         onehot = self._eye[seq.long()]                     # F.one_hot(seq, 5).float()   (:177)
-        if zero_sigma and self._tb_key == ("zero", seq.shape[0], seq.device):
+        if zero_sigma and self._tb_key == ("zero", seq.shape[0], seq.device, self._tb_fingerprint()):
             tb = self._tb
         elif zero_sigma:
             tb = self.zero_time_biases(seq.shape[0], seq.device)

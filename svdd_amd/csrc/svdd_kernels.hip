@@ -118,6 +118,7 @@ struct ProposeArgs {
   const float* logits; const uint8_t* x; float dm, mcs; int B, L, M, layout;
   int rng_kind; uint32_t step; const float* uniforms; uint64_t seed, row_offset;
   uint8_t* cand; float* onehot; float* q_xs; int force_exact; int msplit; int ulayout;
+  unsigned long long* stats;     // optional device counters {masked draws, draws sent to the exact path} (svdd_k1_stats)
 };
 
 constexpr float LOG2E_HI = 1.44269502162933349609375f;        // fl32(log2 e)
@@ -162,6 +163,7 @@ __global__ __launch_bounds__(256) void propose_kernel(ProposeArgs a) {
   const uint32_t nunits = ntiles * (uint32_t)a.msplit;
   const uint32_t wave_global = blockIdx.x * 4u + (threadIdx.x >> 6);
   const uint32_t nwaves = gridDim.x * 4u;
+  uint32_t n_draws = 0, n_exact = 0;
 
   for (uint32_t unit = wave_global; unit < nunits; unit += nwaves) {
     const uint32_t tile = unit / (uint32_t)a.msplit;
@@ -237,7 +239,9 @@ __global__ __launch_bounds__(256) void propose_kernel(ProposeArgs a) {
           decided = (best > 1e-30f) && (second < best * margin);
           c = bi;
         }
+        ++n_draws;
         if (!decided) {                        // rare (~1e-6 of draws): exact arithmetic for this lane
+          ++n_exact;
           if (QGIVEN) {
             c = sample_categorical_1(z, u);
           } else {
@@ -254,6 +258,11 @@ __global__ __launch_bounds__(256) void propose_kernel(ProposeArgs a) {
       oh.z = (c == 2) ? 1.0f : 0.0f; oh.w = (c == 3) ? 1.0f : 0.0f;
       reinterpret_cast<float4*>(a.onehot)[o] = oh;                 // transform_samples, :1462-1470
     }
+  }
+  if (a.stats) {                               // soak / profiling only (wave-uniform branch)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { n_draws += __shfl_xor(n_draws, off, WAVE); n_exact += __shfl_xor(n_exact, off, WAVE); }
+    if (lane == 0) { atomicAdd(&a.stats[0], (unsigned long long)n_draws); atomicAdd(&a.stats[1], (unsigned long long)n_exact); }
   }
 }
 
@@ -589,6 +598,7 @@ TimedLaunch* timed_slot(int k) {
 
 int g_msplit = 0;        // svdd_set_option(SVDD_OPT_MSPLIT, k): override K1's candidate split (0 = auto)
 int g_force_exact = 0;   // svdd_set_option(SVDD_OPT_FORCE_EXACT, 1): K1 takes the exact path for every draw
+unsigned long long* g_k1_stats = nullptr;   // svdd_k1_stats: device counters K1 adds to
 
 inline int check_launch() { return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH; }
 inline bool bad_layout(int layout) { return layout != SVDD_LAYOUT_BLV && layout != SVDD_LAYOUT_BVL; }
@@ -604,6 +614,11 @@ int svdd_set_option(int key, int value) {
   if (key == SVDD_OPT_FORCE_EXACT) { g_force_exact = value ? 1 : 0; return SVDD_OK; }
   if (key == SVDD_OPT_MSPLIT && value >= 0 && value <= 64) { g_msplit = value; return SVDD_OK; }
   return SVDD_E_ARG;
+}
+
+int svdd_k1_stats(unsigned long long* device_counters2) {
+  g_k1_stats = device_counters2;              // NULL switches the counting off again
+  return SVDD_OK;
 }
 
 // used by svdd_nets.hip: start/stop events for a timed launch of net kernel k (nullptrs when profiling is off)
@@ -695,7 +710,7 @@ static int launch_propose(bool q_given, const float* logits, const uint8_t* x, f
   int msplit = g_msplit > 0 ? g_msplit : (ntiles >= 4096 ? 1 : ntiles >= 256 ? 2 : 4);   // measured: tools/k1_microbench.py
   if (msplit > M) msplit = M;
   ProposeArgs a{logits, x, dm, mcs, B, L, M, layout, rng->kind, rng->step, rng->uniforms, rng->seed,
-                rng->row_offset, cand, onehot, q_xs, g_force_exact, msplit, rng->uniforms_layout};
+                rng->row_offset, cand, onehot, q_xs, g_force_exact, msplit, rng->uniforms_layout, g_k1_stats};
   const int64_t nblocks = (ntiles * msplit + 3) / 4;
   const unsigned grid = (unsigned)(nblocks < 2048 ? nblocks : 2048);
   TimedLaunch* t = timed_slot(0);

@@ -29,6 +29,8 @@ Engine knobs (attributes; defaults reproduce the reference's observable behaviou
                    positions it changed — bit-identical, `FusedValueNet.share_parent_tower`).
                    False: call the modules as given.
 """
+import weakref
+
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -36,6 +38,18 @@ from torch import nn
 
 from . import noise_schedule, ops
 from .backbone import CNNModel
+
+
+def weight_fingerprint(*modules):
+    """Cheap identity of the weights of `modules`: (storage address, in-place version counter, shape) of every
+    parameter and buffer. Changes when a tensor is replaced (load_state_dict with assign, .to()), or modified in
+    place (optimizer step, load_state_dict copy_, manual edits) — the cases in which a cached re-packing of the
+    weights would silently go stale."""
+    fp = []
+    for m in modules:
+        for t in list(m.parameters()) + list(m.buffers()):
+            fp.append((t.data_ptr(), t._version, tuple(t.shape)))
+    return tuple(fp)
 
 
 class Diffusion(nn.Module):
@@ -98,16 +112,22 @@ class Diffusion(nn.Module):
         return x if x.dtype == torch.uint8 else x.to(torch.uint8)
 
     def clear_fused(self):
-        """Drop the cached fused formulations (call after changing any net's weights)."""
+        """Drop the cached fused formulations and the backbone's cached zero-sigma time biases. Not needed after a
+        weight change: every cache entry carries a fingerprint of the weights it was built from and is rebuilt when
+        that no longer matches (`weight_fingerprint`)."""
         self._fused = {}
+        if isinstance(self.backbone, CNNModel):
+            self.backbone.clear_time_bias_cache()
 
     def _fused_backbone(self):
-        fb = self._fused.get("backbone")
-        if fb is None:
+        fp = weight_fingerprint(self.backbone)
+        ent = self._fused.get("backbone")
+        if ent is None or ent[0] != fp:
             from .fused import FusedBackbone
-            fb = FusedBackbone(self.backbone).to(self.device).eval()
-            self._fused["backbone"] = fb
-        return fb
+            self.backbone.clear_time_bias_cache()
+            ent = (fp, FusedBackbone(self.backbone).to(self.device).eval())
+            self._fused["backbone"] = ent
+        return ent[1]
 
     def value_callable(self, embedding, head):
         """The callable the engine uses for `head(embedding(onehot))`: onehot fp32 [n,L,4] -> [n,1,1]."""
@@ -115,13 +135,19 @@ class Diffusion(nn.Module):
         if (self.fuse_nets and isinstance(embedding, ConvGRUTrunk) and isinstance(head, ConvHead)
                 and embedding.gru_tower.gru.hidden_size == 64 and embedding.gru_tower.gru.input_size == 64
                 and embedding.gru_tower.gru.num_layers == 1 and next(embedding.parameters()).is_cuda):
+            # The fused net holds re-packed COPIES of the weights, so an entry is valid only for these very module
+            # objects (weak references: id() alone can be recycled after garbage collection) with these very
+            # weights (fingerprint). The check costs ~50 us and is made once per decode, not per step.
             key = ("value", id(embedding), id(head))
-            fv = self._fused.get(key)
-            if fv is None:
+            fp = weight_fingerprint(embedding, head)
+            ent = self._fused.get(key)
+            if ent is None or ent[0]() is not embedding or ent[1]() is not head or ent[2] != fp:
                 from .fused import FusedValueNet
-                fv = FusedValueNet(embedding, head).to(self.device).eval()
-                self._fused[key] = fv
-            return fv
+                for k in [k for k, v in self._fused.items() if k != "backbone" and (v[0]() is None or v[1]() is None)]:
+                    del self._fused[k]                              # entries of collected modules
+                ent = (weakref.ref(embedding), weakref.ref(head), fp, FusedValueNet(embedding, head).to(self.device).eval())
+                self._fused[key] = ent
+            return ent[3]
         return lambda onehot: head(embedding(onehot))
 
     def reward_callable(self, reward_model):

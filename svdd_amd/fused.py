@@ -194,6 +194,71 @@ def backbone_cnn(tokens, pk):
     return out
 
 
+LP_DTYPES = {"f16x3": (torch.float16, 2), "bf16x3": (torch.bfloat16, 2), "f16": (torch.float16, 1), "bf16": (torch.bfloat16, 1)}
+
+
+def _pow2_floor(v):
+    import math
+    return 2.0 ** math.floor(math.log2(v))
+
+
+def _split16(w, dtype, parts):
+    """fp32 tensor -> [..., parts] 16-bit: hi = rn16(w) and (parts == 2) lo = rn16(w - hi)."""
+    hi = w.to(dtype)
+    if parts == 1:
+        return hi.unsqueeze(-1)
+    lo = (w - hi.float()).to(dtype)
+    return torch.stack([hi, lo], dim=-1)
+
+
+def pack_backbone_lp(cnn, precision):
+    """CNNModel -> the operand images of svdd_backbone_cnn_lp (include/svdd_hip.h) for one of the split-precision modes
+    "f16x3", "bf16x3", "f16", "bf16": dict(table0, tiles, vec, lscale, w2, dil, prec).
+    Weight tile (layer, chunk c, tap t): [4 cg][64 lanes = 16 g + j][2 ct][parts][8 e] =
+    s_w * W[32 cg + 2 j + ct][32 c + 8 g + e][t]. f16 operands are scaled by powers of two (exact): the weights of a
+    stage so that max |W| lands in [1024, 2048), the LayerNorm output by sa <= 16 chosen from its bound
+    sqrt(127) max|gamma| + max|beta| so that it cannot overflow; bf16 needs no scaling."""
+    dtype, parts = LP_DTYPES[precision]
+    pk = pack_backbone(cnn)
+    H, nl = 128, len(cnn.convs)
+    f16 = dtype == torch.float16
+    tiles, lscale = [], []
+    with torch.no_grad():
+        def tile_set(w, taps):                      # w [co][ci][taps] fp32 (already scaled) -> [c][t][cg][g][j][ct][parts][e]
+            v = _split16(w.reshape(4, 16, 2, 4, 4, 8, taps), dtype, parts)       # [cg][j][ct][c][g][e][t][parts]
+            return v.permute(3, 6, 0, 4, 1, 2, 7, 5).contiguous()
+        for i, conv in enumerate(cnn.convs):
+            w = conv.weight.detach().float()
+            sw = _pow2_floor(2047.0 / float(w.abs().max())) if f16 else 1.0
+            bound = 11.27 * float(cnn.norms[i].weight.abs().max()) + float(cnn.norms[i].bias.abs().max())
+            sa = min(16.0, _pow2_floor(16384.0 / max(bound, 1e-30))) if f16 else 1.0
+            tiles.append(tile_set(w * sw, 9).reshape(-1))
+            lscale.append((sa, 1.0 / (sa * sw)))
+        wf1 = cnn.final_conv[0].weight.detach().float()                           # [co][ci][1]
+        sw = _pow2_floor(2047.0 / float(wf1.abs().max())) if f16 else 1.0
+        tiles.append(tile_set(wf1 * sw, 1).reshape(-1))
+        lscale.append((1.0, 1.0 / sw))
+        pk["tiles"] = torch.cat(tiles).contiguous()
+        pk["lscale"] = torch.tensor(lscale, dtype=torch.float32, device=pk["vec"].device).contiguous()
+    pk["prec"] = _lib.PRECISIONS[precision]
+    return pk
+
+
+def backbone_cnn_lp(tokens, pk):
+    """tokens [n, L] uint8 -> raw logits fp32 [n, L, 5] on the 16-bit matrix cores (HIP kernel svdd_backbone_cnn_lp);
+    pk from pack_backbone_lp."""
+    assert tokens.is_cuda and tokens.dtype == torch.uint8 and tokens.is_contiguous()
+    n, L = tokens.shape
+    out = torch.empty((n, L, 5), dtype=torch.float32, device=tokens.device)
+    dil = (ctypes.c_int * len(pk["dil"]))(*pk["dil"])
+    rc = _lib.lib().svdd_backbone_cnn_lp(tokens.data_ptr(), pk["table0"].data_ptr(), pk["tiles"].data_ptr(),
+                                         pk["vec"].data_ptr(), pk["lscale"].data_ptr(), pk["w2"].data_ptr(),
+                                         out.data_ptr(), n, L, len(pk["dil"]), dil, pk["prec"],
+                                         ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    _lib.check(rc, "svdd_backbone_cnn_lp")
+    return out
+
+
 TOWER_WINDOW_MARGIN = 27     # +-17 rows receptive field of the 5-layer tower + 10 rows of window-edge error
 
 
