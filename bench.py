@@ -23,6 +23,11 @@ Prints ONE JSON line (rank 0). Extra objects:
                 dispatch on its launch stream (hipExtLaunchKernelGGL, svdd_profile_*).
   cpu_baseline  the CPU oracle port of the same workload, timed on this box's host cores on a bounded
                 sample (a few diffusion steps at full batch), extrapolated to a whole decode.
+  alt_precision the SAME workload with the nets' matrix products on the 16-bit matrix cores (Diffusion.precision,
+                csrc/svdd_nets_lp.hip), one object per mode, each with its own timed decodes and the roofline of its
+                dominant kernel against the dense bf16/f16 MFMA peak. Never the headline: `value` / `dtype` above are
+                the exact-fp32 path. Token agreement with the fp32 decode: profiles/r02_precision_agreement.json.
+  per_rank      (N > 1) every rank's decode time and the time of the one all-gather, so that a scaling run is diagnosable.
 """
 import argparse
 import json
@@ -39,6 +44,21 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec
 FP32_PEAK_TFLOPS = 157.3
+LP_PEAK_TFLOPS = 2500.0    # dense bf16 / f16 MFMA peak (MI355X_MICROARCH.md; the 5 PF headline figure is 2:1 sparse)
+
+
+def host_cpu():
+    """(model name, logical cores) of the box the CPU baseline ran on (stated next to every CPU number)."""
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    model = ln.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return model, os.cpu_count()
 
 
 def cpu_baseline(B, L, M, S, sample_steps, seed=44, threads=16):
@@ -77,8 +97,10 @@ def cpu_baseline(B, L, M, S, sample_steps, seed=44, threads=16):
     orc.finalize(logits, x)
     t_final = time.perf_counter() - t0
     per_decode = float(np.mean(t_steps)) * S + t_final
+    cpu_model, cpu_total = host_cpu()
     return {
         "value": round(B / per_decode, 4), "unit": "sequences/s", "cores": threads,
+        "cpu_model": cpu_model, "cores_total": cpu_total,
         "kind": "port",
         "sample": f"{sample_steps} of {S} diffusion steps at full batch (B={B}, L={L}, M={M}) + the noise-removal "
                   f"forward, extrapolated to one decode; {sum(t_steps) + t_final:.1f} s of CPU work",
@@ -96,6 +118,9 @@ def main():
     ap.add_argument("--diffusion-steps", type=int, default=128)
     ap.add_argument("--cpu-steps", type=int, default=8, help="diffusion steps timed for cpu_baseline (0 = skip)")
     ap.add_argument("--rng", default="philox", choices=["philox", "replay"])
+    ap.add_argument("--alt-precision", default="f16x3,bf16x3,bf16",
+                    help="comma list of split-precision modes measured AFTER the fp32 headline ('' = none)")
+    ap.add_argument("--alt-steps", type=int, default=2, help="timed decodes per alt-precision mode")
     ap.add_argument("--value-net", default="convgru", choices=["convgru", "enformer"],
                     help="enformer: the 230M-parameter Enformer-shaped value trunk of BASELINE config 4 (not the headline config)")
     args = ap.parse_args()
@@ -114,9 +139,19 @@ def main():
     model, emb, head, _ = synthetic.build("dna" if L == 200 else "rna", dev, value=args.value_net)
     model.rng_mode, model.philox_seed, model.row_offset = args.rng, 0, rank * B
 
+    rank_times = []                # (decode s, all-gather s) of every timed decode of this rank
+
     def one_decode():
+        t_a = time.perf_counter()
         x0 = model.controlled_sample(emb, head, num_steps=S, eval_sp_size=B, sample_M=M)
-        return distributed.gather_tokens(x0, B * world)
+        if world > 1:
+            torch.cuda.synchronize()
+        t_b = time.perf_counter()
+        out = distributed.gather_tokens(x0, B * world)
+        if world > 1:
+            torch.cuda.synchronize()
+            rank_times.append((t_b - t_a, time.perf_counter() - t_b))
+        return out
 
     def fence():
         if world > 1:
@@ -126,6 +161,7 @@ def main():
     for _ in range(args.warmup):
         one_decode()
     fence()
+    rank_times.clear()
     t0 = time.perf_counter()
     for k in range(args.steps):
         if k == args.steps - 1:
@@ -143,36 +179,82 @@ def main():
     bb_total_ms, bb_launches = _lib.profile_collect(6)
     tail_total_ms, tail_launches = _lib.profile_collect(7)
     assert out.shape == (B * world, L) and int(out.max()) <= 3
+    per_rank = None
     if world > 1:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+        mine = torch.tensor([sum(t[0] for t in rank_times) / len(rank_times), sum(t[1] for t in rank_times) / len(rank_times)],
+                            device=dev, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = {"decode_ms": [round(float(t[0]) * 1e3, 2) for t in allr],
+                    "allgather_ms": [round(float(t[1]) * 1e3, 3) for t in allr],
+                    "note": "mean over the timed decodes; the all-gather time of a rank includes its wait for the slowest rank"}
+
+    # ---- the same workload with the nets on the 16-bit matrix cores (never the headline)
+    H = 128
+    conv_flops_fwd = sum(2.0 * B * H * H * sum(max(0, L - abs(t - 4) * d) for t in range(9))
+                         for d in (1, 1, 4, 16, 64) for _ in range(4))
+    bb_flops = conv_flops_fwd + 2.0 * B * L * (5 * H * 9 + H * H + H * 5)
+    alt = {}
+    modes = [m for m in args.alt_precision.split(",") if m] if args.value_net == "convgru" else []
+    for mode in modes:
+        model.precision = mode
+        one_decode()
+        fence()
+        t1 = time.perf_counter()
+        for k in range(args.alt_steps):
+            if k == args.alt_steps - 1:
+                _lib.profile_enable(True)
+            one_decode()
+        fence()
+        el = time.perf_counter() - t1
+        _lib.profile_enable(False)
+        prof = {k: _lib.profile_collect(k) for k in (0, 1, 3, 5, 6, 7)}
+        if world > 1:
+            tm = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            el = float(tm.item())
+        bb_ms_lp = prof[6][0] / max(prof[6][1], 1)
+        passes = 3 if mode.endswith("x3") else 1
+        tf = bb_flops / (bb_ms_lp * 1e-3) / 1e12 if prof[6][1] else 0.0
+        alt[mode] = {
+            "value": round(B * world * args.alt_steps / el, 3), "unit": "sequences/s", "ms_per_step": round(el / args.alt_steps * 1e3, 3),
+            "steps": args.alt_steps, "dtype": mode,
+            "arithmetic": ("fp32 operands split hi+lo in %s, a*b = ahi*bhi + ahi*blo + alo*bhi on the 16-bit MFMA, fp32 accumulate"
+                           % mode[:-2]) if passes == 3 else "operands rounded to %s, one MFMA pass, fp32 accumulate" % mode,
+            "roofline": {"bound": "mfma", "kernel": "backbone_lp_kernel (svdd_backbone_cnn_lp, one launch per forward)",
+                         "achieved": round(tf, 2), "peak": LP_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / LP_PEAK_TFLOPS, 5),
+                         "flops_per_launch": round(bb_flops), "mfma_passes": passes,
+                         "issued_frac": round(tf * passes / LP_PEAK_TFLOPS, 5), "avg_launch_us": round(bb_ms_lp * 1e3, 3),
+                         "launches": prof[6][1], "traffic": None},
+            "own_kernels_ms_per_decode": {"backbone_cnn": round(prof[6][0], 2), "conv_tower": round(prof[5][0], 2),
+                                          "gru": round(prof[3][0], 2), "value_tail": round(prof[7][0], 2),
+                                          "propose": round(prof[0][0], 3), "select": round(prof[1][0], 3)},
+        }
+    model.precision = "f32"
 
     if rank == 0:
         k1_ms = k1_total_ms / max(k1_launches, 1)
         k1_bytes = B * L * (21 + 17 * M)
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_k1_pmc.json")
-        if os.path.exists(pmc) and (B, L, M) == (256, 200, 10):
-            traffic = json.load(open(pmc))["traffic_bytes_per_launch"]     # separate --pmc passes, see the file
         achieved = k1_bytes / (k1_ms * 1e-3) / 1e9
         seqs = B * world * args.steps
         flops_seq = (CNNModel.flops_per_position() * L * (S + 1) + ConvGRUTrunk.flops_per_position() * L * S * M)
         # useful FLOPs of the 20 dilated 128->128 x 9-tap convs of one backbone forward (dnaconv.py:151-156)
-        H = 128
-        conv_flops_fwd = sum(2.0 * B * H * H * sum(max(0, L - abs(t - 4) * d) for t in range(9))
-                             for d in (1, 1, 4, 16, 64) for _ in range(4))
         conv_ms = conv_total_ms / max(conv_launches, 1)
         conv_tf = (conv_flops_fwd / 20.0) / (conv_ms * 1e-3) / 1e12 if conv_launches else 0.0
         pmc = {}
-        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc.json")
-        if os.path.exists(pmc_path) and (B, L, M) == (256, 200, 10):
-            pmc = json.load(open(pmc_path))                    # separate --pmc passes, see the file
+        for name in ("r02_pmc.json", "r01_pmc.json"):          # separate --pmc passes of this workload, see the file
+            pmc_path = os.path.join(ROOT, "profiles", name)
+            if os.path.exists(pmc_path) and (B, L, M) == (256, 200, 10):
+                pmc = json.load(open(pmc_path))
+                break
         if bb_launches:
             # the job's dominant kernel: the whole backbone forward in one launch. Algorithmic FLOPs per launch = the
             # multiply-adds of one forward that touch real data (taps that fall into the zero padding excluded):
             # 20 dilated convs + the 9-tap first conv on the one-hot + the two 1x1 convs.
-            bb_flops = conv_flops_fwd + 2.0 * B * L * (5 * H * 9 + H * H + H * 5)
             bb_ms = bb_total_ms / bb_launches
             bb_tf = bb_flops / (bb_ms * 1e-3) / 1e12
             roofline = {"bound": "mfma", "kernel": "backbone_kernel (svdd_backbone_cnn_f32: first conv + 20 x [LayerNorm, "
@@ -208,7 +290,10 @@ def main():
                                           "epilogue_ln": round(epi_total_ms, 2),
                                           "propose": round(k1_total_ms, 3), "select": round(k2_total_ms, 3)},
             "e2e_fp32_frac": round(flops_seq * seqs / elapsed / 1e12 / (FP32_PEAK_TFLOPS * world), 5),
+            "alt_precision": alt or None,
         }
+        if per_rank:
+            line["per_rank"] = per_rank
         if args.value_net != "convgru":
             line["config"]["workload"] += " [value net: Enformer-shaped trunk, 230M params — BASELINE configs[3] shape]"
             line["e2e_fp32_frac"] = None

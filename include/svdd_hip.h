@@ -152,14 +152,15 @@ int svdd_subs_logp(const float* logits, const uint8_t* x, int B, int L, int layo
 
 /*
  * svdd_tds_resample — SMC/TDS baseline resampling step
- *   ratio = exp((num-den)/alpha); p = ratio/ratio.sum(); idx = np.random.choice(B,B,p=p);
+ *   ratio = exp(fl32(1.0/alpha) * (num-den)); p = ratio/ratio.sum(); idx = np.random.choice(B,B,p=p);
+ *   (alpha is the caller's Python float, i.e. a double: the reference rounds the double quotient 1.0/alpha to fp32 once)
  *   return sample[idx]                              diffusion_gosai.py:1280-1284
  *  reward_num, reward_den [B] fp32 ; sample [B,L] u8 ; u [B] fp64 uniforms in [0,1)
  *  (REPLAY of numpy's RandomState.random_sample, supplied by the host) ;
  *  out x_next [B,L] u8 ; idx [B] i32 (may be NULL) ; work [2*B] fp64 scratch (cdf + ratio).
  *  One shard's B particles are resampled by one workgroup (B <= ~64k).
  */
-int svdd_tds_resample(const float* reward_num, const float* reward_den, float alpha,
+int svdd_tds_resample(const float* reward_num, const float* reward_den, double alpha,
                       const uint8_t* sample, const double* u, int B, int L,
                       uint8_t* x_next, int32_t* idx, double* work, void* stream);
 
@@ -269,6 +270,36 @@ int svdd_backbone_cnn_lp(const uint8_t* x, const float* table0, const void* tile
                          const float* lscale, const float* w2, float* out, int n, int L, int nlayers,
                          const int* dilations, int prec, void* stream);
 
+/* svdd_conv_tower_lp / svdd_conv_tower_windows_lp — svdd_conv_tower_f32 / svdd_conv_tower_windows_f32 on the 16-bit
+ *   matrix cores. The input is the TOKEN tensor (u8, 4 = MASK -> zero one-hot row; reference transform_samples,
+ *   diffusion_gosai.py:1462-1470), not the fp32 one-hot: tok [n,L] (windows: the candidates [B,M,L] flattened).
+ *   tiles: [2 + 10*nlayers] weight tiles in execution order (stem chunks 0,1 with k = 4*tap + channel, then per layer,
+ *   per 32-channel chunk, per tap), each [4 cs][64 lanes][P][8] 16-bit: lane (j, g) of column tile cs holds
+ *   s_w * W[16 cs + j][8 g + e]; inv [1 + nlayers] = 1 / s_w of each stage; bias as in the fp32 kernel.
+ *   windows: live_idx [count] (may be NULL = identity) lists the candidates to process, `count` (device scalar, may be
+ *   NULL = n) how many — workgroup i handles candidate live_idx[i] and writes rows [i*L, (i+1)*L) of `out`, so a
+ *   compacted batch needs no host round trip (exact work-skipping). Packing: svdd_amd/fused.py:pack_tower_lp. */
+int svdd_conv_tower_lp(const uint8_t* tok, const void* tiles, const float* bias, const float* inv, float* out,
+                       int n, int L, int nlayers, int residual_mask, int prec, void* stream);
+int svdd_conv_tower_windows_lp(const uint8_t* cand, const void* tiles, const float* bias, const float* inv,
+                               const int32_t* win, const float* parent_out, float* out, int n, int L, int M,
+                               int nlayers, int residual_mask, const int32_t* live_idx, const int32_t* count,
+                               int prec, void* stream);
+
+/* svdd_gru_bidir_lp — svdd_gru_bidir_f32 on the 16-bit matrix cores. wpack [2 dirs][4 waves][64 lanes][6][2][P][8]
+ *   16-bit: lane (j, g) of wave w holds s_w * W_m[16 w + j][32 c + 8 g + e] for m = ir, hr, iz, hz, in, hn and chunk
+ *   c = 0, 1; bpack as in the fp32 kernel; inv [2] = 1 / s_w per direction. `count` (device scalar, may be NULL = n):
+ *   number of valid sequences. Packing: svdd_amd/fused.py:pack_gru_lp. */
+int svdd_gru_bidir_lp(const float* x, const void* wpack, const float* bpack, const float* inv, float* out,
+                      int n, int L, const int32_t* count, int prec, void* stream);
+
+/* svdd_value_tail_lp — svdd_value_tail_f32 with the 64 -> 128 map on the 16-bit matrix cores. w1pack [64 lanes][8 ct][2 c]
+ *   [P][8] 16-bit: s_w * W1'[16 ct + j][32 c + 8 g + e]; inv = 1 / s_w; the rest as in the fp32 kernel. `count` as above.
+ *   Packing: svdd_amd/fused.py:pack_tail_lp. */
+int svdd_value_tail_lp(const float* h_fwd, const float* h_bwd, const void* w1pack, const float* b1,
+                       const float* w_eff, const float* b_eff, float inv, float* out, int n, int L, int n_tasks,
+                       const int32_t* count, int prec, void* stream);
+
 /* Process-wide options (host). SVDD_OPT_FORCE_EXACT != 0 makes svdd_propose evaluate every draw in the
  * exact (fp64, correctly rounded) arithmetic instead of the filtered fast path — same results, used
  * to A/B the filter. */
@@ -300,7 +331,7 @@ int svdd_device_info(char* arch, int arch_len, int* num_cu);
 
 /* ABI version of this header: bumped on any signature change. */
 int svdd_abi_version(void);
-#define SVDD_ABI_VERSION 2
+#define SVDD_ABI_VERSION 3
 
 #ifdef __cplusplus
 }

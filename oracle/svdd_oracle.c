@@ -332,13 +332,13 @@ static float np_pairwise_sum_f32(const float* a, int64_t n) {
  *                                         idx = searchsorted(cdf, u, side='right')
  *   return sample[idx]
  * u: the B doubles RandomState.random_sample(B) yields. */
-void orc_tds_resample(const float* reward_num, const float* reward_den, float alpha,
+void orc_tds_resample(const float* reward_num, const float* reward_den, double alpha,
                       const uint8_t* sample, const double* u, int B, int L,
                       uint8_t* x_next, int32_t* idx, float* ratio_out, double* cdf_out) {
   if (B <= 0) return;
   float* ratio = (float*)calloc((size_t)B, sizeof(float));
   double* cdf = (double*)calloc((size_t)B, sizeof(double));
-  float inv_alpha = (float)(1.0 / (double)alpha);
+  float inv_alpha = (float)(1.0 / alpha);          /* Python double 1.0/alpha, one rounding to fp32 (scalar * float tensor) */
   for (int b = 0; b < B; ++b) ratio[b] = expf_cr(inv_alpha * (reward_num[b] - reward_den[b]));
   float tot = np_pairwise_sum_f32(ratio, B);
   double c = 0.0;

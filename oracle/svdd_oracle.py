@@ -199,7 +199,7 @@ def tds_resample(reward_num, reward_den, alpha, sample, u):
     idx = np.empty(B, dtype=np.int32)
     ratio = np.empty(B, dtype=np.float32)
     cdf = np.empty(B, dtype=np.float64)
-    lib().orc_tds_resample(_p(num, ctypes.c_float), _p(den, ctypes.c_float), ctypes.c_float(alpha),
+    lib().orc_tds_resample(_p(num, ctypes.c_float), _p(den, ctypes.c_float), ctypes.c_double(alpha),
                            _p(sample, ctypes.c_uint8), _p(u, ctypes.c_double), B, L, _p(x_next, ctypes.c_uint8),
                            _p(idx, ctypes.c_int32), _p(ratio, ctypes.c_float), _p(cdf, ctypes.c_double))
     return x_next, idx, ratio, cdf

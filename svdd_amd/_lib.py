@@ -10,8 +10,10 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-SO_PATH = os.path.join(CSRC, "libsvdd_hip.so")
-ABI_VERSION = 2
+# SVDD_HIP_LIB: load another build of the library instead (the timing-experiment scripts under tools/ build patched
+# copies of the kernels in a scratch directory; the tracked sources are never edited in place)
+SO_PATH = os.environ.get("SVDD_HIP_LIB") or os.path.join(CSRC, "libsvdd_hip.so")
+ABI_VERSION = 3
 
 OK, E_ARG, E_LAUNCH, E_NODEVICE = 0, -1, -2, -3
 LAYOUT_BLV, LAYOUT_BVL = 0, 1
@@ -27,7 +29,7 @@ EXPORTS = (
     "svdd_gru_bidir_f32", "svdd_epilogue_ln_f32", "svdd_conv1d_cl_f32",
     "svdd_conv1d_set_dynamic", "svdd_gru_set_mode", "svdd_conv_tower_f32", "svdd_backbone_cnn_f32", "svdd_value_tail_f32",
     "svdd_candidate_windows", "svdd_conv_tower_windows_f32", "svdd_k1_stats",
-    "svdd_backbone_cnn_lp",
+    "svdd_backbone_cnn_lp", "svdd_conv_tower_lp", "svdd_conv_tower_windows_lp", "svdd_gru_bidir_lp", "svdd_value_tail_lp",
 )
 OPT_FORCE_EXACT = 0
 
@@ -48,6 +50,8 @@ def build(force=False):
     srcs = [os.path.join(CSRC, "svdd_kernels.hip"), os.path.join(CSRC, "svdd_nets.hip"),
             os.path.join(CSRC, "svdd_nets_lp.hip"),
             os.path.join(os.path.dirname(_HERE), "include", "svdd_hip.h")]
+    if os.environ.get("SVDD_HIP_LIB"):
+        return SO_PATH                                   # an explicitly chosen build is used as it is
     stale = not os.path.exists(SO_PATH) or os.path.getmtime(SO_PATH) < max(os.path.getmtime(f) for f in srcs)
     if force or stale:
         subprocess.check_call(["make", "-C", CSRC, "-B"])
@@ -81,7 +85,7 @@ def lib():
     L.svdd_finalize.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp]
     L.svdd_transform_samples.argtypes = [vp, i32, i32, i32, vp, vp]
     L.svdd_subs_logp.argtypes = [vp, vp, i32, i32, i32, vp, vp]
-    L.svdd_tds_resample.argtypes = [vp, vp, f32, vp, vp, i32, i32, vp, vp, vp, vp]
+    L.svdd_tds_resample.argtypes = [vp, vp, ctypes.c_double, vp, vp, i32, i32, vp, vp, vp, vp]
     L.svdd_set_option.argtypes = [i32, i32]
     L.svdd_selftest_fastmath.argtypes = [ctypes.POINTER(ctypes.c_double)]
     L.svdd_gru_bidir_f32.argtypes = [vp, vp, vp, vp, i32, i32, vp]
@@ -95,6 +99,10 @@ def lib():
     L.svdd_conv1d_cl_f32.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp]
     L.svdd_epilogue_ln_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_int64, i32, i32, vp]
     L.svdd_k1_stats.argtypes = [vp]
+    L.svdd_conv_tower_lp.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
+    L.svdd_conv_tower_windows_lp.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp]
+    L.svdd_gru_bidir_lp.argtypes = [vp, vp, vp, vp, vp, i32, i32, vp, i32, vp]
+    L.svdd_value_tail_lp.argtypes = [vp, vp, vp, vp, vp, vp, f32, vp, i32, i32, i32, vp, i32, vp]
     L.svdd_backbone_cnn_lp.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, ctypes.POINTER(ctypes.c_int), i32, vp]
     L.svdd_profile_enable.argtypes = [i32]
     L.svdd_profile_collect.argtypes = [i32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]

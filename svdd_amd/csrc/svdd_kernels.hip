@@ -538,7 +538,7 @@ __device__ float np_pairwise_sum_f32(const float* a, int64_t n) {
 }
 
 struct TdsArgs {
-  const float* num; const float* den; float alpha; const uint8_t* sample; const double* u;
+  const float* num; const float* den; double alpha; const uint8_t* sample; const double* u;
   int B, L; uint8_t* x_next; int32_t* idx; double* work;
 };
 
@@ -547,7 +547,7 @@ struct TdsArgs {
 // searchsorted + one wave per particle row copy.
 __global__ __launch_bounds__(1024) void tds_resample_kernel(TdsArgs a) {
   float* ratio = reinterpret_cast<float*>(a.work + a.B);   // work: [B] f64 cdf + [B] f32 ratio
-  const float inv_alpha = (float)(1.0 / (double)a.alpha);
+  const float inv_alpha = (float)(1.0 / a.alpha);                 // the Python double 1.0/alpha, rounded to fp32 once
   for (int b = threadIdx.x; b < a.B; b += blockDim.x)
     ratio[b] = expf_cr(inv_alpha * (a.num[b] - a.den[b]));          // :1280
   __syncthreads();
@@ -763,9 +763,9 @@ int svdd_subs_logp(const float* logits, const uint8_t* x, int B, int L, int layo
   return launch_pos(subs_logp_kernel, PosArgs{logits, x, B, L, layout, logp, nullptr, nullptr, 0}, stream);
 }
 
-int svdd_tds_resample(const float* reward_num, const float* reward_den, float alpha, const uint8_t* sample,
+int svdd_tds_resample(const float* reward_num, const float* reward_den, double alpha, const uint8_t* sample,
                       const double* u, int B, int L, uint8_t* x_next, int32_t* idx, double* work, void* stream) {
-  if (!reward_num || !reward_den || !sample || !u || !x_next || !work || B <= 0 || L <= 0 || !(alpha != 0.0f))
+  if (!reward_num || !reward_den || !sample || !u || !x_next || !work || B <= 0 || L <= 0 || !(alpha != 0.0))
     return SVDD_E_ARG;
   TdsArgs a{reward_num, reward_den, alpha, sample, u, B, L, x_next, idx, work};
   hipLaunchKernelGGL(tds_resample_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);

@@ -28,6 +28,11 @@ Engine knobs (attributes; defaults reproduce the reference's observable behaviou
                    SVDD-MC the conv tower is evaluated once per parent x_t and per candidate only around the
                    positions it changed — bit-identical, `FusedValueNet.share_parent_tower`).
                    False: call the modules as given.
+  precision        "f32" (default): the fused nets compute in exact fp32 — the parity path and what bench.py's
+                   headline measures. "f16x3" / "bf16x3": matrix products on the 16-bit matrix cores with operands
+                   split hi + lo (3 MFMAs per product, fp32 accumulate): fp32-class error (logits / scores within
+                   ~3e-6 / ~3e-5 of the fp32 kernels) at ~2.5x the speed. "f16" / "bf16": one 16-bit pass.
+                   Tokens can differ from the fp32 decode at near-ties; tools/precision_agreement.py reports it.
 """
 import weakref
 
@@ -87,7 +92,9 @@ class Diffusion(nn.Module):
         self.philox_seed = 0
         self.row_offset = 0
         self.fuse_nets = True
+        self.precision = "f32"
         self.trace = None          # set to a list to record (logits, scores) of every step (tests / smoke)
+        self.state_trace = None    # set to a list to record x_t (uint8 clone) at the start of every step + the final x
         self._sched_cache = {}
         self._fused = {}
 
@@ -127,6 +134,7 @@ class Diffusion(nn.Module):
             self.backbone.clear_time_bias_cache()
             ent = (fp, FusedBackbone(self.backbone).to(self.device).eval())
             self._fused["backbone"] = ent
+        ent[1].precision = self.precision
         return ent[1]
 
     def value_callable(self, embedding, head):
@@ -147,6 +155,7 @@ class Diffusion(nn.Module):
                     del self._fused[k]                              # entries of collected modules
                 ent = (weakref.ref(embedding), weakref.ref(head), fp, FusedValueNet(embedding, head).to(self.device).eval())
                 self._fused[key] = ent
+            ent[3].precision = self.precision
             return ent[3]
         return lambda onehot: head(embedding(onehot))
 
@@ -177,6 +186,14 @@ class Diffusion(nn.Module):
         mct = 1 - torch.exp(-sigma_t.squeeze(-1))
         mcs = 1 - torch.exp(-sigma_s.squeeze(-1))
         return float(mct), float(mcs), float(mct - mcs)
+
+    def _step_index(self, t, dt):
+        """Index i of the diffusion step a per-step call belongs to: the reference loops call the per-step methods with
+        t_i = 1 - i * dt (diffusion_gosai.py:1036-1043). It keys the Philox counter, so that a caller who drives the
+        per-step API draws fresh uniforms at every step (with a constant key a position that stays MASK would see the
+        same Gumbel noise again and again)."""
+        t0 = float(t.reshape(-1)[0])
+        return max(0, int(round((1.0 - t0) / float(dt))))
 
     def _replay_layout(self, logits):
         """Memory order in which the REFERENCE consumes its uniforms: rand_like(q_xs) fills in the
@@ -228,13 +245,15 @@ class Diffusion(nn.Module):
             if self.sampler == "analytic":
                 raise NotImplementedError("analytic sampler is not on the reference's decode path")
             logits = self._backbone_logits(x_u8)
-            self._record(logits, None)
+            self._record(logits, None, x_u8)
             return ops.finalize(logits, x_u8)
         return x_u8.long()
 
-    def _record(self, logits, scores):
+    def _record(self, logits, scores, x=None):
         if self.trace is not None:
             self.trace.append((logits.detach().clone(), None if scores is None else scores.detach().clone()))
+        if self.state_trace is not None and x is not None:
+            self.state_trace.append(x.detach().clone())
 
     # ---------------------------------------------------------- reference API: basics ----
     def _process_sigma(self, sigma):
@@ -284,7 +303,7 @@ class Diffusion(nn.Module):
         x_u8 = self._tokens_u8(x)
         logits = self._backbone_logits(x_u8)
         B, L = x_u8.shape
-        cand, _, q = ops.propose(logits, x_u8, dm, mcs, 1, self._rng(0, 1, B, L, logits), want_q=True)
+        cand, _, q = ops.propose(logits, x_u8, dm, mcs, 1, self._rng(self._step_index(t, dt), 1, B, L, logits), want_q=True)
         return cand[:, 0].long(), x, q, (x != self.mask_index).to(x.dtype)
 
     @torch.no_grad()
@@ -295,9 +314,10 @@ class Diffusion(nn.Module):
         x_u8 = self._tokens_u8(x)
         logits = self._backbone_logits(x_u8)
         B, L = x_u8.shape
-        cand, onehot, q = ops.propose(logits, x_u8, dm, mcs, repeats, self._rng(0, repeats, B, L, logits), want_q=True)
+        step = self._step_index(t, dt)
+        cand, onehot, q = ops.propose(logits, x_u8, dm, mcs, repeats, self._rng(step, repeats, B, L, logits), want_q=True)
         scores = self._value_scores(pre_scorer_embedding, pre_scorer_head, onehot, B, repeats, cand, x_u8)
-        x_next = self._select(scores, cand, 0)
+        x_next = self._select(scores, cand, step)
         return x_next.long(), x, q, (x != self.mask_index).to(x.dtype)
 
     @torch.no_grad()
@@ -308,9 +328,10 @@ class Diffusion(nn.Module):
         x_u8 = self._tokens_u8(x)
         logits = self._backbone_logits(x_u8)
         B, L = x_u8.shape
-        cand, _, q = ops.propose(logits, x_u8, dm, mcs, repeats, self._rng(0, repeats, B, L, logits), want_q=True)
+        step = self._step_index(t, dt)
+        cand, _, q = ops.propose(logits, x_u8, dm, mcs, repeats, self._rng(step, repeats, B, L, logits), want_q=True)
         scores = self._tweedie_scores(cand, reward_model, options, task)
-        x_next = self._select(scores, cand, 0)
+        x_next = self._select(scores, cand, step)
         return x_next.long(), x, q, (x != self.mask_index).to(x.dtype)
 
     def _tweedie_scores(self, cand, reward_model, options, task):
@@ -333,7 +354,7 @@ class Diffusion(nn.Module):
         self._require_gpu()
         mct, mcs, dm = self._step_scalars(t, dt)
         x_u8 = self._tokens_u8(x)
-        return self._tds_step(x_u8, dm, mcs, reward_model, alpha, 0).long()
+        return self._tds_step(x_u8, dm, mcs, reward_model, alpha, self._step_index(t, dt)).long()
 
     def _tds_step(self, x_u8, dm, mcs, reward_model, alpha, step):
         B, L = x_u8.shape
@@ -384,7 +405,7 @@ class Diffusion(nn.Module):
         """One DPS (gradient-guidance) step (:1286-1319) -> x_next."""
         self._require_gpu()
         mct, mcs, dm = self._step_scalars(t, dt)
-        return self._dps_step(self._tokens_u8(x), mct, mcs, dm, reward_model, guidance_scale, 0).long()
+        return self._dps_step(self._tokens_u8(x), mct, mcs, dm, reward_model, guidance_scale, self._step_index(t, dt)).long()
 
     def controlled_sample_DPS(self, reward_model, guidance_scale, num_steps=None, eps=1e-5, eval_sp_size=None,
                               sample_M=10):
@@ -444,7 +465,7 @@ class Diffusion(nn.Module):
             logits = self._backbone_logits(x)
             ops.propose(logits, x, sched[i, 2], sched[i, 1], M, self._rng(i, M, B, L, logits), cand=cand, onehot=onehot)
             scores = self._value_scores(pre_scorer_embedding, pre_scorer_head, onehot, B, M, cand, x)
-            self._record(logits, scores)
+            self._record(logits, scores, x)
             x = self._select(scores, cand, i)
         return self._noise_removal(x)
 
@@ -461,7 +482,7 @@ class Diffusion(nn.Module):
             logits = self._backbone_logits(x)
             cand, _, _ = ops.propose(logits, x, sched[i, 2], sched[i, 1], M, self._rng(i, M, B, L, logits))
             scores = self._tweedie_scores(cand, reward_model, options, task)
-            self._record(logits, scores)
+            self._record(logits, scores, x)
             x = self._select(scores, cand, i)
         return self._noise_removal(x)
 

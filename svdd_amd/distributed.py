@@ -1,7 +1,8 @@
 """Batch-sharded decode over the GPUs of one node: one process per GPU, RCCL only for the single
 all-gather of the final decoded tokens. Rows of the batch are independent in
 SVDD-MC / SVDD-PM / un-guided decode, so nothing is exchanged per step; Philox draws are keyed by
-the GLOBAL row index, so the decoded batch is identical for any number of GPUs."""
+the GLOBAL row index, so the decoded batch is identical for any number of GPUs (rng_mode="philox" only: the replay
+mode's mt19937 stream is per process, and sharded_sample refuses it for world > 1)."""
 import os
 
 import torch
@@ -56,6 +57,11 @@ def sharded_sample(model, total_rows, sampler, rank=None, world=None):
     if rank is None:
         rank = dist.get_rank() if dist.is_initialized() else 0
         world = dist.get_world_size() if dist.is_initialized() else 1
+    if world > 1 and getattr(model, "rng_mode", "philox") != "philox":
+        # replay mode draws from each process's own CPU mt19937 stream: with the usual identical manual_seed every rank
+        # would decode the SAME rows and the gathered batch would be `world` copies of one shard
+        raise ValueError("sharded_sample needs rng_mode='philox' when world > 1 (Philox is keyed by the global row; the "
+                         "replay stream is per process)")
     lo, hi = shard_rows(total_rows, rank, world)
     prev = model.row_offset
     model.row_offset = lo

@@ -259,6 +259,110 @@ def backbone_cnn_lp(tokens, pk):
     return out
 
 
+def pack_tower_lp(stem_weight, layer_weights, precision):
+    """(tiles, inv) for svdd_conv_tower_lp: the tiles of pack_tower re-ordered per MFMA lane and split into 16-bit hi / lo,
+    [2 + 10*nlayers][4 cs][64 lanes = 16 g + j][P][8 e] = s_w * W[16 cs + j][8 g + e]; inv[stage] = 1 / s_w (f16: s_w a
+    power of two that puts max |W| of the stage into [1024, 2048); bf16: 1)."""
+    dtype, parts = LP_DTYPES[precision]
+    f16 = dtype == torch.float16
+    t32 = pack_tower(stem_weight, layer_weights)                         # [2 + 10 nl][64 co][32 k]
+    nl = len(layer_weights)
+    stage = torch.tensor([0, 0] + [1 + i for i in range(nl) for _ in range(10)], device=t32.device)
+    inv = []
+    for st in range(nl + 1):
+        m = float(t32[stage == st].abs().max())
+        inv.append(1.0 / _pow2_floor(2047.0 / m) if f16 else 1.0)
+    invt = torch.tensor(inv, dtype=torch.float32, device=t32.device)
+    scaled = t32 / invt[stage][:, None, None]
+    v = _split16(scaled.reshape(-1, 4, 16, 4, 8), dtype, parts)          # [it][cs][j][g][e][parts]
+    return v.permute(0, 1, 3, 2, 5, 4).contiguous().reshape(-1), invt.contiguous()
+
+
+def pack_gru_lp(gru, precision):
+    """nn.GRU(64, 64, bidirectional) -> (wpack, bpack, inv) for svdd_gru_bidir_lp: wpack [2][4 w][64 lanes][6][2 c][P][8] =
+    s_w * W_m[16 w + j][32 c + 8 g + e], m = ir, hr, iz, hz, in, hn; bpack as pack_gru; inv [2] = 1 / s_w per direction."""
+    dtype, parts = LP_DTYPES[precision]
+    f16 = dtype == torch.float16
+    H = gru.hidden_size
+    assert H == 64 and gru.input_size == 64 and gru.bidirectional and gru.num_layers == 1 and gru.bias
+    _, bpack = pack_gru(gru)
+    packs, inv = [], []
+    for sfx in ("", "_reverse"):
+        w_ih = getattr(gru, "weight_ih_l0" + sfx).detach().float()
+        w_hh = getattr(gru, "weight_hh_l0" + sfx).detach().float()
+        mats = torch.stack([w_ih[0:H], w_hh[0:H], w_ih[H:2 * H], w_hh[H:2 * H], w_ih[2 * H:], w_hh[2 * H:]])   # [6][u][k]
+        sw = _pow2_floor(2047.0 / float(mats.abs().max())) if f16 else 1.0
+        v = _split16((mats * sw).reshape(6, 4, 16, 2, 4, 8), dtype, parts)      # [m][w][j][c][g][e][parts]
+        packs.append(v.permute(1, 4, 2, 0, 3, 6, 5).contiguous())               # [w][g][j][m][c][parts][e]
+        inv.append(1.0 / sw)
+    return (torch.stack(packs).contiguous().reshape(-1), bpack,
+            torch.tensor(inv, dtype=torch.float32, device=bpack.device))
+
+
+def pack_tail_lp(w1, b1, gamma, beta, precision):
+    """-> (w1pack 16-bit, b1' fp32 [128], inv float) for svdd_value_tail_lp: the LayerNorm affine folded as in pack_tail,
+    w1pack [64 lanes = 16 g + j][8 ct][2 c][P][8] = s_w * W1'[16 ct + j][32 c + 8 g + e]."""
+    dtype, parts = LP_DTYPES[precision]
+    w64 = w1.detach().double()
+    wf = (w64 * gamma.detach().double()[None, :]).float()
+    bf = (b1.detach().double() + w64 @ beta.detach().double()).float().contiguous()
+    sw = _pow2_floor(2047.0 / float(wf.abs().max())) if dtype == torch.float16 else 1.0
+    v = _split16((wf * sw).reshape(8, 16, 2, 4, 8), dtype, parts)                # [ct][j][c][g][e][parts]
+    return v.permute(3, 1, 0, 2, 5, 4).contiguous().reshape(-1), bf, 1.0 / sw
+
+
+def conv_tower_lp(tok, tiles, bias, inv, residual_mask, prec):
+    """tokens [n, L] u8 -> tower output [n, L, 64] fp32 (HIP kernel svdd_conv_tower_lp)."""
+    assert tok.is_cuda and tok.dtype == torch.uint8 and tok.is_contiguous()
+    n, L = tok.shape
+    out = torch.empty((n, L, 64), dtype=torch.float32, device=tok.device)
+    rc = _lib.lib().svdd_conv_tower_lp(tok.data_ptr(), tiles.data_ptr(), bias.data_ptr(), inv.data_ptr(), out.data_ptr(),
+                                       n, L, bias.shape[0] - 1, int(residual_mask), prec,
+                                       ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    _lib.check(rc, "svdd_conv_tower_lp")
+    return out
+
+
+def conv_tower_windows_lp(cand, win, parent_out, tiles, bias, inv, residual_mask, prec, live_idx=None, count=None, out=None):
+    """Tower output of the candidates cand [B, M, L] u8 on their row windows `win`, the rest copied from parent_out
+    [B, L, 64] (HIP kernel svdd_conv_tower_windows_lp). live_idx / count (int32 device tensors): process only the listed
+    candidates, compacted into the first `count` rows of the output."""
+    B, M, L = cand.shape
+    n = B * M
+    if out is None:
+        out = torch.empty((n, L, 64), dtype=torch.float32, device=cand.device)
+    rc = _lib.lib().svdd_conv_tower_windows_lp(cand.data_ptr(), tiles.data_ptr(), bias.data_ptr(), inv.data_ptr(),
+                                               win.data_ptr(), parent_out.data_ptr(), out.data_ptr(), n, L, M,
+                                               bias.shape[0] - 1, int(residual_mask), _ptr(live_idx), _ptr(count), prec,
+                                               ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    _lib.check(rc, "svdd_conv_tower_windows_lp")
+    return out
+
+
+def gru_bidir_lp(x_nlc, wpack, bpack, inv, prec, count=None, out=None):
+    """x [n, L, 64] fp32 -> [2, n, L, 64] per-direction hidden states on the 16-bit matrix cores (svdd_gru_bidir_lp)."""
+    assert x_nlc.is_cuda and x_nlc.dtype == torch.float32 and x_nlc.is_contiguous() and x_nlc.shape[2] == 64
+    n, L, _ = x_nlc.shape
+    if out is None:
+        out = torch.empty((2, n, L, 64), dtype=torch.float32, device=x_nlc.device)
+    rc = _lib.lib().svdd_gru_bidir_lp(x_nlc.data_ptr(), wpack.data_ptr(), bpack.data_ptr(), inv.data_ptr(), out.data_ptr(),
+                                      n, L, _ptr(count), prec, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    _lib.check(rc, "svdd_gru_bidir_lp")
+    return out
+
+
+def value_tail_lp(h, w1pack, b1f, w_eff, b_eff, inv, prec, count=None):
+    """h [2, n, L, 64] -> scores [n, n_tasks] (svdd_value_tail_lp)."""
+    _, n, L, _ = h.shape
+    T = w_eff.shape[1]
+    out = torch.empty((n, T), dtype=torch.float32, device=h.device)
+    rc = _lib.lib().svdd_value_tail_lp(h[0].data_ptr(), h[1].data_ptr(), w1pack.data_ptr(), b1f.data_ptr(),
+                                       w_eff.data_ptr(), b_eff.data_ptr(), float(inv), out.data_ptr(), n, L, T,
+                                       _ptr(count), prec, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    _lib.check(rc, "svdd_value_tail_lp")
+    return out
+
+
 TOWER_WINDOW_MARGIN = 27     # +-17 rows receptive field of the 5-layer tower + 10 rows of window-edge error
 
 
@@ -371,11 +475,48 @@ class FusedValueNet(nn.Module):
             self.b1f = nn.Parameter(bf, requires_grad=False)
         self.use_fused_tail = True
         self.share_parent_tower = True
+        # "f32" (exact, default) or one of LP_DTYPES: the conv tower, GRU and tail on the 16-bit matrix cores
+        # (csrc/svdd_nets_lp.hip). Needs the reference-shaped net (tower_ok, tail_ok).
+        self.precision = "f32"
+        self._gru_mod = (gt.gru,)                                   # tuple: keeps the module out of this one's registry
+        self._stem_w_raw = stem.weight.detach()
+        self._folded_ws = [w.detach() for w in folded_ws]
+        self._lp = {}
+
+    def lp_ok(self, L):
+        return self.precision != "f32" and self.tower_ok and self.tail_ok and L <= 208
+
+    def _lp_pack(self):
+        """Operand images of the split-precision kernels for self.precision (packed on first use)."""
+        pk = self._lp.get(self.precision)
+        if pk is None:
+            dev = self.tw_bias.device
+            tiles, tinv = pack_tower_lp(self._stem_w_raw.to(dev), [w.to(dev) for w in self._folded_ws], self.precision)
+            gw, gb, ginv = pack_gru_lp(self._gru_mod[0], self.precision)
+            tw, tb1, tail_inv = pack_tail_lp(self.w1, self.b1, self.ln_w, self.ln_b, self.precision)
+            pk = dict(prec=_lib.PRECISIONS[self.precision], tiles=tiles.to(dev), tinv=tinv.to(dev), gw=gw.to(dev),
+                      gb=gb.to(dev), ginv=ginv.to(dev), tw=tw.to(dev), tb1=tb1.to(dev), tail_inv=tail_inv)
+            self._lp[self.precision] = pk
+        return pk
+
+    def forward_tokens(self, tok, count=None):
+        """Scores [n, n_tasks, 1] of the token rows tok [n, L] u8 (4 = MASK), split-precision path."""
+        pk = self._lp_pack()
+        seq = conv_tower_lp(tok.contiguous(), pk["tiles"], self.tw_bias, pk["tinv"], self.tw_resmask, pk["prec"])
+        return self._after_tower_lp(seq, pk, count)
+
+    def _after_tower_lp(self, seq, pk, count=None):
+        h = gru_bidir_lp(seq, pk["gw"], pk["gb"], pk["ginv"], pk["prec"], count=count)
+        return value_tail_lp(h, pk["tw"], pk["tb1"], self.w_eff, self.b_eff, pk["tail_inv"], pk["prec"], count=count)[:, :, None]
 
     def forward(self, x):
         if x.shape[1] == self.in_channels and x.shape[2] != self.in_channels:
             x = x.transpose(1, 2)                                   # reward-model layout [n,4,L] -> [n,L,4]
         n, L, C = x.shape
+        if self.lp_ok(L) and x.is_cuda:
+            # the 16-bit tower takes tokens: the engine's inputs are exact one-hot rows (MASK = zero row)
+            tok = torch.where(x.sum(dim=2) == 0, 4, x.argmax(dim=2)).to(torch.uint8)
+            return self.forward_tokens(tok)
         if self.use_fused_tower and self.tower_ok and L <= 208 and x.is_cuda:
             seq = conv_tower(x.contiguous(), self.tw_tiles, self.tw_bias, self.tw_resmask)
             return self._after_tower(seq, n, L)
@@ -407,6 +548,12 @@ class FusedValueNet(nn.Module):
         only on the row window around the positions it changed (svdd_conv_tower_windows_f32)."""
         from . import ops
         B, M, L = cand.shape
+        if self.lp_ok(L):
+            pk = self._lp_pack()
+            parent_out = conv_tower_lp(x, pk["tiles"], self.tw_bias, pk["tinv"], self.tw_resmask, pk["prec"])
+            win = candidate_windows(cand, x)
+            seq = conv_tower_windows_lp(cand, win, parent_out, pk["tiles"], self.tw_bias, pk["tinv"], self.tw_resmask, pk["prec"])
+            return self._after_tower_lp(seq, pk)
         parent_out = conv_tower(ops.transform_samples(x), self.tw_tiles, self.tw_bias, self.tw_resmask)
         win = candidate_windows(cand, x)
         seq = conv_tower_windows(onehot, win, parent_out, M, self.tw_tiles, self.tw_bias, self.tw_resmask)
@@ -457,6 +604,10 @@ class FusedBackbone(nn.Module):
         # the whole forward in ONE launch (svdd_backbone_cnn_f32): residual stream in registers, activations in LDS
         self.one_launch = self.H == 128 and cnn.alphabet_size == 5 and all(c.kernel_size[0] == 9 for c in cnn.convs)
         self.use_one_launch = True
+        self.min_tiles_one_launch = 0
+        self.precision = "f32"          # or one of LP_DTYPES: the one-launch kernel on the 16-bit matrix cores
+        self._cnn = (cnn,)
+        self._lp = {}
         if self.one_launch:
             pk = pack_backbone(cnn)
             self.ol_dil = pk.pop("dil")
@@ -465,9 +616,20 @@ class FusedBackbone(nn.Module):
 
     def forward(self, seq, sigma=None):
         B, L = seq.shape
-        # one workgroup per tile of whole sequences and ~2.3 ms per workgroup whatever the batch: worth it once the
-        # tiles fill most of the 256 CUs (below that the layer-wise path finishes sooner)
-        if self.one_launch and self.use_one_launch and L <= 208 and B // (208 // L) >= 192 and seq.is_cuda:
+        if self.precision != "f32" and self.one_launch and L <= 208 and seq.is_cuda:
+            pk = self._lp.get(self.precision)
+            if pk is None:
+                pk = self._lp[self.precision] = pack_backbone_lp(self._cnn[0], self.precision)
+            tok = seq if seq.dtype == torch.uint8 else seq.to(torch.uint8)
+            return backbone_cnn_lp(tok.contiguous(), pk)
+        # One workgroup per tile of whole sequences, ~2.2 ms per workgroup whatever the batch. Below ~192 tiles the
+        # layer-wise path (MIOpen + our conv kernels, 41 launches) finishes sooner (0.9 ms at B = 32), but it is a
+        # different fp32 summation order and MIOpen's algorithm choice is not reproducible run to run, so by default
+        # EVERY batch size takes the one-launch kernel: a row's logits are then the same bits whatever batch, tile or
+        # compacted sub-batch it is evaluated in (the exact work-skipping paths rely on that). Raise
+        # `min_tiles_one_launch` to 192 to trade that for small-batch latency.
+        if (self.one_launch and self.use_one_launch and L <= 208 and seq.is_cuda and
+                (B + 208 // L - 1) // (208 // L) >= self.min_tiles_one_launch):
             tok = seq if seq.dtype == torch.uint8 else seq.to(torch.uint8)
             return backbone_cnn(tok.contiguous(), dict(table0=self.ol_table0, tiles=self.ol_tiles, vec=self.ol_vec,
                                                        w2=self.ol_w2, dil=self.ol_dil))

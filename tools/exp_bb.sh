@@ -1,15 +1,21 @@
 #!/bin/bash
-# timing-only experiments on the backbone kernel (results are wrong by construction); restores the source afterwards
-cd /root/repo
-cp svdd_amd/csrc/svdd_nets.hip /tmp/nets_orig.hip
-run() { make -C svdd_amd/csrc 2>&1 | grep -E " error" ; echo "$1: $(timeout 120 python tools/backbone_microbench.py 256 200 | grep one-launch)"; }
-edit() { python3 - "$@" <<'PY'
+# timing-only experiments on the backbone kernel (results are wrong by construction)
+# The tracked sources are never touched: the kernels are copied to a scratch directory, patched and built THERE, and the
+# microbenchmark loads that build through SVDD_HIP_LIB (svdd_amd/_lib.py). The scratch directory is removed on any exit.
+cd "$(dirname "$0")/.." || exit 1
+ROOT=$PWD
+WORK=$(mktemp -d /tmp/svdd_exp.XXXXXX)
+trap 'rm -rf "$WORK"' EXIT
+fresh() { cp svdd_amd/csrc/*.hip svdd_amd/csrc/Makefile "$WORK"/; }
+build() { make -C "$WORK" -j3 INC="$ROOT/include" 2>&1 | grep -E " error"; }
+run() { build; echo "$1: $(SVDD_HIP_LIB=$WORK/libsvdd_hip.so timeout 120 python tools/backbone_microbench.py 256 200 | grep one-launch)"; }
+edit() { python3 - "$WORK" "$@" <<'PY'
 import sys
-p='svdd_amd/csrc/svdd_nets.hip'
+p=sys.argv[1]+'/svdd_nets.hip'
 s=open(p).read()
 a=s.index("template <bool SPT1>\n__global__ __launch_bounds__(512, 2) void backbone_kernel")
 k=s[a:]
-for e in sys.argv[1:]:
+for e in sys.argv[2:]:
     if e=="noA":
         assert "        V[0] = ap_[0]; V[1] = ap_[1]; }" in k
         k=k.replace("        V[0] = ap_[0]; V[1] = ap_[1]; }","        V[0] = float4{bf0[0],bf0[1],bf0[2],bf0[3]}; V[1] = V[0]; (void)ap_; }",1)
@@ -28,8 +34,8 @@ s=s[:a]+k
 open(p,'w').write(s)
 PY
 }
+fresh
 run baseline
-for v in nobranch; do edit $v; run $v; cp /tmp/nets_orig.hip svdd_amd/csrc/svdd_nets.hip; done
-edit noA noB noLN nobranch; run all4; cp /tmp/nets_orig.hip svdd_amd/csrc/svdd_nets.hip
-make -C svdd_amd/csrc 2>&1 | grep -E " error"
+for v in nobranch; do edit $v; run $v; fresh; done
+edit noA noB noLN nobranch; run all4; fresh
 true

@@ -1,15 +1,21 @@
 #!/bin/bash
-# timing-only experiments on gru_bidir_kernel (results wrong by construction); restores the source afterwards
-cd /root/repo
-cp svdd_amd/csrc/svdd_nets.hip /tmp/nets_orig.hip
-run() { make -C svdd_amd/csrc 2>&1 | grep -E " error" ; echo "$1: $(timeout 120 python tools/gru_microbench.py 16 2048 2560 2>&1 | grep 'mode=0' | tr '\n' ' ')"; }
-edit() { python3 - "$@" <<'PY'
+# timing-only experiments on gru_bidir_kernel (results wrong by construction)
+# The tracked sources are never touched: the kernels are copied to a scratch directory, patched and built THERE, and the
+# microbenchmark loads that build through SVDD_HIP_LIB (svdd_amd/_lib.py). The scratch directory is removed on any exit.
+cd "$(dirname "$0")/.." || exit 1
+ROOT=$PWD
+WORK=$(mktemp -d /tmp/svdd_exp.XXXXXX)
+trap 'rm -rf "$WORK"' EXIT
+fresh() { cp svdd_amd/csrc/*.hip svdd_amd/csrc/Makefile "$WORK"/; }
+build() { make -C "$WORK" -j3 INC="$ROOT/include" 2>&1 | grep -E " error"; }
+run() { build; echo "$1: $(SVDD_HIP_LIB=$WORK/libsvdd_hip.so timeout 120 python tools/gru_microbench.py 16 2048 2560 2>&1 | grep 'mode=0' | tr '\n' ' ')"; }
+edit() { python3 - "$WORK" "$@" <<'PY'
 import sys
-p='svdd_amd/csrc/svdd_nets.hip'
+p=sys.argv[1]+'/svdd_nets.hip'
 s=open(p).read()
 a=s.index("template <bool BOTH>"); b=s.index("// ------------------------------------------------------------------ fused conv epilogue + LayerNorm ----")
 k=s[a:b]
-for e in sys.argv[1:]:
+for e in sys.argv[2:]:
     if e=="nomfma":
         k=k.replace("__builtin_amdgcn_mfma_f32_16x16x4f32(ha[s], wr[80 + s], acc_nh, 0, 0, 0)","acc_nh + ha[s] * wr[80+s]")
         k=k.replace("__builtin_amdgcn_mfma_f32_16x16x4f32(ha[s], wr[16 + s], acc_r, 0, 0, 0)","acc_r + ha[s] * wr[16+s]")
@@ -27,10 +33,10 @@ s=s[:a]+k+s[b:]
 open(p,'w').write(s)
 PY
 }
+fresh
 run baseline
-edit nostore; run nostore; cp /tmp/nets_orig.hip svdd_amd/csrc/svdd_nets.hip
-edit nogates; run nogates; cp /tmp/nets_orig.hip svdd_amd/csrc/svdd_nets.hip
-edit noxload; run noxload; cp /tmp/nets_orig.hip svdd_amd/csrc/svdd_nets.hip
-edit nostore nogates noxload; run nostore_nogates_noxload; cp /tmp/nets_orig.hip svdd_amd/csrc/svdd_nets.hip
-make -C svdd_amd/csrc 2>&1 | grep -E " error"
+edit nostore; run nostore; fresh
+edit nogates; run nogates; fresh
+edit noxload; run noxload; fresh
+edit nostore nogates noxload; run nostore_nogates_noxload; fresh
 true

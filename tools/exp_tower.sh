@@ -1,15 +1,21 @@
 #!/bin/bash
-# timing-only experiments on conv_tower_kernel (results wrong by construction); restores the source afterwards
-cd /root/repo
-cp svdd_amd/csrc/svdd_nets.hip /tmp/nets_orig.hip
-run() { make -C svdd_amd/csrc 2>&1 | grep -E " error" ; echo "$1: $(timeout 120 python tools/tower_microbench.py 2>&1 | grep 'n=2560 L=200' | cut -c1-60)"; }
-edit() { python3 - "$@" <<'PY'
+# timing-only experiments on conv_tower_kernel (results wrong by construction)
+# The tracked sources are never touched: the kernels are copied to a scratch directory, patched and built THERE, and the
+# microbenchmark loads that build through SVDD_HIP_LIB (svdd_amd/_lib.py). The scratch directory is removed on any exit.
+cd "$(dirname "$0")/.." || exit 1
+ROOT=$PWD
+WORK=$(mktemp -d /tmp/svdd_exp.XXXXXX)
+trap 'rm -rf "$WORK"' EXIT
+fresh() { cp svdd_amd/csrc/*.hip svdd_amd/csrc/Makefile "$WORK"/; }
+build() { make -C "$WORK" -j3 INC="$ROOT/include" 2>&1 | grep -E " error"; }
+run() { build; echo "$1: $(SVDD_HIP_LIB=$WORK/libsvdd_hip.so timeout 120 python tools/tower_microbench.py 2>&1 | grep 'n=2560 L=200' | cut -c1-60)"; }
+edit() { python3 - "$WORK" "$@" <<'PY'
 import sys
-p='svdd_amd/csrc/svdd_nets.hip'
+p=sys.argv[1]+'/svdd_nets.hip'
 s=open(p).read()
 a=s.index("template <bool SPT1>\n__global__ __launch_bounds__(512, 4) void conv_tower_kernel"); b=s.index("// --------------------------------------------------------- fused dilated-CNN backbone")
 k=s[a:b]
-for e in sys.argv[1:]:
+for e in sys.argv[2:]:
     if e=="noA":
         assert "          V[0] = ap_[0]; V[1] = ap_[1];  " in k or "V[0] = ap_[0]; V[1] = ap_[1];" in k
         k=k.replace("V[0] = ap_[0]; V[1] = ap_[1];","V[0] = float4{bf[0],bf[1],bf[2],bf[3]}; V[1] = V[0]; (void)ap_;")
@@ -27,8 +33,8 @@ s=s[:a]+k+s[b:]
 open(p,'w').write(s)
 PY
 }
+fresh
 run baseline
-for v in noA noB noepi noout; do edit $v; run $v; cp /tmp/nets_orig.hip svdd_amd/csrc/svdd_nets.hip; done
-edit noA noB noepi noout; run all4; cp /tmp/nets_orig.hip svdd_amd/csrc/svdd_nets.hip
-make -C svdd_amd/csrc 2>&1 | grep -E " error"
+for v in noA noB noepi noout; do edit $v; run $v; fresh; done
+edit noA noB noepi noout; run all4; fresh
 true

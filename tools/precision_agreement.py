@@ -1,0 +1,94 @@
+"""Token agreement of the split-precision net paths with the exact-fp32 path over a full SVDD-MC decode (BASELINE.json
+configs[1]: B=256, L=200, M=10, 128 steps, random-init nets, Philox — the same uniforms in every mode).
+
+Per mode ("f16x3", "bf16x3", "f16", "bf16") two measurements:
+  free-running   the decode runs on its own states: first diffusion step at which any token differs from the fp32
+                 decode, per-step fraction of identical rows, agreement of the final x_0 (rows / tokens);
+  teacher-forced the mode's nets are evaluated on the fp32 decode's own states x_t (every 8th step): max |logit| and
+                 |score| difference to the fp32 kernels, and how many of the B argmax-over-M selections agree.
+  vs fp64        on the same teacher-forced states, the scores of the PyTorch modules evaluated in fp64 are the yardstick:
+                 how often the fp32 kernels' and each mode's argmax-over-M selection equals the fp64 one, and the max
+                 score error against fp64. (Agreement WITH the fp32 kernels measures closeness to one particular
+                 rounding; agreement with fp64 measures closeness to the function itself.)
+Random-init nets give near-tied scores (the worst case for exactness), so a trajectory that
+diverges at one row keeps diverging there; rows are independent, so the row-level numbers are the informative ones.
+Usage: python tools/precision_agreement.py [B] > profiles/rNN_precision_agreement.json"""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from svdd_amd import ops, synthetic
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+L, M, S = 200, 10, 128
+dev = "cuda:0"
+model, emb, head, _ = synthetic.build("dna", dev)
+model.rng_mode, model.philox_seed = "philox", 0
+sched = model._schedule(S, 1e-5)[0]
+
+
+def decode(precision):
+    model.precision = precision
+    model.state_trace, model.trace = [], []
+    x0 = model.controlled_sample(emb, head, num_steps=S, eval_sp_size=B, sample_M=M)
+    torch.cuda.synchronize()
+    st, tr = model.state_trace, model.trace
+    model.state_trace, model.trace = None, None
+    return x0, st, tr
+
+
+with torch.no_grad():
+    x0_ref, st_ref, tr_ref = decode("f32")
+    x0_again, _, _ = decode("f32")
+    report = {"config": f"SVDD-MC B={B} L={L} M={M} S={S}, random-init nets (seed 44), Philox seed 0",
+              "fp32_decode_reproducible": bool(torch.equal(x0_ref, x0_again)), "modes": {}}
+    # fp64 yardstick on the fp32 trajectory's states (every 16th step)
+    import copy
+    emb64, head64 = copy.deepcopy(emb).double(), copy.deepcopy(head).double()
+    model.precision = "f32"
+    tf = {}
+    for i in range(0, S, 16):
+        x = st_ref[i]
+        lg_ref, sc_ref = tr_ref[i]
+        cand, onehot, _ = ops.propose(lg_ref, x, sched[i, 2], sched[i, 1], M, model._rng(i, M, B, L, lg_ref))
+        with torch.backends.cudnn.flags(enabled=False):
+            sc64 = head64(emb64(onehot.double())).reshape(B, M)
+        tf[i] = (cand.clone(), onehot.clone(), sc64)
+    report["fp32_vs_fp64"] = {
+        "max_abs_score_err": max(float((tr_ref[i][1].double() - tf[i][2]).abs().max()) for i in tf),
+        "selection_agreement_mean": sum(float((tr_ref[i][1].argmax(1) == tf[i][2].argmax(1)).float().mean()) for i in tf) / len(tf)}
+    for mode in ("f16x3", "bf16x3", "f16", "bf16"):
+        x0, st, tr = decode(mode)
+        rows_same = [float((a == b).all(dim=1).float().mean()) for a, b in zip(st, st_ref)]
+        first_div = next((i for i, r in enumerate(rows_same) if r < 1.0), None)
+        # teacher-forced comparison on the fp32 trajectory
+        model.precision = mode
+        dl, ds, sel = 0.0, 0.0, []
+        for i in range(0, S, 8):
+            x = st_ref[i]
+            lg_ref, sc_ref = tr_ref[i]
+            lg = model._backbone_logits(x)
+            cand, onehot, _ = ops.propose(lg_ref, x, sched[i, 2], sched[i, 1], M, model._rng(i, M, B, L, lg_ref))
+            sc = model._value_scores(emb, head, onehot, B, M, cand, x)
+            dl = max(dl, float((lg - lg_ref).abs().max()))
+            ds = max(ds, float((sc - sc_ref).abs().max()))
+            sel.append(float((sc.argmax(1) == sc_ref.argmax(1)).float().mean()))
+        report["modes"][mode] = {
+            "first_divergence_step": first_div,
+            "rows_identical_at_step": {str(i): round(rows_same[i], 4) for i in (0, 16, 32, 64, 96, 127, 128) if i < len(rows_same)},
+            "final_x0_rows_identical": float((x0 == x0_ref).all(dim=1).float().mean()),
+            "final_x0_tokens_identical": float((x0 == x0_ref).float().mean()),
+            "teacher_forced_max_abs_logit_diff": dl, "teacher_forced_max_abs_score_diff": ds,
+            "teacher_forced_selection_agreement_mean": sum(sel) / len(sel), "teacher_forced_selection_agreement_min": min(sel),
+        }
+        e64, a64 = 0.0, []
+        for i, (cand, onehot, sc64) in tf.items():
+            sc = model._value_scores(emb, head, onehot, B, M, cand, st_ref[i])
+            e64 = max(e64, float((sc.double() - sc64).abs().max()))
+            a64.append(float((sc.argmax(1) == sc64.argmax(1)).float().mean()))
+        report["modes"][mode]["vs_fp64_max_abs_score_err"] = e64
+        report["modes"][mode]["vs_fp64_selection_agreement_mean"] = sum(a64) / len(a64)
+    model.precision = "f32"
+print(json.dumps(report, indent=1))
