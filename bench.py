@@ -24,7 +24,7 @@ Prints ONE JSON line (rank 0). Extra objects:
   cpu_baseline  the CPU oracle port of the same workload, timed on this box's host cores on a bounded
                 sample (a few diffusion steps at full batch), extrapolated to a whole decode.
   alt_precision the SAME workload with the nets' matrix products on the 16-bit matrix cores (Diffusion.precision,
-                csrc/svdd_nets_lp.hip), one object per mode, each with its own timed decodes and the roofline of its
+                csrc/svdd_lp_*.hip), one object per mode, each with its own timed decodes and the roofline of its
                 dominant kernel against the dense bf16/f16 MFMA peak. Never the headline: `value` / `dtype` above are
                 the exact-fp32 path. Token agreement with the fp32 decode: profiles/r02_precision_agreement.json.
   per_rank      (N > 1) every rank's decode time and the time of the one all-gather, so that a scaling run is diagnosable.

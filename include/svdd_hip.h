@@ -251,7 +251,7 @@ int svdd_backbone_cnn_f32(const uint8_t* x, const float* table0, const float* ti
                           void* stream);
 
 /* ------------------------------------------------------------------------------------------------
- * Split-precision net kernels (svdd_amd/csrc/svdd_nets_lp.hip) — the same functions as the *_f32 net kernels above
+ * Split-precision net kernels (svdd_amd/csrc/svdd_lp_*.hip) — the same functions as the *_f32 net kernels above
  * with the matrix products on the 16-bit matrix cores (fp32 accumulate). An explicit opt-in of the caller
  * (Diffusion.precision); the exact-fp32 kernels remain the default and the parity reference.
  *   SVDD_PREC_F16X3 / BF16X3: fp32 operands split hi + lo on the fly, a*b = ahi*bhi + ahi*blo + alo*bhi (3 MFMAs):
@@ -274,24 +274,28 @@ int svdd_backbone_cnn_lp(const uint8_t* x, const float* table0, const void* tile
  *   matrix cores. The input is the TOKEN tensor (u8, 4 = MASK -> zero one-hot row; reference transform_samples,
  *   diffusion_gosai.py:1462-1470), not the fp32 one-hot: tok [n,L] (windows: the candidates [B,M,L] flattened).
  *   tiles: [2 + 10*nlayers] weight tiles in execution order (stem chunks 0,1 with k = 4*tap + channel, then per layer,
- *   per 32-channel chunk, per tap), each [4 cs][64 lanes][P][8] 16-bit: lane (j, g) of column tile cs holds
- *   s_w * W[16 cs + j][8 g + e]; inv [1 + nlayers] = 1 / s_w of each stage; bias as in the fp32 kernel.
+ *   per 32-channel chunk, per tap), each [2 cp][64 lanes][2 ct][P][8] 16-bit: lane (j, g) of column pair cp holds
+ *   s_w * W[32 cp + 2 j + ct][8 g + e]; inv [1 + nlayers] = 1 / s_w of each stage; bias as in the fp32 kernel.
+ *   out (and parent_out): [n, L, P, 64] 16-bit planes — per row the hi halves of the 64 channels, then (x3 modes) the
+ *   lo halves: the form svdd_gru_bidir_lp consumes directly (value = hi + lo).
  *   windows: live_idx [count] (may be NULL = identity) lists the candidates to process, `count` (device scalar, may be
  *   NULL = n) how many — workgroup i handles candidate live_idx[i] and writes rows [i*L, (i+1)*L) of `out`, so a
  *   compacted batch needs no host round trip (exact work-skipping). Packing: svdd_amd/fused.py:pack_tower_lp. */
-int svdd_conv_tower_lp(const uint8_t* tok, const void* tiles, const float* bias, const float* inv, float* out,
+int svdd_conv_tower_lp(const uint8_t* tok, const void* tiles, const float* bias, const float* inv, void* out,
                        int n, int L, int nlayers, int residual_mask, int prec, void* stream);
 int svdd_conv_tower_windows_lp(const uint8_t* cand, const void* tiles, const float* bias, const float* inv,
-                               const int32_t* win, const float* parent_out, float* out, int n, int L, int M,
+                               const int32_t* win, const void* parent_out, void* out, int n, int L, int M,
                                int nlayers, int residual_mask, const int32_t* live_idx, const int32_t* count,
                                int prec, void* stream);
 
 /* svdd_gru_bidir_lp — svdd_gru_bidir_f32 on the 16-bit matrix cores. wpack [2 dirs][4 waves][64 lanes][6][2][P][8]
  *   16-bit: lane (j, g) of wave w holds s_w * W_m[16 w + j][32 c + 8 g + e] for m = ir, hr, iz, hz, in, hn and chunk
  *   c = 0, 1; bpack as in the fp32 kernel; inv [2] = 1 / s_w per direction. `count` (device scalar, may be NULL = n):
- *   number of valid sequences. Packing: svdd_amd/fused.py:pack_gru_lp. */
-int svdd_gru_bidir_lp(const float* x, const void* wpack, const float* bpack, const float* inv, float* out,
-                      int n, int L, const int32_t* count, int prec, void* stream);
+ *   number of valid sequences. The input is EITHER x [n,L,64] fp32 (split into hi / lo by the kernel) OR x16
+ *   [n,L,P,64] 16-bit planes (hi, lo) as the split-precision tower writes them (then x is ignored).
+ *   Packing: svdd_amd/fused.py:pack_gru_lp. */
+int svdd_gru_bidir_lp(const float* x, const void* x16, const void* wpack, const float* bpack, const float* inv,
+                      float* out, int n, int L, const int32_t* count, int prec, void* stream);
 
 /* svdd_value_tail_lp — svdd_value_tail_f32 with the 64 -> 128 map on the 16-bit matrix cores. w1pack [64 lanes][8 ct][2 c]
  *   [P][8] 16-bit: s_w * W1'[16 ct + j][32 c + 8 g + e]; inv = 1 / s_w; the rest as in the fp32 kernel. `count` as above.

@@ -48,7 +48,8 @@ class SvddError(RuntimeError):
 def build(force=False):
     """Compile csrc/svdd_kernels.hip for gfx950 (hipcc cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, "svdd_kernels.hip"), os.path.join(CSRC, "svdd_nets.hip"),
-            os.path.join(CSRC, "svdd_nets_lp.hip"),
+            os.path.join(CSRC, "svdd_lp_backbone.hip"), os.path.join(CSRC, "svdd_lp_tower.hip"),
+            os.path.join(CSRC, "svdd_lp_gru_tail.hip"), os.path.join(CSRC, "svdd_lp_common.h"),
             os.path.join(os.path.dirname(_HERE), "include", "svdd_hip.h")]
     if os.environ.get("SVDD_HIP_LIB"):
         return SO_PATH                                   # an explicitly chosen build is used as it is
@@ -101,7 +102,7 @@ def lib():
     L.svdd_k1_stats.argtypes = [vp]
     L.svdd_conv_tower_lp.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
     L.svdd_conv_tower_windows_lp.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp]
-    L.svdd_gru_bidir_lp.argtypes = [vp, vp, vp, vp, vp, i32, i32, vp, i32, vp]
+    L.svdd_gru_bidir_lp.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, vp, i32, vp]
     L.svdd_value_tail_lp.argtypes = [vp, vp, vp, vp, vp, vp, f32, vp, i32, i32, i32, vp, i32, vp]
     L.svdd_backbone_cnn_lp.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, ctypes.POINTER(ctypes.c_int), i32, vp]
     L.svdd_profile_enable.argtypes = [i32]

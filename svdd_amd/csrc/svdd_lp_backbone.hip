@@ -1,0 +1,368 @@
+// svdd_lp_backbone.hip — the one-launch dilated-CNN backbone, split precision
+// (split-precision net kernels on the 16-bit matrix cores: see svdd_lp_common.h for the arithmetic)
+#include "svdd_lp_common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------- backbone, split precision ----
+// Same decomposition as backbone_kernel (svdd_nets.hip): one workgroup (8 waves) per tile of whole sequences; wave w
+// owns 32 output channels (column group w & 3) of the row tiles of parity w >> 2 and keeps its part of the residual
+// stream in registers in the MFMA C/D layout; the LayerNorm'd image lives in LDS as TWO 16-bit planes (hi, lo) and
+// feeds the A operands directly; weights stream from L2 into the B operands one (layer, chunk, tap) tile ahead.
+// Differences that the 16-bit MFMA brings:
+//   * one v_mfma_f32_16x16x32 covers a whole 32-channel chunk (K = 32), so a (row tile, tap, chunk) costs 2 column
+//     tiles x NP instructions instead of 16;
+//   * a lane's two output channels are ADJACENT (32 cg + 2 j, + 1) so that the hi (lo) halves of both go to LDS in one
+//     4-byte store;
+//   * the weight tile is stored by the host in exactly the order the lanes consume it: [cg][lane][ct][hi|lo][8]
+//     (64 B per lane, 4 KB per wave, fully coalesced).
+struct BackboneLpArgs {
+  const uint8_t* x;        // [n, L] tokens 0..4
+  const float* table0;     // [9][5][128]
+  const void* tiles;       // [nl*36 + 4] tiles of [4 cg][64 lanes][2 ct][NPARTS][8] 16-bit
+  const float* vec;        // [nl + 2][4][128] as in svdd_backbone_cnn_f32
+  const float* lscale;     // [nl + 1][2] = {sa: activation scale, inv: 1 / (sa * weight scale)}
+  const float* w2;         // [5][128] then b2 [5]
+  float* out;              // [n, L, 5]
+  int n, L, spt, nl;
+  int dil[BB_MAXL];
+};
+
+template <typename T, int NP, bool SPT1>
+__global__ __launch_bounds__(512, 2) void backbone_lp_kernel(BackboneLpArgs a) {
+  typedef typename Lp<T>::V8 V8;
+  typedef typename Lp<T>::V2 V2;
+  constexpr int NPARTS = NP == 3 ? 2 : 1;
+  extern __shared__ __attribute__((aligned(16))) char smem_b[];
+  char* plane = smem_b + LPSB;                               // byte address of (row 0, channel 0) of the hi plane
+  float* img32 = reinterpret_cast<float*>(smem_b);           // final stage: fp32 image [TW_ROWS][BB_AP] over the planes
+  float* Bs = reinterpret_cast<float*>(smem_b + IMG_REGION_B);   // [9][5][128] the first layer's lookup table
+  float* psum = Bs + 9 * 5 * BB_C;                           // [4][TW_ROWS]
+  float* rstat = psum + 4 * TW_ROWS;                         // [TW_ROWS]
+  int* toks = reinterpret_cast<int*>(rstat + TW_ROWS);       // [TW_ROWS]
+  int* rpos = toks + TW_ROWS;                                // [TW_ROWS]
+  int* sdil = rpos + TW_ROWS;                                // [BB_MAXL + 1]
+  int* sched = sdil + BB_MAXL + 1;                           // [(nl + 1) * 36]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cg = w & 3, rh = w >> 2;
+  const int j = lane & 15, g = lane >> 4;
+  const int c0 = 32 * cg + 2 * j;                            // this lane's output channels: c0 and c0 + 1
+  const int L = a.L;
+  const int tile_rows = a.spt * L;
+  const int64_t row0 = (int64_t)blockIdx.x * tile_rows;
+  const int64_t total_rows = (int64_t)a.n * L;
+  const int nl = a.nl;
+  const int it_end = (nl + 1) * 36;
+  constexpr int NR = 7;
+
+  for (int e = tid; e < TW_ROWS; e += 512) {
+    toks[e] = (e < tile_rows && row0 + e < total_rows) ? a.x[row0 + e] : -1;
+    rpos[e] = e < tile_rows ? e % L : -(1 << 20);
+  }
+  // zero rows -1 and TW_ROWS of both planes (a tap that leaves the sequence reads them)
+  for (int e = tid; e < LPSB / 4; e += 512) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      reinterpret_cast<int*>(smem_b + p * PLANE_B)[e] = 0;
+      reinterpret_cast<int*>(smem_b + p * PLANE_B + (TW_ROWS + 1) * LPSB)[e] = 0;
+    }
+  }
+  if (tid == 0) {
+#pragma unroll
+    for (int i = 0; i < BB_MAXL; ++i) sdil[i] = a.dil[i];
+    sdil[BB_MAXL] = 1;
+  }
+  for (int e = tid; e < 9 * 5 * BB_C; e += 512) Bs[e] = a.table0[e];
+  __syncthreads();
+  // schedule (identical to backbone_kernel): sched[k] = 0 for a tap that only sees zero padding, else
+  //   bits 0-12 live row tiles ; 13-14 chunk ; 15-18 tap ; 19-28 index of the next live k
+  for (int k = tid; k < it_end; k += 512) {
+    auto entry = [&](int kk) {
+      const int layer = kk / 36, t = kk % 9;
+      if (layer >= nl) return t == 4 ? 0x1fff : 0;
+      const int d = (t - 4) * sdil[layer];
+      const int lo = d < 0 ? -d : 0, hi = d > 0 ? L - d : L;
+      if (lo >= hi) return 0;
+      int m = 0;
+      if (SPT1) {
+        for (int r = 0; r < TW_RT; ++r) if (lo < 16 * r + 16 && hi > 16 * r) m |= 1 << r;
+      } else {
+        for (int row = 0; row < TW_ROWS; ++row) {
+          const int pp = rpos[row];
+          if (pp >= lo && pp < hi) m |= 1 << (row >> 4);
+        }
+      }
+      return m;
+    };
+    const int m = entry(k);
+    int nx = k + 1;
+    while (nx < it_end && entry(nx) == 0) ++nx;
+    sched[k] = m ? (m | ((k % 36) / 9) << 13 | (k % 9) << 15 | nx << 19) : 0;
+  }
+
+  // ---- first layer: table lookup, fp32 (dnaconv.py:177,184)
+  f32x4 f[NR][2], acc[NR][2];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    const int col = c0 + ct;
+    const float b0 = a.vec[col];
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int row = 16 * (rh + 2 * r) + 4 * g + e;
+        float v = b0;
+        if (row < TW_ROWS) {
+          const int pos = rpos[row];
+#pragma unroll
+          for (int t = 0; t < 9; ++t) {
+            const int p = pos + t - 4;
+            const int tk = (p >= 0 && p < L) ? toks[row + t - 4] : -1;
+            if (tk >= 0) v += Bs[(t * 5 + tk) * BB_C + col];
+          }
+        }
+        f[r][ct][e] = row < tile_rows ? fmaxf(v, 0.0f) : 0.0f;
+      }
+  }
+  __syncthreads();                                        // sched is visible
+
+  // A operand addressing (bytes inside a plane): this lane feeds row 16 (rh + 2 r) + j, channels 32 c + 8 g .. + 8
+  const int arow0 = (16 * rh + j) * LPSB + 16 * g;
+  const int a_lo = arow0 - (16 * rh + j + 1) * LPSB;      // row -1
+  const int a_hi = arow0 + (TW_ROWS - 16 * rh - j) * LPSB;    // row TW_ROWS
+  int apos[SPT1 ? 1 : NR];
+  if (!SPT1) {
+#pragma unroll
+    for (int r = 0; r < NR; ++r) apos[r] = 16 * (rh + 2 * r) + j < TW_ROWS ? rpos[16 * (rh + 2 * r) + j] : -(1 << 20);
+  }
+
+  // weight stream: 2 * NPARTS 16-byte pieces per lane per tile, contiguous
+  constexpr int TILE_V8 = 4 * 64 * 2 * NPARTS;
+  const V8* wsrc = reinterpret_cast<const V8*>(a.tiles) + (cg * 64 + lane) * (2 * NPARTS);
+  auto tile_of = [&](int k) { return k < nl * 36 ? k : nl * 36 + (k - nl * 36) / 9; };
+  int it = 0;
+  while (it < it_end && sched[it] == 0) ++it;
+  it = __builtin_amdgcn_readfirstlane(it);
+  int en = __builtin_amdgcn_readfirstlane(sched[it]);
+  V8 bn[2 * NPARTS];
+  {
+    const V8* src = wsrc + (size_t)tile_of(it) * TILE_V8;
+#pragma unroll
+    for (int q = 0; q < 2 * NPARTS; ++q) bn[q] = src[q];
+  }
+
+  for (int layer = 0; layer <= nl; ++layer) {             // layer == nl: the first 1x1 conv of final_conv
+    const float* vl = a.vec + (size_t)(layer + 1) * 4 * BB_C;
+    const float sa = a.lscale[2 * layer], inv = a.lscale[2 * layer + 1];
+    if (layer < nl) {
+      const float tb0 = vl[BB_C + c0], tb1 = vl[BB_C + c0 + 1];
+      // pass 1: row means
+#pragma unroll
+      for (int r = 0; r < NR; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int row = 16 * (rh + 2 * r) + 4 * g + e;
+          const float sm = group16_sum((f[r][0][e] + tb0) + (f[r][1][e] + tb1));
+          if (j == 0 && row < TW_ROWS) psum[cg * TW_ROWS + row] = sm;
+        }
+      __syncthreads();
+      if (tid < TW_ROWS)
+        rstat[tid] = ((psum[tid] + psum[TW_ROWS + tid]) + (psum[2 * TW_ROWS + tid] + psum[3 * TW_ROWS + tid])) * (1.0f / BB_C);
+      __syncthreads();
+      // pass 2: centred second moment
+#pragma unroll
+      for (int r = 0; r < NR; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int row = 16 * (rh + 2 * r) + 4 * g + e;
+          const float mean = row < TW_ROWS ? rstat[row] : 0.0f;
+          const float d0 = f[r][0][e] + tb0 - mean, d1 = f[r][1][e] + tb1 - mean;
+          acc[r][0][e] = d0; acc[r][1][e] = d1;
+          const float sq = group16_sum(d0 * d0 + d1 * d1);
+          if (j == 0 && row < TW_ROWS) psum[cg * TW_ROWS + row] = sq;
+        }
+      __syncthreads();
+      if (tid < TW_ROWS)
+        rstat[tid] = rsqrtf(((psum[tid] + psum[TW_ROWS + tid]) + (psum[2 * TW_ROWS + tid] + psum[3 * TW_ROWS + tid])) *
+                            (1.0f / BB_C) + 1e-5f);
+      __syncthreads();
+      const float gm0 = vl[2 * BB_C + c0] * sa, gm1 = vl[2 * BB_C + c0 + 1] * sa;     // sa is a power of two: exact
+      const float bt0 = vl[3 * BB_C + c0] * sa, bt1 = vl[3 * BB_C + c0 + 1] * sa;
+#pragma unroll
+      for (int r = 0; r < NR; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int row = 16 * (rh + 2 * r) + 4 * g + e;
+          if (row < TW_ROWS) {
+            const float rs = rstat[row];
+            const float v0 = row < tile_rows ? acc[r][0][e] * rs * gm0 + bt0 : 0.0f;
+            const float v1 = row < tile_rows ? acc[r][1][e] * rs * gm1 + bt1 : 0.0f;
+            V2 hi, lo;
+            split2<T>(v0, v1, hi, lo);
+            *reinterpret_cast<V2*>(plane + row * LPSB + 2 * c0) = hi;
+            if constexpr (NP == 3) *reinterpret_cast<V2*>(plane + PLANE_B + row * LPSB + 2 * c0) = lo;
+          }
+        }
+    } else {
+#pragma unroll
+      for (int r = 0; r < NR; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int row = 16 * (rh + 2 * r) + 4 * g + e;
+          if (row < TW_ROWS) {
+            V2 hi, lo;
+            split2<T>(f[r][0][e] * sa, f[r][1][e] * sa, hi, lo);
+            *reinterpret_cast<V2*>(plane + row * LPSB + 2 * c0) = hi;
+            if constexpr (NP == 3) *reinterpret_cast<V2*>(plane + PLANE_B + row * LPSB + 2 * c0) = lo;
+          }
+        }
+    }
+    // ---- implicit GEMM over (chunk, live tap)
+#pragma unroll
+    for (int r = 0; r < NR; ++r) { acc[r][0] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; acc[r][1] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
+    const int dil = __builtin_amdgcn_readfirstlane(sdil[layer < nl ? layer : BB_MAXL]);
+    const int layer_end = (layer + 1) * 36;
+    __syncthreads();                                      // the image is complete
+    while (it < layer_end) {
+      const int nxt = en >> 19;
+      const int en_next_v = sched[nxt < it_end ? nxt : it];
+      V8 bc[2 * NPARTS];
+#pragma unroll
+      for (int q = 0; q < 2 * NPARTS; ++q) bc[q] = bn[q];
+      if (nxt < it_end) {
+        const V8* src = wsrc + (size_t)tile_of(nxt) * TILE_V8;
+#pragma unroll
+        for (int q = 0; q < 2 * NPARTS; ++q) bn[q] = src[q];
+      }
+      const int delta = (((en >> 15) & 15) - 4) * dil;
+      const int coff = ((en >> 13) & 3) * 64;
+      const int dbytes = delta * LPSB + coff;
+      const int live = en >> rh;                          // bit 2 r = owned tile r
+#define LP_ALOAD(R, V)                                                                                       \
+      { int o_;                                                                                              \
+        if (SPT1) o_ = min(max(arow0 + dbytes + (R) * (32 * LPSB), a_lo + coff), a_hi + coff);               \
+        else o_ = ((unsigned)(apos[SPT1 ? 0 : (R)] + delta) < (unsigned)L ? arow0 + dbytes + (R) * (32 * LPSB) \
+                                                                            : a_hi + coff);                  \
+        V[0] = *reinterpret_cast<const V8*>(plane + o_);                                                     \
+        if constexpr (NP == 3) V[1] = *reinterpret_cast<const V8*>(plane + PLANE_B + o_); }
+#define LP_WAIT(NOUT) __builtin_amdgcn_s_waitcnt(0xC07F | ((NOUT) << 8));
+      // bc: [ct][part] -> bc[ct * NPARTS + part]
+#define LP_MM(R, U, NOUT)                                                                                    \
+      __builtin_amdgcn_sched_barrier(0);                                                                     \
+      LP_WAIT(NOUT)                                                                                          \
+      if (live & (1 << (2 * (R)))) {                                                                         \
+        acc[R][0] = Lp<T>::mfma(U[0], bc[0], acc[R][0]);                                                     \
+        acc[R][1] = Lp<T>::mfma(U[0], bc[NPARTS], acc[R][1]);                                                \
+        if constexpr (NP == 3) {                                                                             \
+          acc[R][0] = Lp<T>::mfma(U[0], bc[1], acc[R][0]);                                                   \
+          acc[R][1] = Lp<T>::mfma(U[0], bc[NPARTS + 1], acc[R][1]);                                          \
+          acc[R][0] = Lp<T>::mfma(U[1], bc[0], acc[R][0]);                                                   \
+          acc[R][1] = Lp<T>::mfma(U[1], bc[NPARTS], acc[R][1]);                                              \
+        }                                                                                                    \
+      }                                                                                                      \
+      __builtin_amdgcn_sched_barrier(0);
+      V8 ua[2], ub[2];
+      LP_ALOAD(0, ua) LP_ALOAD(1, ub)
+      LP_MM(0, ua, NPARTS)
+      LP_ALOAD(2, ua)
+      LP_MM(1, ub, NPARTS)
+      LP_ALOAD(3, ub)
+      LP_MM(2, ua, NPARTS)
+      LP_ALOAD(4, ua)
+      LP_MM(3, ub, NPARTS)
+      LP_ALOAD(5, ub)
+      LP_MM(4, ua, NPARTS)
+      if (rh == 0) {
+        LP_ALOAD(6, ua)
+        LP_MM(5, ub, NPARTS)
+        LP_MM(6, ua, 0)
+      } else {
+        LP_MM(5, ub, 0)
+      }
+#undef LP_MM
+#undef LP_WAIT
+#undef LP_ALOAD
+      it = nxt;
+      en = __builtin_amdgcn_readfirstlane(en_next_v);
+    }
+    __syncthreads();                                      // every wave is done reading the image
+    const float bl0 = vl[c0], bl1 = vl[c0 + 1];
+    if (layer < nl) {
+#pragma unroll
+      for (int r = 0; r < NR; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {                     // relu(conv + b) + f
+          f[r][0][e] = fmaxf(acc[r][0][e] * inv + bl0, 0.0f) + f[r][0][e];
+          f[r][1][e] = fmaxf(acc[r][1][e] * inv + bl1, 0.0f) + f[r][1][e];
+        }
+    } else {
+#pragma unroll
+      for (int r = 0; r < NR; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int row = 16 * (rh + 2 * r) + 4 * g + e;
+          if (row < TW_ROWS) {                            // relu(W1 f + b1), fp32 image over the (dead) planes
+            img32[row * BB_AP + c0] = fmaxf(acc[r][0][e] * inv + bl0, 0.0f);
+            img32[row * BB_AP + c0 + 1] = fmaxf(acc[r][1][e] * inv + bl1, 0.0f);
+          }
+        }
+    }
+  }
+  __syncthreads();
+  // ---- last 1x1 conv 128 -> 5 in fp32
+  for (int e = tid; e < tile_rows * 5; e += 512) {
+    const int row = e / 5, v = e - 5 * row;
+    if (row0 + row >= total_rows) continue;
+    const float* hr = img32 + row * BB_AP;
+    const float* wv = a.w2 + v * BB_C;
+    float sm = a.w2[5 * BB_C + v];
+#pragma unroll 8
+    for (int k = 0; k < BB_C; ++k) sm += hr[k] * wv[k];
+    a.out[(row0 + row) * 5 + v] = sm;
+  }
+}
+
+
+}  // namespace
+
+extern "C" int svdd_backbone_cnn_lp(const uint8_t* x, const float* table0, const void* tiles, const float* vec,
+                                    const float* lscale, const float* w2, float* out, int n, int L, int nlayers,
+                                    const int* dilations, int prec, void* stream) {
+  if (!x || !table0 || !tiles || !vec || !lscale || !w2 || !out || !dilations || n <= 0 || L <= 0 || L > TW_ROWS ||
+      nlayers <= 0 || nlayers > BB_MAXL || prec < SVDD_PREC_F16X3 || prec > SVDD_PREC_BF16)
+    return SVDD_E_ARG;
+  BackboneLpArgs a;
+  a.x = x; a.table0 = table0; a.tiles = tiles; a.vec = vec; a.lscale = lscale; a.w2 = w2; a.out = out;
+  a.n = n; a.L = L; a.spt = TW_ROWS / L; a.nl = nlayers;
+  for (int i = 0; i < nlayers; ++i) if (dilations[i] <= 0) return SVDD_E_ARG;
+  for (int i = 0; i < BB_MAXL; ++i) a.dil[i] = i < nlayers ? dilations[i] : 1;
+  const size_t lds = (size_t)IMG_REGION_B + sizeof(float) * (9 * 5 * (size_t)BB_C + 4 * (size_t)TW_ROWS + 3 * (size_t)TW_ROWS +
+                                                              BB_MAXL + 1 + (size_t)(nlayers + 1) * 36);
+  hipEvent_t e0, e1;
+  svdd_internal_timed_events(6, &e0, &e1);
+  const dim3 grid((unsigned)((n + a.spt - 1) / a.spt));
+  const bool spt1 = a.spt == 1;
+#define LP_LAUNCH(TT, NPP)                                                                                          \
+  do {                                                                                                               \
+    if (spt1) {                                                                                                      \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(backbone_lp_kernel<TT, NPP, true>),                    \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                               \
+      hipExtLaunchKernelGGL((backbone_lp_kernel<TT, NPP, true>), grid, dim3(512), lds, (hipStream_t)stream, e0, e1, 0, a);  \
+    } else {                                                                                                         \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(backbone_lp_kernel<TT, NPP, false>),                   \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                               \
+      hipExtLaunchKernelGGL((backbone_lp_kernel<TT, NPP, false>), grid, dim3(512), lds, (hipStream_t)stream, e0, e1, 0, a); \
+    }                                                                                                                \
+  } while (0)
+  switch (prec) {
+    case SVDD_PREC_F16X3: LP_LAUNCH(_Float16, 3); break;
+    case SVDD_PREC_BF16X3: LP_LAUNCH(__bf16, 3); break;
+    case SVDD_PREC_F16: LP_LAUNCH(_Float16, 1); break;
+    default: LP_LAUNCH(__bf16, 1); break;
+  }
+#undef LP_LAUNCH
+  return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
+}
+

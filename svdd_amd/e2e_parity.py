@@ -1,0 +1,77 @@
+"""End-to-end comparison of a GPU decode with real nets against a reference trajectory recorded on the CPU
+(hard part (ii)): the reference's tiny nets (tests/golden/nets_tiny.npz) run on the GPU through this
+engine in replay mode and are compared step by step with the reference's own `controlled_sample` run
+(tests/golden/g6_traj_mc_c1.npz: states, logits, scores of every step; reference diffusion_gosai.py:1021-1061).
+
+argmax is discontinuous, so a last-bit difference between MIOpen / our kernels and the CPU's MKL-DNN convolutions can flip
+a token at a near-tie, after which that ROW's trajectory differs (rows are independent). The report therefore gives, per
+run: the first step at which any state differs, the error of logits and scores up to that step (north-star tolerance
+1e-4), the fraction of rows / tokens of x_0 that still agree, and for the first diverging row how close the deciding
+quantities were in the reference run. Used by tests/test_e2e_gpu.py and tools/e2e_parity_report.py."""
+import numpy as np
+import torch
+
+from .backbone import CNNModel
+from .config import Config, ModelConfig, SamplingConfig
+from .diffusion import Diffusion
+from .value_nets import ConvGRUTrunk, ConvHead
+
+
+def _sd(g, prefix):
+    return {k[len(prefix) + 1:]: torch.from_numpy(np.asarray(v)) for k, v in g.items() if k.startswith(prefix + ".")}
+
+
+def tiny_engine(nets, L, S, device):
+    """The reference's tiny nets (hidden 16 x 1 stack backbone; 8-channel ConvGRU value net) inside the engine."""
+    cfg = Config(model=ModelConfig(hidden_dim=16, num_cnn_stacks=1, length=L), sampling=SamplingConfig(steps=S))
+    bb = CNNModel(cfg.model, alphabet_size=5)
+    bb.load_state_dict(_sd(nets, "backbone"), strict=True)
+    model = Diffusion(cfg, backbone=bb)
+    emb = ConvGRUTrunk(stem_in_channels=4, stem_channels=8, stem_kernel_size=15, n_conv=3, channel_init=8, kernel_size=5,
+                       dropout=0.1)
+    emb.load_state_dict(_sd(nets, "embedding"), strict=True)
+    head = ConvHead(1, 8)
+    head.load_state_dict(_sd(nets, "head"), strict=True)
+    for m in (model, emb, head):
+        m.to(device).eval()
+    return model, emb, head
+
+
+def compare_with_reference_run(g, nets, device="cuda:0", fuse_nets=True, value_batching="batched"):
+    """-> report dict (see module docstring)."""
+    S, B, L, M = int(g["S"]), int(g["B"]), int(g["L"]), int(g["M"])
+    model, emb, head = tiny_engine(nets, L, S, device)
+    model.fuse_nets, model.value_batching, model.rng_mode = fuse_nets, value_batching, "replay"
+    model.trace, model.state_trace = [], []
+    torch.manual_seed(int(g["seed"]))
+    with torch.no_grad():
+        x0 = model.controlled_sample(emb, head, eval_sp_size=B, sample_M=M)
+    torch.cuda.synchronize()
+    xs = np.stack([x.cpu().numpy() for x in model.state_trace])                # [S + 1, B, L] states fed to the backbone
+    logits = [t[0].cpu().numpy() for t in model.trace]
+    scores = [t[1].cpu().numpy() for t in model.trace[:-1]]
+    same = (xs == g["xs"]).all(axis=2)                                            # [S + 1, B]
+    first = next((i for i in range(S + 1) if not same[i].all()), None)
+    upto = S + 1 if first is None else first                                      # steps whose INPUT state is still identical
+    dl = max(float(np.abs(logits[i] - g["logits"][i]).max()) for i in range(upto)) if upto else 0.0
+    ds = max([float(np.abs(scores[i] - g["scores"][i]).max()) for i in range(min(upto, S))] or [0.0])
+    # row-wise: the error on rows that have not diverged yet, over the whole run
+    dl_rows = max(float(np.abs(logits[i][same[i]] - g["logits"][i][same[i]]).max()) for i in range(S + 1) if same[i].any())
+    ds_rows = max(float(np.abs(scores[i][same[i]] - g["scores"][i][same[i]]).max()) for i in range(S) if same[i].any())
+    x0n = x0.cpu().numpy()
+    rep = {"S": S, "B": B, "L": L, "M": M, "fuse_nets": fuse_nets, "value_batching": value_batching,
+           "first_divergence_step": first, "steps_compared": upto,
+           "max_abs_logit_err_before_divergence": dl, "max_abs_score_err_before_divergence": ds,
+           "max_abs_logit_err_on_undiverged_rows": dl_rows, "max_abs_score_err_on_undiverged_rows": ds_rows,
+           "x0_exact": bool(np.array_equal(x0n, g["x0"])),
+           "x0_rows_identical": float((x0n == g["x0"]).all(axis=1).mean()),
+           "x0_tokens_identical": float((x0n == g["x0"]).mean())}
+    if first is not None:
+        i = first - 1                                                              # the step that produced the first differing state
+        row = int(np.nonzero(~same[first])[0][0])
+        sc = np.sort(g["scores"][i][row])[::-1]
+        rep["first_divergence"] = {"row": row, "produced_by_step": i,
+                                   "reference_score_gap_top2": float(sc[0] - sc[1]) if M > 1 else None,
+                                   "gpu_minus_ref_scores": (scores[i][row] - g["scores"][i][row]).tolist()}
+    model.trace = model.state_trace = None
+    return rep

@@ -261,8 +261,8 @@ def backbone_cnn_lp(tokens, pk):
 
 def pack_tower_lp(stem_weight, layer_weights, precision):
     """(tiles, inv) for svdd_conv_tower_lp: the tiles of pack_tower re-ordered per MFMA lane and split into 16-bit hi / lo,
-    [2 + 10*nlayers][4 cs][64 lanes = 16 g + j][P][8 e] = s_w * W[16 cs + j][8 g + e]; inv[stage] = 1 / s_w (f16: s_w a
-    power of two that puts max |W| of the stage into [1024, 2048); bf16: 1)."""
+    [2 + 10*nlayers][2 cp][64 lanes = 16 g + j][2 ct][P][8 e] = s_w * W[32 cp + 2 j + ct][8 g + e]; inv[stage] = 1 / s_w
+    (f16: s_w a power of two that puts max |W| of the stage into [1024, 2048); bf16: 1)."""
     dtype, parts = LP_DTYPES[precision]
     f16 = dtype == torch.float16
     t32 = pack_tower(stem_weight, layer_weights)                         # [2 + 10 nl][64 co][32 k]
@@ -274,8 +274,8 @@ def pack_tower_lp(stem_weight, layer_weights, precision):
         inv.append(1.0 / _pow2_floor(2047.0 / m) if f16 else 1.0)
     invt = torch.tensor(inv, dtype=torch.float32, device=t32.device)
     scaled = t32 / invt[stage][:, None, None]
-    v = _split16(scaled.reshape(-1, 4, 16, 4, 8), dtype, parts)          # [it][cs][j][g][e][parts]
-    return v.permute(0, 1, 3, 2, 5, 4).contiguous().reshape(-1), invt.contiguous()
+    v = _split16(scaled.reshape(-1, 2, 16, 2, 4, 8), dtype, parts)       # [it][cp][j][ct][g][e][parts]
+    return v.permute(0, 1, 4, 2, 3, 6, 5).contiguous().reshape(-1), invt.contiguous()
 
 
 def pack_gru_lp(gru, precision):
@@ -311,11 +311,17 @@ def pack_tail_lp(w1, b1, gamma, beta, precision):
     return v.permute(3, 1, 0, 2, 5, 4).contiguous().reshape(-1), bf, 1.0 / sw
 
 
+def tiles_parts(tiles, bias):
+    """1 or 2: whether a pack_tower_lp image holds hi only or (hi, lo)."""
+    return tiles.numel() // ((2 + 10 * (bias.shape[0] - 1)) * 4 * 64 * 8)
+
+
 def conv_tower_lp(tok, tiles, bias, inv, residual_mask, prec):
-    """tokens [n, L] u8 -> tower output [n, L, 64] fp32 (HIP kernel svdd_conv_tower_lp)."""
+    """tokens [n, L] u8 -> tower output [n, L, P, 64] in 16-bit planes (hi, lo; value = hi + lo), the form the
+    split-precision GRU consumes (HIP kernel svdd_conv_tower_lp)."""
     assert tok.is_cuda and tok.dtype == torch.uint8 and tok.is_contiguous()
     n, L = tok.shape
-    out = torch.empty((n, L, 64), dtype=torch.float32, device=tok.device)
+    out = torch.empty((n, L, tiles_parts(tiles, bias), 64), dtype=tiles.dtype, device=tok.device)
     rc = _lib.lib().svdd_conv_tower_lp(tok.data_ptr(), tiles.data_ptr(), bias.data_ptr(), inv.data_ptr(), out.data_ptr(),
                                        n, L, bias.shape[0] - 1, int(residual_mask), prec,
                                        ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
@@ -330,7 +336,7 @@ def conv_tower_windows_lp(cand, win, parent_out, tiles, bias, inv, residual_mask
     B, M, L = cand.shape
     n = B * M
     if out is None:
-        out = torch.empty((n, L, 64), dtype=torch.float32, device=cand.device)
+        out = torch.empty((n, L, parent_out.shape[2], 64), dtype=tiles.dtype, device=cand.device)
     rc = _lib.lib().svdd_conv_tower_windows_lp(cand.data_ptr(), tiles.data_ptr(), bias.data_ptr(), inv.data_ptr(),
                                                win.data_ptr(), parent_out.data_ptr(), out.data_ptr(), n, L, M,
                                                bias.shape[0] - 1, int(residual_mask), _ptr(live_idx), _ptr(count), prec,
@@ -340,12 +346,16 @@ def conv_tower_windows_lp(cand, win, parent_out, tiles, bias, inv, residual_mask
 
 
 def gru_bidir_lp(x_nlc, wpack, bpack, inv, prec, count=None, out=None):
-    """x [n, L, 64] fp32 -> [2, n, L, 64] per-direction hidden states on the 16-bit matrix cores (svdd_gru_bidir_lp)."""
-    assert x_nlc.is_cuda and x_nlc.dtype == torch.float32 and x_nlc.is_contiguous() and x_nlc.shape[2] == 64
-    n, L, _ = x_nlc.shape
+    """x -> [2, n, L, 64] per-direction hidden states (fp32) on the 16-bit matrix cores (svdd_gru_bidir_lp).
+    x: [n, L, 64] fp32, or the split-precision tower's output [n, L, P, 64] in 16-bit planes (hi, lo)."""
+    assert x_nlc.is_cuda and x_nlc.is_contiguous() and x_nlc.shape[-1] == 64
+    split = x_nlc.dim() == 4
+    assert split or x_nlc.dtype == torch.float32
+    n, L = x_nlc.shape[0], x_nlc.shape[1]
     if out is None:
         out = torch.empty((2, n, L, 64), dtype=torch.float32, device=x_nlc.device)
-    rc = _lib.lib().svdd_gru_bidir_lp(x_nlc.data_ptr(), wpack.data_ptr(), bpack.data_ptr(), inv.data_ptr(), out.data_ptr(),
+    rc = _lib.lib().svdd_gru_bidir_lp(None if split else x_nlc.data_ptr(), x_nlc.data_ptr() if split else None,
+                                      wpack.data_ptr(), bpack.data_ptr(), inv.data_ptr(), out.data_ptr(),
                                       n, L, _ptr(count), prec, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     _lib.check(rc, "svdd_gru_bidir_lp")
     return out
@@ -476,7 +486,7 @@ class FusedValueNet(nn.Module):
         self.use_fused_tail = True
         self.share_parent_tower = True
         # "f32" (exact, default) or one of LP_DTYPES: the conv tower, GRU and tail on the 16-bit matrix cores
-        # (csrc/svdd_nets_lp.hip). Needs the reference-shaped net (tower_ok, tail_ok).
+        # (csrc/svdd_lp_*.hip). Needs the reference-shaped net (tower_ok, tail_ok).
         self.precision = "f32"
         self._gru_mod = (gt.gru,)                                   # tuple: keeps the module out of this one's registry
         self._stem_w_raw = stem.weight.detach()

@@ -7,9 +7,11 @@ Any `nn.Module` with those signatures works. This file provides the architecture
 instantiates for the RNA/“rna_saluki” tasks and that BASELINE.json's synthetic configs use:
 `ConvGRUTrunk` + `ConvHead` (reference Enformer.py:32-49, 1337-1426, 1571-1751, 2131-2173).
 
-Attribute paths of every *used* parameter equal the reference's, so its checkpoints load with
-`load_reference_state_dict` (the reference also registers a few parameters it never uses —
-`Stem.norm`, `FeedForwardBlock.dense` — which are skipped).
+Attribute paths AND creation order of every parameter equal the reference's — including the two modules the
+reference registers but never calls (`Stem.norm`, Enformer.py:1790, and `FeedForwardBlock.dense`, :2031-2033, both
+"saluki" leftovers) — so that a reference checkpoint loads with a plain strict `load_state_dict`, and a given
+`torch.manual_seed` yields the very same random-init network as the reference's classes (the unused Linear consumes
+RNG draws before the head is created; tests/golden/g12_fullsize_probe.npz pins this at full size).
 """
 import torch
 import torch.nn.functional as F
@@ -33,6 +35,7 @@ class Stem(nn.Module):
     def __init__(self, in_channels, out_channels, kernel_size):
         super().__init__()
         self.conv = nn.Conv1d(in_channels, out_channels, kernel_size, padding="same")
+        self.norm = _Wrapped(nn.LayerNorm(out_channels))     # registered, never applied (reference :1790,1801)
 
     def forward(self, x):
         return F.relu(self.conv(x))
@@ -95,6 +98,7 @@ class FeedForwardBlock(nn.Module):
         super().__init__()
         self.dense1 = LinearBlock(in_len, in_len * 2, norm=True, act=True, dropout=dropout)
         self.dense2 = LinearBlock(in_len * 2, in_len, norm=False, act=False, dropout=dropout)
+        self.dense = LinearBlock(in_len, in_len, norm=True, act=True, dropout=dropout)   # registered, never applied (:2031-2046)
 
     def forward(self, x):
         return self.dense2(self.dense1(x))
@@ -167,10 +171,6 @@ class RewardModel(nn.Module):
         return self.head(self.embedding(x))
 
 
-_UNUSED = (".blocks.0.norm.", ".ffn.dense.")
-
-
 def load_reference_state_dict(module, state_dict):
-    """Loads a reference checkpoint, dropping the parameters the reference registers but never uses."""
-    sd = {k: v for k, v in state_dict.items() if not any(u in "." + k for u in _UNUSED)}
-    return module.load_state_dict(sd, strict=True)
+    """Loads a reference checkpoint (strict: every key of the reference's module exists here, used or not)."""
+    return module.load_state_dict(state_dict, strict=True)

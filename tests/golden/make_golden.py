@@ -18,6 +18,9 @@ outputs are stored. Fixtures:
   g10_decode_sample.npz       decode_sample (un-guided), S=16, B=3, L=50
   g11_traj_dps.npz            controlled_sample_DPS, S=6, B=3, L=50: guided q_xs, uniforms, gradients per step
   nets_tiny.npz               state_dicts of the tiny nets used above (for net-parity tests)
+  g12_fullsize_probe.npz      FULL-SIZE reference nets (CNNModel hidden 128 x 4 stacks; ConvGRUTrunk 64 ch, n_conv 6 +
+                              ConvHead) built at torch.manual_seed(44) in the order svdd_amd/synthetic.py builds them,
+                              evaluated on 4 probe rows: logits, value scores, a checksum of every parameter tensor
 """
 import os
 import sys
@@ -395,7 +398,35 @@ def nets():
     save("nets_tiny.npz", **arrs)
 
 
+def g12_fullsize_probe(seed=44):
+    """The nets of BASELINE.json's configs at full size, random-initialised exactly like svdd_amd.synthetic.build
+    (torch.manual_seed(44) — decode.py:181's default — then Diffusion, value trunk, value head, in that order), run by the
+    REFERENCE's own modules. Pins the full-size architecture (20 dilated layers, n_conv = 6, GRU, FFN, head) and the
+    parameter creation order of the build's mirrors, which the tiny fixtures cannot."""
+    torch.manual_seed(seed)
+    d = dg.Diffusion(make_cfg(length=200, hidden_dim=128, num_cnn_stacks=4, steps=128)).eval()
+    emb = En.ConvGRUTrunk(stem_in_channels=4, stem_channels=64, stem_kernel_size=15, n_conv=6, channel_init=64,
+                          channel_mult=1, kernel_size=5, act_func="relu", conv_norm=True, pool_func=None,
+                          pool_size=None, residual=True, crop_len=0, n_gru=1, dropout=0.1, gru_norm=True).eval()
+    head = En.ConvHead(n_tasks=1, in_channels=64, act_func=None, pool_func="avg", norm=False).eval()
+    torch.manual_seed(8)
+    x = torch.where(torch.rand(4, 200) < 0.6, torch.full((4, 200), 4), torch.randint(0, 4, (4, 200)))
+    x[3] = 4                                                     # the all-MASK prior row
+    arrs = {"x": x.numpy().astype(np.uint8), "seed": seed}
+    with torch.no_grad():
+        arrs["logits"] = d.backbone(x, torch.zeros(4)).numpy()                      # raw backbone output [4, 200, 5]
+        arrs["logp"] = d.forward(x, torch.zeros(4)).numpy()                         # after _subs_parameterization
+        oh = d.transform_samples(x).float()
+        arrs["value"] = head(emb(oh)).reshape(-1).numpy()
+    for name, mod in (("backbone", d.backbone), ("embedding", emb), ("head", head)):
+        arrs[name + "_param_sums"] = np.array([float(p.double().sum()) for p in mod.state_dict().values()])
+    save("g12_fullsize_probe.npz", **arrs)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "g12":
+        g12_fullsize_probe()
+        sys.exit(0)
     d = tiny_diffusion(200, 128)
     g9()
     g1()
@@ -410,3 +441,4 @@ if __name__ == "__main__":
     g10()
     traj_dps()
     nets()
+    g12_fullsize_probe()

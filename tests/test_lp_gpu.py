@@ -1,4 +1,4 @@
-"""-m gpu: the split-precision net kernels (svdd_amd/csrc/svdd_nets_lp.hip, Diffusion.precision) against the exact-fp32
+"""-m gpu: the split-precision net kernels (svdd_amd/csrc/svdd_lp_*.hip, Diffusion.precision) against the exact-fp32
 kernels and fp64 evaluations of the PyTorch modules.
 
 Tolerances: the north star allows 1e-4 on reward / soft-value tensors. The x3 modes (operands split hi + lo, three

@@ -49,6 +49,26 @@ def test_value_and_reward_match_reference(golden):
     assert np.abs(r.numpy() - g["probe_reward"]).max() <= 1e-6
 
 
+def test_fullsize_nets_equal_the_reference_classes_at_seed_44(golden):
+    """g12_fullsize_probe.npz: the REFERENCE's CNNModel / ConvGRUTrunk / ConvHead at full size, random-initialised at
+    torch.manual_seed(44) in synthetic.build's order. The mirrors must create the same parameters in the same order
+    (every tensor's sum is compared) and compute the same functions."""
+    from svdd_amd import synthetic
+    g = golden("g12_fullsize_probe.npz")
+    model, emb, head, _ = synthetic.build("dna", "cpu", seed=int(g["seed"]))
+    for name, mod in (("backbone", model.backbone), ("embedding", emb), ("head", head)):
+        sums = np.array([float(p.double().sum()) for p in mod.state_dict().values()])
+        assert sums.shape == g[name + "_param_sums"].shape, name        # same state_dict keys (strict-load compatible)
+        assert np.array_equal(sums, g[name + "_param_sums"]), name
+    x = torch.from_numpy(g["x"].astype(np.int64))
+    with torch.no_grad():
+        logits = model.backbone(x, torch.zeros(4))
+        oh = (torch.nn.functional.one_hot(x.clamp(max=3), 4) * (x != 4)[..., None]).float()
+        value = head(emb(oh)).reshape(-1)
+    assert np.abs(logits.numpy() - g["logits"]).max() <= 2e-6
+    assert np.abs(value.numpy() - g["value"]).max() <= 1e-6
+
+
 def test_flop_formulas():
     assert CNNModel.flops_per_position() == 5_943_808            # SURVEY §8d
 

@@ -1,0 +1,105 @@
+"""Timing-only ablation experiments on the kernels: every variant deletes one component of a kernel (its results are
+wrong by construction) so that the component's cost shows up as a time difference.
+
+    python tools/exp_variants.py build <set>     here (no GPU needed): patched COPIES of svdd_amd/csrc are compiled into
+                                                 build/exp/<set>/<variant>/libsvdd_hip.so (git-ignored, travels with gpurun)
+    python tools/exp_variants.py run <set>       on the GPU box: the set's microbenchmark once per variant (SVDD_HIP_LIB)
+
+The tracked sources are never edited in place."""
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "svdd_amd", "csrc")
+
+GRU_LP = {
+    "file": "svdd_lp_gru_tail.hip",
+    "bench": ["python", "tools/gru_lp_microbench.py", "f16x3", "2560", "2048", "1280"],
+    "variants": {
+        "baseline": [],
+        "nogates": [("const float r = sigmoid_fast(acc_r[rho] * inv + b_r);", "const float r = acc_r[rho] * inv + b_r;"),
+                    ("const float z = sigmoid_fast(acc_z[rho] * inv + b_z);", "const float z = acc_z[rho] * inv + b_z;"),
+                    ("const float nn = tanh_fast(acc_nx[rho] * inv + b_nx + r * (acc_nh[rho] * inv + b_nh));",
+                     "const float nn = acc_nx[rho] * inv + b_nx + r * (acc_nh[rho] * inv + b_nh);")],
+        "nostore": [("if (seq0 + srow < n) a.out[", "if (seq0 + srow < n && hn[rho] == 12345.0f) a.out[")],
+        "noprod_mfma": [("      if (s + 1 < L) project(1, 1);", "      if (s + 1 < L && n == 12345) project(1, 1);"),
+                        ("      if (s + 2 < L) project(0, 0);", "      if (s + 2 < L && n == 12345) project(0, 0);")],
+        "noprod_load": [("      if (s + 3 < L) load_x(t0 + (s + 3) * dt, 1);", "      if (s + 3 < L && n == 12345) load_x(t0 + (s + 3) * dt, 1);"),
+                        ("      if (s + 4 < L) load_x(t0 + (s + 4) * dt, 0);", "      if (s + 4 < L && n == 12345) load_x(t0 + (s + 4) * dt, 0);")],
+        "norec_mfma": [("#pragma unroll\n    for (int c = 0; c < 2; ++c) {\n      acc_nh = Lp<T>::mfma(hh[c], wb[2][c][0], acc_nh);",
+                        "#pragma unroll\n    for (int c = 0; c < 2 && n == 12345; ++c) {\n      acc_nh = Lp<T>::mfma(hh[c], wb[2][c][0], acc_nh);")],
+    },
+}
+GRU_LP["variants"]["nogates_nostore"] = GRU_LP["variants"]["nogates"] + GRU_LP["variants"]["nostore"]
+GRU_LP["variants"]["noprod"] = GRU_LP["variants"]["noprod_mfma"] + GRU_LP["variants"]["noprod_load"]
+GRU_LP["variants"]["only_barrier_lds"] = (GRU_LP["variants"]["nogates"] + GRU_LP["variants"]["nostore"] + GRU_LP["variants"]["noprod"] +
+                                          GRU_LP["variants"]["norec_mfma"])
+TOWER_LP = {
+    "file": "svdd_lp_tower.hip",
+    "bench": ["python", "tools/tower_lp_microbench.py", "f16x3", "3.0"],
+    "variants": {
+        "baseline": [],
+        "noB": [("      if (it + 1 < nit) {\n        const V8* src = wsrc + (size_t)(it + 1) * TILE_V8;",
+                 "      if (it + 1 < nit && a.n == 12345) {\n        const V8* src = wsrc + (size_t)(it + 1) * TILE_V8;")],
+        "noA": [("          V[0] = *reinterpret_cast<const V8*>(plane + o_);                                                    \\\n          if constexpr (NP == 3) V[1] = *reinterpret_cast<const V8*>(plane + TPLANE_B + o_);                  \\",
+                 "          V[0] = bc[0]; (void)o_;                                                                            \\\n          if constexpr (NP == 3) V[1] = bc[1];                                                                \\")],
+        "nocopy": [("      if (row < keep_lo || row >= keep_hi) outc[e] = par[e];", "      if ((row < keep_lo || row >= keep_hi) && a.n == 12345) outc[e] = par[e];")],
+        "nozero": [("  for (int e = tid; e < 2 * TPLANE_B / 4; e += 512) reinterpret_cast<int*>(smem_b)[e] = 0;",
+                    "  for (int e = tid; e < 2 * TPLANE_B / 4 && a.n == 12345; e += 512) reinterpret_cast<int*>(smem_b)[e] = 0;")],
+        "nomfma": [("          acc[R] = Lp<T>::mfma(U[0], bc[0], acc[R]);                                                          \\\n          if constexpr (NP == 3) { acc[R] = Lp<T>::mfma(U[0], bc[1], acc[R]); acc[R] = Lp<T>::mfma(U[1], bc[0], acc[R]); } \\",
+                    "          acc[R][0] += (float)U[0][0] * (float)bc[0][0]; if constexpr (NP == 3) acc[R][1] += (float)U[1][0] * (float)bc[1][0];   \\\n          \\")],
+    },
+}
+TOWER_LP["variants"]["noA_noB"] = TOWER_LP["variants"]["noA"] + TOWER_LP["variants"]["noB"]
+TOWER_LP["variants"]["noA_noB_nomfma"] = TOWER_LP["variants"]["noA"] + TOWER_LP["variants"]["noB"] + TOWER_LP["variants"]["nomfma"]
+SETS = {"gru_lp": GRU_LP, "tower_lp": TOWER_LP}
+
+
+def build_variant(setname, name, spec):
+    work = os.path.join(ROOT, "build", "exp", setname, name)
+    shutil.rmtree(work, ignore_errors=True)
+    os.makedirs(work)
+    for f in os.listdir(CSRC):
+        if f.endswith(".hip") or f.endswith(".h") or f == "Makefile":
+            shutil.copy(os.path.join(CSRC, f), work)
+    for f in os.listdir(CSRC):                       # objects of the untouched sources are reused
+        if f.endswith(".o") and f[:-2] + ".hip" != spec["file"]:
+            shutil.copy(os.path.join(CSRC, f), work)
+            os.utime(os.path.join(work, f))
+    p = os.path.join(work, spec["file"])
+    s = open(p).read()
+    for old, new in spec["variants"][name]:
+        assert old in s, (name, old)
+        s = s.replace(old, new)
+    open(p, "w").write(s)
+    r = subprocess.run(["make", "-C", work, "INC=" + os.path.join(ROOT, "include")], capture_output=True, text=True)
+    ok = os.path.exists(os.path.join(work, "libsvdd_hip.so"))
+    for f in os.listdir(work):                       # keep only the library
+        if f != "libsvdd_hip.so":
+            os.remove(os.path.join(work, f))
+    return name, ok, r.stderr[-400:] if not ok else ""
+
+
+def main():
+    cmd, setname = sys.argv[1], sys.argv[2]
+    spec = SETS[setname]
+    only = sys.argv[3:]
+    names = [n for n in spec["variants"] if not only or n in only]
+    if cmd == "build":
+        with ThreadPoolExecutor(4) as ex:
+            for name, ok, err in ex.map(lambda n: build_variant(setname, n, spec), names):
+                print(name, "ok" if ok else "FAILED " + err)
+    else:
+        for name in names:
+            lib = os.path.join(ROOT, "build", "exp", setname, name, "libsvdd_hip.so")
+            env = dict(os.environ, SVDD_HIP_LIB=lib)
+            r = subprocess.run(spec["bench"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+            lines = [ln for ln in r.stdout.splitlines() if "amdgpu.ids" not in ln]
+            print(f"{name:28s} " + " | ".join(lines) + (" ERR " + r.stderr[-200:] if r.returncode else ""))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,5 +1,5 @@
 // mfma_lp_probe.hip — what the 16-bit matrix cores of gfx950 do with the operands the split-precision net kernels
-// (svdd_amd/csrc/svdd_nets_lp.hip) feed them. Standalone: hipcc --offload-arch=gfx950 -O3 -o mfma_lp_probe mfma_lp_probe.hip
+// (svdd_amd/csrc/svdd_lp_*.hip) feed them. Standalone: hipcc --offload-arch=gfx950 -O3 -o mfma_lp_probe mfma_lp_probe.hip
 //   1. fragment layout of v_mfma_f32_16x16x32_{f16,bf16}: A lane l = row l&15, k = 8 (l>>4) + e ; B lane l = col l&15,
 //      same k ; C/D reg r = row 4 (l>>4) + r, col l&15   (asymmetric random operands vs a host fp64 GEMM)
 //   2. subnormal 16-bit inputs: flushed or kept?
