@@ -64,9 +64,28 @@ class BaseModel(nn.Module):
         onehot = self.transform_samples(tokens).float()
         return self.head(self.embedding(onehot)).squeeze(2).detach()          # Enformer.py:443
 
+    def _next_batch_seed(self):
+        """Philox mode: the sampler is a pure function of (philox_seed, row, step), so consecutive batches would be
+        copies of each other; the reference's batches differ because they share torch's global generator
+        (Enformer.py:439-467). Every batch of a harness call therefore gets the next seed base + k (deterministic given
+        the model's philox_seed at entry); replay mode keeps drawing from the global generator like the reference."""
+        m = self.ref_model
+        if getattr(m, "rng_mode", "replay") == "philox":
+            m.philox_seed = self._seed_base + self._batch_index
+        self._batch_index += 1
+
     def _decode(self, gen_batch_num, sample_M, guided):
+        self._seed_base, self._batch_index = int(getattr(self.ref_model, "philox_seed", 0)), 0
+        try:
+            return self._decode_inner(gen_batch_num, sample_M, guided)
+        finally:
+            if hasattr(self.ref_model, "philox_seed"):
+                self.ref_model.philox_seed = self._seed_base
+
+    def _decode_inner(self, gen_batch_num, sample_M, guided):
         samples, value_func_preds, reward_model_preds = [], [], []
         for _ in range(gen_batch_num):
+            self._next_batch_seed()
             batch = guided()
             samples.append(batch)
             value_func_preds.extend(self._value(batch))
@@ -74,6 +93,7 @@ class BaseModel(nn.Module):
         print("Value-weighted sampling done.")
         baseline_preds, all_preds = [], []
         for i in range(gen_batch_num * sample_M):                             # Enformer.py:456-467
+            self._next_batch_seed()
             batch = self.ref_model.decode_sample(eval_sp_size=self.NUM_SAMPLES_PER_BATCH)
             pred = self._reward(batch)
             if i < gen_batch_num:
@@ -109,8 +129,17 @@ class BaseModel(nn.Module):
         """DPS baseline (reference Enformer.py:560-637). The guided decodes back-propagate through the backbone
         and the reward net, so they run with autograd on; the evaluation / baseline part runs under no_grad.
         (Scoring consumes no RNG, so decoding all guided batches first keeps the reference's RNG order.)"""
-        batches = iter([self.ref_model.controlled_sample_DPS(self.reward_model, guidance_scale,
-                                                             eval_sp_size=self.NUM_SAMPLES_PER_BATCH, sample_M=sample_M)
-                        for _ in range(gen_batch_num)])
+        m = self.ref_model
+        base, out = int(getattr(m, "philox_seed", 0)), []
+        try:
+            for k in range(gen_batch_num):
+                if getattr(m, "rng_mode", "replay") == "philox":
+                    m.philox_seed = base + k                      # the seed _decode would give guided batch k
+                out.append(m.controlled_sample_DPS(self.reward_model, guidance_scale,
+                                                   eval_sp_size=self.NUM_SAMPLES_PER_BATCH, sample_M=sample_M))
+        finally:
+            if hasattr(m, "philox_seed"):
+                m.philox_seed = base
+        batches = iter(out)
         with torch.no_grad():
             return self._decode(gen_batch_num, sample_M, lambda: next(batches))

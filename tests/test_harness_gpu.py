@@ -1,0 +1,147 @@
+"""-m gpu: VALUES of the decode harness (`BaseModel.controlled_decode*`, reference Enformer.py:399-477) and of the
+un-guided `_sample` / `_presample` paths (reference diffusion_gosai.py:820-886, Enformer.py:135-160).
+
+The 5-tuple (samples, value_func_preds, reward_model_preds, top_k_values, baseline_preds) is recomputed independently
+from the engine's primitives: batch k of a harness call is the sampler run with Philox seed base + k (guided batches
+first, then gen_batch_num * sample_M baseline batches); predictions are the plain modules on the batch's one-hot;
+baseline_preds are the first gen_batch_num baseline batches; top-k is the best len / sample_M of ALL baseline rewards."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def small():
+    from svdd_amd import synthetic
+    from svdd_amd.config import SamplingConfig
+    model, emb, head, reward = synthetic.build("rna", DEV)
+    model.config.sampling = SamplingConfig(steps=6)
+    return model, emb, head, reward
+
+
+def _onehot(tok):
+    return (torch.nn.functional.one_hot(tok.clamp(max=3), 4) * (tok != 4)[..., None]).float()
+
+
+@pytest.mark.parametrize("method", ["mc", "tweedie"])
+def test_controlled_decode_values(small, method):
+    from svdd_amd.harness import BaseModel
+    model, emb, head, reward = small
+    Bsz, M, G = 4, 3, 2
+    model.rng_mode, model.philox_seed = "philox", 40
+    hm = BaseModel(emb, head, model, reward, batch_size=Bsz, task="rna")
+    with torch.no_grad():
+        if method == "mc":
+            samples, vpred, rpred, topk, base = hm.controlled_decode(gen_batch_num=G, sample_M=M)
+        else:
+            samples, vpred, rpred, topk, base = hm.controlled_decode_tweedie(gen_batch_num=G, sample_M=M, options="True")
+    assert model.philox_seed == 40                                   # restored
+    # --- independent recomputation
+    exp_samples, exp_v, exp_r = [], [], []
+    with torch.no_grad():
+        for k in range(G):
+            model.philox_seed = 40 + k
+            if method == "mc":
+                b = model.controlled_sample(emb, head, eval_sp_size=Bsz, sample_M=M)
+            else:
+                b = model.controlled_sample_tweedie(reward, eval_sp_size=Bsz, sample_M=M, options="True", task="rna")
+            exp_samples.append(b)
+            exp_v.append(head(emb(_onehot(b))).reshape(Bsz))
+            exp_r.append(reward(_onehot(b).transpose(1, 2))[:, 0].reshape(Bsz))
+        all_base = []
+        for i in range(G * M):
+            model.philox_seed = 40 + G + i
+            b = model.decode_sample(eval_sp_size=Bsz)
+            all_base.append(reward(_onehot(b).transpose(1, 2))[:, 0].reshape(Bsz))
+    model.philox_seed = 40
+    assert len(samples) == G
+    for a, b in zip(samples, exp_samples):
+        assert a.dtype == torch.int64 and torch.equal(a, b)
+    assert not torch.equal(samples[0], samples[1])                    # batches are not copies of each other
+    assert torch.allclose(vpred.reshape(-1), torch.cat(exp_v), atol=1e-6)
+    assert torch.allclose(rpred.reshape(-1), torch.cat(exp_r), atol=1e-6)
+    assert torch.allclose(base.reshape(-1), torch.cat(all_base[:G]), atol=1e-6)          # slice i < gen_batch_num
+    allv = torch.cat(all_base)
+    k = int(len(allv) / M)
+    exp_topk = torch.sort(allv, descending=True).values[:k]
+    assert topk.shape == (k,) and torch.allclose(topk, exp_topk, atol=1e-6)
+    assert bool((topk[:-1] >= topk[1:]).all())                         # descending
+
+
+class _Replay(torch.nn.Module):
+    def __init__(self, logits_seq):
+        super().__init__()
+        self.dummy = torch.nn.Parameter(torch.zeros(1))
+        self.logits_seq, self.k = logits_seq, 0
+
+    def forward(self, x, sigma):
+        lg = self.logits_seq[self.k % len(self.logits_seq)]
+        self.k += 1
+        return torch.from_numpy(np.ascontiguousarray(np.swapaxes(lg, 1, 2))).to(x.device).transpose(1, 2)
+
+
+def _replay_model(g):
+    from svdd_amd.config import Config, ModelConfig, SamplingConfig
+    from svdd_amd.diffusion import Diffusion
+    cfg = Config(model=ModelConfig(hidden_dim=16, num_cnn_stacks=1, length=int(g["L"])),
+                 sampling=SamplingConfig(steps=int(g["S"])))
+    return Diffusion(cfg, backbone=_Replay(g["logits"])).to(DEV).eval()
+
+
+def test_sample_returns_the_references_intermediate_states(golden):
+    """`_sample` (reference :820-886) = decode_sample + the S - 1 intermediate states: on the reference's recorded
+    un-guided run (g10: logits of every step, mt19937 seed) both the states and x_0 are the reference's."""
+    g = golden("g10_decode_sample.npz")
+    S, B = int(g["S"]), int(g["B"])
+    d = _replay_model(g)
+    torch.manual_seed(int(g["seed"]))
+    x0, mid = d._sample(eval_sp_size=B)
+    assert len(mid) == S - 1 and all(m.dtype == torch.int64 for m in mid)
+    for i, m in enumerate(mid):
+        assert np.array_equal(m.cpu().numpy(), g["xs"][i + 1].astype(np.int64)), i
+    assert np.array_equal(x0.cpu().numpy(), g["x0"])
+
+
+def test_presample_builds_the_per_step_eval_sets(golden, small):
+    """BaseModel.__init__'s pre-sampling (reference Enformer.py:135-160): val_batch_num un-guided `_sample` runs; the
+    one-hot states of step j of all runs are concatenated into eval_time_step_batches[j], each paired with the reward of
+    the run's final sample."""
+    from svdd_amd.harness import BaseModel
+    g = golden("g10_decode_sample.npz")
+    S, B, L = int(g["S"]), int(g["B"]), int(g["L"])
+    _, emb, head, reward = small
+    d = _replay_model(g)
+    torch.manual_seed(int(g["seed"]))
+    hm = BaseModel(emb, head, d, reward, batch_size=B, task="rna", val_batch_num=1)
+    assert len(hm.eval_time_step_batches) == S and len(hm.eval_time_step_targets) == S
+    with torch.no_grad():
+        target = reward(_onehot(torch.from_numpy(g["x0"]).to(DEV)).transpose(1, 2))[:, 0]
+    for jstep in range(S):
+        states = g["xs"][jstep + 1].astype(np.int64) if jstep < S - 1 else g["x0"]
+        exp = _onehot(torch.from_numpy(states).to(DEV)).long()
+        assert torch.equal(hm.eval_time_step_batches[jstep], exp), jstep
+        assert torch.allclose(hm.eval_time_step_targets[jstep], target, atol=1e-6)
+
+
+def test_sharded_decode_equals_unsharded_with_the_fused_nets():
+    """SURVEY.md section 8e on one GPU: a config-2-shaped decode of 2 b rows as ONE batch equals the same rows decoded as
+    two shards of b rows through distributed.sharded_sample (Philox keyed by the global row) — token-exact, with the
+    real fused nets (one-launch backbone, parent-sharing tower, GRU, tail), in fp32 and in a split-precision mode."""
+    from svdd_amd import distributed, synthetic
+    model, emb, head, _ = synthetic.build("dna", DEV)
+    model.rng_mode, model.philox_seed = "philox", 123
+    total, M, S = 96, 10, 128
+    for precision in ("f32", "f16x3"):
+        model.precision = precision
+        sampler = lambda **kw: model.controlled_sample(emb, head, num_steps=S, sample_M=M, **kw)   # noqa: E731
+        whole = distributed.sharded_sample(model, total, sampler, rank=0, world=1)
+        parts = [distributed.sharded_sample(model, total, sampler, rank=r, world=2) for r in range(2)]
+        ragged = [distributed.sharded_sample(model, total, sampler, rank=r, world=5) for r in range(5)]
+        assert whole.shape == (total, 200) and int(whole.max()) <= 3
+        assert torch.equal(torch.cat(parts), whole)
+        assert torch.equal(torch.cat(ragged), whole)                  # 96 rows over 5 ranks: 20,19,19,19,19
+    model.precision = "f32"
+    assert model.row_offset == 0
