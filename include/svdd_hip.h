@@ -120,7 +120,7 @@ int svdd_select(const float* scores, const uint8_t* cand, int B, int L, int M, i
  * svdd_x0hat — SVDD-PM / TDS posterior-mean candidate (Tweedie):
  *   forward()'s _subs_parameterization + argmax(dim=2) + one_hot + keep-unmasked merge +
  *   .float().transpose(1,2)                         diffusion_gosai.py:1415-1419,1430 ; :1263-1269
- *  logits [R,L,5] raw backbone output for tokens xt [R,L] ; out onehot_t [R,4,L] fp32 ;
+ *  logits [R,L,5] raw backbone output for tokens xt [R,L] ; out onehot_t [R,4,L] fp32 (may be NULL when x0hat is given) ;
  *  x0hat [R,L] u8 out (may be NULL).
  */
 int svdd_x0hat(const float* logits, const uint8_t* xt, int R, int L, int layout,
@@ -151,6 +151,30 @@ int svdd_subs_logp(const float* logits, const uint8_t* x, int B, int L, int layo
                    void* stream);
 
 /*
+ * Exact work-skipping. A candidate that unmasked nothing is a copy of its parent x_t
+ * (diffusion_gosai.py:1203), and with time_conditioning off (:334-335) every net output for it equals the parent's; a
+ * row whose selected candidate is such a copy keeps its logits. The helpers below let the engine run the nets only on
+ * the LIVE candidates / rows without a host round trip: the compacted index list and its length stay in device memory
+ * and the net kernels take the length as a device pointer (`count` arguments below).
+ *
+ * svdd_compact_flags — stable compaction of n flags (one workgroup): flags[i] != 0 -> live_idx[k] = i, slot[i] = k with
+ *   k = number of live items before i; else slot[i] = -1; count[0] = number of live items.
+ * svdd_gather_rows   — dst[i,:] = src[idx[i],:] for i < count[0] (count may be NULL = n); rows of row_bytes bytes.
+ * svdd_advance_rows  — the selected candidate becomes the next parent: for every b, if slot[b*M + sel[b]] >= 0 then
+ *   dst[b,:] = src[slot[...],:], else dst[b] is left untouched; rows of row_bytes (multiple of 4).
+ * svdd_select_compact — svdd_select on compacted scores: candidate (b, m) has score scores[slot[b*M+m]] if its slot is
+ *   >= 0, else parent_score[b]. Additionally writes sel_score[b] (the selected candidate's score = the NEXT step's
+ *   parent score) and changed[b] (1 iff x_next[b] differs from x[b]). slot == NULL: exactly svdd_select.
+ */
+int svdd_compact_flags(const int32_t* flags, int n, int32_t* live_idx, int32_t* slot, int32_t* count, void* stream);
+int svdd_gather_rows(const void* src, const int32_t* idx, const int32_t* count, int n, int row_bytes, void* dst, void* stream);
+int svdd_advance_rows(const void* src, const int32_t* slot, const int32_t* sel, int B, int M, int row_bytes, void* dst,
+                      void* stream);
+int svdd_select_compact(const float* scores, const int32_t* slot, const float* parent_score, const uint8_t* cand, int B,
+                        int L, int M, int mode, const svdd_rng_t* rng, uint8_t* x_next, float* soft, int32_t* idx,
+                        float* sel_score, int32_t* changed, void* stream);
+
+/*
  * svdd_tds_resample — SMC/TDS baseline resampling step
  *   ratio = exp(fl32(1.0/alpha) * (num-den)); p = ratio/ratio.sum(); idx = np.random.choice(B,B,p=p);
  *   (alpha is the caller's Python float, i.e. a double: the reference rounds the double quotient 1.0/alpha to fp32 once)
@@ -171,9 +195,11 @@ int svdd_tds_resample(const float* reward_num, const float* reward_den, double a
  * svdd_gru_bidir_f32 — bidirectional single-layer GRU, input = hidden = 64, fp32
  *   (reference Enformer.py:1595-1602 nn.GRU(64, 64, bidirectional=True, batch_first=True), gate order r,z,n).
  *   x [n,L,64] ; out [2,n,L,64] = per-direction hidden states (the caller sums them, Enformer.py:1617).
- *   wpack [2][4][64][96], bpack [2][4][64]: weights repacked per MFMA lane, see svdd_amd/fused.py:pack_gru. */
+ *   wpack [2][4][64][96], bpack [2][4][64]: weights repacked per MFMA lane, see svdd_amd/fused.py:pack_gru.
+ *   `count` arguments of the net kernels: device scalar with the number of VALID rows of a compacted batch (the tensors
+ *   stay laid out for n rows); NULL = n. See "Exact work-skipping" above. */
 int svdd_gru_bidir_f32(const float* x, const float* wpack, const float* bpack, float* out, int n, int L,
-                       void* stream);
+                       const int32_t* count, void* stream);
 /* svdd_value_tail_f32 — everything of the ConvGRU value net after the GRU, in one pass over the two GRU outputs:
  *   out[n][t] = b_eff[t] + mean_l sum_c w_eff[c][t] * relu(b1'[c] + sum_k W1'[c][k] * norm(h_fwd + h_bwd)[n][l][k])
  *   norm = LayerNorm over the 64 channels WITHOUT affine (eps 1e-5); the caller folds the LayerNorm affine into the
@@ -183,7 +209,8 @@ int svdd_gru_bidir_f32(const float* x, const float* wpack, const float* bpack, f
  *   W1'[16 ct + j][16 (s / 4) + 4 g + s % 4] at 16 ct + s (svdd_amd/fused.py:pack_tail) ; b1 = b1' [128] ;
  *   w_eff [128][n_tasks] = (W_head W_2)^T, b_eff [n_tasks] = W_head b_2 + b_head ; out [n][n_tasks] ; n_tasks <= 4. */
 int svdd_value_tail_f32(const float* h_fwd, const float* h_bwd, const float* w1pack, const float* b1,
-                        const float* w_eff, const float* b_eff, float* out, int n, int L, int n_tasks, void* stream);
+                        const float* w_eff, const float* b_eff, float* out, int n, int L, int n_tasks,
+                        const int32_t* count, void* stream);
 /* tests / experiments: 2 selects the both-directions-per-workgroup scheduling (balanced but measured slower), else default */
 int svdd_gru_set_mode(int mode);
 
@@ -219,7 +246,7 @@ int svdd_conv1d_set_dynamic(int on);
  *   onehot [n,L,4] ; tiles [2 + 10*nlayers][64][32] weight tiles in execution order (svdd_amd/fused.py:pack_tower) ;
  *   bias [1 + nlayers][64] ; out [n,L,64] ; residual_mask bit k = layer k adds its input ; L <= 208. */
 int svdd_conv_tower_f32(const float* onehot, const float* tiles, const float* bias, float* out, int n, int L,
-                        int nlayers, int residual_mask, void* stream);
+                        int nlayers, int residual_mask, const int32_t* count, void* stream);
 
 /* svdd_candidate_windows + svdd_conv_tower_windows_f32 — the conv tower on the M candidates of every sample, sharing
  *   the work they have in common with their parent x_t (SVDD-MC scoring, reference diffusion_gosai.py:1203-1209: the
@@ -230,12 +257,15 @@ int svdd_conv_tower_f32(const float* onehot, const float* tiles, const float* bi
  *   svdd_candidate_windows: cand [B,M,L] u8, x [B,L] u8 -> win [B*M][2] = (w0, w1), multiples of 16 covering the
  *     positions where the candidate differs from its parent +- margin (27 for the 5-layer tower); (0, 0) if none.
  *   svdd_conv_tower_windows_f32: onehot [n = B*M, L, 4] (row b*M + m), win from above, parent_out [B, L, 64] =
- *     svdd_conv_tower_f32 of the parents' one-hot; out [n, L, 64]. 104 < L <= 208, nlayers = 5. */
+ *     svdd_conv_tower_f32 of the parents' one-hot; out [n, L, 64]. 104 < L <= 208, nlayers = 5.
+ *   flags [B*M] (may be NULL): 1 if the candidate differs from its parent, 0 for an exact copy (input of
+ *     svdd_compact_flags). live_idx / count (may be NULL): process only the listed candidates; workgroup i handles
+ *     candidate live_idx[i] and writes rows [i*L, (i+1)*L) of out (a compacted batch). */
 int svdd_candidate_windows(const uint8_t* cand, const uint8_t* x, int B, int L, int M, int margin, int32_t* win,
-                           void* stream);
+                           int32_t* flags, void* stream);
 int svdd_conv_tower_windows_f32(const float* onehot, const float* tiles, const float* bias, const int32_t* win,
                                 const float* parent_out, float* out, int n, int L, int M, int nlayers,
-                                int residual_mask, void* stream);
+                                int residual_mask, const int32_t* live_idx, const int32_t* count, void* stream);
 
 /* svdd_backbone_cnn_f32 — the whole dilated-CNN masked-diffusion backbone at sigma = 0 in ONE launch
  *   (reference models/dnaconv.py:176-210 as called from diffusion_gosai.py:334-340): one-hot + 9-tap first conv,
@@ -245,10 +275,14 @@ int svdd_conv_tower_windows_f32(const float* onehot, const float* tiles, const f
  *   x [n,L] u8 tokens ; table0 [9][5][128] = W_first[co][c][t] ; tiles [nlayers][4][9][128][32] = W_i[co][32c+k][t]
  *   followed by [4][128][32] = W_f1[co][32c+k] ; vec [nlayers+2][4][128]: row 0 = {b_first}, row 1+i = {b_i, tb_i,
  *   gamma_i, beta_i}, row nlayers+1 = {b_f1} ; w2 [5][128] then b2 [5] ; dilations: HOST int[nlayers] ;
- *   out [n,L,5] raw logits (layout BLV).  Packing: svdd_amd/fused.py:pack_backbone. */
+ *   out [n,L,5] raw logits (layout BLV).  Packing: svdd_amd/fused.py:pack_backbone.
+ *   Exact work-skipping: count (device scalar, NULL = n) limits the forward to the first count[0] compact rows; row_idx
+ *   (NULL = identity) makes compact row r read the tokens of sequence row_idx[r] of x, and with out_scatter != 0 write
+ *   its logits to row row_idx[r] of out (per-row logits cache: only the rows that changed are recomputed, in place)
+ *   instead of row r (candidate compaction). A row's logits are the same bits wherever it is evaluated. */
 int svdd_backbone_cnn_f32(const uint8_t* x, const float* table0, const float* tiles, const float* vec,
                           const float* w2, float* out, int n, int L, int nlayers, const int* dilations,
-                          void* stream);
+                          const int32_t* count, const int32_t* row_idx, int out_scatter, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Split-precision net kernels (svdd_amd/csrc/svdd_lp_*.hip) — the same functions as the *_f32 net kernels above
@@ -268,7 +302,8 @@ enum { SVDD_PREC_F32 = 0, SVDD_PREC_F16X3 = 1, SVDD_PREC_BF16X3 = 2, SVDD_PREC_F
  *   (1 for bf16).  Packing: svdd_amd/fused.py:pack_backbone_lp. */
 int svdd_backbone_cnn_lp(const uint8_t* x, const float* table0, const void* tiles, const float* vec,
                          const float* lscale, const float* w2, float* out, int n, int L, int nlayers,
-                         const int* dilations, int prec, void* stream);
+                         const int* dilations, int prec, const int32_t* count, const int32_t* row_idx, int out_scatter,
+                         void* stream);
 
 /* svdd_conv_tower_lp / svdd_conv_tower_windows_lp — svdd_conv_tower_f32 / svdd_conv_tower_windows_f32 on the 16-bit
  *   matrix cores. The input is the TOKEN tensor (u8, 4 = MASK -> zero one-hot row; reference transform_samples,
@@ -282,7 +317,7 @@ int svdd_backbone_cnn_lp(const uint8_t* x, const float* table0, const void* tile
  *   NULL = n) how many — workgroup i handles candidate live_idx[i] and writes rows [i*L, (i+1)*L) of `out`, so a
  *   compacted batch needs no host round trip (exact work-skipping). Packing: svdd_amd/fused.py:pack_tower_lp. */
 int svdd_conv_tower_lp(const uint8_t* tok, const void* tiles, const float* bias, const float* inv, void* out,
-                       int n, int L, int nlayers, int residual_mask, int prec, void* stream);
+                       int n, int L, int nlayers, int residual_mask, const int32_t* count, int prec, void* stream);
 int svdd_conv_tower_windows_lp(const uint8_t* cand, const void* tiles, const float* bias, const float* inv,
                                const int32_t* win, const void* parent_out, void* out, int n, int L, int M,
                                int nlayers, int residual_mask, const int32_t* live_idx, const int32_t* count,

@@ -30,6 +30,7 @@ EXPORTS = (
     "svdd_conv1d_set_dynamic", "svdd_gru_set_mode", "svdd_conv_tower_f32", "svdd_backbone_cnn_f32", "svdd_value_tail_f32",
     "svdd_candidate_windows", "svdd_conv_tower_windows_f32", "svdd_k1_stats",
     "svdd_backbone_cnn_lp", "svdd_conv_tower_lp", "svdd_conv_tower_windows_lp", "svdd_gru_bidir_lp", "svdd_value_tail_lp",
+    "svdd_compact_flags", "svdd_gather_rows", "svdd_advance_rows", "svdd_select_compact",
 )
 OPT_FORCE_EXACT = 0
 
@@ -89,22 +90,26 @@ def lib():
     L.svdd_tds_resample.argtypes = [vp, vp, ctypes.c_double, vp, vp, i32, i32, vp, vp, vp, vp]
     L.svdd_set_option.argtypes = [i32, i32]
     L.svdd_selftest_fastmath.argtypes = [ctypes.POINTER(ctypes.c_double)]
-    L.svdd_gru_bidir_f32.argtypes = [vp, vp, vp, vp, i32, i32, vp]
+    L.svdd_gru_bidir_f32.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp]
     L.svdd_conv1d_set_dynamic.argtypes = [i32]
     L.svdd_gru_set_mode.argtypes = [i32]
-    L.svdd_conv_tower_f32.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp]
-    L.svdd_value_tail_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]
-    L.svdd_candidate_windows.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp]
-    L.svdd_conv_tower_windows_f32.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
-    L.svdd_backbone_cnn_f32.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, ctypes.POINTER(ctypes.c_int), vp]
+    L.svdd_conv_tower_f32.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]
+    L.svdd_value_tail_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp]
+    L.svdd_candidate_windows.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp]
+    L.svdd_conv_tower_windows_f32.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]
+    L.svdd_backbone_cnn_f32.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, ctypes.POINTER(ctypes.c_int), vp, vp, i32, vp]
     L.svdd_conv1d_cl_f32.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp]
     L.svdd_epilogue_ln_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_int64, i32, i32, vp]
     L.svdd_k1_stats.argtypes = [vp]
-    L.svdd_conv_tower_lp.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
+    L.svdd_compact_flags.argtypes = [vp, i32, vp, vp, vp, vp]
+    L.svdd_gather_rows.argtypes = [vp, vp, vp, i32, i32, vp, vp]
+    L.svdd_advance_rows.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp]
+    L.svdd_select_compact.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, ctypes.POINTER(SvddRng), vp, vp, vp, vp, vp, vp]
+    L.svdd_conv_tower_lp.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, i32, vp]
     L.svdd_conv_tower_windows_lp.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp]
     L.svdd_gru_bidir_lp.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, vp, i32, vp]
     L.svdd_value_tail_lp.argtypes = [vp, vp, vp, vp, vp, vp, f32, vp, i32, i32, i32, vp, i32, vp]
-    L.svdd_backbone_cnn_lp.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, ctypes.POINTER(ctypes.c_int), i32, vp]
+    L.svdd_backbone_cnn_lp.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, ctypes.POINTER(ctypes.c_int), i32, vp, vp, i32, vp]
     L.svdd_profile_enable.argtypes = [i32]
     L.svdd_profile_collect.argtypes = [i32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]
     L.svdd_device_info.argtypes = [ctypes.c_char_p, i32, ctypes.POINTER(ctypes.c_int)]

@@ -299,6 +299,9 @@ struct SelectArgs {
   const float* scores; const uint8_t* cand; int B, L, M, mode;
   uint32_t step; uint64_t seed, row_offset;
   uint8_t* x_next; float* soft; int32_t* idx;
+  // exact work-skipping (svdd_select_compact): scores holds only the LIVE candidates, slot[b*M + m] is a candidate's
+  // position in it or -1 for a candidate that is a copy of its parent (its score is the parent's)
+  const int32_t* slot; const float* parent_score; float* sel_score; int32_t* changed;
 };
 
 __device__ __forceinline__ float wave_max(float v) {
@@ -322,7 +325,12 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
 #pragma unroll
   for (int c = 0; c < MAX_CHUNKS; ++c) {
     const int m = c * WAVE + lane;
-    e[c] = (c < nchunk && m < a.M) ? s[m] : -INFINITY;
+    float sv = -INFINITY;
+    if (c < nchunk && m < a.M) {
+      if (a.slot) { const int sl = a.slot[(int64_t)row * a.M + m]; sv = sl >= 0 ? a.scores[sl] : a.parent_score[row]; }
+      else sv = s[m];
+    }
+    e[c] = sv;
     mx = e[c] > mx ? e[c] : mx;
   }
   mx = wave_max(mx);
@@ -406,6 +414,11 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
     }
   }
   if (a.idx && lane == 0) a.idx[row] = best;
+  if (a.slot && lane == 0) {
+    const int sl = a.slot[(int64_t)row * a.M + best];
+    if (a.sel_score) a.sel_score[row] = sl >= 0 ? a.scores[sl] : a.parent_score[row];   // the next step's parent score
+    if (a.changed) a.changed[row] = sl >= 0 ? 1 : 0;                                      // x_next != x
+  }
 
   // gather the winning candidate row (index-gather compaction, diffusion_gosai.py:1226-1227)
   const uint8_t* src = a.cand + ((int64_t)row * a.M + best) * a.L;
@@ -442,8 +455,10 @@ __global__ __launch_bounds__(256) void x0hat_kernel(PosArgs a) {
     c = best;
   }
   if (a.out_u8) a.out_u8[n] = (uint8_t)c;
+  if (a.out_f) {
 #pragma unroll
-  for (int v = 0; v < 4; ++v) a.out_f[(r * 4 + v) * a.L + l] = (c == v) ? 1.0f : 0.0f;
+    for (int v = 0; v < 4; ++v) a.out_f[(r * 4 + v) * a.L + l] = (c == v) ? 1.0f : 0.0f;
+  }
 }
 
 __global__ __launch_bounds__(256) void finalize_kernel(PosArgs a) {
@@ -569,6 +584,76 @@ __global__ __launch_bounds__(1024) void tds_resample_kernel(TdsArgs a) {
     const int k = lo < a.B ? lo : a.B - 1;
     if (a.idx && lane == 0) a.idx[j] = k;
     for (int i = lane; i < a.L; i += WAVE) a.x_next[(int64_t)j * a.L + i] = a.sample[(int64_t)k * a.L + i];
+  }
+}
+
+// ---------------------------------------------------------------- exact work-skipping: compaction helpers ----
+// A candidate that unmasked nothing IS its parent (diffusion_gosai.py:1203 copies x_t where nothing is drawn), and with
+// time_conditioning off (:334-335) every net output for it is the parent's. The engine therefore evaluates the nets only
+// on the LIVE candidates / rows. The compaction runs on the device (flags -> stable prefix scan -> index list + count in
+// device memory) and every consumer kernel reads the count from there: no host round trip inside the diffusion loop.
+//   flags[i] != 0 -> live_idx[k] = i, slot[i] = k (k = number of live items before i) ; else slot[i] = -1 ; count[0] = #live
+__global__ __launch_bounds__(1024) void compact_flags_kernel(const int32_t* __restrict__ flags, int n, int32_t* __restrict__ live_idx,
+                                                             int32_t* __restrict__ slot, int32_t* __restrict__ count) {
+  __shared__ int wave_tot[16];
+  __shared__ int base_s;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (threadIdx.x == 0) base_s = 0;
+  __syncthreads();
+  for (int i0 = 0; i0 < n; i0 += 1024) {
+    const int i = i0 + threadIdx.x;
+    const bool live = i < n && flags[i] != 0;
+    const unsigned long long m = __ballot(live);
+    const int before = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_tot[w] = __popcll(m);
+    __syncthreads();
+    int off = base_s;
+    for (int k = 0; k < w; ++k) off += wave_tot[k];
+    if (i < n) {
+      if (live) { live_idx[off + before] = i; slot[i] = off + before; }
+      else slot[i] = -1;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { int t = 0; for (int k = 0; k < 16; ++k) t += wave_tot[k]; base_s += t; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) count[0] = base_s;
+}
+
+// dst[i, :] = src[idx[i], :] for i < count : rows of `row_bytes` bytes, one wave per row
+__global__ __launch_bounds__(256) void gather_rows_kernel(const uint8_t* __restrict__ src, const int32_t* __restrict__ idx,
+                                                          const int32_t* __restrict__ count, int n, int row_bytes,
+                                                          uint8_t* __restrict__ dst) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= n || (count && r >= *count)) return;
+  const int lane = threadIdx.x & 63;
+  const uint8_t* s = src + (size_t)idx[r] * row_bytes;
+  uint8_t* d = dst + (size_t)r * row_bytes;
+  if ((row_bytes & 3) == 0) {
+    const uint32_t* s4 = reinterpret_cast<const uint32_t*>(s);
+    uint32_t* d4 = reinterpret_cast<uint32_t*>(d);
+    for (int i = lane; i < (row_bytes >> 2); i += WAVE) d4[i] = s4[i];
+  } else {
+    for (int i = lane; i < row_bytes; i += WAVE) d[i] = s[i];
+  }
+}
+
+// The selected candidate becomes the next parent: dst[b, :] = src[slot[b*M + sel[b]], :] when that candidate was live
+// (slot >= 0), else dst[b] is left as it is (the parent did not change). Rows of `row_bytes` bytes (multiple of 16).
+__global__ __launch_bounds__(256) void advance_rows_kernel(const uint8_t* __restrict__ src, const int32_t* __restrict__ slot,
+                                                           const int32_t* __restrict__ sel, int B, int M, int row_bytes,
+                                                           uint8_t* __restrict__ dst) {
+  const int b = blockIdx.x;
+  const int sl = slot[(size_t)b * M + sel[b]];
+  if (sl < 0) return;
+  if ((row_bytes & 15) == 0) {
+    const uint4* s16 = reinterpret_cast<const uint4*>(src + (size_t)sl * row_bytes);
+    uint4* d16 = reinterpret_cast<uint4*>(dst + (size_t)b * row_bytes);
+    for (int i = threadIdx.x; i < (row_bytes >> 4); i += 256) d16[i] = s16[i];
+  } else {
+    const uint32_t* s4 = reinterpret_cast<const uint32_t*>(src + (size_t)sl * row_bytes);
+    uint32_t* d4 = reinterpret_cast<uint32_t*>(dst + (size_t)b * row_bytes);
+    for (int i = threadIdx.x; i < (row_bytes >> 2); i += 256) d4[i] = s4[i];
   }
 }
 
@@ -724,14 +809,42 @@ static int launch_propose(bool q_given, const float* logits, const uint8_t* x, f
 
 int svdd_select(const float* scores, const uint8_t* cand, int B, int L, int M, int mode, const svdd_rng_t* rng,
                 uint8_t* x_next, float* soft, int32_t* idx, void* stream) {
+  return svdd_select_compact(scores, nullptr, nullptr, cand, B, L, M, mode, rng, x_next, soft, idx, nullptr, nullptr, stream);
+}
+
+int svdd_select_compact(const float* scores, const int32_t* slot, const float* parent_score, const uint8_t* cand, int B,
+                        int L, int M, int mode, const svdd_rng_t* rng, uint8_t* x_next, float* soft, int32_t* idx,
+                        float* sel_score, int32_t* changed, void* stream) {
   if (!scores || !cand || !x_next || B <= 0 || L <= 0 || M <= 0 || M > SVDD_MAX_M) return SVDD_E_ARG;
   if (mode != SVDD_SELECT_ARGMAX && mode != SVDD_SELECT_MULTINOMIAL) return SVDD_E_ARG;
   if (mode == SVDD_SELECT_MULTINOMIAL && (!rng || rng->kind != SVDD_RNG_PHILOX)) return SVDD_E_ARG;
+  if (slot && !parent_score) return SVDD_E_ARG;
   SelectArgs a{scores, cand, B, L, M, mode, rng ? rng->step : 0u, rng ? rng->seed : 0ull,
-               rng ? rng->row_offset : 0ull, x_next, soft, idx};
+               rng ? rng->row_offset : 0ull, x_next, soft, idx, slot, parent_score, sel_score, changed};
   TimedLaunch* t = timed_slot(1);
   hipExtLaunchKernelGGL(select_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                         t ? t->start : nullptr, t ? t->stop : nullptr, 0, a);
+  return check_launch();
+}
+
+int svdd_compact_flags(const int32_t* flags, int n, int32_t* live_idx, int32_t* slot, int32_t* count, void* stream) {
+  if (!flags || !live_idx || !slot || !count || n <= 0) return SVDD_E_ARG;
+  hipLaunchKernelGGL(compact_flags_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, flags, n, live_idx, slot, count);
+  return check_launch();
+}
+
+int svdd_gather_rows(const void* src, const int32_t* idx, const int32_t* count, int n, int row_bytes, void* dst, void* stream) {
+  if (!src || !idx || !dst || n <= 0 || row_bytes <= 0) return SVDD_E_ARG;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                     (const uint8_t*)src, idx, count, n, row_bytes, (uint8_t*)dst);
+  return check_launch();
+}
+
+int svdd_advance_rows(const void* src, const int32_t* slot, const int32_t* sel, int B, int M, int row_bytes, void* dst,
+                      void* stream) {
+  if (!src || !slot || !sel || !dst || B <= 0 || M <= 0 || row_bytes <= 0 || (row_bytes & 3)) return SVDD_E_ARG;
+  hipLaunchKernelGGL(advance_rows_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)src, slot, sel,
+                     B, M, row_bytes, (uint8_t*)dst);
   return check_launch();
 }
 
@@ -743,7 +856,7 @@ static int launch_pos(void (*k)(PosArgs), const PosArgs& a, void* stream) {
 
 int svdd_x0hat(const float* logits, const uint8_t* xt, int R, int L, int layout, float* onehot_t, uint8_t* x0hat,
                void* stream) {
-  if (!logits || !xt || !onehot_t || R <= 0 || L <= 0 || bad_layout(layout)) return SVDD_E_ARG;
+  if (!logits || !xt || (!onehot_t && !x0hat) || R <= 0 || L <= 0 || bad_layout(layout)) return SVDD_E_ARG;
   return launch_pos(x0hat_kernel, PosArgs{logits, xt, R, L, layout, onehot_t, x0hat, nullptr, 1}, stream);
 }
 

@@ -26,6 +26,9 @@ struct BackboneLpArgs {
   float* out;              // [n, L, 5]
   int n, L, spt, nl;
   int dil[BB_MAXL];
+  const int* count;        // device scalar: valid rows (NULL: n) — exact work-skipping on a compacted batch
+  const int* row_idx;      // [count] (NULL: identity): compact row r reads the tokens of sequence row_idx[r] of x ...
+  int out_scatter;         // ... and writes its logits to row row_idx[r] of out (1) or to row r (0)
 };
 
 template <typename T, int NP, bool SPT1>
@@ -52,13 +55,19 @@ __global__ __launch_bounds__(512, 2) void backbone_lp_kernel(BackboneLpArgs a) {
   const int L = a.L;
   const int tile_rows = a.spt * L;
   const int64_t row0 = (int64_t)blockIdx.x * tile_rows;
-  const int64_t total_rows = (int64_t)a.n * L;
+  const int64_t total_rows = (int64_t)(a.count ? __builtin_amdgcn_readfirstlane(*a.count) : a.n) * L;
+  if (row0 >= total_rows) return;
   const int nl = a.nl;
   const int it_end = (nl + 1) * 36;
   constexpr int NR = 7;
 
   for (int e = tid; e < TW_ROWS; e += 512) {
-    toks[e] = (e < tile_rows && row0 + e < total_rows) ? a.x[row0 + e] : -1;
+    int tk = -1;
+    if (e < tile_rows && row0 + e < total_rows) {
+      if (a.row_idx) { const int sq = e / L; tk = a.x[(int64_t)a.row_idx[blockIdx.x * a.spt + sq] * L + (e - sq * L)]; }
+      else tk = a.x[row0 + e];
+    }
+    toks[e] = tk;
     rpos[e] = e < tile_rows ? e % L : -(1 << 20);
   }
   // zero rows -1 and TW_ROWS of both planes (a tap that leaves the sequence reads them)
@@ -320,7 +329,8 @@ __global__ __launch_bounds__(512, 2) void backbone_lp_kernel(BackboneLpArgs a) {
     float sm = a.w2[5 * BB_C + v];
 #pragma unroll 8
     for (int k = 0; k < BB_C; ++k) sm += hr[k] * wv[k];
-    a.out[(row0 + row) * 5 + v] = sm;
+    if (a.row_idx && a.out_scatter) { const int sq = row / L; a.out[((int64_t)a.row_idx[blockIdx.x * a.spt + sq] * L + (row - sq * L)) * 5 + v] = sm; }
+    else a.out[(row0 + row) * 5 + v] = sm;
   }
 }
 
@@ -329,13 +339,14 @@ __global__ __launch_bounds__(512, 2) void backbone_lp_kernel(BackboneLpArgs a) {
 
 extern "C" int svdd_backbone_cnn_lp(const uint8_t* x, const float* table0, const void* tiles, const float* vec,
                                     const float* lscale, const float* w2, float* out, int n, int L, int nlayers,
-                                    const int* dilations, int prec, void* stream) {
+                                    const int* dilations, int prec, const int32_t* count, const int32_t* row_idx,
+                                    int out_scatter, void* stream) {
   if (!x || !table0 || !tiles || !vec || !lscale || !w2 || !out || !dilations || n <= 0 || L <= 0 || L > TW_ROWS ||
       nlayers <= 0 || nlayers > BB_MAXL || prec < SVDD_PREC_F16X3 || prec > SVDD_PREC_BF16)
     return SVDD_E_ARG;
   BackboneLpArgs a;
   a.x = x; a.table0 = table0; a.tiles = tiles; a.vec = vec; a.lscale = lscale; a.w2 = w2; a.out = out;
-  a.n = n; a.L = L; a.spt = TW_ROWS / L; a.nl = nlayers;
+  a.n = n; a.L = L; a.spt = TW_ROWS / L; a.nl = nlayers; a.count = count; a.row_idx = row_idx; a.out_scatter = out_scatter;
   for (int i = 0; i < nlayers; ++i) if (dilations[i] <= 0) return SVDD_E_ARG;
   for (int i = 0; i < BB_MAXL; ++i) a.dil[i] = i < nlayers ? dilations[i] : 1;
   const size_t lds = (size_t)IMG_REGION_B + sizeof(float) * (9 * 5 * (size_t)BB_C + 4 * (size_t)TW_ROWS + 3 * (size_t)TW_ROWS +

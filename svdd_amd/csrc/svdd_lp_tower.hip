@@ -191,7 +191,8 @@ __global__ __launch_bounds__(512, 4) void tower_lp_kernel(TowerLpArgs a) {
   const int nt = (w1 - w0) >> 4;
   const int tile_rows = WIN ? min(L, w1) - w0 : a.spt * L;       // valid local rows
   const int64_t row0 = WIN ? 0 : (int64_t)blockIdx.x * tile_rows;
-  const int64_t total_rows = (int64_t)a.n * L;
+  const int64_t total_rows = (int64_t)((!WIN && a.count) ? __builtin_amdgcn_readfirstlane(*a.count) : a.n) * L;
+  if (!WIN && row0 >= total_rows) return;
   const int keep_lo = !WIN ? 0 : (nt == 0 ? 0 : (w0 == 0 ? 0 : w0 + 10));
   const int keep_hi = !WIN ? 0 : (nt == 0 ? 0 : (w1 >= L ? L : w1 - 10));
   constexpr int ROW16 = NPARTS * 8;                              // 16-byte pieces per output row
@@ -286,12 +287,12 @@ static int launch_tower_lp(const TowerLpArgs& a, bool win, int prec, unsigned gr
 }
 
 extern "C" int svdd_conv_tower_lp(const uint8_t* tok, const void* tiles, const float* bias, const float* inv, void* out,
-                                  int n, int L, int nlayers, int residual_mask, int prec, void* stream) {
+                                  int n, int L, int nlayers, int residual_mask, const int32_t* count, int prec, void* stream) {
   if (!tok || !tiles || !bias || !inv || !out || n <= 0 || L <= 0 || L > TW_ROWS || nlayers <= 0 || nlayers > TW_MAXL ||
       prec < SVDD_PREC_F16X3 || prec > SVDD_PREC_BF16)
     return SVDD_E_ARG;
   const int spt = TW_ROWS / L;
-  TowerLpArgs a{tok, tiles, bias, inv, out, n, L, spt, nlayers, residual_mask, nullptr, nullptr, 1, nullptr, nullptr};
+  TowerLpArgs a{tok, tiles, bias, inv, out, n, L, spt, nlayers, residual_mask, nullptr, nullptr, 1, nullptr, count};
   return launch_tower_lp(a, false, prec, (unsigned)((n + spt - 1) / spt), stream);
 }
 

@@ -55,7 +55,7 @@ __device__ __forceinline__ float tanh_fast(float a) {
 template <bool BOTH>
 __global__ __launch_bounds__(BOTH ? 512 : 256) void gru_bidir_kernel(const float* __restrict__ x, const float* __restrict__ wpack,
                                                                      const float* __restrict__ bpack, float* __restrict__ out,
-                                                                     int n, int L, int ts) {
+                                                                     int n_alloc, int L, int ts, const int* __restrict__ count) {
   __shared__ __attribute__((aligned(16))) float hbuf_all[BOTH ? 2 : 1][2][TS][HPAD];
   const int lane = threadIdx.x & 63;
   const int w = (threadIdx.x >> 6) & 3;
@@ -64,6 +64,9 @@ __global__ __launch_bounds__(BOTH ? 512 : 256) void gru_bidir_kernel(const float
   const int j = lane & 15;            // hidden unit within the wave's 16 / sequence row for A operands
   const int g = lane >> 4;            // k-group of A/B operands ; row-group of C/D
   const int seq0 = blockIdx.x * ts;
+  // n_alloc: rows the output tensor is laid out for ; n: valid rows (device scalar when the batch was compacted)
+  const int n = count ? __builtin_amdgcn_readfirstlane(*count) : n_alloc;
+  if (seq0 >= n) return;
 
   // B operands: this lane's 96 weights stay in registers for the whole sequence
   float wr[96];
@@ -139,7 +142,7 @@ __global__ __launch_bounds__(BOTH ? 512 : 256) void gru_bidir_kernel(const float
       hprev[rho] = hn;
       const int srow = 4 * g + rho;
       hbuf[cur ^ 1][srow][u] = hn;
-      if (srow < ts && seq0 + srow < n) out[(((size_t)dir * n + seq0 + srow) * L + t) * H + u] = hn;
+      if (srow < ts && seq0 + srow < n) out[(((size_t)dir * n_alloc + seq0 + srow) * L + t) * H + u] = hn;
     }
     // next step's input projections (independent of the barrier below)
     acc_r = f32x4{b_r, b_r, b_r, b_r}; acc_z = f32x4{b_z, b_z, b_z, b_z}; acc_nx = f32x4{b_nx, b_nx, b_nx, b_nx};
@@ -663,6 +666,7 @@ struct TowerArgs {
   const float* bias;     // [1 + nlayers][64]   stem bias, then the (BatchNorm-folded) layer biases
   float* out;            // [n, L, 64]
   int n, L, spt, nlayers, residual_mask;
+  const int* count;      // device scalar: valid rows of a compacted batch (NULL: n) ; conv_tower_kernel only
 };
 
 // One LDS activation image only: a layer's outputs wait in the accumulators until every wave has finished reading
@@ -687,7 +691,8 @@ __global__ __launch_bounds__(512, 4) void conv_tower_kernel(TowerArgs a) {
   const int L = a.L;
   const int tile_rows = a.spt * L;
   const int64_t row0 = (int64_t)blockIdx.x * tile_rows;
-  const int64_t total_rows = (int64_t)a.n * L;
+  const int64_t total_rows = (int64_t)(a.count ? __builtin_amdgcn_readfirstlane(*a.count) : a.n) * L;
+  if (row0 >= total_rows) return;
 
   for (int e = tid - 1; e < TW_ROWS + 1; e += 512) {
     float4 v = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -827,6 +832,8 @@ struct TowerWinArgs {
   const int* win;          // [n][2]  (w0, w1) ; w0 == w1: the candidate equals its parent
   const float* parent_out; // [n / M, L, 64]
   int M;
+  const int* live_idx;     // [count] candidate ids to process (NULL: identity); workgroup i writes out[i]
+  const int* count;        // device scalar (NULL: n)
 };
 
 __global__ __launch_bounds__(512, 4) void conv_tower_win_kernel(TowerWinArgs wa) {
@@ -840,14 +847,15 @@ __global__ __launch_bounds__(512, 4) void conv_tower_win_kernel(TowerWinArgs wa)
   const int cs = w & 3, rh = w >> 2;
   const int j = lane & 15, g = lane >> 4;
   const int L = a.L;
-  const int cand = blockIdx.x;
+  if (wa.count && (int)blockIdx.x >= __builtin_amdgcn_readfirstlane(*wa.count)) return;
+  const int cand = wa.live_idx ? __builtin_amdgcn_readfirstlane(wa.live_idx[blockIdx.x]) : (int)blockIdx.x;
   const int w0 = __builtin_amdgcn_readfirstlane(wa.win[2 * cand]);
   const int w1 = __builtin_amdgcn_readfirstlane(wa.win[2 * cand + 1]);
   const int nt = (w1 - w0) >> 4;                        // live row tiles
   const int lrows = min(L, w1) - w0;                    // valid local rows
   const int keep_lo = nt == 0 ? 0 : (w0 == 0 ? 0 : w0 + 10);
   const int keep_hi = nt == 0 ? 0 : (w1 >= L ? L : w1 - 10);
-  float* outc = a.out + (size_t)cand * L * TW_C;
+  float* outc = a.out + (size_t)blockIdx.x * L * TW_C;
   const float* par = wa.parent_out + (size_t)(cand / wa.M) * L * TW_C;
 
   for (int e = tid; e < L * 16; e += 512) {             // rows that are the parent's, straight from its output
@@ -978,7 +986,8 @@ __global__ __launch_bounds__(512, 4) void conv_tower_win_kernel(TowerWinArgs wa)
 
 // (w0, w1) of every candidate: one wave per candidate compares it with its parent.
 __global__ __launch_bounds__(256) void candidate_windows_kernel(const uint8_t* __restrict__ cand, const uint8_t* __restrict__ x,
-                                                               int n, int L, int M, int margin, int* __restrict__ win) {
+                                                               int n, int L, int M, int margin, int* __restrict__ win,
+                                                               int* __restrict__ flags) {
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (c >= n) return;
   const int lane = threadIdx.x & 63;
@@ -996,6 +1005,7 @@ __global__ __launch_bounds__(256) void candidate_windows_kernel(const uint8_t* _
       w1 = min((L + 15) & ~15, (hi + margin + 1 + 15) & ~15);
     }
     win[2 * c] = w0; win[2 * c + 1] = w1;
+    if (flags) flags[c] = hi >= 0 ? 1 : 0;             // 0: the candidate is a copy of its parent
   }
 }
 
@@ -1028,6 +1038,9 @@ struct BackboneArgs {
   float* out;              // [n, L, 5]
   int n, L, spt, nl;
   int dil[BB_MAXL];
+  const int* count;        // device scalar: valid rows (NULL: n) — exact work-skipping on a compacted batch
+  const int* row_idx;      // [count] (NULL: identity): compact row r reads the tokens of sequence row_idx[r] of x ...
+  int out_scatter;         // ... and writes its logits to row row_idx[r] of out (1) or to row r (0)
 };
 
 template <int N>
@@ -1068,13 +1081,19 @@ __global__ __launch_bounds__(512, 2) void backbone_kernel(BackboneArgs a) {
   const int L = a.L;
   const int tile_rows = a.spt * L;
   const int64_t row0 = (int64_t)blockIdx.x * tile_rows;
-  const int64_t total_rows = (int64_t)a.n * L;
+  const int64_t total_rows = (int64_t)(a.count ? __builtin_amdgcn_readfirstlane(*a.count) : a.n) * L;
+  if (row0 >= total_rows) return;
   const int nl = a.nl;
   const int it_end = (nl + 1) * 36;
   constexpr int NR = 7;                                   // owned row tiles rh + 2 r (r = 6 only for rh = 0)
 
   for (int e = tid; e < TW_ROWS; e += 512) {
-    toks[e] = (e < tile_rows && row0 + e < total_rows) ? a.x[row0 + e] : -1;
+    int tk = -1;
+    if (e < tile_rows && row0 + e < total_rows) {
+      if (a.row_idx) { const int sq = e / L; tk = a.x[(int64_t)a.row_idx[blockIdx.x * a.spt + sq] * L + (e - sq * L)]; }
+      else tk = a.x[row0 + e];
+    }
+    toks[e] = tk;
     rpos[e] = e < tile_rows ? e % L : -(1 << 20);
   }
   for (int e = tid; e < BB_AP; e += 512) { smem[e] = 0.0f; img[TW_ROWS * BB_AP + e] = 0.0f; }
@@ -1323,7 +1342,8 @@ __global__ __launch_bounds__(512, 2) void backbone_kernel(BackboneArgs a) {
     float sm = a.w2[5 * BB_C + v];
 #pragma unroll 8
     for (int k = 0; k < BB_C; ++k) sm += hr[k] * wv[k];
-    a.out[(row0 + row) * 5 + v] = sm;
+    if (a.row_idx && a.out_scatter) { const int sq = row / L; a.out[((int64_t)a.row_idx[blockIdx.x * a.spt + sq] * L + (row - sq * L)) * 5 + v] = sm; }
+    else a.out[(row0 + row) * 5 + v] = sm;
   }
 }
 
@@ -1341,9 +1361,11 @@ template <int T>
 __global__ __launch_bounds__(256, 2) void value_tail_kernel(const float* __restrict__ hf, const float* __restrict__ hb,
                                                             const float* __restrict__ w1pack, const float* __restrict__ b1,
                                                             const float* __restrict__ weff, const float* __restrict__ beff,
-                                                            float* __restrict__ out, int n, int L) {
+                                                            float* __restrict__ out, int n_alloc, int L,
+                                                            const int* __restrict__ count) {
   const int lane = threadIdx.x & 63;
   const int seq = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int n = count ? *count : n_alloc;
   if (seq >= n) return;
   const int j = lane & 15, g = lane >> 4;
   // channel of this lane's value i (= MFMA k-step i): ch(i) = 16 (i / 4) + 4 g + (i % 4) — four 16-byte pieces that,
@@ -1430,7 +1452,7 @@ static int g_gru_mode = 0;         // 2 selects the both-directions-per-workgrou
 extern "C" int svdd_gru_set_mode(int mode) { g_gru_mode = mode; return SVDD_OK; }
 
 extern "C" int svdd_gru_bidir_f32(const float* x, const float* wpack, const float* bpack, float* out, int n, int L,
-                                  void* stream) {
+                                  const int32_t* count, void* stream) {
   if (!x || !wpack || !bpack || !out || n <= 0 || L <= 0) return SVDD_E_ARG;
   hipEvent_t e0, e1;
   svdd_internal_timed_events(3, &e0, &e1);
@@ -1438,10 +1460,10 @@ extern "C" int svdd_gru_bidir_f32(const float* x, const float* wpack, const floa
   const int per_cu = (n + 255) / 256;
   if (g_gru_mode == 2 && per_cu <= TS && n >= 256)   // measured slower (841 vs 758 us at n=2560, L=200): opt-in only
     hipExtLaunchKernelGGL(gru_bidir_kernel<true>, dim3((unsigned)((n + per_cu - 1) / per_cu)), dim3(512), 0,
-                          (hipStream_t)stream, e0, e1, 0, x, wpack, bpack, out, n, L, per_cu);
+                          (hipStream_t)stream, e0, e1, 0, x, wpack, bpack, out, n, L, per_cu, count);
   else
     hipExtLaunchKernelGGL(gru_bidir_kernel<false>, dim3((unsigned)((n + TS - 1) / TS), 2), dim3(256), 0,
-                          (hipStream_t)stream, e0, e1, 0, x, wpack, bpack, out, n, L, TS);
+                          (hipStream_t)stream, e0, e1, 0, x, wpack, bpack, out, n, L, TS, count);
   return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
 }
 
@@ -1502,11 +1524,11 @@ extern "C" int svdd_conv1d_cl_f32(const float* x, const float* wpack, float* y, 
 }
 
 extern "C" int svdd_conv_tower_f32(const float* onehot, const float* tiles, const float* bias, float* out, int n, int L,
-                                   int nlayers, int residual_mask, void* stream) {
+                                   int nlayers, int residual_mask, const int32_t* count, void* stream) {
   if (!onehot || !tiles || !bias || !out || n <= 0 || L <= 0 || L > TW_ROWS || nlayers <= 0 || nlayers > TW_MAXL)
     return SVDD_E_ARG;
   const int spt = TW_ROWS / L;
-  TowerArgs a{onehot, tiles, bias, out, n, L, spt, nlayers, residual_mask};
+  TowerArgs a{onehot, tiles, bias, out, n, L, spt, nlayers, residual_mask, count};
   const size_t lds = sizeof(float) * ((size_t)(TW_ROWS + 2) * TW_AP + (size_t)(TW_ROWS + 2) * 4);
   hipEvent_t e0, e1;
   svdd_internal_timed_events(5, &e0, &e1);
@@ -1523,13 +1545,13 @@ extern "C" int svdd_conv_tower_f32(const float* onehot, const float* tiles, cons
 
 extern "C" int svdd_backbone_cnn_f32(const uint8_t* x, const float* table0, const float* tiles, const float* vec,
                                      const float* w2, float* out, int n, int L, int nlayers, const int* dilations,
-                                     void* stream) {
+                                     const int32_t* count, const int32_t* row_idx, int out_scatter, void* stream) {
   if (!x || !table0 || !tiles || !vec || !w2 || !out || !dilations || n <= 0 || L <= 0 || L > TW_ROWS ||
       nlayers <= 0 || nlayers > BB_MAXL)
     return SVDD_E_ARG;
   BackboneArgs a;
   a.x = x; a.table0 = table0; a.tiles = tiles; a.vec = vec; a.w2 = w2; a.out = out;
-  a.n = n; a.L = L; a.spt = TW_ROWS / L; a.nl = nlayers;
+  a.n = n; a.L = L; a.spt = TW_ROWS / L; a.nl = nlayers; a.count = count; a.row_idx = row_idx; a.out_scatter = out_scatter;
   for (int i = 0; i < BB_MAXL; ++i) a.dil[i] = i < nlayers ? dilations[i] : 1;
   for (int i = 0; i < nlayers; ++i) if (dilations[i] <= 0) return SVDD_E_ARG;
   const size_t lds = sizeof(float) * ((size_t)(TW_ROWS + 2) * BB_AP + 9 * 5 * (size_t)BB_C + 8 * (size_t)TW_ROWS +
@@ -1549,7 +1571,7 @@ extern "C" int svdd_backbone_cnn_f32(const uint8_t* x, const float* table0, cons
 
 extern "C" int svdd_value_tail_f32(const float* h_fwd, const float* h_bwd, const float* w1pack, const float* b1,
                                    const float* w_eff, const float* b_eff, float* out, int n, int L, int n_tasks,
-                                   void* stream) {
+                                   const int32_t* count, void* stream) {
   if (!h_fwd || !h_bwd || !w1pack || !b1 || !w_eff || !b_eff || !out || n <= 0 || L <= 0 || n_tasks < 1 || n_tasks > 4)
     return SVDD_E_ARG;
   hipEvent_t e0, e1;
@@ -1557,7 +1579,7 @@ extern "C" int svdd_value_tail_f32(const float* h_fwd, const float* h_bwd, const
   const dim3 grid((unsigned)((n + 3) / 4)), block(256);
 #define SVDD_TAIL(TT)                                                                                              \
   hipExtLaunchKernelGGL(value_tail_kernel<TT>, grid, block, 0, (hipStream_t)stream, e0, e1, 0, h_fwd, h_bwd, w1pack, b1, \
-                        w_eff, b_eff, out, n, L)
+                        w_eff, b_eff, out, n, L, count)
   switch (n_tasks) {
     case 1: SVDD_TAIL(1); break;
     case 2: SVDD_TAIL(2); break;
@@ -1569,21 +1591,21 @@ extern "C" int svdd_value_tail_f32(const float* h_fwd, const float* h_bwd, const
 }
 
 extern "C" int svdd_candidate_windows(const uint8_t* cand, const uint8_t* x, int B, int L, int M, int margin, int32_t* win,
-                                      void* stream) {
+                                      int32_t* flags, void* stream) {
   if (!cand || !x || !win || B <= 0 || L <= 0 || M <= 0 || margin < 0) return SVDD_E_ARG;
   const int n = B * M;
   hipLaunchKernelGGL(candidate_windows_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, cand, x,
-                     n, L, M, margin, win);
+                     n, L, M, margin, win, flags);
   return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
 }
 
 extern "C" int svdd_conv_tower_windows_f32(const float* onehot, const float* tiles, const float* bias, const int32_t* win,
                                            const float* parent_out, float* out, int n, int L, int M, int nlayers,
-                                           int residual_mask, void* stream) {
+                                           int residual_mask, const int32_t* live_idx, const int32_t* count, void* stream) {
   if (!onehot || !tiles || !bias || !win || !parent_out || !out || n <= 0 || M <= 0 || n % M || L <= TW_ROWS / 2 ||
       L > TW_ROWS || nlayers != 5)
     return SVDD_E_ARG;                                   // one sequence per tile; margins below assume the 5-layer tower
-  TowerWinArgs wa{TowerArgs{onehot, tiles, bias, out, n, L, 1, nlayers, residual_mask}, win, parent_out, M};
+  TowerWinArgs wa{TowerArgs{onehot, tiles, bias, out, n, L, 1, nlayers, residual_mask, nullptr}, win, parent_out, M, live_idx, count};
   const size_t lds = sizeof(float) * ((size_t)(TW_ROWS + 2) * TW_AP + (size_t)(TW_ROWS + 16) * 4);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_tower_win_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipEvent_t e0, e1;

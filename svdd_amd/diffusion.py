@@ -33,6 +33,17 @@ Engine knobs (attributes; defaults reproduce the reference's observable behaviou
                    split hi + lo (3 MFMAs per product, fp32 accumulate): fp32-class error (logits / scores within
                    ~3e-6 / ~3e-5 of the fp32 kernels) at ~2.5x the speed. "f16" / "bf16": one 16-bit pass.
                    Tokens can differ from the fp32 decode at near-ties; tools/precision_agreement.py reports it.
+  skip_unchanged   True (default): exact work-skipping. A candidate that unmasked nothing is a copy of
+                   its parent x_t (:1203) and, time_conditioning being off (:334-335), every net output for it is the
+                   parent's: SVDD-MC evaluates the value net only on the live candidates and takes a copy's score from
+                   the parent (= the score of the candidate selected one step earlier); SVDD-PM runs the candidate
+                   backbone forward, x0-hat and reward on the live candidates only and never re-runs the parent forward
+                   (the selected candidate's logits ARE the next parent's). With logits_cache the backbone also skips
+                   rows whose x_t did not change. Compaction is done on the device; no host round trip in the loop.
+                   Decodes are bit-identical to skip_unchanged = False (tests/test_skip_gpu.py). Needs the fused nets.
+  logits_cache     "auto" (default): per-row logits cache when several sequences share a backbone tile (L <= 104; at
+                   L = 200 one workgroup owns one sequence and skipping rows frees CUs but saves no time); "on" / "off".
+  skip_stats       None, or a dict the samplers fill with device-side hit counters (live candidates, changed rows).
 """
 import weakref
 
@@ -93,6 +104,9 @@ class Diffusion(nn.Module):
         self.row_offset = 0
         self.fuse_nets = True
         self.precision = "f32"
+        self.skip_unchanged = True
+        self.logits_cache = "auto"
+        self.skip_stats = None
         self.trace = None          # set to a list to record (logits, scores) of every step (tests / smoke)
         self.state_trace = None    # set to a list to record x_t (uint8 clone) at the start of every step + the final x
         self._sched_cache = {}
@@ -239,12 +253,14 @@ class Diffusion(nn.Module):
     def _num_steps(self, num_steps):
         return self.config.sampling.steps if num_steps is None else num_steps
 
-    def _noise_removal(self, x_u8):
-        """:1049-1060 — x = forward(x, sigma(t_last))[:, :, :-1].argmax(-1) ; returns int64."""
+    def _noise_removal(self, x_u8, logits=None):
+        """:1049-1060 — x = forward(x, sigma(t_last))[:, :, :-1].argmax(-1) ; returns int64. `logits`: the backbone
+        output for x_u8 when the caller already holds it (work-skipping SVDD-PM)."""
         if self.config.sampling.noise_removal:
             if self.sampler == "analytic":
                 raise NotImplementedError("analytic sampler is not on the reference's decode path")
-            logits = self._backbone_logits(x_u8)
+            if logits is None:
+                logits = self._backbone_logits(x_u8)
             self._record(logits, None, x_u8)
             return ops.finalize(logits, x_u8)
         return x_u8.long()
@@ -461,6 +477,9 @@ class Diffusion(nn.Module):
         x = torch.full((B, L), self.mask_index, dtype=torch.uint8, device=self.device)   # _sample_prior
         cand = torch.empty((B, M, L), dtype=torch.uint8, device=self.device)
         onehot = torch.empty((B * M, L, 4), dtype=torch.float32, device=self.device)
+        fn = self.value_callable(pre_scorer_embedding, pre_scorer_head)
+        if self._can_skip(fn, L, M) and fn.candidates_ok(L, M):
+            return self._controlled_sample_skipping(fn, x, cand, onehot, sched, B, L, S, M)
         for i in range(S):
             logits = self._backbone_logits(x)
             ops.propose(logits, x, sched[i, 2], sched[i, 1], M, self._rng(i, M, B, L, logits), cand=cand, onehot=onehot)
@@ -468,6 +487,110 @@ class Diffusion(nn.Module):
             self._record(logits, scores, x)
             x = self._select(scores, cand, i)
         return self._noise_removal(x)
+
+    # ------------------------------------------------------------- exact work-skipping ----
+    def _can_skip(self, fn, L, M):
+        """The skipping paths hand the nets compacted batches whose size only the device knows: they need the
+        hand-written kernels for the value / reward net and (PM, logits cache) the one-launch backbone kernel."""
+        from .fused import FusedValueNet
+        return (self.skip_unchanged and self.fuse_nets and self.value_batching == "batched" and M > 1 and
+                isinstance(fn, FusedValueNet) and fn.kernels_ok(L) and fn.w_eff.shape[1] == 1 and
+                self.select_mode in ("argmax", "multinomial"))
+
+    def _fused_backbone_or_none(self, L):
+        if isinstance(self.backbone, CNNModel) and not self.time_conditioning and self.fuse_nets:
+            fb = self._fused_backbone()
+            if fb.kernel_ok(L):
+                return fb
+        return None
+
+    class _SkipWorkspace:
+        def __init__(self, B, M, dev):
+            i32 = dict(dtype=torch.int32, device=dev)
+            self.flags, self.live_idx, self.slot = (torch.empty(B * M, **i32) for _ in range(3))
+            self.count = torch.zeros(1, **i32)
+            self.row_idx, self.row_slot = torch.empty(B, **i32), torch.empty(B, **i32)
+            self.row_count = torch.zeros(1, **i32)
+            self.parent_score, self.sel_score = torch.empty(B, device=dev), torch.empty(B, device=dev)
+            self.changed, self.idx = torch.empty(B, **i32), torch.empty(B, **i32)
+            self.n_live = torch.zeros(1, dtype=torch.int64, device=dev)
+            self.n_changed = torch.zeros(1, dtype=torch.int64, device=dev)
+
+    def _select_compact(self, sc, ws, cand, step):
+        mode = {"argmax": ops.SELECT_ARGMAX, "multinomial": ops.SELECT_MULTINOMIAL}[self.select_mode]
+        rng = None
+        if mode == ops.SELECT_MULTINOMIAL:
+            if self.rng_mode != "philox":
+                raise ValueError("select_mode='multinomial' needs rng_mode='philox'")
+            rng = ops.Rng(seed=self.philox_seed, row_offset=self.row_offset, step=step)
+        x_next, _, _, _ = ops.select_compact(sc, ws.slot, ws.parent_score, cand, mode=mode, rng=rng, sel_score=ws.sel_score,
+                                             changed=ws.changed, idx=ws.idx)
+        ws.parent_score, ws.sel_score = ws.sel_score, ws.parent_score       # the selected candidate is the next parent
+        if self.skip_stats is not None:
+            ws.n_live += ws.count
+            ws.n_changed += ws.changed.sum()
+        return x_next
+
+    def _dense_scores(self, sc, ws, B, M):
+        """[B, M] scores from the compacted ones (only for the trace: the loop itself never materialises them)."""
+        live = ws.slot >= 0
+        return torch.where(live, sc[ws.slot.clamp(min=0).long()], ws.parent_score.repeat_interleave(M)).view(B, M)
+
+    def _finish_stats(self, ws, B, M, S, kind):
+        if self.skip_stats is not None:
+            self.skip_stats.update(kind=kind, steps=S, candidates=B * M * S, live_candidates=int(ws.n_live),
+                                   row_steps=B * S, changed_row_steps=int(ws.n_changed))
+
+    def _use_logits_cache(self, L):
+        return self.logits_cache == "on" or (self.logits_cache == "auto" and 208 // L >= 2)
+
+    def _controlled_sample_skipping(self, fn, x, cand, onehot, sched, B, L, S, M):
+        """SVDD-MC with exact work-skipping (same tokens as the plain loop, bit for bit)."""
+        ws = self._SkipWorkspace(B, M, self.device)
+        ws.parent_score.copy_(fn.forward_tokens(x).reshape(B))               # scores of the all-MASK parents
+        fb = self._fused_backbone_or_none(L) if self._use_logits_cache(L) else None
+        logits = None
+        for i in range(S):
+            if fb is None or logits is None:
+                logits = self._backbone_logits(x)
+            else:                                                             # only the rows the last select changed
+                ops.compact_flags(ws.changed, ws.row_idx, ws.row_slot, ws.row_count)
+                fb.forward_rows(x, count=ws.row_count, out=logits, row_idx=ws.row_idx, scatter=True)
+            ops.propose(logits, x, sched[i, 2], sched[i, 1], M, self._rng(i, M, B, L, logits), cand=cand, onehot=onehot)
+            sc = fn.candidate_scores_compact(onehot, cand, x, ws).reshape(-1)
+            if self.trace is not None or self.state_trace is not None:
+                self._record(logits, self._dense_scores(sc, ws, B, M), x)
+            x = self._select_compact(sc, ws, cand, i)
+        self._finish_stats(ws, B, M, S, "mc")
+        return self._noise_removal(x)
+
+    def _tweedie_sample_skipping(self, rf, x, sched, B, L, S, M, fb):
+        """SVDD-PM with exact work-skipping: per step ONE backbone forward, on the live candidates only."""
+        dev = self.device
+        ws = self._SkipWorkspace(B, M, dev)
+        n = B * M
+        cand = torch.empty((B, M, L), dtype=torch.uint8, device=dev)
+        toks_c = torch.empty((n, L), dtype=torch.uint8, device=dev)
+        lg_c = torch.empty((n, L, 5), dtype=torch.float32, device=dev)
+        logits = fb.forward_rows(x)                                           # parents' logits; advanced, never recomputed
+        _, xh = ops.x0hat(logits, x, want_tokens=True, want_onehot=False)
+        ws.parent_score.copy_(rf.forward_tokens(xh).reshape(B))               # reward of the parents' x0-hat
+        for i in range(S):
+            ops.propose(logits, x, sched[i, 2], sched[i, 1], M, self._rng(i, M, B, L, logits), cand=cand)
+            from .fused import candidate_windows
+            candidate_windows(cand, x, margin=0, flags=ws.flags)
+            ops.compact_flags(ws.flags, ws.live_idx, ws.slot, ws.count)
+            fb.forward_rows(cand.view(n, L), count=ws.count, out=lg_c, row_idx=ws.live_idx, scatter=False)
+            ops.gather_rows(cand.view(n, L), ws.live_idx, ws.count, toks_c)
+            _, xh = ops.x0hat(lg_c, toks_c, want_tokens=True, want_onehot=False)   # :1415-1419 on the compacted rows
+            sc = rf.forward_tokens(xh, count=ws.count).reshape(-1)                 # :1430
+            if self.trace is not None or self.state_trace is not None:
+                self._record(logits, self._dense_scores(sc, ws, B, M), x)
+            x_next = self._select_compact(sc, ws, cand, i)
+            ops.advance_rows(lg_c, ws.slot, ws.idx, logits, M)                # the selected candidate's logits are the next parent's
+            x = x_next
+        self._finish_stats(ws, B, M, S, "pm")
+        return self._noise_removal(x, logits)
 
     @torch.no_grad()
     def controlled_sample_tweedie(self, reward_model, num_steps=None, eps=1e-5, eval_sp_size=None, sample_M=10,
@@ -478,6 +601,10 @@ class Diffusion(nn.Module):
         B, L, S, M = self._batch_size(eval_sp_size), self.config.model.length, self._num_steps(num_steps), sample_M
         sched, _, _ = self._schedule(S, eps)
         x = torch.full((B, L), self.mask_index, dtype=torch.uint8, device=self.device)
+        rf = self.reward_callable(reward_model)
+        fb = self._fused_backbone_or_none(L)
+        if options == "True" and task != "rna_saluki" and fb is not None and self._can_skip(rf, L, M):
+            return self._tweedie_sample_skipping(rf, x, sched, B, L, S, M, fb)
         for i in range(S):
             logits = self._backbone_logits(x)
             cand, _, _ = ops.propose(logits, x, sched[i, 2], sched[i, 1], M, self._rng(i, M, B, L, logits))

@@ -54,13 +54,15 @@ def pack_gru(gru):
     return torch.stack(packs).contiguous(), torch.stack(biases).contiguous()
 
 
-def gru_bidir(x_nlc, wpack, bpack):
-    """x [n, L, 64] fp32 (contiguous) -> [2, n, L, 64] per-direction hidden states (HIP kernel)."""
+def gru_bidir(x_nlc, wpack, bpack, count=None, out=None):
+    """x [n, L, 64] fp32 (contiguous) -> [2, n, L, 64] per-direction hidden states (HIP kernel). count: int32 device
+    scalar with the number of valid rows of a compacted batch (None: n)."""
     assert x_nlc.is_cuda and x_nlc.dtype == torch.float32 and x_nlc.is_contiguous() and x_nlc.shape[2] == 64
     n, L, _ = x_nlc.shape
-    out = torch.empty((2, n, L, 64), dtype=torch.float32, device=x_nlc.device)
+    if out is None:
+        out = torch.empty((2, n, L, 64), dtype=torch.float32, device=x_nlc.device)
     rc = _lib.lib().svdd_gru_bidir_f32(x_nlc.data_ptr(), wpack.data_ptr(), bpack.data_ptr(), out.data_ptr(), n, L,
-                                       ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+                                       _ptr(count), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     _lib.check(rc, "svdd_gru_bidir_f32")
     return out
 
@@ -111,14 +113,14 @@ def pack_tower(stem_weight, layer_weights):
     return torch.stack([t.contiguous() for t in tiles]).contiguous()
 
 
-def conv_tower(onehot, tiles, bias, residual_mask):
+def conv_tower(onehot, tiles, bias, residual_mask, count=None):
     """onehot [n, L, 4] fp32 -> [n, L, 64]: stem + (len(bias) - 1) residual conv layers in ONE launch
     (HIP kernel svdd_conv_tower_f32, activations resident in LDS)."""
     assert onehot.is_cuda and onehot.dtype == torch.float32 and onehot.is_contiguous() and onehot.shape[2] == 4
     n, L, _ = onehot.shape
     out = torch.empty((n, L, 64), dtype=torch.float32, device=onehot.device)
     rc = _lib.lib().svdd_conv_tower_f32(onehot.data_ptr(), tiles.data_ptr(), bias.data_ptr(), out.data_ptr(), n, L,
-                                        bias.shape[0] - 1, int(residual_mask),
+                                        bias.shape[0] - 1, int(residual_mask), _ptr(count),
                                         ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     _lib.check(rc, "svdd_conv_tower_f32")
     return out
@@ -136,7 +138,7 @@ def pack_tail(w1, b1, gamma, beta):
     return w.permute(3, 1, 0, 2, 4).reshape(64, 128).contiguous(), bf
 
 
-def value_tail(h, w1pack, b1f, w_eff, b_eff):
+def value_tail(h, w1pack, b1f, w_eff, b_eff, count=None):
     """h [2, n, L, 64] (GRU output, both directions) -> scores [n, n_tasks]: direction sum + LayerNorm + dense1 + ReLU +
     collapsed (dense2, head) + mean over length in one pass (HIP kernel svdd_value_tail_f32); (w1pack, b1f) from pack_tail."""
     assert h.is_cuda and h.dtype == torch.float32 and h.is_contiguous() and h.shape[0] == 2 and h.shape[3] == 64
@@ -144,7 +146,7 @@ def value_tail(h, w1pack, b1f, w_eff, b_eff):
     T = w_eff.shape[1]
     out = torch.empty((n, T), dtype=torch.float32, device=h.device)
     rc = _lib.lib().svdd_value_tail_f32(h[0].data_ptr(), h[1].data_ptr(), w1pack.data_ptr(), b1f.data_ptr(),
-                                        w_eff.data_ptr(), b_eff.data_ptr(), out.data_ptr(), n, L, T,
+                                        w_eff.data_ptr(), b_eff.data_ptr(), out.data_ptr(), n, L, T, _ptr(count),
                                         ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     _lib.check(rc, "svdd_value_tail_f32")
     return out
@@ -180,16 +182,18 @@ def pack_backbone(cnn):
     return dict(table0=table0, tiles=tiles, vec=vec.contiguous(), w2=w2, dil=[c.dilation[0] for c in cnn.convs])
 
 
-def backbone_cnn(tokens, pk):
+def backbone_cnn(tokens, pk, count=None, out=None, row_idx=None, scatter=False):
     """tokens [n, L] uint8 -> raw logits fp32 [n, L, 5]: the whole backbone forward in ONE launch
     (HIP kernel svdd_backbone_cnn_f32)."""
     assert tokens.is_cuda and tokens.dtype == torch.uint8 and tokens.is_contiguous()
     n, L = tokens.shape
-    out = torch.empty((n, L, 5), dtype=torch.float32, device=tokens.device)
+    if out is None:
+        out = torch.empty((n, L, 5), dtype=torch.float32, device=tokens.device)
     dil = (ctypes.c_int * len(pk["dil"]))(*pk["dil"])
     rc = _lib.lib().svdd_backbone_cnn_f32(tokens.data_ptr(), pk["table0"].data_ptr(), pk["tiles"].data_ptr(),
                                           pk["vec"].data_ptr(), pk["w2"].data_ptr(), out.data_ptr(), n, L,
-                                          len(pk["dil"]), dil, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+                                          len(pk["dil"]), dil, _ptr(count), _ptr(row_idx), int(scatter),
+                                          ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     _lib.check(rc, "svdd_backbone_cnn_f32")
     return out
 
@@ -244,17 +248,18 @@ def pack_backbone_lp(cnn, precision):
     return pk
 
 
-def backbone_cnn_lp(tokens, pk):
+def backbone_cnn_lp(tokens, pk, count=None, out=None, row_idx=None, scatter=False):
     """tokens [n, L] uint8 -> raw logits fp32 [n, L, 5] on the 16-bit matrix cores (HIP kernel svdd_backbone_cnn_lp);
     pk from pack_backbone_lp."""
     assert tokens.is_cuda and tokens.dtype == torch.uint8 and tokens.is_contiguous()
     n, L = tokens.shape
-    out = torch.empty((n, L, 5), dtype=torch.float32, device=tokens.device)
+    if out is None:
+        out = torch.empty((n, L, 5), dtype=torch.float32, device=tokens.device)
     dil = (ctypes.c_int * len(pk["dil"]))(*pk["dil"])
     rc = _lib.lib().svdd_backbone_cnn_lp(tokens.data_ptr(), pk["table0"].data_ptr(), pk["tiles"].data_ptr(),
                                          pk["vec"].data_ptr(), pk["lscale"].data_ptr(), pk["w2"].data_ptr(),
-                                         out.data_ptr(), n, L, len(pk["dil"]), dil, pk["prec"],
-                                         ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+                                         out.data_ptr(), n, L, len(pk["dil"]), dil, pk["prec"], _ptr(count), _ptr(row_idx),
+                                         int(scatter), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     _lib.check(rc, "svdd_backbone_cnn_lp")
     return out
 
@@ -316,14 +321,14 @@ def tiles_parts(tiles, bias):
     return tiles.numel() // ((2 + 10 * (bias.shape[0] - 1)) * 4 * 64 * 8)
 
 
-def conv_tower_lp(tok, tiles, bias, inv, residual_mask, prec):
+def conv_tower_lp(tok, tiles, bias, inv, residual_mask, prec, count=None):
     """tokens [n, L] u8 -> tower output [n, L, P, 64] in 16-bit planes (hi, lo; value = hi + lo), the form the
     split-precision GRU consumes (HIP kernel svdd_conv_tower_lp)."""
     assert tok.is_cuda and tok.dtype == torch.uint8 and tok.is_contiguous()
     n, L = tok.shape
     out = torch.empty((n, L, tiles_parts(tiles, bias), 64), dtype=tiles.dtype, device=tok.device)
     rc = _lib.lib().svdd_conv_tower_lp(tok.data_ptr(), tiles.data_ptr(), bias.data_ptr(), inv.data_ptr(), out.data_ptr(),
-                                       n, L, bias.shape[0] - 1, int(residual_mask), prec,
+                                       n, L, bias.shape[0] - 1, int(residual_mask), _ptr(count), prec,
                                        ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     _lib.check(rc, "svdd_conv_tower_lp")
     return out
@@ -376,19 +381,19 @@ def value_tail_lp(h, w1pack, b1f, w_eff, b_eff, inv, prec, count=None):
 TOWER_WINDOW_MARGIN = 27     # +-17 rows receptive field of the 5-layer tower + 10 rows of window-edge error
 
 
-def candidate_windows(cand, x, margin=TOWER_WINDOW_MARGIN):
+def candidate_windows(cand, x, margin=TOWER_WINDOW_MARGIN, flags=None):
     """cand [B, M, L] u8, x [B, L] u8 -> int32 [B*M, 2]: the 16-aligned row window (w0, w1) around the positions where a
     candidate differs from its parent, (0, 0) for an exact copy (HIP kernel svdd_candidate_windows)."""
     assert cand.is_cuda and cand.dtype == torch.uint8 and cand.is_contiguous() and x.dtype == torch.uint8 and x.is_contiguous()
     B, M, L = cand.shape
     win = torch.empty((B * M, 2), dtype=torch.int32, device=cand.device)
-    rc = _lib.lib().svdd_candidate_windows(cand.data_ptr(), x.data_ptr(), B, L, M, margin, win.data_ptr(),
+    rc = _lib.lib().svdd_candidate_windows(cand.data_ptr(), x.data_ptr(), B, L, M, margin, win.data_ptr(), _ptr(flags),
                                            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     _lib.check(rc, "svdd_candidate_windows")
     return win
 
 
-def conv_tower_windows(onehot, win, parent_out, M, tiles, bias, residual_mask):
+def conv_tower_windows(onehot, win, parent_out, M, tiles, bias, residual_mask, live_idx=None, count=None):
     """Tower output [n, L, 64] of the candidates' one-hot [n = B*M, L, 4], computing only the row windows `win` and
     copying the rest from the parents' tower output [B, L, 64] (HIP kernel svdd_conv_tower_windows_f32)."""
     assert onehot.is_cuda and onehot.dtype == torch.float32 and onehot.is_contiguous() and onehot.shape[2] == 4
@@ -397,7 +402,8 @@ def conv_tower_windows(onehot, win, parent_out, M, tiles, bias, residual_mask):
     out = torch.empty((n, L, 64), dtype=torch.float32, device=onehot.device)
     rc = _lib.lib().svdd_conv_tower_windows_f32(onehot.data_ptr(), tiles.data_ptr(), bias.data_ptr(), win.data_ptr(),
                                                 parent_out.data_ptr(), out.data_ptr(), n, L, M, bias.shape[0] - 1,
-                                                int(residual_mask), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+                                                int(residual_mask), _ptr(live_idx), _ptr(count),
+                                                ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     _lib.check(rc, "svdd_conv_tower_windows_f32")
     return out
 
@@ -510,10 +516,40 @@ class FusedValueNet(nn.Module):
         return pk
 
     def forward_tokens(self, tok, count=None):
-        """Scores [n, n_tasks, 1] of the token rows tok [n, L] u8 (4 = MASK), split-precision path."""
-        pk = self._lp_pack()
-        seq = conv_tower_lp(tok.contiguous(), pk["tiles"], self.tw_bias, pk["tinv"], self.tw_resmask, pk["prec"])
-        return self._after_tower_lp(seq, pk, count)
+        """Scores [n, n_tasks, 1] of the token rows tok [n, L] u8 (4 = MASK) through the hand-written kernels, in the
+        module's precision. count: int32 device scalar = number of valid rows of a compacted batch (rows beyond it are
+        neither computed nor defined)."""
+        from . import ops
+        if self.precision != "f32":
+            pk = self._lp_pack()
+            seq = conv_tower_lp(tok.contiguous(), pk["tiles"], self.tw_bias, pk["tinv"], self.tw_resmask, pk["prec"], count)
+            return self._after_tower_lp(seq, pk, count)
+        seq = conv_tower(ops.transform_samples(tok.contiguous()), self.tw_tiles, self.tw_bias, self.tw_resmask, count)
+        return self._after_tower(seq, tok.shape[0], tok.shape[1], count)
+
+    def kernels_ok(self, L):
+        """True when the whole net runs on the hand-written kernels (tower, GRU, tail) for sequences of length L."""
+        return self.use_fused_tower and self.tower_ok and self.use_fused_tail and self.tail_ok and L <= 208
+
+    def candidate_scores_compact(self, onehot, cand, x, ws):
+        """Exact work-skipping for SVDD-MC: the scores of the LIVE candidates only — a candidate
+        that unmasked nothing is a copy of its parent and has the parent's score. Fills the workspace ws (flags,
+        live_idx, slot, count: int32 device tensors) and returns the compacted scores [n, n_tasks] (first count[0] rows
+        valid, in live_idx order). Same kernels, same bits per candidate as forward_candidates; no host round trip."""
+        from . import ops
+        B, M, L = cand.shape
+        win = candidate_windows(cand, x, flags=ws.flags)
+        ops.compact_flags(ws.flags, ws.live_idx, ws.slot, ws.count)
+        if self.precision != "f32":
+            pk = self._lp_pack()
+            parent_out = conv_tower_lp(x, pk["tiles"], self.tw_bias, pk["tinv"], self.tw_resmask, pk["prec"])
+            seq = conv_tower_windows_lp(cand, win, parent_out, pk["tiles"], self.tw_bias, pk["tinv"], self.tw_resmask,
+                                        pk["prec"], live_idx=ws.live_idx, count=ws.count)
+            return self._after_tower_lp(seq, pk, ws.count)[:, :, 0]
+        parent_out = conv_tower(ops.transform_samples(x), self.tw_tiles, self.tw_bias, self.tw_resmask)
+        seq = conv_tower_windows(onehot, win, parent_out, M, self.tw_tiles, self.tw_bias, self.tw_resmask,
+                                 live_idx=ws.live_idx, count=ws.count)
+        return self._after_tower(seq, B * M, L, ws.count)[:, :, 0]
 
     def _after_tower_lp(self, seq, pk, count=None):
         h = gru_bidir_lp(seq, pk["gw"], pk["gb"], pk["ginv"], pk["prec"], count=count)
@@ -569,10 +605,11 @@ class FusedValueNet(nn.Module):
         seq = conv_tower_windows(onehot, win, parent_out, M, self.tw_tiles, self.tw_bias, self.tw_resmask)
         return self._after_tower(seq, B * M, L)
 
-    def _after_tower(self, seq, n, L):
-        h = gru_bidir(seq, self.wpack, self.bpack)
+    def _after_tower(self, seq, n, L, count=None):
+        h = gru_bidir(seq, self.wpack, self.bpack, count)
         if self.use_fused_tail and self.tail_ok:
-            return value_tail(h, self.w1pack, self.b1f, self.w_eff, self.b_eff)[:, :, None]
+            return value_tail(h, self.w1pack, self.b1f, self.w_eff, self.b_eff, count)[:, :, None]
+        assert count is None, "compacted batches need the fused tail kernel"
         # LayerNorm(h_fwd + h_bwd) in one pass (the direction sum of Enformer.py:1617 + dense1.norm)
         _, hn = epilogue_ln(h[0], None, h[1], None, self.ln_w, self.ln_b, act=ACT_NONE, want_sum=False)
         z = F.relu(F.linear(hn, self.w1, self.b1))                  # [n,L,128]
@@ -623,6 +660,22 @@ class FusedBackbone(nn.Module):
             self.ol_dil = pk.pop("dil")
             for k, v in pk.items():
                 self.register_buffer("ol_" + k, v, persistent=False)
+
+    def kernel_ok(self, L):
+        """True when a forward of length-L sequences is the one-launch kernel (the work-skipping paths need it: they
+        hand it compacted batches whose size only the device knows)."""
+        return self.one_launch and self.use_one_launch and L <= 208 and self.min_tiles_one_launch == 0
+
+    def forward_rows(self, tok, count=None, out=None, row_idx=None, scatter=False):
+        """One-launch kernel on a compacted batch (see fused.backbone_cnn): tok [n, L] u8; count / row_idx int32 device
+        tensors; out: logits buffer to write into."""
+        if self.precision != "f32":
+            pk = self._lp.get(self.precision)
+            if pk is None:
+                pk = self._lp[self.precision] = pack_backbone_lp(self._cnn[0], self.precision)
+            return backbone_cnn_lp(tok, pk, count, out, row_idx, scatter)
+        return backbone_cnn(tok, dict(table0=self.ol_table0, tiles=self.ol_tiles, vec=self.ol_vec, w2=self.ol_w2,
+                                      dil=self.ol_dil), count, out, row_idx, scatter)
 
     def forward(self, seq, sigma=None):
         B, L = seq.shape

@@ -124,15 +124,63 @@ def select(scores, cand, mode=SELECT_ARGMAX, rng=None, want_soft=True, x_next=No
     return x_next, soft, idx
 
 
-def x0hat(logits, xt, want_tokens=False):
-    """-> (onehot_t f32 [R,4,L], x0hat u8 [R,L] | None)."""
+def select_compact(scores_c, slot, parent_score, cand, mode=SELECT_ARGMAX, rng=None, x_next=None, sel_score=None,
+                   changed=None, idx=None):
+    """svdd_select_compact: select on the scores of the LIVE candidates only. scores_c f32 [>= count] (compacted),
+    slot i32 [B*M] (position in scores_c, or -1 for a copy of the parent), parent_score f32 [B].
+    -> (x_next u8 [B,L], idx i32 [B], sel_score f32 [B], changed i32 [B])."""
+    cand = _need(cand, torch.uint8, "cand").contiguous()
+    B, M, L = cand.shape
+    dev = cand.device
+    scores_c = _need(scores_c, torch.float32, "scores").contiguous()
+    x_next = torch.empty((B, L), dtype=torch.uint8, device=dev) if x_next is None else x_next
+    idx = torch.empty((B,), dtype=torch.int32, device=dev) if idx is None else idx
+    sel_score = torch.empty((B,), dtype=torch.float32, device=dev) if sel_score is None else sel_score
+    changed = torch.empty((B,), dtype=torch.int32, device=dev) if changed is None else changed
+    rs = rng.c_struct() if rng is not None else None
+    rc = _lib.lib().svdd_select_compact(scores_c.data_ptr(), slot.data_ptr(), parent_score.data_ptr(), cand.data_ptr(),
+                                        B, L, M, mode, ctypes.byref(rs) if rs is not None else None, x_next.data_ptr(),
+                                        None, idx.data_ptr(), sel_score.data_ptr(), changed.data_ptr(), _stream())
+    _lib.check(rc, "svdd_select_compact")
+    return x_next, idx, sel_score, changed
+
+
+def compact_flags(flags, live_idx, slot, count):
+    """Stable device-side compaction (svdd_compact_flags): live_idx[k] = i, slot[i] = k for the k-th non-zero flag,
+    slot[i] = -1 otherwise, count[0] = number of non-zero flags. All int32 device tensors; nothing returns to the host."""
+    rc = _lib.lib().svdd_compact_flags(flags.data_ptr(), flags.numel(), live_idx.data_ptr(), slot.data_ptr(), count.data_ptr(),
+                                       _stream())
+    _lib.check(rc, "svdd_compact_flags")
+
+
+def gather_rows(src, idx, count, dst):
+    """dst[i] = src[idx[i]] for i < count[0] (row tensors of equal row size, contiguous)."""
+    n = src.shape[0]
+    row_bytes = src[0].numel() * src.element_size()
+    rc = _lib.lib().svdd_gather_rows(src.data_ptr(), idx.data_ptr(), count.data_ptr() if count is not None else None, n,
+                                     row_bytes, dst.data_ptr(), _stream())
+    _lib.check(rc, "svdd_gather_rows")
+    return dst
+
+
+def advance_rows(src, slot, sel, dst, M):
+    """The selected candidate becomes the next parent: dst[b] = src[slot[b*M + sel[b]]] where that slot is >= 0."""
+    B = dst.shape[0]
+    row_bytes = dst[0].numel() * dst.element_size()
+    rc = _lib.lib().svdd_advance_rows(src.data_ptr(), slot.data_ptr(), sel.data_ptr(), B, M, row_bytes, dst.data_ptr(), _stream())
+    _lib.check(rc, "svdd_advance_rows")
+    return dst
+
+
+def x0hat(logits, xt, want_tokens=False, want_onehot=True):
+    """-> (onehot_t f32 [R,4,L] | None, x0hat u8 [R,L] | None)."""
     logits = _need(logits, torch.float32, "logits")
     xt = _need(xt, torch.uint8, "xt").contiguous()
     R, L = xt.shape
     logits, layout = layout_of(logits)
-    oh = torch.empty((R, 4, L), dtype=torch.float32, device=xt.device)
+    oh = torch.empty((R, 4, L), dtype=torch.float32, device=xt.device) if want_onehot else None
     xh = torch.empty((R, L), dtype=torch.uint8, device=xt.device) if want_tokens else None
-    rc = _lib.lib().svdd_x0hat(logits.data_ptr(), xt.data_ptr(), R, L, layout, oh.data_ptr(),
+    rc = _lib.lib().svdd_x0hat(logits.data_ptr(), xt.data_ptr(), R, L, layout, oh.data_ptr() if oh is not None else None,
                                xh.data_ptr() if xh is not None else None, _stream())
     _lib.check(rc, "svdd_x0hat")
     return oh, xh

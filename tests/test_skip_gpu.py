@@ -1,0 +1,183 @@
+"""-m gpu: exact work-skipping (Diffusion.skip_unchanged, logits_cache).
+
+A candidate that unmasked nothing is its parent (reference diffusion_gosai.py:1203) and the nets do not see the time step
+(:334-335), so its value score (:1207-1209), its Tweedie forward, x0-hat and reward (:1413-1436) are the parent's; a row
+whose selected candidate is such a copy keeps its logits. The engine skips exactly that work. The bar: decodes are
+bit-identical with skipping on and off — tokens, and (traced) the logits and scores of every step — at the BASELINE
+configs[1] (SVDD-MC, B=256, L=200, M=10) and configs[2] (SVDD-PM, B=256, L=50, M=10) sizes, 128 steps, in replay and
+Philox modes, in fp32 and in a split-precision mode. Plus the device-side compaction primitives against torch."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+# ------------------------------------------------------------------------------------------- primitives ----
+@pytest.mark.parametrize("n", [1, 63, 64, 1023, 1024, 1025, 2560, 40960])
+@pytest.mark.parametrize("p", [0.0, 0.3, 1.0])
+def test_compact_flags_vs_torch(n, p):
+    from svdd_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(n)
+    flags = (torch.rand(n, device=DEV, generator=g) < p).to(torch.int32) * 7      # any non-zero value counts
+    live_idx = torch.full((n,), -5, dtype=torch.int32, device=DEV)
+    slot = torch.full((n,), -5, dtype=torch.int32, device=DEV)
+    count = torch.full((1,), -5, dtype=torch.int32, device=DEV)
+    ops.compact_flags(flags, live_idx, slot, count)
+    ref = torch.nonzero(flags).flatten().to(torch.int32)
+    k = int(count)
+    assert k == ref.numel()
+    assert torch.equal(live_idx[:k], ref)                                         # stable: ascending order
+    exp_slot = torch.full((n,), -1, dtype=torch.int32, device=DEV)
+    exp_slot[ref.long()] = torch.arange(k, dtype=torch.int32, device=DEV)
+    assert torch.equal(slot, exp_slot)
+
+
+def test_gather_and_advance_rows():
+    from svdd_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(0)
+    B, M, R = 37, 5, 250                                                          # 1000-byte rows: not a multiple of 16
+    src = torch.randn(B * M, R, device=DEV, generator=g)
+    flags = (torch.rand(B * M, device=DEV, generator=g) < 0.6).to(torch.int32)
+    live_idx = torch.empty(B * M, dtype=torch.int32, device=DEV)
+    slot = torch.empty(B * M, dtype=torch.int32, device=DEV)
+    count = torch.zeros(1, dtype=torch.int32, device=DEV)
+    ops.compact_flags(flags, live_idx, slot, count)
+    k = int(count)
+    comp = torch.full_like(src, 9.0)
+    ops.gather_rows(src, live_idx, count, comp)
+    assert torch.equal(comp[:k], src[live_idx[:k].long()]) and bool((comp[k:] == 9.0).all())
+    sel = torch.randint(0, M, (B,), device=DEV, generator=g).to(torch.int32)
+    dst = torch.zeros(B, R, device=DEV)
+    ops.advance_rows(comp, slot, sel, dst, M)
+    for b in range(B):
+        c = b * M + int(sel[b])
+        exp = src[c] if int(flags[c]) else torch.zeros(R, device=DEV)
+        assert torch.equal(dst[b], exp), b
+    tok = torch.randint(0, 5, (B * M, 200), device=DEV, dtype=torch.uint8, generator=g)   # u8 rows, 200 bytes
+    tc = torch.zeros_like(tok)
+    ops.gather_rows(tok, live_idx, count, tc)
+    assert torch.equal(tc[:k], tok[live_idx[:k].long()])
+
+
+@pytest.mark.parametrize("mode", ["argmax", "multinomial"])
+def test_select_compact_equals_select_on_dense_scores(mode):
+    from svdd_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(4)
+    B, M, L = 41, 10, 200
+    cand = torch.randint(0, 5, (B, M, L), device=DEV, dtype=torch.uint8, generator=g)
+    flags = (torch.rand(B * M, device=DEV, generator=g) < 0.7).to(torch.int32)
+    flags[:M] = 0                                                                 # a row whose candidates are all copies
+    live_idx, slot = torch.empty(B * M, dtype=torch.int32, device=DEV), torch.empty(B * M, dtype=torch.int32, device=DEV)
+    count = torch.zeros(1, dtype=torch.int32, device=DEV)
+    ops.compact_flags(flags, live_idx, slot, count)
+    sc = torch.randn(B * M, device=DEV, generator=g) * 0.01
+    sc[int(count):] = float("nan")                                                # beyond count: must never be read
+    parent = torch.randn(B, device=DEV, generator=g) * 0.01
+    dense = torch.where(slot >= 0, sc[slot.clamp(min=0).long()], parent.repeat_interleave(M)).view(B, M)
+    m = ops.SELECT_ARGMAX if mode == "argmax" else ops.SELECT_MULTINOMIAL
+    rng = ops.Rng(seed=3, step=9, row_offset=100) if mode == "multinomial" else None
+    x_ref, _, idx_ref = ops.select(dense, cand, mode=m, rng=rng, want_soft=False)
+    x_c, idx_c, sel_score, changed = ops.select_compact(sc, slot, parent, cand, mode=m, rng=rng)
+    assert torch.equal(x_c, x_ref) and torch.equal(idx_c, idx_ref)
+    assert torch.equal(sel_score, dense.gather(1, idx_ref.long()[:, None])[:, 0])
+    assert torch.equal(changed.bool(), flags.view(B, M).gather(1, idx_ref.long()[:, None])[:, 0].bool())
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+@pytest.mark.parametrize("L", [200, 50])
+def test_backbone_on_compacted_rows(precision, L):
+    """The one-launch backbone on a device-side row list: compacted output (candidate compaction) and in-place
+    scatter (per-row logits cache) give the same bits as the full forward for the listed rows and touch nothing else."""
+    from svdd_amd import ops, synthetic
+    model, _, _, _ = synthetic.build("dna" if L == 200 else "rna", DEV)
+    model.precision = precision
+    fb = model._fused_backbone()
+    n = 77
+    x = torch.randint(0, 5, (n, L), device=DEV, dtype=torch.uint8)
+    full = fb.forward_rows(x).clone()
+    flags = (torch.rand(n, device=DEV) < 0.4).to(torch.int32)
+    idx, slot, count = torch.empty(n, dtype=torch.int32, device=DEV), torch.empty(n, dtype=torch.int32, device=DEV), torch.zeros(1, dtype=torch.int32, device=DEV)
+    ops.compact_flags(flags, idx, slot, count)
+    k = int(count)
+    comp = torch.full((n, L, 5), 7.0, device=DEV)
+    fb.forward_rows(x, count=count, out=comp, row_idx=idx, scatter=False)
+    assert torch.equal(comp[:k], full[idx[:k].long()])
+    tiles = (k + (208 // L) - 1) // (208 // L)
+    assert bool((comp[tiles * (208 // L):] == 7.0).all())                         # rows of untouched tiles are untouched
+    inplace = torch.full((n, L, 5), 7.0, device=DEV)
+    fb.forward_rows(x, count=count, out=inplace, row_idx=idx, scatter=True)
+    live = flags.bool()
+    assert torch.equal(inplace[live], full[live]) and bool((inplace[~live] == 7.0).all())
+    model.precision = "f32"
+
+
+# ------------------------------------------------------------------------------------------- whole decodes ----
+def _decode(model, kind, emb, head, reward, B, M, S, skip, cache="auto", trace=False):
+    model.skip_unchanged, model.logits_cache = skip, cache
+    model.trace = [] if trace else None
+    model.skip_stats = {} if skip else None
+    torch.manual_seed(0)
+    if kind == "mc":
+        x0 = model.controlled_sample(emb, head, num_steps=S, eval_sp_size=B, sample_M=M)
+    else:
+        x0 = model.controlled_sample_tweedie(reward, num_steps=S, eval_sp_size=B, sample_M=M, options="True", task="rna")
+    torch.cuda.synchronize()
+    tr, st = model.trace, model.skip_stats
+    model.trace, model.skip_stats, model.skip_unchanged, model.logits_cache = None, None, True, "auto"
+    return x0, tr, st
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_mc_decode_config2_skipping_is_bit_identical(precision):
+    from svdd_amd import synthetic
+    model, emb, head, reward = synthetic.build("dna", DEV)
+    model.rng_mode, model.philox_seed, model.precision = "philox", 7, precision
+    B, M, S = 256, 10, 128
+    off, _, _ = _decode(model, "mc", emb, head, reward, B, M, S, skip=False)
+    on, _, st = _decode(model, "mc", emb, head, reward, B, M, S, skip=True)
+    cached, _, _ = _decode(model, "mc", emb, head, reward, B, M, S, skip=True, cache="on")
+    assert torch.equal(on, off) and torch.equal(cached, off)
+    assert st["kind"] == "mc" and 0 < st["live_candidates"] < st["candidates"] and 0 < st["changed_row_steps"] < st["row_steps"]
+    model.precision = "f32"
+
+
+def test_mc_decode_skipping_trace_is_bit_identical():
+    """Every step's logits and [B, M] scores, not just the final tokens (replay mode, so the uniforms are the reference's)."""
+    from svdd_amd import synthetic
+    model, emb, head, reward = synthetic.build("dna", DEV)
+    model.rng_mode = "replay"
+    B, M, S = 24, 6, 40
+    off, tr_off, _ = _decode(model, "mc", emb, head, reward, B, M, S, skip=False, trace=True)
+    on, tr_on, _ = _decode(model, "mc", emb, head, reward, B, M, S, skip=True, cache="on", trace=True)
+    assert torch.equal(on, off) and len(tr_on) == len(tr_off) == S + 1
+    for (la, sa), (lb, sb) in zip(tr_on, tr_off):
+        assert torch.equal(la, lb)
+        assert (sa is None and sb is None) or torch.equal(sa, sb)
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_pm_decode_config3_skipping_is_bit_identical(precision):
+    from svdd_amd import synthetic
+    model, emb, head, reward = synthetic.build("rna", DEV)
+    model.rng_mode, model.philox_seed, model.precision = "philox", 11, precision
+    B, M, S = 256, 10, 128
+    off, _, _ = _decode(model, "pm", emb, head, reward, B, M, S, skip=False)
+    on, _, st = _decode(model, "pm", emb, head, reward, B, M, S, skip=True)
+    assert torch.equal(on, off)
+    assert st["kind"] == "pm" and st["live_candidates"] < 0.8 * st["candidates"]     # L = 50: most candidates are copies
+    model.precision = "f32"
+
+
+def test_pm_decode_skipping_trace_is_bit_identical():
+    from svdd_amd import synthetic
+    model, emb, head, reward = synthetic.build("rna", DEV)
+    model.rng_mode = "replay"
+    B, M, S = 16, 5, 32
+    off, tr_off, _ = _decode(model, "pm", emb, head, reward, B, M, S, skip=False, trace=True)
+    on, tr_on, _ = _decode(model, "pm", emb, head, reward, B, M, S, skip=True, trace=True)
+    assert torch.equal(on, off) and len(tr_on) == len(tr_off)
+    for (la, sa), (lb, sb) in zip(tr_on, tr_off):
+        assert torch.equal(la, lb)
+        assert (sa is None and sb is None) or torch.equal(sa, sb)
