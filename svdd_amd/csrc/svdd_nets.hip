@@ -1202,17 +1202,24 @@ __global__ __launch_bounds__(512, 2) void backbone_kernel(BackboneArgs a) {
         rstat[tid] = ((psum[tid] + psum[TW_ROWS + tid]) + (psum[2 * TW_ROWS + tid] + psum[3 * TW_ROWS + tid])) * (1.0f / BB_C);
       __syncthreads();
       // pass 2: centred second moment
+      // the four rows of a tile that a lane owns are adjacent: one 16-byte read per tile, issued one tile ahead (a read
+      // placed next to its use would pay a full LDS round trip per row: the stores in between pin it in place)
+      float4 st4 = *reinterpret_cast<const float4*>(rstat + min(16 * rh + 4 * g, TW_ROWS - 4));
 #pragma unroll
-      for (int r = 0; r < NR; ++r)
+      for (int r = 0; r < NR; ++r) {
+        const float4 cur4 = st4;
+        if (r + 1 < NR) st4 = *reinterpret_cast<const float4*>(rstat + min(16 * (rh + 2 * r + 2) + 4 * g, TW_ROWS - 4));
+        const float mean4[4] = {cur4.x, cur4.y, cur4.z, cur4.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int row = 16 * (rh + 2 * r) + 4 * g + e;
-          const float mean = row < TW_ROWS ? rstat[row] : 0.0f;
+          const float mean = mean4[e];
           const float d0 = f[r][0][e] + tb0 - mean, d1 = f[r][1][e] + tb1 - mean;
           acc[r][0][e] = d0; acc[r][1][e] = d1;           // keep the centred values
           const float sq = group16_sum(d0 * d0 + d1 * d1);
           if (j == 0 && row < TW_ROWS) psum[cg * TW_ROWS + row] = sq;
         }
+      }
       __syncthreads();
       if (tid < TW_ROWS)
         rstat[tid] = rsqrtf(((psum[tid] + psum[TW_ROWS + tid]) + (psum[2 * TW_ROWS + tid] + psum[3 * TW_ROWS + tid])) *
@@ -1220,17 +1227,22 @@ __global__ __launch_bounds__(512, 2) void backbone_kernel(BackboneArgs a) {
       __syncthreads();
       const float gm0 = vl[2 * BB_C + col0], gm1 = vl[2 * BB_C + col0 + 16];
       const float bt0 = vl[3 * BB_C + col0], bt1 = vl[3 * BB_C + col0 + 16];
+      st4 = *reinterpret_cast<const float4*>(rstat + min(16 * rh + 4 * g, TW_ROWS - 4));
 #pragma unroll
-      for (int r = 0; r < NR; ++r)
+      for (int r = 0; r < NR; ++r) {
+        const float4 cur4 = st4;
+        if (r + 1 < NR) st4 = *reinterpret_cast<const float4*>(rstat + min(16 * (rh + 2 * r + 2) + 4 * g, TW_ROWS - 4));
+        const float rs4[4] = {cur4.x, cur4.y, cur4.z, cur4.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int row = 16 * (rh + 2 * r) + 4 * g + e;
           if (row < TW_ROWS) {
-            const float rs = rstat[row];
+            const float rs = rs4[e];
             img[row * BB_AP + col0] = row < tile_rows ? acc[r][0][e] * rs * gm0 + bt0 : 0.0f;
             img[row * BB_AP + col0 + 16] = row < tile_rows ? acc[r][1][e] * rs * gm1 + bt1 : 0.0f;
           }
         }
+      }
     } else {
 #pragma unroll
       for (int r = 0; r < NR; ++r)

@@ -11,6 +11,22 @@ from svdd_amd import backbone, config, fused
 
 torch.manual_seed(0)
 dev = "cuda"
+if "--time-only" in sys.argv:                    # ablation experiments: time of one mode, nothing else
+    import time as _t
+    mode = sys.argv[sys.argv.index("--time-only") + 1]
+    B, L = int(sys.argv[1]), int(sys.argv[2])
+    cnn = backbone.CNNModel((config.dna_config() if L > 104 else config.rna_config()).model, alphabet_size=5).to(dev).eval()
+    x = torch.randint(0, 5, (B, L), device=dev, dtype=torch.uint8)
+    pk = fused.pack_backbone(cnn) if mode == "f32" else fused.pack_backbone_lp(cnn, mode)
+    fn = (lambda: fused.backbone_cnn(x, pk)) if mode == "f32" else (lambda: fused.backbone_cnn_lp(x, pk))
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize(); t0 = _t.perf_counter()
+    for _ in range(20):
+        fn()
+    torch.cuda.synchronize()
+    print(f"{mode} B={B} L={L}: {(_t.perf_counter() - t0) / 20 * 1e3:.3f} ms")
+    sys.exit(0)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 L = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 cfg = config.dna_config() if L > 104 else config.rna_config()

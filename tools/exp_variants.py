@@ -55,7 +55,33 @@ TOWER_LP = {
 }
 TOWER_LP["variants"]["noA_noB"] = TOWER_LP["variants"]["noA"] + TOWER_LP["variants"]["noB"]
 TOWER_LP["variants"]["noA_noB_nomfma"] = TOWER_LP["variants"]["noA"] + TOWER_LP["variants"]["noB"] + TOWER_LP["variants"]["nomfma"]
-SETS = {"gru_lp": GRU_LP, "tower_lp": TOWER_LP}
+BB_LP = {
+    "file": "svdd_lp_backbone.hip",
+    "bench": ["python", "tools/backbone_lp_check.py", "256", "200", "--time-only", "f16x3"],
+    "variants": {
+        "baseline": [],
+        # LayerNorm statistics deleted: the image is written from f directly (still split + stored)
+        "nostats": [("    if (layer < nl) {\n      const float tb0 = vl[BB_C + c0], tb1 = vl[BB_C + c0 + 1];", "    if (layer < nl && a.n == 12345) {\n      const float tb0 = vl[BB_C + c0], tb1 = vl[BB_C + c0 + 1];")],
+        "nomfma": [("        acc[R][0] = Lp<T>::mfma(U[0], bc[0], acc[R][0]);                                                     \\\n        acc[R][1] = Lp<T>::mfma(U[0], bc[NPARTS], acc[R][1]);                                                \\",
+                    "        acc[R][0][0] += (float)U[0][0] * (float)bc[0][0];                                                    \\\n        acc[R][1][0] += (float)U[0][1] * (float)bc[NPARTS][0];                                               \\"),
+                   ("          acc[R][0] = Lp<T>::mfma(U[0], bc[1], acc[R][0]);                                                   \\\n          acc[R][1] = Lp<T>::mfma(U[0], bc[NPARTS + 1], acc[R][1]);                                          \\\n          acc[R][0] = Lp<T>::mfma(U[1], bc[0], acc[R][0]);                                                   \\\n          acc[R][1] = Lp<T>::mfma(U[1], bc[NPARTS], acc[R][1]);                                              \\",
+                    "          acc[R][0][1] += (float)U[1][0] * (float)bc[1][0];                                                  \\")],
+        "noA": [("        V[0] = *reinterpret_cast<const V8*>(plane + o_);                                                     \\\n        if constexpr (NP == 3) V[1] = *reinterpret_cast<const V8*>(plane + PLANE_B + o_); }",
+                 "        V[0] = bc[0]; (void)o_;                                                                              \\\n        if constexpr (NP == 3) V[1] = bc[1]; }")],
+        "noB": [("      if (nxt < it_end) {\n        const V8* src = wsrc + (size_t)tile_of(nxt) * TILE_V8;", "      if (nxt < it_end && a.n == 12345) {\n        const V8* src = wsrc + (size_t)tile_of(nxt) * TILE_V8;")],
+        "nofirst": [("            if (tk >= 0) v += Bs[(t * 5 + tk) * BB_C + col];", "            if (tk >= 12345) v += Bs[(t * 5 + tk) * BB_C + col];")],
+    },
+}
+BB_LP["variants"]["nodpp"] = [("  v += row_ror<8>(v); v += row_ror<4>(v); v += row_ror<2>(v); v += row_ror<1>(v);\n  return v;", "  return v;")]
+BB_LP["variants"]["nobar"] = [("          if (j == 0 && row < TW_ROWS) psum[cg * TW_ROWS + row] = sm;\n        }\n      __syncthreads();", "          if (j == 0 && row < TW_ROWS) psum[cg * TW_ROWS + row] = sm;\n        }"),
+                              ("          if (j == 0 && row < TW_ROWS) psum2[cg * TW_ROWS + row] = sq;     // second buffer: pass-1 partials may still be read\n        }\n      __syncthreads();", "          if (j == 0 && row < TW_ROWS) psum2[cg * TW_ROWS + row] = sq;\n        }")]
+BB_LP["variants"]["nopsumread"] = [("          const float mean = row < TW_ROWS ? ((psum[row] + psum[TW_ROWS + row]) + (psum[2 * TW_ROWS + row] + psum[3 * TW_ROWS + row])) * (1.0f / BB_C) : 0.0f;", "          const float mean = 0.01f * sa;"),
+                                   ("            const float rs = rsqrtf(((psum2[row] + psum2[TW_ROWS + row]) + (psum2[2 * TW_ROWS + row] + psum2[3 * TW_ROWS + row])) *\n                                    (1.0f / BB_C) + 1e-5f);", "            const float rs = 0.9f * sa;")]
+BB_LP["variants"]["nopsumwrite"] = [("          if (j == 0 && row < TW_ROWS) psum[cg * TW_ROWS + row] = sm;", "          if (j == 0 && row < TW_ROWS && sm == 12345.0f) psum[cg * TW_ROWS + row] = sm;"),
+                                    ("          if (j == 0 && row < TW_ROWS) psum2[cg * TW_ROWS + row] = sq;", "          if (j == 0 && row < TW_ROWS && sq == 12345.0f) psum2[cg * TW_ROWS + row] = sq;")]
+BB_LP["variants"]["nomfma_noA_noB"] = BB_LP["variants"]["nomfma"] + BB_LP["variants"]["noA"] + BB_LP["variants"]["noB"]
+BB_LP["variants"]["nostats_nomfma_noA_noB"] = BB_LP["variants"]["nostats"] + BB_LP["variants"]["nomfma_noA_noB"]
+SETS = {"gru_lp": GRU_LP, "tower_lp": TOWER_LP, "bb_lp": BB_LP}
 
 
 def build_variant(setname, name, spec):
