@@ -51,10 +51,11 @@ __global__ __launch_bounds__(512) void gru_lp_kernel(GruLpArgs a) {
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const bool producer = wv >= 4;
   const int w = wv & 3;
-  const int dir = blockIdx.y;
+  const int dir = blockIdx.x & 1;                                 // unit u = (tile u >> 1, direction u & 1): live units of a
+                                                                  // compacted batch form a dense prefix of the grid
   const int j = lane & 15, g = lane >> 4;
   const int n = a.count ? __builtin_amdgcn_readfirstlane(*a.count) : a.n;
-  const int seq0 = blockIdx.x * 16;
+  const int seq0 = (blockIdx.x >> 1) * 16;
   if (seq0 >= n) return;
   const int L = a.L;
   const int t0 = dir == 0 ? 0 : L - 1;
@@ -319,7 +320,7 @@ extern "C" int svdd_gru_bidir_lp(const float* x, const void* x16, const void* wp
   GruLpArgs a{x16 ? nullptr : x, x16, wpack, bpack, inv, out, n, L, count};
   hipEvent_t e0, e1;
   svdd_internal_timed_events(3, &e0, &e1);
-  const dim3 grid((unsigned)((n + 15) / 16), 2);
+  const dim3 grid(2 * (unsigned)((n + 15) / 16));
   switch (prec) {
     case SVDD_PREC_F16X3: hipExtLaunchKernelGGL((gru_lp_kernel<_Float16, 3>), grid, dim3(512), 0, (hipStream_t)stream, e0, e1, 0, a); break;
     case SVDD_PREC_BF16X3: hipExtLaunchKernelGGL((gru_lp_kernel<__bf16, 3>), grid, dim3(512), 0, (hipStream_t)stream, e0, e1, 0, a); break;

@@ -59,11 +59,14 @@ __global__ __launch_bounds__(BOTH ? 512 : 256) void gru_bidir_kernel(const float
   __shared__ __attribute__((aligned(16))) float hbuf_all[BOTH ? 2 : 1][2][TS][HPAD];
   const int lane = threadIdx.x & 63;
   const int w = (threadIdx.x >> 6) & 3;
-  const int dir = BOTH ? (int)(threadIdx.x >> 8) : (int)blockIdx.y;
+  // BOTH = false: unit u = blockIdx.x covers (tile u >> 1, direction u & 1), so that the units of a compacted batch are a
+  // dense prefix of the grid: the dispatcher hands consecutive workgroups to different CUs, and with the dead tiles
+  // interleaved (grid (tiles, 2)) 256 live units of 320 landed two to a CU on 32 CUs — 678 us instead of 368.
+  const int dir = BOTH ? (int)(threadIdx.x >> 8) : (int)(blockIdx.x & 1);
   float (*hbuf)[TS][HPAD] = hbuf_all[BOTH ? dir : 0];
   const int j = lane & 15;            // hidden unit within the wave's 16 / sequence row for A operands
   const int g = lane >> 4;            // k-group of A/B operands ; row-group of C/D
-  const int seq0 = blockIdx.x * ts;
+  const int seq0 = (BOTH ? (int)blockIdx.x : (int)(blockIdx.x >> 1)) * ts;
   // n_alloc: rows the output tensor is laid out for ; n: valid rows (device scalar when the batch was compacted)
   const int n = count ? __builtin_amdgcn_readfirstlane(*count) : n_alloc;
   if (seq0 >= n) return;
@@ -1473,9 +1476,15 @@ extern "C" int svdd_gru_bidir_f32(const float* x, const float* wpack, const floa
   if (g_gru_mode == 2 && per_cu <= TS && n >= 256)   // measured slower (841 vs 758 us at n=2560, L=200): opt-in only
     hipExtLaunchKernelGGL(gru_bidir_kernel<true>, dim3((unsigned)((n + per_cu - 1) / per_cu)), dim3(512), 0,
                           (hipStream_t)stream, e0, e1, 0, x, wpack, bpack, out, n, L, per_cu, count);
-  else
-    hipExtLaunchKernelGGL(gru_bidir_kernel<false>, dim3((unsigned)((n + TS - 1) / TS), 2), dim3(256), 0,
+  else {
+    // (Reserving > 80 KB of dynamic LDS to force one workgroup per CU was measured: 2560 sequences = 320 units take
+    //  749 us in two exclusive rounds against 678 us shared, and <= 256 units spread over the CUs by themselves: 367 us
+    //  either way. Kept as mode 3 for the record.)
+    const size_t pad = g_gru_mode == 3 ? 84 * 1024 : 0;
+    if (pad) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gru_bidir_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
+    hipExtLaunchKernelGGL(gru_bidir_kernel<false>, dim3(2 * (unsigned)((n + TS - 1) / TS)), dim3(256), pad,
                           (hipStream_t)stream, e0, e1, 0, x, wpack, bpack, out, n, L, TS, count);
+  }
   return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
 }
 
