@@ -61,9 +61,42 @@ def host_cpu():
     return model, os.cpu_count()
 
 
-def cpu_baseline(B, L, M, S, sample_steps, seed=44, threads=16):
+def sampler_saturated(dev, L=200, M=10, B=16384, masked_frac=0.5, iters=10):
+    """K1 (propose) at a size that leaves launch latency behind (B*M*L = 32.8 M candidate tokens, 626 MB per launch):
+    the HBM fraction the north star quotes for the resample kernel is only measurable there (SURVEY.md section 7
+    "launch-bound inner loop"). Same kernel, same arguments as in the decode; HIP events bound to each dispatch."""
+    from svdd_amd import _lib, ops
+    g = torch.Generator(device=dev).manual_seed(0)
+    logits = torch.randn(B, 5, L, device=dev, generator=g).transpose(1, 2)          # the CNN backbone's memory image
+    x = torch.where(torch.rand(B, L, device=dev, generator=g) < masked_frac, 4,
+                    torch.randint(0, 4, (B, L), device=dev, generator=g)).to(torch.uint8)
+    cand = torch.empty(B, M, L, dtype=torch.uint8, device=dev)
+    onehot = torch.empty(B * M, L, 4, device=dev)
+    rng = ops.Rng(seed=1, step=64)
+    for _ in range(3):
+        ops.propose(logits, x, 0.0078, 0.5, M, rng, cand=cand, onehot=onehot)
+    torch.cuda.synchronize()
+    _lib.profile_enable(True)
+    for _ in range(iters):
+        ops.propose(logits, x, 0.0078, 0.5, M, rng, cand=cand, onehot=onehot)
+    torch.cuda.synchronize()
+    _lib.profile_enable(False)
+    tot, n = _lib.profile_collect(0)
+    nbytes = B * L * (21 + 17 * M)
+    gbs = nbytes / (tot / n * 1e-3) / 1e9
+    del cand, onehot, logits
+    torch.cuda.empty_cache()
+    return {"bound": "hbm", "kernel": "propose_kernel (K1), saturated", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5), "bytes_per_launch": nbytes, "traffic": None,
+            "avg_launch_us": round(tot / n * 1e3, 2), "launches": n,
+            "workload": f"B={B} L={L} M={M}, {masked_frac:.0%} of the positions masked, Philox"}
+
+
+def cpu_baseline(B, L, M, S, sample_steps, seed=44, threads=16, states=None):
     """Oracle (CPU port of the reference path: M value-net calls of batch B per step, like
-    diffusion_gosai.py:1207-1209) on `sample_steps` diffusion steps of the same workload.
+    diffusion_gosai.py:1207-1209) on `sample_steps` diffusion steps of the same workload. `states`: the x_t of every
+    step of a GPU decode of this very workload — the sampled steps then run on the real states of the trajectory
+    (real masked fractions, real tokens) rather than on synthetic ones.
     16 torch threads: the fastest setting on the GPU box's host (2 x EPYC 9575F; 8/16/32/64/128 threads
     measured 0.63/0.36/0.53/0.73/1.68 s per backbone forward, tools/exp_cpu_threads.py)."""
     from oracle import svdd_oracle as orc
@@ -79,9 +112,11 @@ def cpu_baseline(B, L, M, S, sample_steps, seed=44, threads=16):
     rng = np.random.default_rng(0)
     t_steps = []
     for i in picks:
-        # a state with the masked fraction step i would see (move chance ~ t_i)
-        frac = 1.0 - i / S
-        x = np.where(rng.random((B, L)) < frac, orc.MASK, rng.integers(0, 4, (B, L))).astype(np.uint8)
+        if states is not None:
+            x = states[int(i)]
+        else:                      # a state with the masked fraction step i would see (move chance ~ t_i)
+            frac = 1.0 - i / S
+            x = np.where(rng.random((B, L)) < frac, orc.MASK, rng.integers(0, 4, (B, L))).astype(np.uint8)
         t0 = time.perf_counter()
         with torch.no_grad():
             logits = bb(torch.from_numpy(x.astype(np.int64))).contiguous().numpy()
@@ -102,8 +137,9 @@ def cpu_baseline(B, L, M, S, sample_steps, seed=44, threads=16):
         "value": round(B / per_decode, 4), "unit": "sequences/s", "cores": threads,
         "cpu_model": cpu_model, "cores_total": cpu_total,
         "kind": "port",
-        "sample": f"{sample_steps} of {S} diffusion steps at full batch (B={B}, L={L}, M={M}) + the noise-removal "
-                  f"forward, extrapolated to one decode; {sum(t_steps) + t_final:.1f} s of CPU work",
+        "sample": f"{sample_steps} of {S} diffusion steps (evenly spaced, on the {'states of a GPU decode of this workload' if states is not None else 'synthetic states'}) "
+                  f"at full batch (B={B}, L={L}, M={M}) + the noise-removal forward, scaled by {S}/{sample_steps} to one decode; "
+                  f"{sum(t_steps) + t_final:.1f} s of CPU work",
     }
 
 
@@ -289,16 +325,25 @@ def main():
                                           "conv1d": round(conv_total_ms, 2), "gru": round(gru_total_ms, 2),
                                           "epilogue_ln": round(epi_total_ms, 2),
                                           "propose": round(k1_total_ms, 3), "select": round(k2_total_ms, 3)},
+            # reference-equivalent FLOPs (every candidate through every net) per second over the fp32 peak:
+            # a throughput normalisation, not a utilisation — exact work-skipping executes fewer FLOPs than that
             "e2e_fp32_frac": round(flops_seq * seqs / elapsed / 1e12 / (FP32_PEAK_TFLOPS * world), 5),
             "alt_precision": alt or None,
         }
         if per_rank:
             line["per_rank"] = per_rank
+        if world == 1 and args.value_net == "convgru":
+            line["roofline_sampler_saturated"] = sampler_saturated(dev, L=L, M=M)
         if args.value_net != "convgru":
             line["config"]["workload"] += " [value net: Enformer-shaped trunk, 230M params — BASELINE configs[3] shape]"
             line["e2e_fp32_frac"] = None
         if args.cpu_steps > 0 and world == 1 and args.value_net == "convgru":
-            line["cpu_baseline"] = cpu_baseline(B, L, M, S, args.cpu_steps)
+            model.state_trace = []                                  # one extra (untimed) decode: the trajectory's states
+            model.controlled_sample(emb, head, num_steps=S, eval_sp_size=B, sample_M=M)
+            torch.cuda.synchronize()
+            states = [x.cpu().numpy() for x in model.state_trace]
+            model.state_trace = None
+            line["cpu_baseline"] = cpu_baseline(B, L, M, S, args.cpu_steps, states=states)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line))

@@ -172,3 +172,30 @@ def test_philox_known_answer():
     want = [(w >> 8) / 16777216.0 for w in words]
     want.append(((words[0] & 0xFF) | ((words[1] & 0xFF) << 8) | ((words[2] & 0xFF) << 16)) / 16777216.0)
     assert np.array_equal(u, np.array(want, dtype=np.float32))
+
+
+@pytest.mark.parametrize("M", [2, 10, 16, 20])
+@pytest.mark.parametrize("kind", ["random", "ties", "ulp"])
+def test_select_matches_torch_softmax_argmax_up_to_M20(M, kind):
+    """`argmax(softmax(scores, dim=1), dim=1)` (reference diffusion_gosai.py:1219-1225) as torch's CPU kernels compute it,
+    against the oracle's restatement, at the sample widths the reference is run with (M = 10 default, 20 in
+    BASELINE.json configs[3]) — the committed reference trajectories only have M <= 5. ATen reduces the normaliser with a
+    vectorised tree, the oracle left to right: from M = 16 on the SOFT VALUES differ in the last bit in about half of
+    the rows (never by more than 1e-6, far inside the north star's 1e-4); the SELECTION must not differ, including on
+    exact ties and on scores one ulp apart, where the first-index rule and the rounding of e * (1 / sum) decide."""
+    import torch
+    rng = np.random.default_rng(M)
+    B = 20000
+    if kind == "random":
+        s = (rng.standard_normal((B, M)) * 0.01).astype(np.float32)
+    elif kind == "ties":
+        s = rng.integers(-2, 3, (B, M)).astype(np.float32) * np.float32(0.125)
+    else:
+        base = np.repeat((rng.standard_normal((B, 1)) * 0.3).astype(np.float32), M, 1)
+        jit = rng.integers(-1, 2, (B, M))
+        s = np.where(jit == 1, np.nextafter(base, np.float32(10)),
+                     np.where(jit == -1, np.nextafter(base, np.float32(-10)), base)).astype(np.float32)
+    _, soft, idx = orc.select(s, np.zeros((B, M, 4), np.uint8))
+    tp = torch.softmax(torch.from_numpy(s), dim=1)
+    assert np.array_equal(idx, tp.argmax(dim=1).numpy())
+    assert np.abs(soft - tp.numpy()).max() <= 1e-6
