@@ -513,6 +513,8 @@ class Diffusion(nn.Module):
             self.row_count = torch.zeros(1, **i32)
             self.parent_score, self.sel_score = torch.empty(B, device=dev), torch.empty(B, device=dev)
             self.changed, self.idx = torch.empty(B, **i32), torch.empty(B, **i32)
+            self.parent_out, self.parent_out_lp, self.seq = None, None, None   # the parents' tower output (FusedValueNet)
+            self.M = M
             self.n_live = torch.zeros(1, dtype=torch.int64, device=dev)
             self.n_changed = torch.zeros(1, dtype=torch.int64, device=dev)
 
@@ -526,6 +528,8 @@ class Diffusion(nn.Module):
         x_next, _, _, _ = ops.select_compact(sc, ws.slot, ws.parent_score, cand, mode=mode, rng=rng, sel_score=ws.sel_score,
                                              changed=ws.changed, idx=ws.idx)
         ws.parent_score, ws.sel_score = ws.sel_score, ws.parent_score       # the selected candidate is the next parent
+        if ws.parent_out is not None and ws.seq is not None:                # ... and so is its tower output
+            ops.advance_rows(ws.seq, ws.slot, ws.idx, ws.parent_out, ws.M)
         if self.skip_stats is not None:
             ws.n_live += ws.count
             ws.n_changed += ws.changed.sum()

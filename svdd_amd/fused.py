@@ -540,16 +540,25 @@ class FusedValueNet(nn.Module):
         B, M, L = cand.shape
         win = candidate_windows(cand, x, flags=ws.flags)
         ops.compact_flags(ws.flags, ws.live_idx, ws.slot, ws.count)
-        if self.precision != "f32":
+        # The parents' tower output is carried from step to step: the next parent IS the selected candidate, whose tower
+        # output this step computes (bit-identical to a full tower pass on it) — ws.advance_parent copies it over after
+        # the select. Only the first step runs the tower on the parents.
+        lp = self.precision != "f32"
+        if ws.parent_out is None or ws.parent_out_lp != self.precision:
+            if lp:
+                pk = self._lp_pack()
+                ws.parent_out = conv_tower_lp(x, pk["tiles"], self.tw_bias, pk["tinv"], self.tw_resmask, pk["prec"])
+            else:
+                ws.parent_out = conv_tower(ops.transform_samples(x), self.tw_tiles, self.tw_bias, self.tw_resmask)
+            ws.parent_out_lp = self.precision
+        if lp:
             pk = self._lp_pack()
-            parent_out = conv_tower_lp(x, pk["tiles"], self.tw_bias, pk["tinv"], self.tw_resmask, pk["prec"])
-            seq = conv_tower_windows_lp(cand, win, parent_out, pk["tiles"], self.tw_bias, pk["tinv"], self.tw_resmask,
-                                        pk["prec"], live_idx=ws.live_idx, count=ws.count)
-            return self._after_tower_lp(seq, pk, ws.count)[:, :, 0]
-        parent_out = conv_tower(ops.transform_samples(x), self.tw_tiles, self.tw_bias, self.tw_resmask)
-        seq = conv_tower_windows(onehot, win, parent_out, M, self.tw_tiles, self.tw_bias, self.tw_resmask,
-                                 live_idx=ws.live_idx, count=ws.count)
-        return self._after_tower(seq, B * M, L, ws.count)[:, :, 0]
+            ws.seq = conv_tower_windows_lp(cand, win, ws.parent_out, pk["tiles"], self.tw_bias, pk["tinv"], self.tw_resmask,
+                                           pk["prec"], live_idx=ws.live_idx, count=ws.count)
+            return self._after_tower_lp(ws.seq, pk, ws.count)[:, :, 0]
+        ws.seq = conv_tower_windows(onehot, win, ws.parent_out, M, self.tw_tiles, self.tw_bias, self.tw_resmask,
+                                    live_idx=ws.live_idx, count=ws.count)
+        return self._after_tower(ws.seq, B * M, L, ws.count)[:, :, 0]
 
     def _after_tower_lp(self, seq, pk, count=None):
         h = gru_bidir_lp(seq, pk["gw"], pk["gb"], pk["ginv"], pk["prec"], count=count)
