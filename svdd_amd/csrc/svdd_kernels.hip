@@ -164,23 +164,27 @@ __global__ __launch_bounds__(256) void propose_kernel(ProposeArgs a) {
   const uint32_t wave_global = blockIdx.x * 4u + (threadIdx.x >> 6);
   const uint32_t nwaves = gridDim.x * 4u;
   uint32_t n_draws = 0, n_exact = 0;
+  __shared__ float prm[4][12 * WAVE];          // per wave, by rank of the masked position: q~[5], margin, owner lane, z[5]
+  __shared__ uint8_t tokl[4][WAVE][WAVE];      // per wave: drawn tokens [candidate of the chunk][lane of the position]
+  const int wv = threadIdx.x >> 6;
 
   for (uint32_t unit = wave_global; unit < nunits; unit += nwaves) {
     const uint32_t tile = unit / (uint32_t)a.msplit;
     const int s0 = (int)(unit - tile * (uint32_t)a.msplit);
     const uint32_t n = tile * WAVE + lane;
-    if (n >= N) continue;
-    const uint32_t b = n / (uint32_t)a.L;
-    const uint32_t l = n - b * (uint32_t)a.L;
+    const bool valid = n < N;                 // lanes past the end of the batch stay in the loop: they take draws too
+    const uint32_t nn = valid ? n : N - 1;
+    const uint32_t b = nn / (uint32_t)a.L;
+    const uint32_t l = nn - b * (uint32_t)a.L;
 
     // issue the token and logit loads together (the logits of an unmasked position are simply unused)
-    const int xt = a.x[n];
+    const int xt = a.x[nn];
     float z[V];
 #pragma unroll
     for (int v = 0; v < V; ++v) z[v] = a.logits[at(a.layout, b, l, v, a.L)];
-    const bool masked = xt == MASK;
+    const bool masked = valid && xt == MASK;
 
-    if (!QGIVEN && a.q_xs && s0 == 0) {       // per-step API only: q_xs is returned to the caller (:1228)
+    if (!QGIVEN && a.q_xs && s0 == 0 && valid) {       // per-step API only: q_xs is returned to the caller (:1228)
       float q[V];
       q_exact(z, xt, a.dm, a.mcs, q);
 #pragma unroll
@@ -211,52 +215,97 @@ __global__ __launch_bounds__(256) void propose_kernel(ProposeArgs a) {
         margin = 1.0f - (1.52587890625e-05f + 3.814697265625e-06f * fabsf(lse));
       }
     }
-    const uint64_t pos = (a.row_offset + (uint64_t)b) * (uint64_t)a.L + (uint64_t)l;
     const uint64_t obase = (uint64_t)b * (uint64_t)a.M * (uint64_t)a.L + l;
 
-    for (int m = s0; m < a.M; m += a.msplit) {
-      int c = xt;
-      if (masked) {
-        float u[V];
-        if (REPLAY) {
-          const float* ub = a.uniforms + (uint64_t)m * N * V;
+    // ---- the draws, on ALL 64 lanes. Only the masked positions of the tile draw anything (an unmasked one copies its
+    // token, :1203), and over a decode half of the positions are unmasked: with lane = position those lanes idle through
+    // the ~550 issue cycles of a draw (one Philox block + 5 log + 5 rcp). So the masked positions park their parameters
+    // in LDS by rank, the (masked position, candidate) pairs are dealt densely to the lanes, and the drawn tokens come
+    // back through an LDS byte table to the lane that owns the position, which stores them coalesced as before. Which
+    // lane draws a token does not matter: the Philox counter is keyed by (global position, step, m).
+    const unsigned long long bal = __ballot(masked);
+    const int k = __popcll(bal);                                         // masked positions in this tile
+    const int rank = __popcll(bal & ((1ull << lane) - 1ull));
+    float* pw = prm[wv];
+    if (masked) {
 #pragma unroll
-          for (int v = 0; v < V; ++v) u[v] = ub[at(a.ulayout, b, l, v, a.L)];
-        } else {
-          philox_uniform5(a.seed, pos, a.step, (uint32_t)m, u);
-        }
-        bool decided = false;
-        if (fast_ok) {
-          float best = -1.0f, second = -1.0f;
-          int bi = 0;
+      for (int v = 0; v < V; ++v) { pw[v * WAVE + rank] = qf[v]; pw[(7 + v) * WAVE + rank] = z[v]; }
+      pw[5 * WAVE + rank] = fast_ok ? margin : -1.0f;                    // < 0: this position always takes the exact path
+      pw[6 * WAVE + rank] = __int_as_float(lane);
+    }
+    const int Mloc = (a.M - s0 + a.msplit - 1) / a.msplit;               // candidates of this unit: m = s0 + i * msplit
+    for (int mc = 0; mc < Mloc; mc += WAVE) {                            // chunks of 64 candidates (token table size)
+      const int Mc = min(WAVE, Mloc - mc);
+      const int T = k * Mc;
+      const float inv_mc = 1.0f / (float)Mc;
+      for (int base = 0; base < T; base += WAVE) {
+        const int wi = base + lane;
+        if (wi < T) {
+          int p = (int)(((float)wi + 0.5f) * inv_mc);                    // wi / Mc (T <= 4096: exact in fp32)
+          int mi = wi - p * Mc;
+          if (mi < 0) { --p; mi += Mc; } else if (mi >= Mc) { ++p; mi -= Mc; }
+          const int m = s0 + (mc + mi) * a.msplit;
+          const int src = __float_as_int(pw[6 * WAVE + p]);              // the lane that owns this position
+          const float mg = pw[5 * WAVE + p];
+          float qv[V];
 #pragma unroll
-          for (int v = 0; v < V; ++v) {
-            const float g = 1e-10f - log_fast(u[v] + 1e-10f);
-            const float r = qf[v] * __builtin_amdgcn_rcpf(g);
-            if (r > best) { second = best; best = r; bi = v; }
-            else if (r > second) second = r;
-          }
-          decided = (best > 1e-30f) && (second < best * margin);
-          c = bi;
-        }
-        ++n_draws;
-        if (!decided) {                        // rare (~1e-6 of draws): exact arithmetic for this lane
-          ++n_exact;
-          if (QGIVEN) {
-            c = sample_categorical_1(z, u);
+          for (int v = 0; v < V; ++v) qv[v] = pw[v * WAVE + p];
+          const uint32_t nsrc = tile * WAVE + (uint32_t)src;
+          const uint32_t bs = nsrc / (uint32_t)a.L, ls = nsrc - bs * (uint32_t)a.L;
+          float u[V];
+          if (REPLAY) {
+            const float* ub = a.uniforms + (uint64_t)m * N * V;
+#pragma unroll
+            for (int v = 0; v < V; ++v) u[v] = ub[at(a.ulayout, bs, ls, v, a.L)];
           } else {
-            float q[V];
-            q_exact(z, xt, a.dm, a.mcs, q);
-            c = sample_categorical_1(q, u);
+            philox_uniform5(a.seed, (a.row_offset + (uint64_t)bs) * (uint64_t)a.L + (uint64_t)ls, a.step, (uint32_t)m, u);
           }
+          int c = 0;
+          bool decided = false;
+          if (mg >= 0.0f) {
+            float best = -1.0f, second = -1.0f;
+            int bi = 0;
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+              const float g = 1e-10f - log_fast(u[v] + 1e-10f);
+              const float r = qv[v] * __builtin_amdgcn_rcpf(g);
+              if (r > best) { second = best; best = r; bi = v; }
+              else if (r > second) second = r;
+            }
+            decided = (best > 1e-30f) && (second < best * mg);
+            c = bi;
+          }
+          ++n_draws;
+          if (!decided) {                        // rare (~1e-6 of draws): exact arithmetic for this draw
+            ++n_exact;
+            float zs[V];
+#pragma unroll
+            for (int v = 0; v < V; ++v) zs[v] = pw[(7 + v) * WAVE + p];
+            if (QGIVEN) {
+              c = sample_categorical_1(zs, u);
+            } else {
+              float q[V];
+              q_exact(zs, MASK, a.dm, a.mcs, q);
+              c = sample_categorical_1(q, u);
+            }
+          }
+          tokl[wv][mi][src] = (uint8_t)c;
         }
       }
-      const uint64_t o = obase + (uint64_t)m * (uint64_t)a.L;
-      a.cand[o] = (uint8_t)c;
-      float4 oh;
-      oh.x = (c == 0) ? 1.0f : 0.0f; oh.y = (c == 1) ? 1.0f : 0.0f;
-      oh.z = (c == 2) ? 1.0f : 0.0f; oh.w = (c == 3) ? 1.0f : 0.0f;
-      reinterpret_cast<float4*>(a.onehot)[o] = oh;                 // transform_samples, :1462-1470
+      // coalesced write-out: lane = position again
+      for (int mi = 0; mi < Mc && valid; ++mi) {
+        const int m = s0 + (mc + mi) * a.msplit;
+        const int c = masked ? (int)tokl[wv][mi][lane] : xt;
+        const uint64_t o = obase + (uint64_t)m * (uint64_t)a.L;
+        a.cand[o] = (uint8_t)c;
+        typedef float f32x4_t __attribute__((ext_vector_type(4)));
+        f32x4_t oh;
+        oh[0] = (c == 0) ? 1.0f : 0.0f; oh[1] = (c == 1) ? 1.0f : 0.0f;
+        oh[2] = (c == 2) ? 1.0f : 0.0f; oh[3] = (c == 3) ? 1.0f : 0.0f;
+        // transform_samples, :1462-1470. Streaming store: the one-hot is 94 % of the bytes K1 moves and is read once, by
+        // another kernel
+        __builtin_nontemporal_store(oh, reinterpret_cast<f32x4_t*>(a.onehot) + o);
+      }
     }
   }
   if (a.stats) {                               // soak / profiling only (wave-uniform branch)
