@@ -274,3 +274,60 @@ def test_mc_decode_with_dit_backbone(small_nets):
             uf = lambda i, M_, B_, L_: torch.rand(M_, B_, L_, 5).numpy()      # noqa: E731  contiguous logits: row-major stream
         x_orc = orc.replay_controlled_sample(trace, sched, B, L, M, uniform_fn=uf, seed=21)
         assert np.array_equal(x_gpu, x_orc)
+
+
+def test_fused_net_cache_follows_weight_changes():
+    """The fused formulations hold re-packed COPIES of the weights, keyed on weak references to the modules plus a weight
+    fingerprint (data pointer, in-place version): training the value function between decodes, load_state_dict, or a new
+    module that happens to reuse a collected one's id() must never be scored with stale weights."""
+    import gc
+    from svdd_amd import synthetic
+    model, emb, head, _ = synthetic.build("dna", DEV)
+    x = torch.randint(0, 5, (8, 200), device=DEV, dtype=torch.uint8)
+    oh = model.transform_samples(x.long()).float()
+    with torch.no_grad():
+        f1 = model.value_callable(emb, head)
+        a = f1(oh).clone()
+        assert model.value_callable(emb, head) is f1                        # cached
+        head.channel_transform.conv.layer.bias.add_(0.25)                   # in-place weight change
+        f2 = model.value_callable(emb, head)
+        assert f2 is not f1
+        assert torch.allclose(f2(oh), a + 0.25, atol=1e-5)                  # the head bias shifts every score by 0.25
+        lg0 = model._backbone_logits(x).clone()
+        sd = {k: v.clone() for k, v in model.backbone.state_dict().items()}
+        model.backbone.final_conv[2].bias.add_(1.0)
+        assert torch.allclose(model._backbone_logits(x), lg0 + 1.0, atol=1e-5)
+        model.backbone.load_state_dict(sd)                                  # back: copy_ bumps the versions again
+        assert torch.equal(model._backbone_logits(x), lg0)
+        # modules that die must not leave their entries behind for an id() twin
+        n_before = len(model._fused)
+        _, emb2, head2, _ = synthetic.build("dna", DEV, seed=7)
+        model.value_callable(emb2, head2)
+        del emb2, head2
+        gc.collect()
+        _, emb3, head3, _ = synthetic.build("dna", DEV, seed=9)
+        model.value_callable(emb3, head3)
+        assert len(model._fused) <= n_before + 1
+
+
+def test_per_step_api_draws_fresh_uniforms_every_step():
+    """Driving the per-step API in Philox mode (the reference's loop body, diffusion_gosai.py:1041-1047): the Philox
+    counter follows t, so a position that stays MASK sees different noise at every step, and the per-step loop
+    reproduces controlled_sample."""
+    from svdd_amd import synthetic
+    model, emb, head, _ = synthetic.build("rna", DEV)
+    model.rng_mode, model.philox_seed = "philox", 31
+    B, L, S, M = 6, 50, 16, 3
+    eps = 1e-5
+    ts = torch.linspace(1, eps, S + 1, device=DEV)
+    dt = (1 - eps) / S
+    x = torch.full((B, L), 4, dtype=torch.int64, device=DEV)
+    x1, _, _, _ = model._ddpm_update_finetune(x, ts[0] * torch.ones(B, 1, device=DEV), dt)
+    x2, _, _, _ = model._ddpm_update_finetune(x, ts[1] * torch.ones(B, 1, device=DEV), dt)   # same state, next step
+    x1b, _, _, _ = model._ddpm_update_finetune(x, ts[0] * torch.ones(B, 1, device=DEV), dt)
+    assert torch.equal(x1, x1b) and not torch.equal(x1, x2)
+    ref = model.controlled_sample(emb, head, num_steps=S, eval_sp_size=B, sample_M=M)
+    xs = torch.full((B, L), 4, dtype=torch.int64, device=DEV)
+    for i in range(S):
+        xs, _, _, _ = model._ddpm_update_finetune_controlled(xs, ts[i] * torch.ones(B, 1, device=DEV), dt, emb, head, repeats=M)
+    assert torch.equal(model._noise_removal(xs.to(torch.uint8)), ref)

@@ -177,3 +177,49 @@ def test_detokenizer_roundtrip():
     assert tokens.dna_detokenize(x[0]) == "ACGTTA"
     assert tokens.DNASequenceDetokenizer().detokenize(x)[1] == "TTNACG"
     assert tokens.dna_tokenize("acgtn").tolist() == [0, 1, 2, 3, 4]
+
+
+def test_sharded_sample_refuses_replay_rng_across_ranks():
+    """Replay mode draws from each process's own mt19937 stream: with the usual identical manual_seed every rank would decode
+    the same rows. sharded_sample must refuse it for world > 1 (and accept it for a single rank)."""
+    from svdd_amd import distributed
+
+    class M:
+        rng_mode, row_offset = "replay", 0
+    m = M()
+    with pytest.raises(ValueError, match="philox"):
+        distributed.sharded_sample(m, 8, lambda **kw: None, rank=0, world=2)
+    out = distributed.sharded_sample(m, 8, lambda eval_sp_size: torch.zeros(eval_sp_size, 3, dtype=torch.uint8), rank=0, world=1)
+    assert out.shape == (8, 3) and m.row_offset == 0
+    m.rng_mode = "philox"
+    seen = []
+    distributed.sharded_sample(m, 10, lambda eval_sp_size: seen.append((m.row_offset, eval_sp_size)) or torch.zeros(eval_sp_size, 3, dtype=torch.uint8),
+                               rank=2, world=3)
+    assert seen == [(7, 3)] and m.row_offset == 0          # rows 7..9 of 10 belong to rank 2 of 3
+
+
+def test_step_index_of_the_per_step_api():
+    """The per-step methods receive (t, dt) like the reference's (diffusion_gosai.py:1036-1043: t_i = 1 - i dt); the step
+    index derived from them keys the Philox counter, so consecutive steps never reuse a draw."""
+    from svdd_amd.config import dna_config
+    from svdd_amd.diffusion import Diffusion
+    d = Diffusion(dna_config(hidden_dim=16, num_cnn_stacks=1))
+    S, eps = 128, 1e-5
+    ts = torch.linspace(1, eps, S + 1)
+    dt = (1 - eps) / S
+    assert [d._step_index(ts[i] * torch.ones(4, 1), dt) for i in (0, 1, 2, 63, 127)] == [0, 1, 2, 63, 127]
+
+
+def test_weight_fingerprint_tracks_in_place_and_replaced_weights():
+    from svdd_amd.diffusion import weight_fingerprint
+    lin = torch.nn.Linear(4, 4)
+    fp0 = weight_fingerprint(lin)
+    assert weight_fingerprint(lin) == fp0
+    with torch.no_grad():
+        lin.weight.mul_(2.0)                                 # in-place update (optimizer step, load_state_dict copy_)
+    fp1 = weight_fingerprint(lin)
+    assert fp1 != fp0
+    lin.load_state_dict({k: v.clone() for k, v in lin.state_dict().items()})
+    assert weight_fingerprint(lin) != fp1
+    lin.weight = torch.nn.Parameter(lin.weight.detach().clone())   # replaced tensor
+    assert weight_fingerprint(lin) != fp1
