@@ -331,3 +331,26 @@ def test_per_step_api_draws_fresh_uniforms_every_step():
     for i in range(S):
         xs, _, _, _ = model._ddpm_update_finetune_controlled(xs, ts[i] * torch.ones(B, 1, device=DEV), dt, emb, head, repeats=M)
     assert torch.equal(model._noise_removal(xs.to(torch.uint8)), ref)
+
+
+def test_whole_decode_is_graph_capturable():
+    """with Philox and the device-side work-skipping there is no host round trip inside the
+    diffusion loop, so a whole controlled_sample captures into one HIP graph; a replay reproduces the eager tokens.
+    (It is not enabled by default: profiles/r02_graph_probe.txt — replay and eager take the same time at B = 4..256.)"""
+    from svdd_amd import synthetic
+    model, emb, head, _ = synthetic.build("dna", DEV)
+    model.rng_mode, model.philox_seed = "philox", 5
+    run = lambda: model.controlled_sample(emb, head, num_steps=12, eval_sp_size=5, sample_M=4)   # noqa: E731
+    ref = run()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        run()
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = run()
+    for _ in range(2):
+        g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
