@@ -56,7 +56,7 @@ def build(force=False):
         return SO_PATH                                   # an explicitly chosen build is used as it is
     stale = not os.path.exists(SO_PATH) or os.path.getmtime(SO_PATH) < max(os.path.getmtime(f) for f in srcs)
     if force or stale:
-        subprocess.check_call(["make", "-C", CSRC, "-B"])
+        subprocess.check_call(["make", "-C", CSRC, "-B", "-j", str(min(5, os.cpu_count() or 1))])   # 5 translation units
     return SO_PATH
 
 

@@ -354,3 +354,28 @@ def test_whole_decode_is_graph_capturable():
         g.replay()
     torch.cuda.synchronize()
     assert torch.equal(out, ref)
+
+
+def test_tds_config5_size_equals_oracle_loop_on_the_gpu_nets():
+    """BASELINE.json configs[4] shape (TDS / SMC, one population of B = 2048 particles, L = 200): the engine's
+    controlled_sample_TDS against the CPU oracle's outer loop (propose, x0-hat, numpy-order resampling, finalize) driven by
+    the SAME GPU nets (fused backbone + fused reward net) and the same torch / numpy RNG streams — every token equal."""
+    from svdd_amd import synthetic
+    model, _, _, reward = synthetic.build("dna", DEV)
+    B, L, S, alpha = 2048, 200, 4, 0.5
+    sched = model._schedule(S, 1e-5)[0]
+    model.rng_mode = "replay"
+    torch.manual_seed(21)
+    np.random.seed(22)
+    x_gpu = model.controlled_sample_TDS(reward, alpha, num_steps=S, eval_sp_size=B).cpu().numpy()
+
+    rf = model.reward_callable(reward)
+    bb = lambda x: model._backbone_logits(x.to(DEV).to(torch.uint8)).cpu()                      # noqa: E731
+    rw = lambda oh: rf(oh.to(DEV))[:, 0].cpu()                                                  # noqa: E731
+    torch.manual_seed(21)
+    np.random.seed(22)
+    us = [np.random.random_sample(B) for _ in range(S)]
+    uf = lambda i, M_, B_, L_: torch.rand(M_, B_, 5, L_).numpy().transpose(0, 1, 3, 2).copy()   # noqa: E731
+    x_orc = orc.controlled_sample_tds(bb, rw, sched, alpha, B, L, uf, lambda i, B_: us[i])
+    assert x_gpu.shape == (B, L) and int(x_gpu.max()) <= 3
+    assert np.array_equal(x_gpu, x_orc)

@@ -143,6 +143,18 @@ def test_mc_decode_config2_skipping_is_bit_identical(precision):
     model.precision = "f32"
 
 
+def test_mc_decode_config4_shard_skipping_is_bit_identical():
+    """BASELINE.json configs[3] per-GPU shard (SVDD-MC, B = 2048 / 8 = 256, L = 200, M = 20), ConvGRU value net."""
+    from svdd_amd import synthetic
+    model, emb, head, reward = synthetic.build("dna", DEV)
+    model.rng_mode, model.philox_seed, model.row_offset = "philox", 3, 5 * 256          # the 6th rank's rows
+    off, _, _ = _decode(model, "mc", emb, head, reward, 256, 20, 128, skip=False)
+    on, _, st = _decode(model, "mc", emb, head, reward, 256, 20, 128, skip=True)
+    model.row_offset = 0
+    assert torch.equal(on, off) and int(on.max()) <= 3
+    assert st["live_candidates"] < st["candidates"]
+
+
 def test_mc_decode_skipping_trace_is_bit_identical():
     """Every step's logits and [B, M] scores, not just the final tokens (replay mode, so the uniforms are the reference's)."""
     from svdd_amd import synthetic
