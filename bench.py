@@ -168,8 +168,12 @@ def main():
 
     rank, world, local = distributed.init_from_env()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    local = local % max(torch.cuda.device_count(), 1)        # (dry runs with more ranks than GPUs share devices)
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
+    nccl = world > 1 and dist.get_backend() == "nccl"
+    barrier = (lambda: dist.barrier(device_ids=[local])) if nccl else (lambda: dist.barrier())
+    to_dist = (lambda t: t) if (world == 1 or nccl) else (lambda t: t.cpu())      # gloo dry run: collectives on host tensors
     B, L, M, S = args.batch, args.length, args.sample_M, args.diffusion_steps
 
     model, emb, head, _ = synthetic.build("dna" if L == 200 else "rna", dev, value=args.value_net)
@@ -191,7 +195,7 @@ def main():
 
     def fence():
         if world > 1:
-            dist.barrier(device_ids=[local])
+            barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -217,11 +221,11 @@ def main():
     assert out.shape == (B * world, L) and int(out.max()) <= 3
     per_rank = None
     if world > 1:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tmax = to_dist(torch.tensor([elapsed], device=dev, dtype=torch.float64))
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-        mine = torch.tensor([sum(t[0] for t in rank_times) / len(rank_times), sum(t[1] for t in rank_times) / len(rank_times)],
-                            device=dev, dtype=torch.float64)
+        mine = to_dist(torch.tensor([sum(t[0] for t in rank_times) / len(rank_times), sum(t[1] for t in rank_times) / len(rank_times)],
+                                    device=dev, dtype=torch.float64))
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         per_rank = {"decode_ms": [round(float(t[0]) * 1e3, 2) for t in allr],
@@ -249,7 +253,7 @@ def main():
         _lib.profile_enable(False)
         prof = {k: _lib.profile_collect(k) for k in (0, 1, 3, 5, 6, 7)}
         if world > 1:
-            tm = torch.tensor([el], device=dev, dtype=torch.float64)
+            tm = to_dist(torch.tensor([el], device=dev, dtype=torch.float64))
             dist.all_reduce(tm, op=dist.ReduceOp.MAX)
             el = float(tm.item())
         bb_ms_lp = prof[6][0] / max(prof[6][1], 1)
@@ -348,7 +352,7 @@ def main():
             line["cpu_baseline"] = None
         print(json.dumps(line))
     if world > 1:
-        dist.barrier(device_ids=[local])
+        barrier()
         dist.destroy_process_group()
 
 

@@ -17,7 +17,9 @@ def init_from_env(backend=None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"      # "nccl" is RCCL on ROCm
+            # "nccl" is RCCL on ROCm. SVDD_DIST_BACKEND=gloo: dry runs of the N > 1 code path on a box with fewer GPUs
+            # than ranks (several ranks share a device; RCCL refuses that) — never for measurements.
+            backend = os.environ.get("SVDD_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 
@@ -45,7 +47,12 @@ def gather_tokens(local_tokens, total_rows=None):
     if t.shape[0] < maxrows:
         t = torch.cat([t, t.new_zeros(maxrows - t.shape[0], t.shape[1])], dim=0)
     out = t.new_empty((world * maxrows, t.shape[1]))
-    dist.all_gather_into_tensor(out, t)
+    if dist.get_backend() == "gloo" and t.is_cuda:                     # dry-run path: gloo gathers through the host
+        parts = [torch.empty_like(t, device="cpu") for _ in range(world)]
+        dist.all_gather(parts, t.cpu())
+        out = torch.cat(parts).to(t.device)
+    else:
+        dist.all_gather_into_tensor(out, t)
     parts = [out[r * maxrows: r * maxrows + (hi - lo)] for r, (lo, hi) in enumerate(sizes)]
     return torch.cat(parts, dim=0).to(out_dtype)
 
