@@ -44,6 +44,13 @@ Engine knobs (attributes; defaults reproduce the reference's observable behaviou
   logits_cache     "auto" (default): per-row logits cache when several sequences share a backbone tile (L <= 104; at
                    L = 200 one workgroup owns one sequence and skipping rows frees CUs but saves no time); "on" / "off".
   skip_stats       None, or a dict the samplers fill with device-side hit counters (live candidates, changed rows).
+  skip_generic     False (default). True: SVDD-MC also skips the copies of the parent for an OPAQUE value function (any
+                   nn.Module, e.g. the Enformer-shaped trunk): the live candidates are gathered into a smaller batch whose
+                   size is read back once per step (one host sync, negligible next to a net that takes milliseconds).
+                   Mathematically identical; bit-identical only if the module's kernels do not depend on the batch size
+                   (vendor libraries pick — and sometimes build — kernels per size; with a large MIOpen-backed trunk the
+                   first decode pays for every new live-batch size, rounded to 256 rows here), hence opt-in. The one-pass modes "bf16" / "f16" run an
+                   opaque value / reward net under torch.autocast; the x3 modes leave it in fp32.
 """
 import weakref
 
@@ -107,6 +114,7 @@ class Diffusion(nn.Module):
         self.skip_unchanged = True
         self.logits_cache = "auto"
         self.skip_stats = None
+        self.skip_generic = False
         self.trace = None          # set to a list to record (logits, scores) of every step (tests / smoke)
         self.state_trace = None    # set to a list to record x_t (uint8 clone) at the start of every step + the final x
         self._sched_cache = {}
@@ -171,6 +179,13 @@ class Diffusion(nn.Module):
                 self._fused[key] = ent
             ent[3].precision = self.precision
             return ent[3]
+        if self.precision in ("bf16", "f16"):                       # opaque nets: PyTorch-ROCm's own 16-bit kernels
+            dt = torch.bfloat16 if self.precision == "bf16" else torch.float16
+
+            def autocast_value(onehot):
+                with torch.autocast("cuda", dtype=dt):
+                    return head(embedding(onehot)).float()
+            return autocast_value
         return lambda onehot: head(embedding(onehot))
 
     def reward_callable(self, reward_model):
@@ -480,6 +495,8 @@ class Diffusion(nn.Module):
         fn = self.value_callable(pre_scorer_embedding, pre_scorer_head)
         if self._can_skip(fn, L, M) and fn.candidates_ok(L, M):
             return self._controlled_sample_skipping(fn, x, cand, onehot, sched, B, L, S, M)
+        if self.skip_unchanged and self.skip_generic and M > 1 and self.value_batching == "batched":
+            return self._controlled_sample_generic_skipping(fn, x, cand, onehot, sched, B, L, S, M)
         for i in range(S):
             logits = self._backbone_logits(x)
             ops.propose(logits, x, sched[i, 2], sched[i, 1], M, self._rng(i, M, B, L, logits), cand=cand, onehot=onehot)
@@ -566,6 +583,33 @@ class Diffusion(nn.Module):
                 self._record(logits, self._dense_scores(sc, ws, B, M), x)
             x = self._select_compact(sc, ws, cand, i)
         self._finish_stats(ws, B, M, S, "mc")
+        return self._noise_removal(x)
+
+    def _controlled_sample_generic_skipping(self, fn, x, cand, onehot, sched, B, L, S, M):
+        """SVDD-MC work-skipping for an opaque value function: live candidates gathered into a smaller batch (its size is
+        read back once per step), copies take the parent's score (= the score of the candidate selected a step earlier)."""
+        from .fused import candidate_windows
+        ws = self._SkipWorkspace(B, M, self.device)
+        ws.parent_score.copy_(fn(ops.transform_samples(x)).reshape(B).float())
+        sc = torch.zeros(B * M, device=self.device)
+        for i in range(S):
+            logits = self._backbone_logits(x)
+            ops.propose(logits, x, sched[i, 2], sched[i, 1], M, self._rng(i, M, B, L, logits), cand=cand, onehot=onehot)
+            candidate_windows(cand, x, margin=0, flags=ws.flags)
+            ops.compact_flags(ws.flags, ws.live_idx, ws.slot, ws.count)
+            k = int(ws.count)                                                 # the one host round trip of the step
+            if k:
+                # batch sizes in steps of 256 rows (padded with repeats of the first live row): vendor libraries pick and
+                # sometimes compile kernels per problem size, and k takes a new value at almost every step
+                kp = min(B * M, -(-k // 256) * 256)
+                idx = ws.live_idx[:kp].long()
+                if kp > k:
+                    idx = torch.cat([idx[:k], idx[:1].expand(kp - k)])
+                sc[:k] = fn(onehot.index_select(0, idx)).reshape(kp)[:k].float()
+            if self.trace is not None or self.state_trace is not None:
+                self._record(logits, self._dense_scores(sc, ws, B, M), x)
+            x = self._select_compact(sc, ws, cand, i)
+        self._finish_stats(ws, B, M, S, "mc-generic")
         return self._noise_removal(x)
 
     def _tweedie_sample_skipping(self, rf, x, sched, B, L, S, M, fb):

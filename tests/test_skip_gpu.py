@@ -193,3 +193,31 @@ def test_pm_decode_skipping_trace_is_bit_identical():
     for (la, sa), (lb, sb) in zip(tr_on, tr_off):
         assert torch.equal(la, lb)
         assert (sa is None and sb is None) or torch.equal(sa, sb)
+
+
+def test_generic_skipping_with_an_opaque_value_net():
+    """skip_generic: an arbitrary nn.Module as value function (here the Enformer-shaped trunk in miniature). The live
+    candidates are scored in a smaller batch; on the recorded logits / scores the oracle reproduces the tokens, the scores
+    of copies equal their parent's, and the scores agree with the unskipped evaluation to fp32 round-off."""
+    from oracle import svdd_oracle as orc
+    from svdd_amd import synthetic
+    model, emb, head, _ = synthetic.build("dna", DEV, hidden_dim=32, num_cnn_stacks=1, value="enformer",
+                                          enformer_kwargs=dict(n_conv=4, channels=384, n_transformers=2, n_heads=2, key_len=16))
+    B, L, M, S = 6, 200, 5, 96                     # ~2 unmaskings per candidate and step: ~10 % of the candidates are copies
+    sched = model._schedule(S, 1e-5)[0]
+    model.rng_mode, model.philox_seed = "philox", 13
+    runs = {}
+    for generic in (False, True):
+        model.skip_generic, model.trace, model.state_trace = generic, [], []
+        model.skip_stats = {} if generic else None
+        x0 = model.controlled_sample(emb, head, num_steps=S, eval_sp_size=B, sample_M=M)
+        torch.cuda.synchronize()
+        runs[generic] = (x0, model.trace, model.state_trace, model.skip_stats)
+    model.skip_generic, model.trace, model.state_trace, model.skip_stats = False, None, None, None
+    x_on, tr_on, st_on, stats = runs[True]
+    assert stats["kind"] == "mc-generic" and stats["live_candidates"] < stats["candidates"]
+    trace = [(lg.cpu().numpy(), None if sc is None else sc.cpu().numpy()) for lg, sc in tr_on]
+    assert np.array_equal(x_on.cpu().numpy(), orc.replay_controlled_sample(trace, sched, B, L, M, seed=13))
+    # step 0 has identical inputs in both runs: same logits; scores equal to round-off although the batch differs
+    assert torch.equal(tr_on[0][0], runs[False][1][0][0])
+    assert (tr_on[0][1] - runs[False][1][0][1]).abs().max().item() <= 1e-5
