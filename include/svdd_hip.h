@@ -248,6 +248,11 @@ int svdd_conv1d_set_dynamic(int on);
 int svdd_conv_tower_f32(const float* onehot, const float* tiles, const float* bias, float* out, int n, int L,
                         int nlayers, int residual_mask, const int32_t* count, void* stream);
 
+/* tests / A-B of the fp32 tower kernels (all produce the same bits): 1 = first generation (runtime tile predicates),
+ * 2 / 3 = second generation (live-tile count as a template parameter) with two / one column tile per wave; 0 = default
+ * (= 3, the fastest on whole sequences and on windows: profiles/r02_tower_ab.txt) */
+int svdd_set_tower_version(int v);
+
 /* svdd_candidate_windows + svdd_conv_tower_windows_f32 — the conv tower on the M candidates of every sample, sharing
  *   the work they have in common with their parent x_t (SVDD-MC scoring, reference diffusion_gosai.py:1203-1209: the
  *   candidates are copies of x_t with a few MASKs replaced). The tower's receptive field is +-17 rows, so a

@@ -987,6 +987,224 @@ __global__ __launch_bounds__(512, 4) void conv_tower_win_kernel(TowerWinArgs wa)
   }
 }
 
+// ----------------------------------------------------- conv tower, second generation (whole sequences AND windows) ----
+// Same function, same bits as conv_tower_kernel / conv_tower_win_kernel (every output element accumulates the same
+// products in the same order), restructured after what the 16-bit twin taught (svdd_lp_tower.hip):
+//   * wave w owns 32 output channels (column tiles 2 cp, 2 cp + 1, cp = w & 1) of the row tiles rq + 4 r (rq = w >> 1), so
+//     an A fragment (two ds_read_b128) feeds 16 MFMAs instead of 8: half the LDS read traffic;
+//   * the number of live row tiles of a wave (4 / 3 for whole sequences, 0..4 for a window) is a TEMPLATE parameter of the
+//     layer loop, chosen once per wave: straight-line code, no per-tile predicates;
+//   * <= 128 VGPRs: two workgroups per CU.
+struct TowerCtx2 {
+  float* act;            // LDS image, row 0 ; rows -1 and TW_ROWS are zero
+  const float* xs;       // LDS one-hot rows [row][4]
+  const float* wsrc;     // this lane's slice of tile 0
+  const float* bias;
+  int L, tile_rows, nlayers, residual_mask;
+  int rq, cp, j, g;
+  int apos[7];
+};
+
+// CT = column tiles (16 output channels each) per wave: the 8 waves are 4 / CT channel groups x 2 CT row groups, wave
+// (rq, cp) computes row tiles rq + 2 CT r, r < NL.
+template <bool CLAMP, int NL, int CT>
+__device__ __forceinline__ void tower2_layers(const TowerCtx2& c) {
+  constexpr int RS = 2 * CT;                                     // row-tile stride of a wave
+  constexpr int NA = NL > 0 ? NL : 1;
+  const int j = c.j, g = c.g, L = c.L;
+  const int arow0 = 16 * c.rq + j;
+  const int abase = (arow0 * TW_AP + 8 * g) * 4;                 // byte offset of (row arow0, channel 8 g)
+  const int a_lo = abase - (arow0 + 1) * TW_AP * 4;              // row -1
+  const int a_hi = abase + (TW_ROWS - arow0) * TW_AP * 4;        // row TW_ROWS
+  const char* actb = reinterpret_cast<const char*>(c.act);
+  const int ch0 = 16 * CT * c.cp + j;                            // this lane's output channels: ch0 + 16 ct
+  const int nit = 2 + 10 * c.nlayers;
+  float4 bn[2 * CT];                                             // [ct][half]: W[ch0 + 16 ct][8 g .. 8 g + 8] of the next tile
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+    bn[2 * ct] = *reinterpret_cast<const float4*>(c.wsrc + ct * 16 * CH);
+    bn[2 * ct + 1] = *reinterpret_cast<const float4*>(c.wsrc + ct * 16 * CH + 4);
+  }
+  int it = 0;
+  f32x4 acc[NA][CT];
+
+  for (int layer = -1; layer < c.nlayers; ++layer) {
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      const float bl = c.bias[(layer + 1) * TW_C + ch0 + 16 * ct];
+#pragma unroll
+      for (int r = 0; r < NL; ++r) acc[r][ct] = f32x4{bl, bl, bl, bl};
+    }
+    const int niter = layer < 0 ? 2 : 10;
+    for (int ci = 0; ci < niter; ++ci, ++it) {
+      float b[CT][8];
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        b[ct][0] = bn[2 * ct].x; b[ct][1] = bn[2 * ct].y; b[ct][2] = bn[2 * ct].z; b[ct][3] = bn[2 * ct].w;
+        b[ct][4] = bn[2 * ct + 1].x; b[ct][5] = bn[2 * ct + 1].y; b[ct][6] = bn[2 * ct + 1].z; b[ct][7] = bn[2 * ct + 1].w;
+      }
+      if (it + 1 < nit) {
+        const float* src = c.wsrc + (size_t)(it + 1) * TW_C * CH;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          bn[2 * ct] = *reinterpret_cast<const float4*>(src + ct * 16 * CH);
+          bn[2 * ct + 1] = *reinterpret_cast<const float4*>(src + ct * 16 * CH + 4);
+        }
+      }
+      float4 af[NA][2];
+      if (layer < 0) {
+        const int t0 = 8 * ci + 2 * g;                           // k = 32 ci + 8 g + s: taps t0, t0 + 1 (4 channels each)
+#pragma unroll
+        for (int r = 0; r < NL; ++r)
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const int rr = arow0 + 16 * RS * r + t0 + q - 7;
+            int idx;
+            if (CLAMP) idx = rr;                                 // xs holds zero rows outside the sequence / window
+            else idx = (unsigned)(c.apos[r] + t0 + q - 7) < (unsigned)L ? rr : TW_ROWS + 7;
+            af[r][q] = *reinterpret_cast<const float4*>(c.xs + 4 * idx);
+          }
+      } else {
+        const int chk = ci / 5, delta = ci - 5 * chk - 2;
+        const int dbytes = delta * (TW_AP * 4) + chk * (CH * 4);
+#pragma unroll
+        for (int r = 0; r < NL; ++r) {
+          int o;
+          if (CLAMP) o = min(max(abase + dbytes + r * (16 * RS * TW_AP * 4), a_lo + chk * (CH * 4)), a_hi + chk * (CH * 4));
+          else o = (unsigned)(c.apos[r] + delta) < (unsigned)L ? abase + dbytes + r * (16 * RS * TW_AP * 4) : a_hi + chk * (CH * 4);
+          const float4* ap = reinterpret_cast<const float4*>(actb + o);
+          af[r][0] = ap[0]; af[r][1] = ap[1];
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < NL; ++r)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const float av[4] = {af[r][q].x, af[r][q].y, af[r][q].z, af[r][q].w};
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+              acc[r][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s4], b[ct][4 * q + s4], acc[r][ct], 0, 0, 0);
+        }
+    }
+    if (layer >= 0) __syncthreads();                     // every wave is done reading the image (the stem reads xs)
+    const bool res = layer >= 0 && ((c.residual_mask >> layer) & 1);
+#pragma unroll
+    for (int r = 0; r < NL; ++r)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {                      // C/D layout: reg e -> row 4 g + e, column j
+        const int row = 16 * (c.rq + RS * r) + 4 * g + e;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          const int o = row * TW_AP + ch0 + 16 * ct;
+          const float v = acc[r][ct][e] + (res ? c.act[o] : 0.0f);
+          c.act[o] = row < c.tile_rows ? fmaxf(v, 0.0f) : 0.0f;
+        }
+      }
+    __syncthreads();                                     // the image is complete
+  }
+}
+
+template <bool CLAMP, bool WIN, int CT>
+__device__ __forceinline__ void tower2_dispatch(const TowerCtx2& c, int nlive) {
+  if constexpr (CT == 2) {
+    switch (nlive) {                                    // wave-uniform; every path runs the same barriers
+      case 4: tower2_layers<CLAMP, 4, 2>(c); break;
+      case 3: tower2_layers<CLAMP, 3, 2>(c); break;
+      case 2: if constexpr (WIN) tower2_layers<CLAMP, 2, 2>(c); break;
+      case 1: if constexpr (WIN) tower2_layers<CLAMP, 1, 2>(c); break;
+      default: if constexpr (WIN) tower2_layers<CLAMP, 0, 2>(c); break;
+    }
+  } else {
+    switch (nlive) {
+      case 7: tower2_layers<CLAMP, 7, 1>(c); break;
+      case 6: tower2_layers<CLAMP, 6, 1>(c); break;
+      case 5: if constexpr (WIN) tower2_layers<CLAMP, 5, 1>(c); break;
+      case 4: if constexpr (WIN) tower2_layers<CLAMP, 4, 1>(c); break;
+      case 3: if constexpr (WIN) tower2_layers<CLAMP, 3, 1>(c); break;
+      case 2: if constexpr (WIN) tower2_layers<CLAMP, 2, 1>(c); break;
+      case 1: if constexpr (WIN) tower2_layers<CLAMP, 1, 1>(c); break;
+      default: if constexpr (WIN) tower2_layers<CLAMP, 0, 1>(c); break;
+    }
+  }
+}
+
+template <bool SPT1, bool WIN, int CT>
+__global__ __launch_bounds__(512, 4) void conv_tower2_kernel(TowerWinArgs wa) {
+  const TowerArgs& a = wa.t;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* act = smem + TW_AP;                            // rows -1 .. TW_ROWS ; [-1] and [TW_ROWS] stay zero
+  float* xs = smem + (TW_ROWS + 2) * TW_AP + 8 * 4;     // one-hot rows -8 .. TW_ROWS + 8
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int L = a.L;
+  int cand = blockIdx.x, w0 = 0, w1 = 0;
+  if (WIN) {
+    if (wa.count && (int)blockIdx.x >= __builtin_amdgcn_readfirstlane(*wa.count)) return;
+    if (wa.live_idx) cand = __builtin_amdgcn_readfirstlane(wa.live_idx[blockIdx.x]);
+    w0 = __builtin_amdgcn_readfirstlane(wa.win[2 * cand]);
+    w1 = __builtin_amdgcn_readfirstlane(wa.win[2 * cand + 1]);
+  }
+  const int nt = (w1 - w0) >> 4;
+  const int tile_rows = WIN ? min(L, w1) - w0 : a.spt * L;
+  const int64_t row0 = WIN ? 0 : (int64_t)blockIdx.x * tile_rows;
+  const int64_t total_rows = (int64_t)((!WIN && a.count) ? __builtin_amdgcn_readfirstlane(*a.count) : a.n) * L;
+  if (!WIN && row0 >= total_rows) return;
+  const int keep_lo = !WIN ? 0 : (nt == 0 ? 0 : (w0 == 0 ? 0 : w0 + 10));
+  const int keep_hi = !WIN ? 0 : (nt == 0 ? 0 : (w1 >= L ? L : w1 - 10));
+  float* outc = a.out + (WIN ? (size_t)blockIdx.x * L * TW_C : 0);
+
+  if (WIN) {
+    const float* par = wa.parent_out + (size_t)(cand / wa.M) * L * TW_C;
+    for (int e = tid; e < L * 16; e += 512) {           // rows that are the parent's, straight from its output
+      const int row = e >> 4;
+      if (row < keep_lo || row >= keep_hi)
+        *reinterpret_cast<float4*>(outc + (size_t)row * TW_C + 4 * (e & 15)) = *reinterpret_cast<const float4*>(par + (size_t)row * TW_C + 4 * (e & 15));
+    }
+    if (nt == 0) return;
+  }
+  {
+    const float* xc = a.x + (WIN ? (size_t)cand * L * 4 : 0);
+    for (int e = tid - 8; e < TW_ROWS + 8; e += 512) {
+      float4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (WIN) { const int gl = w0 + e; if (gl >= 0 && gl < L) v = *reinterpret_cast<const float4*>(xc + (size_t)gl * 4); }
+      else if (e >= 0 && e < tile_rows && row0 + e < total_rows) v = *reinterpret_cast<const float4*>(xc + (row0 + e) * 4);
+      *reinterpret_cast<float4*>(xs + 4 * e) = v;
+    }
+  }
+  for (int e = tid; e < (TW_ROWS + 2) * TW_AP; e += 512) smem[e] = 0.0f;      // image incl. the zero rows
+
+  TowerCtx2 c;
+  c.act = act; c.xs = xs; c.bias = a.bias;
+  c.L = L; c.tile_rows = tile_rows; c.nlayers = a.nlayers; c.residual_mask = a.residual_mask;
+  constexpr int CG = 4 / CT, RS = 2 * CT;               // channel groups ; row-tile stride
+  c.cp = w % CG; c.rq = w / CG; c.j = lane & 15; c.g = lane >> 4;
+  c.wsrc = a.tiles + (16 * CT * c.cp + c.j) * CH + 8 * c.g;
+#pragma unroll
+  for (int r = 0; r < 7; ++r) {
+    const int row = 16 * (c.rq + RS * r) + c.j;
+    c.apos[r] = (!SPT1 && !WIN && row < tile_rows) ? row % L : -(1 << 20);
+  }
+  const int nlive = ((WIN ? nt : TW_ROWS / 16) - c.rq + RS - 1) / RS;
+  __syncthreads();
+  tower2_dispatch<SPT1 || WIN, WIN, CT>(c, nlive);
+  if (WIN) {
+    for (int e = tid; e < L * 16; e += 512) {
+      const int row = e >> 4, q = e & 15;
+      if (row >= keep_lo && row < keep_hi)
+        *reinterpret_cast<float4*>(outc + (size_t)row * TW_C + 4 * q) = *reinterpret_cast<const float4*>(act + (row - w0) * TW_AP + 4 * q);
+    }
+  } else {
+    for (int e = tid; e < tile_rows * 16; e += 512) {
+      const int row = e >> 4, q = e & 15;
+      if (row0 + row < total_rows)
+        *reinterpret_cast<float4*>(a.out + (row0 + row) * TW_C + 4 * q) = *reinterpret_cast<const float4*>(act + row * TW_AP + 4 * q);
+    }
+  }
+}
+
 // (w0, w1) of every candidate: one wave per candidate compares it with its parent.
 __global__ __launch_bounds__(256) void candidate_windows_kernel(const uint8_t* __restrict__ cand, const uint8_t* __restrict__ x,
                                                                int n, int L, int M, int margin, int* __restrict__ win,
@@ -1504,6 +1722,9 @@ extern "C" int svdd_epilogue_ln_f32(const float* y, const float* bias, const flo
   return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
 }
 
+static int g_tower_ver = 0;        // svdd_set_tower_version: 0 = default (= 3), 1 = first generation, 2 / 3 = second generation
+extern "C" int svdd_set_tower_version(int v) { g_tower_ver = v; return SVDD_OK; }   // with 2 / 1 column tiles per wave
+
 static int g_conv_dynamic = 0;     // tests: force the dynamically scheduled kernel
 extern "C" int svdd_conv1d_set_dynamic(int on) { g_conv_dynamic = on; return SVDD_OK; }
 
@@ -1554,6 +1775,17 @@ extern "C" int svdd_conv_tower_f32(const float* onehot, const float* tiles, cons
   hipEvent_t e0, e1;
   svdd_internal_timed_events(5, &e0, &e1);
   const dim3 grid((unsigned)((n + spt - 1) / spt));
+  if (g_tower_ver != 1) {
+    TowerWinArgs wa{a, nullptr, nullptr, 1, nullptr, nullptr};
+    const size_t lds2 = sizeof(float) * ((size_t)(TW_ROWS + 2) * TW_AP + (size_t)(TW_ROWS + 16) * 4);
+    auto go = [&](auto kern) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+      hipExtLaunchKernelGGL(kern, grid, dim3(512), lds2, (hipStream_t)stream, e0, e1, 0, wa);
+    };
+    if (g_tower_ver == 2) { if (spt == 1) go(conv_tower2_kernel<true, false, 2>); else go(conv_tower2_kernel<false, false, 2>); }
+    else { if (spt == 1) go(conv_tower2_kernel<true, false, 1>); else go(conv_tower2_kernel<false, false, 1>); }
+    return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
+  }
   if (spt == 1) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_tower_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipExtLaunchKernelGGL(conv_tower_kernel<true>, grid, dim3(512), lds, (hipStream_t)stream, e0, e1, 0, a);
@@ -1628,9 +1860,17 @@ extern "C" int svdd_conv_tower_windows_f32(const float* onehot, const float* til
     return SVDD_E_ARG;                                   // one sequence per tile; margins below assume the 5-layer tower
   TowerWinArgs wa{TowerArgs{onehot, tiles, bias, out, n, L, 1, nlayers, residual_mask, nullptr}, win, parent_out, M, live_idx, count};
   const size_t lds = sizeof(float) * ((size_t)(TW_ROWS + 2) * TW_AP + (size_t)(TW_ROWS + 16) * 4);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_tower_win_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipEvent_t e0, e1;
   svdd_internal_timed_events(5, &e0, &e1);
+  if (g_tower_ver != 1) {
+    auto go = [&](auto kern) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipExtLaunchKernelGGL(kern, dim3((unsigned)n), dim3(512), lds, (hipStream_t)stream, e0, e1, 0, wa);
+    };
+    if (g_tower_ver == 2) go(conv_tower2_kernel<true, true, 2>); else go(conv_tower2_kernel<true, true, 1>);
+    return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
+  }
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_tower_win_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipExtLaunchKernelGGL(conv_tower_win_kernel, dim3((unsigned)n), dim3(512), lds, (hipStream_t)stream, e0, e1, 0, wa);
   return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
 }

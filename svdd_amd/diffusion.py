@@ -109,6 +109,7 @@ class Diffusion(nn.Module):
         self.select_mode = "argmax"
         self.philox_seed = 0
         self.row_offset = 0
+        self._shard = None               # (lo, hi, total, world) while distributed.sharded_sample runs this model
         self.fuse_nets = True
         self.precision = "f32"
         self.skip_unchanged = True
@@ -398,6 +399,15 @@ class Diffusion(nn.Module):
         # forward(x, sigma_s) == forward(x, sigma_t): sigma is zeroed (:334-335), so `logits` is reused (:1273)
         oh_den, _ = ops.x0hat(logits, x_u8)
         reward_den = reward_fn(oh_den)[:, 0][:, 0].float()                # :1277
+        shard = getattr(self, "_shard", None)
+        if shard is not None and shard[3] > 1:
+            # batch sharded over GPUs: the resample draws ancestors from the WHOLE batch — one all-gather, then every rank
+            # resamples the whole batch identically and keeps its rows (distributed.tds_exchange)
+            from . import distributed
+            u_all = torch.from_numpy(np.random.random_sample(shard[2]))
+            sample_all, num_all, den_all, u = distributed.tds_exchange(shard, sample, reward_num, reward_den, u_all)
+            x_all, _ = ops.tds_resample(num_all, den_all, alpha, sample_all, u)
+            return x_all[shard[0]:shard[1]].contiguous()
         u = torch.from_numpy(np.random.random_sample(B)).to(x_u8.device)   # what np.random.choice draws (:1282)
         x_next, _ = ops.tds_resample(reward_num, reward_den, alpha, sample, u)
         return x_next

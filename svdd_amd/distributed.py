@@ -2,7 +2,12 @@
 all-gather of the final decoded tokens. Rows of the batch are independent in
 SVDD-MC / SVDD-PM / un-guided decode, so nothing is exchanged per step; Philox draws are keyed by
 the GLOBAL row index, so the decoded batch is identical for any number of GPUs (rng_mode="philox" only: the replay
-mode's mt19937 stream is per process, and sharded_sample refuses it for world > 1)."""
+mode's mt19937 stream is per process, and sharded_sample refuses it for world > 1).
+
+The SMC/TDS baseline is the one sampler whose step couples rows (the resample draws ancestors from the WHOLE batch,
+reference diffusion_gosai.py:1279-1284): `tds_exchange` all-gathers each rank's proposals, both reward vectors and its
+slice of the uniforms in ONE small collective per step ((L + 16) bytes per row), every rank runs the same K4 resample on
+the whole batch and keeps its rows — token-exact against the unsharded decode."""
 import os
 
 import torch
@@ -57,6 +62,26 @@ def gather_tokens(local_tokens, total_rows=None):
     return torch.cat(parts, dim=0).to(out_dtype)
 
 
+def tds_exchange(shard, sample, reward_num, reward_den, u_all):
+    """The cross-rank half of a TDS step. shard = (lo, hi, total, world) ; sample [b, L] u8, reward_* [b] f32 of this
+    rank's rows ; u_all [total] f64 this rank's draw of the step's uniforms (only its own slice travels, so all ranks
+    agree on the assembled vector even if their numpy streams differ; with equal seeds it is the unsharded vector).
+    -> (sample, reward_num, reward_den, u) of the whole batch, identical on every rank."""
+    lo, hi, total, world = shard
+    if not dist.is_initialized() or dist.get_world_size() != world:
+        raise RuntimeError("the TDS resample couples every row of the batch: a sharded TDS decode needs an initialised "
+                           "process group of the shard's world size (launch one process per GPU)")
+    b, L = sample.shape
+    pack = torch.empty((b, L + 16), dtype=torch.uint8, device=sample.device)
+    pack[:, :L] = sample
+    pack[:, L:L + 4] = reward_num.float().contiguous().view(torch.uint8).view(b, 4)
+    pack[:, L + 4:L + 8] = reward_den.float().contiguous().view(torch.uint8).view(b, 4)
+    pack[:, L + 8:] = u_all[lo:hi].to(sample.device).contiguous().view(torch.uint8).view(b, 8)
+    g = gather_tokens(pack, total)
+    f32 = lambda a, c: g[:, a:a + c].contiguous().view(torch.float32 if c == 4 else torch.float64).view(total)  # noqa: E731
+    return g[:, :L].contiguous(), f32(L, 4), f32(L + 4, 4), f32(L + 8, 8)
+
+
 def sharded_sample(model, total_rows, sampler, rank=None, world=None):
     """Runs `sampler(eval_sp_size=<rows of this rank>)` with the model's Philox row offset set to this
     rank's first global row, then gathers. `sampler` is e.g.
@@ -72,8 +97,10 @@ def sharded_sample(model, total_rows, sampler, rank=None, world=None):
     lo, hi = shard_rows(total_rows, rank, world)
     prev = model.row_offset
     model.row_offset = lo
+    model._shard = (lo, hi, total_rows, world)            # read by the one sampler that exchanges per step (TDS)
     try:
         local = sampler(eval_sp_size=hi - lo)
     finally:
         model.row_offset = prev
+        model._shard = None
     return gather_tokens(local, total_rows)

@@ -282,3 +282,36 @@ def test_full_size_c2_net_paths(nets):
         ref = head(emb(onehot))
         assert scores.shape == ref.shape == (B * M, 1, 1)
         assert (scores - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("n,L", [(2560, 200), (9, 50), (3, 37), (5, 208)])
+def test_tower_generations_bit_identical(nets, n, L):
+    """The second-generation tower kernel (two column tiles per wave, live-tile count as a template parameter) keeps
+    every output element's accumulation order: same bits as the first generation, whole sequences and windows."""
+    from svdd_amd import _lib, fused, ops
+    model, emb, head, _ = nets
+    fv = fused.FusedValueNet(emb, head).to(DEV).eval()
+    g = torch.Generator(device="cpu").manual_seed(n + L)
+    M = 3
+    B = max(1, n // M)
+    x = torch.randint(0, 5, (B, L), generator=g).to(torch.uint8)
+    x[:, ::2] = 4
+    cand = x[:, None, :].repeat(1, M, 1).clone()
+    flip = (torch.rand(B, M, L, generator=g) < 0.03) & (cand == 4)
+    cand[flip] = torch.randint(0, 4, (int(flip.sum()),), generator=g).to(torch.uint8)
+    x, cand = x.to(DEV), cand.to(DEV).contiguous()
+    onehot = ops.transform_samples(cand.view(B * M, L))
+    win = fused.candidate_windows(cand, x)
+    outs = []
+    try:
+        for v in (1, 2, 3):
+            _lib.lib().svdd_set_tower_version(v)
+            full = fused.conv_tower(onehot, fv.tw_tiles, fv.tw_bias, fv.tw_resmask)
+            parent = fused.conv_tower(ops.transform_samples(x), fv.tw_tiles, fv.tw_bias, fv.tw_resmask)
+            outs.append((full, fused.conv_tower_windows(onehot, win, parent, M, fv.tw_tiles, fv.tw_bias, fv.tw_resmask)
+                         if L > 104 else full))                     # windows: one sequence per 208-row tile only
+    finally:
+        _lib.lib().svdd_set_tower_version(0)
+    for o in outs[1:]:
+        assert torch.equal(outs[0][0], o[0]) and torch.equal(outs[0][1], o[1])
+    assert torch.equal(outs[1][0], outs[1][1])

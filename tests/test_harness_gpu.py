@@ -145,3 +145,47 @@ def test_sharded_decode_equals_unsharded_with_the_fused_nets():
         assert torch.equal(torch.cat(ragged), whole)                  # 96 rows over 5 ranks: 20,19,19,19,19
     model.precision = "f32"
     assert model.row_offset == 0
+
+
+_TDS_RANKS = r"""
+import os, sys, numpy as np, torch
+sys.path.insert(0, {root!r})
+import torch.distributed as dist
+from svdd_amd import distributed, synthetic
+rank, world, local = distributed.init_from_env("gloo")      # two ranks share the box's one GPU: gloo through the host
+dev = "cuda:0"
+model, emb, head, reward = synthetic.build("dna", dev)
+model.rng_mode, model.philox_seed = "philox", 9
+total, S, alpha = {total}, 24, 0.5
+sampler = lambda **kw: model.controlled_sample_TDS(reward, alpha, num_steps=S, **kw)
+np.random.seed(3)
+out = distributed.sharded_sample(model, total, sampler)      # the per-step all-gather + whole-batch resample
+assert out.shape == (total, 200) and model._shard is None
+if rank == 0:
+    np.random.seed(3)
+    whole = sampler(eval_sp_size=total)                      # the same decode as one batch on one GPU
+    assert torch.equal(out, whole), int((out != whole).sum())
+    assert len(torch.unique(whole, dim=0)) < total           # resampling did duplicate particles: rows were coupled
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+@pytest.mark.parametrize("total", [32, 27])
+def test_tds_sharded_over_two_ranks_equals_unsharded(tmp_path, total):
+    """BASELINE.json configs[4] sharded: SMC/TDS is the one sampler whose step couples the rows of the batch. Two
+    processes (gloo; both on this box's GPU) decode a population of `total` particles through sharded_sample, exchanging
+    proposals + rewards + uniforms once per step; the gathered result equals the one-process decode token for token."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "tds_ranks.py"
+    script.write_text(_TDS_RANKS.format(root=root, total=total))
+    port = 33500 + os.getpid() % 2000 + total
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)]
+    env = dict(os.environ, OMP_NUM_THREADS="1", SVDD_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    assert res.stdout.count("ok") == 2

@@ -223,3 +223,46 @@ def test_weight_fingerprint_tracks_in_place_and_replaced_weights():
     assert weight_fingerprint(lin) != fp1
     lin.weight = torch.nn.Parameter(lin.weight.detach().clone())   # replaced tensor
     assert weight_fingerprint(lin) != fp1
+
+
+_TDS_WORKER = r"""
+import os, sys, numpy as np, torch
+sys.path.insert(0, {root!r})
+import torch.distributed as dist
+from svdd_amd import distributed
+rank, world, local = distributed.init_from_env("gloo")
+total, L = {total}, 9
+g = torch.Generator().manual_seed(5)
+sample = torch.randint(0, 4, (total, L), generator=g).to(torch.uint8)
+num, den = torch.randn(total, generator=g), torch.randn(total, generator=g)
+u = torch.rand(total, generator=g, dtype=torch.float64)
+lo, hi = distributed.shard_rows(total, rank, world)
+mine = u.clone()
+mine[:lo] = -1.0; mine[hi:] = -1.0                    # only this rank's slice of the uniforms may travel
+out = distributed.tds_exchange((lo, hi, total, world), sample[lo:hi], num[lo:hi], den[lo:hi], mine)
+for got, ref in zip(out, (sample, num, den, u)):
+    assert got.dtype == ref.dtype and torch.equal(got, ref), rank
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+@pytest.mark.parametrize("total", [8, 7])
+def test_tds_exchange_two_ranks_gloo(tmp_path, total):
+    """The one per-step collective of the path (SMC/TDS resample over a sharded batch): every rank ends up with the whole
+    batch's proposals, rewards and uniforms, bit for bit, ragged shards included."""
+    script = tmp_path / "worker.py"
+    script.write_text(_TDS_WORKER.format(root=ROOT, total=total))
+    port = 31500 + os.getpid() % 2000 + total
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=dict(os.environ, OMP_NUM_THREADS="1"))
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    assert res.stdout.count("ok") == 2
+
+
+def test_tds_exchange_needs_a_process_group():
+    from svdd_amd import distributed
+    with pytest.raises(RuntimeError, match="process group"):
+        distributed.tds_exchange((0, 2, 4, 2), torch.zeros(2, 3, dtype=torch.uint8), torch.zeros(2), torch.zeros(2),
+                                 torch.zeros(4, dtype=torch.float64))
