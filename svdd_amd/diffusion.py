@@ -388,29 +388,62 @@ class Diffusion(nn.Module):
         x_u8 = self._tokens_u8(x)
         return self._tds_step(x_u8, dm, mcs, reward_model, alpha, self._step_index(t, dt)).long()
 
-    def _tds_step(self, x_u8, dm, mcs, reward_model, alpha, step):
+    def _tds_step(self, x_u8, dm, mcs, reward_model, alpha, step, carry=None):
+        """One SMC/TDS step. `carry`: None, or a dict the decode loop threads through the steps for EXACT reuse: the
+        resampled particles x_next = sample[idx] are copies of proposals whose backbone logits and x0-hat reward this step
+        already computed, so the next step's forward(x_next) and its denominator reward are row gathers of this step's
+        forward(sample) and numerator reward (2 of the 3 net evaluations of a step; bit-identical because the hand-written
+        kernels' output for a row does not depend on where the row sits in the batch)."""
         B, L = x_u8.shape
-        logits = self._backbone_logits(x_u8)
+        have = carry is not None and "logits" in carry
+        logits = carry["logits"] if have else self._backbone_logits(x_u8)
         cand, _, _ = ops.propose(logits, x_u8, dm, mcs, 1, self._rng(step, 1, B, L, logits))
         sample = cand[:, 0].contiguous()
-        oh_num, _ = ops.x0hat(self._backbone_logits(sample), sample)      # :1263-1268
+        logits_s = self._backbone_logits(sample)
+        oh_num, _ = ops.x0hat(logits_s, sample)                           # :1263-1268
         reward_fn = self.reward_callable(reward_model)
         reward_num = reward_fn(oh_num)[:, 0][:, 0].float()                # :1269
-        # forward(x, sigma_s) == forward(x, sigma_t): sigma is zeroed (:334-335), so `logits` is reused (:1273)
-        oh_den, _ = ops.x0hat(logits, x_u8)
-        reward_den = reward_fn(oh_den)[:, 0][:, 0].float()                # :1277
+        if have and "den" in carry:
+            reward_den = carry["den"]
+        else:
+            # forward(x, sigma_s) == forward(x, sigma_t): sigma is zeroed (:334-335), so `logits` is reused (:1273)
+            oh_den, _ = ops.x0hat(logits, x_u8)
+            reward_den = reward_fn(oh_den)[:, 0][:, 0].float()            # :1277
+        keep_logits = carry is not None and carry.get("keep_logits")
+        keep_den = carry is not None and carry.get("keep_den")
         shard = getattr(self, "_shard", None)
         if shard is not None and shard[3] > 1:
             # batch sharded over GPUs: the resample draws ancestors from the WHOLE batch — one all-gather, then every rank
             # resamples the whole batch identically and keeps its rows (distributed.tds_exchange)
             from . import distributed
             u_all = torch.from_numpy(np.random.random_sample(shard[2]))
-            sample_all, num_all, den_all, u = distributed.tds_exchange(shard, sample, reward_num, reward_den, u_all)
-            x_all, _ = ops.tds_resample(num_all, den_all, alpha, sample_all, u)
-            return x_all[shard[0]:shard[1]].contiguous()
-        u = torch.from_numpy(np.random.random_sample(B)).to(x_u8.device)   # what np.random.choice draws (:1282)
-        x_next, _ = ops.tds_resample(reward_num, reward_den, alpha, sample, u)
+            extra = logits_s.reshape(B, -1) if keep_logits else None
+            sample_all, num_all, den_all, u, extra_all = distributed.tds_exchange(shard, sample, reward_num, reward_den,
+                                                                                  u_all, extra)
+            x_all, idx = ops.tds_resample(num_all, den_all, alpha, sample_all, u)
+            mine = idx[shard[0]:shard[1]].long()
+            x_next, src_logits, src_num = x_all[shard[0]:shard[1]].contiguous(), extra_all, num_all
+        else:
+            u = torch.from_numpy(np.random.random_sample(B)).to(x_u8.device)   # what np.random.choice draws (:1282)
+            x_next, idx = ops.tds_resample(reward_num, reward_den, alpha, sample, u)
+            mine, src_logits, src_num = idx.long(), logits_s.reshape(B, -1), reward_num
+        if carry is not None:
+            carry.pop("logits", None), carry.pop("den", None)
+            if keep_logits:
+                carry["logits"] = src_logits.index_select(0, mine).view(B, *logits_s.shape[1:])
+            if keep_den:
+                carry["den"] = src_num.index_select(0, mine)
         return x_next
+
+    def _tds_carry(self, reward_model, L):
+        """What a TDS decode may reuse from step to step (see _tds_step): only results of kernels whose output for a row
+        is independent of the batch around it — the one-launch backbone, the hand-written value-net kernels."""
+        if not (self.skip_unchanged and self.fuse_nets):
+            return None
+        from .fused import FusedValueNet
+        fn = self.reward_callable(reward_model)
+        return {"keep_logits": self._fused_backbone_or_none(L) is not None,
+                "keep_den": isinstance(fn, FusedValueNet) and fn.kernels_ok(L)}
 
     # ------------------------------------------------------------------ DPS baseline ----
     def compute_gradient_DPS(self, x_onehot, x, reward_model, sigma_s, copy_flag):
@@ -678,6 +711,7 @@ class Diffusion(nn.Module):
         B, L, S = self._batch_size(eval_sp_size), self.config.model.length, self._num_steps(num_steps)
         sched, _, _ = self._schedule(S, eps)
         x = torch.full((B, L), self.mask_index, dtype=torch.uint8, device=self.device)
+        carry = self._tds_carry(reward_model, L)
         for i in range(S):
-            x = self._tds_step(x, sched[i, 2], sched[i, 1], reward_model, alpha, i)
-        return self._noise_removal(x)
+            x = self._tds_step(x, sched[i, 2], sched[i, 1], reward_model, alpha, i, carry)
+        return self._noise_removal(x, carry.get("logits") if carry else None)

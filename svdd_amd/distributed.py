@@ -62,24 +62,30 @@ def gather_tokens(local_tokens, total_rows=None):
     return torch.cat(parts, dim=0).to(out_dtype)
 
 
-def tds_exchange(shard, sample, reward_num, reward_den, u_all):
+def tds_exchange(shard, sample, reward_num, reward_den, u_all, extra=None):
     """The cross-rank half of a TDS step. shard = (lo, hi, total, world) ; sample [b, L] u8, reward_* [b] f32 of this
     rank's rows ; u_all [total] f64 this rank's draw of the step's uniforms (only its own slice travels, so all ranks
     agree on the assembled vector even if their numpy streams differ; with equal seeds it is the unsharded vector).
-    -> (sample, reward_num, reward_den, u) of the whole batch, identical on every rank."""
+    extra: optional fp32 [b, K] per-row payload that rides along (the proposals' backbone logits, which the next step
+    reuses for the resampled particles).
+    -> (sample, reward_num, reward_den, u, extra | None) of the whole batch, identical on every rank."""
     lo, hi, total, world = shard
     if not dist.is_initialized() or dist.get_world_size() != world:
         raise RuntimeError("the TDS resample couples every row of the batch: a sharded TDS decode needs an initialised "
                            "process group of the shard's world size (launch one process per GPU)")
     b, L = sample.shape
-    pack = torch.empty((b, L + 16), dtype=torch.uint8, device=sample.device)
+    K = 0 if extra is None else 4 * extra.shape[1]
+    pack = torch.empty((b, L + 16 + K), dtype=torch.uint8, device=sample.device)
     pack[:, :L] = sample
     pack[:, L:L + 4] = reward_num.float().contiguous().view(torch.uint8).view(b, 4)
     pack[:, L + 4:L + 8] = reward_den.float().contiguous().view(torch.uint8).view(b, 4)
-    pack[:, L + 8:] = u_all[lo:hi].to(sample.device).contiguous().view(torch.uint8).view(b, 8)
+    pack[:, L + 8:L + 16] = u_all[lo:hi].to(sample.device).contiguous().view(torch.uint8).view(b, 8)
+    if K:
+        pack[:, L + 16:] = extra.float().contiguous().view(torch.uint8).view(b, K)
     g = gather_tokens(pack, total)
     f32 = lambda a, c: g[:, a:a + c].contiguous().view(torch.float32 if c == 4 else torch.float64).view(total)  # noqa: E731
-    return g[:, :L].contiguous(), f32(L, 4), f32(L + 4, 4), f32(L + 8, 8)
+    extra_all = g[:, L + 16:].contiguous().view(torch.float32).view(total, K // 4) if K else None
+    return g[:, :L].contiguous(), f32(L, 4), f32(L + 4, 4), f32(L + 8, 8), extra_all
 
 
 def sharded_sample(model, total_rows, sampler, rank=None, world=None):

@@ -239,8 +239,10 @@ u = torch.rand(total, generator=g, dtype=torch.float64)
 lo, hi = distributed.shard_rows(total, rank, world)
 mine = u.clone()
 mine[:lo] = -1.0; mine[hi:] = -1.0                    # only this rank's slice of the uniforms may travel
-out = distributed.tds_exchange((lo, hi, total, world), sample[lo:hi], num[lo:hi], den[lo:hi], mine)
-for got, ref in zip(out, (sample, num, den, u)):
+extra = torch.randn(total, 5, generator=g)
+out = distributed.tds_exchange((lo, hi, total, world), sample[lo:hi], num[lo:hi], den[lo:hi], mine, extra[lo:hi])
+assert distributed.tds_exchange((lo, hi, total, world), sample[lo:hi], num[lo:hi], den[lo:hi], mine)[4] is None
+for got, ref in zip(out, (sample, num, den, u, extra)):
     assert got.dtype == ref.dtype and torch.equal(got, ref), rank
 dist.barrier(); dist.destroy_process_group()
 print("rank", rank, "ok")

@@ -221,3 +221,23 @@ def test_generic_skipping_with_an_opaque_value_net():
     # step 0 has identical inputs in both runs: same logits; scores equal to round-off although the batch differs
     assert torch.equal(tr_on[0][0], runs[False][1][0][0])
     assert (tr_on[0][1] - runs[False][1][0][1]).abs().max().item() <= 1e-5
+
+
+@pytest.mark.parametrize("B,L,task", [(256, 200, "dna"), (96, 50, "rna")])
+def test_tds_carry_is_bit_identical(B, L, task):
+    """SMC/TDS: the resampled particles are copies of proposals, so the next step's forward(x) and denominator reward are
+    row gathers of this step's forward(sample) and numerator reward (2 of the 3 net evaluations of a step). Same tokens
+    as evaluating everything, bit for bit."""
+    import numpy as np
+    from svdd_amd import synthetic
+    model, _, _, reward = synthetic.build(task, DEV)
+    model.rng_mode, model.philox_seed = "philox", 5
+    outs = []
+    for skip in (False, True):
+        model.skip_unchanged = skip
+        np.random.seed(11)
+        outs.append(model.controlled_sample_TDS(reward, 0.5, num_steps=32, eval_sp_size=B))
+    model.skip_unchanged = True
+    assert model._tds_carry(reward, L) == {"keep_logits": True, "keep_den": True}
+    assert torch.equal(outs[0], outs[1])
+    assert len(torch.unique(outs[0], dim=0)) < B                    # the resample did duplicate particles
