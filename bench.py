@@ -182,6 +182,10 @@ def main():
     #  size makes MIOpen pick / build kernels for that size; with the 1536-channel Enformer-shaped trunk that cost more than
     #  the skipped work in a 25-minute trial. Left off.)
 
+    if world > 1:                  # communicator set-up (seconds with RCCL) never lands in the timed region, even with --warmup 0
+        dist.all_reduce(to_dist(torch.zeros(1, device=dev)))
+        barrier()
+
     rank_times = []                # (decode s, all-gather s) of every timed decode of this rank
 
     def one_decode():

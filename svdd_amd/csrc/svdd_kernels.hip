@@ -119,6 +119,7 @@ struct ProposeArgs {
   int rng_kind; uint32_t step; const float* uniforms; uint64_t seed, row_offset;
   uint8_t* cand; float* onehot; float* q_xs; int force_exact; int msplit; int ulayout;
   unsigned long long* stats;     // optional device counters {masked draws, draws sent to the exact path} (svdd_k1_stats)
+  int tok_rows;                  // candidates per chunk of the LDS token table = min(64, candidates of a unit)
 };
 
 constexpr float LOG2E_HI = 1.44269502162933349609375f;        // fl32(log2 e)
@@ -152,7 +153,7 @@ __device__ __forceinline__ void q_exact(const float (&z)[V], int xt, float dm, f
 // Work decomposition: a *unit* = (tile of 64 consecutive (b,l) positions, candidate group s of
 // `msplit`): the wave that owns a unit rebuilds the tile's cheap fast-path q in registers (no LDS, no
 // barrier) and draws candidates m = s, s + msplit, ... Waves take units in a grid-stride loop, so a
-// large launch runs as <= 2048 persistent blocks instead of one short-lived wave per unit (wave
+// large launch runs as persistent blocks (as many as the chip holds at once) instead of one short-lived wave per unit (wave
 // dispatch was the bottleneck of the one-wave-per-unit version). msplit is chosen by the host: 1 when
 // there are enough tiles to fill the chip, up to 4 for small batches where latency dominates.
 template <bool REPLAY, bool QGIVEN>
@@ -164,9 +165,22 @@ __global__ __launch_bounds__(256) void propose_kernel(ProposeArgs a) {
   const uint32_t wave_global = blockIdx.x * 4u + (threadIdx.x >> 6);
   const uint32_t nwaves = gridDim.x * 4u;
   uint32_t n_draws = 0, n_exact = 0;
-  __shared__ float prm[4][12 * WAVE];          // per wave, by rank of the masked position: q~[5], margin, owner lane, z[5]
-  __shared__ uint8_t tokl[4][WAVE][WAVE];      // per wave: drawn tokens [candidate of the chunk][lane of the position]
+  // per wave, by rank of the masked position: q~[5], margin, owner lane, z[5], then the position's RNG key (Philox: the
+  // 64-bit global position, lo / hi ; replay: b, l) so that a draw needs no division or 64-bit multiply of its own
+  __shared__ float prm[4][14 * WAVE];
+  __shared__ float4 oh_lut[V];                 // one-hot rows by token (MASK: zeros): one ds_read_b128 instead of 8 VALU ops
+  // per wave: drawn tokens [candidate of the chunk][lane of the position]; sized by the host for min(64, candidates of a
+  // unit) rows, so that at M = 10 a block holds 15 KB of LDS instead of 28 and the CU's resident waves are limited by
+  // registers (7 per SIMD), not LDS (5): more waves to overlap one wave's draws with another's stores
+  extern __shared__ __attribute__((aligned(16))) uint8_t tok_dyn[];
   const int wv = threadIdx.x >> 6;
+  const int CR = a.tok_rows;
+  uint8_t* tokw = tok_dyn + (size_t)wv * CR * WAVE;
+
+  if (threadIdx.x < V)
+    oh_lut[threadIdx.x] = float4{threadIdx.x == 0 ? 1.0f : 0.0f, threadIdx.x == 1 ? 1.0f : 0.0f, threadIdx.x == 2 ? 1.0f : 0.0f,
+                                 threadIdx.x == 3 ? 1.0f : 0.0f};
+  __syncthreads();
 
   for (uint32_t unit = wave_global; unit < nunits; unit += nwaves) {
     const uint32_t tile = unit / (uint32_t)a.msplit;
@@ -174,14 +188,25 @@ __global__ __launch_bounds__(256) void propose_kernel(ProposeArgs a) {
     const uint32_t n = tile * WAVE + lane;
     const bool valid = n < N;                 // lanes past the end of the batch stay in the loop: they take draws too
     const uint32_t nn = valid ? n : N - 1;
-    const uint32_t b = nn / (uint32_t)a.L;
-    const uint32_t l = nn - b * (uint32_t)a.L;
+    // (b, l) of the lane's position: ONE wave-uniform division per tile, then a small per-lane remainder. Integer
+    // multiplies and divides are quarter rate; the generic 64-bit index arithmetic of this prologue used to be ~50 of them.
+    const uint32_t b0 = __builtin_amdgcn_readfirstlane((tile * WAVE) / (uint32_t)a.L);
+    uint32_t rr = min(tile * WAVE + (uint32_t)lane, N - 1) - b0 * (uint32_t)a.L;      // < L + 64
+    uint32_t b = b0;
+    if ((uint32_t)a.L >= WAVE) { if (rr >= (uint32_t)a.L) { rr -= (uint32_t)a.L; ++b; } }
+    else { const uint32_t qd = rr / (uint32_t)a.L; b += qd; rr -= qd * (uint32_t)a.L; }
+    const uint32_t l = rr;
 
     // issue the token and logit loads together (the logits of an unmasked position are simply unused)
     const int xt = a.x[nn];
     float z[V];
+    {
+      const bool blv = a.layout == SVDD_LAYOUT_BLV;
+      const float* zp = a.logits + (blv ? (uint64_t)nn * V : (uint64_t)b * (uint64_t)(V * a.L) + l);
+      const uint32_t vs = blv ? 1u : (uint32_t)a.L;
 #pragma unroll
-    for (int v = 0; v < V; ++v) z[v] = a.logits[at(a.layout, b, l, v, a.L)];
+      for (int v = 0; v < V; ++v) z[v] = zp[v * vs];
+    }
     const bool masked = valid && xt == MASK;
 
     if (!QGIVEN && a.q_xs && s0 == 0 && valid) {       // per-step API only: q_xs is returned to the caller (:1228)
@@ -215,7 +240,7 @@ __global__ __launch_bounds__(256) void propose_kernel(ProposeArgs a) {
         margin = 1.0f - (1.52587890625e-05f + 3.814697265625e-06f * fabsf(lse));
       }
     }
-    const uint64_t obase = (uint64_t)b * (uint64_t)a.M * (uint64_t)a.L + l;
+    const uint64_t obase = (uint64_t)b * (uint64_t)((uint32_t)a.M * (uint32_t)a.L) + l;
 
     // ---- the draws, on ALL 64 lanes. Only the masked positions of the tile draw anything (an unmasked one copies its
     // token, :1203), and over a decode half of the positions are unmasked: with lane = position those lanes idle through
@@ -225,40 +250,62 @@ __global__ __launch_bounds__(256) void propose_kernel(ProposeArgs a) {
     // lane draws a token does not matter: the Philox counter is keyed by (global position, step, m).
     const unsigned long long bal = __ballot(masked);
     const int k = __popcll(bal);                                         // masked positions in this tile
-    const int rank = __popcll(bal & ((1ull << lane) - 1ull));
+    const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
     float* pw = prm[wv];
     if (masked) {
 #pragma unroll
       for (int v = 0; v < V; ++v) { pw[v * WAVE + rank] = qf[v]; pw[(7 + v) * WAVE + rank] = z[v]; }
       pw[5 * WAVE + rank] = fast_ok ? margin : -1.0f;                    // < 0: this position always takes the exact path
       pw[6 * WAVE + rank] = __int_as_float(lane);
+      if (REPLAY) {
+        pw[12 * WAVE + rank] = __int_as_float((int)b); pw[13 * WAVE + rank] = __int_as_float((int)l);
+      } else {
+        const uint64_t pos = (a.row_offset + (uint64_t)b) * (uint64_t)a.L + (uint64_t)l;
+        pw[12 * WAVE + rank] = __int_as_float((int)(uint32_t)pos); pw[13 * WAVE + rank] = __int_as_float((int)(uint32_t)(pos >> 32));
+      }
     }
     const int Mloc = (a.M - s0 + a.msplit - 1) / a.msplit;               // candidates of this unit: m = s0 + i * msplit
-    for (int mc = 0; mc < Mloc; mc += WAVE) {                            // chunks of 64 candidates (token table size)
-      const int Mc = min(WAVE, Mloc - mc);
+    const float inv_k = 1.0f / (float)max(k, 1);
+    // coalesced write-out of candidate mi of the chunk: lane = position again
+    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+    uint64_t ow = obase + (uint64_t)s0 * (uint64_t)a.L;                  // output offset of the next candidate to write
+    const uint64_t ow_step = (uint64_t)a.msplit * (uint64_t)a.L;
+    auto write_out = [&](int mi) {                                       // candidates are written in order: ow runs along
+      const int c = masked ? (int)tokw[mi * WAVE + lane] : xt;
+      a.cand[ow] = (uint8_t)c;
+      const float4 t = oh_lut[c];                                        // transform_samples, :1462-1470
+      // streaming store: the one-hot is 94 % of the bytes K1 moves and is read once, by another kernel
+      __builtin_nontemporal_store(f32x4_t{t.x, t.y, t.z, t.w}, reinterpret_cast<f32x4_t*>(a.onehot) + ow);
+      ow += ow_step;
+    };
+    for (int mc = 0; mc < Mloc; mc += CR) {                              // chunks of <= 64 candidates (token table size)
+      const int Mc = min(CR, Mloc - mc);
       const int T = k * Mc;
-      const float inv_mc = 1.0f / (float)Mc;
+      // The pairs are dealt candidate-major (wi = mi * k + rank), and a candidate is written out as soon as its last pair
+      // is drawn: its stores are in flight while the wave draws the next ones. With all draws first and all stores after,
+      // every wave of the chip alternated between a VALU-only and a store-only phase in step with the others, and the
+      // launch took draw time PLUS store time (137 us at B = 16384, 50 % masked, against a 76 us fill of the same bytes).
+      int written = 0;
       for (int base = 0; base < T; base += WAVE) {
         const int wi = base + lane;
         if (wi < T) {
-          int p = (int)(((float)wi + 0.5f) * inv_mc);                    // wi / Mc (T <= 4096: exact in fp32)
-          int mi = wi - p * Mc;
-          if (mi < 0) { --p; mi += Mc; } else if (mi >= Mc) { ++p; mi -= Mc; }
+          int mi = (int)(((float)wi + 0.5f) * inv_k);                   // wi / k (T <= 4096: exact in fp32 up to the fix-up)
+          int p = wi - mi * k;
+          if (p < 0) { --mi; p += k; } else if (p >= k) { ++mi; p -= k; }
           const int m = s0 + (mc + mi) * a.msplit;
           const int src = __float_as_int(pw[6 * WAVE + p]);              // the lane that owns this position
           const float mg = pw[5 * WAVE + p];
           float qv[V];
 #pragma unroll
           for (int v = 0; v < V; ++v) qv[v] = pw[v * WAVE + p];
-          const uint32_t nsrc = tile * WAVE + (uint32_t)src;
-          const uint32_t bs = nsrc / (uint32_t)a.L, ls = nsrc - bs * (uint32_t)a.L;
+          const uint32_t key0 = (uint32_t)__float_as_int(pw[12 * WAVE + p]), key1 = (uint32_t)__float_as_int(pw[13 * WAVE + p]);
           float u[V];
           if (REPLAY) {
             const float* ub = a.uniforms + (uint64_t)m * N * V;
 #pragma unroll
-            for (int v = 0; v < V; ++v) u[v] = ub[at(a.ulayout, bs, ls, v, a.L)];
+            for (int v = 0; v < V; ++v) u[v] = ub[at(a.ulayout, key0, key1, v, a.L)];
           } else {
-            philox_uniform5(a.seed, (a.row_offset + (uint64_t)bs) * (uint64_t)a.L + (uint64_t)ls, a.step, (uint32_t)m, u);
+            philox_uniform5(a.seed, (uint64_t)key0 | ((uint64_t)key1 << 32), a.step, (uint32_t)m, u);
           }
           int c = 0;
           bool decided = false;
@@ -289,23 +336,15 @@ __global__ __launch_bounds__(256) void propose_kernel(ProposeArgs a) {
               c = sample_categorical_1(q, u);
             }
           }
-          tokl[wv][mi][src] = (uint8_t)c;
+          tokw[mi * WAVE + src] = (uint8_t)c;
         }
+        const int done = min(Mc, (base + WAVE) / k);                     // candidates whose pairs are all drawn (k > 0 here)
+        if (valid)
+          for (int mi = written; mi < done; ++mi) write_out(mi);
+        written = done;
       }
-      // coalesced write-out: lane = position again
-      for (int mi = 0; mi < Mc && valid; ++mi) {
-        const int m = s0 + (mc + mi) * a.msplit;
-        const int c = masked ? (int)tokl[wv][mi][lane] : xt;
-        const uint64_t o = obase + (uint64_t)m * (uint64_t)a.L;
-        a.cand[o] = (uint8_t)c;
-        typedef float f32x4_t __attribute__((ext_vector_type(4)));
-        f32x4_t oh;
-        oh[0] = (c == 0) ? 1.0f : 0.0f; oh[1] = (c == 1) ? 1.0f : 0.0f;
-        oh[2] = (c == 2) ? 1.0f : 0.0f; oh[3] = (c == 3) ? 1.0f : 0.0f;
-        // transform_samples, :1462-1470. Streaming store: the one-hot is 94 % of the bytes K1 moves and is read once, by
-        // another kernel
-        __builtin_nontemporal_store(oh, reinterpret_cast<f32x4_t*>(a.onehot) + o);
-      }
+      if (valid)
+        for (int mi = written; mi < Mc; ++mi) write_out(mi);             // tiles without a masked position: copies
     }
   }
   if (a.stats) {                               // soak / profiling only (wave-uniform branch)
@@ -838,21 +877,40 @@ static int launch_propose(bool q_given, const float* logits, const uint8_t* x, f
   if (rng->kind == SVDD_RNG_REPLAY ? (rng->uniforms == nullptr || bad_layout(rng->uniforms_layout))
                                    : rng->kind != SVDD_RNG_PHILOX) return SVDD_E_ARG;
   const int64_t N = (int64_t)B * L;
-  if (N >= (int64_t)1 << 31) return SVDD_E_ARG;
+  if (N >= (int64_t)1 << 31 || (int64_t)M * L >= (int64_t)1 << 32) return SVDD_E_ARG;
   const int64_t ntiles = (N + WAVE - 1) / WAVE;
   // split the M candidates of a tile over up to 4 waves only while the chip (256 CUs x 4 SIMDs) is underfilled
   int msplit = g_msplit > 0 ? g_msplit : (ntiles >= 4096 ? 1 : ntiles >= 256 ? 2 : 4);   // measured: tools/k1_microbench.py
   if (msplit > M) msplit = M;
+  const int mloc = (M + msplit - 1) / msplit;
+  const int tok_rows = mloc < WAVE ? mloc : WAVE;
   ProposeArgs a{logits, x, dm, mcs, B, L, M, layout, rng->kind, rng->step, rng->uniforms, rng->seed,
-                rng->row_offset, cand, onehot, q_xs, g_force_exact, msplit, rng->uniforms_layout, g_k1_stats};
-  const int64_t nblocks = (ntiles * msplit + 3) / 4;
-  const unsigned grid = (unsigned)(nblocks < 2048 ? nblocks : 2048);
-  TimedLaunch* t = timed_slot(0);
-  hipEvent_t e0 = t ? t->start : nullptr, e1 = t ? t->stop : nullptr;
+                rng->row_offset, cand, onehot, q_xs, g_force_exact, msplit, rng->uniforms_layout, g_k1_stats, tok_rows};
+  const size_t lds = (size_t)4 * tok_rows * WAVE;
   const bool replay = rng->kind == SVDD_RNG_REPLAY;
   auto k = q_given ? (replay ? propose_kernel<true, true> : propose_kernel<false, true>)
                    : (replay ? propose_kernel<true, false> : propose_kernel<false, false>);
-  hipExtLaunchKernelGGL(k, dim3(grid), dim3(256), 0, (hipStream_t)stream, e0, e1, 0, a);
+  // persistent blocks: exactly as many as the chip holds at once (a second, partly filled round of blocks cost 20 %)
+  static int s_cus = 0;
+  static int s_occ[4][WAVE + 1];                          // blocks per CU by (kernel variant, tok_rows)
+  if (!s_cus) {
+    hipDeviceProp_t prop;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return SVDD_E_NODEVICE;
+    s_cus = prop.multiProcessorCount;
+  }
+  int& occ = s_occ[(q_given ? 2 : 0) + (replay ? 1 : 0)][tok_rows];
+  if (!occ) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(k), 256, lds) != hipSuccess || nb < 1) nb = 4;
+    occ = nb;
+  }
+  const int64_t nblocks = (ntiles * msplit + 3) / 4;
+  const int64_t cap = (int64_t)s_cus * occ;
+  const unsigned grid = (unsigned)(nblocks < cap ? nblocks : cap);
+  TimedLaunch* t = timed_slot(0);
+  hipEvent_t e0 = t ? t->start : nullptr, e1 = t ? t->stop : nullptr;
+  hipExtLaunchKernelGGL(k, dim3(grid), dim3(256), lds, (hipStream_t)stream, e0, e1, 0, a);
   return check_launch();
 }
 

@@ -81,7 +81,26 @@ BB_LP["variants"]["nopsumwrite"] = [("          if (j == 0 && row < TW_ROWS) psu
                                     ("          if (j == 0 && row < TW_ROWS) psum2[cg * TW_ROWS + row] = sq;", "          if (j == 0 && row < TW_ROWS && sq == 12345.0f) psum2[cg * TW_ROWS + row] = sq;")]
 BB_LP["variants"]["nomfma_noA_noB"] = BB_LP["variants"]["nomfma"] + BB_LP["variants"]["noA"] + BB_LP["variants"]["noB"]
 BB_LP["variants"]["nostats_nomfma_noA_noB"] = BB_LP["variants"]["nostats"] + BB_LP["variants"]["nomfma_noA_noB"]
-SETS = {"gru_lp": GRU_LP, "tower_lp": TOWER_LP, "bb_lp": BB_LP}
+K1 = {
+    "file": "svdd_kernels.hip",
+    "bench": ["python", "tools/k1_one.py", "0.5"],
+    "variants": {
+        "baseline": [],
+        "nostore": [("      a.cand[o] = (uint8_t)c;\n", "      if (c == 77) a.cand[o] = (uint8_t)c;\n"),
+                    ("      __builtin_nontemporal_store(oh, reinterpret_cast<f32x4_t*>(a.onehot) + o);\n    };",
+                     "      if (c == 77) __builtin_nontemporal_store(oh, reinterpret_cast<f32x4_t*>(a.onehot) + o);\n    };")],
+        "plainstore": [("      __builtin_nontemporal_store(oh, reinterpret_cast<f32x4_t*>(a.onehot) + o);\n    };",
+                        "      reinterpret_cast<f32x4_t*>(a.onehot)[o] = oh;\n    };")],
+        "nophilox": [("            philox_uniform5(a.seed, (a.row_offset + (uint64_t)bs) * (uint64_t)a.L + (uint64_t)ls, a.step, (uint32_t)m, u);",
+                      "            for (int v = 0; v < V; ++v) u[v] = (float)((ls * 5u + (uint32_t)v + (uint32_t)m * 977u) & 1023u) * (1.0f / 1024.0f);")],
+        "nolog": [("              const float g = 1e-10f - log_fast(u[v] + 1e-10f);\n              const float r = qv[v] * __builtin_amdgcn_rcpf(g);",
+                   "              const float g = 1.0f + u[v];\n              const float r = qv[v] * g;")],
+        "nocandbyte": [("      a.cand[o] = (uint8_t)c;\n", "      if (c == 77) a.cand[o] = (uint8_t)c;\n")],
+    },
+}
+K1["variants"]["nodraw"] = K1["variants"]["nophilox"] + K1["variants"]["nolog"]
+K1["variants"]["nodraw_nostore"] = K1["variants"]["nodraw"] + K1["variants"]["nostore"]
+SETS = {"gru_lp": GRU_LP, "tower_lp": TOWER_LP, "bb_lp": BB_LP, "k1": K1}
 
 
 def build_variant(setname, name, spec):
