@@ -271,7 +271,8 @@ __global__ __launch_bounds__(256) void propose_kernel(ProposeArgs a) {
     uint64_t ow = obase + (uint64_t)s0 * (uint64_t)a.L;                  // output offset of the next candidate to write
     const uint64_t ow_step = (uint64_t)a.msplit * (uint64_t)a.L;
     auto write_out = [&](int mi) {                                       // candidates are written in order: ow runs along
-      const int c = masked ? (int)tokw[mi * WAVE + lane] : xt;
+      const int tk = (int)tokw[mi * WAVE + lane];                        // (stale but in range for an unmasked lane)
+      const int c = masked ? tk : xt;
       a.cand[ow] = (uint8_t)c;
       const float4 t = oh_lut[c];                                        // transform_samples, :1462-1470
       // streaming store: the one-hot is 94 % of the bytes K1 moves and is read once, by another kernel
@@ -291,7 +292,8 @@ __global__ __launch_bounds__(256) void propose_kernel(ProposeArgs a) {
         if (wi < T) {
           int mi = (int)(((float)wi + 0.5f) * inv_k);                   // wi / k (T <= 4096: exact in fp32 up to the fix-up)
           int p = wi - mi * k;
-          if (p < 0) { --mi; p += k; } else if (p >= k) { ++mi; p -= k; }
+          const int adj = p < 0 ? -1 : (p >= k ? 1 : 0);                // (selects, not branches: a divergent branch costs
+          mi += adj; p -= adj * k;                                       //  more than the few VALU ops it skips)
           const int m = s0 + (mc + mi) * a.msplit;
           const int src = __float_as_int(pw[6 * WAVE + p]);              // the lane that owns this position
           const float mg = pw[5 * WAVE + p];
@@ -313,11 +315,13 @@ __global__ __launch_bounds__(256) void propose_kernel(ProposeArgs a) {
             float best = -1.0f, second = -1.0f;
             int bi = 0;
 #pragma unroll
-            for (int v = 0; v < V; ++v) {
+            for (int v = 0; v < V; ++v) {                                // first maximum wins (:33), runner-up for the margin
               const float g = 1e-10f - log_fast(u[v] + 1e-10f);
               const float r = qv[v] * __builtin_amdgcn_rcpf(g);
-              if (r > best) { second = best; best = r; bi = v; }
-              else if (r > second) second = r;
+              const bool gt = r > best;
+              second = gt ? best : fmaxf(second, r);
+              bi = gt ? v : bi;
+              best = gt ? r : best;
             }
             decided = (best > 1e-30f) && (second < best * mg);
             c = bi;
