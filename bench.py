@@ -61,7 +61,7 @@ def host_cpu():
     return model, os.cpu_count()
 
 
-def sampler_saturated(dev, L=200, M=10, B=16384, masked_frac=0.5, iters=10):
+def sampler_saturated(dev, L=200, M=10, B=16384, masked_frac=0.5, iters=100):
     """K1 (propose) at a size that leaves launch latency behind (B*M*L = 32.8 M candidate tokens, 626 MB per launch):
     the HBM fraction the north star quotes for the resample kernel is only measurable there (SURVEY.md section 7
     "launch-bound inner loop"). Same kernel, same arguments as in the decode; HIP events bound to each dispatch."""
@@ -73,7 +73,7 @@ def sampler_saturated(dev, L=200, M=10, B=16384, masked_frac=0.5, iters=10):
     cand = torch.empty(B, M, L, dtype=torch.uint8, device=dev)
     onehot = torch.empty(B * M, L, 4, device=dev)
     rng = ops.Rng(seed=1, step=64)
-    for _ in range(3):
+    for _ in range(20):                                   # (the clocks take a few ms of load to settle)
         ops.propose(logits, x, 0.0078, 0.5, M, rng, cand=cand, onehot=onehot)
     torch.cuda.synchronize()
     _lib.profile_enable(True)
