@@ -40,9 +40,10 @@ __global__ __launch_bounds__(512, 2) void backbone_lp_kernel(BackboneLpArgs a) {
   char* plane = smem_b + LPSB;                               // byte address of (row 0, channel 0) of the hi plane
   float* img32 = reinterpret_cast<float*>(smem_b);           // final stage: fp32 image [TW_ROWS][BB_AP] over the planes
   float* Bs = reinterpret_cast<float*>(smem_b + IMG_REGION_B);   // [9][5][128] the first layer's lookup table
-  float* psum = Bs + 9 * 5 * BB_C;                           // [4][TW_ROWS]
-  float* rstat = psum + 4 * TW_ROWS;                         // [TW_ROWS]
-  int* toks = reinterpret_cast<int*>(rstat + TW_ROWS);       // [TW_ROWS]
+  float* psum = Bs + 9 * 5 * BB_C;                           // [8][TW_ROWS]: first / second moment partials of the 4 column groups
+  float* rstat = psum + 8 * TW_ROWS;                         // [TW_ROWS]
+  float* rmean = rstat + TW_ROWS;                            // [TW_ROWS] row means (this layer's shift = last layer's mean)
+  int* toks = reinterpret_cast<int*>(rmean + TW_ROWS);       // [TW_ROWS]
   int* rpos = toks + TW_ROWS;                                // [TW_ROWS]
   int* sdil = rpos + TW_ROWS;                                // [BB_MAXL + 1]
   int* sched = sdil + BB_MAXL + 1;                           // [(nl + 1) * 36]
@@ -68,6 +69,7 @@ __global__ __launch_bounds__(512, 2) void backbone_lp_kernel(BackboneLpArgs a) {
       else tk = a.x[row0 + e];
     }
     toks[e] = tk;
+    rmean[e] = 0.0f;
     rpos[e] = e < tile_rows ? e % L : -(1 << 20);
   }
   // zero rows -1 and TW_ROWS of both planes (a tap that leaves the sequence reads them)
@@ -167,58 +169,54 @@ __global__ __launch_bounds__(512, 2) void backbone_lp_kernel(BackboneLpArgs a) {
     const float sa = a.lscale[2 * layer], inv = a.lscale[2 * layer + 1];
     if (layer < nl) {
       const float tb0 = vl[BB_C + c0], tb1 = vl[BB_C + c0 + 1];
-      // pass 1: row means
-#pragma unroll
-      for (int r = 0; r < NR; ++r)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int row = 16 * (rh + 2 * r) + 4 * g + e;
-          const float sm = group16_sum((f[r][0][e] + tb0) + (f[r][1][e] + tb1));
-          if (j == 0 && row < TW_ROWS) psum[cg * TW_ROWS + row] = sm;
-        }
-      __syncthreads();
-      if (tid < TW_ROWS)
-        rstat[tid] = ((psum[tid] + psum[TW_ROWS + tid]) + (psum[2 * TW_ROWS + tid] + psum[3 * TW_ROWS + tid])) * (1.0f / BB_C);
-      __syncthreads();
-      // pass 2: centred second moment
-      // the four rows of a tile that a lane owns are adjacent: one 16-byte read per tile, issued one tile ahead (a read
-      // placed next to its use would pay a full LDS round trip per row: the stores in between pin it in place)
-      float4 st4 = *reinterpret_cast<const float4*>(rstat + min(16 * rh + 4 * g, TW_ROWS - 4));
+      // ONE statistics pass: first and second moment about a per-row shift K = the row's mean one layer earlier (the
+      // residual stream drifts slowly, so |mean - K| stays of the order of the row's sigma and var = S2/n - (S1/n)^2 loses
+      // nothing; layer 0: K = 0). The two-pass form (kept in the exact-fp32 kernel, where the phases weigh 8 %) cost this
+      // kernel two more barriers and an LDS round trip per layer.
+      // The four rows of a tile that a lane owns are adjacent: one 16-byte read per tile, issued one tile ahead.
+      float4 st4 = *reinterpret_cast<const float4*>(rmean + min(16 * rh + 4 * g, TW_ROWS - 4));
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
         const float4 cur4 = st4;
-        if (r + 1 < NR) st4 = *reinterpret_cast<const float4*>(rstat + min(16 * (rh + 2 * r + 2) + 4 * g, TW_ROWS - 4));
-        const float mean4[4] = {cur4.x, cur4.y, cur4.z, cur4.w};
+        if (r + 1 < NR) st4 = *reinterpret_cast<const float4*>(rmean + min(16 * (rh + 2 * r + 2) + 4 * g, TW_ROWS - 4));
+        const float k4[4] = {cur4.x, cur4.y, cur4.z, cur4.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int row = 16 * (rh + 2 * r) + 4 * g + e;
-          const float mean = mean4[e];
-          const float d0 = f[r][0][e] + tb0 - mean, d1 = f[r][1][e] + tb1 - mean;
-          acc[r][0][e] = d0; acc[r][1][e] = d1;
-          const float sq = group16_sum(d0 * d0 + d1 * d1);
-          if (j == 0 && row < TW_ROWS) psum[cg * TW_ROWS + row] = sq;
+          const float d0 = f[r][0][e] + tb0 - k4[e], d1 = f[r][1][e] + tb1 - k4[e];
+          const float s1 = group16_sum(d0 + d1);
+          const float s2 = group16_sum(d0 * d0 + d1 * d1);
+          if (j == 0 && row < TW_ROWS) { psum[cg * TW_ROWS + row] = s1; psum[(4 + cg) * TW_ROWS + row] = s2; }
         }
       }
       __syncthreads();
-      if (tid < TW_ROWS)
-        rstat[tid] = rsqrtf(((psum[tid] + psum[TW_ROWS + tid]) + (psum[2 * TW_ROWS + tid] + psum[3 * TW_ROWS + tid])) *
-                            (1.0f / BB_C) + 1e-5f);
+      if (tid < TW_ROWS) {
+        const float m = ((psum[tid] + psum[TW_ROWS + tid]) + (psum[2 * TW_ROWS + tid] + psum[3 * TW_ROWS + tid])) * (1.0f / BB_C);
+        const float q = ((psum[4 * TW_ROWS + tid] + psum[5 * TW_ROWS + tid]) + (psum[6 * TW_ROWS + tid] + psum[7 * TW_ROWS + tid])) * (1.0f / BB_C);
+        rmean[tid] += m;
+        rstat[tid] = rsqrtf(fmaxf(q - m * m, 0.0f) + 1e-5f);
+      }
       __syncthreads();
       const float gm0 = vl[2 * BB_C + c0] * sa, gm1 = vl[2 * BB_C + c0 + 1] * sa;     // sa is a power of two: exact
       const float bt0 = vl[3 * BB_C + c0] * sa, bt1 = vl[3 * BB_C + c0 + 1] * sa;
       st4 = *reinterpret_cast<const float4*>(rstat + min(16 * rh + 4 * g, TW_ROWS - 4));
+      float4 mn4 = *reinterpret_cast<const float4*>(rmean + min(16 * rh + 4 * g, TW_ROWS - 4));
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
-        const float4 cur4 = st4;
-        if (r + 1 < NR) st4 = *reinterpret_cast<const float4*>(rstat + min(16 * (rh + 2 * r + 2) + 4 * g, TW_ROWS - 4));
+        const float4 cur4 = st4, curm = mn4;
+        if (r + 1 < NR) {
+          st4 = *reinterpret_cast<const float4*>(rstat + min(16 * (rh + 2 * r + 2) + 4 * g, TW_ROWS - 4));
+          mn4 = *reinterpret_cast<const float4*>(rmean + min(16 * (rh + 2 * r + 2) + 4 * g, TW_ROWS - 4));
+        }
         const float rs4[4] = {cur4.x, cur4.y, cur4.z, cur4.w};
+        const float mean4[4] = {curm.x, curm.y, curm.z, curm.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int row = 16 * (rh + 2 * r) + 4 * g + e;
           if (row < TW_ROWS) {
-            const float rs = rs4[e];
-            const float v0 = row < tile_rows ? acc[r][0][e] * rs * gm0 + bt0 : 0.0f;
-            const float v1 = row < tile_rows ? acc[r][1][e] * rs * gm1 + bt1 : 0.0f;
+            const float rs = rs4[e], mean = mean4[e];
+            const float v0 = row < tile_rows ? (f[r][0][e] + tb0 - mean) * rs * gm0 + bt0 : 0.0f;
+            const float v1 = row < tile_rows ? (f[r][1][e] + tb1 - mean) * rs * gm1 + bt1 : 0.0f;
             V2 hi, lo;
             split2<T>(v0, v1, hi, lo);
             *reinterpret_cast<V2*>(plane + row * LPSB + 2 * c0) = hi;
@@ -361,7 +359,7 @@ extern "C" int svdd_backbone_cnn_lp(const uint8_t* x, const float* table0, const
   a.n = n; a.L = L; a.spt = TW_ROWS / L; a.nl = nlayers; a.count = count; a.row_idx = row_idx; a.out_scatter = out_scatter;
   for (int i = 0; i < nlayers; ++i) if (dilations[i] <= 0) return SVDD_E_ARG;
   for (int i = 0; i < BB_MAXL; ++i) a.dil[i] = i < nlayers ? dilations[i] : 1;
-  const size_t lds = (size_t)IMG_REGION_B + sizeof(float) * (9 * 5 * (size_t)BB_C + 4 * (size_t)TW_ROWS + 3 * (size_t)TW_ROWS +
+  const size_t lds = (size_t)IMG_REGION_B + sizeof(float) * (9 * 5 * (size_t)BB_C + 8 * (size_t)TW_ROWS + 4 * (size_t)TW_ROWS +
                                                               BB_MAXL + 1 + (size_t)(nlayers + 1) * 36);
   hipEvent_t e0, e1;
   svdd_internal_timed_events(6, &e0, &e1);
