@@ -100,7 +100,34 @@ K1 = {
 }
 K1["variants"]["nodraw"] = K1["variants"]["nophilox"] + K1["variants"]["nolog"]
 K1["variants"]["nodraw_nostore"] = K1["variants"]["nodraw"] + K1["variants"]["nostore"]
-SETS = {"gru_lp": GRU_LP, "tower_lp": TOWER_LP, "bb_lp": BB_LP, "k1": K1}
+TOWER2 = {
+    "file": "svdd_nets.hip",
+    "bench": ["python", "tools/tower_ab.py", "1", "3"],
+    "variants": {
+        "baseline": [],
+        "nocopy": [("      if (row < keep_lo || row >= keep_hi)\n        *reinterpret_cast<float4*>(outc + (size_t)row * TW_C + 4 * (e & 15)) = *reinterpret_cast<const float4*>(par + (size_t)row * TW_C + 4 * (e & 15));",
+                    "      if ((row < keep_lo || row >= keep_hi) && a.n == 12345)\n        *reinterpret_cast<float4*>(outc + (size_t)row * TW_C + 4 * (e & 15)) = *reinterpret_cast<const float4*>(par + (size_t)row * TW_C + 4 * (e & 15));")],
+        "noB": [("      if (it + 1 < nit) {\n        const float* src = c.wsrc + (size_t)(it + 1) * TW_C * CH;",
+                 "      if (it + 1 < nit && c.L == 12345) {\n        const float* src = c.wsrc + (size_t)(it + 1) * TW_C * CH;")],
+        "nomfma": [("              acc[r][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s4], b[ct][4 * q + s4], acc[r][ct], 0, 0, 0);",
+                    "              acc[r][ct][s4] += av[s4] * b[ct][4 * q + s4];")],
+        "nozero": [("  for (int e = tid; e < (TW_ROWS + 2) * TW_AP; e += 512) smem[e] = 0.0f;      // image incl. the zero rows",
+                    "  for (int e = tid; e < (TW_ROWS + 2) * TW_AP && a.n == 12345; e += 512) smem[e] = 0.0f;")],
+        "nowriteback": [("      if (row >= keep_lo && row < keep_hi)\n        *reinterpret_cast<float4*>(outc + (size_t)row * TW_C + 4 * q) = *reinterpret_cast<const float4*>(act + (row - w0) * TW_AP + 4 * q);",
+                         "      if (row >= keep_lo && row < keep_hi && a.n == 12345)\n        *reinterpret_cast<float4*>(outc + (size_t)row * TW_C + 4 * q) = *reinterpret_cast<const float4*>(act + (row - w0) * TW_AP + 4 * q);")],
+    },
+}
+TOWER2["variants"]["nomfma0"] = [("              acc[r][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s4], b[ct][4 * q + s4], acc[r][ct], 0, 0, 0);",
+                                  "              if (c.L == 12345) acc[r][ct][s4] += av[s4] * b[ct][4 * q + s4];")]
+TOWER2["variants"]["noA"] = [("          const float4* ap = reinterpret_cast<const float4*>(actb + o);\n          af[r][0] = ap[0]; af[r][1] = ap[1];",
+                              "          af[r][0] = bn[0]; af[r][1] = bn[1]; (void)o;")]
+TOWER2["variants"]["noepi"] = [("          c.act[o] = row < c.tile_rows ? fmaxf(v, 0.0f) : 0.0f;", "          if (v == 12345.0f) c.act[o] = row < c.tile_rows ? fmaxf(v, 0.0f) : 0.0f;")]
+TOWER2["variants"]["nolayers"] = [("  tower2_dispatch<SPT1 || WIN, WIN, CT>(c, nlive);", "  if (a.n == 12345) tower2_dispatch<SPT1 || WIN, WIN, CT>(c, nlive);")]
+TOWER2["variants"]["nomfma0_noA_noB"] = TOWER2["variants"]["nomfma0"] + TOWER2["variants"]["noA"] + TOWER2["variants"]["noB"]
+TOWER2["variants"]["nomfma0_noA_noB_noepi"] = TOWER2["variants"]["nomfma0_noA_noB"] + TOWER2["variants"]["noepi"]
+TOWER2["variants"]["nocopy_nowriteback"] = TOWER2["variants"]["nocopy"] + TOWER2["variants"]["nowriteback"]
+TOWER2["variants"]["nomfma_noB"] = TOWER2["variants"]["nomfma"] + TOWER2["variants"]["noB"]
+SETS = {"gru_lp": GRU_LP, "tower_lp": TOWER_LP, "bb_lp": BB_LP, "k1": K1, "tower2": TOWER2}
 
 
 def build_variant(setname, name, spec):

@@ -1,5 +1,5 @@
-"""A/B of the two generations of the fp32 conv tower (svdd_set_tower_version): whole sequences and candidate windows.
-Usage: python tools/tower_ab.py [changes_per_candidate]"""
+"""A/B of the generations of the fp32 conv tower (svdd_set_tower_version): whole sequences and candidate windows.
+Usage: python tools/tower_ab.py [changes_per_candidate] [only this generation]"""
 import os
 import sys
 
@@ -37,7 +37,7 @@ def timed(fn, slot, n=10):
     return tot / k * 1e3
 
 
-for v in (1, 2, 3):
+for v in ((int(sys.argv[2]),) if len(sys.argv) > 2 else (1, 2, 3)):
     _lib.lib().svdd_set_tower_version(v)
     t_win = timed(lambda: fused.conv_tower_windows(onehot, win, parent, M, fv.tw_tiles, fv.tw_bias, fv.tw_resmask), 5)
     t_full = timed(lambda: fused.conv_tower(onehot, fv.tw_tiles, fv.tw_bias, fv.tw_resmask), 5)
