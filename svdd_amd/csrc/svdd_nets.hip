@@ -161,6 +161,134 @@ __global__ __launch_bounds__(BOTH ? 512 : 256) void gru_bidir_kernel(const float
   }
 }
 
+// Producer / consumer variant of gru_bidir_kernel<false> (same bits: every accumulator sees the same products in the same
+// order). Workgroup = 8 waves on one (tile of 16 sequences, direction): waves 0-3 are CONSUMERS and run the recurrence
+// (read h_t and the input projections of step t from LDS -> 48 recurrent MFMAs -> gates -> write h_{t+1}); waves 4-7
+// are PRODUCERS and compute bias + W_i* x of step t + 1 into an LDS ring one step ahead, from x rows they prefetched two
+// further steps ahead. Consumer w and producer w + 4 share a SIMD and own the same 16 hidden units, so a producer lane's
+// accumulators are exactly what its partner consumer lane continues from. The consumer's serial chain loses the 48
+// input-projection MFMAs and the x loads. Measured (tools/gru_microbench.py): 369 -> 359 us at <= 256 units, 727 -> 670 us
+// at n = 2560 — the step stays at ~1.8 us against the 1.28 us the 96 MFMAs of a wave pair need; wave priorities
+// (s_setprio 3 for the consumers) changed nothing.
+// (The 16-bit twin gru_lp_kernel, svdd_lp_gru_tail.hip, was built this way first.)
+__global__ __launch_bounds__(512) void gru_pc_kernel(const float* __restrict__ x, const float* __restrict__ wpack,
+                                                     const float* __restrict__ bpack, float* __restrict__ out,
+                                                     int n_alloc, int L, const int* __restrict__ count) {
+  __shared__ __attribute__((aligned(16))) float hbuf[2][TS][HPAD];
+  __shared__ __attribute__((aligned(16))) float xproj[2][4][3][64 * 4];        // [slot][wave][gate][lane x 4]
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const bool producer = wv >= 4;
+  const int w = wv & 3;
+  const int dir = (int)(blockIdx.x & 1);               // unit u = (tile u >> 1, direction u & 1): dense prefix when compacted
+  const int j = lane & 15, g = lane >> 4;
+  const int seq0 = (int)(blockIdx.x >> 1) * TS;
+  const int n = count ? __builtin_amdgcn_readfirstlane(*count) : n_alloc;
+  if (seq0 >= n) return;
+  const int u = 16 * w + j;
+  const int t0 = dir == 0 ? 0 : L - 1;
+  const int dt = dir == 0 ? 1 : -1;
+
+  // this wave's half of the lane's 96 gate weights: producers W_ir, W_iz, W_in ; consumers W_hr, W_hz, W_hn
+  float wr[3][16];
+  {
+    const float4* wp = reinterpret_cast<const float4*>(wpack + (((size_t)dir * 4 + w) * 64 + lane) * 96 + (producer ? 0 : 16));
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float4 v = wp[8 * m + i];
+        wr[m][4 * i] = v.x; wr[m][4 * i + 1] = v.y; wr[m][4 * i + 2] = v.z; wr[m][4 * i + 3] = v.w;
+      }
+  }
+  for (int i = threadIdx.x; i < TS * HPAD; i += 512) (&hbuf[0][0][0])[i] = 0.0f;          // h_0 = 0
+  float* myproj = &xproj[0][w][0][lane * 4];
+  constexpr int SLOT = 4 * 3 * 64 * 4;                 // floats per ring slot
+
+  if (producer) {
+    const float b_r = bpack[(dir * 4 + 0) * H + u], b_z = bpack[(dir * 4 + 1) * H + u], b_nx = bpack[(dir * 4 + 2) * H + u];
+    const int arow = min(seq0 + j, n - 1);             // clamped for the ragged last tile
+    const float* xrow = x + (size_t)arow * L * H + 16 * g;
+    float xa[2][16];                                   // two x rows in flight
+    auto load_x = [&](int t, int bufi) {
+      const float4* xp = reinterpret_cast<const float4*>(xrow + (size_t)t * H);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float4 v = xp[i];
+        xa[bufi][4 * i] = v.x; xa[bufi][4 * i + 1] = v.y; xa[bufi][4 * i + 2] = v.z; xa[bufi][4 * i + 3] = v.w;
+      }
+    };
+    auto project = [&](int bufi, int slot) {           // bias + x W_i* of one step -> ring slot
+      f32x4 pr = {b_r, b_r, b_r, b_r}, pz = {b_z, b_z, b_z, b_z}, pn = {b_nx, b_nx, b_nx, b_nx};
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        pr = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[bufi][s], wr[0][s], pr, 0, 0, 0);
+        pz = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[bufi][s], wr[1][s], pz, 0, 0, 0);
+        pn = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[bufi][s], wr[2][s], pn, 0, 0, 0);
+      }
+      float* dst = myproj + slot * SLOT;
+      *reinterpret_cast<f32x4*>(dst) = pr;
+      *reinterpret_cast<f32x4*>(dst + 256) = pz;
+      *reinterpret_cast<f32x4*>(dst + 512) = pn;
+    };
+    // prologue: projections of step 0 in slot 0; x of steps 1 and 2 in flight
+    load_x(t0, 0);
+    if (L > 1) load_x(t0 + dt, 1);
+    project(0, 0);
+    if (L > 2) load_x(t0 + 2 * dt, 0);
+    __syncthreads();
+    // step s (consumers work on slot s & 1): project x_{s+1} into slot (s + 1) & 1, prefetch x_{s+3}
+    for (int s = 0; s < L; s += 2) {
+      if (s + 1 < L) project(1, 1);
+      if (s + 3 < L) load_x(t0 + (s + 3) * dt, 1);
+      __syncthreads();
+      if (s + 1 >= L) break;
+      if (s + 2 < L) project(0, 0);
+      if (s + 4 < L) load_x(t0 + (s + 4) * dt, 0);
+      __syncthreads();
+    }
+    return;
+  }
+
+  // ---- consumers
+  const float b_nh = bpack[(dir * 4 + 3) * H + u];
+  float hprev[4] = {0.0f, 0.0f, 0.0f, 0.0f};           // h[seq = 4g + rho][u] of the previous step
+  __syncthreads();                                     // h_0 and slot 0 are ready
+  for (int step = 0; step < L; ++step) {
+    const int t = t0 + dt * step;
+    const int cur = step & 1;
+    float ha[16];
+    {
+      const float4* hp = reinterpret_cast<const float4*>(&hbuf[cur][j][16 * g]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { const float4 v = hp[i]; ha[4 * i] = v.x; ha[4 * i + 1] = v.y; ha[4 * i + 2] = v.z; ha[4 * i + 3] = v.w; }
+    }
+    const float* src = myproj + cur * SLOT;
+    f32x4 acc_r = *reinterpret_cast<const f32x4*>(src);
+    f32x4 acc_z = *reinterpret_cast<const f32x4*>(src + 256);
+    const f32x4 acc_nx = *reinterpret_cast<const f32x4*>(src + 512);
+    f32x4 acc_nh = {b_nh, b_nh, b_nh, b_nh};
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      acc_nh = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[s], wr[2][s], acc_nh, 0, 0, 0);
+      acc_r = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[s], wr[0][s], acc_r, 0, 0, 0);
+      acc_z = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[s], wr[1][s], acc_z, 0, 0, 0);
+    }
+#pragma unroll
+    for (int rho = 0; rho < 4; ++rho) {                // C/D layout: reg rho -> row (sequence) 4g + rho, column (unit) j
+      const float r = sigmoid_fast(acc_r[rho]);
+      const float z = sigmoid_fast(acc_z[rho]);
+      const float nn = tanh_fast(acc_nx[rho] + r * acc_nh[rho]);
+      const float hn = (1.0f - z) * nn + z * hprev[rho];
+      hprev[rho] = hn;
+      const int srow = 4 * g + rho;
+      hbuf[cur ^ 1][srow][u] = hn;
+      if (seq0 + srow < n) out[(((size_t)dir * n_alloc + seq0 + srow) * L + t) * H + u] = hn;
+    }
+    __syncthreads();
+  }
+}
+
 // ------------------------------------------------------------------ fused conv epilogue + LayerNorm ----
 // Channels-last rows [R, C]. One pass replaces the bias-add, ReLU, residual-add, time-bias-add and
 // LayerNorm kernels PyTorch launches between two convolutions of the dilated-CNN backbone
@@ -1681,7 +1809,8 @@ __global__ __launch_bounds__(256, 2) void value_tail_kernel(const float* __restr
 
 }  // namespace
 
-static int g_gru_mode = 0;         // 2 selects the both-directions-per-workgroup variant (tests / experiments)
+static int g_gru_mode = 0;         // 0 / 4: producer-consumer kernel (default) ; 1: one wave does both halves ; 2: both
+                                   // directions per workgroup ; 3: mode 1 with an LDS reservation (experiments, A/B tests)
 extern "C" int svdd_gru_set_mode(int mode) { g_gru_mode = mode; return SVDD_OK; }
 
 extern "C" int svdd_gru_bidir_f32(const float* x, const float* wpack, const float* bpack, float* out, int n, int L,
@@ -1691,6 +1820,11 @@ extern "C" int svdd_gru_bidir_f32(const float* x, const float* wpack, const floa
   svdd_internal_timed_events(3, &e0, &e1);
   // both directions per workgroup when that fills the chip evenly (<= 16 sequences per CU); else one direction each
   const int per_cu = (n + 255) / 256;
+  if (g_gru_mode == 0 || g_gru_mode == 4) {          // default: producer / consumer waves (same bits as mode 1)
+    hipExtLaunchKernelGGL(gru_pc_kernel, dim3(2 * (unsigned)((n + TS - 1) / TS)), dim3(512), 0, (hipStream_t)stream, e0, e1, 0,
+                          x, wpack, bpack, out, n, L, count);
+    return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
+  }
   if (g_gru_mode == 2 && per_cu <= TS && n >= 256)   // measured slower (841 vs 758 us at n=2560, L=200): opt-in only
     hipExtLaunchKernelGGL(gru_bidir_kernel<true>, dim3((unsigned)((n + per_cu - 1) / per_cu)), dim3(512), 0,
                           (hipStream_t)stream, e0, e1, 0, x, wpack, bpack, out, n, L, per_cu, count);

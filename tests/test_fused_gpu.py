@@ -16,7 +16,8 @@ def nets():
     return synthetic.build("dna", DEV)
 
 
-@pytest.mark.parametrize("mode", [0, 2])            # 0: one direction per workgroup (default), 2: both directions per workgroup
+@pytest.mark.parametrize("mode", [0, 1, 2])         # 0: producer / consumer waves (default), 1: one wave does both halves,
+                                                    # 2: both directions per workgroup
 @pytest.mark.parametrize("n,L", [(16, 200), (37, 50), (2560, 200), (1, 7), (300, 50), (4000, 20)])
 def test_gru_kernel_vs_torch(n, L, mode):
     from svdd_amd import _lib
@@ -44,6 +45,29 @@ def test_gru_kernel_vs_torch(n, L, mode):
         ref64 = g64(x[:nn_].double().cpu())[0]
     assert (out[0, :nn_].double().cpu() - ref64[:, :, :64]).abs().max().item() <= 2e-5
     assert (out[1, :nn_].double().cpu() - ref64[:, :, 64:]).abs().max().item() <= 2e-5
+
+
+@pytest.mark.parametrize("n,L,live", [(2560, 200, None), (37, 50, None), (1, 7, None), (320, 200, 200), (64, 33, 17)])
+def test_gru_producer_consumer_same_bits(n, L, live):
+    """gru_pc_kernel (producer waves compute the input projections one step ahead, consumer waves run the recurrence) keeps
+    every accumulator's order of products: same bits as the single-role kernel, also on a compacted batch."""
+    from svdd_amd import _lib
+    from svdd_amd.fused import gru_bidir, pack_gru
+    torch.manual_seed(n + L)
+    gru = torch.nn.GRU(64, 64, bidirectional=True, batch_first=True).to(DEV).eval()
+    x = torch.randn(n, L, 64, device=DEV)
+    wpack, bpack = pack_gru(gru)
+    cnt = None if live is None else torch.tensor([live], dtype=torch.int32, device=DEV)
+    outs = []
+    try:
+        for mode in (1, 4):
+            _lib.lib().svdd_gru_set_mode(mode)
+            outs.append(gru_bidir(x, wpack.to(DEV), bpack.to(DEV), count=cnt, out=torch.zeros(2, n, L, 64, device=DEV)))
+    finally:
+        _lib.lib().svdd_gru_set_mode(0)
+    assert torch.equal(outs[0], outs[1])
+    if live is not None:
+        assert float(outs[1][:, live:].abs().max()) == 0.0              # rows beyond the count are not touched
 
 
 def test_fused_value_net_vs_plain(nets):

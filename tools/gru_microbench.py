@@ -8,7 +8,7 @@ gru = torch.nn.GRU(64, 64, bidirectional=True, batch_first=True).to(dev).eval()
 wp, bp = pack_gru(gru)
 for n, L in [(2560, 200), (2048, 200), (1984, 200), (1280, 200), (5120, 200)]:
     x = torch.randn(n, L, 64, device=dev)
-    for mode in (0, 3):
+    for mode in (1, 4):                              # 1: one wave does both halves ; 4 (= default): producer / consumer waves
         _lib.lib().svdd_gru_set_mode(mode)
         for _ in range(3): gru_bidir(x, wp, bp)
         torch.cuda.synchronize()
