@@ -127,7 +127,26 @@ TOWER2["variants"]["nomfma0_noA_noB"] = TOWER2["variants"]["nomfma0"] + TOWER2["
 TOWER2["variants"]["nomfma0_noA_noB_noepi"] = TOWER2["variants"]["nomfma0_noA_noB"] + TOWER2["variants"]["noepi"]
 TOWER2["variants"]["nocopy_nowriteback"] = TOWER2["variants"]["nocopy"] + TOWER2["variants"]["nowriteback"]
 TOWER2["variants"]["nomfma_noB"] = TOWER2["variants"]["nomfma"] + TOWER2["variants"]["noB"]
-SETS = {"gru_lp": GRU_LP, "tower_lp": TOWER_LP, "bb_lp": BB_LP, "k1": K1, "tower2": TOWER2}
+GRU_PC = {
+    "file": "svdd_nets.hip",
+    "bench": ["python", "tools/gru_one.py", "2048", "2560"],
+    "variants": {
+        "baseline": [],
+        "nogates": [("      const float r = sigmoid_fast(acc_r[rho]);\n      const float z = sigmoid_fast(acc_z[rho]);\n      const float nn = tanh_fast(acc_nx[rho] + r * acc_nh[rho]);\n      const float hn = (1.0f - z) * nn + z * hprev[rho];\n      hprev[rho] = hn;\n      const int srow = 4 * g + rho;\n      hbuf[cur ^ 1][srow][u] = hn;\n      if (seq0 + srow < n) out[",
+                     "      const float r = acc_r[rho];\n      const float z = acc_z[rho];\n      const float nn = acc_nx[rho] + r * acc_nh[rho];\n      const float hn = (1.0f - z) * nn + z * hprev[rho];\n      hprev[rho] = hn;\n      const int srow = 4 * g + rho;\n      hbuf[cur ^ 1][srow][u] = hn;\n      if (seq0 + srow < n) out[")],
+        "nostore": [("      hbuf[cur ^ 1][srow][u] = hn;\n      if (seq0 + srow < n) out[(((size_t)dir * n_alloc + seq0 + srow) * L + t) * H + u] = hn;\n    }\n    __syncthreads();\n  }\n}\n\n// ------------------------------------------------------------------ fused conv epilogue",
+                     "      hbuf[cur ^ 1][srow][u] = hn;\n      if (seq0 + srow < n && hn == 12345.0f) out[(((size_t)dir * n_alloc + seq0 + srow) * L + t) * H + u] = hn;\n    }\n    __syncthreads();\n  }\n}\n\n// ------------------------------------------------------------------ fused conv epilogue")],
+        "noprod_mfma": [("      if (s + 1 < L) project(1, 1);", "      if (s + 1 < L && n == 12345) project(1, 1);"),
+                        ("      if (s + 2 < L) project(0, 0);", "      if (s + 2 < L && n == 12345) project(0, 0);")],
+        "noprod_load": [("      if (s + 3 < L) load_x(t0 + (s + 3) * dt, 1);", "      if (s + 3 < L && n == 12345) load_x(t0 + (s + 3) * dt, 1);"),
+                        ("      if (s + 4 < L) load_x(t0 + (s + 4) * dt, 0);", "      if (s + 4 < L && n == 12345) load_x(t0 + (s + 4) * dt, 0);")],
+        "norec_mfma": [("    for (int s = 0; s < 16; ++s) {\n      acc_nh = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[s], wr[2][s], acc_nh, 0, 0, 0);",
+                        "    for (int s = 0; s < 16 && n == 12345; ++s) {\n      acc_nh = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[s], wr[2][s], acc_nh, 0, 0, 0);")],
+    },
+}
+GRU_PC["variants"]["nogates_nostore"] = GRU_PC["variants"]["nogates"] + GRU_PC["variants"]["nostore"]
+GRU_PC["variants"]["noprod"] = GRU_PC["variants"]["noprod_mfma"] + GRU_PC["variants"]["noprod_load"]
+SETS = {"gru_pc": GRU_PC, "gru_lp": GRU_LP, "tower_lp": TOWER_LP, "bb_lp": BB_LP, "k1": K1, "tower2": TOWER2}
 
 
 def build_variant(setname, name, spec):
