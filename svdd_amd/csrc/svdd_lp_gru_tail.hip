@@ -38,7 +38,7 @@ struct GruLpArgs {
 // prefetched two further steps ahead. Consumer w and producer w + 4 share a SIMD and own the same 16 hidden units, so
 // the producer's accumulator layout is exactly what the consumer needs (each lane reads back the 12 floats its
 // partner lane wrote). A step is then only as long as the consumer's serial chain; in the first version one wave did
-// both halves back to back and the chain was 2.4x longer (profiles/r02_exp_gru_lp.txt: 314 us with ONE workgroup per
+// both halves back to back and the chain was 2.4x longer (profiles/r02_exp_ablations.txt, gru_lp: 314 us with ONE workgroup per
 // CU, i.e. latency- not throughput-bound; x loads and the x split alone were 40 % of it).
 template <typename T, int NP>
 __global__ __launch_bounds__(512) void gru_lp_kernel(GruLpArgs a) {

@@ -7,7 +7,7 @@ namespace {
 // ------------------------------------------------------------------------ conv tower, split precision ----
 // conv_tower_kernel / conv_tower_win_kernel of svdd_nets.hip on the 16-bit matrix cores: one workgroup (8 waves) per tile
 // of whole sequences (WIN: per candidate window); the activation image lives in LDS as two 16-bit planes (hi, lo) and is
-// the A operand directly. What differs from the fp32 kernels (measured: profiles/r02_exp_tower_lp.txt):
+// the A operand directly. What differs from the fp32 kernels (measured: profiles/r02_exp_ablations.txt, tower_lp):
 //   * the input is the TOKEN row (u8), not the fp32 one-hot: the one-hot is built in LDS (exact in 16 bits, so the stem
 //     needs only A * Bhi + A * Blo); one MFMA covers a whole (tap, 32-channel chunk);
 //   * wave w owns 32 output channels (column pair w & 1; a lane's two channels are ADJACENT, 32 cp + 2 j, + 1, so both
