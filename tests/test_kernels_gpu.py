@@ -87,6 +87,31 @@ def test_propose_philox_vs_oracle(ops, B, L, M):
         assert np.array_equal(onehot.cpu().numpy(), oh_ref)
 
 
+@pytest.mark.parametrize("M,msplit", [(70, 1), (129, 1), (64, 1), (65, 2), (300, 0), (1000, 4)])
+def test_propose_many_candidates_vs_oracle(ops, M, msplit):
+    """More candidates per position than one pass of K1's LDS token table holds (64 per unit): the chunked path, for every
+    way of splitting the candidates over waves (msplit forced through svdd_set_option; 0 = the host's choice), in both RNG
+    modes, against the oracle."""
+    from svdd_amd import _lib
+    rng = np.random.default_rng(M)
+    B, L = 3, 77
+    logits, x = rand_case(rng, B, L, frac_unmasked=0.4)
+    dm, mcs = np.float32(0.0078), np.float32(0.35)
+    uni = rng.random((M, B, L, 5), dtype=np.float32)
+    c_ref, oh_ref, _ = orc.propose(logits, x, dm, mcs, M, uniforms=uni, layout=orc.BLV)
+    p_ref, _, _ = orc.propose(logits, x, dm, mcs, M, seed=11, row_offset=5, step=9, want_q=False)
+    _lib.check(_lib.lib().svdd_set_option(1, msplit), "msplit")
+    try:
+        cand, onehot, _ = ops.propose(dev(logits), dev(x), dm, mcs, M, ops.Rng(uniforms=dev(uni)))
+        pc, _, _ = ops.propose(dev(logits), dev(x), dm, mcs, M, ops.Rng(seed=11, row_offset=5, step=9))
+        torch.cuda.synchronize()
+    finally:
+        _lib.check(_lib.lib().svdd_set_option(1, 0), "msplit")
+    assert np.array_equal(cand.cpu().numpy(), c_ref)
+    assert np.array_equal(onehot.cpu().numpy(), oh_ref)
+    assert np.array_equal(pc.cpu().numpy(), p_ref)
+
+
 def test_propose_philox_shard_invariance(ops):
     """Rows keyed by global index: decoding a shard with row_offset equals slicing the full batch."""
     rng = np.random.default_rng(8)
