@@ -47,7 +47,8 @@ def test_gru_kernel_vs_torch(n, L, mode):
     assert (out[1, :nn_].double().cpu() - ref64[:, :, 64:]).abs().max().item() <= 2e-5
 
 
-@pytest.mark.parametrize("n,L,live", [(2560, 200, None), (37, 50, None), (1, 7, None), (320, 200, 200), (64, 33, 17)])
+@pytest.mark.parametrize("n,L,live", [(2560, 200, None), (37, 50, None), (1, 7, None), (3, 1, None), (5, 2, None), (17, 3, None),
+                                      (320, 200, 200), (64, 33, 17)])
 def test_gru_producer_consumer_same_bits(n, L, live):
     """gru_pc_kernel (producer waves compute the input projections one step ahead, consumer waves run the recurrence) keeps
     every accumulator's order of products: same bits as the single-role kernel, also on a compacted batch."""
