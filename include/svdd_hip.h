@@ -248,6 +248,11 @@ int svdd_conv1d_set_dynamic(int on);
 int svdd_conv_tower_f32(const float* onehot, const float* tiles, const float* bias, float* out, int n, int L,
                         int nlayers, int residual_mask, const int32_t* count, void* stream);
 
+/* tests / A-B: 1 = the backbone kernels always fill their 208-row tile with whole sequences (round-1 behaviour); 0 (default)
+ * = when several sequences fit a tile (L <= 104) the number taken minimises rounds x tile cost, chosen on the host or, for a
+ * device-side row count, by the workgroups themselves (csrc/svdd_spt.h). A row's logits do not depend on the choice. */
+int svdd_set_backbone_packing(int full);
+
 /* tests / A-B of the fp32 tower kernels (all produce the same bits): 1 = first generation (runtime tile predicates),
  * 2 / 3 = second generation (live-tile count as a template parameter) with two / one column tile per wave; 0 = default
  * (= 3, the fastest on whole sequences and on windows: profiles/r02_tower_ab.txt) */

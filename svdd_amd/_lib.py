@@ -30,7 +30,7 @@ EXPORTS = (
     "svdd_conv1d_set_dynamic", "svdd_gru_set_mode", "svdd_conv_tower_f32", "svdd_backbone_cnn_f32", "svdd_value_tail_f32",
     "svdd_candidate_windows", "svdd_conv_tower_windows_f32", "svdd_k1_stats",
     "svdd_backbone_cnn_lp", "svdd_conv_tower_lp", "svdd_conv_tower_windows_lp", "svdd_gru_bidir_lp", "svdd_value_tail_lp",
-    "svdd_compact_flags", "svdd_gather_rows", "svdd_advance_rows", "svdd_select_compact", "svdd_set_tower_version",
+    "svdd_compact_flags", "svdd_gather_rows", "svdd_advance_rows", "svdd_select_compact", "svdd_set_tower_version", "svdd_set_backbone_packing",
 )
 OPT_FORCE_EXACT = 0
 
@@ -102,6 +102,7 @@ def lib():
     L.svdd_epilogue_ln_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_int64, i32, i32, vp]
     L.svdd_k1_stats.argtypes = [vp]
     L.svdd_set_tower_version.argtypes = [i32]
+    L.svdd_set_backbone_packing.argtypes = [i32]
     L.svdd_compact_flags.argtypes = [vp, i32, vp, vp, vp, vp]
     L.svdd_gather_rows.argtypes = [vp, vp, vp, i32, i32, vp, vp]
     L.svdd_advance_rows.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp]

@@ -1,6 +1,10 @@
 // svdd_lp_backbone.hip — the one-launch dilated-CNN backbone, split precision
 // (split-precision net kernels on the 16-bit matrix cores: see svdd_lp_common.h for the arithmetic)
 #include "svdd_lp_common.h"
+#include "svdd_spt.h"
+
+extern "C" int svdd_internal_num_cus();      // svdd_nets.hip
+extern "C" int svdd_internal_fixed_spt();    // svdd_nets.hip (svdd_set_backbone_packing)
 
 namespace {
 
@@ -29,6 +33,7 @@ struct BackboneLpArgs {
   const int* count;        // device scalar: valid rows (NULL: n) — exact work-skipping on a compacted batch
   const int* row_idx;      // [count] (NULL: identity): compact row r reads the tokens of sequence row_idx[r] of x ...
   int out_scatter;         // ... and writes its logits to row row_idx[r] of out (1) or to row r (0)
+  int auto_spt, ncu;       // auto_spt: the workgroups pick the sequences per tile from the device-side row count (svdd_spt.h)
 };
 
 template <typename T, int NP, bool SPT1>
@@ -54,9 +59,11 @@ __global__ __launch_bounds__(512, 2) void backbone_lp_kernel(BackboneLpArgs a) {
   const int j = lane & 15, g = lane >> 4;
   const int c0 = 32 * cg + 2 * j;                            // this lane's output channels: c0 and c0 + 1
   const int L = a.L;
-  const int tile_rows = a.spt * L;
+  const int nvalid = a.count ? __builtin_amdgcn_readfirstlane(*a.count) : a.n;
+  const int spt = (!SPT1 && a.auto_spt) ? __builtin_amdgcn_readfirstlane(svdd_choose_spt(nvalid, L, a.ncu, NP == 3 ? 13 : 20)) : a.spt;
+  const int tile_rows = spt * L;
   const int64_t row0 = (int64_t)blockIdx.x * tile_rows;
-  const int64_t total_rows = (int64_t)(a.count ? __builtin_amdgcn_readfirstlane(*a.count) : a.n) * L;
+  const int64_t total_rows = (int64_t)nvalid * L;
   if (row0 >= total_rows) return;
   const int nl = a.nl;
   const int it_end = (nl + 1) * 36;
@@ -65,7 +72,7 @@ __global__ __launch_bounds__(512, 2) void backbone_lp_kernel(BackboneLpArgs a) {
   for (int e = tid; e < TW_ROWS; e += 512) {
     int tk = -1;
     if (e < tile_rows && row0 + e < total_rows) {
-      if (a.row_idx) { const int sq = e / L; tk = a.x[(int64_t)a.row_idx[blockIdx.x * a.spt + sq] * L + (e - sq * L)]; }
+      if (a.row_idx) { const int sq = e / L; tk = a.x[(int64_t)a.row_idx[blockIdx.x * spt + sq] * L + (e - sq * L)]; }
       else tk = a.x[row0 + e];
     }
     toks[e] = tk;
@@ -339,7 +346,7 @@ __global__ __launch_bounds__(512, 2) void backbone_lp_kernel(BackboneLpArgs a) {
     float sm = a.w2[5 * BB_C + v];
 #pragma unroll 8
     for (int k = 0; k < BB_C; ++k) sm += hr[k] * wv[k];
-    if (a.row_idx && a.out_scatter) { const int sq = row / L; a.out[((int64_t)a.row_idx[blockIdx.x * a.spt + sq] * L + (row - sq * L)) * 5 + v] = sm; }
+    if (a.row_idx && a.out_scatter) { const int sq = row / L; a.out[((int64_t)a.row_idx[blockIdx.x * spt + sq] * L + (row - sq * L)) * 5 + v] = sm; }
     else a.out[(row0 + row) * 5 + v] = sm;
   }
 }
@@ -363,8 +370,16 @@ extern "C" int svdd_backbone_cnn_lp(const uint8_t* x, const float* table0, const
                                                               BB_MAXL + 1 + (size_t)(nlayers + 1) * 36);
   hipEvent_t e0, e1;
   svdd_internal_timed_events(6, &e0, &e1);
-  const dim3 grid((unsigned)((n + a.spt - 1) / a.spt));
-  const bool spt1 = a.spt == 1;
+  a.auto_spt = 0; a.ncu = svdd_internal_num_cus();
+  unsigned nwg = (unsigned)((n + a.spt - 1) / a.spt);
+  const int fixed = svdd_internal_fixed_spt();
+  if (a.spt > 1 && fixed <= 0) {                         // several sequences fit a tile: how many to take (svdd_spt.h)
+    if (fixed < 0) { a.spt = -fixed < a.spt ? -fixed : a.spt; nwg = (unsigned)((n + a.spt - 1) / a.spt); }
+    else if (count) { a.auto_spt = 1; nwg = (unsigned)n; }   // decided on the device from *count; grid for one sequence per tile
+    else { a.spt = svdd_choose_spt(n, L, a.ncu, (prec == SVDD_PREC_F16X3 || prec == SVDD_PREC_BF16X3) ? 13 : 20); nwg = (unsigned)((n + a.spt - 1) / a.spt); }
+  }
+  const dim3 grid(nwg);
+  const bool spt1 = a.spt == 1 && !a.auto_spt;
 #define LP_LAUNCH(TT, NPP)                                                                                          \
   do {                                                                                                               \
     if (spt1) {                                                                                                      \

@@ -16,6 +16,7 @@
 #include <stdint.h>
 
 #include "svdd_hip.h"
+#include "svdd_spt.h"
 
 extern "C" void svdd_internal_timed_events(int k, hipEvent_t* e0, hipEvent_t* e1);   // svdd_kernels.hip (profiling)
 
@@ -1390,6 +1391,7 @@ struct BackboneArgs {
   const int* count;        // device scalar: valid rows (NULL: n) — exact work-skipping on a compacted batch
   const int* row_idx;      // [count] (NULL: identity): compact row r reads the tokens of sequence row_idx[r] of x ...
   int out_scatter;         // ... and writes its logits to row row_idx[r] of out (1) or to row r (0)
+  int auto_spt, ncu;       // auto_spt: the workgroups pick the sequences per tile from the device-side row count (svdd_spt.h)
 };
 
 template <int N>
@@ -1428,9 +1430,11 @@ __global__ __launch_bounds__(512, 2) void backbone_kernel(BackboneArgs a) {
   const int j = lane & 15, g = lane >> 4;
   const int col0 = 32 * cg + j;                           // this lane's columns: col0 and col0 + 16
   const int L = a.L;
-  const int tile_rows = a.spt * L;
+  const int nvalid = a.count ? __builtin_amdgcn_readfirstlane(*a.count) : a.n;
+  const int spt = (!SPT1 && a.auto_spt) ? __builtin_amdgcn_readfirstlane(svdd_choose_spt(nvalid, L, a.ncu, 3)) : a.spt;
+  const int tile_rows = spt * L;
   const int64_t row0 = (int64_t)blockIdx.x * tile_rows;
-  const int64_t total_rows = (int64_t)(a.count ? __builtin_amdgcn_readfirstlane(*a.count) : a.n) * L;
+  const int64_t total_rows = (int64_t)nvalid * L;
   if (row0 >= total_rows) return;
   const int nl = a.nl;
   const int it_end = (nl + 1) * 36;
@@ -1439,7 +1443,7 @@ __global__ __launch_bounds__(512, 2) void backbone_kernel(BackboneArgs a) {
   for (int e = tid; e < TW_ROWS; e += 512) {
     int tk = -1;
     if (e < tile_rows && row0 + e < total_rows) {
-      if (a.row_idx) { const int sq = e / L; tk = a.x[(int64_t)a.row_idx[blockIdx.x * a.spt + sq] * L + (e - sq * L)]; }
+      if (a.row_idx) { const int sq = e / L; tk = a.x[(int64_t)a.row_idx[blockIdx.x * spt + sq] * L + (e - sq * L)]; }
       else tk = a.x[row0 + e];
     }
     toks[e] = tk;
@@ -1703,7 +1707,7 @@ __global__ __launch_bounds__(512, 2) void backbone_kernel(BackboneArgs a) {
     float sm = a.w2[5 * BB_C + v];
 #pragma unroll 8
     for (int k = 0; k < BB_C; ++k) sm += hr[k] * wv[k];
-    if (a.row_idx && a.out_scatter) { const int sq = row / L; a.out[((int64_t)a.row_idx[blockIdx.x * a.spt + sq] * L + (row - sq * L)) * 5 + v] = sm; }
+    if (a.row_idx && a.out_scatter) { const int sq = row / L; a.out[((int64_t)a.row_idx[blockIdx.x * spt + sq] * L + (row - sq * L)) * 5 + v] = sm; }
     else a.out[(row0 + row) * 5 + v] = sm;
   }
 }
@@ -1808,6 +1812,20 @@ __global__ __launch_bounds__(256, 2) void value_tail_kernel(const float* __restr
 }
 
 }  // namespace
+
+static int g_fixed_spt = 0;        // svdd_set_backbone_packing: 1 = always fill the 208-row tile (round-1 behaviour), -s = exactly
+                                   // s sequences per tile (calibration of svdd_spt.h), 0 = choose (default)
+extern "C" int svdd_set_backbone_packing(int full) { g_fixed_spt = full; return SVDD_OK; }
+extern "C" int svdd_internal_fixed_spt() { return g_fixed_spt; }
+extern "C" int svdd_internal_num_cus() {
+  static int ncu = 0;
+  if (!ncu) {
+    hipDeviceProp_t prop;
+    int dev = 0;
+    ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+  }
+  return ncu;
+}
 
 static int g_gru_mode = 0;         // 0 / 4: producer-consumer kernel (default) ; 1: one wave does both halves ; 2: both
                                    // directions per workgroup ; 3: mode 1 with an LDS reservation (experiments, A/B tests)
@@ -1939,14 +1957,21 @@ extern "C" int svdd_backbone_cnn_f32(const uint8_t* x, const float* table0, cons
   BackboneArgs a;
   a.x = x; a.table0 = table0; a.tiles = tiles; a.vec = vec; a.w2 = w2; a.out = out;
   a.n = n; a.L = L; a.spt = TW_ROWS / L; a.nl = nlayers; a.count = count; a.row_idx = row_idx; a.out_scatter = out_scatter;
+  a.auto_spt = 0; a.ncu = svdd_internal_num_cus();
+  unsigned nwg = (unsigned)((n + a.spt - 1) / a.spt);
+  if (a.spt > 1 && g_fixed_spt <= 0) {                   // several sequences fit a tile: how many to take (svdd_spt.h)
+    if (g_fixed_spt < 0) { a.spt = -g_fixed_spt < a.spt ? -g_fixed_spt : a.spt; nwg = (unsigned)((n + a.spt - 1) / a.spt); }
+    else if (count) { a.auto_spt = 1; nwg = (unsigned)n; }   // decided on the device from *count; grid for one sequence per tile
+    else { a.spt = svdd_choose_spt(n, L, a.ncu, 3); nwg = (unsigned)((n + a.spt - 1) / a.spt); }
+  }
   for (int i = 0; i < BB_MAXL; ++i) a.dil[i] = i < nlayers ? dilations[i] : 1;
   for (int i = 0; i < nlayers; ++i) if (dilations[i] <= 0) return SVDD_E_ARG;
   const size_t lds = sizeof(float) * ((size_t)(TW_ROWS + 2) * BB_AP + 9 * 5 * (size_t)BB_C + 8 * (size_t)TW_ROWS +
                                       3 * (size_t)TW_ROWS + BB_MAXL + 1 + (size_t)(nlayers + 1) * 36);
   hipEvent_t e0, e1;
   svdd_internal_timed_events(6, &e0, &e1);
-  const dim3 grid((unsigned)((n + a.spt - 1) / a.spt));
-  if (a.spt == 1) {
+  const dim3 grid(nwg);
+  if (a.spt == 1 && !a.auto_spt) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(backbone_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipExtLaunchKernelGGL(backbone_kernel<true>, grid, dim3(512), lds, (hipStream_t)stream, e0, e1, 0, a);
   } else {

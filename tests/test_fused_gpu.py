@@ -340,3 +340,35 @@ def test_tower_generations_bit_identical(nets, n, L):
     for o in outs[1:]:
         assert torch.equal(outs[0][0], o[0]) and torch.equal(outs[0][1], o[1])
     assert torch.equal(outs[1][0], outs[1][1])
+
+
+@pytest.mark.parametrize("n,L", [(256, 50), (1408, 50), (2560, 50), (37, 33), (700, 9), (3, 104)])
+@pytest.mark.parametrize("mode", ["f32", "f16x3"])
+def test_backbone_sequences_per_tile_choice_same_bits(n, L, mode):
+    """Short sequences (several fit a 208-row tile): the number a workgroup takes is chosen to minimise rounds x tile cost
+    (csrc/svdd_spt.h) — on the host for a known row count, by the workgroups for a device-side count, with or without a
+    row index list. Every variant gives the bits of the always-full tiles of round 1."""
+    from svdd_amd import _lib, backbone, config, fused
+    torch.manual_seed(L)
+    cnn = backbone.CNNModel(config.rna_config().model, alphabet_size=5).to(DEV).eval()
+    x = torch.randint(0, 5, (n, L), device=DEV, dtype=torch.uint8)
+    pk = fused.pack_backbone(cnn) if mode == "f32" else fused.pack_backbone_lp(cnn, mode)
+    fwd = fused.backbone_cnn if mode == "f32" else fused.backbone_cnn_lp
+    live = max(1, (2 * n) // 3)
+    cnt = torch.tensor([live], dtype=torch.int32, device=DEV)
+    idx = torch.randperm(n, device=DEV)[:live].sort().values.to(torch.int32).contiguous()
+    outs = []
+    try:
+        for full in (1, 0):
+            _lib.lib().svdd_set_backbone_packing(full)
+            a = fwd(x, pk)
+            b = fwd(x, pk, count=cnt, out=torch.zeros(n, L, 5, device=DEV))
+            c = fwd(x, pk, count=cnt, row_idx=idx, scatter=True, out=torch.zeros(n, L, 5, device=DEV))
+            outs.append((a, b, c))
+    finally:
+        _lib.lib().svdd_set_backbone_packing(0)
+    for u, v in zip(outs[0], outs[1]):
+        assert torch.equal(u, v)
+    a, b, c = outs[1]
+    assert torch.equal(b[:live], a[:live]) and float(b[live:].abs().max() if live < n else 0.0) == 0.0
+    assert torch.equal(c[idx.long()], a[idx.long()])
