@@ -458,7 +458,8 @@ class Diffusion(nn.Module):
         scores.mean().backward()
         return x_onehot.grad.clone()
 
-    def _dps_step(self, x_u8, mct, mcs, dm, reward_model, guidance_scale, step):
+    def _dps_guided_q(self, x_u8, mcs, dm, reward_model, guidance_scale):
+        """The guided transition weights q_xs of one DPS step (:1306-1314) -> fp32 [B, L, 5]."""
         B, L = x_u8.shape
         with torch.no_grad():
             q_xs = torch.exp(ops.subs_logp(self._backbone_logits(x_u8), x_u8)) * float(dm)   # :1306-1307
@@ -471,7 +472,12 @@ class Diffusion(nn.Module):
         with torch.no_grad():
             guidance = guidance_scale * (x_grad - x_grad[:, :, self.mask_index][:, :, None])   # :1311
             q_xs[:, :, self.mask_index] = float(mcs)                                          # :1312
-            q_xs = q_xs * guidance.exp()                                                      # :1314
+            return q_xs * guidance.exp()                                                      # :1314
+
+    def _dps_step(self, x_u8, mct, mcs, dm, reward_model, guidance_scale, step):
+        B, L = x_u8.shape
+        q_xs = self._dps_guided_q(x_u8, mcs, dm, reward_model, guidance_scale)
+        with torch.no_grad():
             cand, _ = ops.sample_categorical(q_xs, x_u8, 1, self._rng(step, 1, B, L, q_xs))   # :1316-1319
         return cand.view(B, L)
 

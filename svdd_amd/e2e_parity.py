@@ -38,14 +38,31 @@ def tiny_engine(nets, L, S, device):
 
 
 def compare_with_reference_run(g, nets, device="cuda:0", fuse_nets=True, value_batching="batched"):
-    """-> report dict (see module docstring)."""
-    S, B, L, M = int(g["S"]), int(g["B"]), int(g["L"]), int(g["M"])
+    """The reference's TINY nets (hidden 16, GRU 8: below every gate of the hand-written net kernels, so they run as
+    PyTorch-ROCm modules whatever fuse_nets says — what this pins is the sampler kernels + host loop on a whole real
+    trajectory) -> report dict (see module docstring)."""
+    S, L = int(g["S"]), int(g["L"])
     model, emb, head = tiny_engine(nets, L, S, device)
-    model.fuse_nets, model.value_batching, model.rng_mode = fuse_nets, value_batching, "replay"
+    return compare_engine_with_reference_run(g, model, emb, head, fuse_nets, value_batching)
+
+
+def uses_hand_written_kernels(model, emb, head, L):
+    """True when this engine evaluates (backbone, value net) through the one-launch backbone kernel and the
+    tower / GRU / tail kernels of svdd_amd/csrc — i.e. the kernels that are 99 % of a decode's time."""
+    from .fused import FusedValueNet
+    fb = model._fused_backbone_or_none(L)
+    fn = model.value_callable(emb, head)
+    return fb is not None and isinstance(fn, FusedValueNet) and fn.kernels_ok(L)
+
+
+def compare_engine_with_reference_run(g, model, emb, head, fuse_nets=True, value_batching="batched", precision="f32"):
+    """Free-running decode of `model` in replay mode against a recorded reference controlled_sample run `g`."""
+    S, B, L, M = int(g["S"]), int(g["B"]), int(g["L"]), int(g["M"])
+    model.fuse_nets, model.value_batching, model.rng_mode, model.precision = fuse_nets, value_batching, "replay", precision
     model.trace, model.state_trace = [], []
     torch.manual_seed(int(g["seed"]))
     with torch.no_grad():
-        x0 = model.controlled_sample(emb, head, eval_sp_size=B, sample_M=M)
+        x0 = model.controlled_sample(emb, head, num_steps=S, eval_sp_size=B, sample_M=M)
     torch.cuda.synchronize()
     xs = np.stack([x.cpu().numpy() for x in model.state_trace])                # [S + 1, B, L] states fed to the backbone
     logits = [t[0].cpu().numpy() for t in model.trace]
@@ -59,7 +76,8 @@ def compare_with_reference_run(g, nets, device="cuda:0", fuse_nets=True, value_b
     dl_rows = max(float(np.abs(logits[i][same[i]] - g["logits"][i][same[i]]).max()) for i in range(S + 1) if same[i].any())
     ds_rows = max(float(np.abs(scores[i][same[i]] - g["scores"][i][same[i]]).max()) for i in range(S) if same[i].any())
     x0n = x0.cpu().numpy()
-    rep = {"S": S, "B": B, "L": L, "M": M, "fuse_nets": fuse_nets, "value_batching": value_batching,
+    rep = {"S": S, "B": B, "L": L, "M": M, "fuse_nets": fuse_nets, "value_batching": value_batching, "precision": precision,
+           "hand_written_net_kernels": bool(fuse_nets and uses_hand_written_kernels(model, emb, head, L)),
            "first_divergence_step": first, "steps_compared": upto,
            "max_abs_logit_err_before_divergence": dl, "max_abs_score_err_before_divergence": ds,
            "max_abs_logit_err_on_undiverged_rows": dl_rows, "max_abs_score_err_on_undiverged_rows": ds_rows,
@@ -74,4 +92,58 @@ def compare_with_reference_run(g, nets, device="cuda:0", fuse_nets=True, value_b
                                    "reference_score_gap_top2": float(sc[0] - sc[1]) if M > 1 else None,
                                    "gpu_minus_ref_scores": (scores[i][row] - g["scores"][i][row]).tolist()}
     model.trace = model.state_trace = None
+    model.precision = "f32"
     return rep
+
+
+def teacher_forced_report(g, model, emb, head, precision="f32"):
+    """Every state of a recorded reference run `g` (full-size nets: tests/golden/g13_*.npz, reference
+    diffusion_gosai.py:1021-1061, 1174-1228) is fed to the hand-written net kernels: x_t -> one-launch backbone -> raw
+    logits; the reference's own M candidates -> value net three ways (whole-sequence tower; parent-sharing row windows;
+    the compacted live-candidate path of the work-skipping decode) -> scores. Each step is compared with what the
+    reference computed on the CPU at that step, so an error cannot hide behind an earlier divergence. Also: the select
+    kernel applied to the GPU scores against the reference's next state (selection agreement), and the gap between the
+    two best reference scores where a selection differs."""
+    from . import ops
+    from .fused import FusedBackbone, FusedValueNet
+    S, B, L, M = int(g["S"]), int(g["B"]), int(g["L"]), int(g["M"])
+    dev = model.device
+    model.fuse_nets, model.precision = True, precision
+    fb, fn = model._fused_backbone_or_none(L), model.value_callable(emb, head)
+    if not (isinstance(fb, FusedBackbone) and isinstance(fn, FusedValueNet) and fn.kernels_ok(L)):
+        raise ops.SvddError("teacher_forced_report needs nets the hand-written kernels take (full-size CNN + ConvGRU)")
+    dl, ds = np.zeros(S + 1), np.zeros((S, 3))
+    agree = np.zeros((S, B), dtype=bool)
+    gaps = []
+    xs = torch.from_numpy(g["xs"]).to(dev)
+    cands = torch.from_numpy(g["cand"]).to(dev)
+    with torch.no_grad():
+        for i in range(S + 1):
+            x = xs[i].contiguous()
+            lg = model._backbone_logits(x)
+            dl[i] = float((lg.cpu() - torch.from_numpy(g["logits"][i])).abs().max())
+            if i == S:
+                break
+            cand = cands[i].contiguous()
+            onehot = ops.transform_samples(cand.view(B * M, L))
+            ref = torch.from_numpy(g["scores"][i])
+            whole = fn(onehot).reshape(B, M).float()
+            windows = fn.forward_candidates(onehot, cand, x).reshape(B, M).float() if fn.candidates_ok(L, M) else whole
+            ws = model._SkipWorkspace(B, M, dev)
+            ws.parent_score.copy_(fn.forward_tokens(x).reshape(B))
+            sc = fn.candidate_scores_compact(onehot, cand, x, ws).reshape(-1) if fn.candidates_ok(L, M) else None
+            compact = model._dense_scores(sc, ws, B, M) if sc is not None else whole
+            for k, v in enumerate((whole, windows, compact)):
+                ds[i, k] = float((v.cpu() - ref).abs().max())
+            x_next, _, _ = ops.select(compact.contiguous(), cand, mode=ops.SELECT_ARGMAX, want_soft=False)
+            agree[i] = (x_next.cpu().numpy() == g["xs"][i + 1]).all(axis=1)
+            for b in np.nonzero(~agree[i])[0]:
+                top = np.sort(g["scores"][i][b])[::-1]
+                gaps.append(float(top[0] - top[1]))
+    model.precision = "f32"
+    return {"S": S, "B": B, "L": L, "M": M, "precision": precision, "steps_compared": S + 1,
+            "max_abs_logit_err": float(dl.max()), "max_abs_score_err_whole_tower": float(ds[:, 0].max()),
+            "max_abs_score_err_windows": float(ds[:, 1].max()), "max_abs_score_err_compact": float(ds[:, 2].max()),
+            "selection_agreement": float(agree.mean()), "row_steps": int(agree.size),
+            "disagreeing_row_steps": int((~agree).sum()),
+            "max_reference_top2_gap_where_selection_differs": max(gaps) if gaps else None}

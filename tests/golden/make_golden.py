@@ -18,6 +18,13 @@ outputs are stored. Fixtures:
   g10_decode_sample.npz       decode_sample (un-guided), S=16, B=3, L=50
   g11_traj_dps.npz            controlled_sample_DPS, S=6, B=3, L=50: guided q_xs, uniforms, gradients per step
   nets_tiny.npz               state_dicts of the tiny nets used above (for net-parity tests)
+  g13_traj_mc_full_c1.npz     controlled_sample with the FULL-SIZE nets of g12 (seed 44): BASELINE configs[0] (B=4, L=200, M=2,
+                              S=128), every step's state, raw logits, candidates and value scores
+  g13_traj_mc_full_m10.npz    same nets, B=4, L=200, M=10, S=32
+  g14_traj_pm_heuristic.npz   controlled_sample_tweedie with the DEFAULT options=True (a bool: `options == "True"` is False,
+                              :1414), i.e. the heuristic branch :1420-1424, tiny nets, S=8, B=3, L=50, M=3
+  g15_step_mc_m10.npz / _m20  one _ddpm_update_finetune_controlled step at the widths the reference is run with (M=10
+                              default, M=20 in BASELINE configs[3]) with adversarial ties: pins softmax/argmax over M
   g12_fullsize_probe.npz      FULL-SIZE reference nets (CNNModel hidden 128 x 4 stacks; ConvGRUTrunk 64 ch, n_conv 6 +
                               ConvHead) built at torch.manual_seed(44) in the order svdd_amd/synthetic.py builds them,
                               evaluated on 4 probe rows: logits, value scores, a checksum of every parameter tensor
@@ -122,6 +129,22 @@ def g2_g4(d):
     save("g2_subs.npz", logits=logits, xt=xt, logp=logp)
     oh = d.transform_samples(xt)
     save("g4_transform.npz", tokens=xt, onehot=oh)
+
+
+def sched_rows(d, S, eps=1e-5):
+    """[S, 6] fp32 rows (t_i, sigma_t, sigma_s, mct, mcs, mct - mcs) exactly as the per-step prologue computes them."""
+    timesteps = torch.linspace(1, eps, S + 1)
+    dt = (1 - eps) / S
+    rows = []
+    for i in range(S):
+        t = timesteps[i] * torch.ones(2, 1)
+        sigma_t, _ = d.noise(t)
+        sigma_s, _ = d.noise(t - dt)
+        mct = 1 - torch.exp(-sigma_t.squeeze(-1))
+        mcs = 1 - torch.exp(-sigma_s.squeeze(-1))
+        rows.append([t[0, 0].item(), sigma_t[0, 0].item(), sigma_s[0, 0].item(), mct[0].item(), mcs[0].item(),
+                     (mct - mcs)[0].item()])
+    return np.asarray(rows, dtype=np.float32)
 
 
 # ----------------------------------------------------------------------------- G3
@@ -423,9 +446,131 @@ def g12_fullsize_probe(seed=44):
     save("g12_fullsize_probe.npz", **arrs)
 
 
+def full_nets(seed=44, length=200, steps=128):
+    """The reference's own classes at full size, initialised exactly like g12 / svdd_amd.synthetic.build."""
+    torch.manual_seed(seed)
+    d = dg.Diffusion(make_cfg(length=length, hidden_dim=128, num_cnn_stacks=4, steps=steps)).eval()
+    emb = En.ConvGRUTrunk(stem_in_channels=4, stem_channels=64, stem_kernel_size=15, n_conv=6, channel_init=64,
+                          channel_mult=1, kernel_size=5, act_func="relu", conv_norm=True, pool_func=None,
+                          pool_size=None, residual=True, crop_len=0, n_gru=1, dropout=0.1, gru_norm=True).eval()
+    head = En.ConvHead(n_tasks=1, in_channels=64, act_func=None, pool_func="avg", norm=False).eval()
+    return d, emb, head
+
+
+def g13_traj_mc_full(name, S, B, M, seed):
+    """A whole reference controlled_sample run (diffusion_gosai.py:1021-1061, 1174-1228) with the FULL-SIZE random-init
+    nets (the ones bench.py times), recording every step: the state x_t, the raw backbone output, the M candidates and
+    their value scores. The -m gpu tests feed these states to the hand-written net kernels (teacher forcing) and compare
+    every step's logits / scores; the weights are not stored: seed 44 in synthetic.build's order reproduces them (g12)."""
+    d, emb_m, head_m = full_nets(steps=S)
+    rec = RecBackbone(d.backbone)
+    d.backbone = rec
+    emb, head = RecCallable(emb_m), RecCallable(head_m)
+    torch.manual_seed(seed)
+    x0 = d.controlled_sample(emb, head, eval_sp_size=B, sample_M=M)
+    L = 200
+    xs = torch.stack([c[0] for c in rec.calls])
+    logits = torch.stack([c[1] for c in rec.calls])
+    onehots = torch.stack(emb.inputs).view(S, M, B, L, 4)
+    scores = torch.stack([o.squeeze() for o in head.outputs]).view(S, M, B).permute(0, 2, 1).contiguous()
+    d.backbone = rec.inner
+    arrs = {n_ + "_param_sums": np.array([float(p.double().sum()) for p in mod.state_dict().values()])
+            for n_, mod in (("backbone", d.backbone), ("embedding", emb_m), ("head", head_m))}
+    save(name, xs=xs.to(torch.uint8), logits=logits, scores=scores,
+         cand=(onehots.argmax(-1) * (onehots.sum(-1) > 0) + 4 * (onehots.sum(-1) == 0)).permute(0, 2, 1, 3).to(torch.uint8),
+         x0=x0, seed=seed, net_seed=44, B=B, L=L, M=M, S=S, sched=sched_rows(d, S), **arrs)
+
+
+def g14_traj_pm_heuristic(seed=13):
+    """controlled_sample_tweedie called the way decode_tweedie.py calls it — options left at its default, the bool True —
+    which the string compare at :1414 sends down the heuristic branch :1420-1424 (reward of the raw x_t with MASK rows
+    zero; no candidate backbone forward)."""
+    L, S, B, M = 50, 8, 3, 3
+    d = tiny_diffusion(L, S)
+    emb_m, head_m = tiny_value()
+    reward = RewardWrap(emb_m, head_m).eval()
+    rec = RecBackbone(d.backbone)
+    d.backbone = rec
+    rr = RecCallable(reward)
+    torch.manual_seed(seed)
+    x0 = d.controlled_sample_tweedie(rr, eval_sp_size=B, sample_M=M)
+    assert len(rec.calls) == S + 1                     # one backbone call per step: no Tweedie forward in this branch
+    xs = torch.stack([c[0] for c in rec.calls])
+    logits = torch.stack([c[1] for c in rec.calls])
+    scores = torch.stack([o[:, 0].squeeze() for o in rr.outputs]).view(S, M, B).permute(0, 2, 1).contiguous()
+    oh = torch.stack(rr.inputs).view(S, M, B, 4, L)    # what the reward model saw: [B,4,L] one-hot of the candidate
+    cand = (oh.argmax(3) * (oh.sum(3) > 0) + 4 * (oh.sum(3) == 0)).permute(0, 2, 1, 3).to(torch.uint8)
+    d.backbone = rec.inner
+    save("g14_traj_pm_heuristic.npz", xs=xs.to(torch.uint8), logits=logits, cand=cand, scores=scores, x0=x0, seed=seed,
+         B=B, L=L, M=M, S=S)
+
+
+def g15_step(d, M):
+    """G5 at the sample widths the reference actually runs (M = 10: decode.py's default; M = 20: BASELINE configs[3]),
+    reference memory layout ([B,5,L] buffer behind the logits). Scores hold exact ties, 1-ulp near-ties spread over all
+    M columns and |s| < 0.5 rows where distinct scores can collapse after exp / sum."""
+    torch.manual_seed(150 + M)
+    B, L = 12, 200
+    logits = (torch.randn(B, L, 5) * 1.5).permute(0, 2, 1).contiguous().permute(0, 2, 1)
+    x = torch.where(torch.rand(B, L) < 0.45, torch.randint(0, 4, (B, L)), torch.full((B, L), 4))
+    x[7] = 4
+    scores = torch.randn(B, M) * 0.3
+    scores[1] = 0.25                                                   # all tied -> index 0
+    scores[2, M - 2] = scores[2].max() + 0.5                            # clear winner near the end
+    scores[3, 2] = scores[3, M - 1] = scores[3].max() + 1.0             # exact two-way tie -> lowest index
+    base = torch.full((M,), 0.1)
+    base[1::2] = 0.1 + 2 ** -27                                        # alternating 1-ulp pattern
+    scores[4] = base
+    scores[5] = scores[5] * 50.0                                       # large spread
+    scores[6] = -30.0 + torch.arange(M) * 1e-3                         # offset
+    scores[8] = torch.randn(M) * 1e-7                                  # near-uniform: what random-init value nets give
+    scores[9] = 0.3 + torch.randint(-1, 2, (M,)).float() * 2 ** -25    # +-1 ulp jitter around one value
+    scores[10] = torch.nextafter(torch.full((M,), 0.4), torch.tensor(1.0))
+    scores[10, M // 2:] = 0.4                                          # two plateaus one ulp apart, larger one first
+    scores[11] = torch.flip(scores[10], dims=[0])                      # ... larger one last
+    inner = d.backbone
+    d.backbone = FixedBackbone(logits)
+    emb = RecCallable(lambda t: t)
+    calls = {"n": 0}
+
+    def head_fn(t):
+        m = calls["n"]
+        calls["n"] += 1
+        return scores[:, m].clone().view(B, 1, 1)
+
+    head = RecCallable(head_fn)
+    S, eps = 128, 1e-5
+    t = torch.linspace(1, eps, S + 1)[70] * torch.ones(B, 1)
+    dt = (1 - eps) / S
+    torch.manual_seed(56)          # the M x rand_like(q_xs) draws are torch.rand(M, B, 5, L) of this seed (pinned by g9 / g5)
+    x_next, x_in, q_xs, copy_flag = d._ddpm_update_finetune_controlled(x, t, dt, emb, head, repeats=M)
+    cand = torch.stack([oh.argmax(-1) * (oh.sum(-1) > 0) + 4 * (oh.sum(-1) == 0) for oh in emb.inputs], 1)
+    soft = torch.softmax(scores, 1)
+    idx = torch.argmax(soft, 1)
+    sigma_t, _ = d.noise(t)
+    sigma_s, _ = d.noise(t - dt)
+    mct = (1 - torch.exp(-sigma_t.squeeze(-1)))[0]
+    mcs = (1 - torch.exp(-sigma_s.squeeze(-1)))[0]
+    d.backbone = inner
+    save(f"g15_step_mc_m{M}.npz", logits=logits, x=x, scores=scores, seed=56, mct=mct, mcs=mcs,
+         dm=(mct - mcs), q_xs=q_xs, cand=cand.to(torch.uint8), soft=soft, idx=idx, x_next=x_next)
+
+
+def new_round3():
+    g13_traj_mc_full("g13_traj_mc_full_c1.npz", S=128, B=4, M=2, seed=0)
+    g13_traj_mc_full("g13_traj_mc_full_m10.npz", S=32, B=4, M=10, seed=2)
+    g14_traj_pm_heuristic()
+    d = tiny_diffusion(200, 128)
+    g15_step(d, 10)
+    g15_step(d, 20)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "g12":
         g12_fullsize_probe()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "r3":
+        new_round3()
         sys.exit(0)
     d = tiny_diffusion(200, 128)
     g9()
@@ -442,3 +587,4 @@ if __name__ == "__main__":
     traj_dps()
     nets()
     g12_fullsize_probe()
+    new_round3()

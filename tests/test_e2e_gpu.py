@@ -3,8 +3,16 @@
  (1) The reference's tiny nets (tests/golden/nets_tiny.npz) run on the GPU through the engine in replay mode against the
      reference's own recorded `controlled_sample` trajectory (g6, BASELINE.json configs[0]: B=4, L=200, M=2, 128 steps):
      logits and scores within the north-star tolerance 1e-4 on every row for as long as that row's state is still the
-     reference's; where the whole run stays identical the decoded x_0 must be exact (svdd_amd/e2e_parity.py; the numbers
-     of the last run are kept in profiles/r02_e2e_parity.json).
+     reference's; where the whole run stays identical the decoded x_0 must be exact (svdd_amd/e2e_parity.py). The tiny
+     nets (hidden 16, GRU 8) are below the gates of the hand-written NET kernels and run as PyTorch-ROCm modules: this
+     pins the sampler kernels and the host loop on a real trajectory, not the net kernels — (3) does that.
+ (3) The FULL-SIZE nets on the reference's own trajectory (g13: the reference's classes at seed 44 running
+     controlled_sample at BASELINE configs[0] and at M = 10): every recorded x_t goes through the one-launch backbone
+     kernel, every recorded candidate set through the tower / GRU / tail kernels (whole-sequence, parent-sharing windows
+     and compacted paths), and EVERY step's logits and scores must be within 1e-4 of what the reference computed on the
+     CPU (teacher forcing: an error cannot hide behind an earlier divergence). Then the free-running decode in replay
+     mode: it may leave the reference trajectory only at a near-tie of the deciding scores. Numbers of the last run:
+     profiles/r03_e2e_parity.json.
  (2) Full-size nets: the reference's classes, random-initialised at torch.manual_seed(44) in the order synthetic.build
      uses, gave tests/golden/g12_fullsize_probe.npz; the HIP kernels (exact fp32 and the x3 split modes) must reproduce
      its logits / log-probabilities / value scores within 1e-4 on the GPU."""
@@ -18,10 +26,11 @@ TOL = 1e-4            # BASELINE.json north_star: "reward/soft-value tensors wit
 
 
 @pytest.mark.parametrize("fixture", ["g6_traj_mc_c1.npz", "g6_traj_mc_s16.npz"])
-@pytest.mark.parametrize("fuse,batching", [(True, "batched"), (False, "batched"), (False, "reference")])
-def test_real_tiny_nets_follow_the_reference_trajectory(golden, fixture, fuse, batching):
+@pytest.mark.parametrize("batching", ["batched", "reference"])
+def test_real_tiny_nets_follow_the_reference_trajectory(golden, fixture, batching):
     from svdd_amd import e2e_parity
-    rep = e2e_parity.compare_with_reference_run(golden(fixture), golden("nets_tiny.npz"), DEV, fuse, batching)
+    rep = e2e_parity.compare_with_reference_run(golden(fixture), golden("nets_tiny.npz"), DEV, True, batching)
+    assert not rep["hand_written_net_kernels"]          # tiny nets: PyTorch-ROCm modules + the sampler kernels
     assert rep["steps_compared"] >= 1
     assert rep["max_abs_logit_err_on_undiverged_rows"] <= TOL, rep
     assert rep["max_abs_score_err_on_undiverged_rows"] <= TOL, rep
@@ -61,3 +70,45 @@ def test_fullsize_probe_on_the_hip_kernels(golden, full_nets, precision):
     assert np.array_equal(logp.cpu().numpy() > -1e5, keep)
     assert np.abs(logp.cpu().numpy()[keep] - g["logp"][keep]).max() <= TOL
     assert np.abs(value.cpu().numpy() - g["value"]).max() <= TOL
+
+
+@pytest.mark.parametrize("fixture", ["g13_traj_mc_full_c1.npz", "g13_traj_mc_full_m10.npz"])
+@pytest.mark.parametrize("precision", ["f32", "f16x3", "bf16x3"])
+def test_hand_written_net_kernels_on_the_reference_trajectory(golden, full_nets, fixture, precision):
+    """Teacher-forced: all S + 1 states and all S candidate sets of the reference's own full-size run."""
+    from svdd_amd import e2e_parity
+    g = golden(fixture)
+    model, emb, head, _ = full_nets
+    for name, mod in (("backbone", model.backbone), ("embedding", emb), ("head", head)):     # same nets as the reference's
+        sums = np.array([float(p.double().sum()) for p in mod.state_dict().values()])
+        assert np.allclose(sums, g[name + "_param_sums"], rtol=0, atol=1e-6), name
+    rep = e2e_parity.teacher_forced_report(g, model, emb, head, precision)
+    assert rep["steps_compared"] == int(g["S"]) + 1
+    assert rep["max_abs_logit_err"] <= TOL, rep
+    for k in ("whole_tower", "windows", "compact"):
+        assert rep["max_abs_score_err_" + k] <= TOL, rep
+    # a selection may differ from the reference's only where the reference's two best scores are a near-tie
+    if rep["disagreeing_row_steps"]:
+        assert rep["max_reference_top2_gap_where_selection_differs"] <= 2 * TOL, rep
+    if precision == "f32":
+        assert rep["selection_agreement"] >= 0.9, rep
+
+
+@pytest.mark.parametrize("fixture", ["g13_traj_mc_full_c1.npz", "g13_traj_mc_full_m10.npz"])
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_fullsize_free_running_decode_vs_reference_run(golden, full_nets, fixture, precision):
+    """Free-running (replay RNG) with the hand-written net kernels against the reference's CPU run of the same nets."""
+    from svdd_amd import e2e_parity
+    g = golden(fixture)
+    model, emb, head, _ = full_nets
+    rep = e2e_parity.compare_engine_with_reference_run(g, model, emb, head, True, "batched", precision)
+    assert rep["hand_written_net_kernels"]
+    assert rep["steps_compared"] >= 1
+    assert rep["max_abs_logit_err_on_undiverged_rows"] <= TOL, rep
+    assert rep["max_abs_score_err_on_undiverged_rows"] <= TOL, rep
+    if rep["first_divergence_step"] is None:
+        assert rep["x0_exact"], rep
+    else:
+        fd = rep["first_divergence"]
+        assert max(abs(v) for v in fd["gpu_minus_ref_scores"]) <= TOL, rep
+        assert fd["reference_score_gap_top2"] is None or fd["reference_score_gap_top2"] <= 2 * TOL, rep

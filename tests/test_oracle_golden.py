@@ -111,6 +111,64 @@ def test_g6_trajectory_stepwise(golden, name):
     assert np.array_equal(orc.finalize(bvl(g["logits"][S]), x, layout=orc.BVL), g["x0"])
 
 
+@pytest.mark.parametrize("name", ["g13_traj_mc_full_c1.npz", "g13_traj_mc_full_m10.npz"])
+def test_g13_fullsize_trajectory_stepwise(golden, name):
+    """The reference's controlled_sample with its FULL-SIZE random-init nets (BASELINE configs[0], and an M = 10 run): the
+    oracle, fed the recorded logits / scores, reproduces every candidate set, every x_t and x_0. With these nets the
+    candidates' scores lie ~1e-7 apart, so this is the near-tie regime the benchmark decode lives in."""
+    g = golden(name)
+    S, B, L, M = int(g["S"]), int(g["B"]), int(g["L"]), int(g["M"])
+    sched = g["sched"]
+    if S == 128:
+        assert np.array_equal(sched, golden("g3_schedule.npz")["S128"])
+    mt = orc.MT19937(int(g["seed"]))
+    x = np.full((B, L), 4, dtype=np.uint8)
+    for i in range(S):
+        assert np.array_equal(x, g["xs"][i]), f"step {i}"
+        uni = mt.torch_rand(M, B, 5, L)
+        cand, _, _ = orc.propose(bvl(g["logits"][i]), x, sched[i, 5], sched[i, 4], M, uniforms=uni, want_q=False, layout=orc.BVL)
+        assert np.array_equal(cand, g["cand"][i]), f"step {i}"
+        x, _, _ = orc.select(g["scores"][i], cand)
+    assert np.array_equal(x, g["xs"][S])
+    assert np.array_equal(orc.finalize(bvl(g["logits"][S]), x, layout=orc.BVL), g["x0"])
+
+
+def test_g14_tweedie_heuristic_branch_stepwise(golden):
+    """controlled_sample_tweedie as decode_tweedie.py calls it (options = the bool True -> `options == "True"` is False ->
+    heuristic branch diffusion_gosai.py:1420-1424): the reward model sees the candidate itself, MASK rows zero."""
+    g = golden("g14_traj_pm_heuristic.npz")
+    S, B, L, M = int(g["S"]), int(g["B"]), int(g["L"]), int(g["M"])
+    sched = golden("g3_schedule.npz")[f"S{S}"]
+    mt = orc.MT19937(int(g["seed"]))
+    x = np.full((B, L), 4, dtype=np.uint8)
+    for i in range(S):
+        assert np.array_equal(x, g["xs"][i])
+        uni = mt.torch_rand(M, B, 5, L)
+        cand, _, _ = orc.propose(bvl(g["logits"][i]), x, sched[i, 5], sched[i, 4], M, uniforms=uni, want_q=False, layout=orc.BVL)
+        assert np.array_equal(cand, g["cand"][i])             # = what the reward model was shown (transform_samples^T)
+        x, _, _ = orc.select(g["scores"][i], cand)
+    assert np.array_equal(x, g["xs"][S])
+    assert np.array_equal(orc.finalize(bvl(g["logits"][S]), x, layout=orc.BVL), g["x0"])
+
+
+@pytest.mark.parametrize("M", [10, 20])
+def test_g15_step_at_reference_widths(golden, M):
+    """One reference SVDD-MC step at M = 10 (decode.py's default) and M = 20 (BASELINE configs[3]) with exact ties,
+    1-ulp plateaus and near-uniform scores: the selection index is the reference's in every row; the soft values agree
+    to 1e-6 (ATen's vectorised normaliser vs the oracle's left-to-right sum differ in the last bit from M = 16 on)."""
+    g = golden(f"g15_step_mc_m{M}.npz")
+    x = g["x"].astype(np.uint8)
+    B, L = x.shape
+    uni = orc.MT19937(int(g["seed"])).torch_rand(M, B, 5, L)
+    cand, _, q = orc.propose(bvl(g["logits"]), x, float(g["dm"]), float(g["mcs"]), M, uniforms=uni, layout=orc.BVL)
+    assert np.allclose(np.swapaxes(q, 1, 2), g["q_xs"], rtol=2e-6, atol=0)
+    assert np.array_equal(cand, g["cand"])
+    x_next, soft, idx = orc.select(g["scores"], cand)
+    assert np.array_equal(idx, g["idx"])
+    assert np.abs(soft - g["soft"]).max() <= 1e-6
+    assert np.array_equal(x_next, g["x_next"])
+
+
 def test_g7_tweedie_trajectory_stepwise(golden):
     g = golden("g7_traj_pm.npz")
     S, B, L, M = int(g["S"]), int(g["B"]), int(g["L"]), int(g["M"])

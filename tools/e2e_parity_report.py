@@ -6,13 +6,20 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-from svdd_amd import e2e_parity
+from svdd_amd import e2e_parity, synthetic
 
 G = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 nets = dict(np.load(os.path.join(G, "nets_tiny.npz")))
-out = {}
+out = {"tiny_nets_free_running": {}, "fullsize_teacher_forced": {}, "fullsize_free_running": {}}
 for name in ("g6_traj_mc_c1.npz", "g6_traj_mc_s16.npz"):
     g = dict(np.load(os.path.join(G, name)))
-    out[name] = [e2e_parity.compare_with_reference_run(g, nets, fuse_nets=f, value_batching=vb)
-                 for f, vb in ((True, "batched"), (False, "batched"), (False, "reference"))]
+    out["tiny_nets_free_running"][name] = [e2e_parity.compare_with_reference_run(g, nets, fuse_nets=True, value_batching=vb)
+                                           for vb in ("batched", "reference")]
+model, emb, head, _ = synthetic.build("dna", "cuda:0")
+for name in ("g13_traj_mc_full_c1.npz", "g13_traj_mc_full_m10.npz"):
+    g = dict(np.load(os.path.join(G, name)))
+    out["fullsize_teacher_forced"][name] = [e2e_parity.teacher_forced_report(g, model, emb, head, p)
+                                            for p in ("f32", "f16x3", "bf16x3", "f16", "bf16")]
+    out["fullsize_free_running"][name] = [e2e_parity.compare_engine_with_reference_run(g, model, emb, head, True, "batched", p)
+                                          for p in ("f32", "f16x3", "bf16x3")]
 print(json.dumps(out, indent=1))
