@@ -41,8 +41,9 @@ Engine knobs (attributes; defaults reproduce the reference's observable behaviou
                    (the selected candidate's logits ARE the next parent's). With logits_cache the backbone also skips
                    rows whose x_t did not change. Compaction is done on the device; no host round trip in the loop.
                    Decodes are bit-identical to skip_unchanged = False (tests/test_skip_gpu.py). Needs the fused nets.
-  logits_cache     "auto" (default): per-row logits cache when several sequences share a backbone tile (L <= 104; at
-                   L = 200 one workgroup owns one sequence and skipping rows frees CUs but saves no time); "on" / "off".
+  logits_cache     "auto" (default): SVDD-MC keeps a per-row logits cache when several sequences share a backbone tile
+                   (L <= 104; at L = 200 one workgroup owns one sequence and skipping rows frees CUs but saves no
+                   time); "on" / "off". (SVDD-PM always carries the selected candidate's logits forward.)
   skip_stats       None, or a dict the samplers fill with device-side hit counters (live candidates, changed rows).
   skip_generic     False (default). True: SVDD-MC also skips the copies of the parent for an OPAQUE value function (any
                    nn.Module, e.g. the Enformer-shaped trunk): the live candidates are gathered into a smaller batch whose
@@ -63,16 +64,55 @@ from . import noise_schedule, ops
 from .backbone import CNNModel
 
 
-def weight_fingerprint(*modules):
-    """Cheap identity of the weights of `modules`: (storage address, in-place version counter, shape) of every
-    parameter and buffer. Changes when a tensor is replaced (load_state_dict with assign, .to()), or modified in
-    place (optimizer step, load_state_dict copy_, manual edits) — the cases in which a cached re-packing of the
-    weights would silently go stale."""
-    fp = []
+def _capturing():
+    return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+
+
+def weight_fingerprint(*modules, content=True):
+    """Identity of the weights of `modules`: (storage address, in-place version counter, shape) of every parameter and
+    buffer — changes when a tensor is replaced (load_state_dict with assign, .to()) or modified in place through autograd-
+    visible ops (optimizer step, load_state_dict copy_) — plus, with `content`, a CONTENT checksum (1- and 2-norm of every
+    floating tensor, two multi-tensor launches and one read-back): writes through `.data` do not bump `_version`
+    (`p.data.copy_(...)` is how the reference swaps EMA weights around sampling, models/ema.py:62,87 with
+    diffusion_gosai.py:1564-1574), and a cached re-packing of the weights must not survive them. -> (meta, content)."""
+    meta, tensors = [], []
     for m in modules:
         for t in list(m.parameters()) + list(m.buffers()):
-            fp.append((t.data_ptr(), t._version, tuple(t.shape)))
-    return tuple(fp)
+            meta.append((t.data_ptr(), t._version, tuple(t.shape)))
+            if t.is_floating_point() and t.numel():
+                tensors.append(t.detach())
+    chk = None
+    if content and tensors and not _capturing():
+        by_dev = {}
+        for t in tensors:
+            by_dev.setdefault((t.device, t.dtype), []).append(t)
+        parts = []
+        for ts in by_dev.values():
+            parts.append(torch.stack(torch._foreach_norm(ts, 1) + torch._foreach_norm(ts, 2)).double().cpu())
+        chk = tuple(torch.cat(parts).tolist())
+    return tuple(meta), chk
+
+
+def _same_weights(a, b):
+    """Fingerprints equal; a side without a content checksum (taken during graph capture) compares by meta only."""
+    return a[0] == b[0] and (a[1] is None or b[1] is None or a[1] == b[1])
+
+
+def _decode_scope(fn):
+    """Marks one call of a public sampler method: the fused-net caches are validated against the modules' weights once
+    per outermost call (a decode), not at every diffusion step."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, *a, **k):
+        if self._scope_depth == 0:
+            self._scope_id += 1
+        self._scope_depth += 1
+        try:
+            return fn(self, *a, **k)
+        finally:
+            self._scope_depth -= 1
+    return wrapped
 
 
 class Diffusion(nn.Module):
@@ -120,6 +160,7 @@ class Diffusion(nn.Module):
         self.state_trace = None    # set to a list to record x_t (uint8 clone) at the start of every step + the final x
         self._sched_cache = {}
         self._fused = {}
+        self._scope_depth, self._scope_id = 0, 0
 
     # ------------------------------------------------------------------ plumbing ----
     @property
@@ -142,20 +183,27 @@ class Diffusion(nn.Module):
         return x if x.dtype == torch.uint8 else x.to(torch.uint8)
 
     def clear_fused(self):
-        """Drop the cached fused formulations and the backbone's cached zero-sigma time biases. Not needed after a
-        weight change: every cache entry carries a fingerprint of the weights it was built from and is rebuilt when
-        that no longer matches (`weight_fingerprint`)."""
+        """Drop the cached fused formulations and the backbone's cached zero-sigma time biases. Every cache entry carries
+        a fingerprint of the weights it was built from (tensor identity, in-place version AND a content checksum, so
+        `.data` / EMA swaps are caught too) and is rebuilt at the next decode when that no longer matches; call this to
+        force it, or after changing weights in the middle of a per-step loop inside one sampler call."""
         self._fused = {}
         if isinstance(self.backbone, CNNModel):
             self.backbone.clear_time_bias_cache()
 
+    def _checked_now(self, stamp):
+        return self._scope_depth > 0 and stamp == self._scope_id
+
     def _fused_backbone(self):
-        fp = weight_fingerprint(self.backbone)
         ent = self._fused.get("backbone")
-        if ent is None or ent[0] != fp:
-            from .fused import FusedBackbone
-            self.backbone.clear_time_bias_cache()
-            ent = (fp, FusedBackbone(self.backbone).to(self.device).eval())
+        if ent is None or not self._checked_now(ent[2]):
+            fp = weight_fingerprint(self.backbone)
+            if ent is None or not _same_weights(ent[0], fp):
+                from .fused import FusedBackbone
+                self.backbone.clear_time_bias_cache()
+                ent = (fp, FusedBackbone(self.backbone).to(self.device).eval(), self._scope_id)
+            else:
+                ent = (ent[0], ent[1], self._scope_id)
             self._fused["backbone"] = ent
         ent[1].precision = self.precision
         return ent[1]
@@ -168,15 +216,20 @@ class Diffusion(nn.Module):
                 and embedding.gru_tower.gru.num_layers == 1 and next(embedding.parameters()).is_cuda):
             # The fused net holds re-packed COPIES of the weights, so an entry is valid only for these very module
             # objects (weak references: id() alone can be recycled after garbage collection) with these very
-            # weights (fingerprint). The check costs ~50 us and is made once per decode, not per step.
+            # weights (fingerprint incl. a content checksum). Checked once per decode (_decode_scope), not per step.
             key = ("value", id(embedding), id(head))
-            fp = weight_fingerprint(embedding, head)
             ent = self._fused.get(key)
-            if ent is None or ent[0]() is not embedding or ent[1]() is not head or ent[2] != fp:
-                from .fused import FusedValueNet
-                for k in [k for k, v in self._fused.items() if k != "backbone" and (v[0]() is None or v[1]() is None)]:
-                    del self._fused[k]                              # entries of collected modules
-                ent = (weakref.ref(embedding), weakref.ref(head), fp, FusedValueNet(embedding, head).to(self.device).eval())
+            alive = ent is not None and ent[0]() is embedding and ent[1]() is head
+            if not (alive and self._checked_now(ent[4])):
+                fp = weight_fingerprint(embedding, head)
+                if not (alive and _same_weights(ent[2], fp)):
+                    from .fused import FusedValueNet
+                    for k in [k for k, v in self._fused.items() if k != "backbone" and (v[0]() is None or v[1]() is None)]:
+                        del self._fused[k]                          # entries of collected modules
+                    ent = (weakref.ref(embedding), weakref.ref(head), fp,
+                           FusedValueNet(embedding, head).to(self.device).eval(), self._scope_id)
+                else:
+                    ent = ent[:4] + (self._scope_id,)
                 self._fused[key] = ent
             ent[3].precision = self.precision
             return ent[3]
@@ -296,6 +349,7 @@ class Diffusion(nn.Module):
         assert sigma.ndim == 1, sigma.shape
         return sigma
 
+    @_decode_scope
     def forward(self, x, sigma):
         """Returns log score: backbone logits under the SUBS parameterization (:339-357)."""
         self._require_gpu()
@@ -327,6 +381,7 @@ class Diffusion(nn.Module):
         return F.one_hot((samples * mask).long(), num_classes=num_classes) * mask.unsqueeze(-1)
 
     # --------------------------------------------------------------- per-step updates ----
+    @_decode_scope
     @torch.no_grad()
     def _ddpm_update_finetune(self, x, t, dt):
         """Un-guided ancestral step (:1147-1172) -> (x_next, x, q_xs, copy_flag)."""
@@ -338,6 +393,7 @@ class Diffusion(nn.Module):
         cand, _, q = ops.propose(logits, x_u8, dm, mcs, 1, self._rng(self._step_index(t, dt), 1, B, L, logits), want_q=True)
         return cand[:, 0].long(), x, q, (x != self.mask_index).to(x.dtype)
 
+    @_decode_scope
     @torch.no_grad()
     def _ddpm_update_finetune_controlled(self, x, t, dt, pre_scorer_embedding, pre_scorer_head, repeats=10):
         """One SVDD-MC step (:1174-1228) -> (final_samples, x, q_xs, copy_flag)."""
@@ -352,6 +408,7 @@ class Diffusion(nn.Module):
         x_next = self._select(scores, cand, step)
         return x_next.long(), x, q, (x != self.mask_index).to(x.dtype)
 
+    @_decode_scope
     @torch.no_grad()
     def _ddpm_update_finetune_controlled_twedie(self, x, t, dt, reward_model, repeats=10, options="True", task="dna"):
         """One SVDD-PM step (:1373-1460) -> (final_samples, x, q_xs, copy_flag)."""
@@ -379,6 +436,7 @@ class Diffusion(nn.Module):
             oh = ops.transform_samples(flat, transposed=True)             # heuristic branch :1420-1424
         return self.reward_callable(reward_model)(oh)[:, 0].reshape(B, M).float()   # :1430,1436
 
+    @_decode_scope
     @torch.no_grad()
     def _ddpm_update_finetune_controlled_TDS(self, x, t, dt, reward_model, alpha=1.0):
         """One SMC/TDS step (:1230-1284) -> x_next. Consumes B doubles of numpy's global RandomState,
@@ -481,12 +539,14 @@ class Diffusion(nn.Module):
             cand, _ = ops.sample_categorical(q_xs, x_u8, 1, self._rng(step, 1, B, L, q_xs))   # :1316-1319
         return cand.view(B, L)
 
+    @_decode_scope
     def _ddpm_update_finetune_controlled_DPS(self, x, t, dt, reward_model, guidance_scale):
         """One DPS (gradient-guidance) step (:1286-1319) -> x_next."""
         self._require_gpu()
         mct, mcs, dm = self._step_scalars(t, dt)
         return self._dps_step(self._tokens_u8(x), mct, mcs, dm, reward_model, guidance_scale, self._step_index(t, dt)).long()
 
+    @_decode_scope
     def controlled_sample_DPS(self, reward_model, guidance_scale, num_steps=None, eps=1e-5, eval_sp_size=None,
                               sample_M=10):
         """DPS baseline decode (:980-1019). Not under no_grad in the reference either: it back-propagates."""
@@ -500,6 +560,7 @@ class Diffusion(nn.Module):
             return self._noise_removal(x)
 
     # ------------------------------------------------------------------ outer loops ----
+    @_decode_scope
     @torch.no_grad()
     def decode_sample(self, num_steps=None, eps=1e-5, eval_sp_size=None, cdq=False):
         """Un-guided decode (:888-936) -> LongTensor[B,L]."""
@@ -513,6 +574,7 @@ class Diffusion(nn.Module):
             x = cand.view(B, L)
         return self._noise_removal(x)
 
+    @_decode_scope
     @torch.no_grad()
     def _sample(self, num_steps=None, eps=1e-5, eval_sp_size=None, cdq=False):
         """Un-guided decode that also returns the S-1 intermediate states (:820-886)."""
@@ -531,6 +593,7 @@ class Diffusion(nn.Module):
                 mid_x.append(x.long())
         return self._noise_removal(x), mid_x
 
+    @_decode_scope
     @torch.no_grad()
     def controlled_sample(self, pre_scorer_embedding, pre_scorer_head, num_steps=None, eps=1e-5,
                           eval_sp_size=None, sample_M=10):
@@ -542,9 +605,10 @@ class Diffusion(nn.Module):
         cand = torch.empty((B, M, L), dtype=torch.uint8, device=self.device)
         onehot = torch.empty((B * M, L, 4), dtype=torch.float32, device=self.device)
         fn = self.value_callable(pre_scorer_embedding, pre_scorer_head)
-        if self._can_skip(fn, L, M) and fn.candidates_ok(L, M):
+        if self._can_skip(fn, L, M):
             return self._controlled_sample_skipping(fn, x, cand, onehot, sched, B, L, S, M)
-        if self.skip_unchanged and self.skip_generic and M > 1 and self.value_batching == "batched":
+        if (self.skip_unchanged and self.skip_generic and M > 1 and self.value_batching == "batched" and
+                self.select_mode in ("argmax", "multinomial")):
             return self._controlled_sample_generic_skipping(fn, x, cand, onehot, sched, B, L, S, M)
         for i in range(S):
             logits = self._backbone_logits(x)
@@ -612,13 +676,20 @@ class Diffusion(nn.Module):
                                    row_steps=B * S, changed_row_steps=int(ws.n_changed))
 
     def _use_logits_cache(self, L):
+        """Per-row logits cache of the SVDD-MC skipping loop. "auto": where several sequences share a backbone tile
+        (L <= 104) — at L = 200 one workgroup owns one sequence and skipping rows frees CUs but saves no time."""
         return self.logits_cache == "on" or (self.logits_cache == "auto" and 208 // L >= 2)
 
     def _controlled_sample_skipping(self, fn, x, cand, onehot, sched, B, L, S, M):
-        """SVDD-MC with exact work-skipping (same tokens as the plain loop, bit for bit)."""
+        """SVDD-MC with exact work-skipping (same tokens as the plain loop, bit for bit). 104 < L <= 208 (one sequence per
+        tile): the value net's tower also shares the parent's rows (candidate_scores_compact); shorter sequences: the
+        live candidates' token rows are gathered into a compact batch and scored whole (forward_tokens)."""
+        from .fused import candidate_windows
         ws = self._SkipWorkspace(B, M, self.device)
         ws.parent_score.copy_(fn.forward_tokens(x).reshape(B))               # scores of the all-MASK parents
         fb = self._fused_backbone_or_none(L) if self._use_logits_cache(L) else None
+        share = fn.candidates_ok(L, M)
+        toks_c = None if share else torch.empty((B * M, L), dtype=torch.uint8, device=self.device)
         logits = None
         for i in range(S):
             if fb is None or logits is None:
@@ -627,7 +698,13 @@ class Diffusion(nn.Module):
                 ops.compact_flags(ws.changed, ws.row_idx, ws.row_slot, ws.row_count)
                 fb.forward_rows(x, count=ws.row_count, out=logits, row_idx=ws.row_idx, scatter=True)
             ops.propose(logits, x, sched[i, 2], sched[i, 1], M, self._rng(i, M, B, L, logits), cand=cand, onehot=onehot)
-            sc = fn.candidate_scores_compact(onehot, cand, x, ws).reshape(-1)
+            if share:
+                sc = fn.candidate_scores_compact(onehot, cand, x, ws).reshape(-1)
+            else:
+                candidate_windows(cand, x, margin=0, flags=ws.flags)
+                ops.compact_flags(ws.flags, ws.live_idx, ws.slot, ws.count)
+                ops.gather_rows(cand.view(B * M, L), ws.live_idx, ws.count, toks_c)
+                sc = fn.forward_tokens(toks_c, count=ws.count).reshape(-1)
             if self.trace is not None or self.state_trace is not None:
                 self._record(logits, self._dense_scores(sc, ws, B, M), x)
             x = self._select_compact(sc, ws, cand, i)
@@ -639,7 +716,11 @@ class Diffusion(nn.Module):
         read back once per step), copies take the parent's score (= the score of the candidate selected a step earlier)."""
         from .fused import candidate_windows
         ws = self._SkipWorkspace(B, M, self.device)
-        ws.parent_score.copy_(fn(ops.transform_samples(x)).reshape(B).float())
+        first = fn(ops.transform_samples(x))
+        if first.numel() != B:
+            raise ops.SvddError("skip_generic needs a single-task value function (one score per candidate); "
+                                f"got {tuple(first.shape)} for a batch of {B}")
+        ws.parent_score.copy_(first.reshape(B).float())
         sc = torch.zeros(B * M, device=self.device)
         for i in range(S):
             logits = self._backbone_logits(x)
@@ -689,6 +770,7 @@ class Diffusion(nn.Module):
         self._finish_stats(ws, B, M, S, "pm")
         return self._noise_removal(x, logits)
 
+    @_decode_scope
     @torch.no_grad()
     def controlled_sample_tweedie(self, reward_model, num_steps=None, eps=1e-5, eval_sp_size=None, sample_M=10,
                                   options=True, task="dna"):
@@ -710,6 +792,7 @@ class Diffusion(nn.Module):
             x = self._select(scores, cand, i)
         return self._noise_removal(x)
 
+    @_decode_scope
     @torch.no_grad()
     def controlled_sample_TDS(self, reward_model, alpha, num_steps=None, eps=1e-5, eval_sp_size=None, sample_M=10):
         """SMC/TDS baseline decode (:938-978)."""

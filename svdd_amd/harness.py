@@ -13,6 +13,18 @@ The reference's `BaseModel.__init__` hard-wires checkpoint paths, Hydra and `.cu
 import torch
 from torch import nn
 
+_M64 = (1 << 64) - 1
+
+
+def batch_seed(base, k):
+    """64-bit Philox key of batch k of a harness call whose model carries philox_seed = base: splitmix64 of
+    (base, k). `base + k` would make batch k + 1 of seed s the same decode as batch k of seed s + 1, so runs at seeds
+    0, 1, 2, ... would share all but one of their batches and understate the run-to-run variance."""
+    z = (int(base) + 0x9E3779B97F4A7C15 * (int(k) + 1)) & _M64
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _M64
+    return z ^ (z >> 31)
+
 
 class BaseModel(nn.Module):
     def __init__(self, embedding, head, ref_model, reward_model, batch_size, task="dna", n_tasks=1,
@@ -67,11 +79,12 @@ class BaseModel(nn.Module):
     def _next_batch_seed(self):
         """Philox mode: the sampler is a pure function of (philox_seed, row, step), so consecutive batches would be
         copies of each other; the reference's batches differ because they share torch's global generator
-        (Enformer.py:439-467). Every batch of a harness call therefore gets the next seed base + k (deterministic given
-        the model's philox_seed at entry); replay mode keeps drawing from the global generator like the reference."""
+        (Enformer.py:439-467). Batch k of a harness call therefore gets the key batch_seed(base, k) (deterministic given
+        the model's philox_seed at entry, and never shared between different entry seeds); replay mode keeps drawing
+        from the global generator like the reference."""
         m = self.ref_model
         if getattr(m, "rng_mode", "replay") == "philox":
-            m.philox_seed = self._seed_base + self._batch_index
+            m.philox_seed = batch_seed(self._seed_base, self._batch_index)
         self._batch_index += 1
 
     def _decode(self, gen_batch_num, sample_M, guided):
@@ -134,7 +147,7 @@ class BaseModel(nn.Module):
         try:
             for k in range(gen_batch_num):
                 if getattr(m, "rng_mode", "replay") == "philox":
-                    m.philox_seed = base + k                      # the seed _decode would give guided batch k
+                    m.philox_seed = batch_seed(base, k)           # the key _decode would give guided batch k
                 out.append(m.controlled_sample_DPS(self.reward_model, guidance_scale,
                                                    eval_sp_size=self.NUM_SAMPLES_PER_BATCH, sample_M=sample_M))
         finally:

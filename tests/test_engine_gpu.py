@@ -299,6 +299,20 @@ def test_fused_net_cache_follows_weight_changes():
         assert torch.allclose(model._backbone_logits(x), lg0 + 1.0, atol=1e-5)
         model.backbone.load_state_dict(sd)                                  # back: copy_ bumps the versions again
         assert torch.equal(model._backbone_logits(x), lg0)
+        # EMA-style swap through .data (reference models/ema.py:62,87 around diffusion_gosai.py:1564-1574): no version
+        # bump, caught by the content checksum at the next decode
+        b = model.backbone.final_conv[2].bias
+        v, saved = b._version, b.data.clone()
+        b.data.copy_(saved + 2.0)
+        assert b._version == v
+        assert torch.allclose(model._backbone_logits(x), lg0 + 2.0, atol=1e-5)
+        b.data.copy_(saved)
+        assert torch.equal(model._backbone_logits(x), lg0)
+        hb = head.channel_transform.conv.layer.bias
+        f3 = model.value_callable(emb, head)
+        a3 = f3(oh).clone()
+        hb.data.copy_(hb.data - 0.25)
+        assert torch.allclose(model.value_callable(emb, head)(oh), a3 - 0.25, atol=1e-5)
         # modules that die must not leave their entries behind for an id() twin
         n_before = len(model._fused)
         _, emb2, head2, _ = synthetic.build("dna", DEV, seed=7)

@@ -28,7 +28,7 @@ def _onehot(tok):
 
 @pytest.mark.parametrize("method", ["mc", "tweedie"])
 def test_controlled_decode_values(small, method):
-    from svdd_amd.harness import BaseModel
+    from svdd_amd.harness import BaseModel, batch_seed
     model, emb, head, reward = small
     Bsz, M, G = 4, 3, 2
     model.rng_mode, model.philox_seed = "philox", 40
@@ -43,7 +43,7 @@ def test_controlled_decode_values(small, method):
     exp_samples, exp_v, exp_r = [], [], []
     with torch.no_grad():
         for k in range(G):
-            model.philox_seed = 40 + k
+            model.philox_seed = batch_seed(40, k)
             if method == "mc":
                 b = model.controlled_sample(emb, head, eval_sp_size=Bsz, sample_M=M)
             else:
@@ -53,7 +53,7 @@ def test_controlled_decode_values(small, method):
             exp_r.append(reward(_onehot(b).transpose(1, 2))[:, 0].reshape(Bsz))
         all_base = []
         for i in range(G * M):
-            model.philox_seed = 40 + G + i
+            model.philox_seed = batch_seed(40, G + i)
             b = model.decode_sample(eval_sp_size=Bsz)
             all_base.append(reward(_onehot(b).transpose(1, 2))[:, 0].reshape(Bsz))
     model.philox_seed = 40

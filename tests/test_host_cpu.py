@@ -223,6 +223,15 @@ def test_weight_fingerprint_tracks_in_place_and_replaced_weights():
     assert weight_fingerprint(lin) != fp1
     lin.weight = torch.nn.Parameter(lin.weight.detach().clone())   # replaced tensor
     assert weight_fingerprint(lin) != fp1
+    # writes through .data do not bump _version (how the reference's EMA swaps weights around sampling,
+    # models/ema.py:62,87): only the content checksum sees them
+    fp2, v = weight_fingerprint(lin), lin.weight._version
+    saved = lin.weight.data.clone()
+    lin.weight.data.copy_(saved * 0.5)
+    assert lin.weight._version == v and weight_fingerprint(lin, content=False) == weight_fingerprint(lin, content=False)
+    assert weight_fingerprint(lin)[0] == fp2[0] and weight_fingerprint(lin) != fp2
+    lin.weight.data.copy_(saved)                                    # restore: the packed copy is valid again
+    assert weight_fingerprint(lin) == fp2
 
 
 _TDS_WORKER = r"""
@@ -268,3 +277,13 @@ def test_tds_exchange_needs_a_process_group():
     with pytest.raises(RuntimeError, match="process group"):
         distributed.tds_exchange((0, 2, 4, 2), torch.zeros(2, 3, dtype=torch.uint8), torch.zeros(2), torch.zeros(2),
                                  torch.zeros(4, dtype=torch.float64))
+
+
+def test_harness_batch_keys_do_not_collide_across_user_seeds():
+    """Philox mode: batch k of a harness call is keyed by splitmix64(seed, k). With `seed + k` the runs at seeds 0, 1, 2, ...
+    shared all but one batch each (batch k + 1 of seed s == batch k of seed s + 1)."""
+    from svdd_amd.harness import batch_seed
+    keys = {(s, k): batch_seed(s, k) for s in range(64) for k in range(64)}
+    assert len(set(keys.values())) == len(keys)
+    assert all(0 <= v < 2 ** 64 for v in keys.values())
+    assert batch_seed(7, 3) == batch_seed(7, 3) and batch_seed(0, 1) != batch_seed(1, 0)
