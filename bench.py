@@ -3,6 +3,12 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+`python bench.py --gpus N` with N > 1 from a bare shell (no WORLD_SIZE in the environment) starts the N ranks itself:
+the parent spawns `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD process before it has
+touched the GPU, relays rank 0's JSON line and exits with the child's code. `--dry-run` exercises the launch, the
+rendezvous, the barrier / max-over-ranks timing and the one all-gather with a stand-in decode on the host (gloo; no GPU
+needed): its line says "dry_run": true and carries no throughput.
+
 One bench "step" = one full `Diffusion.controlled_sample` decode of one batch (config 2 of
 BASELINE.json: DNA enhancer SVDD-MC, batch=256 per GPU, L=200, M=10, 128 diffusion steps,
 random-init dilated-CNN backbone + ConvGRU value net, synthetic all-MASK prior), from the prior to
@@ -32,6 +38,8 @@ Prints ONE JSON line (rank 0). Extra objects:
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -143,6 +151,86 @@ def cpu_baseline(B, L, M, S, sample_steps, seed=44, threads=16, states=None):
     }
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` from a bare shell: start the N ranks as a child `torch.distributed.run` (one process per
+    GPU, rendezvous on 127.0.0.1) and return its exit code. Runs BEFORE this process has touched the GPU — a process that
+    initialised the GPU must never replace itself with another program on this pool, so nothing is exec'd here either."""
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    if "--dry-run" not in sys.argv and torch.cuda.device_count() < n:     # (device_count does not initialise the GPU)
+        # fewer GPUs than ranks: the ranks share devices, which RCCL refuses — host-side collectives, labelled in the line
+        env.setdefault("SVDD_DIST_BACKEND", "gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # the child's stdout is filtered: rank 0's JSON line goes to stdout, anything else (gloo's connection banner, ...) to stderr
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+    for ln in proc.stdout:
+        (sys.stdout if ln.lstrip().startswith("{") else sys.stderr).write(ln)
+    sys.stdout.flush()
+    return proc.wait()
+
+
+def dry_run(args):
+    """The N-rank skeleton of the bench without the GPU: rendezvous (gloo), barrier-bracketed timing with the MAX over
+    ranks, weak-scaling row ownership (rank r owns global rows r*B .. r*B + B - 1) and the one all-gather of the decoded
+    tokens, with a stand-in "decode" that is a pure function of the global row (what Philox keying gives the real one).
+    Verifies the gathered batch on every rank. No throughput is reported."""
+    import torch.distributed as dist
+    from svdd_amd import distributed
+    rank, world, _ = distributed.init_from_env("gloo")
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    B, L = args.batch, args.length
+    rows = lambda lo, n: ((torch.arange(lo, lo + n)[:, None] * 7 + torch.arange(L)[None, :]) % 4).to(torch.uint8)   # noqa: E731
+    rank_times = []
+
+    def one():
+        t_a = time.perf_counter()
+        x0 = rows(rank * B, B)
+        t_b = time.perf_counter()
+        out = distributed.gather_tokens(x0, B * world)
+        rank_times.append((t_b - t_a, time.perf_counter() - t_b))
+        return out
+    for _ in range(args.warmup):
+        one()
+    if world > 1:
+        dist.barrier()
+    rank_times.clear()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = one()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    assert torch.equal(out, rows(0, B * world)), f"rank {rank}: gathered batch differs"
+    per_rank = None
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        mine = torch.tensor([sum(t[0] for t in rank_times) / len(rank_times), sum(t[1] for t in rank_times) / len(rank_times)],
+                            dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = {"decode_ms": [round(float(t[0]) * 1e3, 3) for t in allr],
+                    "allgather_ms": [round(float(t[1]) * 1e3, 3) for t in allr]}
+    if rank == 0:
+        print(json.dumps({"metric": "decoded sequences/sec (whole node), L=200 M=10 128-step SVDD-MC", "value": None,
+                          "unit": "sequences/s", "dry_run": True, "n_gpus": world,
+                          "ranks_seen": dist.get_world_size() if world > 1 else 1,
+                          "backend": dist.get_backend() if world > 1 else None, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(elapsed / args.steps * 1e3, 3), "scaling": "weak",
+                          "config": {"workload": "stand-in decode on the host (launch / rendezvous / all-gather check only)",
+                                     "global_batch": B * world, "sharding": f"rows x{world}, 1 all-gather"},
+                          "gathered_rows_verified": B * world, "per_rank": per_rank}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -159,7 +247,15 @@ def main():
     ap.add_argument("--alt-steps", type=int, default=2, help="timed decodes per alt-precision mode")
     ap.add_argument("--value-net", default="convgru", choices=["convgru", "enformer"],
                     help="enformer: the 230M-parameter Enformer-shaped value trunk of BASELINE config 4 (not the headline config)")
+    ap.add_argument("--cpu-passes", type=int, default=3, help="cpu_baseline passes; the median is reported (BASELINE.md section 2)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launch / rendezvous / all-gather skeleton with a stand-in decode on the host (no GPU, gloo)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
+    if args.dry_run:
+        return dry_run(args)
 
     from svdd_amd import _lib, distributed, synthetic
     from svdd_amd.backbone import CNNModel
@@ -167,7 +263,7 @@ def main():
     import torch.distributed as dist
 
     rank, world, local = distributed.init_from_env()
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     local = local % max(torch.cuda.device_count(), 1)        # (dry runs with more ranks than GPUs share devices)
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"

@@ -287,3 +287,26 @@ def test_harness_batch_keys_do_not_collide_across_user_seeds():
     assert len(set(keys.values())) == len(keys)
     assert all(0 <= v < 2 ** 64 for v in keys.values())
     assert batch_seed(7, 3) == batch_seed(7, 3) and batch_seed(0, 1) != batch_seed(1, 0)
+
+
+def test_bench_starts_its_own_ranks_from_a_bare_shell():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment (how the driver invokes it): the parent spawns the
+    two ranks itself (torch.distributed.run as a child, 127.0.0.1 rendezvous), relays rank 0's single JSON line and its
+    exit code. --dry-run keeps the GPU out of it: launch, gloo rendezvous, barrier / max-over-ranks timing, row ownership
+    and the one all-gather are the real code; the decode is a stand-in."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "2",
+                          "--warmup", "1", "--batch", "12"], capture_output=True, text=True, timeout=300, env=env, cwd="/tmp")
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, res.stdout
+    line = json.loads(lines[0])
+    assert line["dry_run"] is True and line["value"] is None
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["backend"] == "gloo"
+    assert line["gathered_rows_verified"] == 24 and len(line["per_rank"]["decode_ms"]) == 2
+    # a failing rank must fail the whole command
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "0"],
+                         capture_output=True, text=True, timeout=300, env=env, cwd="/tmp")
+    assert bad.returncode != 0

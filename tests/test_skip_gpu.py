@@ -143,6 +143,27 @@ def test_mc_decode_config2_skipping_is_bit_identical(precision):
     model.precision = "f32"
 
 
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_mc_decode_short_sequences_skipping_is_bit_identical(precision):
+    """SVDD-MC at L = 50 (several sequences per tile): the live candidates' token rows are gathered and scored as a compact
+    batch, and the per-row logits cache (logits_cache = "auto" applies here) recomputes only the rows the last select
+    changed. Tokens and every step's logits / scores equal the plain loop's, bit for bit."""
+    from svdd_amd import synthetic
+    model, emb, head, reward = synthetic.build("rna", DEV)
+    model.rng_mode, model.philox_seed, model.precision = "philox", 21, precision
+    B, M, S = 256, 10, 128
+    assert model._use_logits_cache(50) and not model._use_logits_cache(200)
+    off, tr_off, _ = _decode(model, "mc", emb, head, reward, B, M, S, skip=False, trace=True)
+    on, tr_on, st = _decode(model, "mc", emb, head, reward, B, M, S, skip=True, trace=True)
+    nocache, _, _ = _decode(model, "mc", emb, head, reward, B, M, S, skip=True, cache="off")
+    assert torch.equal(on, off) and torch.equal(nocache, off)
+    assert st["kind"] == "mc" and st["live_candidates"] < 0.8 * st["candidates"] and st["changed_row_steps"] < st["row_steps"]
+    for (la, sa), (lb, sb) in zip(tr_on, tr_off):
+        assert torch.equal(la, lb)
+        assert (sa is None and sb is None) or torch.equal(sa, sb)
+    model.precision = "f32"
+
+
 def test_mc_decode_config4_shard_skipping_is_bit_identical():
     """BASELINE.json configs[3] per-GPU shard (SVDD-MC, B = 2048 / 8 = 256, L = 200, M = 20), ConvGRU value net."""
     from svdd_amd import synthetic

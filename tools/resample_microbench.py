@@ -1,0 +1,67 @@
+"""K2 (select + index-gather compaction) and K4 (TDS resample) at sizes where launch latency is gone.
+Usage (GPU box): python tools/resample_microbench.py  -> one line per case: us per launch, algorithmic GB/s, fraction of 8 TB/s.
+Algorithmic bytes: K2 B*(4M + 2L + 4) (scores + winning row in, x_next + idx out); K4 B*(2L + 8 + 8 + 4 + 4)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from svdd_amd import ops
+
+DEV = "cuda:0"
+PEAK = 8000.0
+
+
+def timed(fn, iters=20, warm=5):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3          # us
+
+
+def k2(B, M, L=200, compact=False):
+    g = torch.Generator(device=DEV).manual_seed(0)
+    scores = torch.randn(B, M, device=DEV, generator=g) * 1e-3
+    cand = torch.randint(0, 5, (B, M, L), device=DEV, generator=g, dtype=torch.uint8)
+    x_next = torch.empty(B, L, dtype=torch.uint8, device=DEV)
+    if compact:
+        live = torch.rand(B * M, device=DEV, generator=g) < 0.77
+        slot = torch.where(live, torch.cumsum(live.int(), 0) - 1, -1).int()
+        sc = scores.reshape(-1)[live].contiguous()
+        parent = torch.randn(B, device=DEV, generator=g) * 1e-3
+        sel, ch, idx = torch.empty(B, device=DEV), torch.empty(B, dtype=torch.int32, device=DEV), torch.empty(B, dtype=torch.int32, device=DEV)
+        fn = lambda: ops.select_compact(sc, slot, parent, cand, x_next=x_next, sel_score=sel, changed=ch, idx=idx)   # noqa: E731
+        nbytes = B * (4 * M + 4 * M + 2 * L + 4 + 12)
+    else:
+        fn = lambda: ops.select(scores, cand, want_soft=False, x_next=x_next)   # noqa: E731
+        nbytes = B * (4 * M + 2 * L + 4)
+    us = timed(fn)
+    gbs = nbytes / us / 1e3
+    print(f"K2 select{'_compact' if compact else ''} B={B} M={M} L={L}: {us:9.1f} us  {gbs:8.1f} GB/s  frac {gbs / PEAK:.3f}  ({nbytes / 1e6:.1f} MB)")
+
+
+def k4(B, L=200):
+    g = torch.Generator(device=DEV).manual_seed(0)
+    num, den = torch.randn(B, device=DEV, generator=g) * 0.1, torch.randn(B, device=DEV, generator=g) * 0.1
+    sample = torch.randint(0, 5, (B, L), device=DEV, generator=g, dtype=torch.uint8)
+    u = torch.rand(B, device=DEV, generator=g, dtype=torch.float64)
+    us = timed(lambda: ops.tds_resample(num, den, 0.5, sample, u), iters=10, warm=2)
+    nbytes = B * (2 * L + 24)
+    gbs = nbytes / us / 1e3
+    print(f"K4 tds_resample B={B} L={L}: {us:9.1f} us  {gbs:8.1f} GB/s  frac {gbs / PEAK:.4f}  ({nbytes / 1e6:.2f} MB)")
+
+
+if __name__ == "__main__":
+    for M in (10, 20):
+        k2(1 << 18, M)
+    k2(1 << 18, 10, compact=True)
+    k2(256, 10)
+    k2(256, 10, compact=True)
+    for B in (256, 2048, 65536):
+        k4(B)
