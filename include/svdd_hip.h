@@ -182,7 +182,8 @@ int svdd_select_compact(const float* scores, const int32_t* slot, const float* p
  *  reward_num, reward_den [B] fp32 ; sample [B,L] u8 ; u [B] fp64 uniforms in [0,1)
  *  (REPLAY of numpy's RandomState.random_sample, supplied by the host) ;
  *  out x_next [B,L] u8 ; idx [B] i32 (may be NULL) ; work [2*B] fp64 scratch (cdf + ratio).
- *  One shard's B particles are resampled by one workgroup (B <= ~64k).
+ *  Two launches on `stream`: the CDF (one workgroup; the float64 cumsum is a serial chain by numpy's definition) and the
+ *  searchsorted + row gather (whole chip). Any B; the pairwise sum's blocks run in parallel up to B = 131072.
  */
 int svdd_tds_resample(const float* reward_num, const float* reward_den, double alpha,
                       const uint8_t* sample, const double* u, int B, int L,
@@ -353,7 +354,8 @@ int svdd_value_tail_lp(const float* h_fwd, const float* h_bwd, const void* w1pac
  * exact (fp64, correctly rounded) arithmetic instead of the filtered fast path — same results, used
  * to A/B the filter. */
 enum { SVDD_OPT_FORCE_EXACT = 0,
-       SVDD_OPT_MSPLIT = 1 /* tuning: waves per 64-position tile in svdd_propose, 0 = auto */ };
+       SVDD_OPT_MSPLIT = 1 /* tuning: waves per 64-position tile in svdd_propose, 0 = auto */,
+       SVDD_OPT_SELECT_ONE_ROW = 2 /* A/B: svdd_select as one wave per row for every M (default: several rows per wave for M <= 64) */ };
 int svdd_set_option(int key, int value);
 
 /* Soak / profiling aid: while `device_counters2` (two zero-initialised uint64 on the device) is non-NULL, every

@@ -524,6 +524,116 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
   }
 }
 
+// K2 for M <= 64 (every BASELINE config: M = 2, 10, 20): SEVERAL ROWS PER WAVE. With one wave per row, 10 of 64 lanes
+// did the work and every row paid a whole wave's issue slots for the fp64 exp and the ordered sum: 212 us for 2^18 rows
+// (0.07 of the HBM roofline, profiles/r03_resample_before.txt). Here a wave owns G = 64 / MP consecutive rows (MP = M
+// rounded up to a power of two), lane = (row g, candidate m): the max / argmax reductions stay inside the MP-lane group
+// (xor shuffles with offsets < MP), the normaliser is still summed in candidate order (one bpermute per candidate, all
+// groups at once), and the G winning rows are copied with 8-byte units spread over all 64 lanes.
+// Argmax shortcut (exact): when a row's best score leads the runner-up by >= 2^-18, e_best = exp(0) = 1 and every other
+// e <= 1 - 2^-19, so after the common factor 1/sum the best candidate's soft value is strictly the largest — the softmax
+// need not be evaluated to know its argmax. Rows closer than that (the near-uniform scores of random-init value nets,
+// exact ties) take the exact path; the result is the same bits either way.
+template <int MP>
+__global__ __launch_bounds__(256) void select_rows_kernel(SelectArgs a) {
+  constexpr int G = WAVE / MP;
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int g = lane / MP, m = lane % MP;
+  const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * G;
+  if (row0 >= a.B) return;
+  const int64_t row = row0 + g;
+  const bool rv = row < a.B, valid = rv && m < a.M;
+  float sv = -INFINITY;
+  int sl_mine = -1;
+  if (valid) {
+    if (a.slot) { sl_mine = a.slot[row * a.M + m]; sv = sl_mine >= 0 ? a.scores[sl_mine] : a.parent_score[row]; }
+    else sv = a.scores[row * a.M + m];
+  }
+  // first-index argmax of the raw scores and the runner-up, inside the group
+  float bv = sv; int bi = valid ? m : 0x7fffffff;
+#pragma unroll
+  for (int off = MP / 2; off > 0; off >>= 1) {
+    const float ov = __shfl_xor(bv, off, WAVE);
+    const int oi = __shfl_xor(bi, off, WAVE);
+    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+  }
+  const float mx = bv;
+  float s2 = (valid && m != bi) ? sv : -INFINITY;
+#pragma unroll
+  for (int off = MP / 2; off > 0; off >>= 1) { const float o = __shfl_xor(s2, off, WAVE); s2 = o > s2 ? o : s2; }
+  int best = bi;
+  float p = 0.0f;
+  const bool clear = !rv || (mx - s2 >= 3.814697265625e-06f);                 // 2^-18; also M == 1 (s2 = -inf)
+  const bool exact = a.mode != SVDD_SELECT_ARGMAX || a.soft != nullptr || !clear;
+  if (__any(exact)) {
+    const float e = valid ? expf_cr(sv - mx) : 0.0f;
+    const int base = lane & ~(MP - 1);
+    float sum = 0.0f;
+    for (int j = 0; j < a.M; ++j) {                                           // candidate order: ((e0 + e1) + e2) + ...
+      const float ej = __shfl(e, base + j, WAVE);
+      sum = j == 0 ? ej : sum + ej;
+    }
+    const float r = __fdiv_rn(1.0f, sum);
+    p = e * r;                                                                // ATen CPU softmax: e * (1 / sum)
+    if (a.mode == SVDD_SELECT_ARGMAX) {
+      float pv = valid ? p : -INFINITY; int pi = valid ? m : 0x7fffffff;
+#pragma unroll
+      for (int off = MP / 2; off > 0; off >>= 1) {
+        const float ov = __shfl_xor(pv, off, WAVE);
+        const int oi = __shfl_xor(pi, off, WAVE);
+        if (ov > pv || (ov == pv && oi < pi)) { pv = ov; pi = oi; }
+      }
+      best = pi;
+    } else {
+      const uint64_t grow = a.row_offset + (uint64_t)(rv ? row : 0);
+      uint32_t ctr[4] = {(uint32_t)grow, (uint32_t)(grow >> 32), (a.step << 16), 2u};
+      philox4x32_10(ctr, (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
+      const float u = u24(ctr[0]);
+      float tot = 0.0f;
+      for (int j = 0; j < a.M; ++j) { const float pj = __shfl(p, base + j, WAVE); tot = j == 0 ? pj : tot + pj; }
+      const float thr = u * tot;
+      float run = 0.0f;
+      best = a.M - 1;
+      bool found = false;
+      for (int j = 0; j < a.M; ++j) {
+        const float pj = __shfl(p, base + j, WAVE);
+        run = j == 0 ? pj : run + pj;
+        if (!found && thr < run) { best = j; found = true; }
+      }
+    }
+    if (a.soft && valid) a.soft[row * a.M + m] = p;
+  }
+  if (rv && m == 0) {
+    if (a.idx) a.idx[row] = best;
+    if (a.slot) {
+      const int sl = a.slot[row * a.M + best];
+      if (a.sel_score) a.sel_score[row] = sl >= 0 ? a.scores[sl] : a.parent_score[row];   // the next step's parent score
+      if (a.changed) a.changed[row] = sl >= 0 ? 1 : 0;                                      // x_next != x
+    }
+  }
+  // index-gather compaction (diffusion_gosai.py:1226-1227): the G winning rows, unit-strided over the whole wave
+  const bool al8 = (a.L & 7) == 0 && ((reinterpret_cast<uintptr_t>(a.cand) | reinterpret_cast<uintptr_t>(a.x_next)) & 7) == 0;
+  const bool al4 = (a.L & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.cand) | reinterpret_cast<uintptr_t>(a.x_next)) & 3) == 0;
+  const bool al2 = (a.L & 1) == 0 && ((reinterpret_cast<uintptr_t>(a.cand) | reinterpret_cast<uintptr_t>(a.x_next)) & 1) == 0;
+  const int ub = al8 ? 8 : al4 ? 4 : al2 ? 2 : 1;
+  const int U = a.L / ub, total = G * U;
+  for (int i0 = 0; i0 < total; i0 += WAVE) {
+    const int i = i0 + lane;
+    const int gq = i < total ? i / U : 0;
+    const int bq = __shfl(best, gq * MP, WAVE);
+    const int64_t rq = row0 + gq;
+    if (i < total && rq < a.B) {
+      const int c = i - gq * U;
+      const uint8_t* src = a.cand + (rq * a.M + bq) * a.L + (int64_t)c * ub;
+      uint8_t* dst = a.x_next + rq * a.L + (int64_t)c * ub;
+      if (al8) *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<const uint2*>(src);
+      else if (al4) *reinterpret_cast<uint32_t*>(dst) = *reinterpret_cast<const uint32_t*>(src);
+      else if (al2) *reinterpret_cast<uint16_t*>(dst) = *reinterpret_cast<const uint16_t*>(src);
+      else *dst = *src;
+    }
+  }
+}
+
 // ------------------------------------------------- K3 / K5 / K6 / K7: per-position kernels ----
 struct PosArgs {
   const float* logits; const uint8_t* x; int R, L, layout;
@@ -602,43 +712,48 @@ __global__ __launch_bounds__(256) void subs_logp_kernel(PosArgs a) {
 }
 
 // -------------------------------------------------------------------- K4 TDS resample ----
-// numpy's pairwise float32 sum (np.add.reduce), the order `ratio.sum()` uses at :1282.
-__device__ float np_pairwise_sum_f32(const float* a, int64_t n) {
-  // explicit stack instead of recursion: sizes halve, depth <= 40
-  struct Frame { const float* p; int64_t n; };
+// numpy's pairwise float32 sum (np.add.reduce), the order `ratio.sum()` uses at :1282: the array is halved (left half
+// rounded down to a multiple of 8) until a block has <= 128 elements; a block is summed with 8 running accumulators.
+// The blocks are independent, so they can be summed in parallel and combined in the recursion's order — same bits.
+__device__ __forceinline__ float np_leaf_sum_f32(const float* p, int n) {
+  if (n < 8) {
+    float res = 0.0f;
+    for (int i = 0; i < n; ++i) res += p[i];
+    return res;
+  }
+  float r[8];
+  for (int k = 0; k < 8; ++k) r[k] = p[k];
+  int i;
+  for (i = 8; i < n - (n % 8); i += 8)
+    for (int k = 0; k < 8; ++k) r[k] += p[i + k];
+  float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+  for (; i < n; ++i) res += p[i];
+  return res;
+}
+
+// Walks the recursion over [0, n) in evaluation order (explicit stack: sizes halve, depth <= 40); leaf(off, len) is
+// called once per block, left to right, and returns the block's sum.
+template <class LeafFn>
+__device__ float np_pairwise_walk(int64_t n, LeafFn leaf) {
+  struct Frame { int64_t off, n; };            // n < 0: combine marker (adds the two top values, left below right)
   Frame stack[48];
   float vals[48];
   int sp = 0, vp = 0;
-  // post-order evaluation with an operand stack: push (p,n); leaves produce values; internal
-  // nodes are encoded by pushing a marker frame (p == nullptr) that adds the two top values.
-  stack[sp++] = {a, n};
+  stack[sp++] = {0, n};
   while (sp > 0) {
-    Frame f = stack[--sp];
-    if (f.p == nullptr) {            // combine marker: left value is below right value
+    const Frame f = stack[--sp];
+    if (f.n < 0) {
       const float right = vals[--vp];
       const float left = vals[--vp];
       vals[vp++] = left + right;
-      continue;
-    }
-    if (f.n < 8) {
-      float res = 0.0f;
-      for (int64_t i = 0; i < f.n; ++i) res += f.p[i];
-      vals[vp++] = res;
     } else if (f.n <= 128) {
-      float r[8];
-      for (int k = 0; k < 8; ++k) r[k] = f.p[k];
-      int64_t i;
-      for (i = 8; i < f.n - (f.n % 8); i += 8)
-        for (int k = 0; k < 8; ++k) r[k] += f.p[i + k];
-      float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-      for (; i < f.n; ++i) res += f.p[i];
-      vals[vp++] = res;
+      vals[vp++] = leaf(f.off, (int)f.n);
     } else {
       int64_t n2 = f.n / 2;
       n2 -= n2 % 8;
-      stack[sp++] = {nullptr, 0};                 // evaluated last: left + right
-      stack[sp++] = {f.p + n2, f.n - n2};         // right (evaluated second)
-      stack[sp++] = {f.p, n2};                    // left (evaluated first)
+      stack[sp++] = {0, -1};
+      stack[sp++] = {f.off + n2, f.n - n2};      // right (evaluated second)
+      stack[sp++] = {f.off, n2};                 // left (evaluated first)
     }
   }
   return vals[0];
@@ -649,33 +764,105 @@ struct TdsArgs {
   int B, L; uint8_t* x_next; int32_t* idx; double* work;
 };
 
-// Single workgroup (the resample is a cross-particle exchange over one shard's B particles):
-// phase 1 parallel ratio, phase 2 one lane replays numpy's summation orders, phase 3 parallel
-// searchsorted + one wave per particle row copy.
-__global__ __launch_bounds__(1024) void tds_resample_kernel(TdsArgs a) {
+constexpr int TDS_LEAF_CAP = 2048;               // blocks of 64..128 elements: B <= 131072 in parallel, beyond that serially
+
+// Phase 1 — ONE workgroup: the normalised CDF of np.random.choice, in numpy's summation orders (:1280-1282).
+//   ratio (parallel, correctly rounded exp) -> ratio.sum() (pairwise: blocks in parallel, combined in recursion order by
+//   one lane) -> p = ratio / tot widened to f64 (parallel) -> cumsum: an inherently serial chain of B float64 adds, run by
+//   one wave on values it already holds in registers (64 coalesced loads, then 64 readlane + add steps; lane j keeps the
+//   j-th prefix; the next 64 values are in flight meanwhile) -> cdf /= cdf[-1] (parallel).
+// Round 2 ran the two serial loops on one lane straight from global memory: ~0.3 us per element (0.6 ms at B = 2048,
+// 28.8 ms at B = 65536, profiles/r03_resample_before.txt).
+__global__ __launch_bounds__(1024) void tds_cdf_kernel(TdsArgs a) {
+  __shared__ int leaf_off[TDS_LEAF_CAP];
+  __shared__ int leaf_len[TDS_LEAF_CAP];
+  __shared__ float leaf_val[TDS_LEAF_CAP];
+  __shared__ int nleaf_s;
+  __shared__ float tot_s;
   float* ratio = reinterpret_cast<float*>(a.work + a.B);   // work: [B] f64 cdf + [B] f32 ratio
-  const float inv_alpha = (float)(1.0 / a.alpha);                 // the Python double 1.0/alpha, rounded to fp32 once
+  const float inv_alpha = (float)(1.0 / a.alpha);           // the Python double 1.0/alpha, rounded to fp32 once
   for (int b = threadIdx.x; b < a.B; b += blockDim.x)
-    ratio[b] = expf_cr(inv_alpha * (a.num[b] - a.den[b]));          // :1280
-  __syncthreads();
+    ratio[b] = expf_cr(inv_alpha * (a.num[b] - a.den[b]));  // :1280
   if (threadIdx.x == 0) {
-    const float tot = np_pairwise_sum_f32(ratio, a.B);               // ratio.sum()
+    int n = 0;
+    np_pairwise_walk(a.B, [&](int64_t off, int len) {
+      if (n < TDS_LEAF_CAP) { leaf_off[n] = (int)off; leaf_len[n] = len; }
+      ++n;
+      return 0.0f;
+    });
+    nleaf_s = n;
+  }
+  __syncthreads();
+  const int nleaf = nleaf_s;
+  if (nleaf <= TDS_LEAF_CAP) {
+    for (int k = threadIdx.x; k < nleaf; k += blockDim.x) leaf_val[k] = np_leaf_sum_f32(ratio + leaf_off[k], leaf_len[k]);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int k = 0;
+      tot_s = np_pairwise_walk(a.B, [&](int64_t, int) { return leaf_val[k++]; });
+    }
+  } else if (threadIdx.x == 0) {
+    tot_s = np_pairwise_walk(a.B, [&](int64_t off, int len) { return np_leaf_sum_f32(ratio + off, len); });
+  }
+  __syncthreads();
+  const float tot = tot_s;                                                       // ratio.sum()
+  for (int b = threadIdx.x; b < a.B; b += blockDim.x) a.work[b] = (double)__fdiv_rn(ratio[b], tot);   // p (f32) -> f64
+  __syncthreads();
+  if (threadIdx.x < WAVE) {                                                      // p.cumsum(): c_j = c_{j-1} + p_j
+    const int lane = threadIdx.x;
     double c = 0.0;
-    for (int b = 0; b < a.B; ++b) { c += (double)__fdiv_rn(ratio[b], tot); a.work[b] = c; }  // p.cumsum()
+    double pcur = lane < a.B ? a.work[lane] : 0.0;
+    for (int base = 0; base < a.B; base += WAVE) {
+      const int nx = base + WAVE + lane;
+      const double pnext = nx < a.B ? a.work[nx] : 0.0;
+      const int lo = __double2loint(pcur), hi = __double2hiint(pcur);
+      double keep = 0.0;
+#pragma unroll
+      for (int j = 0; j < WAVE; ++j) {
+        c += __hiloint2double(__builtin_amdgcn_readlane(hi, j), __builtin_amdgcn_readlane(lo, j));   // (+ 0.0 past the end)
+        if (lane == j) keep = c;
+      }
+      if (base + lane < a.B) a.work[base + lane] = keep;
+      pcur = pnext;
+    }
   }
   __syncthreads();
   const double last = a.work[a.B - 1];
   __syncthreads();
   for (int b = threadIdx.x; b < a.B; b += blockDim.x) a.work[b] = a.work[b] / last;   // cdf /= cdf[-1]
-  __syncthreads();
-  const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
-  for (int j = wave; j < a.B; j += nwave) {
+}
+
+// Phase 2 — the whole chip: lane = particle: searchsorted(cdf, u, side='right') (:1282), then the wave copies its 64
+// ancestors' rows x_next[j] = sample[idx[j]] (:1284) in 8-byte units spread over all lanes.
+__global__ __launch_bounds__(256) void tds_gather_kernel(TdsArgs a) {
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int64_t j0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * WAVE;
+  if (j0 >= a.B) return;
+  const int64_t j = j0 + lane;
+  int k = 0;
+  if (j < a.B) {
     const double uj = a.u[j];
-    int lo = 0, hi = a.B;                                            // searchsorted(side='right')
+    int lo = 0, hi = a.B;
     while (lo < hi) { const int mid = (lo + hi) >> 1; if (a.work[mid] <= uj) lo = mid + 1; else hi = mid; }
-    const int k = lo < a.B ? lo : a.B - 1;
-    if (a.idx && lane == 0) a.idx[j] = k;
-    for (int i = lane; i < a.L; i += WAVE) a.x_next[(int64_t)j * a.L + i] = a.sample[(int64_t)k * a.L + i];
+    k = lo < a.B ? lo : a.B - 1;
+    if (a.idx) a.idx[j] = k;
+  }
+  const uintptr_t both = reinterpret_cast<uintptr_t>(a.sample) | reinterpret_cast<uintptr_t>(a.x_next);
+  const int ub = ((a.L | both) & 7) == 0 ? 8 : ((a.L | both) & 3) == 0 ? 4 : ((a.L | both) & 1) == 0 ? 2 : 1;
+  const int U = a.L / ub, total = WAVE * U;
+  for (int i0 = 0; i0 < total; i0 += WAVE) {
+    const int i = i0 + lane;
+    const int rq = i / U;                                   // < 64
+    const int kq = __shfl(k, rq, WAVE);
+    if (j0 + rq < a.B) {
+      const int c = i - rq * U;
+      const uint8_t* src = a.sample + (int64_t)kq * a.L + (int64_t)c * ub;
+      uint8_t* dst = a.x_next + (j0 + rq) * a.L + (int64_t)c * ub;
+      if (ub == 8) *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<const uint2*>(src);
+      else if (ub == 4) *reinterpret_cast<uint32_t*>(dst) = *reinterpret_cast<const uint32_t*>(src);
+      else if (ub == 2) *reinterpret_cast<uint16_t*>(dst) = *reinterpret_cast<const uint16_t*>(src);
+      else *dst = *src;
+    }
   }
 }
 
@@ -753,7 +940,7 @@ __global__ __launch_bounds__(256) void advance_rows_kernel(const uint8_t* __rest
 // hipExtLaunchKernelGGL start/stop events, i.e. HIP events bound to the dispatch itself on the launch
 // stream; svdd_profile_collect() sums hipEventElapsedTime over the recorded launches.
 struct TimedLaunch { hipEvent_t start, stop; };
-constexpr int PROFILE_KERNELS = 8;            // 0 propose (K1), 1 select (K2), 2 conv1d, 3 gru, 4 epilogue_ln, 5 conv_tower, 6 backbone_cnn, 7 value_tail
+constexpr int PROFILE_KERNELS = 9;            // 0 propose (K1), 1 select (K2), 2 conv1d, 3 gru, 4 epilogue_ln, 5 conv_tower, 6 backbone_cnn, 7 value_tail, 8 tds_resample (K4, both phases)
 bool g_profile = false;
 TimedLaunch* g_timed[PROFILE_KERNELS] = {};
 int g_timed_n[PROFILE_KERNELS] = {}, g_timed_cap[PROFILE_KERNELS] = {};
@@ -775,6 +962,7 @@ TimedLaunch* timed_slot(int k) {
 
 int g_msplit = 0;        // svdd_set_option(SVDD_OPT_MSPLIT, k): override K1's candidate split (0 = auto)
 int g_force_exact = 0;   // svdd_set_option(SVDD_OPT_FORCE_EXACT, 1): K1 takes the exact path for every draw
+int g_select_one_row_per_wave = 0;   // svdd_set_option(SVDD_OPT_SELECT_ONE_ROW, 1): K2 as one wave per row for every M (A/B)
 unsigned long long* g_k1_stats = nullptr;   // svdd_k1_stats: device counters K1 adds to
 
 inline int check_launch() { return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH; }
@@ -790,6 +978,7 @@ int svdd_abi_version(void) { return SVDD_ABI_VERSION; }
 int svdd_set_option(int key, int value) {
   if (key == SVDD_OPT_FORCE_EXACT) { g_force_exact = value ? 1 : 0; return SVDD_OK; }
   if (key == SVDD_OPT_MSPLIT && value >= 0 && value <= 64) { g_msplit = value; return SVDD_OK; }
+  if (key == SVDD_OPT_SELECT_ONE_ROW) { g_select_one_row_per_wave = value ? 1 : 0; return SVDD_OK; }
   return SVDD_E_ARG;
 }
 
@@ -933,8 +1122,24 @@ int svdd_select_compact(const float* scores, const int32_t* slot, const float* p
   SelectArgs a{scores, cand, B, L, M, mode, rng ? rng->step : 0u, rng ? rng->seed : 0ull,
                rng ? rng->row_offset : 0ull, x_next, soft, idx, slot, parent_score, sel_score, changed};
   TimedLaunch* t = timed_slot(1);
-  hipExtLaunchKernelGGL(select_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                        t ? t->start : nullptr, t ? t->stop : nullptr, 0, a);
+  hipEvent_t e0 = t ? t->start : nullptr, e1 = t ? t->stop : nullptr;
+  if (M <= WAVE && !g_select_one_row_per_wave) {
+    int mp = 1;
+    while (mp < M) mp <<= 1;
+    const int64_t waves = ((int64_t)B + WAVE / mp - 1) / (WAVE / mp);
+    const dim3 grid((unsigned)((waves + 3) / 4));
+    switch (mp) {
+      case 1: hipExtLaunchKernelGGL(select_rows_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, e0, e1, 0, a); break;
+      case 2: hipExtLaunchKernelGGL(select_rows_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, e0, e1, 0, a); break;
+      case 4: hipExtLaunchKernelGGL(select_rows_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, e0, e1, 0, a); break;
+      case 8: hipExtLaunchKernelGGL(select_rows_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, e0, e1, 0, a); break;
+      case 16: hipExtLaunchKernelGGL(select_rows_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, e0, e1, 0, a); break;
+      case 32: hipExtLaunchKernelGGL(select_rows_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, e0, e1, 0, a); break;
+      default: hipExtLaunchKernelGGL(select_rows_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, e0, e1, 0, a); break;
+    }
+    return check_launch();
+  }
+  hipExtLaunchKernelGGL(select_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, e0, e1, 0, a);
   return check_launch();
 }
 
@@ -992,7 +1197,11 @@ int svdd_tds_resample(const float* reward_num, const float* reward_den, double a
   if (!reward_num || !reward_den || !sample || !u || !x_next || !work || B <= 0 || L <= 0 || !(alpha != 0.0))
     return SVDD_E_ARG;
   TdsArgs a{reward_num, reward_den, alpha, sample, u, B, L, x_next, idx, work};
-  hipLaunchKernelGGL(tds_resample_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
+  TimedLaunch* t = timed_slot(8);              // one timed span over both launches: start of phase 1 .. stop of phase 2
+  hipExtLaunchKernelGGL(tds_cdf_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, t ? t->start : nullptr, nullptr, 0, a);
+  if (check_launch() != SVDD_OK) return SVDD_E_LAUNCH;
+  hipExtLaunchKernelGGL(tds_gather_kernel, dim3((unsigned)(((int64_t)B + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                        nullptr, t ? t->stop : nullptr, 0, a);
   return check_launch();
 }
 

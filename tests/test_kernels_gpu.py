@@ -159,6 +159,51 @@ def test_select_vs_oracle(ops, M, mode):
     assert ulp_diff(soft.cpu().numpy(), soft_ref).max() <= 1
 
 
+@pytest.mark.parametrize("M,L", [(10, 200), (20, 200), (10, 50), (3, 7), (2, 200), (64, 36), (1, 200)])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_select_rows_per_wave_equals_one_row_per_wave_and_oracle(ops, M, L, mode):
+    """K2 for M <= 64 packs 64 / pow2(M) rows into a wave and skips the softmax where the best score leads by >= 2^-18
+    (exact shortcut). Against the one-wave-per-row kernel (svdd_set_option A/B) on 50 k rows, and against the oracle on a
+    slice: near-uniform scores (what random-init value nets give), gaps straddling the shortcut threshold, exact ties,
+    clear winners; ragged last wave; row copies in 8-, 4-, 2- and 1-byte units."""
+    from svdd_amd import _lib
+    rng = np.random.default_rng(1000 * M + L + mode)
+    B = 50001
+    scores = (rng.standard_normal((B, M)) * 0.3).astype(np.float32)
+    scores[:10000] = (rng.standard_normal((10000, M)) * 1e-7).astype(np.float32) + np.float32(0.01)      # near-uniform
+    thr = np.float32(2.0 ** -18)
+    for k, d in enumerate([thr, np.nextafter(thr, np.float32(0)), np.nextafter(thr, np.float32(1)), thr / 2, thr * 2]):
+        rows = slice(10000 + 1000 * k, 11000 + 1000 * k)
+        base = (rng.standard_normal((1000, M)) * 0.2).astype(np.float32)
+        if M > 1:
+            top = base.max(axis=1)
+            j = rng.integers(0, M, 1000)
+            base[np.arange(1000), j] = top + d * rng.choice([1.0, -1.0], 1000).astype(np.float32)
+        scores[rows] = base
+    scores[20000:21000] = np.float32(0.25)                                                          # all tied
+    scores[21000:22000] = (rng.integers(-2, 3, (1000, M)) * 0.125).astype(np.float32)             # many exact ties
+    cand = rng.integers(0, 5, (B, M, L)).astype(np.uint8)
+    r = ops.Rng(seed=11, row_offset=5, step=9)
+    sc_d, cand_d = dev(scores), dev(cand)
+    fast = ops.select(sc_d, cand_d, mode=mode, rng=r, want_soft=False)
+    fast_soft = ops.select(sc_d, cand_d, mode=mode, rng=r, want_soft=True)
+    _lib.check(_lib.lib().svdd_set_option(2, 1), "one row per wave")
+    try:
+        slow = ops.select(sc_d, cand_d, mode=mode, rng=r, want_soft=True)
+        torch.cuda.synchronize()
+    finally:
+        _lib.check(_lib.lib().svdd_set_option(2, 0), "rows per wave")
+    assert torch.equal(fast[2], slow[2]) and torch.equal(fast_soft[2], slow[2])        # idx
+    assert torch.equal(fast[0], slow[0]) and torch.equal(fast_soft[0], slow[0])        # gathered rows
+    assert torch.equal(fast_soft[1], slow[1])                                          # soft values, bit for bit
+    sl = np.r_[0:300, 9990:15100:7, 20000:20050, 21000:21300, B - 70:B]
+    x_ref, soft_ref, idx_ref = orc.select(scores[sl], cand[sl], mode=mode, seed=11, row_offset=0, step=9)
+    if mode == 0:                                                                      # (Philox is keyed by the row: argmax only)
+        assert np.array_equal(fast[2].cpu().numpy()[sl], idx_ref)
+        assert np.array_equal(fast[0].cpu().numpy()[sl], x_ref)
+    assert ulp_diff(fast_soft[1].cpu().numpy()[sl], soft_ref).max() <= 1
+
+
 @pytest.mark.parametrize("layout", [orc.BLV, orc.BVL])
 def test_pointwise_kernels_vs_oracle(ops, layout):
     rng = np.random.default_rng(21)
@@ -250,10 +295,13 @@ def test_golden_g10_decode_sample(ops, golden):
     assert np.array_equal(ops.finalize(bvl_view(g["logits"][S]), x).cpu().numpy(), g["x0"])
 
 
-@pytest.mark.parametrize("B", [1, 6, 130, 2048])
-def test_tds_resample_vs_oracle(ops, B):
+@pytest.mark.parametrize("B,L", [(1, 200), (6, 200), (63, 50), (64, 200), (65, 7), (129, 200), (130, 200), (257, 50), (2048, 200),
+                                 (5000, 33), (65536, 200), (140001, 8)])
+def test_tds_resample_vs_oracle(ops, B, L):
+    """K4 against the oracle's numpy-order restatement: pairwise float32 sum (one block, several blocks, beyond the
+    parallel block capacity of 131072), serial float64 cumsum in 64-element chunks (ragged tails), searchsorted, row
+    gather in 8 / 4 / 2 / 1-byte units. BASELINE configs[4] is B = 2048."""
     rng = np.random.default_rng(B)
-    L = 200
     num = rng.standard_normal(B).astype(np.float32)
     den = rng.standard_normal(B).astype(np.float32)
     sample = rng.integers(0, 5, (B, L)).astype(np.uint8)
