@@ -96,11 +96,72 @@ def sampler_saturated(dev, L=200, M=10, B=16384, masked_frac=0.5, iters=100):
     torch.cuda.empty_cache()
     return {"bound": "hbm", "kernel": "propose_kernel (K1), saturated", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5), "bytes_per_launch": nbytes, "traffic": None,
-            "avg_launch_us": round(tot / n * 1e3, 2), "launches": n,
+            "traffic_source": None, "avg_launch_us": round(tot / n * 1e3, 2), "launches": n,
             "workload": f"B={B} L={L} M={M}, {masked_frac:.0%} of the positions masked, Philox"}
 
 
-def cpu_baseline(B, L, M, S, sample_steps, seed=44, threads=16, states=None):
+def select_saturated(dev, L=200, M=10, B=1 << 18, iters=50, near_uniform=False):
+    """K2 (select + index-gather compaction: the north star's "multinomial resample with index-gather compaction") at a size
+    where launch latency is gone: 2^18 rows. Algorithmic bytes per launch B*(4M + 2L + 4): the scores and the winning
+    candidate row in, x_next and the index out. near_uniform: scores ~1e-7 apart, what random-init value nets produce —
+    every row then needs the exact softmax (correctly rounded exp + ordered sum) instead of the argmax shortcut."""
+    from svdd_amd import _lib, ops
+    g = torch.Generator(device=dev).manual_seed(0)
+    scores = torch.randn(B, M, device=dev, generator=g) * (1e-7 if near_uniform else 1e-2) + 0.01
+    cand = torch.randint(0, 5, (B, M, L), device=dev, generator=g, dtype=torch.uint8)
+    x_next = torch.empty(B, L, dtype=torch.uint8, device=dev)
+    for _ in range(10):
+        ops.select(scores, cand, want_soft=False, x_next=x_next)
+    torch.cuda.synchronize()
+    _lib.profile_collect(1)
+    _lib.profile_enable(True)
+    for _ in range(iters):
+        ops.select(scores, cand, want_soft=False, x_next=x_next)
+    torch.cuda.synchronize()
+    _lib.profile_enable(False)
+    tot, n = _lib.profile_collect(1)
+    nbytes = B * (4 * M + 2 * L + 4)
+    gbs = nbytes / (tot / n * 1e-3) / 1e9
+    del cand, scores
+    torch.cuda.empty_cache()
+    return {"bound": "hbm", "kernel": "select_rows_kernel (K2: softmax over M, argmax, index-gather compaction), saturated",
+            "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5),
+            "bytes_per_launch": nbytes, "traffic": None, "traffic_source": None, "avg_launch_us": round(tot / n * 1e3, 2),
+            "launches": n, "workload": f"B={B} L={L} M={M}, scores {'~1e-7 apart (exact softmax in every row)' if near_uniform else 'N(0.01, 1e-2)'}"}
+
+
+def tds_saturated(dev, L=200, B=65536, iters=10):
+    """K4 (SMC/TDS resample) at B = 65536 particles and at BASELINE configs[4]'s 2048. Bytes B*(2L + 24). Its float64 cumsum
+    is a serial chain by numpy's definition (np.random.choice), so the kernel is latency-bound, not HBM-bound: the figure
+    is reported for completeness."""
+    from svdd_amd import _lib, ops
+    out = []
+    for b in (2048, B):
+        g = torch.Generator(device=dev).manual_seed(0)
+        num, den = torch.randn(b, device=dev, generator=g) * 0.1, torch.randn(b, device=dev, generator=g) * 0.1
+        sample = torch.randint(0, 5, (b, L), device=dev, generator=g, dtype=torch.uint8)
+        u = torch.rand(b, device=dev, generator=g, dtype=torch.float64)
+        for _ in range(3):
+            ops.tds_resample(num, den, 0.5, sample, u)
+        torch.cuda.synchronize()
+        _lib.profile_collect(8)
+        _lib.profile_enable(True)
+        for _ in range(iters):
+            ops.tds_resample(num, den, 0.5, sample, u)
+        torch.cuda.synchronize()
+        _lib.profile_enable(False)
+        tot, n = _lib.profile_collect(8)
+        nbytes = b * (2 * L + 24)
+        gbs = nbytes / (tot / n * 1e-3) / 1e9
+        out.append({"bound": "hbm", "kernel": "tds_cdf_kernel + tds_gather_kernel (K4)", "achieved": round(gbs, 2),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 6), "bytes_per_launch": nbytes,
+                    "traffic": None, "traffic_source": None, "avg_launch_us": round(tot / n * 1e3, 2), "launches": n,
+                    "workload": f"B={b} particles, L={L}",
+                    "note": "serial float64 cumsum of B terms (numpy's order) bounds it: latency, not bandwidth"})
+    return out
+
+
+def cpu_baseline(B, L, M, S, sample_steps, seed=44, threads=16, states=None, passes=3):
     """Oracle (CPU port of the reference path: M value-net calls of batch B per step, like
     diffusion_gosai.py:1207-1209) on `sample_steps` diffusion steps of the same workload. `states`: the x_t of every
     step of a GPU decode of this very workload — the sampled steps then run on the real states of the trajectory
@@ -116,38 +177,42 @@ def cpu_baseline(B, L, M, S, sample_steps, seed=44, threads=16, states=None):
     bb = lambda x: model.backbone(x, torch.zeros(x.shape[0]))                               # noqa: E731
     val = lambda oh: head(emb(oh)).reshape(-1)                                              # noqa: E731
     picks = np.linspace(0, S - 1, sample_steps).astype(int)
-    x = np.full((B, L), orc.MASK, np.uint8)
     rng = np.random.default_rng(0)
-    t_steps = []
-    for i in picks:
-        if states is not None:
-            x = states[int(i)]
-        else:                      # a state with the masked fraction step i would see (move chance ~ t_i)
-            frac = 1.0 - i / S
-            x = np.where(rng.random((B, L)) < frac, orc.MASK, rng.integers(0, 4, (B, L))).astype(np.uint8)
+    per_pass, work_s = [], 0.0
+    for _ in range(max(1, passes)):
+        x = np.full((B, L), orc.MASK, np.uint8)
+        t_steps = []
+        for i in picks:
+            if states is not None:
+                x = states[int(i)]
+            else:                      # a state with the masked fraction step i would see (move chance ~ t_i)
+                frac = 1.0 - i / S
+                x = np.where(rng.random((B, L)) < frac, orc.MASK, rng.integers(0, 4, (B, L))).astype(np.uint8)
+            t0 = time.perf_counter()
+            with torch.no_grad():
+                logits = bb(torch.from_numpy(x.astype(np.int64))).contiguous().numpy()
+            cand, onehot, _ = orc.propose(logits, x, sched[i, 2], sched[i, 1], M, seed=1, step=int(i), want_q=False)
+            oh = onehot.reshape(B, M, L, 4)
+            with torch.no_grad():
+                sc = np.stack([val(torch.from_numpy(np.ascontiguousarray(oh[:, m]))).numpy() for m in range(M)], 1)
+            orc.select(sc, cand)
+            t_steps.append(time.perf_counter() - t0)
         t0 = time.perf_counter()
         with torch.no_grad():
             logits = bb(torch.from_numpy(x.astype(np.int64))).contiguous().numpy()
-        cand, onehot, _ = orc.propose(logits, x, sched[i, 2], sched[i, 1], M, seed=1, step=int(i), want_q=False)
-        oh = onehot.reshape(B, M, L, 4)
-        with torch.no_grad():
-            sc = np.stack([val(torch.from_numpy(np.ascontiguousarray(oh[:, m]))).numpy() for m in range(M)], 1)
-        orc.select(sc, cand)
-        t_steps.append(time.perf_counter() - t0)
-    t0 = time.perf_counter()
-    with torch.no_grad():
-        logits = bb(torch.from_numpy(x.astype(np.int64))).contiguous().numpy()
-    orc.finalize(logits, x)
-    t_final = time.perf_counter() - t0
-    per_decode = float(np.mean(t_steps)) * S + t_final
+        orc.finalize(logits, x)
+        t_final = time.perf_counter() - t0
+        per_pass.append(float(np.mean(t_steps)) * S + t_final)
+        work_s += sum(t_steps) + t_final
+    per_decode = float(np.median(per_pass))
     cpu_model, cpu_total = host_cpu()
     return {
         "value": round(B / per_decode, 4), "unit": "sequences/s", "cores": threads,
         "cpu_model": cpu_model, "cores_total": cpu_total,
-        "kind": "port",
-        "sample": f"{sample_steps} of {S} diffusion steps (evenly spaced, on the {'states of a GPU decode of this workload' if states is not None else 'synthetic states'}) "
+        "kind": "port", "passes": len(per_pass), "seq_per_s_each_pass": [round(B / t, 4) for t in per_pass],
+        "sample": f"median of {len(per_pass)} passes over {sample_steps} of {S} diffusion steps (evenly spaced, on the {'states of a GPU decode of this workload' if states is not None else 'synthetic states'}) "
                   f"at full batch (B={B}, L={L}, M={M}) + the noise-removal forward, scaled by {S}/{sample_steps} to one decode; "
-                  f"{sum(t_steps) + t_final:.1f} s of CPU work",
+                  f"{work_s:.1f} s of CPU work in all",
     }
 
 
@@ -341,6 +406,12 @@ def main():
                          for d in (1, 1, 4, 16, 64) for _ in range(4))
     bb_flops = conv_flops_fwd + 2.0 * B * L * (5 * H * 9 + H * H + H * 5)
     alt = {}
+    pmc_lp, pmc_lp_src = {}, None                # HBM bytes per backbone_lp_kernel launch, from separate --pmc passes
+    for name in ("r03_pmc.json",):
+        pth = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(pth) and (B, L, M) == (256, 200, 10):
+            pmc_lp = json.load(open(pth)).get("backbone_lp_traffic_bytes_per_launch", {})
+            pmc_lp_src = f"profiles/{name} (separate rocprofv3 --pmc passes, not measured in this run)"
     modes = [m for m in args.alt_precision.split(",") if m]
     if args.value_net != "convgru":            # opaque value net: only the autocast modes mean anything for it
         modes = [m for m in modes if m in ("bf16", "f16")]
@@ -373,7 +444,7 @@ def main():
                          "achieved": round(tf, 2), "peak": LP_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / LP_PEAK_TFLOPS, 5),
                          "flops_per_launch": round(bb_flops), "mfma_passes": passes,
                          "issued_frac": round(tf * passes / LP_PEAK_TFLOPS, 5), "avg_launch_us": round(bb_ms_lp * 1e3, 3),
-                         "launches": prof[6][1], "traffic": None},
+                         "launches": prof[6][1], "traffic": pmc_lp.get(mode), "traffic_source": pmc_lp_src if pmc_lp.get(mode) else None},
             "own_kernels_ms_per_decode": {"backbone_cnn": round(prof[6][0], 2), "conv_tower": round(prof[5][0], 2),
                                           "gru": round(prof[3][0], 2), "value_tail": round(prof[7][0], 2),
                                           "propose": round(prof[0][0], 3), "select": round(prof[1][0], 3)},
@@ -390,11 +461,13 @@ def main():
         # useful FLOPs of the 20 dilated 128->128 x 9-tap convs of one backbone forward (dnaconv.py:151-156)
         conv_ms = conv_total_ms / max(conv_launches, 1)
         conv_tf = (conv_flops_fwd / 20.0) / (conv_ms * 1e-3) / 1e12 if conv_launches else 0.0
-        pmc = {}
-        for name in ("r02_pmc.json", "r01_pmc.json"):          # separate --pmc passes of this workload, see the file
+        pmc, pmc_src = {}, None
+        for name in ("r03_pmc.json", "r02_pmc.json", "r01_pmc.json"):   # separate --pmc passes of this workload, see the file
             pmc_path = os.path.join(ROOT, "profiles", name)
             if os.path.exists(pmc_path) and (B, L, M) == (256, 200, 10):
                 pmc = json.load(open(pmc_path))
+                pmc_src = (f"profiles/{name}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload collected "
+                           "separately (tools/collect_round_profile.sh), not measured in this run")
                 break
         if bb_launches:
             # the job's dominant kernel: the whole backbone forward in one launch. Algorithmic FLOPs per launch = the
@@ -406,17 +479,21 @@ def main():
                                                    "dilated 9-tap conv 128->128, ReLU, residual] + 2 x 1x1 conv, one launch)",
                         "achieved": round(bb_tf, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(bb_tf / FP32_PEAK_TFLOPS, 5), "traffic": pmc.get("backbone_traffic_bytes_per_launch"),
+                        "traffic_source": pmc_src if pmc.get("backbone_traffic_bytes_per_launch") else None,
                         "flops_per_launch": round(bb_flops), "avg_launch_us": round(bb_ms * 1e3, 3), "launches": bb_launches}
         else:
             roofline = {"bound": "mfma", "kernel": "conv1d_cl_static_kernel<128,128,9,dil,200> (backbone dilated conv, "
                                                    "dil 1,1,4,16,64 x4 per forward)",
                         "achieved": round(conv_tf, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(conv_tf / FP32_PEAK_TFLOPS, 5), "traffic": pmc.get("conv_traffic_bytes_per_launch"),
+                        "traffic_source": pmc_src if pmc.get("conv_traffic_bytes_per_launch") else None,
                         "flops_per_launch": round(conv_flops_fwd / 20.0), "avg_launch_us": round(conv_ms * 1e3, 3),
                         "launches": conv_launches}
         line = {
             "metric": "decoded sequences/sec (whole node), L=200 M=10 128-step SVDD-MC",
             "value": round(seqs / elapsed, 3), "unit": "sequences/s", "n_gpus": world,
+            "ranks_seen": dist.get_world_size() if world > 1 else 1,
+            "backend": ({"nccl": "nccl (RCCL)"}.get(dist.get_backend(), dist.get_backend()) if world > 1 else None),
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic (random-init nets, all-MASK prior)",
@@ -426,7 +503,9 @@ def main():
             "roofline": roofline,
             "roofline_sampler": {"bound": "hbm", "kernel": "propose_kernel (K1)", "achieved": round(achieved, 2),
                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                                 "traffic": pmc.get("k1_traffic_bytes_per_launch", traffic), "bytes_per_launch": k1_bytes,
+                                 "traffic": pmc.get("k1_traffic_bytes_per_launch", traffic),
+                                 "traffic_source": pmc_src if pmc.get("k1_traffic_bytes_per_launch") else None,
+                                 "bytes_per_launch": k1_bytes,
                                  "avg_launch_us": round(k1_ms * 1e3, 3), "launches": k1_launches,
                                  "select_kernel_avg_launch_us": round(k2_total_ms / max(k2_launches, 1) * 1e3, 3)},
             "own_kernels_ms_per_decode": {"backbone_cnn": round(bb_total_ms, 2), "conv_tower": round(tower_total_ms, 2),
@@ -443,6 +522,9 @@ def main():
             line["per_rank"] = per_rank
         if world == 1 and args.value_net == "convgru":
             line["roofline_sampler_saturated"] = sampler_saturated(dev, L=L, M=M)
+            line["roofline_select_saturated"] = [select_saturated(dev, L=L, M=M), select_saturated(dev, L=L, M=M, near_uniform=True),
+                                                 select_saturated(dev, L=L, M=20)]
+            line["roofline_tds_resample"] = tds_saturated(dev, L=L)
         if args.value_net != "convgru":
             line["config"]["workload"] += " [value net: Enformer-shaped trunk, 230M params — BASELINE configs[3] shape]"
             line["e2e_fp32_frac"] = None
@@ -452,7 +534,7 @@ def main():
             torch.cuda.synchronize()
             states = [x.cpu().numpy() for x in model.state_trace]
             model.state_trace = None
-            line["cpu_baseline"] = cpu_baseline(B, L, M, S, args.cpu_steps, states=states)
+            line["cpu_baseline"] = cpu_baseline(B, L, M, S, args.cpu_steps, states=states, passes=args.cpu_passes)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line))

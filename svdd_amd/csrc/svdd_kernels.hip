@@ -534,56 +534,64 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
 // e <= 1 - 2^-19, so after the common factor 1/sum the best candidate's soft value is strictly the largest — the softmax
 // need not be evaluated to know its argmax. Rows closer than that (the near-uniform scores of random-init value nets,
 // exact ties) take the exact path; the result is the same bits either way.
+// max over the MP-lane group of a lane (MP a power of two <= 64); every lane of the group gets it. Steps below 16 are
+// DPP lane permutations inside a 16-lane row (no LDS crossbar, no address arithmetic): xor 1 and 2 as quad_perm, then
+// row_half_mirror / row_mirror, which after the quad steps pair every quad with the one it still lacks.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+template <int MP>
+__device__ __forceinline__ float group_max(float v) {
+  if constexpr (MP >= 2) v = fmaxf(v, dpp_mov<0xB1>(v));        // quad_perm [1,0,3,2]
+  if constexpr (MP >= 4) v = fmaxf(v, dpp_mov<0x4E>(v));        // quad_perm [2,3,0,1]
+  if constexpr (MP >= 8) v = fmaxf(v, dpp_mov<0x141>(v));       // row_half_mirror
+  if constexpr (MP >= 16) v = fmaxf(v, dpp_mov<0x140>(v));      // row_mirror
+  if constexpr (MP >= 32) v = fmaxf(v, __shfl_xor(v, 16, WAVE));
+  if constexpr (MP >= 64) v = fmaxf(v, __shfl_xor(v, 32, WAVE));
+  return v;
+}
+// lowest candidate index m of the lane's group whose predicate holds (the group's lanes are base .. base + MP - 1)
+template <int MP>
+__device__ __forceinline__ int group_first(bool pred, int base) {
+  const unsigned long long mask = __ballot(pred) >> base;
+  constexpr unsigned long long GM = MP == 64 ? ~0ull : ((1ull << (MP & 63)) - 1ull);
+  return __ffsll((long long)(mask & GM)) - 1;
+}
+
 template <int MP>
 __global__ __launch_bounds__(256) void select_rows_kernel(SelectArgs a) {
   constexpr int G = WAVE / MP;
   const int lane = threadIdx.x & (WAVE - 1);
-  const int g = lane / MP, m = lane % MP;
+  const int g = lane / MP, m = lane % MP, base = lane & ~(MP - 1);
   const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * G;
   if (row0 >= a.B) return;
   const int64_t row = row0 + g;
-  const bool rv = row < a.B, valid = rv && m < a.M;
+  const bool rv = row < a.B, valid = rv & (m < a.M);
   float sv = -INFINITY;
-  int sl_mine = -1;
   if (valid) {
-    if (a.slot) { sl_mine = a.slot[row * a.M + m]; sv = sl_mine >= 0 ? a.scores[sl_mine] : a.parent_score[row]; }
+    if (a.slot) { const int sl = a.slot[row * a.M + m]; sv = sl >= 0 ? a.scores[sl] : a.parent_score[row]; }
     else sv = a.scores[row * a.M + m];
   }
-  // first-index argmax of the raw scores and the runner-up, inside the group
-  float bv = sv; int bi = valid ? m : 0x7fffffff;
-#pragma unroll
-  for (int off = MP / 2; off > 0; off >>= 1) {
-    const float ov = __shfl_xor(bv, off, WAVE);
-    const int oi = __shfl_xor(bi, off, WAVE);
-    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-  }
-  const float mx = bv;
-  float s2 = (valid && m != bi) ? sv : -INFINITY;
-#pragma unroll
-  for (int off = MP / 2; off > 0; off >>= 1) { const float o = __shfl_xor(s2, off, WAVE); s2 = o > s2 ? o : s2; }
+  // first-index argmax of the raw scores, and the runner-up
+  const float mx = group_max<MP>(sv);
+  const int bi = group_first<MP>(valid & (sv == mx), base);
+  const float s2 = group_max<MP>((valid & (m != bi)) ? sv : -INFINITY);
   int best = bi;
-  float p = 0.0f;
-  const bool clear = !rv || (mx - s2 >= 3.814697265625e-06f);                 // 2^-18; also M == 1 (s2 = -inf)
-  const bool exact = a.mode != SVDD_SELECT_ARGMAX || a.soft != nullptr || !clear;
+  const bool clear = !rv | (mx - s2 >= 3.814697265625e-06f);                  // 2^-18; also M == 1 (s2 = -inf)
+  const bool exact = (a.mode != SVDD_SELECT_ARGMAX) | (a.soft != nullptr) | !clear;
   if (__any(exact)) {
     const float e = valid ? expf_cr(sv - mx) : 0.0f;
-    const int base = lane & ~(MP - 1);
     float sum = 0.0f;
     for (int j = 0; j < a.M; ++j) {                                           // candidate order: ((e0 + e1) + e2) + ...
       const float ej = __shfl(e, base + j, WAVE);
       sum = j == 0 ? ej : sum + ej;
     }
     const float r = __fdiv_rn(1.0f, sum);
-    p = e * r;                                                                // ATen CPU softmax: e * (1 / sum)
+    const float p = e * r;                                                    // ATen CPU softmax: e * (1 / sum)
     if (a.mode == SVDD_SELECT_ARGMAX) {
-      float pv = valid ? p : -INFINITY; int pi = valid ? m : 0x7fffffff;
-#pragma unroll
-      for (int off = MP / 2; off > 0; off >>= 1) {
-        const float ov = __shfl_xor(pv, off, WAVE);
-        const int oi = __shfl_xor(pi, off, WAVE);
-        if (ov > pv || (ov == pv && oi < pi)) { pv = ov; pi = oi; }
-      }
-      best = pi;
+      const float pm = group_max<MP>(valid ? p : -INFINITY);
+      best = group_first<MP>(valid & (p == pm), base);
     } else {
       const uint64_t grow = a.row_offset + (uint64_t)(rv ? row : 0);
       uint32_t ctr[4] = {(uint32_t)grow, (uint32_t)(grow >> 32), (a.step << 16), 2u};
@@ -598,11 +606,14 @@ __global__ __launch_bounds__(256) void select_rows_kernel(SelectArgs a) {
       for (int j = 0; j < a.M; ++j) {
         const float pj = __shfl(p, base + j, WAVE);
         run = j == 0 ? pj : run + pj;
-        if (!found && thr < run) { best = j; found = true; }
+        const bool hit = !found & (thr < run);
+        best = hit ? j : best;
+        found |= hit;
       }
     }
     if (a.soft && valid) a.soft[row * a.M + m] = p;
   }
+  best = best < 0 ? 0 : best;                               // (all-NaN scores: no maximum; stay inside the row's candidates)
   if (rv && m == 0) {
     if (a.idx) a.idx[row] = best;
     if (a.slot) {
@@ -611,24 +622,24 @@ __global__ __launch_bounds__(256) void select_rows_kernel(SelectArgs a) {
       if (a.changed) a.changed[row] = sl >= 0 ? 1 : 0;                                      // x_next != x
     }
   }
-  // index-gather compaction (diffusion_gosai.py:1226-1227): the G winning rows, unit-strided over the whole wave
-  const bool al8 = (a.L & 7) == 0 && ((reinterpret_cast<uintptr_t>(a.cand) | reinterpret_cast<uintptr_t>(a.x_next)) & 7) == 0;
-  const bool al4 = (a.L & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.cand) | reinterpret_cast<uintptr_t>(a.x_next)) & 3) == 0;
-  const bool al2 = (a.L & 1) == 0 && ((reinterpret_cast<uintptr_t>(a.cand) | reinterpret_cast<uintptr_t>(a.x_next)) & 1) == 0;
-  const int ub = al8 ? 8 : al4 ? 4 : al2 ? 2 : 1;
+  // index-gather compaction (diffusion_gosai.py:1226-1227): the G winning rows, in units of ub bytes spread over the wave
+  const uintptr_t both = reinterpret_cast<uintptr_t>(a.cand) | reinterpret_cast<uintptr_t>(a.x_next);
+  const int ub = ((a.L | both) & 7) == 0 ? 8 : ((a.L | both) & 3) == 0 ? 4 : ((a.L | both) & 1) == 0 ? 2 : 1;
   const int U = a.L / ub, total = G * U;
+  const float inv_u = 1.0f / (float)U;
   for (int i0 = 0; i0 < total; i0 += WAVE) {
     const int i = i0 + lane;
-    const int gq = i < total ? i / U : 0;
+    int gq = (int)(((float)i + 0.5f) * inv_u);              // i / U (i < 2^22: exact after the half-unit offset)
+    gq = gq < G ? gq : G - 1;
     const int bq = __shfl(best, gq * MP, WAVE);
     const int64_t rq = row0 + gq;
     if (i < total && rq < a.B) {
       const int c = i - gq * U;
       const uint8_t* src = a.cand + (rq * a.M + bq) * a.L + (int64_t)c * ub;
       uint8_t* dst = a.x_next + rq * a.L + (int64_t)c * ub;
-      if (al8) *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<const uint2*>(src);
-      else if (al4) *reinterpret_cast<uint32_t*>(dst) = *reinterpret_cast<const uint32_t*>(src);
-      else if (al2) *reinterpret_cast<uint16_t*>(dst) = *reinterpret_cast<const uint16_t*>(src);
+      if (ub == 8) *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<const uint2*>(src);
+      else if (ub == 4) *reinterpret_cast<uint32_t*>(dst) = *reinterpret_cast<const uint32_t*>(src);
+      else if (ub == 2) *reinterpret_cast<uint16_t*>(dst) = *reinterpret_cast<const uint16_t*>(src);
       else *dst = *src;
     }
   }
