@@ -355,7 +355,9 @@ int svdd_value_tail_lp(const float* h_fwd, const float* h_bwd, const void* w1pac
  * to A/B the filter. */
 enum { SVDD_OPT_FORCE_EXACT = 0,
        SVDD_OPT_MSPLIT = 1 /* tuning: waves per 64-position tile in svdd_propose, 0 = auto */,
-       SVDD_OPT_SELECT_ONE_ROW = 2 /* A/B: svdd_select as one wave per row for every M (default: several rows per wave for M <= 64) */ };
+       SVDD_OPT_SELECT_ONE_ROW = 2 /* A/B: svdd_select as one wave per row for every M (default: several rows per wave for M <= 64) */,
+       SVDD_OPT_BACKBONE_LP_VERSION = 3 /* A/B: 1 = svdd_backbone_cnn_lp runs the round-2 kernel for every shape; 2 (default) = the
+                                            transposed-accumulator kernel where one sequence fills a tile (104 < L <= 208) */ };
 int svdd_set_option(int key, int value);
 
 /* Soak / profiling aid: while `device_counters2` (two zero-initialised uint64 on the device) is non-NULL, every

@@ -6,7 +6,16 @@
 extern "C" int svdd_internal_num_cus();      // svdd_nets.hip
 extern "C" int svdd_internal_fixed_spt();    // svdd_nets.hip (svdd_set_backbone_packing)
 
+static int g_bb_lp_version = 2;     // svdd_set_option(SVDD_OPT_BACKBONE_LP_VERSION, 1): the round-2 kernel for every shape (A/B)
+static int g_bb_lp_rg = 2;          // ... 22 / 23 / 24: the transposed kernel with 2 / 3 / 4 row groups (waves per SIMD); measured
+                                    // (f16x3 / bf16, B = 256, L = 200): 2: 0.718 / 0.384 ms ; 3: 0.886 / 0.381 ms (x3 spills at 168 VGPRs) ; 4: spills
+extern "C" void svdd_internal_set_bb_lp_version(int v) {
+  if (v >= 22 && v <= 23) { g_bb_lp_version = 2; g_bb_lp_rg = v - 20; }
+  else g_bb_lp_version = v == 1 ? 1 : 2;
+}
+
 namespace {
+constexpr int WAVE_SZ = 64;
 
 // ---------------------------------------------------------------------------------- backbone, split precision ----
 // Same decomposition as backbone_kernel (svdd_nets.hip): one workgroup (8 waves) per tile of whole sequences; wave w
@@ -20,22 +29,6 @@ namespace {
 //     4-byte store;
 //   * the weight tile is stored by the host in exactly the order the lanes consume it: [cg][lane][ct][hi|lo][8]
 //     (64 B per lane, 4 KB per wave, fully coalesced).
-struct BackboneLpArgs {
-  const uint8_t* x;        // [n, L] tokens 0..4
-  const float* table0;     // [9][5][128]
-  const void* tiles;       // [nl*36 + 4] tiles of [4 cg][64 lanes][2 ct][NPARTS][8] 16-bit
-  const float* vec;        // [nl + 2][4][128] as in svdd_backbone_cnn_f32
-  const float* lscale;     // [nl + 1][2] = {sa: activation scale, inv: 1 / (sa * weight scale)}
-  const float* w2;         // [5][128] then b2 [5]
-  float* out;              // [n, L, 5]
-  int n, L, spt, nl;
-  int dil[BB_MAXL];
-  const int* count;        // device scalar: valid rows (NULL: n) — exact work-skipping on a compacted batch
-  const int* row_idx;      // [count] (NULL: identity): compact row r reads the tokens of sequence row_idx[r] of x ...
-  int out_scatter;         // ... and writes its logits to row row_idx[r] of out (1) or to row r (0)
-  int auto_spt, ncu;       // auto_spt: the workgroups pick the sequences per tile from the device-side row count (svdd_spt.h)
-};
-
 template <typename T, int NP, bool SPT1>
 __global__ __launch_bounds__(512, 2) void backbone_lp_kernel(BackboneLpArgs a) {
   typedef typename Lp<T>::V8 V8;
@@ -352,6 +345,407 @@ __global__ __launch_bounds__(512, 2) void backbone_lp_kernel(BackboneLpArgs a) {
 }
 
 
+// ------------------------------------------------------------------- backbone, split precision, TRANSPOSED tiles ----
+// Round 3. Same tile decomposition, LDS image, weight stream and schedule as backbone_lp_kernel<.., SPT1 = true> above, but
+// the two MFMA operands trade places: A = the weight fragment, B = the activation fragment (the very same registers:
+// both operand layouts are "lane (j, g) holds index j of the tile and k = 8 g .. 8 g + 7"), so the accumulator tile comes
+// out TRANSPOSED: lane (j, g) register e holds output channel 4 g + e of the column tile at POSITION 16 R + j.
+// With the host's weight order (tile row j of column tile ct = channel 32 cg + 2 j + ct) a lane then owns EIGHT ADJACENT
+// channels 32 cg + 8 g .. + 7 (value (ct, e) <-> channel offset 2 e + ct) of ONE position per row tile, instead of two
+// channels of four positions. What that buys — the ablation of the first version put the LayerNorm phases at 0.19 ms, the
+// first-layer lookup at 0.05 ms and the MFMAs at 0.39 ms of its 0.77 ms (profiles/r02_exp_ablations.txt):
+//   * LayerNorm statistics: a position's 128 channels are 8 values in a lane (summed with packed fp32 adds), 4 lanes
+//     (g) and 4 waves: two cross-lane steps per row tile instead of 4 DPP steps for each of 4 rows and 2 moments;
+//   * the image write is one 16-byte LDS store per plane and row tile (8 halves) instead of four 4-byte stores, with
+//     one mean / rstd read per tile instead of four;
+//   * the first layer reads its 8 channels of a (tap, token) as two 16-byte LDS loads: 18 loads per row tile, not 72;
+//   * per-channel parameters are two 16-byte loads per vector.
+// One sequence per tile only (104 < L <= 208); shorter sequences keep the kernel above.
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+
+// RG = row groups = waves per SIMD (2, 3 or 4): wave w = (column group w & 3, row group w >> 2) owns the row tiles
+// rg, rg + RG, rg + 2 RG, ... With 2 the waves spent 43 % of their time in s_waitcnt and the matrix pipe was busy 48 %
+// (profiles/r03_pmc_bb_lpt.txt): two waves per SIMD do not cover the LDS / L2 latencies of each other's loads.
+template <typename T, int NP, int RG>
+__global__ __launch_bounds__(256 * RG, RG) void backbone_lp_t_kernel(BackboneLpArgs a) {
+  constexpr int NTH = 256 * RG;
+  typedef typename Lp<T>::V8 V8;
+  constexpr int NPARTS = NP == 3 ? 2 : 1;
+  extern __shared__ __attribute__((aligned(16))) char smem_b[];
+  char* plane = smem_b + LPSB;                               // byte address of (row 0, channel 0) of the hi plane
+  float* img32 = reinterpret_cast<float*>(smem_b);           // final stage: fp32 image [TW_ROWS][BB_AP] over the planes
+  float* Bs = reinterpret_cast<float*>(smem_b + IMG_REGION_B);   // [9][5][128] the first layer's lookup table
+  float* psum = Bs + 9 * 5 * BB_C;                           // [8][TW_ROWS]: first / second moment partials of the 4 column groups
+  float* rstat = psum + 8 * TW_ROWS;                         // [TW_ROWS]
+  float* rmean = rstat + TW_ROWS;                            // [TW_ROWS] row means (this layer's shift = last layer's mean)
+  int* toks = reinterpret_cast<int*>(rmean + TW_ROWS);       // [TW_ROWS]
+  int* sdil = toks + 2 * TW_ROWS;                            // [BB_MAXL + 1]   (same map as the kernel above)
+  int* sched = sdil + BB_MAXL + 1;                           // [(nl + 1) * 36]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cg = w & 3, rg = w >> 2;
+  const int j = lane & 15, g = lane >> 4;
+  const int cb = 32 * cg + 8 * g;                            // this lane's channels cb .. cb + 7: (ct, e) <-> cb + 2 e + ct
+  const int L = a.L;
+  const int nvalid = a.count ? __builtin_amdgcn_readfirstlane(*a.count) : a.n;
+  if ((int)blockIdx.x >= nvalid) return;
+  const int64_t seq = a.row_idx ? a.row_idx[blockIdx.x] : (int64_t)blockIdx.x;
+  const int nl = a.nl;
+  const int it_end = (nl + 1) * 9;                           // (layer, tap) entries
+  constexpr int NR = (TW_RT + RG - 1) / RG;                  // row tiles of row group 0 (the others may own one less)
+
+  for (int e = tid; e < TW_ROWS; e += NTH) {
+    toks[e] = e < L ? (int)a.x[seq * L + e] : -1;
+    rmean[e] = 0.0f;
+  }
+  for (int e = tid; e < LPSB / 4; e += NTH) {                // zero rows -1 and TW_ROWS of both planes
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      reinterpret_cast<int*>(smem_b + p * PLANE_B)[e] = 0;
+      reinterpret_cast<int*>(smem_b + p * PLANE_B + (TW_ROWS + 1) * LPSB)[e] = 0;
+    }
+  }
+  if (tid == 0) {
+#pragma unroll
+    for (int i = 0; i < BB_MAXL; ++i) sdil[i] = a.dil[i];
+    sdil[BB_MAXL] = 1;
+  }
+  for (int e = tid; e < 9 * 5 * BB_C; e += NTH) Bs[e] = a.table0[e];
+  __syncthreads();
+  // schedule, one entry per (layer, tap): 0 for a tap that only sees zero padding, else
+  //   bits 0-12 live row tiles ; 15-18 tap ; 19-28 index of the next live entry. The four 32-channel chunks of a tap share it.
+  for (int k = tid; k < it_end; k += NTH) {
+    auto entry = [&](int kk) {
+      const int layer = kk / 9, t = kk % 9;
+      if (layer >= nl) return t == 4 ? 0x1fff : 0;
+      const int d = (t - 4) * sdil[layer];
+      const int lo = d < 0 ? -d : 0, hi = d > 0 ? L - d : L;
+      if (lo >= hi) return 0;
+      int m = 0;
+      for (int r = 0; r < TW_RT; ++r) if (lo < 16 * r + 16 && hi > 16 * r) m |= 1 << r;
+      return m;
+    };
+    const int m = entry(k);
+    int nx = k + 1;
+    while (nx < it_end && entry(nx) == 0) ++nx;
+    sched[k] = m ? (m | (k % 9) << 15 | nx << 19) : 0;
+  }
+
+  // ---- first layer: table lookup, fp32 (dnaconv.py:177,184); position 16 (rh + 2 r) + j, channels cb .. cb + 7
+  f32x4 f[NR][2], acc[NR][2];
+  {
+    const f32x4 b0a = *reinterpret_cast<const f32x4*>(a.vec + cb), b0b = *reinterpret_cast<const f32x4*>(a.vec + cb + 4);
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const int p = 16 * (rg + RG * r) + j;
+      f32x4 va = b0a, vb = b0b;
+      if (rg + RG * r < TW_RT) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int q = p + t - 4;
+          const int tk = (q >= 0 && q < L) ? toks[q < 0 ? 0 : (q < TW_ROWS ? q : TW_ROWS - 1)] : -1;
+          const float* row = Bs + (t * 5 + (tk < 0 ? 0 : tk)) * BB_C + cb;
+          const f32x4 ta = *reinterpret_cast<const f32x4*>(row), tb = *reinterpret_cast<const f32x4*>(row + 4);
+          const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+          va += tk >= 0 ? ta : z;
+          vb += tk >= 0 ? tb : z;
+        }
+      }
+      const bool in = p < L;
+      f[r][0] = f32x4{in ? fmaxf(va[0], 0.0f) : 0.0f, in ? fmaxf(va[2], 0.0f) : 0.0f, in ? fmaxf(vb[0], 0.0f) : 0.0f, in ? fmaxf(vb[2], 0.0f) : 0.0f};
+      f[r][1] = f32x4{in ? fmaxf(va[1], 0.0f) : 0.0f, in ? fmaxf(va[3], 0.0f) : 0.0f, in ? fmaxf(vb[1], 0.0f) : 0.0f, in ? fmaxf(vb[3], 0.0f) : 0.0f};
+    }
+  }
+  __syncthreads();                                        // sched is visible
+
+  // activation-fragment addressing (bytes inside a plane): this lane feeds position 16 (rh + 2 r) + j, channels 32 c + 8 g .. + 8
+  const int arow0 = (16 * rg + j) * LPSB + 16 * g;
+  const int a_lo = arow0 - (16 * rg + j + 1) * LPSB;      // row -1
+  const int a_hi = arow0 + (TW_ROWS - 16 * rg - j) * LPSB;    // row TW_ROWS
+
+  constexpr int TILE_V8 = 4 * 64 * 2 * NPARTS;
+  const V8* wsrc = reinterpret_cast<const V8*>(a.tiles) + (cg * 64 + lane) * (2 * NPARTS);
+  // weight tile of (entry k = 9 layer + tap, chunk c): the host's order is [layer][chunk][tap], then the 4 chunks of the 1x1 conv
+  auto tile_of = [&](int k, int c) { const int ly = k / 9; return ly < nl ? ly * 36 + c * 9 + (k - 9 * ly) : nl * 36 + c; };
+  int it = 0;
+  while (it < it_end && sched[it] == 0) ++it;
+  it = __builtin_amdgcn_readfirstlane(it);
+  int en = __builtin_amdgcn_readfirstlane(sched[it]);
+  V8 wA[2 * NPARTS], wB[2 * NPARTS];                       // the two weight-fragment sets: chunks alternate between them
+  {
+    const V8* src = wsrc + (size_t)tile_of(it, 0) * TILE_V8;
+#pragma unroll
+    for (int q = 0; q < 2 * NPARTS; ++q) wA[q] = src[q];
+  }
+  // per-channel vectors of this lane in channel order -> (ct, e) order
+  auto chan8 = [&](const float* v, int cbx, f32x4& c0, f32x4& c1, float scale) {
+    const f32x4 lo4 = *reinterpret_cast<const f32x4*>(v + cbx) * scale, hi4 = *reinterpret_cast<const f32x4*>(v + cbx + 4) * scale;
+    c0 = f32x4{lo4[0], lo4[2], hi4[0], hi4[2]};
+    c1 = f32x4{lo4[1], lo4[3], hi4[1], hi4[3]};
+  };
+  auto store_image = [&](int wrow0, int r, f32x4 v0, f32x4 v1) {   // (ct, e) values of position 16 (rh + 2 r) + j -> both planes
+    const f32x8 v = {v0[0], v1[0], v0[1], v1[1], v0[2], v1[2], v0[3], v1[3]};
+    const V8 hi = __builtin_convertvector(v, V8);
+    *reinterpret_cast<V8*>(plane + wrow0 + r * (16 * RG * LPSB)) = hi;
+    if constexpr (NP == 3) {
+      const V8 lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x8), V8);
+      *reinterpret_cast<V8*>(plane + PLANE_B + wrow0 + r * (16 * RG * LPSB)) = lo;
+    }
+  };
+
+  for (int layer = 0; layer <= nl; ++layer) {             // layer == nl: the first 1x1 conv of final_conv
+    const float* vl = a.vec + (size_t)(layer + 1) * 4 * BB_C;
+    const float sa = a.lscale[2 * layer], inv = a.lscale[2 * layer + 1];
+    // The phase code below addresses LDS by (row tile, lane): 7 tiles x 5 arrays of loop-invariant addresses, which the
+    // compiler otherwise hoists out of the layer loop and then SPILLS across the MFMA loop. Re-deriving them from lane ids
+    // it cannot see through costs a few VALU ops per layer and keeps the MFMA loop's registers free.
+    int jo = j, cbo = cb;
+    asm volatile("" : "+v"(jo), "+v"(cbo));
+    const int wrow = (16 * rg + jo) * LPSB + 2 * cbo;
+    if (layer < nl) {
+      f32x4 tb0, tb1;
+      chan8(vl + BB_C, cbo, tb0, tb1, 1.0f);
+      // ONE statistics pass about the per-row shift K = the row's mean one layer earlier (see the kernel above)
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        const int p = 16 * (rg + RG * r) + jo;
+        const float K = rmean[p < TW_ROWS ? p : TW_ROWS - 1];
+        const f32x4 d0 = f[r][0] + tb0 - K, d1 = f[r][1] + tb1 - K;
+        const f32x4 s = d0 + d1, q = d0 * d0 + d1 * d1;
+        float s1 = (s[0] + s[1]) + (s[2] + s[3]), s2 = (q[0] + q[1]) + (q[2] + q[3]);
+        s1 += __shfl_xor(s1, 16, WAVE_SZ); s2 += __shfl_xor(s2, 16, WAVE_SZ);
+        s1 += __shfl_xor(s1, 32, WAVE_SZ); s2 += __shfl_xor(s2, 32, WAVE_SZ);
+        if (cbo == 32 * cg && p < TW_ROWS) { psum[cg * TW_ROWS + p] = s1; psum[(4 + cg) * TW_ROWS + p] = s2; }
+        if (r & 1) __builtin_amdgcn_sched_barrier(0);       // two tiles' worth of loads in flight, not seven (VGPR pressure)
+      }
+      __syncthreads();
+      if (tid < TW_ROWS) {
+        const float m = ((psum[tid] + psum[TW_ROWS + tid]) + (psum[2 * TW_ROWS + tid] + psum[3 * TW_ROWS + tid])) * (1.0f / BB_C);
+        const float q = ((psum[4 * TW_ROWS + tid] + psum[5 * TW_ROWS + tid]) + (psum[6 * TW_ROWS + tid] + psum[7 * TW_ROWS + tid])) * (1.0f / BB_C);
+        rmean[tid] += m;
+        rstat[tid] = rsqrtf(fmaxf(q - m * m, 0.0f) + 1e-5f);
+      }
+      __syncthreads();
+      f32x4 gm0, gm1, bt0, bt1;
+      chan8(vl + 2 * BB_C, cbo, gm0, gm1, sa);              // sa is a power of two: exact
+      chan8(vl + 3 * BB_C, cbo, bt0, bt1, sa);
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        const int p = 16 * (rg + RG * r) + jo;
+        if (rg + RG * r < TW_RT) {
+          const float rs = rstat[p], mean = rmean[p];
+          const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+          const f32x4 v0 = p < L ? (f[r][0] + tb0 - mean) * rs * gm0 + bt0 : z;
+          const f32x4 v1 = p < L ? (f[r][1] + tb1 - mean) * rs * gm1 + bt1 : z;
+          store_image(wrow, r, v0, v1);
+        }
+        if (r & 1) __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < NR; ++r)
+        if (rg + RG * r < TW_RT) store_image(wrow, r, f[r][0] * sa, f[r][1] * sa);
+    }
+    // ---- implicit GEMM over (chunk, live tap): acc^T[channel, position] += W[channel, k] X^T[k, position]
+#pragma unroll
+    for (int r = 0; r < NR; ++r) { acc[r][0] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; acc[r][1] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
+    const int dil = __builtin_amdgcn_readfirstlane(sdil[layer < nl ? layer : BB_MAXL]);
+    const int layer_end = (layer + 1) * 9;
+    __syncthreads();                                      // the image is complete
+    while (it < layer_end) {                              // one live tap: 4 chunks x the wave's row tiles
+      const int nxt = en >> 19;
+      const int en_next_v = sched[nxt < it_end ? nxt : it];
+      const int delta = (((en >> 15) & 15) - 4) * dil;
+      const int live = en >> rg;                          // bit RG r = owned tile r
+      int xa[NR];                                         // clamped fragment address of every owned tile, chunk 0
+#pragma unroll
+      for (int r = 0; r < NR; ++r) xa[r] = min(max(arow0 + delta * LPSB + r * (16 * RG * LPSB), a_lo), a_hi);
+      // the chunk's 64-byte step is an immediate offset of the LDS read
+#define LPT_XLOAD(C, R, V)                                                                                   \
+      { V[0] = *reinterpret_cast<const V8*>(plane + xa[R] + 64 * (C));                                       \
+        if constexpr (NP == 3) V[1] = *reinterpret_cast<const V8*>(plane + PLANE_B + xa[R] + 64 * (C)); }
+#define LPT_WPF(WN, TILE, COND)                                                                              \
+      if (COND) { const V8* src_ = wsrc + (size_t)(TILE) * TILE_V8;                                          \
+        _Pragma("unroll") for (int q = 0; q < 2 * NPARTS; ++q) WN[q] = src_[q]; }
+#define LPT_WAIT(NOUT) __builtin_amdgcn_s_waitcnt(0xC07F | ((NOUT) << 8));
+      // W: [ct][part] -> W[ct * NPARTS + part]; pass order as in the kernel above: hi hi, w_lo x_hi, w_hi x_lo
+#define LPT_MM(R, U, W, NOUT)                                                                                \
+      __builtin_amdgcn_sched_barrier(0);                                                                     \
+      LPT_WAIT(NOUT)                                                                                         \
+      if (live & (1 << (RG * (R)))) {                                                                         \
+        acc[R][0] = Lp<T>::mfma(W[0], U[0], acc[R][0]);                                                      \
+        acc[R][1] = Lp<T>::mfma(W[NPARTS], U[0], acc[R][1]);                                                 \
+        if constexpr (NP == 3) {                                                                             \
+          acc[R][0] = Lp<T>::mfma(W[1], U[0], acc[R][0]);                                                    \
+          acc[R][1] = Lp<T>::mfma(W[NPARTS + 1], U[0], acc[R][1]);                                           \
+          acc[R][0] = Lp<T>::mfma(W[0], U[1], acc[R][0]);                                                    \
+          acc[R][1] = Lp<T>::mfma(W[NPARTS], U[1], acc[R][1]);                                               \
+        }                                                                                                    \
+      }                                                                                                      \
+      __builtin_amdgcn_sched_barrier(0);
+      V8 ua[2], ub[2];                                    // activation fragments, one (chunk, row tile) step ahead of the MFMAs
+      if constexpr (RG == 2) {
+        if (rg == 0) {                          // 7 row tiles
+          LPT_XLOAD(0, 0, ua)
+          LPT_WPF(wB, tile_of(it, 1), true)
+          LPT_XLOAD(0, 1, ub) LPT_MM(0, ua, wA, NPARTS)
+          LPT_XLOAD(0, 2, ua) LPT_MM(1, ub, wA, NPARTS)
+          LPT_XLOAD(0, 3, ub) LPT_MM(2, ua, wA, NPARTS)
+          LPT_XLOAD(0, 4, ua) LPT_MM(3, ub, wA, NPARTS)
+          LPT_XLOAD(0, 5, ub) LPT_MM(4, ua, wA, NPARTS)
+          LPT_XLOAD(0, 6, ua) LPT_MM(5, ub, wA, NPARTS)
+          LPT_XLOAD(1, 0, ub) LPT_MM(6, ua, wA, NPARTS)
+          LPT_WPF(wA, tile_of(it, 2), true)
+          LPT_XLOAD(1, 1, ua) LPT_MM(0, ub, wB, NPARTS)
+          LPT_XLOAD(1, 2, ub) LPT_MM(1, ua, wB, NPARTS)
+          LPT_XLOAD(1, 3, ua) LPT_MM(2, ub, wB, NPARTS)
+          LPT_XLOAD(1, 4, ub) LPT_MM(3, ua, wB, NPARTS)
+          LPT_XLOAD(1, 5, ua) LPT_MM(4, ub, wB, NPARTS)
+          LPT_XLOAD(1, 6, ub) LPT_MM(5, ua, wB, NPARTS)
+          LPT_XLOAD(2, 0, ua) LPT_MM(6, ub, wB, NPARTS)
+          LPT_WPF(wB, tile_of(it, 3), true)
+          LPT_XLOAD(2, 1, ub) LPT_MM(0, ua, wA, NPARTS)
+          LPT_XLOAD(2, 2, ua) LPT_MM(1, ub, wA, NPARTS)
+          LPT_XLOAD(2, 3, ub) LPT_MM(2, ua, wA, NPARTS)
+          LPT_XLOAD(2, 4, ua) LPT_MM(3, ub, wA, NPARTS)
+          LPT_XLOAD(2, 5, ub) LPT_MM(4, ua, wA, NPARTS)
+          LPT_XLOAD(2, 6, ua) LPT_MM(5, ub, wA, NPARTS)
+          LPT_XLOAD(3, 0, ub) LPT_MM(6, ua, wA, NPARTS)
+          LPT_WPF(wA, tile_of(nxt, 0), nxt < it_end)
+          LPT_XLOAD(3, 1, ua) LPT_MM(0, ub, wB, NPARTS)
+          LPT_XLOAD(3, 2, ub) LPT_MM(1, ua, wB, NPARTS)
+          LPT_XLOAD(3, 3, ua) LPT_MM(2, ub, wB, NPARTS)
+          LPT_XLOAD(3, 4, ub) LPT_MM(3, ua, wB, NPARTS)
+          LPT_XLOAD(3, 5, ua) LPT_MM(4, ub, wB, NPARTS)
+          LPT_XLOAD(3, 6, ub) LPT_MM(5, ua, wB, NPARTS)
+          LPT_MM(6, ub, wB, 0)
+        } else if (rg == 1) {                          // 6 row tiles
+          LPT_XLOAD(0, 0, ua)
+          LPT_WPF(wB, tile_of(it, 1), true)
+          LPT_XLOAD(0, 1, ub) LPT_MM(0, ua, wA, NPARTS)
+          LPT_XLOAD(0, 2, ua) LPT_MM(1, ub, wA, NPARTS)
+          LPT_XLOAD(0, 3, ub) LPT_MM(2, ua, wA, NPARTS)
+          LPT_XLOAD(0, 4, ua) LPT_MM(3, ub, wA, NPARTS)
+          LPT_XLOAD(0, 5, ub) LPT_MM(4, ua, wA, NPARTS)
+          LPT_XLOAD(1, 0, ua) LPT_MM(5, ub, wA, NPARTS)
+          LPT_WPF(wA, tile_of(it, 2), true)
+          LPT_XLOAD(1, 1, ub) LPT_MM(0, ua, wB, NPARTS)
+          LPT_XLOAD(1, 2, ua) LPT_MM(1, ub, wB, NPARTS)
+          LPT_XLOAD(1, 3, ub) LPT_MM(2, ua, wB, NPARTS)
+          LPT_XLOAD(1, 4, ua) LPT_MM(3, ub, wB, NPARTS)
+          LPT_XLOAD(1, 5, ub) LPT_MM(4, ua, wB, NPARTS)
+          LPT_XLOAD(2, 0, ua) LPT_MM(5, ub, wB, NPARTS)
+          LPT_WPF(wB, tile_of(it, 3), true)
+          LPT_XLOAD(2, 1, ub) LPT_MM(0, ua, wA, NPARTS)
+          LPT_XLOAD(2, 2, ua) LPT_MM(1, ub, wA, NPARTS)
+          LPT_XLOAD(2, 3, ub) LPT_MM(2, ua, wA, NPARTS)
+          LPT_XLOAD(2, 4, ua) LPT_MM(3, ub, wA, NPARTS)
+          LPT_XLOAD(2, 5, ub) LPT_MM(4, ua, wA, NPARTS)
+          LPT_XLOAD(3, 0, ua) LPT_MM(5, ub, wA, NPARTS)
+          LPT_WPF(wA, tile_of(nxt, 0), nxt < it_end)
+          LPT_XLOAD(3, 1, ub) LPT_MM(0, ua, wB, NPARTS)
+          LPT_XLOAD(3, 2, ua) LPT_MM(1, ub, wB, NPARTS)
+          LPT_XLOAD(3, 3, ub) LPT_MM(2, ua, wB, NPARTS)
+          LPT_XLOAD(3, 4, ua) LPT_MM(3, ub, wB, NPARTS)
+          LPT_XLOAD(3, 5, ub) LPT_MM(4, ua, wB, NPARTS)
+          LPT_MM(5, ub, wB, 0)
+        }
+      }
+      if constexpr (RG == 3) {
+        if (rg == 0) {                          // 5 row tiles
+          LPT_XLOAD(0, 0, ua)
+          LPT_WPF(wB, tile_of(it, 1), true)
+          LPT_XLOAD(0, 1, ub) LPT_MM(0, ua, wA, NPARTS)
+          LPT_XLOAD(0, 2, ua) LPT_MM(1, ub, wA, NPARTS)
+          LPT_XLOAD(0, 3, ub) LPT_MM(2, ua, wA, NPARTS)
+          LPT_XLOAD(0, 4, ua) LPT_MM(3, ub, wA, NPARTS)
+          LPT_XLOAD(1, 0, ub) LPT_MM(4, ua, wA, NPARTS)
+          LPT_WPF(wA, tile_of(it, 2), true)
+          LPT_XLOAD(1, 1, ua) LPT_MM(0, ub, wB, NPARTS)
+          LPT_XLOAD(1, 2, ub) LPT_MM(1, ua, wB, NPARTS)
+          LPT_XLOAD(1, 3, ua) LPT_MM(2, ub, wB, NPARTS)
+          LPT_XLOAD(1, 4, ub) LPT_MM(3, ua, wB, NPARTS)
+          LPT_XLOAD(2, 0, ua) LPT_MM(4, ub, wB, NPARTS)
+          LPT_WPF(wB, tile_of(it, 3), true)
+          LPT_XLOAD(2, 1, ub) LPT_MM(0, ua, wA, NPARTS)
+          LPT_XLOAD(2, 2, ua) LPT_MM(1, ub, wA, NPARTS)
+          LPT_XLOAD(2, 3, ub) LPT_MM(2, ua, wA, NPARTS)
+          LPT_XLOAD(2, 4, ua) LPT_MM(3, ub, wA, NPARTS)
+          LPT_XLOAD(3, 0, ub) LPT_MM(4, ua, wA, NPARTS)
+          LPT_WPF(wA, tile_of(nxt, 0), nxt < it_end)
+          LPT_XLOAD(3, 1, ua) LPT_MM(0, ub, wB, NPARTS)
+          LPT_XLOAD(3, 2, ub) LPT_MM(1, ua, wB, NPARTS)
+          LPT_XLOAD(3, 3, ua) LPT_MM(2, ub, wB, NPARTS)
+          LPT_XLOAD(3, 4, ub) LPT_MM(3, ua, wB, NPARTS)
+          LPT_MM(4, ub, wB, 0)
+        } else if (rg == 1 || rg == 2) {                          // 4 row tiles
+          LPT_XLOAD(0, 0, ua)
+          LPT_WPF(wB, tile_of(it, 1), true)
+          LPT_XLOAD(0, 1, ub) LPT_MM(0, ua, wA, NPARTS)
+          LPT_XLOAD(0, 2, ua) LPT_MM(1, ub, wA, NPARTS)
+          LPT_XLOAD(0, 3, ub) LPT_MM(2, ua, wA, NPARTS)
+          LPT_XLOAD(1, 0, ua) LPT_MM(3, ub, wA, NPARTS)
+          LPT_WPF(wA, tile_of(it, 2), true)
+          LPT_XLOAD(1, 1, ub) LPT_MM(0, ua, wB, NPARTS)
+          LPT_XLOAD(1, 2, ua) LPT_MM(1, ub, wB, NPARTS)
+          LPT_XLOAD(1, 3, ub) LPT_MM(2, ua, wB, NPARTS)
+          LPT_XLOAD(2, 0, ua) LPT_MM(3, ub, wB, NPARTS)
+          LPT_WPF(wB, tile_of(it, 3), true)
+          LPT_XLOAD(2, 1, ub) LPT_MM(0, ua, wA, NPARTS)
+          LPT_XLOAD(2, 2, ua) LPT_MM(1, ub, wA, NPARTS)
+          LPT_XLOAD(2, 3, ub) LPT_MM(2, ua, wA, NPARTS)
+          LPT_XLOAD(3, 0, ua) LPT_MM(3, ub, wA, NPARTS)
+          LPT_WPF(wA, tile_of(nxt, 0), nxt < it_end)
+          LPT_XLOAD(3, 1, ub) LPT_MM(0, ua, wB, NPARTS)
+          LPT_XLOAD(3, 2, ua) LPT_MM(1, ub, wB, NPARTS)
+          LPT_XLOAD(3, 3, ub) LPT_MM(2, ua, wB, NPARTS)
+          LPT_MM(3, ub, wB, 0)
+        }
+      }
+#undef LPT_MM
+#undef LPT_WAIT
+#undef LPT_WPF
+#undef LPT_XLOAD
+      it = nxt;
+      en = __builtin_amdgcn_readfirstlane(en_next_v);
+    }
+    __syncthreads();                                      // every wave is done reading the image
+    f32x4 bl0, bl1;
+    chan8(vl, cbo, bl0, bl1, 1.0f);
+    const f32x4 z4 = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (layer < nl) {
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {                      // relu(conv + b) + f
+        f[r][0] = __builtin_elementwise_max(acc[r][0] * inv + bl0, z4) + f[r][0];
+        f[r][1] = __builtin_elementwise_max(acc[r][1] * inv + bl1, z4) + f[r][1];
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        const int p = 16 * (rg + RG * r) + jo;
+        if (rg + RG * r < TW_RT) {                         // relu(W1 f + b1), fp32 image over the (dead) planes
+          const f32x4 o0 = __builtin_elementwise_max(acc[r][0] * inv + bl0, z4), o1 = __builtin_elementwise_max(acc[r][1] * inv + bl1, z4);
+          *reinterpret_cast<f32x4*>(img32 + p * BB_AP + cbo) = f32x4{o0[0], o1[0], o0[1], o1[1]};
+          *reinterpret_cast<f32x4*>(img32 + p * BB_AP + cbo + 4) = f32x4{o0[2], o1[2], o0[3], o1[3]};
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- last 1x1 conv 128 -> 5 in fp32
+  for (int e = tid; e < L * 5; e += NTH) {
+    const int row = e / 5, v = e - 5 * row;
+    const float* hr = img32 + row * BB_AP;
+    const float* wv = a.w2 + v * BB_C;
+    float sm = a.w2[5 * BB_C + v];
+#pragma unroll 8
+    for (int k = 0; k < BB_C; ++k) sm += hr[k] * wv[k];
+    if (a.row_idx && !a.out_scatter) a.out[((int64_t)blockIdx.x * L + row) * 5 + v] = sm;
+    else a.out[(seq * L + row) * 5 + v] = sm;
+  }
+}
+
 }  // namespace
 
 extern "C" int svdd_backbone_cnn_lp(const uint8_t* x, const float* table0, const void* tiles, const float* vec,
@@ -380,9 +774,20 @@ extern "C" int svdd_backbone_cnn_lp(const uint8_t* x, const float* table0, const
   }
   const dim3 grid(nwg);
   const bool spt1 = a.spt == 1 && !a.auto_spt;
+  // the transposed-accumulator kernel (round 3) where one sequence per tile is the ONLY packing (104 < L <= 208): for
+  // shorter sequences every packing must give a row the same bits (exact work-skipping), so they all stay on one kernel
+  const bool transposed = spt1 && TW_ROWS / L == 1 && g_bb_lp_version != 1;
+#define LPT_LAUNCH_ONE(TT, NPP, RGG)                                                                                \
+  { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(backbone_lp_t_kernel<TT, NPP, RGG>),                    \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                 \
+    hipExtLaunchKernelGGL((backbone_lp_t_kernel<TT, NPP, RGG>), grid, dim3(256 * RGG), lds, (hipStream_t)stream, e0, e1, 0, a); }
+#define LPT_LAUNCH_RG(TT, NPP)                                                                                      \
+  if (g_bb_lp_rg == 3) LPT_LAUNCH_ONE(TT, NPP, 3) else LPT_LAUNCH_ONE(TT, NPP, 2)
 #define LP_LAUNCH(TT, NPP)                                                                                          \
   do {                                                                                                               \
-    if (spt1) {                                                                                                      \
+    if (transposed) {                                                                                                \
+      LPT_LAUNCH_RG(TT, NPP)                                                                                         \
+    } else if (spt1) {                                                                                               \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(backbone_lp_kernel<TT, NPP, true>),                    \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                               \
       hipExtLaunchKernelGGL((backbone_lp_kernel<TT, NPP, true>), grid, dim3(512), lds, (hipStream_t)stream, e0, e1, 0, a);  \

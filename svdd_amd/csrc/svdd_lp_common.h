@@ -69,4 +69,22 @@ constexpr int LPS = 144;                   // 16-bit row stride of an operand pl
 constexpr int LPSB = LPS * 2;
 constexpr int PLANE_B = (TW_ROWS + 2) * LPSB;              // 60,480 B: rows -1 .. TW_ROWS
 constexpr int IMG_REGION_B = 2 * PLANE_B;                  // >= the fp32 final-stage image (208 x 132 x 4 = 109,824 B)
+
+// arguments of the split-precision backbone kernels (svdd_lp_backbone.hip, svdd_lp_backbone2.hip)
+struct BackboneLpArgs {
+  const uint8_t* x;        // [n, L] tokens 0..4
+  const float* table0;     // [9][5][128]
+  const void* tiles;       // [nl*36 + 4] tiles of [4 cg][64 lanes][2 ct][NPARTS][8] 16-bit
+  const float* vec;        // [nl + 2][4][128] as in svdd_backbone_cnn_f32
+  const float* lscale;     // [nl + 1][2] = {sa: activation scale, inv: 1 / (sa * weight scale)}
+  const float* w2;         // [5][128] then b2 [5]
+  float* out;              // [n, L, 5]
+  int n, L, spt, nl;
+  int dil[BB_MAXL];
+  const int* count;        // device scalar: valid rows (NULL: n) — exact work-skipping on a compacted batch
+  const int* row_idx;      // [count] (NULL: identity): compact row r reads the tokens of sequence row_idx[r] of x ...
+  int out_scatter;         // ... and writes its logits to row row_idx[r] of out (1) or to row r (0)
+  int auto_spt, ncu;       // auto_spt: the workgroups pick the sequences per tile from the device-side row count (svdd_spt.h)
+};
+
 }  // namespace

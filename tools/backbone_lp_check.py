@@ -11,6 +11,15 @@ from svdd_amd import backbone, config, fused
 
 torch.manual_seed(0)
 dev = "cuda"
+if "--rg" in sys.argv:                            # A/B: row groups (waves per SIMD) of the transposed kernel: 2, 3 or 4
+    from svdd_amd import _lib
+    k = sys.argv.index("--rg")
+    _lib.check(_lib.lib().svdd_set_option(3, 20 + int(sys.argv[k + 1])), "backbone lp row groups")
+    del sys.argv[k:k + 2]
+if "--v1" in sys.argv:                            # A/B: the round-2 kernel (svdd_set_option SVDD_OPT_BACKBONE_LP_VERSION = 1)
+    from svdd_amd import _lib
+    _lib.check(_lib.lib().svdd_set_option(3, 1), "backbone lp version")
+    sys.argv.remove("--v1")
 if "--time-only" in sys.argv:                    # ablation experiments: time of one mode, nothing else
     import time as _t
     mode = sys.argv[sys.argv.index("--time-only") + 1]
@@ -19,8 +28,16 @@ if "--time-only" in sys.argv:                    # ablation experiments: time of
     x = torch.randint(0, 5, (B, L), device=dev, dtype=torch.uint8)
     pk = fused.pack_backbone(cnn) if mode == "f32" else fused.pack_backbone_lp(cnn, mode)
     fn = (lambda: fused.backbone_cnn(x, pk)) if mode == "f32" else (lambda: fused.backbone_cnn_lp(x, pk))
-    for _ in range(3):
+    for _ in range(5):
         fn()
+    if "--events" in sys.argv:                   # kernel time: events around 50 back-to-back launches
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(); e0.record()
+        for _ in range(50):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        print(f"{mode} B={B} L={L}: {e0.elapsed_time(e1) / 50:.3f} ms (events)")
+        sys.exit(0)
     torch.cuda.synchronize(); t0 = _t.perf_counter()
     for _ in range(20):
         fn()

@@ -146,7 +146,37 @@ GRU_PC = {
 }
 GRU_PC["variants"]["nogates_nostore"] = GRU_PC["variants"]["nogates"] + GRU_PC["variants"]["nostore"]
 GRU_PC["variants"]["noprod"] = GRU_PC["variants"]["noprod_mfma"] + GRU_PC["variants"]["noprod_load"]
-SETS = {"gru_pc": GRU_PC, "gru_lp": GRU_LP, "tower_lp": TOWER_LP, "bb_lp": BB_LP, "k1": K1, "tower2": TOWER2}
+
+# the transposed-accumulator split-precision backbone (round 3): kernel time by HIP events (not wall time)
+BB_LPT = {
+    "file": "svdd_lp_backbone.hip",
+    "bench": ["python", "tools/backbone_lp_check.py", "256", "200", "--time-only", "f16x3", "--events"],
+    "variants": {
+        "baseline": [],
+        "nostats": [("    if (layer < nl) {\n      f32x4 tb0, tb1;\n      chan8(vl + BB_C, tb0, tb1, 1.0f);", "    if (layer < nl && a.n == 12345) {\n      f32x4 tb0, tb1;\n      chan8(vl + BB_C, tb0, tb1, 1.0f);")],
+        "nostatpass": [("#pragma unroll\n      for (int r = 0; r < NR; ++r) {\n        const int p = 16 * (rh + 2 * r) + j;\n        const float K = rmean[p < TW_ROWS ? p : TW_ROWS - 1];",
+                        "      for (int r = 0; r < NR && a.n == 12345; ++r) {\n        const int p = 16 * (rh + 2 * r) + j;\n        const float K = rmean[p < TW_ROWS ? p : TW_ROWS - 1];")],
+        "noxlane": [("        s1 += __shfl_xor(s1, 16, WAVE_SZ); s2 += __shfl_xor(s2, 16, WAVE_SZ);\n        s1 += __shfl_xor(s1, 32, WAVE_SZ); s2 += __shfl_xor(s2, 32, WAVE_SZ);\n", "")],
+        "nomfma": [("        acc[R][0] = Lp<T>::mfma(bc[0], U[0], acc[R][0]);                                                     \\\n        acc[R][1] = Lp<T>::mfma(bc[NPARTS], U[0], acc[R][1]);                                                \\",
+                    "        acc[R][0][0] += (float)U[0][0] * (float)bc[0][0];                                                    \\\n        acc[R][1][0] += (float)U[0][1] * (float)bc[NPARTS][0];                                               \\"),
+                   ("          acc[R][0] = Lp<T>::mfma(bc[1], U[0], acc[R][0]);                                                   \\\n          acc[R][1] = Lp<T>::mfma(bc[NPARTS + 1], U[0], acc[R][1]);                                          \\\n          acc[R][0] = Lp<T>::mfma(bc[0], U[1], acc[R][0]);                                                   \\\n          acc[R][1] = Lp<T>::mfma(bc[NPARTS], U[1], acc[R][1]);                                              \\",
+                    "          acc[R][0][1] += (float)U[1][0] * (float)bc[1][0];                                                  \\")],
+        "noX": [("        V[0] = *reinterpret_cast<const V8*>(plane + o_);                                                     \\\n        if constexpr (NP == 3) V[1] = *reinterpret_cast<const V8*>(plane + PLANE_B + o_); }\n#define LPT_WAIT",
+                 "        V[0] = bc[0]; (void)o_;                                                                              \\\n        if constexpr (NP == 3) V[1] = bc[1]; }\n#define LPT_WAIT")],
+        "noW": [("      if (nxt < it_end) {\n        const V8* src = wsrc + (size_t)tile_of(nxt) * TILE_V8;\n#pragma unroll\n        for (int q = 0; q < 2 * NPARTS; ++q) bn[q] = src[q];\n      }\n      const int delta = (((en >> 15) & 15) - 4) * dil;\n      const int coff = ((en >> 13) & 3) * 64;\n      const int dbytes = delta * LPSB + coff;\n      const int live = en >> rh;                          // bit 2 r = owned tile r\n#define LPT_XLOAD",
+                 "      if (nxt < it_end && a.n == 12345) {\n        const V8* src = wsrc + (size_t)tile_of(nxt) * TILE_V8;\n#pragma unroll\n        for (int q = 0; q < 2 * NPARTS; ++q) bn[q] = src[q];\n      }\n      const int delta = (((en >> 15) & 15) - 4) * dil;\n      const int coff = ((en >> 13) & 3) * 64;\n      const int dbytes = delta * LPSB + coff;\n      const int live = en >> rh;                          // bit 2 r = owned tile r\n#define LPT_XLOAD")],
+        "nofirst": [("          va += tk >= 0 ? ta : z;\n          vb += tk >= 0 ? tb : z;", "          va += tk >= 12345 ? ta : z;\n          vb += tk >= 12345 ? tb : z;")],
+        "noepi": [("        f[r][0] = __builtin_elementwise_max(acc[r][0] * inv + bl0, z4) + f[r][0];\n        f[r][1] = __builtin_elementwise_max(acc[r][1] * inv + bl1, z4) + f[r][1];",
+                   "        f[r][0] = acc[r][0] + f[r][0];\n        f[r][1] = acc[r][1] + f[r][1];")],
+    },
+}
+# scheduling experiments (correct results)
+BB_LPT["variants"]["x_nofence"] = [("      __builtin_amdgcn_sched_barrier(0);                                                                     \\\n      LPT_WAIT(NOUT)                                                                                         \\\n".replace("\\\\", "\\"), "      \\\n".replace("\\\\", "\\")),
+                                   ("      }                                                                                                      \\\n      __builtin_amdgcn_sched_barrier(0);\n".replace("\\\\", "\\"), "      }\n")]
+BB_LPT["variants"]["nomfma_noX_noW"] = BB_LPT["variants"]["nomfma"] + BB_LPT["variants"]["noX"] + BB_LPT["variants"]["noW"]
+BB_LPT["variants"]["nostats_nomfma_noX_noW"] = BB_LPT["variants"]["nostats"] + BB_LPT["variants"]["nomfma_noX_noW"]
+BB_LPT["variants"]["noX_noW"] = BB_LPT["variants"]["noX"] + BB_LPT["variants"]["noW"]
+SETS = {"bb_lpt": BB_LPT, "gru_pc": GRU_PC, "gru_lp": GRU_LP, "tower_lp": TOWER_LP, "bb_lp": BB_LP, "k1": K1, "tower2": TOWER2}
 
 
 def build_variant(setname, name, spec):
