@@ -413,8 +413,8 @@ def main():
             pmc_lp = json.load(open(pth)).get("backbone_lp_traffic_bytes_per_launch", {})
             pmc_lp_src = f"profiles/{name} (separate rocprofv3 --pmc passes, not measured in this run)"
     modes = [m for m in args.alt_precision.split(",") if m]
-    if args.value_net != "convgru":            # opaque value net: only the autocast modes mean anything for it
-        modes = [m for m in modes if m in ("bf16", "f16")]
+    # (value net = the Enformer-shaped trunk: every split-precision mode runs it on the hand-written kernels of
+    #  csrc/svdd_trunk.hip — the x3 modes as bf16x3, the one-pass modes as bf16; the fp32 line above is the PyTorch module)
     for mode in modes:
         model.precision = mode
         one_decode()

@@ -386,6 +386,33 @@ int svdd_device_info(char* arch, int arch_len, int* num_cu);
 int svdd_abi_version(void);
 #define SVDD_ABI_VERSION 3
 
+/*
+ * Enformer-shaped value trunk (BASELINE.json configs[3]; reference decode.py:78-80, Enformer.py:1271-1334 trunk, :1807-1884
+ * conv tower, :1887-2007 transformer tower, :2176-2292 ConvBlock "NACDR") on the 16-bit matrix cores, split precision
+ * bf16x3 (a_lo != NULL) or one-pass bf16 (a_lo == NULL). csrc/svdd_trunk.hip. Activations are channels-last rows
+ * [n * rows_per_seq, C]; for the k = 5 convolutions rows_per_seq = L + 4 (two zero rows either side of a sequence), so that a
+ * tap is a row shift of a plain GEMM. count (may be NULL): device scalar, number of live sequences of a compacted batch.
+ *
+ * svdd_trunk_gemm        out[M, N] = act(sum_{t < T} A[rows + t - T/2, Cin] W_t[Cin, N] + bias) (+ resid), fp32 [M, ldo].
+ *                        a_hi / a_lo: bf16 operand planes [>= M + 128 + T rows, lda] with T/2 readable rows before row 0;
+ *                        w: bf16 weight fragments packed by svdd_amd.fused_trunk.pack_gemm_weight ; N % 128 == 0, Cin % 32 == 0,
+ *                        T odd ; act 0 none, 1 relu, 2 x * sigmoid(1.702 x).
+ * svdd_trunk_act_split   x fp32 [rows, C] -> act(scale[c] x + shift[c]) (scale / shift NULL: identity) -> planes hi (lo may be
+ *                        NULL) ; rows whose position in their sequence is within `pad` of either end are written as zeros.
+ * svdd_trunk_layernorm_split   LayerNorm(x[row, :C]) gamma + beta -> planes (C % 8 == 0, C <= 4096).
+ * svdd_trunk_attn_pool   softmax-weighted pooling over position pairs: x, logits fp32 [n, L + 4, C] -> out [n, ceil(L/2) + 4, C].
+ * svdd_trunk_stem_unfold tokens [n, L] u8 -> hi plane [n (L + 4), 64]: channel 4 t + token of position l + t - 7 (t < 15) set to 1.
+ */
+int svdd_trunk_gemm(const void* a_hi, const void* a_lo, const void* w, const float* bias, const float* resid, float* out,
+                    int M, int N, int Cin, int T, int lda, int ldo, int act, const int32_t* count, int rows_per_seq,
+                    void* stream);
+int svdd_trunk_act_split(const float* x, const float* scale, const float* shift, int act, int64_t rows, int C,
+                         int rows_per_seq, int pad, void* hi, void* lo, const int32_t* count, void* stream);
+int svdd_trunk_layernorm_split(const float* x, const float* gamma, const float* beta, float eps, int64_t rows, int C,
+                               void* hi, void* lo, const int32_t* count, int rows_per_seq, void* stream);
+int svdd_trunk_attn_pool(const float* x, const float* logits, int n, int L, int C, float* out, const int32_t* count, void* stream);
+int svdd_trunk_stem_unfold(const uint8_t* tok, int n, int L, void* hi, const int32_t* count, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -31,6 +31,7 @@ EXPORTS = (
     "svdd_candidate_windows", "svdd_conv_tower_windows_f32", "svdd_k1_stats",
     "svdd_backbone_cnn_lp", "svdd_conv_tower_lp", "svdd_conv_tower_windows_lp", "svdd_gru_bidir_lp", "svdd_value_tail_lp",
     "svdd_compact_flags", "svdd_gather_rows", "svdd_advance_rows", "svdd_select_compact", "svdd_set_tower_version", "svdd_set_backbone_packing",
+    "svdd_trunk_gemm", "svdd_trunk_act_split", "svdd_trunk_layernorm_split", "svdd_trunk_attn_pool", "svdd_trunk_stem_unfold",
 )
 OPT_FORCE_EXACT = 0
 
@@ -48,7 +49,7 @@ class SvddError(RuntimeError):
 
 def build(force=False):
     """Compile csrc/svdd_kernels.hip for gfx950 (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, "svdd_kernels.hip"), os.path.join(CSRC, "svdd_nets.hip"),
+    srcs = [os.path.join(CSRC, "svdd_kernels.hip"), os.path.join(CSRC, "svdd_nets.hip"), os.path.join(CSRC, "svdd_trunk.hip"),
             os.path.join(CSRC, "svdd_lp_backbone.hip"), os.path.join(CSRC, "svdd_lp_tower.hip"),
             os.path.join(CSRC, "svdd_lp_gru_tail.hip"), os.path.join(CSRC, "svdd_lp_common.h"),
             os.path.join(os.path.dirname(_HERE), "include", "svdd_hip.h")]
@@ -56,7 +57,7 @@ def build(force=False):
         return SO_PATH                                   # an explicitly chosen build is used as it is
     stale = not os.path.exists(SO_PATH) or os.path.getmtime(SO_PATH) < max(os.path.getmtime(f) for f in srcs)
     if force or stale:
-        subprocess.check_call(["make", "-C", CSRC, "-B", "-j", str(min(5, os.cpu_count() or 1))])   # 5 translation units
+        subprocess.check_call(["make", "-C", CSRC, "-B", "-j", str(min(6, os.cpu_count() or 1))])   # 6 translation units
     return SO_PATH
 
 
@@ -112,6 +113,12 @@ def lib():
     L.svdd_gru_bidir_lp.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, vp, i32, vp]
     L.svdd_value_tail_lp.argtypes = [vp, vp, vp, vp, vp, vp, f32, vp, i32, i32, i32, vp, i32, vp]
     L.svdd_backbone_cnn_lp.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, ctypes.POINTER(ctypes.c_int), i32, vp, vp, i32, vp]
+    i64 = ctypes.c_int64
+    L.svdd_trunk_gemm.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp]
+    L.svdd_trunk_act_split.argtypes = [vp, vp, vp, i32, i64, i32, i32, i32, vp, vp, vp, vp]
+    L.svdd_trunk_layernorm_split.argtypes = [vp, vp, vp, f32, i64, i32, vp, vp, vp, i32, vp]
+    L.svdd_trunk_attn_pool.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp]
+    L.svdd_trunk_stem_unfold.argtypes = [vp, i32, i32, vp, vp, vp]
     L.svdd_profile_enable.argtypes = [i32]
     L.svdd_profile_collect.argtypes = [i32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]
     L.svdd_device_info.argtypes = [ctypes.c_char_p, i32, ctypes.POINTER(ctypes.c_int)]

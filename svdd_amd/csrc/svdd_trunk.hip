@@ -1,0 +1,333 @@
+// svdd_trunk.hip — hand-written kernels for the Enformer-shaped value trunk of BASELINE.json configs[3]
+// (reference decode.py:78-80: EnformerTrunk(n_conv=7, channels=1536, n_transformers=11, n_heads=8, key_len=64) +
+// ConvHead(1, 3072); layer structure Enformer.py:1271-1334 trunk, :1807-1884 conv tower, :1887-2007 transformer tower,
+// :2176-2292 ConvBlock order "NACDR"). Round 2 ran that trunk as an opaque PyTorch / MIOpen module: 60 TFLOP/s.
+//
+// The trunk is GEMM-shaped from end to end (k = 5 / k = 1 convolutions over 768..1536 channels on 200..2 positions, then
+// 11 transformer blocks on 2 tokens), so it goes to the 16-bit matrix cores with the split-precision arithmetic of
+// svdd_lp_common.h: every fp32 operand v = hi + lo with hi = bf16(v), lo = bf16(v - hi);
+// a*b ~ a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on v_mfma_f32_16x16x32_bf16 with fp32 accumulation ("bf16x3", error
+// ~5e-7 of sum|a b|), or one pass on hi ("bf16"). bf16 keeps fp32's exponent range: no operand scaling is needed for
+// activations of unknown magnitude (that is why the trunk does not offer f16x3).
+//
+// Data layout: activations are channels-last rows [n * Lp, C], Lp = L + 4: every sequence carries two zero rows in
+// front and two behind. A k = 5 convolution is then FIVE PLAIN GEMMS ACCUMULATED IN ONE KERNEL — K block kb of tap t reads
+// the A tile shifted by t - 2 rows — with no boundary predicate anywhere in the GEMM. The pad rows of an output are
+// garbage; the element-wise pass that prepares the next GEMM's operands (BatchNorm + GELU + hi/lo split) writes zeros there.
+//
+//   trunk_gemm_kernel         out[M, N] = act(A[M (+shift), K] W[K, N] + bias) (+ residual), fp32 out
+//   trunk_act_split_kernel    fp32 rows -> act(scale * x + shift) -> (hi, lo) planes, pad rows zeroed
+//   trunk_ln_split_kernel     LayerNorm over the row -> (hi, lo) planes
+//   trunk_attn_pool_kernel    softmax-weighted pooling over position pairs (enformer AttentionPool, pool 2)
+//   trunk_stem_unfold_kernel  tokens -> the stem's K = 15 taps x 4 one-hot operand rows (exact in bf16: no lo plane)
+// Every kernel takes the number of live sequences as a DEVICE scalar (exact work-skipping: the candidates that are copies
+// of their parent never enter the trunk, and no host round trip is needed to know how many are left).
+#include "svdd_lp_common.h"
+
+namespace {
+
+typedef __bf16 bf16_t;
+typedef b8 BV8;
+typedef float f32x8_t __attribute__((ext_vector_type(8)));
+
+constexpr int G_BM = 128, G_BN = 128, G_BK = 32;
+constexpr int G_AS = 40;                   // halves per LDS row of the A tile (80 B: 64 B of data + 16 B pad)
+constexpr int ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2;
+
+__device__ __forceinline__ float gelu_enformer(float x) { return x / (1.0f + __expf(-1.702f * x)); }   // x * sigmoid(1.702 x)
+__device__ __forceinline__ float apply_act(float v, int act) {
+  return act == ACT_RELU ? fmaxf(v, 0.0f) : act == ACT_GELU ? gelu_enformer(v) : v;
+}
+
+struct GemmArgs {
+  const bf16_t* a_hi; const bf16_t* a_lo;  // [rows][lda] operand planes; row 0 = logical row 0 (guard rows exist before / after)
+  const BV8* w;                            // packed weights [KB][N / 128][8 n-tiles][parts][64 lanes][8]
+  const float* bias; const float* resid; float* out;
+  int M, N, KB, cb, T, lda, ldo, act;
+  const int* count; int rows_per_seq;
+};
+
+// One workgroup (4 waves) = a 128 x 128 output tile; wave (wm, wn) owns 64 x 64 = 4 x 4 MFMA tiles. Per K block (32 wide):
+// the 128 x 32 A tile (shifted by the block's tap) and the 32 x 128 W tile go through LDS; the next block's global loads
+// are in flight while this block's 48 (x3) MFMAs per wave run.
+template <int NPARTS>
+__global__ __launch_bounds__(256, 3) void trunk_gemm_kernel(GemmArgs a) {
+  __shared__ __attribute__((aligned(16))) bf16_t sA[NPARTS][G_BM][G_AS];
+  __shared__ __attribute__((aligned(16))) BV8 sB[8][NPARTS][64];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wm = w >> 1, wn = w & 1, j = lane & 15, g = lane >> 4;
+  const int m_live = a.count ? min(a.M, *a.count * a.rows_per_seq) : a.M;
+  const int m0 = blockIdx.y * G_BM, nb = blockIdx.x;
+  if (m0 >= m_live) return;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) acc[i][nt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  // staging registers: A: thread -> (row tid >> 1, 32-byte half tid & 1); W: 4 (x3) / 2 pieces of 16 B
+  const int ar = tid >> 1, ah = tid & 1;
+  uint4 ra[NPARTS][2];
+  BV8 rb[2 * NPARTS];
+  const int NB = a.N / G_BN;
+  auto load = [&](int kb) {
+    const int t = kb / a.cb, c = kb - t * a.cb;
+    const int64_t row = (int64_t)m0 + ar + t - a.T / 2;
+    const size_t off = (size_t)(row * a.lda + 32 * c + 16 * ah);            // halves; guard rows make row = -2.. valid
+    ra[0][0] = *reinterpret_cast<const uint4*>(a.a_hi + off);
+    ra[0][1] = *reinterpret_cast<const uint4*>(a.a_hi + off + 8);
+    if constexpr (NPARTS == 2) {
+      ra[1][0] = *reinterpret_cast<const uint4*>(a.a_lo + off);
+      ra[1][1] = *reinterpret_cast<const uint4*>(a.a_lo + off + 8);
+    }
+    const BV8* src = a.w + ((size_t)kb * NB + nb) * (8 * NPARTS * 64);
+#pragma unroll
+    for (int q = 0; q < 2 * NPARTS; ++q) rb[q] = src[q * 256 + tid];
+  };
+  load(0);
+  for (int kb = 0; kb < a.KB; ++kb) {
+    __syncthreads();                                        // the previous block's fragments have been read
+#pragma unroll
+    for (int p = 0; p < NPARTS; ++p) {
+      *reinterpret_cast<uint4*>(&sA[p][ar][16 * ah]) = ra[p][0];
+      *reinterpret_cast<uint4*>(&sA[p][ar][16 * ah + 8]) = ra[p][1];
+    }
+#pragma unroll
+    for (int q = 0; q < 2 * NPARTS; ++q) (&sB[0][0][0])[q * 256 + tid] = rb[q];
+    __syncthreads();
+    if (kb + 1 < a.KB) load(kb + 1);
+    BV8 bf[4][NPARTS];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int p = 0; p < NPARTS; ++p) bf[nt][p] = sB[4 * wn + nt][p][lane];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      BV8 af[NPARTS];
+#pragma unroll
+      for (int p = 0; p < NPARTS; ++p) af[p] = *reinterpret_cast<const BV8*>(&sA[p][64 * wm + 16 * i + j][8 * g]);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bf[nt][0], acc[i][nt], 0, 0, 0);
+        if constexpr (NPARTS == 2) {
+          acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bf[nt][1], acc[i][nt], 0, 0, 0);
+          acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bf[nt][0], acc[i][nt], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // epilogue: lane (j, g) holds column j, rows 4 g + e of every tile
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    const int col = nb * G_BN + 64 * wn + 16 * nt + j;
+    const float b = a.bias ? a.bias[col] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int row = m0 + 64 * wm + 16 * i + 4 * g + e;
+        if (row < m_live) {
+          float v = apply_act(acc[i][nt][e] + b, a.act);
+          if (a.resid) v += a.resid[(size_t)row * a.ldo + col];
+          a.out[(size_t)row * a.ldo + col] = v;
+        }
+      }
+  }
+}
+
+// fp32 rows [rows, C] -> act(scale[c] x + shift[c]) -> (hi, lo) bf16 planes [rows, C]; rows whose position inside their
+// sequence (row % rows_per_seq) lies in the `pad` rows at either end become zero. One thread = 8 adjacent channels.
+struct ActArgs {
+  const float* x; const float* scale; const float* shift; int act; int64_t rows; int C, rows_per_seq, pad;
+  bf16_t* hi; bf16_t* lo; const int* count;
+};
+__global__ __launch_bounds__(256) void trunk_act_split_kernel(ActArgs a) {
+  const int64_t live = a.count ? min(a.rows, (int64_t)*a.count * a.rows_per_seq) : a.rows;
+  const int c8 = a.C >> 3;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= live * c8) return;
+  const int64_t row = idx / c8;
+  const int c = (int)(idx - row * c8) * 8;
+  const int pos = (int)(row % a.rows_per_seq);
+  f32x8_t v;
+  if (pos < a.pad || pos >= a.rows_per_seq - a.pad) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.0f;
+  } else {
+    const f32x4* px = reinterpret_cast<const f32x4*>(a.x + row * a.C + c);
+    const f32x4 x0 = px[0], x1 = px[1];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float t = e < 4 ? x0[e] : x1[e - 4];
+      if (a.scale) t = t * a.scale[c + e] + a.shift[c + e];
+      v[e] = apply_act(t, a.act);
+    }
+  }
+  const BV8 h = __builtin_convertvector(v, BV8);
+  *reinterpret_cast<BV8*>(a.hi + row * a.C + c) = h;
+  if (a.lo) *reinterpret_cast<BV8*>(a.lo + row * a.C + c) = __builtin_convertvector(v - __builtin_convertvector(h, f32x8_t), BV8);
+}
+
+// LayerNorm over a row of C <= 4096 channels (two-pass mean / centred variance, like ATen) -> (hi, lo) planes.
+// One wave per row; lane l holds channels 8 (l + 64 q) .. + 7.
+struct LnArgs { const float* x; const float* gamma; const float* beta; float eps; int64_t rows; int C; bf16_t* hi; bf16_t* lo; const int* count; int rows_per_seq; };
+__global__ __launch_bounds__(256) void trunk_ln_split_kernel(LnArgs a) {
+  const int64_t live = a.count ? min(a.rows, (int64_t)*a.count * a.rows_per_seq) : a.rows;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= live) return;
+  const int lane = threadIdx.x & 63;
+  constexpr int QMAX = 8;                                   // 64 lanes x 8 channels x 8 = 4096
+  const int nq = (a.C + 511) / 512;
+  f32x8_t v[QMAX];
+  float s = 0.0f;
+#pragma unroll
+  for (int q = 0; q < QMAX; ++q) {
+    const int c = 8 * (lane + 64 * q);
+    if (q < nq && c < a.C) {
+      const f32x4* px = reinterpret_cast<const f32x4*>(a.x + row * a.C + c);
+      const f32x4 x0 = px[0], x1 = px[1];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { v[q][e] = e < 4 ? x0[e] : x1[e - 4]; s += v[q][e]; }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[q][e] = 0.0f;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  const float mean = s / (float)a.C;
+  float q2 = 0.0f;
+#pragma unroll
+  for (int q = 0; q < QMAX; ++q) {
+    const int c = 8 * (lane + 64 * q);
+    if (q < nq && c < a.C) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = v[q][e] - mean; q2 += d * d; }
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) q2 += __shfl_xor(q2, off, 64);
+  const float rs = rsqrtf(q2 / (float)a.C + a.eps);
+#pragma unroll
+  for (int q = 0; q < QMAX; ++q) {
+    const int c = 8 * (lane + 64 * q);
+    if (q < nq && c < a.C) {
+      f32x8_t o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (v[q][e] - mean) * rs * a.gamma[c + e] + a.beta[c + e];
+      const BV8 h = __builtin_convertvector(o, BV8);
+      *reinterpret_cast<BV8*>(a.hi + row * a.C + c) = h;
+      if (a.lo) *reinterpret_cast<BV8*>(a.lo + row * a.C + c) = __builtin_convertvector(o - __builtin_convertvector(h, f32x8_t), BV8);
+    }
+  }
+}
+
+// AttentionPool(pool_size = 2): out[b, i, c] = sum_k x[b, 2 i + k, c] softmax_k(logits[b, 2 i + k, c]); an odd L is padded
+// with one masked position (weight 0). x / logits [n, L + 4, C] and out [n, ceil(L / 2) + 4, C] in the padded layout
+// (the pad rows of out are left untouched: the next element-wise pass zeroes them in the operand planes).
+struct PoolArgs { const float* x; const float* logits; int n, L, C; float* out; const int* count; };
+__global__ __launch_bounds__(256) void trunk_attn_pool_kernel(PoolArgs a) {
+  const int nlive = a.count ? min(a.n, *a.count) : a.n;
+  const int Lo = (a.L + 1) / 2, c4 = a.C >> 2;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)nlive * Lo * c4) return;
+  const int c = (int)(idx % c4) * 4;
+  const int64_t t = idx / c4;
+  const int i = (int)(t % Lo);
+  const int64_t b = t / Lo;
+  const int64_t r0 = b * (a.L + 4) + 2 + 2 * i;
+  const f32x4 x0 = *reinterpret_cast<const f32x4*>(a.x + r0 * a.C + c), l0 = *reinterpret_cast<const f32x4*>(a.logits + r0 * a.C + c);
+  f32x4 o = x0;
+  if (2 * i + 1 < a.L) {
+    const f32x4 x1 = *reinterpret_cast<const f32x4*>(a.x + (r0 + 1) * a.C + c), l1 = *reinterpret_cast<const f32x4*>(a.logits + (r0 + 1) * a.C + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float m = fmaxf(l0[e], l1[e]);
+      const float e0 = __expf(l0[e] - m), e1 = __expf(l1[e] - m);
+      o[e] = (x0[e] * e0 + x1[e] * e1) / (e0 + e1);
+    }
+  }
+  *reinterpret_cast<f32x4*>(a.out + (b * (Lo + 4) + 2 + i) * a.C + c) = o;
+}
+
+// Stem operand: row (b, l) of the padded layout gets the 64 channels [tap t = 0..14][one-hot 4] (+ 4 zeros) of the k = 15
+// convolution: channel 4 t + tok[l + t - 7]. Exact in bf16, so the stem GEMM needs A_hi x (W_hi + W_lo) only.
+struct StemArgs { const uint8_t* tok; int n, L; bf16_t* hi; const int* count; };
+__global__ __launch_bounds__(256) void trunk_stem_unfold_kernel(StemArgs a) {
+  const int nlive = a.count ? min(a.n, *a.count) : a.n;
+  const int Lp = a.L + 4;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;       // one thread = 8 channels (two taps) of one row
+  if (idx >= (int64_t)nlive * Lp * 8) return;
+  const int q = (int)(idx & 7);
+  const int64_t row = idx >> 3;
+  const int pos = (int)(row % Lp) - 2;
+  const int64_t b = row / Lp;
+  BV8 v;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = (bf16_t)0.0f;
+  if (pos >= 0 && pos < a.L) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int t = 2 * q + h, p = pos + t - 7;
+      if (t < 15 && p >= 0 && p < a.L) {
+        const int tk = a.tok[b * a.L + p];
+        if (tk < 4) v[4 * h + tk] = (bf16_t)1.0f;
+      }
+    }
+  }
+  *reinterpret_cast<BV8*>(a.hi + row * 64 + 8 * q) = v;
+}
+
+}  // namespace
+
+extern "C" {
+
+int svdd_trunk_gemm(const void* a_hi, const void* a_lo, const void* w, const float* bias, const float* resid, float* out,
+                    int M, int N, int Cin, int T, int lda, int ldo, int act, const int32_t* count, int rows_per_seq,
+                    void* stream) {
+  if (!a_hi || !w || !out || M <= 0 || N <= 0 || (N % G_BN) || Cin <= 0 || (Cin % G_BK) || T < 1 || !(T & 1) || lda < Cin ||
+      ldo < N || act < 0 || act > 2 || (count && rows_per_seq <= 0))
+    return SVDD_E_ARG;
+  GemmArgs a{(const bf16_t*)a_hi, (const bf16_t*)a_lo, (const BV8*)w, bias, resid, out, M, N, T * (Cin / G_BK), Cin / G_BK, T,
+             lda, ldo, act, count, rows_per_seq};
+  const dim3 grid((unsigned)(N / G_BN), (unsigned)((M + G_BM - 1) / G_BM));
+  if (a_lo) hipLaunchKernelGGL(trunk_gemm_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(trunk_gemm_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
+}
+
+int svdd_trunk_act_split(const float* x, const float* scale, const float* shift, int act, int64_t rows, int C,
+                         int rows_per_seq, int pad, void* hi, void* lo, const int32_t* count, void* stream) {
+  if (!x || !hi || rows <= 0 || C <= 0 || (C & 7) || rows_per_seq <= 0 || pad < 0 || 2 * pad > rows_per_seq || act < 0 || act > 2 ||
+      ((scale == nullptr) != (shift == nullptr)))
+    return SVDD_E_ARG;
+  ActArgs a{x, scale, shift, act, rows, C, rows_per_seq, pad, (bf16_t*)hi, (bf16_t*)lo, count};
+  const int64_t nthr = rows * (C >> 3);
+  hipLaunchKernelGGL(trunk_act_split_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
+}
+
+int svdd_trunk_layernorm_split(const float* x, const float* gamma, const float* beta, float eps, int64_t rows, int C,
+                               void* hi, void* lo, const int32_t* count, int rows_per_seq, void* stream) {
+  if (!x || !gamma || !beta || !hi || rows <= 0 || C <= 0 || (C & 7) || C > 4096 || (count && rows_per_seq <= 0)) return SVDD_E_ARG;
+  LnArgs a{x, gamma, beta, eps, rows, C, (bf16_t*)hi, (bf16_t*)lo, count, rows_per_seq};
+  hipLaunchKernelGGL(trunk_ln_split_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
+  return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
+}
+
+int svdd_trunk_attn_pool(const float* x, const float* logits, int n, int L, int C, float* out, const int32_t* count, void* stream) {
+  if (!x || !logits || !out || n <= 0 || L <= 0 || C <= 0 || (C & 3)) return SVDD_E_ARG;
+  PoolArgs a{x, logits, n, L, C, out, count};
+  const int64_t nthr = (int64_t)n * ((L + 1) / 2) * (C >> 2);
+  hipLaunchKernelGGL(trunk_attn_pool_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
+}
+
+int svdd_trunk_stem_unfold(const uint8_t* tok, int n, int L, void* hi, const int32_t* count, void* stream) {
+  if (!tok || !hi || n <= 0 || L <= 0) return SVDD_E_ARG;
+  StemArgs a{tok, n, L, (bf16_t*)hi, count};
+  const int64_t nthr = (int64_t)n * (L + 4) * 8;
+  hipLaunchKernelGGL(trunk_stem_unfold_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
+}
+
+}  // extern "C"

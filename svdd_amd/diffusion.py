@@ -233,6 +233,26 @@ class Diffusion(nn.Module):
                 self._fused[key] = ent
             ent[3].precision = self.precision
             return ent[3]
+        from .enformer_value import EnformerTrunk
+        if (self.fuse_nets and self.precision != "f32" and isinstance(embedding, EnformerTrunk) and isinstance(head, ConvHead)
+                and next(embedding.parameters()).is_cuda):
+            # BASELINE configs[3]'s Enformer-shaped trunk on the hand-written split-precision kernels (svdd_trunk.hip): the x3
+            # modes map to bf16x3 (bf16 keeps fp32's exponent range: no operand scaling needed), the one-pass modes to bf16
+            tp = "bf16x3" if self.precision.endswith("x3") else "bf16"
+            key = ("trunk", id(embedding), id(head), tp)
+            ent = self._fused.get(key)
+            alive = ent is not None and ent[0]() is embedding and ent[1]() is head
+            if not (alive and self._checked_now(ent[4])):
+                fp = weight_fingerprint(embedding, head)
+                if not (alive and _same_weights(ent[2], fp)):
+                    from .fused_trunk import FusedEnformerValueNet
+                    for k in [k for k, v in self._fused.items() if k != "backbone" and (v[0]() is None or v[1]() is None)]:
+                        del self._fused[k]
+                    ent = (weakref.ref(embedding), weakref.ref(head), fp, FusedEnformerValueNet(embedding, head, tp), self._scope_id)
+                else:
+                    ent = ent[:4] + (self._scope_id,)
+                self._fused[key] = ent
+            return ent[3]
         if self.precision in ("bf16", "f16"):                       # opaque nets: PyTorch-ROCm's own 16-bit kernels
             dt = torch.bfloat16 if self.precision == "bf16" else torch.float16
 
@@ -623,8 +643,10 @@ class Diffusion(nn.Module):
         """The skipping paths hand the nets compacted batches whose size only the device knows: they need the
         hand-written kernels for the value / reward net and (PM, logits cache) the one-launch backbone kernel."""
         from .fused import FusedValueNet
-        return (self.skip_unchanged and self.fuse_nets and self.value_batching == "batched" and M > 1 and
-                isinstance(fn, FusedValueNet) and fn.kernels_ok(L) and fn.w_eff.shape[1] == 1 and
+        from .fused_trunk import FusedEnformerValueNet
+        ok = ((isinstance(fn, FusedValueNet) and fn.kernels_ok(L) and fn.w_eff.shape[1] == 1) or
+              (isinstance(fn, FusedEnformerValueNet) and fn.head_w.shape[1] == 1))
+        return (self.skip_unchanged and self.fuse_nets and self.value_batching == "batched" and M > 1 and ok and
                 self.select_mode in ("argmax", "multinomial"))
 
     def _fused_backbone_or_none(self, L):
@@ -688,7 +710,7 @@ class Diffusion(nn.Module):
         ws = self._SkipWorkspace(B, M, self.device)
         ws.parent_score.copy_(fn.forward_tokens(x).reshape(B))               # scores of the all-MASK parents
         fb = self._fused_backbone_or_none(L) if self._use_logits_cache(L) else None
-        share = fn.candidates_ok(L, M)
+        share = hasattr(fn, "candidates_ok") and fn.candidates_ok(L, M)
         toks_c = None if share else torch.empty((B * M, L), dtype=torch.uint8, device=self.device)
         logits = None
         for i in range(S):

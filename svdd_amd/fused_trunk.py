@@ -1,0 +1,277 @@
+"""The Enformer-shaped value trunk of BASELINE.json configs[3] on hand-written kernels (csrc/svdd_trunk.hip).
+
+`FusedEnformerValueNet(trunk, head)` computes the same function as `head(trunk(onehot))` for an
+`enformer_value.EnformerTrunk` + `value_nets.ConvHead` pair (reference decode.py:78-80; layer structure
+Enformer.py:1271-1334, :1807-1884 conv tower, :1887-2007 transformer tower, :2176-2292 ConvBlock "NACDR"), with every
+matrix product on the 16-bit matrix cores in split precision:
+
+    precision "bf16x3"  operands split hi + lo in bf16, 3 MFMAs per product, fp32 accumulate (fp32-class error);
+              "bf16"    one pass on hi.
+
+Layout and kernels (see the header of svdd_trunk.hip): channels-last rows with two zero rows either side of every
+sequence, so a k = 5 convolution is five row-shifted GEMMs accumulated in one launch; BatchNorm (eval) + GELU + the hi / lo
+split are one element-wise pass that writes the next GEMM's operand planes; the attention pooling is a 1x1 GEMM for
+the logits plus one pair-softmax pass. The transformer tower works on the 2 tokens a 200-long sequence is pooled down to:
+its projections and FFNs are the same GEMM kernel (q, k, v fused into one launch), its 2 x 2 attention is a handful of
+tiny tensor ops. Every kernel takes the number of live sequences as a device scalar (`count`), so the exact work-skipping
+of the SVDD-MC loop needs no host round trip.
+
+The module takes TOKENS ([n, L] uint8, 4 = MASK): the engine's one-hot rows are exact, and the stem's k = 15 convolution
+over a one-hot input is a K = 60 GEMM whose A operand is exactly representable in bf16."""
+import ctypes
+
+import torch
+from torch import nn
+
+from . import _lib
+from .enformer_value import EnformerTrunk, _positional_features, _relative_shift
+from .value_nets import ConvHead
+
+ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
+GUARD = 4            # operand-plane rows in front of row 0 (a k = 5 tap reads rows -2 .. of the first tile)
+TAIL = 136           # ... and behind the last row (the last 128-row tile + 2 tap rows)
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def pack_gemm_weight(w, parts):
+    """Conv1d / Linear weight [N, Cin, T] (or [N, Cin]) fp32 -> bf16 fragments for svdd_trunk_gemm:
+    [KB = T * Cin/32][N/128][8 n-tiles][parts][64 lanes = 16 g + j][8 e] = part(W[128 nb + 16 nt + j][32 c + 8 g + e][t]),
+    kb = t * (Cin / 32) + c ; part 0 = bf16(W), part 1 = bf16(W - part 0)."""
+    if w.dim() == 2:
+        w = w[:, :, None]
+    N, Cin, T = w.shape
+    assert N % 128 == 0 and Cin % 32 == 0, (N, Cin)
+    w = w.detach().float()
+    hi = w.to(torch.bfloat16)
+    ps = [hi] if parts == 1 else [hi, (w - hi.float()).to(torch.bfloat16)]
+    v = torch.stack(ps, dim=0).reshape(parts, N // 128, 8, 16, Cin // 32, 4, 8, T)     # [p][nb][nt][j][c][g][e][t]
+    return v.permute(7, 4, 1, 2, 0, 5, 3, 6).contiguous().reshape(-1)                  # [t][c][nb][nt][p][g][j][e]
+
+
+class _Planes:
+    """(hi, lo) bf16 operand planes inside one allocation, with guard rows so that shifted / overrunning tile reads stay
+    inside it."""
+
+    def __init__(self, max_elems, parts, dev):
+        self.buf = [torch.zeros(max_elems, dtype=torch.bfloat16, device=dev) for _ in range(parts)]
+
+    def view(self, rows, C):
+        need = (GUARD + rows + TAIL) * C
+        assert need <= self.buf[0].numel(), (rows, C, self.buf[0].numel())
+        return [b[GUARD * C:] for b in self.buf]
+
+
+class FusedEnformerValueNet(nn.Module):
+    def __init__(self, trunk: EnformerTrunk, head: ConvHead, precision="bf16x3"):
+        super().__init__()
+        assert precision in ("bf16x3", "bf16")
+        self.precision = precision
+        self.parts = 2 if precision == "bf16x3" else 1
+        self._src = (trunk, head)
+        self._ws = {}
+        dev = next(trunk.parameters()).device
+        P = self.parts
+        pk = lambda w: pack_gemm_weight(w, P).to(dev)                                  # noqa: E731
+
+        def bn_affine(bn):
+            s = (bn.weight.detach() / torch.sqrt(bn.running_var + bn.eps)).float()
+            return s.contiguous(), (bn.bias.detach() - bn.running_mean * s).float().contiguous()
+
+        with torch.no_grad():
+            blocks = trunk.conv_tower.blocks
+            stem = blocks[0][0]
+            assert tuple(stem.weight.shape[1:]) == (4, 15)
+            half = stem.weight.shape[0]
+            wk = torch.zeros(half, 64, device=dev)
+            wk[:, :60] = stem.weight.detach().float().permute(0, 2, 1).reshape(half, 60)      # K index 4 t + ci
+            self.stem_w, self.stem_b = pk(wk), stem.bias.detach().float().contiguous()
+            self.levels = []
+            for i, blk in enumerate(blocks):
+                lv = {}
+                if i > 0:
+                    a = blk[0]
+                    assert a.conv.kernel_size[0] == 5 and not a.residual and isinstance(a.pool, nn.Identity)
+                    lv["a_bn"], lv["a_w"], lv["a_b"] = bn_affine(a.norm), pk(a.conv.weight), a.conv.bias.detach().float().contiguous()
+                    lv["a_cin"], lv["a_cout"] = a.conv.in_channels, a.conv.out_channels
+                b = blk[1]
+                assert b.conv.kernel_size[0] == 1 and b.residual
+                lv["b_bn"], lv["b_w"], lv["b_b"] = bn_affine(b.norm), pk(b.conv.weight), b.conv.bias.detach().float().contiguous()
+                lv["C"] = b.conv.out_channels
+                lv["pool_w"] = pk(b.pool.to_attn_logits.weight.detach()[:, :, 0, 0])
+                self.levels.append(lv)
+            self.C = trunk.pointwise_conv.conv.in_channels
+            self.tf = []
+            for tb in trunk.transformer_tower:
+                m = tb.mha
+                d = {"ln1": (tb.norm.weight.detach().float().contiguous(), tb.norm.bias.detach().float().contiguous(), tb.norm.eps),
+                     "qkv_w": pk(torch.cat([m.to_q.weight, m.to_k.weight, m.to_v.weight], dim=0)),
+                     "nq": m.to_q.weight.shape[0], "nv": m.to_v.weight.shape[0],
+                     "out_w": pk(m.to_out.weight), "out_b": m.to_out.bias.detach().float().contiguous(),
+                     "heads": m.heads, "dk": m.dim_key, "dv": m.dim_value,
+                     "content_bias": m.rel_content_bias.detach().float(), "pos_bias": m.rel_pos_bias.detach().float(),
+                     "rel_w": m.to_rel_k.weight.detach().float(), "nfeat": m.num_rel_pos_features,
+                     "ln2": (tb.ffn_norm.weight.detach().float().contiguous(), tb.ffn_norm.bias.detach().float().contiguous(), tb.ffn_norm.eps),
+                     "f1_w": pk(tb.ffn1.weight), "f1_b": tb.ffn1.bias.detach().float().contiguous(),
+                     "f2_w": pk(tb.ffn2.weight), "f2_b": tb.ffn2.bias.detach().float().contiguous()}
+                assert (2 * d["nq"] + d["nv"]) % 128 == 0
+                self.tf.append(d)
+            pw = trunk.pointwise_conv
+            assert pw.conv.kernel_size[0] == 1 and not pw.residual
+            self.pw_bn, self.pw_w, self.pw_b = bn_affine(pw.norm), pk(pw.conv.weight), pw.conv.bias.detach().float().contiguous()
+            self.pw_out = pw.conv.out_channels
+            hw = head.channel_transform.conv.layer
+            self.head_w = hw.weight.detach().float()[:, :, 0].t().contiguous()        # [3072, n_tasks]
+            self.head_b = hw.bias.detach().float()
+        self._relk = {}
+
+    # ------------------------------------------------------------------ thin kernel wrappers
+    def _gemm(self, planes, w, bias, resid, out, M, N, Cin, T, act, count, rps):
+        rc = _lib.lib().svdd_trunk_gemm(planes[0].data_ptr(), planes[1].data_ptr() if len(planes) > 1 else None, w.data_ptr(),
+                                        _ptr(bias), _ptr(resid), out.data_ptr(), M, N, Cin, T, Cin, N, act, _ptr(count), rps, _stream())
+        _lib.check(rc, "svdd_trunk_gemm")
+
+    def _act(self, x, bn, act, rows, C, rps, pad, planes, count):
+        rc = _lib.lib().svdd_trunk_act_split(x.data_ptr(), _ptr(bn[0]) if bn else None, _ptr(bn[1]) if bn else None, act, rows, C, rps,
+                                             pad, planes[0].data_ptr(), planes[1].data_ptr() if len(planes) > 1 else None,
+                                             _ptr(count), _stream())
+        _lib.check(rc, "svdd_trunk_act_split")
+
+    def _ln(self, x, ln, rows, C, planes, count, rps):
+        rc = _lib.lib().svdd_trunk_layernorm_split(x.data_ptr(), ln[0].data_ptr(), ln[1].data_ptr(), float(ln[2]), rows, C,
+                                                   planes[0].data_ptr(), planes[1].data_ptr() if len(planes) > 1 else None,
+                                                   _ptr(count), rps, _stream())
+        _lib.check(rc, "svdd_trunk_layernorm_split")
+
+    def _workspace(self, n, L, dev):
+        key = (n, L, str(dev))
+        ws = self._ws.get(key)
+        if ws is None:
+            rows0 = n * (L + 4)
+            Tf = L
+            for _ in self.levels:
+                Tf = (Tf + 1) // 2                                # tokens left for the transformer tower
+            cmax = max([lv["C"] for lv in self.levels])
+            # the largest activation is at the first level (rows halve per level, channels at most double overall)
+            fmax = max(rows0 * self.levels[0]["C"], max((n * ((L >> i) + 5)) * lv["C"] for i, lv in enumerate(self.levels)),
+                       n * Tf * max(self.pw_out, 2 * self.C, 2 * self.tf[0]["nq"] + self.tf[0]["nv"] if self.tf else 0)) + 1024
+            pmax = max((GUARD + rows0 + TAIL) * max(64, self.levels[0]["C"]),
+                       max((GUARD + n * ((L >> max(i - 1, 0)) + 5) + TAIL) * lv["C"] for i, lv in enumerate(self.levels)),
+                       (GUARD + Tf * n + TAIL) * max(self.pw_out, 2 * self.C))
+            ws = {"f": [torch.empty(fmax, dtype=torch.float32, device=dev) for _ in range(4)],
+                  "p": _Planes(pmax, 2, dev), "cmax": cmax}
+            self._ws = {key: ws}                                   # one workspace at a time (GBs at the C4 shard size)
+        return ws
+
+    def _rel_k(self, d, length, dev):
+        key = (id(d), length)
+        r = self._relk.get(key)
+        if r is None:
+            pos = _positional_features(length, d["nfeat"], dev)
+            r = (pos @ d["rel_w"].t()).view(2 * length - 1, d["heads"], d["dk"]).transpose(0, 1).contiguous()   # [h, 2L-1, dk]
+            self._relk[key] = r
+        return r
+
+    # ------------------------------------------------------------------ forward
+    @torch.no_grad()
+    def forward_tokens(self, tok, count=None):
+        """tok [n, L] u8 -> scores [n, n_tasks, 1]; count: int32 device scalar = live rows (rows beyond it are undefined)."""
+        assert tok.is_cuda and tok.dtype == torch.uint8 and tok.is_contiguous()
+        n, L = tok.shape
+        dev = tok.device
+        ws = self._workspace(n, L, dev)
+        f, P = ws["f"], self.parts
+        planes_all = ws["p"]
+        lib = _lib.lib()
+
+        def planes(rows, C):
+            return planes_all.view(rows, C)[:P]
+
+        # ---- conv tower
+        Lc, rps = L, L + 4
+        rows = n * rps
+        ph = planes_all.view(rows, 64)
+        _lib.check(lib.svdd_trunk_stem_unfold(tok.data_ptr(), n, L, ph[0].data_ptr(), _ptr(count), _stream()), "svdd_trunk_stem_unfold")
+        if P == 2:
+            ph[1][: rows * 64].zero_()                           # the one-hot operand is exact: its lo plane is zero
+        x = f[0]
+        C = self.levels[0]["C"]
+        self._gemm(ph[:P], self.stem_w, self.stem_b, None, x, rows, C, 64, 1, ACT_NONE, count, rps)
+        cur = 0                                                   # index of the buffer that holds x
+        for i, lv in enumerate(self.levels):
+            rows = n * rps
+            if i > 0:                                             # k = 5 block: z = conv5(gelu(bn(x)))
+                pl = planes(rows, lv["a_cin"])
+                self._act(f[cur], lv["a_bn"], ACT_GELU, rows, lv["a_cin"], rps, 2, pl, count)
+                z = f[(cur + 1) % 4]
+                self._gemm(pl, lv["a_w"], lv["a_b"], None, z, rows, lv["a_cout"], lv["a_cin"], 5, ACT_NONE, count, rps)
+                cur = (cur + 1) % 4
+            C = lv["C"]
+            pl = planes(rows, C)                                  # 1x1 residual block: y = conv1(gelu(bn(x))) + x
+            self._act(f[cur], lv["b_bn"], ACT_GELU, rows, C, rps, 2, pl, count)
+            y = f[(cur + 1) % 4]
+            self._gemm(pl, lv["b_w"], lv["b_b"], f[cur], y, rows, C, C, 1, ACT_NONE, count, rps)
+            self._act(y, None, ACT_NONE, rows, C, rps, 2, pl, count)          # attention pooling: logits = W_pool y
+            lg = f[(cur + 2) % 4]
+            self._gemm(pl, lv["pool_w"], None, None, lg, rows, C, C, 1, ACT_NONE, count, rps)
+            xn = f[(cur + 3) % 4]
+            _lib.check(lib.svdd_trunk_attn_pool(y.data_ptr(), lg.data_ptr(), n, Lc, C, xn.data_ptr(), _ptr(count), _stream()),
+                       "svdd_trunk_attn_pool")
+            cur = (cur + 3) % 4
+            Lc = (Lc + 1) // 2
+            rps = Lc + 4
+        # ---- transformer tower on the Lc tokens left (2 for L = 200)
+        C = self.C
+        T = Lc
+        x = f[cur][: n * rps * C].view(n, rps, C)[:, 2:2 + T].reshape(n * T, C).contiguous()
+        rows = n * T
+        for d in self.tf:
+            h, dk, dv, nq, nv = d["heads"], d["dk"], d["dv"], d["nq"], d["nv"]
+            pl = planes(rows, C)
+            self._ln(x, d["ln1"], rows, C, pl, count, T)
+            nqkv = 2 * nq + nv
+            qkv = f[(cur + 1) % 4][: rows * nqkv].view(rows, nqkv)
+            self._gemm(pl, d["qkv_w"], None, None, qkv, rows, nqkv, C, 1, ACT_NONE, count, T)
+            q = qkv[:, :nq].view(n, T, h, dk).transpose(1, 2) * dk ** -0.5
+            k = qkv[:, nq:2 * nq].view(n, T, h, dk).transpose(1, 2)
+            v = qkv[:, 2 * nq:].view(n, T, h, dv).transpose(1, 2)
+            rel_logits = _relative_shift(torch.einsum("bhid,hjd->bhij", q + d["pos_bias"], self._rel_k(d, T, dev)))
+            logits = torch.matmul(q + d["content_bias"], k.transpose(-1, -2)) + rel_logits
+            o = torch.matmul(torch.softmax(logits, dim=-1), v).transpose(1, 2).reshape(rows, h * dv).contiguous()
+            pl = planes(rows, h * dv)
+            self._act(o, None, ACT_NONE, rows, h * dv, T, 0, pl, count)
+            x2 = f[(cur + 2) % 4][: rows * C].view(rows, C)
+            self._gemm(pl, d["out_w"], d["out_b"], x, x2, rows, C, h * dv, 1, ACT_NONE, count, T)
+            pl = planes(rows, C)
+            self._ln(x2, d["ln2"], rows, C, pl, count, T)
+            hid = f[(cur + 1) % 4][: rows * 2 * C].view(rows, 2 * C)
+            self._gemm(pl, d["f1_w"], d["f1_b"], None, hid, rows, 2 * C, C, 1, ACT_RELU, count, T)
+            pl = planes(rows, 2 * C)
+            self._act(hid, None, ACT_NONE, rows, 2 * C, T, 0, pl, count)
+            x3 = f[(cur + 3) % 4][: rows * C].view(rows, C)
+            self._gemm(pl, d["f2_w"], d["f2_b"], x2, x3, rows, C, 2 * C, 1, ACT_NONE, count, T)
+            x = x3
+            cur = (cur + 3) % 4
+        # ---- pointwise block (no residual, no pool) + trunk GELU, then the head: 1x1 conv + mean over length
+        pl = planes(rows, C)
+        self._act(x, self.pw_bn, ACT_GELU, rows, C, T, 0, pl, count)
+        z = f[(cur + 1) % 4][: rows * self.pw_out].view(rows, self.pw_out)
+        self._gemm(pl, self.pw_w, self.pw_b, None, z, rows, self.pw_out, C, 1, ACT_GELU, count, T)
+        s = (z @ self.head_w + self.head_b).view(n, T, -1).mean(dim=1)
+        return s[:, :, None]
+
+    def forward(self, onehot):
+        """Value-function interface: one-hot fp32 [n, L, 4] (or the reward-model layout [n, 4, L]) -> [n, n_tasks, 1]."""
+        if onehot.shape[1] == 4 and onehot.shape[2] != 4:
+            onehot = onehot.transpose(1, 2)
+        tok = torch.where(onehot.sum(dim=2) == 0, 4, onehot.argmax(dim=2)).to(torch.uint8).contiguous()
+        return self.forward_tokens(tok)
+
+    def tokens_ok(self, L):
+        return True

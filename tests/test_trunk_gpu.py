@@ -1,0 +1,111 @@
+"""-m gpu: the hand-written kernels of the Enformer-shaped value trunk (csrc/svdd_trunk.hip, svdd_amd/fused_trunk.py;
+BASELINE.json configs[3], reference decode.py:78-80 / Enformer.py:1271-1334, 1807-2007) against the PyTorch module they
+replace, in fp32 on the same weights. (The trunk's attention / pooling blocks come from an un-vendored dependency of the
+reference — SURVEY section 8c: parity unpinned by construction — so the PyTorch module IS the definition here.)"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _randomise(emb, head, seed):
+    """Non-trivial BatchNorm statistics, attention output projections (zero at init) and pooling logits."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    with torch.no_grad():
+        for m in emb.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+                m.running_var.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+                m.weight.copy_(1.0 + 0.2 * torch.randn(m.num_features, generator=g))
+                m.bias.copy_(0.1 * torch.randn(m.num_features, generator=g))
+        for blk in emb.transformer_tower:
+            w = blk.mha.to_out.weight
+            w.copy_(torch.randn(w.shape, generator=g) * (w.shape[1] ** -0.5))
+            blk.mha.to_out.bias.copy_(torch.randn(w.shape[0], generator=g) * 0.05)
+        for blk in emb.conv_tower.blocks:
+            pw = blk[1].pool.to_attn_logits.weight
+            pw.add_((torch.randn(pw.shape, generator=g) * 0.05).to(pw.device))
+
+
+@pytest.mark.parametrize("precision,tol", [("bf16x3", 1e-4), ("bf16", 3e-2)])
+@pytest.mark.parametrize("L,kw", [(200, dict(n_conv=4, channels=768, n_transformers=2, n_heads=4, key_len=16)),
+                                  (50, dict(n_conv=4, channels=768, n_transformers=2, n_heads=4, key_len=16)),
+                                  (37, dict(n_conv=3, channels=768, n_transformers=1, n_heads=2, key_len=32))])
+def test_fused_trunk_equals_the_module_small(precision, tol, L, kw):
+    from svdd_amd import synthetic
+    from svdd_amd.fused_trunk import FusedEnformerValueNet
+    _, emb, head, _ = synthetic.build("dna", DEV, hidden_dim=32, num_cnn_stacks=1, value="enformer", enformer_kwargs=kw)
+    _randomise(emb, head, L)
+    g = torch.Generator(device=DEV).manual_seed(L)
+    n = 37
+    tok = torch.randint(0, 5, (n, L), device=DEV, generator=g, dtype=torch.uint8)
+    tok[0] = 4                                                       # the all-MASK prior
+    onehot = (torch.nn.functional.one_hot(tok.long().clamp(max=3), 4) * (tok != 4)[..., None]).float()
+    with torch.no_grad():
+        ref = head(emb(onehot)).reshape(n)
+        fn = FusedEnformerValueNet(emb, head, precision)
+        out = fn.forward_tokens(tok).reshape(n)
+        out2 = fn(onehot).reshape(n)
+        # a compacted batch: only the first `live` rows are computed, and they are the same bits
+        live = 11
+        cnt = torch.tensor([live], dtype=torch.int32, device=DEV)
+        part = fn.forward_tokens(tok, count=cnt).reshape(n)[:live]
+    scale = float(ref.abs().max())
+    assert torch.isfinite(out).all()
+    assert float((out - ref).abs().max()) <= tol * max(1.0, scale), (float((out - ref).abs().max()), scale)
+    assert torch.equal(out, out2)
+    assert torch.equal(part, out[:live])
+
+
+def test_fused_trunk_full_size_c4():
+    """BASELINE configs[3]: the 230 M-parameter trunk (7 conv levels to 1536 channels, 11 transformer blocks on 2 tokens),
+    160 candidates of length 200."""
+    from svdd_amd import synthetic
+    from svdd_amd.fused_trunk import FusedEnformerValueNet
+    _, emb, head, _ = synthetic.build("dna", DEV, value="enformer")
+    _randomise(emb, head, 3)
+    g = torch.Generator(device=DEV).manual_seed(1)
+    n, L = 160, 200
+    tok = torch.randint(0, 5, (n, L), device=DEV, generator=g, dtype=torch.uint8)
+    tok[:8, 40:] = 4
+    onehot = (torch.nn.functional.one_hot(tok.long().clamp(max=3), 4) * (tok != 4)[..., None]).float()
+    with torch.no_grad():
+        ref = head(emb(onehot)).reshape(n)
+        out = FusedEnformerValueNet(emb, head, "bf16x3").forward_tokens(tok).reshape(n)
+        one = FusedEnformerValueNet(emb, head, "bf16").forward_tokens(tok).reshape(n)
+    scale = max(1.0, float(ref.abs().max()))
+    err3, err1 = float((out - ref).abs().max()), float((one - ref).abs().max())
+    print(f"full-size trunk: |score| max {float(ref.abs().max()):.3f}  bf16x3 err {err3:.2e}  bf16 err {err1:.2e}")
+    assert err3 <= 1e-4 * scale
+    assert err1 <= 5e-2 * scale
+
+
+def test_mc_decode_with_the_fused_trunk_vs_oracle():
+    """SVDD-MC (M = 20, L = 200) with the fused trunk as value function, precision bf16x3: the work-skipping loop (live
+    candidates gathered on the device, `count` fed to every trunk kernel) against the plain loop, and the oracle's replay of
+    the recorded logits / scores."""
+    from oracle import svdd_oracle as orc
+    from svdd_amd import synthetic
+    from svdd_amd.fused_trunk import FusedEnformerValueNet
+    model, emb, head, _ = synthetic.build("dna", DEV, value="enformer",
+                                          enformer_kwargs=dict(n_conv=4, channels=768, n_transformers=2, n_heads=4, key_len=16))
+    _randomise(emb, head, 5)
+    B, L, M, S = 6, 200, 20, 24
+    sched = model._schedule(S, 1e-5)[0]
+    model.precision, model.rng_mode, model.philox_seed = "bf16x3", "philox", 8
+    assert isinstance(model.value_callable(emb, head), FusedEnformerValueNet)
+    outs = {}
+    for skip in (False, True):
+        model.skip_unchanged, model.trace, model.skip_stats = skip, [], ({} if skip else None)
+        x = model.controlled_sample(emb, head, num_steps=S, eval_sp_size=B, sample_M=M).cpu().numpy()
+        tr = [(lg.cpu().numpy(), None if sc is None else sc.cpu().numpy()) for lg, sc in model.trace]
+        outs[skip] = (x, tr, model.skip_stats)
+    model.precision, model.skip_unchanged, model.trace, model.skip_stats, model.rng_mode = "f32", True, None, None, "replay"
+    x_on, tr_on, st = outs[True]
+    assert st["kind"] == "mc" and st["live_candidates"] < st["candidates"]
+    assert np.array_equal(x_on, orc.replay_controlled_sample(tr_on, sched, B, L, M, seed=8))
+    assert np.array_equal(x_on, outs[False][0])
+    for (la, sa), (lb, sb) in zip(tr_on, outs[False][1]):
+        assert np.array_equal(la, lb) and (sa is None or np.array_equal(sa, sb))
