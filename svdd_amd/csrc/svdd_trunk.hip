@@ -41,96 +41,129 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 
 struct GemmArgs {
   const bf16_t* a_hi; const bf16_t* a_lo;  // [rows][lda] operand planes; row 0 = logical row 0 (guard rows exist before / after)
-  const BV8* w;                            // packed weights [KB][N / 128][8 n-tiles][parts][64 lanes][8]
+  const BV8* w;                            // packed weights [KB = chunk * T + tap][N / 128][8 n-tiles][parts][64 lanes][8]
   const float* bias; const float* resid; float* out;
   int M, N, KB, cb, T, lda, ldo, act;
   const int* count; int rows_per_seq;
 };
 
-// One workgroup (4 waves) = a 128 x 128 output tile; wave (wm, wn) owns 64 x 64 = 4 x 4 MFMA tiles. Per K block (32 wide):
-// the 128 x 32 A tile (shifted by the block's tap) and the 32 x 128 W tile go through LDS; the next block's global loads
-// are in flight while this block's 48 (x3) MFMAs per wave run.
+// One workgroup (4 waves) = a 128 x 128 output tile; wave (wm, wn) owns 64 x 64 = 4 x 4 MFMA tiles. A stage = one K block
+// (32 wide): the 128 x 32 A tile (shifted by the block's tap) and the 32 x 128 W tile. FOUR stages are in flight: stage s is
+// read from one of two LDS buffers by the MFMAs, stage s + 1 moves from registers into the other buffer, the global loads of
+// stages s + 2 and s + 3 are outstanding — the A operand streams from HBM (GBs per layer) and one stage of MFMAs does not cover that latency
+// (first version: one LDS buffer, loads one stage ahead, two barriers per stage: 350 - 500 TFLOP/s on the MFMA).
+// K blocks are ordered channel chunk major, TAP MINOR: the T taps of a chunk read the same 64-byte column of A shifted by one
+// row each, T consecutive K blocks, so all but the first come from L1 / L2.
+// Workgroup -> tile: consecutive workgroup ids are dealt round-robin to the 8 XCDs (each with its own L2). The N / 128
+// column tiles of one row tile share the A operand, so they are given ids 8 apart: same XCD, back to back.
+// The MFMA takes the WEIGHT fragment as its A operand and the activation fragment as B (same registers either way), so a
+// lane's accumulator registers are 4 adjacent output columns of one row: 16-byte stores / residual loads in the epilogue.
 template <int NPARTS>
-__global__ __launch_bounds__(256, 3) void trunk_gemm_kernel(GemmArgs a) {
-  __shared__ __attribute__((aligned(16))) bf16_t sA[NPARTS][G_BM][G_AS];
-  __shared__ __attribute__((aligned(16))) BV8 sB[8][NPARTS][64];
+__global__ __launch_bounds__(256, 2) void trunk_gemm_kernel(GemmArgs a) {
+  __shared__ __attribute__((aligned(16))) bf16_t sA[2][NPARTS][G_BM][G_AS];
+  __shared__ __attribute__((aligned(16))) BV8 sB[2][8][NPARTS][64];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wm = w >> 1, wn = w & 1, j = lane & 15, g = lane >> 4;
   const int m_live = a.count ? min(a.M, *a.count * a.rows_per_seq) : a.M;
-  const int m0 = blockIdx.y * G_BM, nb = blockIdx.x;
+  const int NB = a.N / G_BN;
+  const int MB = (a.M + G_BM - 1) / G_BM;
+  const int lid = blockIdx.x;                               // XCD-aware tile order
+  const int grp = lid / (8 * NB), rem = lid - grp * 8 * NB; // 8 row tiles x NB column tiles per group
+  const int by = grp * 8 + (rem & 7), nb = rem >> 3;
+  if (by >= MB) return;
+  const int m0 = by * G_BM;
   if (m0 >= m_live) return;
   f32x4 acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) acc[i][nt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-  // staging registers: A: thread -> (row tid >> 1, 32-byte half tid & 1); W: 4 (x3) / 2 pieces of 16 B
+  // staging registers, two stages: A: thread -> (row tid >> 1, 32-byte half tid & 1); W: 2 NPARTS pieces of 16 B
   const int ar = tid >> 1, ah = tid & 1;
-  uint4 ra[NPARTS][2];
-  BV8 rb[2 * NPARTS];
-  const int NB = a.N / G_BN;
-  auto load = [&](int kb) {
-    const int t = kb / a.cb, c = kb - t * a.cb;
-    const int64_t row = (int64_t)m0 + ar + t - a.T / 2;
-    const size_t off = (size_t)(row * a.lda + 32 * c + 16 * ah);            // halves; guard rows make row = -2.. valid
-    ra[0][0] = *reinterpret_cast<const uint4*>(a.a_hi + off);
-    ra[0][1] = *reinterpret_cast<const uint4*>(a.a_hi + off + 8);
-    if constexpr (NPARTS == 2) {
-      ra[1][0] = *reinterpret_cast<const uint4*>(a.a_lo + off);
-      ra[1][1] = *reinterpret_cast<const uint4*>(a.a_lo + off + 8);
-    }
-    const BV8* src = a.w + ((size_t)kb * NB + nb) * (8 * NPARTS * 64);
-#pragma unroll
-    for (int q = 0; q < 2 * NPARTS; ++q) rb[q] = src[q * 256 + tid];
-  };
-  load(0);
-  for (int kb = 0; kb < a.KB; ++kb) {
-    __syncthreads();                                        // the previous block's fragments have been read
-#pragma unroll
-    for (int p = 0; p < NPARTS; ++p) {
-      *reinterpret_cast<uint4*>(&sA[p][ar][16 * ah]) = ra[p][0];
-      *reinterpret_cast<uint4*>(&sA[p][ar][16 * ah + 8]) = ra[p][1];
-    }
-#pragma unroll
-    for (int q = 0; q < 2 * NPARTS; ++q) (&sB[0][0][0])[q * 256 + tid] = rb[q];
-    __syncthreads();
-    if (kb + 1 < a.KB) load(kb + 1);
-    BV8 bf[4][NPARTS];
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-      for (int p = 0; p < NPARTS; ++p) bf[nt][p] = sB[4 * wn + nt][p][lane];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      BV8 af[NPARTS];
-#pragma unroll
-      for (int p = 0; p < NPARTS; ++p) af[p] = *reinterpret_cast<const BV8*>(&sA[p][64 * wm + 16 * i + j][8 * g]);
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
-        acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bf[nt][0], acc[i][nt], 0, 0, 0);
-        if constexpr (NPARTS == 2) {
-          acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bf[nt][1], acc[i][nt], 0, 0, 0);
-          acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bf[nt][0], acc[i][nt], 0, 0, 0);
-        }
-      }
-    }
+  uint4 ra0[NPARTS][2], ra1[NPARTS][2], ra2[NPARTS][2];      // three register sets: stage k waits in set k % 3
+  BV8 rb0[2 * NPARTS], rb1[2 * NPARTS], rb2[2 * NPARTS];
+#define TG_LOAD(KB_, RA, RB)                                                                                 \
+  { const int kb_ = (KB_);                                                                                   \
+    const int c_ = kb_ / a.T, t_ = kb_ - c_ * a.T;                                                           \
+    const int64_t row_ = (int64_t)m0 + ar + t_ - a.T / 2;                                                    \
+    const size_t off_ = (size_t)(row_ * a.lda + 32 * c_ + 16 * ah);                                          \
+    RA[0][0] = *reinterpret_cast<const uint4*>(a.a_hi + off_);                                               \
+    RA[0][1] = *reinterpret_cast<const uint4*>(a.a_hi + off_ + 8);                                           \
+    if constexpr (NPARTS == 2) {                                                                             \
+      RA[1][0] = *reinterpret_cast<const uint4*>(a.a_lo + off_);                                             \
+      RA[1][1] = *reinterpret_cast<const uint4*>(a.a_lo + off_ + 8);                                         \
+    }                                                                                                        \
+    const BV8* src_ = a.w + ((size_t)kb_ * NB + nb) * (8 * NPARTS * 64);                                     \
+    _Pragma("unroll") for (int q = 0; q < 2 * NPARTS; ++q) RB[q] = src_[q * 256 + tid]; }
+#define TG_STORE(BUF, RA, RB)                                                                                \
+  { _Pragma("unroll") for (int p = 0; p < NPARTS; ++p) {                                                     \
+      *reinterpret_cast<uint4*>(&sA[BUF][p][ar][16 * ah]) = RA[p][0];                                        \
+      *reinterpret_cast<uint4*>(&sA[BUF][p][ar][16 * ah + 8]) = RA[p][1]; }                                  \
+    _Pragma("unroll") for (int q = 0; q < 2 * NPARTS; ++q) (&sB[BUF][0][0][0])[q * 256 + tid] = RB[q]; }
+  // the three passes of a product go to the same accumulator: a whole row of tiles (4 independent accumulators) between
+  // dependent MFMAs
+#define TG_COMPUTE(BUF)                                                                                      \
+  { BV8 bf[4][NPARTS], af[4][NPARTS];                                                                        \
+    _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                         \
+      _Pragma("unroll") for (int p = 0; p < NPARTS; ++p) bf[nt][p] = sB[BUF][4 * wn + nt][p][lane];          \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                            \
+      _Pragma("unroll") for (int p = 0; p < NPARTS; ++p)                                                     \
+        af[i][p] = *reinterpret_cast<const BV8*>(&sA[BUF][p][64 * wm + 16 * i + j][8 * g]);                  \
+    __builtin_amdgcn_sched_barrier(0);          /* every fragment of the stage is requested before the first MFMA */ \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                          \
+      _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                       \
+        acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[nt][0], af[i][0], acc[i][nt], 0, 0, 0);      \
+      if constexpr (NPARTS == 2) {                                                                           \
+        _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                     \
+          acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[nt][1], af[i][0], acc[i][nt], 0, 0, 0);    \
+        _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                     \
+          acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[nt][0], af[i][1], acc[i][nt], 0, 0, 0);    \
+      } } }
+  const int KB = a.KB;
+  TG_LOAD(0, ra0, rb0)
+  if (KB > 1) TG_LOAD(1, ra1, rb1)
+  if (KB > 2) TG_LOAD(2, ra2, rb2)
+  TG_STORE(0, ra0, rb0)
+  if (KB > 3) TG_LOAD(3, ra0, rb0)
+  __syncthreads();
+  // iteration s: MFMAs on stage s (LDS buffer s & 1); stage s + 1 moves from its register set into the other buffer;
+  // that set is refilled with stage s + 4: four stages in flight, one barrier per stage
+#define TG_ITER(S, BUF, RA, RB)                                                                              \
+  if ((S) < KB) {                                                                                            \
+    TG_COMPUTE(BUF)                                                                                          \
+    if ((S) + 1 < KB) TG_STORE(1 - (BUF), RA, RB)                                                            \
+    if ((S) + 4 < KB) TG_LOAD((S) + 4, RA, RB)                                                               \
+    __syncthreads();                                                                                         \
   }
-  // epilogue: lane (j, g) holds column j, rows 4 g + e of every tile
+  for (int s = 0; s < KB; s += 6) {
+    TG_ITER(s, 0, ra1, rb1)
+    TG_ITER(s + 1, 1, ra2, rb2)
+    TG_ITER(s + 2, 0, ra0, rb0)
+    TG_ITER(s + 3, 1, ra1, rb1)
+    TG_ITER(s + 4, 0, ra2, rb2)
+    TG_ITER(s + 5, 1, ra0, rb0)
+  }
+#undef TG_ITER
+#undef TG_COMPUTE
+#undef TG_STORE
+#undef TG_LOAD
+  // epilogue: lane (j, g) holds row 16 i + j, columns 16 nt + 4 g .. + 3 of every tile
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) {
-    const int col = nb * G_BN + 64 * wn + 16 * nt + j;
-    const float b = a.bias ? a.bias[col] : 0.0f;
+    const int col = nb * G_BN + 64 * wn + 16 * nt + 4 * g;
+    f32x4 b4 = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (a.bias) b4 = *reinterpret_cast<const f32x4*>(a.bias + col);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i) {
+      const int row = m0 + 64 * wm + 16 * i + j;
+      if (row < m_live) {
+        f32x4 v = acc[i][nt] + b4;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int row = m0 + 64 * wm + 16 * i + 4 * g + e;
-        if (row < m_live) {
-          float v = apply_act(acc[i][nt][e] + b, a.act);
-          if (a.resid) v += a.resid[(size_t)row * a.ldo + col];
-          a.out[(size_t)row * a.ldo + col] = v;
-        }
+        for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], a.act);
+        if (a.resid) v += *reinterpret_cast<const f32x4*>(a.resid + (size_t)row * a.ldo + col);
+        *reinterpret_cast<f32x4*>(a.out + (size_t)row * a.ldo + col) = v;
       }
+    }
   }
 }
 
@@ -289,7 +322,8 @@ int svdd_trunk_gemm(const void* a_hi, const void* a_lo, const void* w, const flo
     return SVDD_E_ARG;
   GemmArgs a{(const bf16_t*)a_hi, (const bf16_t*)a_lo, (const BV8*)w, bias, resid, out, M, N, T * (Cin / G_BK), Cin / G_BK, T,
              lda, ldo, act, count, rows_per_seq};
-  const dim3 grid((unsigned)(N / G_BN), (unsigned)((M + G_BM - 1) / G_BM));
+  const int mb = (M + G_BM - 1) / G_BM;
+  const dim3 grid((unsigned)(((mb + 7) / 8) * 8 * (N / G_BN)));         // groups of 8 row tiles x N / 128 column tiles
   if (a_lo) hipLaunchKernelGGL(trunk_gemm_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(trunk_gemm_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a);
   return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;

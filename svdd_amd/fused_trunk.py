@@ -43,7 +43,7 @@ def _stream():
 def pack_gemm_weight(w, parts):
     """Conv1d / Linear weight [N, Cin, T] (or [N, Cin]) fp32 -> bf16 fragments for svdd_trunk_gemm:
     [KB = T * Cin/32][N/128][8 n-tiles][parts][64 lanes = 16 g + j][8 e] = part(W[128 nb + 16 nt + j][32 c + 8 g + e][t]),
-    kb = t * (Cin / 32) + c ; part 0 = bf16(W), part 1 = bf16(W - part 0)."""
+    kb = c * T + t (chunk major, tap minor) ; part 0 = bf16(W), part 1 = bf16(W - part 0)."""
     if w.dim() == 2:
         w = w[:, :, None]
     N, Cin, T = w.shape
@@ -52,7 +52,7 @@ def pack_gemm_weight(w, parts):
     hi = w.to(torch.bfloat16)
     ps = [hi] if parts == 1 else [hi, (w - hi.float()).to(torch.bfloat16)]
     v = torch.stack(ps, dim=0).reshape(parts, N // 128, 8, 16, Cin // 32, 4, 8, T)     # [p][nb][nt][j][c][g][e][t]
-    return v.permute(7, 4, 1, 2, 0, 5, 3, 6).contiguous().reshape(-1)                  # [t][c][nb][nt][p][g][j][e]
+    return v.permute(4, 7, 1, 2, 0, 5, 3, 6).contiguous().reshape(-1)                  # [c][t][nb][nt][p][g][j][e]
 
 
 class _Planes:
@@ -130,9 +130,20 @@ class FusedEnformerValueNet(nn.Module):
             self.head_w = hw.weight.detach().float()[:, :, 0].t().contiguous()        # [3072, n_tasks]
             self.head_b = hw.bias.detach().float()
         self._relk = {}
+        self.timing = None
 
     # ------------------------------------------------------------------ thin kernel wrappers
     def _gemm(self, planes, w, bias, resid, out, M, N, Cin, T, act, count, rps):
+        if self.timing is not None:                                # tools/trunk_microbench.py --gemms: per-launch events
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self._gemm_launch(planes, w, bias, resid, out, M, N, Cin, T, act, count, rps)
+            e1.record()
+            self.timing.append((M, N, Cin, T, e0, e1))
+            return
+        self._gemm_launch(planes, w, bias, resid, out, M, N, Cin, T, act, count, rps)
+
+    def _gemm_launch(self, planes, w, bias, resid, out, M, N, Cin, T, act, count, rps):
         rc = _lib.lib().svdd_trunk_gemm(planes[0].data_ptr(), planes[1].data_ptr() if len(planes) > 1 else None, w.data_ptr(),
                                         _ptr(bias), _ptr(resid), out.data_ptr(), M, N, Cin, T, Cin, N, act, _ptr(count), rps, _stream())
         _lib.check(rc, "svdd_trunk_gemm")

@@ -1,0 +1,55 @@
+"""The fused Enformer-shaped value trunk (svdd_amd/fused_trunk.py) at the BASELINE configs[3] shard size: time per forward
+against the PyTorch module.  Usage: python tools/trunk_microbench.py [n] [precision] [--module]
+(run under `rocprofv3 --kernel-trace --stats` for the per-kernel split)"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from svdd_amd import synthetic
+from svdd_amd.fused_trunk import FusedEnformerValueNet
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 5120
+prec = sys.argv[2] if len(sys.argv) > 2 else "bf16x3"
+dev = "cuda:0"
+_, emb, head, _ = synthetic.build("dna", dev, value="enformer")
+tok = torch.randint(0, 5, (n, 200), device=dev, dtype=torch.uint8)
+fn = FusedEnformerValueNet(emb, head, prec)
+
+
+def bench(f, it=3):
+    f(); torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(it):
+        f()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t) / it * 1e3
+
+
+fl = emb.flops_per_sequence() * n
+ms = bench(lambda: fn.forward_tokens(tok))
+print(f"fused trunk {prec} n={n}: {ms:.1f} ms  = {fl / ms / 1e9:.1f} TFLOP/s fp32-equivalent ({fl / 1e12:.2f} TFLOP per forward)")
+if "--module" in sys.argv:
+    oh = (torch.nn.functional.one_hot(tok.long().clamp(max=3), 4) * (tok != 4)[..., None]).float()
+    with torch.no_grad():
+        ms = bench(lambda: head(emb(oh)), it=2)
+    print(f"PyTorch module fp32 n={n}: {ms:.1f} ms  = {fl / ms / 1e9:.1f} TFLOP/s")
+
+if "--gemms" in sys.argv:
+    fn.timing = []
+    fn.forward_tokens(tok)
+    torch.cuda.synchronize()
+    agg = {}
+    for M, N, C, T, e0, e1 in fn.timing:
+        k = (M, N, C, T)
+        a = agg.setdefault(k, [0, 0.0])
+        a[0] += 1
+        a[1] += e0.elapsed_time(e1)
+    tot = 0.0
+    passes = 3 if prec == "bf16x3" else 1
+    for (M, N, C, T), (cnt, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        fl = 2.0 * M * N * C * T * cnt
+        tot += ms
+        print(f"  M={M:8d} N={N:5d} Cin={C:5d} T={T}  x{cnt:3d}  {ms:8.2f} ms  {fl / ms / 1e9:8.1f} TFLOP/s fp32-equiv  ({fl * passes / ms / 1e9:7.1f} on the MFMA)")
+    print(f"  all GEMMs: {tot:.1f} ms")
