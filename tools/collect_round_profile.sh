@@ -2,11 +2,11 @@
 # Collects the judged evidence of a round on the GPU box into gpurun_out/<tag>_*:
 #   bench JSON line, rocprofv3 --kernel-trace --stats summary of the same command, per-kernel trace summary of our
 #   kernels, and FETCH_SIZE / WRITE_SIZE PMC passes (separate runs, --kernel-trace only) for the roofline kernels.
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=/root/repo/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-OURS="backbone_kernel backbone_lp_kernel conv_tower tower_lp gru_bidir gru_lp value_tail tail_lp candidate_windows compact_flags propose_kernel select_kernel transform advance_rows gather_rows x0hat epilogue_ln conv1d_cl"
+OURS="backbone_kernel backbone_lp_kernel backbone_lp_t_kernel conv_tower tower_lp gru_bidir gru_pc gru_lp value_tail tail_lp candidate_windows compact_flags propose_kernel select_kernel select_rows_kernel tds_cdf tds_gather transform advance_rows gather_rows x0hat epilogue_ln conv1d_cl"
 python3 /root/repo/bench.py --steps 3 --warmup 1 2>/dev/null | tail -1 > $OUT/${TAG}_bench.json
 rm -rf /tmp/prof_$TAG
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o $TAG -- python3 /root/repo/bench.py --steps 2 --warmup 1 --cpu-steps 0 > /tmp/prof_$TAG.log 2>&1
@@ -15,16 +15,45 @@ python3 /root/repo/tools/trace_summary.py $(find /tmp/prof_$TAG -name "*kernel_t
 : > $OUT/${TAG}_pmc.txt
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -- python3 /root/repo/bench.py --steps 1 --warmup 0 --cpu-steps 0 --alt-precision f16x3 --alt-steps 1 > /tmp/pmc_$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -- python3 /root/repo/bench.py --steps 1 --warmup 0 --cpu-steps 0 --alt-precision f16x3,bf16x3,bf16 --alt-steps 1 > /tmp/pmc_$c.log 2>&1
   python3 - $(find /tmp/pmc_$c -name "*counter_collection.csv" | head -1) $c >> $OUT/${TAG}_pmc.txt <<'PY'
 import csv, sys, collections
 agg = collections.defaultdict(list)
 for r in csv.DictReader(open(sys.argv[1])):
     n = r["Kernel_Name"]
-    if any(p in n for p in ("backbone_kernel", "backbone_lp_kernel", "propose_kernel", "conv_tower", "tower_lp", "gru_bidir", "gru_lp", "value_tail", "tail_lp")):
+    if any(p in n for p in ("backbone_kernel", "backbone_lp_kernel", "backbone_lp_t_kernel", "propose_kernel", "select_rows_kernel", "conv_tower", "tower_lp", "gru_bidir", "gru_lp", "value_tail", "tail_lp")):
         agg[(n[:90], r["Grid_Size_X"] if "Grid_Size_X" in r else "")].append(float(r["Counter_Value"]))
 for k, v in sorted(agg.items()):
     print("%s per dispatch (KB) %-92s grid=%-8s n=%d mean=%.3f min=%.3f max=%.3f" % (sys.argv[2], k[0], k[1], len(v), sum(v) / len(v), min(v), max(v)))
 PY
 done
+# HBM bytes per launch of the roofline kernels -> ${TAG}_pmc.json (read by bench.py; FETCH_SIZE x 2: MI355X_MICROARCH.md, HBM section)
+python3 - $OUT/${TAG}_pmc.txt $OUT/${TAG}_pmc.json $TAG <<'PY'
+import json, re, sys
+rows = {}
+for ln in open(sys.argv[1]):
+    m = re.match(r"(FETCH_SIZE|WRITE_SIZE) per dispatch \(KB\) (.*?)\s+grid=\s*\S*\s+n=(\d+) mean=([\d.]+) min=([\d.]+)", ln)
+    if m:
+        rows.setdefault(m.group(2).strip(), {})[m.group(1)] = (float(m.group(4)), float(m.group(5)), int(m.group(3)))
+def traffic(pat, use_min=False):
+    for name, d in rows.items():
+        if re.search(pat, name) and "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+            k = 1 if use_min else 0
+            return int(2 * d["FETCH_SIZE"][k] * 1024 + d["WRITE_SIZE"][k] * 1024), name, d
+    return None, None, None
+out = {"how": "two separate passes per counter (tools/collect_round_profile.sh %s): rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace "
+              "--output-format csv -- python3 bench.py --steps 1 --warmup 0 --cpu-steps 0 --alt-precision f16x3,bf16x3,bf16 --alt-steps 1 ; "
+              "per-dispatch means in profiles/%s_pmc.txt (rocprofv3 reports KB)" % (sys.argv[3], sys.argv[3]),
+       "fetch_correction": "x2: on gfx950 FETCH_SIZE tallies 128-B requests as 64 B for wide coalesced streams (MI355X_MICROARCH.md, HBM section)"}
+t, name, d = traffic(r"backbone_kernel<true>")
+if t: out["backbone_traffic_bytes_per_launch"] = t; out["backbone"] = {"kernel": name, "FETCH_SIZE_KB": d["FETCH_SIZE"][0], "WRITE_SIZE_KB": d["WRITE_SIZE"][0], "algorithmic_bytes_per_launch": 14405104}
+t, name, d = traffic(r"propose_kernel<false, false>", use_min=True)
+if t: out["k1_traffic_bytes_per_launch"] = t; out["k1"] = {"kernel": name + " (min over the dispatches: the list also holds bench.py's saturated launches)", "FETCH_SIZE_KB": d["FETCH_SIZE"][1], "WRITE_SIZE_KB": d["WRITE_SIZE"][1], "algorithmic_bytes_per_launch": 9779200}
+lp = {}
+for mode, pat in (("f16x3", r"backbone_lp_t_kernelIDF16_Li3E"), ("bf16x3", r"backbone_lp_t_kernelIDF16bLi3E"), ("bf16", r"backbone_lp_t_kernelIDF16bLi1E|backbone_lp_t_kernel<bool _Accum")):
+    t, name, d = traffic(pat)
+    if t: lp[mode] = t; out["backbone_lp_" + mode] = {"kernel": name, "FETCH_SIZE_KB": d["FETCH_SIZE"][0], "WRITE_SIZE_KB": d["WRITE_SIZE"][0]}
+out["backbone_lp_traffic_bytes_per_launch"] = lp
+json.dump(out, open(sys.argv[2], "w"), indent=1)
+PY
 cat $OUT/${TAG}_bench.json | cut -c1-400; cat $OUT/${TAG}_pmc.txt; cat $OUT/${TAG}_own_kernels_trace_summary.txt
