@@ -1,9 +1,11 @@
 """DiT masked-diffusion backbone (reference `models/dit.py:324-370`) as a PyTorch-ROCm module.
 
 In the reference snapshot this backbone is dead code (`models/__init__.py:1` comments the import out and
-it needs the CUDA-only `flash_attn`), so no reference output exists to pin it against: **parity unpinned**.
-It is provided because BASELINE.json's north star names it: same layer structure and parameter names as the
-reference `DIT` (so its checkpoints would load), with
+it needs the CUDA-only `flash_attn`). It is pinned against the reference's own `models/dit.py` run on CPU with a
+plain matmul-softmax / rotate-half STAND-IN for flash_attn's two entry points (`tests/golden/make_golden.py`
+`install_flash_attn_standin`, fixture `g16_dit.npz`, `tests/test_nets_cpu.py::test_dit_equals_reference_fixture`):
+**pinned up to that stand-in**. Same layer structure, parameter AND buffer names as the reference `DIT` (its
+state_dict loads with strict=True), with
   * attention through `F.scaled_dot_product_attention` (ROCm's fused kernels; the GEMMs are where MFMA is used),
   * rotary embeddings applied to q and k in the non-interleaved ("rotate-half") convention of
     `flash_attn.layers.rotary.apply_rotary_emb_qkv_` (`models/dit.py:111-115`),
@@ -68,11 +70,18 @@ class EmbeddingLayer(nn.Module):
         return self.embedding[x]
 
 
-def _rotary(q, k, base=10000.0):
+class Rotary(nn.Module):
+    """Holds the reference's `rotary_emb.inv_freq` buffer (models/dit.py:81-85) so that checkpoints load strictly."""
+
+    def __init__(self, dim, base=10000.0):
+        super().__init__()
+        self.register_buffer("inv_freq", 1.0 / (base ** (torch.arange(0, dim, 2).float() / dim)))
+
+
+def _rotary(q, k, inv_freq):
     """q, k: [B, H, L, D]. Non-interleaved rotary: (x1, x2) halves -> (x1 cos - x2 sin, x1 sin + x2 cos)."""
     d, length = q.shape[-1], q.shape[-2]
-    inv_freq = 1.0 / (base ** (torch.arange(0, d, 2, device=q.device, dtype=torch.float32) / d))
-    ang = torch.arange(length, device=q.device, dtype=torch.float32)[:, None] * inv_freq[None]
+    ang = torch.arange(length, device=q.device, dtype=torch.float32)[:, None] * inv_freq[None].float()
     cos, sin = ang.cos().to(q.dtype), ang.sin().to(q.dtype)
 
     def rot(x):
@@ -97,12 +106,12 @@ class DDiTBlock(nn.Module):
         nn.init.zeros_(self.adaLN_modulation.weight)
         nn.init.zeros_(self.adaLN_modulation.bias)
 
-    def forward(self, x, c):
+    def forward(self, x, c, inv_freq):
         B, L, D = x.shape
         shift_a, scale_a, gate_a, shift_m, scale_m, gate_m = self.adaLN_modulation(c)[:, None].chunk(6, dim=2)
         h = self.norm1(x) * (1 + scale_a) + shift_a
         q, k, v = self.attn_qkv(h).view(B, L, 3, self.n_heads, D // self.n_heads).permute(2, 0, 3, 1, 4)
-        q, k = _rotary(q, k)
+        q, k = _rotary(q, k, inv_freq)
         a = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B, L, D)
         x = x + gate_a * self.dropout(self.attn_out(a))
         h = self.norm2(x) * (1 + scale_m) + shift_m
@@ -131,6 +140,7 @@ class DIT(nn.Module):
         self.vocab_size = vocab_size
         self.vocab_embed = EmbeddingLayer(m.hidden_size, vocab_size)
         self.sigma_map = TimestepEmbedder(m.cond_dim)
+        self.rotary_emb = Rotary(m.hidden_size // m.n_heads)
         self.blocks = nn.ModuleList([DDiTBlock(m.hidden_size, m.n_heads, m.cond_dim, dropout=m.dropout)
                                      for _ in range(m.n_blocks)])
         self.output_layer = DDitFinalLayer(m.hidden_size, vocab_size, m.cond_dim)
@@ -142,6 +152,6 @@ class DIT(nn.Module):
         c = F.silu(self.sigma_map(sigma))
         with torch.autocast(device_type=x.device.type, dtype=torch.bfloat16, enabled=self.autocast_bf16):
             for blk in self.blocks:
-                x = blk(x, c)
+                x = blk(x, c, self.rotary_emb.inv_freq)
             x = self.output_layer(x, c)
         return x.float()

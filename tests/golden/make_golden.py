@@ -25,6 +25,10 @@ outputs are stored. Fixtures:
                               :1414), i.e. the heuristic branch :1420-1424, tiny nets, S=8, B=3, L=50, M=3
   g15_step_mc_m10.npz / _m20  one _ddpm_update_finetune_controlled step at the widths the reference is run with (M=10
                               default, M=20 in BASELINE configs[3]) with adversarial ties: pins softmax/argmax over M
+  g16_dit.npz                 the reference's models/dit.py DIT (hidden 32, 2 blocks, 2 heads, cond 16; zero-initialised adaLN /
+                              output maps re-drawn so that every path carries signal) on B=3, L=24 tokens with non-zero sigma:
+                              state_dict, indices, sigma, logits. flash_attn (CUDA-only, absent) is replaced by a plain
+                              matmul-softmax / rotate-half STAND-IN of its two entry points: pinned up to that stand-in
   g12_fullsize_probe.npz      FULL-SIZE reference nets (CNNModel hidden 128 x 4 stacks; ConvGRUTrunk 64 ch, n_conv 6 +
                               ConvHead) built at torch.manual_seed(44) in the order svdd_amd/synthetic.py builds them,
                               evaluated on 4 probe rows: logits, value scores, a checksum of every parameter tensor
@@ -556,6 +560,80 @@ def g15_step(d, M):
          dm=(mct - mcs), q_xs=q_xs, cand=cand.to(torch.uint8), soft=soft, idx=idx, x_next=x_next)
 
 
+# ----------------------------------------------------------------------------- G16 (DiT)
+def install_flash_attn_standin():
+    """models/dit.py:4-5 imports the CUDA-only flash_attn and uses two of its entry points (:115, :272). Stand-ins with the
+    published semantics of flash-attn 2.x, in plain fp32 torch ops (no fused kernel):
+      layers.rotary.apply_rotary_emb_qkv_(qkv[b,s,3,h,d], cos[s,d/2], sin[s,d/2])  non-interleaved rotary on q and k, in place
+      flash_attn_interface.flash_attn_varlen_qkvpacked_func(qkv[(b s),3,h,d], cu_seqlens, max_seqlen, p, causal=False)
+                                                                                 softmax(q k^T / sqrt(d)) v per sequence"""
+    import importlib.machinery
+    import types
+
+    def mod(name):
+        m = types.ModuleType(name)
+        m.__spec__ = importlib.machinery.ModuleSpec(name, None)
+        m.__path__ = []
+        sys.modules[name] = m
+        return m
+
+    def apply_rotary_emb_qkv_(qkv, cos, sin):
+        half = cos.shape[-1]
+        c, s_ = cos[None, :, None, :], sin[None, :, None, :]
+        for i in (0, 1):
+            x1, x2 = qkv[:, :, i, :, :half].clone(), qkv[:, :, i, :, half:2 * half].clone()
+            qkv[:, :, i, :, :half] = x1 * c - x2 * s_
+            qkv[:, :, i, :, half:2 * half] = x1 * s_ + x2 * c
+        return qkv
+
+    def flash_attn_varlen_qkvpacked_func(qkv, cu_seqlens, max_seqlen, dropout_p=0.0, softmax_scale=None, causal=False):
+        assert dropout_p == 0.0 and not causal
+        out = torch.empty_like(qkv[:, 0])
+        scale = softmax_scale if softmax_scale is not None else qkv.shape[-1] ** -0.5
+        cu = cu_seqlens.tolist()
+        for a, b in zip(cu[:-1], cu[1:]):
+            q, k, v = (qkv[a:b, i].transpose(0, 1) for i in range(3))            # [h, s, d]
+            out[a:b] = (torch.softmax(q @ k.transpose(1, 2) * scale, dim=-1) @ v).transpose(0, 1)
+        return out
+
+    fa = mod("flash_attn")
+    fa.layers = mod("flash_attn.layers")
+    fa.layers.rotary = mod("flash_attn.layers.rotary")
+    fa.layers.rotary.apply_rotary_emb_qkv_ = apply_rotary_emb_qkv_
+    fa.flash_attn_interface = mod("flash_attn.flash_attn_interface")
+    fa.flash_attn_interface.flash_attn_varlen_qkvpacked_func = flash_attn_varlen_qkvpacked_func
+    if "omegaconf" not in sys.modules:
+        try:
+            import omegaconf  # noqa: F401
+        except ImportError:
+            mod("omegaconf").OmegaConf = type("OmegaConf", (), {"create": staticmethod(lambda d: d)})
+
+
+def g16_dit(seed=61):
+    install_flash_attn_standin()
+    import importlib
+    dit = importlib.import_module("models.dit")            # /root/reference/models/dit.py, imported where it lies
+    from _ref_import import Cfg
+    hp = dict(hidden_size=32, cond_dim=16, n_blocks=2, n_heads=2, dropout=0.0, scale_by_sigma=True, length=24)
+    torch.manual_seed(seed)
+    m = dit.DIT(Cfg(model=hp), vocab_size=5).eval()
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():                                  # adaLN-zero / zero output map: re-draw, or the logits are all 0
+        for mod_ in list(m.blocks) + [m.output_layer]:
+            mod_.adaLN_modulation.weight.copy_(torch.randn(mod_.adaLN_modulation.weight.shape, generator=g) * 0.2)
+            mod_.adaLN_modulation.bias.copy_(torch.randn(mod_.adaLN_modulation.bias.shape, generator=g) * 0.2)
+        m.output_layer.linear.weight.copy_(torch.randn(m.output_layer.linear.weight.shape, generator=g) * 0.3)
+        m.output_layer.linear.bias.copy_(torch.randn(5, generator=g) * 0.1)
+    idx = torch.randint(0, 5, (3, hp["length"]), generator=g)
+    sigma = torch.tensor([0.0, 0.37, 2.5])
+    with torch.no_grad():
+        logits = m(idx, sigma).float()
+        logits0 = m(idx, torch.zeros(3)).float()           # what the sampler feeds with time_conditioning off
+    assert float(logits.abs().max()) > 0.1
+    save("g16_dit.npz", indices=idx.to(torch.uint8), sigma=sigma, logits=logits, logits_sigma0=logits0,
+         hp=np.array([hp["hidden_size"], hp["cond_dim"], hp["n_blocks"], hp["n_heads"], hp["length"]]), **sd_np("dit", m))
+
+
 def new_round3():
     g13_traj_mc_full("g13_traj_mc_full_c1.npz", S=128, B=4, M=2, seed=0)
     g13_traj_mc_full("g13_traj_mc_full_m10.npz", S=32, B=4, M=10, seed=2)
@@ -563,11 +641,15 @@ def new_round3():
     d = tiny_diffusion(200, 128)
     g15_step(d, 10)
     g15_step(d, 20)
+    g16_dit()
 
 
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "g12":
         g12_fullsize_probe()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "g16":
+        g16_dit()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "r3":
         new_round3()

@@ -276,6 +276,23 @@ def test_mc_decode_with_dit_backbone(small_nets):
         assert np.array_equal(x_gpu, x_orc)
 
 
+def test_dit_on_the_gpu_equals_reference_fixture():
+    """g16 (the reference's models/dit.py on CPU with the flash_attn stand-in, see tests/test_nets_cpu.py) through ROCm's
+    fused SDPA on the device: logits within 1e-4, fp32."""
+    import os
+    from svdd_amd import dit as D
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g16_dit.npz"))
+    hs, cd, nb, nh, L = (int(v) for v in g["hp"])
+    m = D.DIT(D.DiTModelConfig(hidden_size=hs, cond_dim=cd, n_blocks=nb, n_heads=nh, dropout=0.0, length=L), vocab_size=5)
+    m.load_state_dict({k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("dit.")}, strict=True)
+    m = m.to(DEV).eval()
+    idx = torch.from_numpy(g["indices"]).to(DEV)
+    with torch.no_grad():
+        out = m(idx, torch.from_numpy(g["sigma"]).to(DEV)).cpu().numpy()
+        out0 = m(idx, torch.zeros(idx.shape[0], device=DEV)).cpu().numpy()
+    assert np.abs(out - g["logits"]).max() <= 1e-4 and np.abs(out0 - g["logits_sigma0"]).max() <= 1e-4
+
+
 def test_fused_net_cache_follows_weight_changes():
     """The fused formulations hold re-packed COPIES of the weights, keyed on weak references to the modules plus a weight
     fingerprint (data pointer, in-place version): training the value function between decodes, load_state_dict, or a new

@@ -101,7 +101,7 @@ def test_enformer_shaped_value_trunk():
 
 
 def test_dit_backbone_structure():
-    """DiT backbone (dead code in the reference: parity unpinned). Checks the reference's parameter names, the
+    """DiT backbone (dead code in the reference; pinned by g16 in the test below). Checks the reference's parameter names, the
     adaLN-zero init (zero logits at init, like the reference's zero-initialised final layer), and the attention
     block against an explicit softmax formulation."""
     from svdd_amd.config import dit_config
@@ -129,12 +129,35 @@ def test_dit_backbone_structure():
         sa, sc, ga, _, _, _ = blk.adaLN_modulation(c)[:, None].chunk(6, dim=2)
         h = blk.norm1(h0) * (1 + sc) + sa
         q, k, v = blk.attn_qkv(h).view(3, 50, 3, 4, 16).permute(2, 0, 3, 1, 4)
-        q, k = D._rotary(q, k)
+        q, k = D._rotary(q, k, d.backbone.rotary_emb.inv_freq)
         att = torch.softmax(q @ k.transpose(-1, -2) / 4.0, -1) @ v
         ref = h0 + ga * blk.attn_out(att.transpose(1, 2).reshape(3, 50, 64))
         mid = h0 + ga * blk.attn_out(torch.nn.functional.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(3, 50, 64))
     assert torch.allclose(ref, mid, atol=1e-5) and torch.isfinite(out).all() and float(out.abs().max()) > 0
     # rotary: position 0 is unrotated, norms are preserved
     qq = torch.randn(1, 2, 7, 16)
-    r, _ = D._rotary(qq, qq)
+    r, _ = D._rotary(qq, qq, D.Rotary(16).inv_freq)
     assert torch.allclose(r[:, :, 0], qq[:, :, 0]) and torch.allclose(r.norm(dim=-1), qq.norm(dim=-1), atol=1e-5)
+
+
+def test_dit_equals_reference_fixture():
+    """g16: the reference's own models/dit.py (`/root/reference/models/dit.py:214-369`) run on CPU by make_golden.py, with
+    flash_attn's two entry points (:115 rotary, :272 varlen attention) replaced by a plain matmul-softmax / rotate-half
+    stand-in — pinned up to that stand-in. The reference state_dict must load with strict=True (parameter AND buffer names),
+    and the logits must agree for non-zero sigma (time conditioning) and for the zero sigma the sampler feeds."""
+    import os
+    import numpy as np
+    from svdd_amd import dit as D
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g16_dit.npz"))
+    hs, cd, nb, nh, L = (int(v) for v in g["hp"])
+    m = D.DIT(D.DiTModelConfig(hidden_size=hs, cond_dim=cd, n_blocks=nb, n_heads=nh, dropout=0.0, length=L), vocab_size=5).eval()
+    sd = {k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("dit.")}
+    m.load_state_dict(sd, strict=True)
+    idx = torch.from_numpy(g["indices"])
+    with torch.no_grad():
+        out = m(idx, torch.from_numpy(g["sigma"]))
+        out0 = m(idx, torch.zeros(idx.shape[0]))
+    assert out.shape == g["logits"].shape
+    assert float(np.abs(g["logits"]).max()) > 0.1
+    assert float((out - torch.from_numpy(g["logits"])).abs().max()) <= 2e-5
+    assert float((out0 - torch.from_numpy(g["logits_sigma0"])).abs().max()) <= 2e-5
