@@ -5,7 +5,9 @@
 Why self-contained: the reference builds this trunk from `enformer_pytorch` (lucidrains), an un-vendored,
 un-pinned dependency that is absent offline (`Enformer.py:8-9`) — its `Attention`,
 `AttentionPool`, `GELU`, `relative_shift`, `exponential_linspace_int` cannot be imported, so there is no
-reference output to pin against: **parity unpinned** for this module. It follows the layer structure of the
+reference output for the attention math: **parity unpinned** for it. The WIRING is pinned: the reference's own classes run
+with these restatements bound to the five missing names reproduce this module (fixture g17, `tests/test_nets_cpu.py`).
+It follows the layer structure of the
 reference wrapper (`Enformer.py:1271-1334` trunk, `:1807-1884` conv tower, `:1887-2007` transformer tower,
 `:2176-2292` ConvBlock order "NACDR") and the published Enformer design (Avsec et al. 2021: attention pooling,
 relative positional attention with exponential / central-mask / gamma basis functions). To the SVDD hot path

@@ -29,6 +29,11 @@ outputs are stored. Fixtures:
                               output maps re-drawn so that every path carries signal) on B=3, L=24 tokens with non-zero sigma:
                               state_dict, indices, sigma, logits. flash_attn (CUDA-only, absent) is replaced by a plain
                               matmul-softmax / rotate-half STAND-IN of its two entry points: pinned up to that stand-in
+  g17_enformer_trunk.npz      the reference's Enformer.py EnformerTrunk + ConvHead (n_conv=3, channels=384, 2 transformer blocks, 2
+                              heads, key_len=16) on B=3, L=40 one-hot rows. enformer_pytorch (absent, unpinned) is replaced by a
+                              STAND-IN = this repo's restatement of its five symbols (svdd_amd/enformer_value.py), so the fixture
+                              pins the reference's OWN wiring (conv tower, block order NACDR, residuals, transformer block,
+                              feed-forward, pointwise, head) and not the attention math: pinned up to that stand-in
   g12_fullsize_probe.npz      FULL-SIZE reference nets (CNNModel hidden 128 x 4 stacks; ConvGRUTrunk 64 ch, n_conv 6 +
                               ConvHead) built at torch.manual_seed(44) in the order svdd_amd/synthetic.py builds them,
                               evaluated on 4 probe rows: logits, value scores, a checksum of every parameter tensor
@@ -634,6 +639,46 @@ def g16_dit(seed=61):
          hp=np.array([hp["hidden_size"], hp["cond_dim"], hp["n_blocks"], hp["n_heads"], hp["length"]]), **sd_np("dit", m))
 
 
+# ----------------------------------------------------------------------------- G17 (Enformer-shaped trunk)
+def g17_enformer_trunk(seed=71):
+    """Enformer.py:8-9 imports GELU, AttentionPool, relative_shift, Attention, exponential_linspace_int from enformer_pytorch
+    (absent offline, version unpinned). The reference module was imported with those names stubbed to None; here they are
+    bound to adapters over svdd_amd.enformer_value's restatements and the reference's EnformerTrunk / ConvHead are run as
+    they are."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from svdd_amd import enformer_value as ev
+
+    class Attention(ev.RelPosAttention):
+        def __init__(self, dim, heads, dim_key, dim_value, dropout=0.0, pos_dropout=0.0, num_rel_pos_features=None,
+                     use_tf_gamma=False):
+            assert not use_tf_gamma
+            super().__init__(dim, heads, dim_key, dim_value, num_rel_pos_features)
+
+    En.GELU, En.AttentionPool, En.Attention = ev.EnformerGELU, ev.AttentionPool, Attention
+    En.relative_shift, En.exponential_linspace_int = ev._relative_shift, ev.exponential_linspace_int
+    from seeded_weights import draw
+    torch.manual_seed(seed)
+    trunk = En.EnformerTrunk(n_conv=3, channels=384, n_transformers=2, n_heads=2, key_len=16).eval()
+    head = En.ConvHead(n_tasks=1, in_channels=768, act_func=None, pool_func="avg", norm=False).eval()
+    # 3.6 M parameters: not stored. Every tensor is re-drawn from a seeded generator in state_dict order (seeded_weights.py);
+    # the test regenerates the same tensors from the recorded names / shapes.
+    both = torch.nn.ModuleDict({"trunk": trunk, "head": head})
+    sd = both.state_dict()
+    names, shapes = list(sd), [tuple(v.shape) for v in sd.values()]
+    both.load_state_dict(draw(names, shapes, seed), strict=True)
+    g = torch.Generator().manual_seed(seed + 1)
+    tok = torch.randint(0, 5, (3, 40), generator=g)
+    x = torch.nn.functional.one_hot(tok.clamp(max=3), 4).float() * (tok < 4)[..., None]      # MASK rows all-zero (a8)
+    with torch.no_grad():
+        y = trunk(x)
+        v = head(y)
+    assert y.shape == (3, 768, 5) and v.shape == (3, 1, 1) and float(y.abs().max()) > 0.05
+    maxr = max(len(sh) for sh in shapes)
+    save("g17_enformer_trunk.npz", tokens=tok.to(torch.uint8), trunk_out=y, value=v, seed=seed,
+         hp=np.array([3, 384, 2, 2, 16]), names=np.array(names),
+         shapes=np.array([list(sh) + [-1] * (maxr - len(sh)) for sh in shapes], dtype=np.int64))
+
+
 def new_round3():
     g13_traj_mc_full("g13_traj_mc_full_c1.npz", S=128, B=4, M=2, seed=0)
     g13_traj_mc_full("g13_traj_mc_full_m10.npz", S=32, B=4, M=10, seed=2)
@@ -642,11 +687,15 @@ def new_round3():
     g15_step(d, 10)
     g15_step(d, 20)
     g16_dit()
+    g17_enformer_trunk()
 
 
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "g12":
         g12_fullsize_probe()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "g17":
+        g17_enformer_trunk()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "g16":
         g16_dit()

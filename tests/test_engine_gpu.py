@@ -293,6 +293,17 @@ def test_dit_on_the_gpu_equals_reference_fixture():
     assert np.abs(out - g["logits"]).max() <= 1e-4 and np.abs(out0 - g["logits_sigma0"]).max() <= 1e-4
 
 
+def test_enformer_trunk_on_the_gpu_equals_reference_wiring_fixture():
+    """g17 (see tests/test_nets_cpu.py) with the PyTorch-ROCm module on the device: within 1e-4. (The hand-written trunk
+    kernels need 128-multiples of channels and are compared with this module at full size in tests/test_trunk_gpu.py.)"""
+    from tests.test_nets_cpu import _g17_modules
+    trunk, head, x, g = _g17_modules()
+    with torch.no_grad():
+        y = trunk.to(DEV)(x.to(DEV))
+        v = head.to(DEV)(y).cpu().numpy()
+    assert np.abs(y.cpu().numpy() - g["trunk_out"]).max() <= 1e-4 and np.abs(v - g["value"]).max() <= 1e-4
+
+
 def test_fused_net_cache_follows_weight_changes():
     """The fused formulations hold re-packed COPIES of the weights, keyed on weak references to the modules plus a weight
     fingerprint (data pointer, in-place version): training the value function between decodes, load_state_dict, or a new

@@ -161,3 +161,53 @@ def test_dit_equals_reference_fixture():
     assert float(np.abs(g["logits"]).max()) > 0.1
     assert float((out - torch.from_numpy(g["logits"])).abs().max()) <= 2e-5
     assert float((out0 - torch.from_numpy(g["logits_sigma0"])).abs().max()) <= 2e-5
+
+
+def _g17_modules():
+    """Builds this repo's EnformerTrunk + ConvHead at g17's size with the fixture's (seed-regenerated) reference weights,
+    mapped from the reference's parameter names (`Enformer.py` wrappers keep their layer in `.layer`; its transformer tower
+    keeps the blocks in `.blocks`; its FeedForwardBlock `:2010-2047` = dense1 (LayerNorm + Linear + ReLU) -> dense2 (Linear),
+    `ffn.dense` is an unused leftover)."""
+    import os
+    import sys
+    import numpy as np
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    sys.path.insert(0, gdir)
+    from seeded_weights import draw
+    from svdd_amd.enformer_value import EnformerTrunk
+    from svdd_amd.value_nets import ConvHead
+    g = np.load(os.path.join(gdir, "g17_enformer_trunk.npz"))
+    n_conv, ch, n_tf, heads, key_len = (int(v) for v in g["hp"])
+    names = [str(n) for n in g["names"]]
+    ref = draw(names, [[d for d in sh if d >= 0] for sh in g["shapes"]], int(g["seed"]))
+    trunk = EnformerTrunk(n_conv=n_conv, channels=ch, n_transformers=n_tf, n_heads=heads, key_len=key_len).eval()
+    head = ConvHead(1, 2 * ch).eval()
+
+    def to_ours(k):
+        k = k.replace(".norm.layer.", ".norm.").replace(".pool.layer.", ".pool.")
+        k = k.replace("transformer_tower.blocks.", "transformer_tower.")
+        k = k.replace(".ffn.dense1.norm.", ".ffn_norm.").replace(".ffn.dense1.linear.", ".ffn1.").replace(".ffn.dense2.linear.", ".ffn2.")
+        return k
+    sd_t = {to_ours(k[6:]): v for k, v in ref.items() if k.startswith("trunk.") and ".ffn.dense." not in k}
+    sd_h = {k[5:]: v for k, v in ref.items() if k.startswith("head.")}
+    trunk.load_state_dict(sd_t, strict=True)
+    head.load_state_dict(sd_h, strict=True)
+    tok = torch.from_numpy(g["tokens"]).long()
+    x = torch.nn.functional.one_hot(tok.clamp(max=3), 4).float() * (tok < 4)[..., None]
+    return trunk, head, x, g
+
+
+def test_enformer_trunk_equals_reference_wiring_fixture():
+    """g17: the reference's own EnformerTrunk / ConvHead classes (`/root/reference/Enformer.py:1271-1334, 1807-2047, 2131-2173`)
+    run on CPU by make_golden.py with enformer_pytorch's five symbols bound to this repo's restatements: pins the reference's
+    wiring (conv tower channel schedule, NACDR order, residuals, attention pooling placement, transformer / feed-forward
+    block, pointwise block, head) — "pinned up to the enformer_pytorch stand-in"; the attention math itself stays
+    unpinned."""
+    import numpy as np
+    trunk, head, x, g = _g17_modules()
+    with torch.no_grad():
+        y = trunk(x)
+        v = head(y)
+    assert y.shape == g["trunk_out"].shape and float(np.abs(g["trunk_out"]).max()) > 0.05
+    assert float((y - torch.from_numpy(g["trunk_out"])).abs().max()) <= 2e-5
+    assert float((v - torch.from_numpy(g["value"])).abs().max()) <= 2e-5
