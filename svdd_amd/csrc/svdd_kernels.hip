@@ -982,6 +982,7 @@ inline bool bad_layout(int layout) { return layout != SVDD_LAYOUT_BLV && layout 
 }  // namespace
 
 extern "C" void svdd_internal_set_bb_lp_version(int v);      // svdd_lp_backbone.hip
+extern "C" void svdd_internal_set_trunk_gemm_version(int v); // svdd_trunk.hip
 
 // ================================================================================ C ABI ====
 extern "C" {
@@ -993,6 +994,7 @@ int svdd_set_option(int key, int value) {
   if (key == SVDD_OPT_MSPLIT && value >= 0 && value <= 64) { g_msplit = value; return SVDD_OK; }
   if (key == SVDD_OPT_SELECT_ONE_ROW) { g_select_one_row_per_wave = value ? 1 : 0; return SVDD_OK; }
   if (key == SVDD_OPT_BACKBONE_LP_VERSION) { svdd_internal_set_bb_lp_version(value); return SVDD_OK; }
+  if (key == SVDD_OPT_TRUNK_GEMM_VERSION) { svdd_internal_set_trunk_gemm_version(value); return SVDD_OK; }
   return SVDD_E_ARG;
 }
 

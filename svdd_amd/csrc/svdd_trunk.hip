@@ -24,6 +24,13 @@
 // of their parent never enter the trunk, and no host round trip is needed to know how many are left).
 #include "svdd_lp_common.h"
 
+extern "C" int svdd_internal_num_cus();      // svdd_nets.hip
+
+// svdd_set_option(SVDD_OPT_TRUNK_GEMM_VERSION, v): 1 = the 128 x 128 kernel everywhere (A/B), 2 = automatic (default),
+// 3 = the 256 x 256 kernel everywhere
+static int g_trunk_gemm_version = 2;
+extern "C" void svdd_internal_set_trunk_gemm_version(int v) { g_trunk_gemm_version = (v >= 1 && v <= 3) ? v : 2; }
+
 namespace {
 
 typedef __bf16 bf16_t;
@@ -156,6 +163,161 @@ __global__ __launch_bounds__(256, 2) void trunk_gemm_kernel(GemmArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = m0 + 64 * wm + 16 * i + j;
+      if (row < m_live) {
+        f32x4 v = acc[i][nt] + b4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], a.act);
+        if (a.resid) v += *reinterpret_cast<const f32x4*>(a.resid + (size_t)row * a.ldo + col);
+        *reinterpret_cast<f32x4*>(a.out + (size_t)row * a.ldo + col) = v;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ 256 x 256 tiles ----
+// Round 3, second GEMM kernel. The 128 x 128 kernel above moves (128 + 128) x 32 x 2 parts x 2 B = 32 KB from L2 into LDS
+// for every 1.57 M multiply-adds: at the 2.5 PFLOP/s of the matrix cores that is 26 TB/s, more than the L2s deliver — it ran
+// at 370 - 490 TFLOP/s on the MFMA (profiles/r03_trunk_gemms_before.txt), waves parked in s_waitcnt half of the time. Here:
+//   * one workgroup (8 waves, one per CU) = a 256 x 256 output tile: twice the multiply-adds per staged byte;
+//     wave (wm, wn) owns 128 x 64 = 8 x 4 MFMA tiles (128 accumulator registers);
+//   * operands go global -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass). The DMA
+//     writes 1 KB per wave instruction at wave-uniform base + 16 lane, the SOURCE address is per lane: lane 16 g + j
+//     fetches bytes 16 g .. + 15 of row j of a 16-row x 32-column sub-tile, so the LDS image of a sub-tile is exactly the
+//     MFMA fragment order and every fragment read is ds_read_b128 at base + 16 lane — conflict-free by construction
+//     (the 80-byte row pitch of the kernel above spent a third of its LDS cycles on bank conflicts); the weights are
+//     stored in that order by the host, their DMA is a straight copy;
+//   * LDS holds two K blocks (2 x 64 KB for hi + lo planes of both operands); K block s + 1 is requested while s is
+//     multiplied and waited for (vmcnt(0)) two segments later;
+//   * the two waves of a SIMD (wm = 0 / 1) run HALF A PHASE APART: a phase = [load segment: fragment reads (+ DMA
+//     issue)] barrier [compute segment: 48 MFMAs] barrier, and wave group 1 starts one barrier late, so that on every
+//     SIMD one wave multiplies while its partner reads (MI355X_MICROARCH.md, "Two waves per SIMD").
+// N need not be a multiple of 256: in a last, half-wide column block the waves with wn >= 2 only stage and synchronise.
+constexpr int H_BM = 256, H_BN = 256;
+
+template <int NPARTS>
+__global__ __launch_bounds__(512, 2) void trunk_gemm256_kernel(GemmArgs a) {
+  extern __shared__ __attribute__((aligned(1024))) char hsm[];
+  constexpr int SUB_B = 1024;                               // one 16 x 32 sub-tile of one part
+  constexpr int OPER_B = 16 * NPARTS * SUB_B;               // the 16 sub-tiles of an operand: [sub][part][1 KB]
+  constexpr int BUF_B = 2 * OPER_B;                         // A operand, then W operand
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = w >> 2, wn = w & 3, j = lane & 15, g = lane >> 4;
+  const int m_live = a.count ? min(a.M, *a.count * a.rows_per_seq) : a.M;
+  const int NB128 = a.N / 128;
+  const int NB = (a.N + H_BN - 1) / H_BN;
+  const int MB = (a.M + H_BM - 1) / H_BM;
+  const int lid = blockIdx.x;                               // XCD-aware tile order (as above)
+  const int grp = lid / (8 * NB), rem = lid - grp * 8 * NB;
+  const int by = grp * 8 + (rem & 7), nb = rem >> 3;
+  if (by >= MB) return;
+  const int m0 = by * H_BM;
+  if (m0 >= m_live) return;
+  const bool cols_ok = 256 * nb + 64 * wn < a.N;            // this wave's 64 columns exist
+  const bool wstage_ok = 2 * nb + (w >> 2) < NB128;         // ... and so do the weight sub-tiles it stages
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) acc[i][nt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  // DMA sources: wave w stages the A sub-tiles 2 w, 2 w + 1 (rows m0 + 32 w ..) and the W sub-tiles 2 w, 2 w + 1
+  const bf16_t* asrc[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int row = min(m0 + 16 * (2 * w + q) + j, a.M - 1);
+    asrc[q] = a.a_hi + (int64_t)row * a.lda + 8 * g;
+  }
+  const int64_t lo_off = NPARTS == 2 ? a.a_lo - a.a_hi : 0;
+  const BV8* wsrc = a.w + ((size_t)(2 * nb + (w >> 2)) * 8 + ((2 * w) & 7)) * (NPARTS * 64) + lane;
+  const size_t wstep = (size_t)NB128 * 8 * NPARTS * 64;      // V8s per K block
+  char* const stage_a = hsm + (2 * w) * NPARTS * SUB_B;
+  char* const stage_w = hsm + OPER_B + (2 * w) * NPARTS * SUB_B;
+#define H_DMA(KB_, BUF)                                                                                      \
+  { const int kb_ = (KB_);                                                                                   \
+    const int c_ = kb_ / a.T, t_ = kb_ - c_ * a.T;                                                           \
+    const int64_t koff_ = (int64_t)(t_ - a.T / 2) * a.lda + 32 * c_;                                         \
+    _Pragma("unroll") for (int q = 0; q < 2; ++q)                                                            \
+      _Pragma("unroll") for (int p = 0; p < NPARTS; ++p)                                                     \
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(asrc[q] + koff_ + p * lo_off),                          \
+                                         (lds_ptr_t)(stage_a + (BUF) * BUF_B + (q * NPARTS + p) * SUB_B), 16, 0, 0); \
+    if (wstage_ok) {                                                                                         \
+      const BV8* ws_ = wsrc + (size_t)kb_ * wstep;                                                           \
+      _Pragma("unroll") for (int q = 0; q < 2 * NPARTS; ++q)                                                 \
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(ws_ + q * 64),                                          \
+                                         (lds_ptr_t)(stage_w + (BUF) * BUF_B + q * SUB_B), 16, 0, 0);        \
+    } }
+  const char* const frag_a = hsm + (8 * wm) * NPARTS * SUB_B + 16 * lane;
+  const char* const frag_w = hsm + OPER_B + (4 * wn) * NPARTS * SUB_B + 16 * lane;
+  BV8 bf[4][NPARTS], af[4][NPARTS];
+#define H_READ_W(BUF)                                                                                        \
+  _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                           \
+    _Pragma("unroll") for (int p = 0; p < NPARTS; ++p)                                                       \
+      bf[nt][p] = *reinterpret_cast<const BV8*>(frag_w + (BUF) * BUF_B + (nt * NPARTS + p) * SUB_B);
+#define H_READ_A(BUF, H)                                                                                     \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                              \
+    _Pragma("unroll") for (int p = 0; p < NPARTS; ++p)                                                       \
+      af[i][p] = *reinterpret_cast<const BV8*>(frag_a + (BUF) * BUF_B + ((4 * (H) + i) * NPARTS + p) * SUB_B);
+  // the three passes of a product go to the same accumulator: 16 independent MFMAs between dependent ones
+#define H_MFMA(H)                                                                                            \
+  if (cols_ok) {                                                                                             \
+    __builtin_amdgcn_s_setprio(1);                                                                           \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                            \
+      _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                       \
+        acc[4 * (H) + i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[nt][0], af[i][0], acc[4 * (H) + i][nt], 0, 0, 0); \
+    if constexpr (NPARTS == 2) {                                                                             \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                          \
+        _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                     \
+          acc[4 * (H) + i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[nt][1], af[i][0], acc[4 * (H) + i][nt], 0, 0, 0); \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                          \
+        _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                     \
+          acc[4 * (H) + i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[nt][0], af[i][1], acc[4 * (H) + i][nt], 0, 0, 0); \
+    }                                                                                                        \
+    __builtin_amdgcn_s_setprio(0);                                                                           \
+  }
+#define H_BARRIER() { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
+  // K block S (LDS buffer BUF): two phases of [load segment | barrier | compute segment | barrier]
+#define H_KBLOCK(S, BUF)                                                                                     \
+  if ((S) < KB) {                                                                                            \
+    if (cols_ok) { H_READ_W(BUF) H_READ_A(BUF, 0) }                                                          \
+    if ((S) + 1 < KB) H_DMA((S) + 1, 1 - (BUF))                                                              \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                       \
+    H_BARRIER()                                                                                              \
+    H_MFMA(0)                                                                                                \
+    H_BARRIER()                                                                                              \
+    if (cols_ok) { H_READ_A(BUF, 1) }                                                                        \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   /* K block S + 1 has landed (this wave's share) */ \
+    H_BARRIER()                                                                                              \
+    H_MFMA(1)                                                                                                \
+    H_BARRIER()                                                                                              \
+  }
+  const int KB = a.KB;
+  H_DMA(0, 0)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  H_BARRIER()
+  if (wm == 1) H_BARRIER()                                  // wave group 1 runs one segment behind group 0
+  for (int s = 0; s < KB; s += 2) {
+    H_KBLOCK(s, 0)
+    H_KBLOCK(s + 1, 1)
+  }
+  if (wm == 0) H_BARRIER()
+#undef H_KBLOCK
+#undef H_BARRIER
+#undef H_MFMA
+#undef H_READ_A
+#undef H_READ_W
+#undef H_DMA
+  // epilogue: lane (j, g) holds row 16 i + j, columns 16 nt + 4 g .. + 3 of every tile of its wave
+  if (!cols_ok) return;
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    const int col = nb * H_BN + 64 * wn + 16 * nt + 4 * g;
+    f32x4 b4 = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (a.bias) b4 = *reinterpret_cast<const f32x4*>(a.bias + col);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = m0 + 128 * wm + 16 * i + j;
       if (row < m_live) {
         f32x4 v = acc[i][nt] + b4;
 #pragma unroll
@@ -322,6 +484,24 @@ int svdd_trunk_gemm(const void* a_hi, const void* a_lo, const void* w, const flo
     return SVDD_E_ARG;
   GemmArgs a{(const bf16_t*)a_hi, (const bf16_t*)a_lo, (const BV8*)w, bias, resid, out, M, N, T * (Cin / G_BK), Cin / G_BK, T,
              lda, ldo, act, count, rows_per_seq};
+  // 256 x 256 tiles where they fill the chip at least twice over; the 128 x 128 kernel for the small-M GEMMs of the
+  // transformer tower (2 tokens per sequence) and for the one-pass mode
+  const int mb2 = (M + H_BM - 1) / H_BM, nb2 = (N + H_BN - 1) / H_BN;
+  const bool big = g_trunk_gemm_version == 2 ? (a_lo != nullptr && (int64_t)mb2 * nb2 >= 2 * svdd_internal_num_cus())
+                                              : g_trunk_gemm_version == 3;
+  if (big) {
+    const dim3 grid((unsigned)(((mb2 + 7) / 8) * 8 * nb2));
+    if (a_lo) {
+      constexpr int lds = 2 * 2 * 16 * 2 * 1024;
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(trunk_gemm256_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      hipLaunchKernelGGL(trunk_gemm256_kernel<2>, grid, dim3(512), lds, (hipStream_t)stream, a);
+    } else {
+      constexpr int lds = 2 * 2 * 16 * 1 * 1024;
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(trunk_gemm256_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      hipLaunchKernelGGL(trunk_gemm256_kernel<1>, grid, dim3(512), lds, (hipStream_t)stream, a);
+    }
+    return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
+  }
   const int mb = (M + G_BM - 1) / G_BM;
   const dim3 grid((unsigned)(((mb + 7) / 8) * 8 * (N / G_BN)));         // groups of 8 row tiles x N / 128 column tiles
   if (a_lo) hipLaunchKernelGGL(trunk_gemm_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, a);

@@ -109,3 +109,54 @@ def test_mc_decode_with_the_fused_trunk_vs_oracle():
     assert np.array_equal(x_on, outs[False][0])
     for (la, sa), (lb, sb) in zip(tr_on, outs[False][1]):
         assert np.array_equal(la, lb) and (sa is None or np.array_equal(sa, sb))
+
+
+@pytest.mark.parametrize("M,N,Cin,T,rps,live", [(1000, 768, 96, 1, 8, None), (2100, 896, 64, 5, 14, None),
+                                                (777, 256, 160, 5, 7, 40), (5000, 1152, 64, 1, 10, 333)])
+@pytest.mark.parametrize("parts", [2, 1])
+def test_gemm_256_tiles_equal_128_tiles(M, N, Cin, T, rps, live, parts):
+    """svdd_trunk_gemm's two kernels (128 x 128 register-staged tiles, 256 x 256 LDS-DMA tiles with staggered wave groups)
+    accumulate every output element in the same order: bit-identical results, for ragged M, a half-wide last column block
+    (N = 896, 1152), 5 row-shifted taps, bias / residual / GELU epilogue and a device-side live-row count; and both agree
+    with an fp64 product of the hi + lo operands."""
+    from svdd_amd import _lib
+    from svdd_amd.fused_trunk import pack_gemm_weight, GUARD, TAIL
+    lib = _lib.lib()
+    g = torch.Generator(device="cpu").manual_seed(M + N)
+    a = torch.randn(M, Cin, generator=g)
+    w = torch.randn(N, Cin, T, generator=g) * (Cin * T) ** -0.5
+    bias = torch.randn(N, generator=g)
+    resid = torch.randn(M, N, generator=g).to(DEV)
+    a_hi = a.to(torch.bfloat16)
+    a_lo = (a - a_hi.float()).to(torch.bfloat16)
+    planes = []
+    for pl in ((a_hi, a_lo) if parts == 2 else (a_hi,)):
+        buf = torch.zeros((GUARD + M + TAIL) * Cin, dtype=torch.bfloat16, device=DEV)
+        buf[GUARD * Cin:(GUARD + M) * Cin] = pl.reshape(-1).to(DEV)
+        planes.append(buf[GUARD * Cin:])
+    wp = pack_gemm_weight(w, parts).to(DEV)
+    cnt = None if live is None else torch.tensor([live], dtype=torch.int32, device=DEV)
+    m_live = M if live is None else min(M, live * rps)
+    outs = {}
+    for ver in (1, 3):
+        _lib.check(lib.svdd_set_option(4, ver), "svdd_set_option")
+        out = torch.full((M, N), 7.0, device=DEV)
+        rc = lib.svdd_trunk_gemm(planes[0].data_ptr(), planes[1].data_ptr() if parts == 2 else None, wp.data_ptr(),
+                                 bias.to(DEV).data_ptr(), resid.data_ptr(), out.data_ptr(), M, N, Cin, T, Cin, N, 2,
+                                 None if cnt is None else cnt.data_ptr(), rps, None)
+        _lib.check(rc, "svdd_trunk_gemm")
+        torch.cuda.synchronize()
+        outs[ver] = out.cpu()
+    _lib.check(lib.svdd_set_option(4, 2), "svdd_set_option")
+    assert torch.equal(outs[1][:m_live], outs[3][:m_live])
+    assert bool((outs[3][m_live:] == 7.0).all())                       # rows beyond the live count are not written
+    # fp64 reference on the operands the kernels see (x3: hi + lo of both; dropped lo * lo term ~ 2^-16 relative)
+    a_eff = (a_hi.double() + (a_lo.double() if parts == 2 else 0.0))
+    w_hi = w.to(torch.bfloat16)
+    w_eff = w_hi.double() + ((w - w_hi.float()).to(torch.bfloat16).double() if parts == 2 else 0.0)
+    ap = torch.zeros(M + 4, Cin, dtype=torch.float64)
+    ap[2:M + 2] = a_eff
+    acc = sum(ap[t - T // 2 + 2: t - T // 2 + 2 + M] @ w_eff[:, :, t].t() for t in range(T)) + bias.double()
+    ref = acc / (1.0 + torch.exp(-1.702 * acc)) + resid.cpu().double()
+    err = float((outs[3][:m_live].double() - ref[:m_live]).abs().max())
+    assert err <= (2e-5 if parts == 2 else 1e-4), err
