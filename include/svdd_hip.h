@@ -386,7 +386,7 @@ int svdd_device_info(char* arch, int arch_len, int* num_cu);
 
 /* ABI version of this header: bumped on any signature change. */
 int svdd_abi_version(void);
-#define SVDD_ABI_VERSION 3
+#define SVDD_ABI_VERSION 4
 
 /*
  * Enformer-shaped value trunk (BASELINE.json configs[3]; reference decode.py:78-80, Enformer.py:1271-1334 trunk, :1807-1884
@@ -399,20 +399,32 @@ int svdd_abi_version(void);
  *                        a_hi / a_lo: bf16 operand planes [>= M + 128 + T rows, lda] with T/2 readable rows before row 0;
  *                        w: bf16 weight fragments packed by svdd_amd.fused_trunk.pack_gemm_weight ; N % 128 == 0, Cin % 32 == 0,
  *                        T odd ; act 0 none, 1 relu, 2 x * sigmoid(1.702 x).
+ *                        Fused second output (out_hi != NULL; out may then be NULL): the operand planes of the NEXT GEMM,
+ *                        post_act(post_scale[c] y + post_shift[c]) -> (out_hi, out_lo) [M, N] (scale / shift NULL: identity), zero in
+ *                        the `pad` rows at either end of every sequence — what svdd_trunk_act_split would write from `out`. The
+ *                        output planes must not be the input planes. Two kernels behind it (SVDD_OPT_TRUNK_GEMM_VERSION).
  * svdd_trunk_act_split   x fp32 [rows, C] -> act(scale[c] x + shift[c]) (scale / shift NULL: identity) -> planes hi (lo may be
  *                        NULL) ; rows whose position in their sequence is within `pad` of either end are written as zeros.
  * svdd_trunk_layernorm_split   LayerNorm(x[row, :C]) gamma + beta -> planes (C % 8 == 0, C <= 4096).
- * svdd_trunk_attn_pool   softmax-weighted pooling over position pairs: x, logits fp32 [n, L + 4, C] -> out [n, ceil(L/2) + 4, C].
+ * svdd_trunk_attn_pool   softmax-weighted pooling over position pairs: x, logits fp32 [n, L + 4, C] -> out [n, ceil(L/2) + 4, C]
+ *                        (may be NULL) and / or the next GEMM's operand planes post_act(post_scale o + post_shift), pad rows zeroed.
+ * svdd_trunk_attn_small  relative-position attention on T <= 4 tokens per sequence (what the conv tower leaves of L <= 512): qkv fp32
+ *                        [n T, heads (2 dk + dv)] = [q | k | v], rel_k [heads, 2 T - 1, dk] (positional keys), content / pos bias
+ *                        [heads, dk] -> softmax(((q s + cb) k^T + shift((q s + pb) rel_k^T))) v as (hi, lo) planes [n T, heads dv].
  * svdd_trunk_stem_unfold tokens [n, L] u8 -> hi plane [n (L + 4), 64]: channel 4 t + token of position l + t - 7 (t < 15) set to 1.
  */
 int svdd_trunk_gemm(const void* a_hi, const void* a_lo, const void* w, const float* bias, const float* resid, float* out,
                     int M, int N, int Cin, int T, int lda, int ldo, int act, const int32_t* count, int rows_per_seq,
+                    void* out_hi, void* out_lo, const float* post_scale, const float* post_shift, int post_act, int pad,
                     void* stream);
 int svdd_trunk_act_split(const float* x, const float* scale, const float* shift, int act, int64_t rows, int C,
                          int rows_per_seq, int pad, void* hi, void* lo, const int32_t* count, void* stream);
 int svdd_trunk_layernorm_split(const float* x, const float* gamma, const float* beta, float eps, int64_t rows, int C,
                                void* hi, void* lo, const int32_t* count, int rows_per_seq, void* stream);
-int svdd_trunk_attn_pool(const float* x, const float* logits, int n, int L, int C, float* out, const int32_t* count, void* stream);
+int svdd_trunk_attn_pool(const float* x, const float* logits, int n, int L, int C, float* out, const int32_t* count,
+                         void* out_hi, void* out_lo, const float* post_scale, const float* post_shift, int post_act, void* stream);
+int svdd_trunk_attn_small(const float* qkv, const float* rel_k, const float* content_bias, const float* pos_bias, int n, int T,
+                          int heads, int dk, int dv, void* hi, void* lo, const int32_t* count, void* stream);
 int svdd_trunk_stem_unfold(const uint8_t* tok, int n, int L, void* hi, const int32_t* count, void* stream);
 
 #ifdef __cplusplus

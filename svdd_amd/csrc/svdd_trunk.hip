@@ -52,7 +52,35 @@ struct GemmArgs {
   const float* bias; const float* resid; float* out;
   int M, N, KB, cb, T, lda, ldo, act;
   const int* count; int rows_per_seq;
+  // fused second output: the NEXT GEMM's operand planes p_act(p_scale y + p_shift) -> (hi, lo) [M][N], zero in the `pad`
+  // rows at either end of every sequence (what a separate svdd_trunk_act_split pass over y would write)
+  bf16_t* o_hi; bf16_t* o_lo; const float* p_scale; const float* p_shift; int p_act, pad;
 };
+
+typedef bf16_t BV4 __attribute__((ext_vector_type(4)));
+
+// Epilogue of four adjacent columns of one row, shared by both GEMM kernels: y = act(acc + bias) (+ resid) -> fp32 out
+// (if any) and / or the operand planes of the next GEMM.
+__device__ __forceinline__ void gemm_store4(const GemmArgs& a, int row, int col, bool pad_row, f32x4 v, f32x4 b4, f32x4 ps4, f32x4 pb4) {
+  v += b4;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], a.act);
+  if (a.resid) v += *reinterpret_cast<const f32x4*>(a.resid + (size_t)row * a.ldo + col);
+  if (a.out) *reinterpret_cast<f32x4*>(a.out + (size_t)row * a.ldo + col) = v;
+  if (a.o_hi) {
+    f32x4 t = v * ps4 + pb4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) t[e] = pad_row ? 0.0f : apply_act(a.p_scale ? t[e] : v[e], a.p_act);
+    const BV4 h = __builtin_convertvector(t, BV4);
+    *reinterpret_cast<BV4*>(a.o_hi + (size_t)row * a.N + col) = h;
+    if (a.o_lo) *reinterpret_cast<BV4*>(a.o_lo + (size_t)row * a.N + col) = __builtin_convertvector(t - __builtin_convertvector(h, f32x4), BV4);
+  }
+}
+__device__ __forceinline__ bool gemm_pad_row(const GemmArgs& a, int row) {
+  if (a.pad <= 0) return false;
+  const int pos = row % a.rows_per_seq;
+  return pos < a.pad || pos >= a.rows_per_seq - a.pad;
+}
 
 // One workgroup (4 waves) = a 128 x 128 output tile; wave (wm, wn) owns 64 x 64 = 4 x 4 MFMA tiles. A stage = one K block
 // (32 wide): the 128 x 32 A tile (shifted by the block's tap) and the 32 x 128 W tile. FOUR stages are in flight: stage s is
@@ -155,21 +183,19 @@ __global__ __launch_bounds__(256, 2) void trunk_gemm_kernel(GemmArgs a) {
 #undef TG_STORE
 #undef TG_LOAD
   // epilogue: lane (j, g) holds row 16 i + j, columns 16 nt + 4 g .. + 3 of every tile
+  bool padr[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) padr[i] = gemm_pad_row(a, m0 + 64 * wm + 16 * i + j);
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) {
     const int col = nb * G_BN + 64 * wn + 16 * nt + 4 * g;
-    f32x4 b4 = {0.0f, 0.0f, 0.0f, 0.0f};
+    f32x4 b4 = {0.0f, 0.0f, 0.0f, 0.0f}, ps4 = {1.0f, 1.0f, 1.0f, 1.0f}, pb4 = {0.0f, 0.0f, 0.0f, 0.0f};
     if (a.bias) b4 = *reinterpret_cast<const f32x4*>(a.bias + col);
+    if (a.p_scale) { ps4 = *reinterpret_cast<const f32x4*>(a.p_scale + col); pb4 = *reinterpret_cast<const f32x4*>(a.p_shift + col); }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = m0 + 64 * wm + 16 * i + j;
-      if (row < m_live) {
-        f32x4 v = acc[i][nt] + b4;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], a.act);
-        if (a.resid) v += *reinterpret_cast<const f32x4*>(a.resid + (size_t)row * a.ldo + col);
-        *reinterpret_cast<f32x4*>(a.out + (size_t)row * a.ldo + col) = v;
-      }
+      if (row < m_live) gemm_store4(a, row, col, padr[i], acc[i][nt], b4, ps4, pb4);
     }
   }
 }
@@ -310,21 +336,19 @@ __global__ __launch_bounds__(512, 2) void trunk_gemm256_kernel(GemmArgs a) {
 #undef H_DMA
   // epilogue: lane (j, g) holds row 16 i + j, columns 16 nt + 4 g .. + 3 of every tile of its wave
   if (!cols_ok) return;
+  bool padr[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) padr[i] = gemm_pad_row(a, m0 + 128 * wm + 16 * i + j);
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) {
     const int col = nb * H_BN + 64 * wn + 16 * nt + 4 * g;
-    f32x4 b4 = {0.0f, 0.0f, 0.0f, 0.0f};
+    f32x4 b4 = {0.0f, 0.0f, 0.0f, 0.0f}, ps4 = {1.0f, 1.0f, 1.0f, 1.0f}, pb4 = {0.0f, 0.0f, 0.0f, 0.0f};
     if (a.bias) b4 = *reinterpret_cast<const f32x4*>(a.bias + col);
+    if (a.p_scale) { ps4 = *reinterpret_cast<const f32x4*>(a.p_scale + col); pb4 = *reinterpret_cast<const f32x4*>(a.p_shift + col); }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int row = m0 + 128 * wm + 16 * i + j;
-      if (row < m_live) {
-        f32x4 v = acc[i][nt] + b4;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], a.act);
-        if (a.resid) v += *reinterpret_cast<const f32x4*>(a.resid + (size_t)row * a.ldo + col);
-        *reinterpret_cast<f32x4*>(a.out + (size_t)row * a.ldo + col) = v;
-      }
+      if (row < m_live) gemm_store4(a, row, col, padr[i], acc[i][nt], b4, ps4, pb4);
     }
   }
 }
@@ -417,31 +441,122 @@ __global__ __launch_bounds__(256) void trunk_ln_split_kernel(LnArgs a) {
 }
 
 // AttentionPool(pool_size = 2): out[b, i, c] = sum_k x[b, 2 i + k, c] softmax_k(logits[b, 2 i + k, c]); an odd L is padded
-// with one masked position (weight 0). x / logits [n, L + 4, C] and out [n, ceil(L / 2) + 4, C] in the padded layout
-// (the pad rows of out are left untouched: the next element-wise pass zeroes them in the operand planes).
-struct PoolArgs { const float* x; const float* logits; int n, L, C; float* out; const int* count; };
+// with one masked position (weight 0). x / logits [n, L + 4, C] and out [n, ceil(L / 2) + 4, C] in the padded layout.
+// Outputs (either may be NULL): the fp32 rows (their pad rows are left untouched) and / or the operand planes of the next
+// GEMM, act(scale o + shift) -> (hi, lo), INCLUDING zeroed pad rows (what svdd_trunk_act_split would write from the fp32 rows).
+struct PoolArgs { const float* x; const float* logits; int n, L, C; float* out; const int* count;
+                  bf16_t* hi; bf16_t* lo; const float* scale; const float* shift; int act; };
 __global__ __launch_bounds__(256) void trunk_attn_pool_kernel(PoolArgs a) {
   const int nlive = a.count ? min(a.n, *a.count) : a.n;
   const int Lo = (a.L + 1) / 2, c4 = a.C >> 2;
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (int64_t)nlive * Lo * c4) return;
+  if (idx >= (int64_t)nlive * (Lo + 4) * c4) return;
   const int c = (int)(idx % c4) * 4;
   const int64_t t = idx / c4;
-  const int i = (int)(t % Lo);
-  const int64_t b = t / Lo;
-  const int64_t r0 = b * (a.L + 4) + 2 + 2 * i;
-  const f32x4 x0 = *reinterpret_cast<const f32x4*>(a.x + r0 * a.C + c), l0 = *reinterpret_cast<const f32x4*>(a.logits + r0 * a.C + c);
-  f32x4 o = x0;
-  if (2 * i + 1 < a.L) {
-    const f32x4 x1 = *reinterpret_cast<const f32x4*>(a.x + (r0 + 1) * a.C + c), l1 = *reinterpret_cast<const f32x4*>(a.logits + (r0 + 1) * a.C + c);
+  const int i = (int)(t % (Lo + 4)) - 2;                     // output position; -2, -1, Lo, Lo + 1 are the pad rows
+  const int64_t b = t / (Lo + 4);
+  const int64_t orow = b * (Lo + 4) + 2 + i;
+  f32x4 o = {0.0f, 0.0f, 0.0f, 0.0f};
+  const bool real = i >= 0 && i < Lo;
+  if (real) {
+    const int64_t r0 = b * (a.L + 4) + 2 + 2 * i;
+    const f32x4 x0 = *reinterpret_cast<const f32x4*>(a.x + r0 * a.C + c), l0 = *reinterpret_cast<const f32x4*>(a.logits + r0 * a.C + c);
+    o = x0;
+    if (2 * i + 1 < a.L) {
+      const f32x4 x1 = *reinterpret_cast<const f32x4*>(a.x + (r0 + 1) * a.C + c), l1 = *reinterpret_cast<const f32x4*>(a.logits + (r0 + 1) * a.C + c);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float m = fmaxf(l0[e], l1[e]);
-      const float e0 = __expf(l0[e] - m), e1 = __expf(l1[e] - m);
-      o[e] = (x0[e] * e0 + x1[e] * e1) / (e0 + e1);
+      for (int e = 0; e < 4; ++e) {
+        const float m = fmaxf(l0[e], l1[e]);
+        const float e0 = __expf(l0[e] - m), e1 = __expf(l1[e] - m);
+        o[e] = (x0[e] * e0 + x1[e] * e1) / (e0 + e1);
+      }
+    }
+    if (a.out) *reinterpret_cast<f32x4*>(a.out + orow * a.C + c) = o;
+  }
+  if (a.hi) {
+    f32x4 tt = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (real) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) tt[e] = apply_act(a.scale ? o[e] * a.scale[c + e] + a.shift[c + e] : o[e], a.act);
+    }
+    const BV4 h = __builtin_convertvector(tt, BV4);
+    *reinterpret_cast<BV4*>(a.hi + orow * a.C + c) = h;
+    if (a.lo) *reinterpret_cast<BV4*>(a.lo + orow * a.C + c) = __builtin_convertvector(tt - __builtin_convertvector(h, f32x4), BV4);
+  }
+}
+
+// Relative-position attention of the transformer tower on the T <= 4 tokens a sequence is pooled down to (2 for L = 200;
+// enformer-pytorch Attention as restated in svdd_amd/enformer_value.py RelPosAttention): one wave per (sequence, head),
+//   logits[i][j] = (q_i s + content_bias) . k_j + (q_i s + pos_bias) . rel_k[j - i + T - 1],  s = dk^-1/2
+//   out_i = sum_j softmax_j(logits[i][.]) v_j  -> written as the (hi, lo) operand planes of the output projection.
+// (Round 2/3a ran these as five batched torch matmul / einsum calls per block: two skinny rocBLAS kernels, 0.76 ms per
+// block at 3840 sequences for 0.1 GFLOP — profiles/r03_trunk_kernel_split.txt.)
+struct AttnArgs {
+  const float* qkv; const float* rel_k; const float* content_bias; const float* pos_bias;
+  int n, h, dk, dv, ld; float scale; bf16_t* hi; bf16_t* lo; const int* count;
+};
+template <int T>
+__global__ __launch_bounds__(256) void trunk_attn_small_kernel(AttnArgs a) {
+  const int nlive = a.count ? min(a.n, *a.count) : a.n;
+  const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int b = wid / a.h, hd = wid - b * a.h;
+  if (b >= nlive) return;
+  const int nq = a.h * a.dk;
+  const float* row0 = a.qkv + (size_t)b * T * a.ld;
+  float lg[T][T];
+#pragma unroll
+  for (int i = 0; i < T; ++i)
+#pragma unroll
+    for (int jj = 0; jj < T; ++jj) lg[i][jj] = 0.0f;
+  for (int d = lane; d < a.dk; d += 64) {
+    const float cb = a.content_bias[hd * a.dk + d], pb = a.pos_bias[hd * a.dk + d];
+    float kk[T], rk[2 * T - 1];
+#pragma unroll
+    for (int jj = 0; jj < T; ++jj) kk[jj] = row0[(size_t)jj * a.ld + nq + hd * a.dk + d];
+#pragma unroll
+    for (int r = 0; r < 2 * T - 1; ++r) rk[r] = a.rel_k[((size_t)hd * (2 * T - 1) + r) * a.dk + d];
+#pragma unroll
+    for (int i = 0; i < T; ++i) {
+      const float q = row0[(size_t)i * a.ld + hd * a.dk + d] * a.scale;
+#pragma unroll
+      for (int jj = 0; jj < T; ++jj) lg[i][jj] += (q + cb) * kk[jj] + (q + pb) * rk[jj - i + T - 1];
     }
   }
-  *reinterpret_cast<f32x4*>(a.out + (b * (Lo + 4) + 2 + i) * a.C + c) = o;
+#pragma unroll
+  for (int i = 0; i < T; ++i)
+#pragma unroll
+    for (int jj = 0; jj < T; ++jj)
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) lg[i][jj] += __shfl_xor(lg[i][jj], off, 64);
+  float pr[T][T];
+#pragma unroll
+  for (int i = 0; i < T; ++i) {
+    float m = lg[i][0];
+#pragma unroll
+    for (int jj = 1; jj < T; ++jj) m = fmaxf(m, lg[i][jj]);
+    float sum = 0.0f;
+#pragma unroll
+    for (int jj = 0; jj < T; ++jj) { pr[i][jj] = __expf(lg[i][jj] - m); sum += pr[i][jj]; }
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int jj = 0; jj < T; ++jj) pr[i][jj] *= inv;
+  }
+  const int ldo = a.h * a.dv;
+  for (int c = lane; c < a.dv; c += 64) {
+    float vv[T];
+#pragma unroll
+    for (int jj = 0; jj < T; ++jj) vv[jj] = row0[(size_t)jj * a.ld + 2 * nq + hd * a.dv + c];
+#pragma unroll
+    for (int i = 0; i < T; ++i) {
+      float o = 0.0f;
+#pragma unroll
+      for (int jj = 0; jj < T; ++jj) o += pr[i][jj] * vv[jj];
+      const size_t at = ((size_t)b * T + i) * ldo + hd * a.dv + c;
+      const bf16_t hb = (bf16_t)o;
+      a.hi[at] = hb;
+      if (a.lo) a.lo[at] = (bf16_t)(o - (float)hb);
+    }
+  }
 }
 
 // Stem operand: row (b, l) of the padded layout gets the 64 channels [tap t = 0..14][one-hot 4] (+ 4 zeros) of the k = 15
@@ -478,16 +593,19 @@ extern "C" {
 
 int svdd_trunk_gemm(const void* a_hi, const void* a_lo, const void* w, const float* bias, const float* resid, float* out,
                     int M, int N, int Cin, int T, int lda, int ldo, int act, const int32_t* count, int rows_per_seq,
+                    void* out_hi, void* out_lo, const float* post_scale, const float* post_shift, int post_act, int pad,
                     void* stream) {
-  if (!a_hi || !w || !out || M <= 0 || N <= 0 || (N % G_BN) || Cin <= 0 || (Cin % G_BK) || T < 1 || !(T & 1) || lda < Cin ||
-      ldo < N || act < 0 || act > 2 || (count && rows_per_seq <= 0))
+  if (!a_hi || !w || (!out && !out_hi) || M <= 0 || N <= 0 || (N % G_BN) || Cin <= 0 || (Cin % G_BK) || T < 1 || !(T & 1) ||
+      lda < Cin || ldo < N || act < 0 || act > 2 || ((count || pad > 0) && rows_per_seq <= 0) || (out_lo && !out_hi) ||
+      ((post_scale == nullptr) != (post_shift == nullptr)) || post_act < 0 || post_act > 2 || pad < 0 ||
+      out_hi == a_hi || (out_lo && out_lo == a_lo))
     return SVDD_E_ARG;
   GemmArgs a{(const bf16_t*)a_hi, (const bf16_t*)a_lo, (const BV8*)w, bias, resid, out, M, N, T * (Cin / G_BK), Cin / G_BK, T,
-             lda, ldo, act, count, rows_per_seq};
-  // 256 x 256 tiles where they fill the chip at least twice over; the 128 x 128 kernel for the small-M GEMMs of the
-  // transformer tower (2 tokens per sequence) and for the one-pass mode
+             lda, ldo, act, count, rows_per_seq, (bf16_t*)out_hi, (bf16_t*)out_lo, post_scale, post_shift, post_act, pad};
+  // 256 x 256 tiles from half a chip's worth of tiles on (the 7680-row GEMMs of the transformer tower make 180 - 360 of them and
+  // still run 2.3x faster than on 128 x 128 tiles: 0.79 - 0.98 vs 0.37 - 0.42 PFLOP/s); the 128 x 128 kernel below that
   const int mb2 = (M + H_BM - 1) / H_BM, nb2 = (N + H_BN - 1) / H_BN;
-  const bool big = g_trunk_gemm_version == 2 ? (a_lo != nullptr && (int64_t)mb2 * nb2 >= 2 * svdd_internal_num_cus())
+  const bool big = g_trunk_gemm_version == 2 ? ((int64_t)mb2 * nb2 >= svdd_internal_num_cus() / 2)
                                               : g_trunk_gemm_version == 3;
   if (big) {
     const dim3 grid((unsigned)(((mb2 + 7) / 8) * 8 * nb2));
@@ -528,11 +646,30 @@ int svdd_trunk_layernorm_split(const float* x, const float* gamma, const float* 
   return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
 }
 
-int svdd_trunk_attn_pool(const float* x, const float* logits, int n, int L, int C, float* out, const int32_t* count, void* stream) {
-  if (!x || !logits || !out || n <= 0 || L <= 0 || C <= 0 || (C & 3)) return SVDD_E_ARG;
-  PoolArgs a{x, logits, n, L, C, out, count};
-  const int64_t nthr = (int64_t)n * ((L + 1) / 2) * (C >> 2);
+int svdd_trunk_attn_pool(const float* x, const float* logits, int n, int L, int C, float* out, const int32_t* count,
+                         void* out_hi, void* out_lo, const float* post_scale, const float* post_shift, int post_act, void* stream) {
+  if (!x || !logits || (!out && !out_hi) || n <= 0 || L <= 0 || C <= 0 || (C & 3) || (out_lo && !out_hi) ||
+      ((post_scale == nullptr) != (post_shift == nullptr)) || post_act < 0 || post_act > 2)
+    return SVDD_E_ARG;
+  PoolArgs a{x, logits, n, L, C, out, count, (bf16_t*)out_hi, (bf16_t*)out_lo, post_scale, post_shift, post_act};
+  const int64_t nthr = (int64_t)n * ((L + 1) / 2 + 4) * (C >> 2);
   hipLaunchKernelGGL(trunk_attn_pool_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
+}
+
+int svdd_trunk_attn_small(const float* qkv, const float* rel_k, const float* content_bias, const float* pos_bias, int n, int T,
+                          int heads, int dk, int dv, void* hi, void* lo, const int32_t* count, void* stream) {
+  if (!qkv || !rel_k || !content_bias || !pos_bias || !hi || n <= 0 || T < 1 || T > 4 || heads <= 0 || dk <= 0 || dv <= 0)
+    return SVDD_E_ARG;
+  AttnArgs a{qkv, rel_k, content_bias, pos_bias, n, heads, dk, dv, heads * (2 * dk + dv), 1.0f / sqrtf((float)dk),
+             (bf16_t*)hi, (bf16_t*)lo, count};
+  const dim3 grid((unsigned)(((int64_t)n * heads + 3) / 4));
+  switch (T) {
+    case 1: hipLaunchKernelGGL(trunk_attn_small_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a); break;
+    case 2: hipLaunchKernelGGL(trunk_attn_small_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, a); break;
+    case 3: hipLaunchKernelGGL(trunk_attn_small_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, a); break;
+    default: hipLaunchKernelGGL(trunk_attn_small_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, a); break;
+  }
   return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
 }
 

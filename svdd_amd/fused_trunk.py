@@ -115,7 +115,7 @@ class FusedEnformerValueNet(nn.Module):
                      "nq": m.to_q.weight.shape[0], "nv": m.to_v.weight.shape[0],
                      "out_w": pk(m.to_out.weight), "out_b": m.to_out.bias.detach().float().contiguous(),
                      "heads": m.heads, "dk": m.dim_key, "dv": m.dim_value,
-                     "content_bias": m.rel_content_bias.detach().float(), "pos_bias": m.rel_pos_bias.detach().float(),
+                     "content_bias": m.rel_content_bias.detach().float().contiguous(), "pos_bias": m.rel_pos_bias.detach().float().contiguous(),
                      "rel_w": m.to_rel_k.weight.detach().float(), "nfeat": m.num_rel_pos_features,
                      "ln2": (tb.ffn_norm.weight.detach().float().contiguous(), tb.ffn_norm.bias.detach().float().contiguous(), tb.ffn_norm.eps),
                      "f1_w": pk(tb.ffn1.weight), "f1_b": tb.ffn1.bias.detach().float().contiguous(),
@@ -133,19 +133,23 @@ class FusedEnformerValueNet(nn.Module):
         self.timing = None
 
     # ------------------------------------------------------------------ thin kernel wrappers
-    def _gemm(self, planes, w, bias, resid, out, M, N, Cin, T, act, count, rps):
+    def _gemm(self, planes, w, bias, resid, out, M, N, Cin, T, act, count, rps, nxt=None, post=None, post_act=ACT_NONE, pad=0):
+        """out (fp32, may be None) = act(A W + bias) (+ resid); nxt: the operand planes the NEXT GEMM reads, written by this
+        GEMM's epilogue as post_act(post[0] y + post[1]) with the `pad` rows of every sequence zeroed."""
         if self.timing is not None:                                # tools/trunk_microbench.py --gemms: per-launch events
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            self._gemm_launch(planes, w, bias, resid, out, M, N, Cin, T, act, count, rps)
+            self._gemm_launch(planes, w, bias, resid, out, M, N, Cin, T, act, count, rps, nxt, post, post_act, pad)
             e1.record()
             self.timing.append((M, N, Cin, T, e0, e1))
             return
-        self._gemm_launch(planes, w, bias, resid, out, M, N, Cin, T, act, count, rps)
+        self._gemm_launch(planes, w, bias, resid, out, M, N, Cin, T, act, count, rps, nxt, post, post_act, pad)
 
-    def _gemm_launch(self, planes, w, bias, resid, out, M, N, Cin, T, act, count, rps):
+    def _gemm_launch(self, planes, w, bias, resid, out, M, N, Cin, T, act, count, rps, nxt, post, post_act, pad):
         rc = _lib.lib().svdd_trunk_gemm(planes[0].data_ptr(), planes[1].data_ptr() if len(planes) > 1 else None, w.data_ptr(),
-                                        _ptr(bias), _ptr(resid), out.data_ptr(), M, N, Cin, T, Cin, N, act, _ptr(count), rps, _stream())
+                                        _ptr(bias), _ptr(resid), _ptr(out), M, N, Cin, T, Cin, N, act, _ptr(count), rps,
+                                        nxt[0].data_ptr() if nxt else None, nxt[1].data_ptr() if nxt and len(nxt) > 1 else None,
+                                        _ptr(post[0]) if post else None, _ptr(post[1]) if post else None, post_act, pad, _stream())
         _lib.check(rc, "svdd_trunk_gemm")
 
     def _act(self, x, bn, act, rows, C, rps, pad, planes, count):
@@ -175,8 +179,9 @@ class FusedEnformerValueNet(nn.Module):
             pmax = max((GUARD + rows0 + TAIL) * max(64, self.levels[0]["C"]),
                        max((GUARD + n * ((L >> max(i - 1, 0)) + 5) + TAIL) * lv["C"] for i, lv in enumerate(self.levels)),
                        (GUARD + Tf * n + TAIL) * max(self.pw_out, 2 * self.C))
+            # two sets of operand planes: a GEMM reads one and writes the next GEMM's operands into the other
             ws = {"f": [torch.empty(fmax, dtype=torch.float32, device=dev) for _ in range(4)],
-                  "p": _Planes(pmax, 2, dev), "cmax": cmax}
+                  "p": [_Planes(pmax, self.parts, dev), _Planes(pmax, self.parts, dev)], "cmax": cmax}
             self._ws = {key: ws}                                   # one workspace at a time (GBs at the C4 shard size)
         return ws
 
@@ -198,44 +203,55 @@ class FusedEnformerValueNet(nn.Module):
         dev = tok.device
         ws = self._workspace(n, L, dev)
         f, P = ws["f"], self.parts
-        planes_all = ws["p"]
         lib = _lib.lib()
+        side = 0                                                  # the plane set the NEXT GEMM reads
 
-        def planes(rows, C):
-            return planes_all.view(rows, C)[:P]
+        def planes(rows, C, which):
+            return ws["p"][which].view(rows, C)[:P]
 
-        # ---- conv tower
+        # ---- conv tower. Every GEMM / pooling epilogue writes the operand planes of the GEMM that follows it
+        # (BatchNorm + GELU + hi / lo split fused; round 3a ran a separate element-wise pass per GEMM: 9 ms of 73).
         Lc, rps = L, L + 4
         rows = n * rps
-        ph = planes_all.view(rows, 64)
+        ph = planes(rows, 64, side)
         _lib.check(lib.svdd_trunk_stem_unfold(tok.data_ptr(), n, L, ph[0].data_ptr(), _ptr(count), _stream()), "svdd_trunk_stem_unfold")
         if P == 2:
             ph[1][: rows * 64].zero_()                           # the one-hot operand is exact: its lo plane is zero
-        x = f[0]
-        C = self.levels[0]["C"]
-        self._gemm(ph[:P], self.stem_w, self.stem_b, None, x, rows, C, 64, 1, ACT_NONE, count, rps)
-        cur = 0                                                   # index of the buffer that holds x
+        lv0 = self.levels[0]
+        C = lv0["C"]
+        cur = 0                                                   # index of the fp32 buffer that holds x
+        self._gemm(ph, self.stem_w, self.stem_b, None, f[cur], rows, C, 64, 1, ACT_NONE, count, rps,
+                   nxt=planes(rows, C, 1 - side), post=lv0["b_bn"], post_act=ACT_GELU, pad=2)
+        side = 1 - side
         for i, lv in enumerate(self.levels):
             rows = n * rps
-            if i > 0:                                             # k = 5 block: z = conv5(gelu(bn(x)))
-                pl = planes(rows, lv["a_cin"])
-                self._act(f[cur], lv["a_bn"], ACT_GELU, rows, lv["a_cin"], rps, 2, pl, count)
+            if i > 0:                                             # k = 5 block: z = conv5(gelu(bn(x))); planes of x come from the pool
                 z = f[(cur + 1) % 4]
-                self._gemm(pl, lv["a_w"], lv["a_b"], None, z, rows, lv["a_cout"], lv["a_cin"], 5, ACT_NONE, count, rps)
+                self._gemm(planes(rows, lv["a_cin"], side), lv["a_w"], lv["a_b"], None, z, rows, lv["a_cout"], lv["a_cin"], 5,
+                           ACT_NONE, count, rps, nxt=planes(rows, lv["C"], 1 - side), post=lv["b_bn"], post_act=ACT_GELU, pad=2)
+                side = 1 - side
                 cur = (cur + 1) % 4
             C = lv["C"]
-            pl = planes(rows, C)                                  # 1x1 residual block: y = conv1(gelu(bn(x))) + x
-            self._act(f[cur], lv["b_bn"], ACT_GELU, rows, C, rps, 2, pl, count)
-            y = f[(cur + 1) % 4]
-            self._gemm(pl, lv["b_w"], lv["b_b"], f[cur], y, rows, C, C, 1, ACT_NONE, count, rps)
-            self._act(y, None, ACT_NONE, rows, C, rps, 2, pl, count)          # attention pooling: logits = W_pool y
-            lg = f[(cur + 2) % 4]
-            self._gemm(pl, lv["pool_w"], None, None, lg, rows, C, C, 1, ACT_NONE, count, rps)
+            y = f[(cur + 1) % 4]                                  # 1x1 residual block: y = conv1(gelu(bn(x))) + x ; planes of y for the pool
+            self._gemm(planes(rows, C, side), lv["b_w"], lv["b_b"], f[cur], y, rows, C, C, 1, ACT_NONE, count, rps,
+                       nxt=planes(rows, C, 1 - side), post=None, post_act=ACT_NONE, pad=2)
+            side = 1 - side
+            lg = f[(cur + 2) % 4]                                 # attention pooling: logits = W_pool y
+            self._gemm(planes(rows, C, side), lv["pool_w"], None, None, lg, rows, C, C, 1, ACT_NONE, count, rps)
+            Lo = (Lc + 1) // 2
+            last = i + 1 == len(self.levels)
             xn = f[(cur + 3) % 4]
-            _lib.check(lib.svdd_trunk_attn_pool(y.data_ptr(), lg.data_ptr(), n, Lc, C, xn.data_ptr(), _ptr(count), _stream()),
-                       "svdd_trunk_attn_pool")
+            if last:                                              # the transformer tower takes the fp32 rows
+                args = (xn.data_ptr(), _ptr(count), None, None, None, None, ACT_NONE)
+            else:                                                 # the next level's k = 5 block takes gelu(bn(x)) as planes only
+                nx = self.levels[i + 1]
+                pn = planes(n * (Lo + 4), nx["a_cin"], 1 - side)
+                args = (None, _ptr(count), pn[0].data_ptr(), pn[1].data_ptr() if P == 2 else None, _ptr(nx["a_bn"][0]),
+                        _ptr(nx["a_bn"][1]), ACT_GELU)
+                side = 1 - side
+            _lib.check(lib.svdd_trunk_attn_pool(y.data_ptr(), lg.data_ptr(), n, Lc, C, *args, _stream()), "svdd_trunk_attn_pool")
             cur = (cur + 3) % 4
-            Lc = (Lc + 1) // 2
+            Lc = Lo
             rps = Lc + 4
         # ---- transformer tower on the Lc tokens left (2 for L = 200)
         C = self.C
@@ -244,33 +260,38 @@ class FusedEnformerValueNet(nn.Module):
         rows = n * T
         for d in self.tf:
             h, dk, dv, nq, nv = d["heads"], d["dk"], d["dv"], d["nq"], d["nv"]
-            pl = planes(rows, C)
+            pl = planes(rows, C, 0)
             self._ln(x, d["ln1"], rows, C, pl, count, T)
             nqkv = 2 * nq + nv
             qkv = f[(cur + 1) % 4][: rows * nqkv].view(rows, nqkv)
             self._gemm(pl, d["qkv_w"], None, None, qkv, rows, nqkv, C, 1, ACT_NONE, count, T)
-            q = qkv[:, :nq].view(n, T, h, dk).transpose(1, 2) * dk ** -0.5
-            k = qkv[:, nq:2 * nq].view(n, T, h, dk).transpose(1, 2)
-            v = qkv[:, 2 * nq:].view(n, T, h, dv).transpose(1, 2)
-            rel_logits = _relative_shift(torch.einsum("bhid,hjd->bhij", q + d["pos_bias"], self._rel_k(d, T, dev)))
-            logits = torch.matmul(q + d["content_bias"], k.transpose(-1, -2)) + rel_logits
-            o = torch.matmul(torch.softmax(logits, dim=-1), v).transpose(1, 2).reshape(rows, h * dv).contiguous()
-            pl = planes(rows, h * dv)
-            self._act(o, None, ACT_NONE, rows, h * dv, T, 0, pl, count)
+            pl = planes(rows, h * dv, 1)
+            if T <= 4:                                            # one launch: logits, softmax, weighted sum, hi / lo split
+                rc = lib.svdd_trunk_attn_small(qkv.data_ptr(), self._rel_k(d, T, dev).data_ptr(), d["content_bias"].data_ptr(),
+                                               d["pos_bias"].data_ptr(), n, T, h, dk, dv, pl[0].data_ptr(),
+                                               pl[1].data_ptr() if P == 2 else None, _ptr(count), _stream())
+                _lib.check(rc, "svdd_trunk_attn_small")
+            else:
+                q = qkv[:, :nq].view(n, T, h, dk).transpose(1, 2) * dk ** -0.5
+                k = qkv[:, nq:2 * nq].view(n, T, h, dk).transpose(1, 2)
+                v = qkv[:, 2 * nq:].view(n, T, h, dv).transpose(1, 2)
+                rel_logits = _relative_shift(torch.einsum("bhid,hjd->bhij", q + d["pos_bias"], self._rel_k(d, T, dev)))
+                logits = torch.matmul(q + d["content_bias"], k.transpose(-1, -2)) + rel_logits
+                o = torch.matmul(torch.softmax(logits, dim=-1), v).transpose(1, 2).reshape(rows, h * dv).contiguous()
+                self._act(o, None, ACT_NONE, rows, h * dv, T, 0, pl, count)
             x2 = f[(cur + 2) % 4][: rows * C].view(rows, C)
             self._gemm(pl, d["out_w"], d["out_b"], x, x2, rows, C, h * dv, 1, ACT_NONE, count, T)
-            pl = planes(rows, C)
+            pl = planes(rows, C, 0)
             self._ln(x2, d["ln2"], rows, C, pl, count, T)
-            hid = f[(cur + 1) % 4][: rows * 2 * C].view(rows, 2 * C)
-            self._gemm(pl, d["f1_w"], d["f1_b"], None, hid, rows, 2 * C, C, 1, ACT_RELU, count, T)
-            pl = planes(rows, 2 * C)
-            self._act(hid, None, ACT_NONE, rows, 2 * C, T, 0, pl, count)
+            # FFN: the hidden layer only ever exists as the operand planes of the second GEMM
+            hid = planes(rows, 2 * C, 1)
+            self._gemm(pl, d["f1_w"], d["f1_b"], None, None, rows, 2 * C, C, 1, ACT_RELU, count, T, nxt=hid)
             x3 = f[(cur + 3) % 4][: rows * C].view(rows, C)
-            self._gemm(pl, d["f2_w"], d["f2_b"], x2, x3, rows, C, 2 * C, 1, ACT_NONE, count, T)
+            self._gemm(hid, d["f2_w"], d["f2_b"], x2, x3, rows, C, 2 * C, 1, ACT_NONE, count, T)
             x = x3
             cur = (cur + 3) % 4
         # ---- pointwise block (no residual, no pool) + trunk GELU, then the head: 1x1 conv + mean over length
-        pl = planes(rows, C)
+        pl = planes(rows, C, 0)
         self._act(x, self.pw_bn, ACT_GELU, rows, C, T, 0, pl, count)
         z = f[(cur + 1) % 4][: rows * self.pw_out].view(rows, self.pw_out)
         self._gemm(pl, self.pw_w, self.pw_b, None, z, rows, self.pw_out, C, 1, ACT_GELU, count, T)

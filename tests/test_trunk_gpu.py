@@ -137,16 +137,32 @@ def test_gemm_256_tiles_equal_128_tiles(M, N, Cin, T, rps, live, parts):
     wp = pack_gemm_weight(w, parts).to(DEV)
     cnt = None if live is None else torch.tensor([live], dtype=torch.int32, device=DEV)
     m_live = M if live is None else min(M, live * rps)
-    outs = {}
+    outs, pls = {}, {}
+    ps, pb = (1.0 + 0.1 * torch.randn(N, generator=g)).to(DEV), (0.1 * torch.randn(N, generator=g)).to(DEV)
     for ver in (1, 3):
         _lib.check(lib.svdd_set_option(4, ver), "svdd_set_option")
         out = torch.full((M, N), 7.0, device=DEV)
+        o_hi = torch.full((M, N), 3.0, device=DEV, dtype=torch.bfloat16)
+        o_lo = torch.full((M, N), 3.0, device=DEV, dtype=torch.bfloat16)
         rc = lib.svdd_trunk_gemm(planes[0].data_ptr(), planes[1].data_ptr() if parts == 2 else None, wp.data_ptr(),
                                  bias.to(DEV).data_ptr(), resid.data_ptr(), out.data_ptr(), M, N, Cin, T, Cin, N, 2,
-                                 None if cnt is None else cnt.data_ptr(), rps, None)
+                                 None if cnt is None else cnt.data_ptr(), rps,
+                                 o_hi.data_ptr(), o_lo.data_ptr() if parts == 2 else None, ps.data_ptr(), pb.data_ptr(), 2, 2, None)
         _lib.check(rc, "svdd_trunk_gemm")
         torch.cuda.synchronize()
         outs[ver] = out.cpu()
+        pls[ver] = (o_hi.float().cpu(), o_lo.float().cpu())
+    # the fused second output = what the separate element-wise pass writes from the fp32 output
+    r_hi = torch.full((M, N), 3.0, device=DEV, dtype=torch.bfloat16)
+    r_lo = torch.full((M, N), 3.0, device=DEV, dtype=torch.bfloat16)
+    rc = lib.svdd_trunk_act_split(out.data_ptr(), ps.data_ptr(), pb.data_ptr(), 2, m_live if live is None else M, N, rps, 2,
+                                  r_hi.data_ptr(), r_lo.data_ptr() if parts == 2 else None, None if cnt is None else cnt.data_ptr(), None)
+    _lib.check(rc, "svdd_trunk_act_split")
+    torch.cuda.synchronize()
+    for ver in (1, 3):
+        assert torch.equal(pls[ver][0], r_hi.float().cpu())
+        if parts == 2:
+            assert torch.equal(pls[ver][1], r_lo.float().cpu())
     _lib.check(lib.svdd_set_option(4, 2), "svdd_set_option")
     assert torch.equal(outs[1][:m_live], outs[3][:m_live])
     assert bool((outs[3][m_live:] == 7.0).all())                       # rows beyond the live count are not written

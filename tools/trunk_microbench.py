@@ -16,6 +16,9 @@ dev = "cuda:0"
 _, emb, head, _ = synthetic.build("dna", dev, value="enformer")
 tok = torch.randint(0, 5, (n, 200), device=dev, dtype=torch.uint8)
 fn = FusedEnformerValueNet(emb, head, prec)
+if os.environ.get("SVDD_TRUNK_GEMM"):                  # A/B: 1 = 128 x 128 tiles everywhere, 3 = 256 x 256 everywhere
+    from svdd_amd import _lib
+    _lib.check(_lib.lib().svdd_set_option(4, int(os.environ["SVDD_TRUNK_GEMM"])), "svdd_set_option")
 
 
 def bench(f, it=3):
