@@ -29,7 +29,11 @@ extern "C" int svdd_internal_num_cus();      // svdd_nets.hip
 // svdd_set_option(SVDD_OPT_TRUNK_GEMM_VERSION, v): 1 = the 128 x 128 kernel everywhere (A/B), 2 = automatic (default),
 // 3 = the 256 x 256 kernel everywhere
 static int g_trunk_gemm_version = 2;
-extern "C" void svdd_internal_set_trunk_gemm_version(int v) { g_trunk_gemm_version = (v >= 1 && v <= 3) ? v : 2; }
+static int g_trunk_gemm_dbg = 0;     // timing experiments only (value 13 / 14): 256 x 256 kernel without epilogue / without K loop
+extern "C" void svdd_internal_set_trunk_gemm_version(int v) {
+  g_trunk_gemm_dbg = (v == 13 || v == 14) ? v - 12 : 0;
+  g_trunk_gemm_version = (v >= 1 && v <= 3) ? v : (g_trunk_gemm_dbg ? 3 : 2);
+}
 
 namespace {
 
@@ -55,6 +59,7 @@ struct GemmArgs {
   // fused second output: the NEXT GEMM's operand planes p_act(p_scale y + p_shift) -> (hi, lo) [M][N], zero in the `pad`
   // rows at either end of every sequence (what a separate svdd_trunk_act_split pass over y would write)
   bf16_t* o_hi; bf16_t* o_lo; const float* p_scale; const float* p_shift; int p_act, pad;
+  int dbg;
 };
 
 typedef bf16_t BV4 __attribute__((ext_vector_type(4)));
@@ -318,7 +323,7 @@ __global__ __launch_bounds__(512, 2) void trunk_gemm256_kernel(GemmArgs a) {
     H_MFMA(1)                                                                                                \
     H_BARRIER()                                                                                              \
   }
-  const int KB = a.KB;
+  const int KB = a.dbg == 2 ? 1 : a.KB;
   H_DMA(0, 0)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   H_BARRIER()
@@ -334,21 +339,37 @@ __global__ __launch_bounds__(512, 2) void trunk_gemm256_kernel(GemmArgs a) {
 #undef H_READ_A
 #undef H_READ_W
 #undef H_DMA
-  // epilogue: lane (j, g) holds row 16 i + j, columns 16 nt + 4 g .. + 3 of every tile of its wave
-  if (!cols_ok) return;
-  bool padr[8];
+  // epilogue. Lane (j, g) holds row 16 i + j, columns 16 nt + 4 g .. + 3 of every tile of its wave: stored from there, a
+  // wave instruction touches 16 rows x 64 B (fp32) or 16 rows x 32 B (planes) — partial cache lines, and the epilogues ran at
+  // 1.9 - 3.5 TB/s (profiles/r03_trunk_gemm_epilogue.txt: 17.7 ms of the 45 ms of GEMMs). The accumulators are therefore
+  // turned through a wave-private 64-row x 64-column LDS slab (the K-block buffers are dead by now; row pitch 68 floats:
+  // conflict-free 16-byte writes and reads) and leave row-contiguously: 4 rows x 256 B per fp32 store, 4 rows x 128 B per
+  // plane store, residual rows read the same way. Same arithmetic per element as gemm_store4 from the accumulator layout.
+  if (!cols_ok || a.dbg == 1) return;
+  constexpr int SP = 68;
+  float* const slab = reinterpret_cast<float*>(hsm) + w * (64 * SP);
+  const int rsub = lane >> 4, c4 = (lane & 15) * 4;
+  const int col = nb * H_BN + 64 * wn + c4;
+  f32x4 b4 = {0.0f, 0.0f, 0.0f, 0.0f}, ps4 = {1.0f, 1.0f, 1.0f, 1.0f}, pb4 = {0.0f, 0.0f, 0.0f, 0.0f};
+  if (a.bias) b4 = *reinterpret_cast<const f32x4*>(a.bias + col);
+  if (a.p_scale) { ps4 = *reinterpret_cast<const f32x4*>(a.p_scale + col); pb4 = *reinterpret_cast<const f32x4*>(a.p_shift + col); }
 #pragma unroll
-  for (int i = 0; i < 8; ++i) padr[i] = gemm_pad_row(a, m0 + 128 * wm + 16 * i + j);
+  for (int h = 0; h < 2; ++h) {
 #pragma unroll
-  for (int nt = 0; nt < 4; ++nt) {
-    const int col = nb * H_BN + 64 * wn + 16 * nt + 4 * g;
-    f32x4 b4 = {0.0f, 0.0f, 0.0f, 0.0f}, ps4 = {1.0f, 1.0f, 1.0f, 1.0f}, pb4 = {0.0f, 0.0f, 0.0f, 0.0f};
-    if (a.bias) b4 = *reinterpret_cast<const f32x4*>(a.bias + col);
-    if (a.p_scale) { ps4 = *reinterpret_cast<const f32x4*>(a.p_scale + col); pb4 = *reinterpret_cast<const f32x4*>(a.p_shift + col); }
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int row = m0 + 128 * wm + 16 * i + j;
-      if (row < m_live) gemm_store4(a, row, col, padr[i], acc[i][nt], b4, ps4, pb4);
+      for (int nt = 0; nt < 4; ++nt)
+        *reinterpret_cast<f32x4*>(slab + (16 * i + j) * SP + 16 * nt + 4 * g) = acc[4 * h + i][nt];
+    const int rbase = m0 + 128 * wm + 64 * h + rsub;
+    int pos = a.pad > 0 ? rbase % a.rows_per_seq : 0;
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+      const int row = rbase + 4 * p;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(slab + (4 * p + rsub) * SP + c4);
+      const bool pad_row = a.pad > 0 && (pos < a.pad || pos >= a.rows_per_seq - a.pad);
+      if (row < m_live) gemm_store4(a, row, col, pad_row, v, b4, ps4, pb4);
+      pos += 4;
+      if (pos >= a.rows_per_seq) pos -= a.rows_per_seq;
     }
   }
 }
@@ -601,7 +622,7 @@ int svdd_trunk_gemm(const void* a_hi, const void* a_lo, const void* w, const flo
       out_hi == a_hi || (out_lo && out_lo == a_lo))
     return SVDD_E_ARG;
   GemmArgs a{(const bf16_t*)a_hi, (const bf16_t*)a_lo, (const BV8*)w, bias, resid, out, M, N, T * (Cin / G_BK), Cin / G_BK, T,
-             lda, ldo, act, count, rows_per_seq, (bf16_t*)out_hi, (bf16_t*)out_lo, post_scale, post_shift, post_act, pad};
+             lda, ldo, act, count, rows_per_seq, (bf16_t*)out_hi, (bf16_t*)out_lo, post_scale, post_shift, post_act, pad, g_trunk_gemm_dbg};
   // 256 x 256 tiles from half a chip's worth of tiles on (the 7680-row GEMMs of the transformer tower make 180 - 360 of them and
   // still run 2.3x faster than on 128 x 128 tiles: 0.79 - 0.98 vs 0.37 - 0.42 PFLOP/s); the 128 x 128 kernel below that
   const int mb2 = (M + H_BM - 1) / H_BM, nb2 = (N + H_BN - 1) / H_BN;
@@ -610,11 +631,11 @@ int svdd_trunk_gemm(const void* a_hi, const void* a_lo, const void* w, const flo
   if (big) {
     const dim3 grid((unsigned)(((mb2 + 7) / 8) * 8 * nb2));
     if (a_lo) {
-      constexpr int lds = 2 * 2 * 16 * 2 * 1024;
+      constexpr int lds = 8 * 64 * 68 * 4;                  // the epilogue's 8 wave slabs (139,264 B) > the two K-block buffers (131,072 B)
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(trunk_gemm256_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       hipLaunchKernelGGL(trunk_gemm256_kernel<2>, grid, dim3(512), lds, (hipStream_t)stream, a);
     } else {
-      constexpr int lds = 2 * 2 * 16 * 1 * 1024;
+      constexpr int lds = 8 * 64 * 68 * 4;
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(trunk_gemm256_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       hipLaunchKernelGGL(trunk_gemm256_kernel<1>, grid, dim3(512), lds, (hipStream_t)stream, a);
     }
