@@ -189,3 +189,53 @@ def test_tds_sharded_over_two_ranks_equals_unsharded(tmp_path, total):
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
     assert res.stdout.count("ok") == 2
+
+
+_RCCL_PROBE = r'''
+import os, sys, torch
+sys.path.insert(0, sys.argv[1])
+import torch.distributed as dist
+from svdd_amd import distributed
+rank, world, local = distributed.init_from_env()            # backend "nccl" = RCCL (what bench.py --gpus N uses)
+assert world == 2 or os.environ.get("SVDD_PROBE_ONE_RANK")
+if world == 1:
+    dist.init_process_group(backend="nccl", rank=0, world_size=1)
+torch.cuda.set_device(0)
+dev = "cuda:0"
+assert dist.get_backend() == "nccl"
+dist.all_reduce(torch.zeros(1, device=dev)); dist.barrier(device_ids=[0])
+t = torch.arange(256 * 200, device=dev).remainder(4).to(torch.uint8).view(256, 200)
+out = t.new_empty((dist.get_world_size() * 256, 200))
+dist.all_gather_into_tensor(out, t)                          # distributed.gather_tokens's collective, uint8
+assert torch.equal(out[:256], t)
+tm = torch.tensor([1.5], device=dev, dtype=torch.float64)
+dist.all_reduce(tm, op=dist.ReduceOp.MAX)                    # bench.py: max over ranks of the elapsed time
+mine = torch.tensor([0.25, 0.5], device=dev, dtype=torch.float64)
+allr = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+dist.all_gather(allr, mine)                                  # bench.py: per_rank
+assert float(tm.item()) == 1.5 and float(allr[0][1]) == 0.5
+dist.barrier(device_ids=[0]); dist.destroy_process_group()
+print("RCCL_PROBE_OK")
+'''
+
+
+def test_rccl_collectives_of_the_bench_on_one_rank(tmp_path):
+    """bench.py --gpus N and distributed.gather_tokens over the REAL backend (RCCL), as far as a one-GPU box allows: a
+    one-rank RCCL process group running exactly the collectives the N > 1 bench issues (float32 warm-up all-reduce, barrier
+    with device_ids, uint8 all_gather_into_tensor of the tokens, float64 MAX all-reduce, float64 all_gather). The N-rank
+    logic itself is covered with gloo (tests/test_host_cpu.py, test_tds_sharded_over_two_ranks_equals_unsharded)."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "rccl_probe.py"
+    script.write_text(_RCCL_PROBE)
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               SVDD_PROBE_ONE_RANK="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("SVDD_DIST_BACKEND", None)
+    r = subprocess.run([sys.executable, str(script), root], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "RCCL_PROBE_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
