@@ -112,7 +112,8 @@ def test_mc_decode_with_the_fused_trunk_vs_oracle():
 
 
 @pytest.mark.parametrize("M,N,Cin,T,rps,live", [(1000, 768, 96, 1, 8, None), (2100, 896, 64, 5, 14, None),
-                                                (777, 256, 160, 5, 7, 40), (5000, 1152, 64, 1, 10, 333)])
+                                                (777, 256, 160, 5, 7, 40), (5000, 1152, 64, 1, 10, 333),
+                                                (100, 128, 32, 1, 5, None), (513, 384, 32, 3, 9, 0)])
 @pytest.mark.parametrize("parts", [2, 1])
 def test_gemm_256_tiles_equal_128_tiles(M, N, Cin, T, rps, live, parts):
     """svdd_trunk_gemm's two kernels (128 x 128 register-staged tiles, 256 x 256 LDS-DMA tiles with staggered wave groups)
@@ -174,5 +175,6 @@ def test_gemm_256_tiles_equal_128_tiles(M, N, Cin, T, rps, live, parts):
     ap[2:M + 2] = a_eff
     acc = sum(ap[t - T // 2 + 2: t - T // 2 + 2 + M] @ w_eff[:, :, t].t() for t in range(T)) + bias.double()
     ref = acc / (1.0 + torch.exp(-1.702 * acc)) + resid.cpu().double()
-    err = float((outs[3][:m_live].double() - ref[:m_live]).abs().max())
-    assert err <= (2e-5 if parts == 2 else 1e-4), err
+    if m_live > 0:
+        err = float((outs[3][:m_live].double() - ref[:m_live]).abs().max())
+        assert err <= (2e-5 if parts == 2 else 1e-4), err
