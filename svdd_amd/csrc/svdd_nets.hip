@@ -1612,27 +1612,15 @@ __global__ __launch_bounds__(512, 2) void backbone_kernel(BackboneArgs a) {
     const int dil = __builtin_amdgcn_readfirstlane(sdil[layer < nl ? layer : BB_MAXL]);
     const int layer_end = (layer + 1) * 36;
     __syncthreads();                                      // the image is complete
-    while (it < layer_end) {
-      const int nxt = en >> 19;
-      const int en_next_v = sched[nxt < it_end ? nxt : it];
-      const float bf0[8] = {bn[0].x, bn[0].y, bn[0].z, bn[0].w, bn[1].x, bn[1].y, bn[1].z, bn[1].w};
-      const float bf1[8] = {bn[2].x, bn[2].y, bn[2].z, bn[2].w, bn[3].x, bn[3].y, bn[3].z, bn[3].w};
-      if (nxt < it_end) {
-        const float* src = wsrc + (size_t)tile_of(nxt) * BB_C * CH;
-        bn[0] = *reinterpret_cast<const float4*>(src);
-        bn[1] = *reinterpret_cast<const float4*>(src + 4);
-        bn[2] = *reinterpret_cast<const float4*>(src + 16 * CH);
-        bn[3] = *reinterpret_cast<const float4*>(src + 16 * CH + 4);
-      }
-      const int delta = (((en >> 15) & 15) - 4) * dil;
-      const int coff = ((en >> 13) & 3) * (CH * 4);
-      const int dbytes = delta * (BB_AP * 4) + coff;
-      const int live = en >> rh;                          // bit 2 r = owned tile r
-#define B2_ALOAD(R, V)                                                                                       \
+    // A fragments of row tiles 0 and 1 of an entry are requested during the LAST MFMA groups of the entry before it (first
+    // entry of a layer: right here), so that the matrix pipe does not run dry at every (chunk, tap) boundary while both waves
+    // of a SIMD wait for their first LDS reads (round 3; same bits: only the loads move). A wave with 7 row tiles ends an
+    // entry on the fragment set it began with, so its two sets trade roles from entry to entry (two copies of the body).
+#define B2_ALOAD(R, V, DELTA, COFF, DBYTES)                                                                  \
       { int o_;                                                                                              \
-        if (SPT1) o_ = min(max(arow0 + dbytes + (R) * (32 * BB_AP * 4), a_lo + coff), a_hi + coff);          \
-        else o_ = ((unsigned)(apos[SPT1 ? 0 : (R)] + delta) < (unsigned)L ? arow0 + dbytes + (R) * (32 * BB_AP * 4) \
-                                                                            : a_hi + coff);                  \
+        if (SPT1) o_ = min(max(arow0 + (DBYTES) + (R) * (32 * BB_AP * 4), a_lo + (COFF)), a_hi + (COFF));    \
+        else o_ = ((unsigned)(apos[SPT1 ? 0 : (R)] + (DELTA)) < (unsigned)L ? arow0 + (DBYTES) + (R) * (32 * BB_AP * 4) \
+                                                                             : a_hi + (COFF));               \
         const float4* ap_ = reinterpret_cast<const float4*>(imgb + o_);                                      \
         V[0] = ap_[0]; V[1] = ap_[1]; }
 #define B2_WAIT(NOUT) __builtin_amdgcn_s_waitcnt(0xC07F | ((NOUT) << 8));
@@ -1652,30 +1640,72 @@ __global__ __launch_bounds__(512, 2) void backbone_kernel(BackboneArgs a) {
         }                                                                                                    \
       }                                                                                                      \
       __builtin_amdgcn_sched_barrier(0);
-      float4 ua[2], ub[2];
-      B2_ALOAD(0, ua) B2_ALOAD(1, ub)
-      B2_MM(0, ua, 2)
-      B2_ALOAD(2, ua)
-      B2_MM(1, ub, 2)
-      B2_ALOAD(3, ub)
-      B2_MM(2, ua, 2)
-      B2_ALOAD(4, ua)
-      B2_MM(3, ub, 2)
-      B2_ALOAD(5, ub)
-      B2_MM(4, ua, 2)
-      if (rh == 0) {
-        B2_ALOAD(6, ua)
-        B2_MM(5, ub, 2)
-        B2_MM(6, ua, 0)
-      } else {
-        B2_MM(5, ub, 0)
+    // entry parameters from a schedule word
+#define B2_PARAMS(EN, DELTA, COFF, DBYTES)                                                                   \
+      const int DELTA = ((((EN) >> 15) & 15) - 4) * dil;                                                     \
+      const int COFF = (((EN) >> 13) & 3) * (CH * 4);                                                        \
+      const int DBYTES = DELTA * (BB_AP * 4) + COFF;
+    // one (chunk, tap) entry; UA holds (or is receiving) row tile 0, UB row tile 1
+#define B2_ENTRY(UA, UB)                                                                                     \
+    { const int nxt = en >> 19;                                                                              \
+      const int en_next_v = sched[nxt < it_end ? nxt : it];                                                  \
+      const float bf0[8] = {bn[0].x, bn[0].y, bn[0].z, bn[0].w, bn[1].x, bn[1].y, bn[1].z, bn[1].w};         \
+      const float bf1[8] = {bn[2].x, bn[2].y, bn[2].z, bn[2].w, bn[3].x, bn[3].y, bn[3].z, bn[3].w};         \
+      if (nxt < it_end) {                                                                                    \
+        const float* src = wsrc + (size_t)tile_of(nxt) * BB_C * CH;                                          \
+        bn[0] = *reinterpret_cast<const float4*>(src);                                                       \
+        bn[1] = *reinterpret_cast<const float4*>(src + 4);                                                   \
+        bn[2] = *reinterpret_cast<const float4*>(src + 16 * CH);                                             \
+        bn[3] = *reinterpret_cast<const float4*>(src + 16 * CH + 4);                                         \
+      }                                                                                                      \
+      B2_PARAMS(en, delta, coff, dbytes)                                                                     \
+      const int live = en >> rh;                          /* bit 2 r = owned tile r */                       \
+      /* (after a layer's last entry the "next entry" loads below read the dying image with the wrong dilation: clamped \
+         addresses, values never used — the layer prologue reloads both sets; cheaper than a second copy of the MFMA groups) */ \
+      B2_MM(0, UA, 3)                                     /* in flight: tile 1 (2 reads) + the schedule word */ \
+      B2_ALOAD(2, UA, delta, coff, dbytes)                                                                   \
+      B2_MM(1, UB, 2)                                                                                        \
+      const int en2 = __builtin_amdgcn_readfirstlane(en_next_v);                                             \
+      B2_PARAMS(en2, delta2, coff2, dbytes2)                                                                 \
+      B2_ALOAD(3, UB, delta, coff, dbytes)                                                                   \
+      B2_MM(2, UA, 2)                                                                                        \
+      B2_ALOAD(4, UA, delta, coff, dbytes)                                                                   \
+      B2_MM(3, UB, 2)                                                                                        \
+      B2_ALOAD(5, UB, delta, coff, dbytes)                                                                   \
+      B2_MM(4, UA, 2)                                                                                        \
+      if (rh == 0) {                                                                                         \
+        B2_ALOAD(6, UA, delta, coff, dbytes)                                                                 \
+        B2_MM(5, UB, 2)                                                                                      \
+        B2_ALOAD(0, UB, delta2, coff2, dbytes2)           /* next entry: tile 0 in UB, tile 1 in UA */       \
+        B2_MM(6, UA, 2)                                                                                      \
+        B2_ALOAD(1, UA, delta2, coff2, dbytes2)                                                              \
+      } else {                                                                                               \
+        B2_ALOAD(0, UA, delta2, coff2, dbytes2)                                                              \
+        B2_MM(5, UB, 2)                                                                                      \
+        B2_ALOAD(1, UB, delta2, coff2, dbytes2)                                                              \
+      }                                                                                                      \
+      it = nxt;                                                                                              \
+      en = en2; }
+    float4 ua[2], ub[2];
+    if (it < layer_end) {
+      B2_PARAMS(en, delta0, coff0, dbytes0)
+      B2_ALOAD(0, ua, delta0, coff0, dbytes0)
+      B2_ALOAD(1, ub, delta0, coff0, dbytes0)
+    }
+    if (rh == 0) {
+      while (it < layer_end) {
+        B2_ENTRY(ua, ub)
+        if (it >= layer_end) break;
+        B2_ENTRY(ub, ua)
       }
+    } else {
+      while (it < layer_end) B2_ENTRY(ua, ub)
+    }
+#undef B2_ENTRY
+#undef B2_PARAMS
 #undef B2_MM
 #undef B2_WAIT
 #undef B2_ALOAD
-      it = nxt;
-      en = __builtin_amdgcn_readfirstlane(en_next_v);
-    }
     __syncthreads();                                      // every wave is done reading the image
     if (layer < nl) {
 #pragma unroll
