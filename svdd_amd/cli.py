@@ -37,6 +37,14 @@ def build_parser(method="mc"):
     p.add_argument("--tweedie", default="True", help='"True": posterior-mean scoring (decode_tweedie.py:206)')
     p.add_argument("--alpha", type=float, default=0.5)                               # decode_TDS.py:183
     p.add_argument("--guidance_scale", type=float, default=1e5)                      # decode_DPS.py:184
+    p.add_argument("--model", default="convgru", choices=["convgru", "enformer"],
+                   help="value-function trunk: convgru = ConvGRUTrunk + ConvHead (Enformer.py:32-49; BASELINE configs 1-3, SURVEY "
+                        "section 8d); enformer = the 230 M-parameter EnformerTrunk(7, 1536, 11, 8, 64) + ConvHead(1, 3072) the "
+                        "reference's decode.py:78-80 builds for --model enformer (BASELINE configs[3])")                   # decode.py:149
+    p.add_argument("--precision", default="f32", choices=["f32", "f16x3", "bf16x3", "f16", "bf16"],
+                   help="f32: exact fp32 net kernels (default, the parity reference); x3: fp32 operands split hi + lo on the 16-bit "
+                        "matrix cores (fp32-class error); f16 / bf16: one pass. With --model enformer any non-f32 mode runs the "
+                        "hand-written trunk kernels (bf16x3 / bf16); f32 runs the PyTorch module")
     p.add_argument("--rng", default="replay", choices=["replay", "philox"],
                    help="replay: the reference's torch-CPU RNG stream; philox: in-kernel counter RNG")
     p.add_argument("--diffusion_ckpt", default=None)
@@ -55,7 +63,8 @@ def run(args):
 
     set_seed(args.seed)
     reward_name = args.reward_name or ("HepG2" if args.task == "dna" else "MRL")
-    ref_model, embedding, head, reward = synthetic.build(args.task, "cuda", seed=args.seed)
+    ref_model, embedding, head, reward = synthetic.build(args.task, "cuda", seed=args.seed, value=args.model)
+    ref_model.precision = args.precision
     if args.diffusion_ckpt:
         sd = torch.load(args.diffusion_ckpt, map_location="cpu")
         ref_model.load_state_dict(sd.get("state_dict", sd), strict=False)

@@ -178,3 +178,32 @@ def test_gemm_256_tiles_equal_128_tiles(M, N, Cin, T, rps, live, parts):
     if m_live > 0:
         err = float((outs[3][:m_live].double() - ref[:m_live]).abs().max())
         assert err <= (2e-5 if parts == 2 else 1e-4), err
+
+
+def test_cli_mc_with_the_enformer_value_trunk(tmp_path):
+    """decode.py --model enformer (reference decode.py:72-80,149: the Enformer-shaped trunk as value function) through the CLI
+    mirror with --precision bf16x3: the hand-written trunk kernels score the candidates; npz contract of decode.py:117."""
+    from svdd_amd import cli
+    from svdd_amd.config import SamplingConfig
+    from svdd_amd.fused_trunk import FusedEnformerValueNet
+    import svdd_amd.synthetic as syn
+    orig = syn.build
+    seen = {}
+
+    def small_build(task, device, seed=44, value="convgru", **kw):
+        m = orig(task, device, seed=seed, value=value,
+                 enformer_kwargs=dict(n_conv=4, channels=768, n_transformers=2, n_heads=4, key_len=16))
+        m[0].config.sampling = SamplingConfig(steps=4)
+        seen["model"], seen["emb"], seen["head"] = m[0], m[1], m[2]
+        return m
+
+    syn.build = small_build
+    try:
+        path, out = cli.main("mc", ["--task", "dna", "--model", "enformer", "--precision", "bf16x3", "--batch_size", "3",
+                                    "--sample_M", "4", "--val_batch_num", "1", "--out_dir", str(tmp_path), "--rng", "philox"])
+    finally:
+        syn.build = orig
+    assert isinstance(seen["model"].value_callable(seen["emb"], seen["head"]), FusedEnformerValueNet)
+    z = np.load(path)
+    assert path.endswith("dna-HepG2.npz") and set(z.files) == {"decoding", "baseline"}
+    assert z["decoding"].shape == (3,) and np.isfinite(z["decoding"]).all() and np.isfinite(z["baseline"]).all()
