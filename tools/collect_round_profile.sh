@@ -56,4 +56,20 @@ for mode, pat in (("f16x3", r"backbone_lp_t_kernelIDF16_Li3E"), ("bf16x3", r"bac
 out["backbone_lp_traffic_bytes_per_launch"] = lp
 json.dump(out, open(sys.argv[2], "w"), indent=1)
 PY
+# K2 / K4 at saturation: HBM bytes actually moved (the gather of 200-byte rows over-fetches) -> ${TAG}_pmc_k2_raw.txt
+: > $OUT/${TAG}_pmc_k2_raw.txt
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/pmc_k2
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_k2 -- python3 /root/repo/tools/resample_microbench.py > /dev/null 2>&1
+  python3 - $(find /tmp/pmc_k2 -name "*counter_collection.csv" | head -1) $c >> $OUT/${TAG}_pmc_k2_raw.txt <<'PY'
+import csv, sys, collections
+agg = collections.defaultdict(list)
+for r in csv.DictReader(open(sys.argv[1])):
+    n = r["Kernel_Name"]
+    if "select_rows" in n or "tds_" in n:
+        agg[(n[:70], r["Grid_Size"])].append(float(r["Counter_Value"]))
+for k, v in sorted(agg.items()):
+    print("%s per dispatch (KB) %-72s grid=%-8s n=%d mean=%.1f" % (sys.argv[2], k[0], k[1], len(v), sum(v) / len(v)))
+PY
+done
 cat $OUT/${TAG}_bench.json | cut -c1-400; cat $OUT/${TAG}_pmc.txt; cat $OUT/${TAG}_own_kernels_trace_summary.txt
