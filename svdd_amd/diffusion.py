@@ -837,5 +837,7 @@ class Diffusion(nn.Module):
         x = torch.full((B, L), self.mask_index, dtype=torch.uint8, device=self.device)
         carry = self._tds_carry(reward_model, L)
         for i in range(S):
+            if self.state_trace is not None:
+                self.state_trace.append(x.detach().clone())
             x = self._tds_step(x, sched[i, 2], sched[i, 1], reward_model, alpha, i, carry)
         return self._noise_removal(x, carry.get("logits") if carry else None)

@@ -147,3 +147,121 @@ def teacher_forced_report(g, model, emb, head, precision="f32"):
             "selection_agreement": float(agree.mean()), "row_steps": int(agree.size),
             "disagreeing_row_steps": int((~agree).sum()),
             "max_reference_top2_gap_where_selection_differs": max(gaps) if gaps else None}
+
+
+def teacher_forced_pm_report(g, model, reward_model, precision="f32"):
+    """The SVDD-PM twin of teacher_forced_report, on a recorded reference controlled_sample_tweedie(options="True") run `g`
+    with full-size nets (tests/golden/g18_traj_pm_full_rna.npz; reference diffusion_gosai.py:1105-1145, 1373-1460): every
+    state x_t and every candidate set goes through the one-launch backbone kernel (L = 50: several sequences per tile), the
+    x0-hat one-hots (:1415-1419) are rebuilt from the GPU's candidate logits and compared with what the reward model saw in
+    the reference run, and the reward model (hand-written tower / GRU / tail kernels) scores the REFERENCE's one-hots."""
+    from . import ops
+    S, B, L, M = int(g["S"]), int(g["B"]), int(g["L"]), int(g["M"])
+    dev = model.device
+    model.fuse_nets, model.precision = True, precision
+    fn = model.reward_callable(reward_model)
+    dl, dcl, ds = np.zeros(S + 1), np.zeros(S), np.zeros(S)
+    oh_same, oh_total = 0, 0
+    agree = np.zeros((S, B), dtype=bool)
+    gaps = []
+    with torch.no_grad():
+        for i in range(S + 1):
+            x = torch.from_numpy(g["xs"][i]).to(dev).contiguous()
+            dl[i] = float((model._backbone_logits(x).cpu() - torch.from_numpy(g["logits"][i])).abs().max())
+            if i == S:
+                break
+            cand = torch.from_numpy(g["cand"][i]).to(dev).contiguous()                 # [B, M, L]
+            flat = cand.view(B * M, L)
+            cl = model._backbone_logits(flat)
+            dcl[i] = float((cl.cpu().view(B, M, L, 5) - torch.from_numpy(g["cand_logits"][i])).abs().max())
+            oh, _ = ops.x0hat(cl, flat)
+            ref_oh = torch.from_numpy(g["x0hat_onehot_t"][i].astype(np.float32)).view(B * M, 4, L)
+            same_rows = (oh.cpu() == ref_oh).all(dim=2).all(dim=1)
+            oh_same += int(same_rows.sum())
+            oh_total += B * M
+            sc = fn(ref_oh.to(dev))[:, 0].reshape(B, M).float()
+            ref = torch.from_numpy(g["scores"][i])
+            ds[i] = float((sc.cpu() - ref).abs().max())
+            x_next, _, _ = ops.select(sc.contiguous(), cand, mode=ops.SELECT_ARGMAX, want_soft=False)
+            agree[i] = (x_next.cpu().numpy() == g["xs"][i + 1]).all(axis=1)
+            for b in np.nonzero(~agree[i])[0]:
+                top = np.sort(g["scores"][i][b])[::-1]
+                gaps.append(float(top[0] - top[1]))
+    model.precision = "f32"
+    return {"S": S, "B": B, "L": L, "M": M, "precision": precision, "steps_compared": S + 1,
+            "hand_written_net_kernels": bool(isinstance(fn, torch.nn.Module) and fn is not reward_model),
+            "max_abs_logit_err": float(dl.max()), "max_abs_candidate_logit_err": float(dcl.max()),
+            "max_abs_score_err": float(ds.max()), "x0hat_rows_identical": oh_same / max(oh_total, 1),
+            "selection_agreement": float(agree.mean()), "disagreeing_row_steps": int((~agree).sum()),
+            "max_reference_top2_gap_where_selection_differs": max(gaps) if gaps else None}
+
+
+def free_running_pm_report(g, model, reward_model, precision="f32"):
+    """Free-running controlled_sample_tweedie in replay mode with the hand-written net kernels against the reference's run."""
+    S, B, M = int(g["S"]), int(g["B"]), int(g["M"])
+    model.fuse_nets, model.rng_mode, model.precision = True, "replay", precision
+    model.state_trace = []
+    torch.manual_seed(int(g["seed"]))
+    with torch.no_grad():
+        x0 = model.controlled_sample_tweedie(reward_model, num_steps=S, eval_sp_size=B, sample_M=M, options="True")
+    torch.cuda.synchronize()
+    xs = np.stack([x.cpu().numpy() for x in model.state_trace])
+    model.state_trace = None
+    model.precision = "f32"
+    n = min(len(xs), S + 1)
+    same = (xs[:n] == g["xs"][:n]).all(axis=2)
+    first = next((i for i in range(n) if not same[i].all()), None)
+    x0n = x0.cpu().numpy()
+    return {"precision": precision, "states_recorded": int(len(xs)), "first_divergence_step": first,
+            "x0_exact": bool(np.array_equal(x0n, g["x0"])), "x0_rows_identical": float((x0n == g["x0"]).all(axis=1).mean())}
+
+
+def tds_reference_run_report(g, model, reward_model, precision="f32"):
+    """A recorded reference controlled_sample_TDS run `g` with full-size nets (tests/golden/g19_traj_tds_full.npz; reference
+    diffusion_gosai.py:938-978, 1230-1284). Teacher-forced: every x_t and every proposal through the one-launch backbone, the
+    numerator / denominator rewards (:1263-1277) through the hand-written reward kernels on the x0-hat of the GPU's logits.
+    Free-running: the engine's decode in replay mode (torch + numpy streams seeded as in the reference run; exact reuse of
+    forward(sample) and of the numerator reward across steps) against the reference's states and x_0."""
+    from . import ops
+    S, B, L = int(g["S"]), int(g["B"]), int(g["L"])
+    dev = model.device
+    model.fuse_nets, model.precision = True, precision
+    fn = model.reward_callable(reward_model)
+    dl, dsl, dnum, dden = np.zeros(S + 1), np.zeros(S), np.zeros(S), np.zeros(S)
+    oh_same, oh_total = 0, 0
+    with torch.no_grad():
+        for i in range(S + 1):
+            x = torch.from_numpy(g["xs"][i]).to(dev).contiguous()
+            lg = model._backbone_logits(x)
+            dl[i] = float((lg.cpu() - torch.from_numpy(g["logits"][i])).abs().max())
+            if i == S:
+                break
+            smp = torch.from_numpy(g["samples"][i]).to(dev).contiguous()
+            ls = model._backbone_logits(smp)
+            dsl[i] = float((ls.cpu() - torch.from_numpy(g["sample_logits"][i])).abs().max())
+            # the reward model is scored on the x0-hat of the REFERENCE's logits (what it saw in the reference run); how often the
+            # GPU logits give the same x0-hat rows is reported separately (an argmax over 4 near-uniform logits can flip at a tie)
+            oh_num, _ = ops.x0hat(torch.from_numpy(g["sample_logits"][i]).to(dev).contiguous(), smp)
+            oh_den, _ = ops.x0hat(torch.from_numpy(g["den_logits"][i]).to(dev).contiguous(), x)
+            for mine, ref_oh in ((ops.x0hat(ls, smp)[0], oh_num), (ops.x0hat(lg, x)[0], oh_den)):
+                oh_same += int((mine == ref_oh).all(dim=2).all(dim=1).sum())
+                oh_total += B
+            dnum[i] = float((fn(oh_num)[:, 0][:, 0].float().cpu() - torch.from_numpy(g["num"][i])).abs().max())
+            dden[i] = float((fn(oh_den)[:, 0][:, 0].float().cpu() - torch.from_numpy(g["den"][i])).abs().max())
+    model.rng_mode, model.state_trace = "replay", []
+    torch.manual_seed(int(g["seed"]))
+    np.random.seed(int(g["np_seed"]))
+    with torch.no_grad():
+        x0 = model.controlled_sample_TDS(reward_model, float(g["alpha"]), num_steps=S, eval_sp_size=B)
+    torch.cuda.synchronize()
+    xs = [x.cpu().numpy() for x in model.state_trace]
+    model.state_trace = None
+    model.precision = "f32"
+    n = min(len(xs), S + 1)
+    first = next((i for i in range(n) if not np.array_equal(xs[i], g["xs"][i])), None)
+    x0n = x0.cpu().numpy()
+    return {"precision": precision, "hand_written_net_kernels": bool(isinstance(fn, torch.nn.Module) and fn is not reward_model),
+            "max_abs_logit_err": float(dl.max()), "max_abs_proposal_logit_err": float(dsl.max()),
+            "max_abs_reward_num_err": float(dnum.max()), "max_abs_reward_den_err": float(dden.max()),
+            "x0hat_rows_identical": oh_same / max(oh_total, 1), "states_recorded": len(xs), "first_divergence_step": first, "x0_exact": bool(np.array_equal(x0n, g["x0"])),
+            "x0_rows_identical": float((x0n == g["x0"]).all(axis=1).mean())}

@@ -34,6 +34,14 @@ outputs are stored. Fixtures:
                               STAND-IN = this repo's restatement of its five symbols (svdd_amd/enformer_value.py), so the fixture
                               pins the reference's OWN wiring (conv tower, block order NACDR, residuals, transformer block,
                               feed-forward, pointwise, head) and not the attention math: pinned up to that stand-in
+  g18_traj_mc_full_rna.npz    controlled_sample with the FULL-SIZE nets at L = 50 (the RNA configs' length: several sequences share a
+                              208-row kernel tile), B=6, M=5, S=24: every step's state, logits, candidates, scores (as g13)
+  g18_traj_pm_full_rna.npz    controlled_sample_tweedie(options="True") — BASELINE configs[2]'s sampler — with the FULL-SIZE nets and a
+                              full-size ConvGRU reward model (the fifth / sixth module synthetic.build("rna") creates), B=4, M=4, S=16:
+                              states, logits, candidates, candidate logits, the x0-hat one-hots the reward model saw, scores
+  g19_traj_tds_full.npz       controlled_sample_TDS (BASELINE configs[4]'s SMC baseline) with the FULL-SIZE nets and reward model at L = 200,
+                              B=8, S=10, alpha=0.5: states, proposals, the three backbone outputs of a step, both reward vectors,
+                              numpy's uniforms
   g12_fullsize_probe.npz      FULL-SIZE reference nets (CNNModel hidden 128 x 4 stacks; ConvGRUTrunk 64 ch, n_conv 6 +
                               ConvHead) built at torch.manual_seed(44) in the order svdd_amd/synthetic.py builds them,
                               evaluated on 4 probe rows: logits, value scores, a checksum of every parameter tensor
@@ -331,10 +339,15 @@ def traj_pm(seed=3):
 
 
 # ----------------------------------------------------------------------------- G8
-def traj_tds(seed=4, np_seed=9, alpha=0.5):
-    L, S, B = 50, 8, 6
-    d = tiny_diffusion(L, S)
-    emb_m, head_m = tiny_value()
+def traj_tds(seed=4, np_seed=9, alpha=0.5, full=False):
+    if full:                                            # g19: the reference's full-size classes, seed 44 (synthetic.build's order)
+        L, S, B = 200, 10, 8
+        d, emb_v, head_v = full_nets(length=L, steps=S)
+        emb_m, head_m = full_reward()
+    else:
+        L, S, B = 50, 8, 6
+        d = tiny_diffusion(L, S)
+        emb_m, head_m = tiny_value()
     reward = RewardWrap(emb_m, head_m).eval()
     rec = RecBackbone(d.backbone)
     d.backbone = rec
@@ -354,10 +367,16 @@ def traj_tds(seed=4, np_seed=9, alpha=0.5):
     np.random.seed(np_seed)
     choice_u = np.random.random_sample(S * B).reshape(S, B)
     d.backbone = rec.inner
-    save("g8_traj_tds.npz", xs=torch.stack(xs).to(torch.uint8), logits=torch.stack(logits),
+    extra = {}
+    if full:
+        extra = {n_ + "_param_sums": np.array([float(p.double().sum()) for p in mod.state_dict().values()])
+                 for n_, mod in (("backbone", d.backbone), ("embedding", emb_v), ("head", head_v), ("reward_embedding", emb_m),
+                                 ("reward_head", head_m))}
+        extra["sched"] = sched_rows(d, S)
+    save("g19_traj_tds_full.npz" if full else "g8_traj_tds.npz", xs=torch.stack(xs).to(torch.uint8), logits=torch.stack(logits),
          samples=torch.stack(samples).to(torch.uint8), sample_logits=torch.stack(s_logits),
          den_logits=torch.stack(den_logits), num=num, den=den, choice_u=choice_u, x0=x0, alpha=alpha,
-         seed=seed, np_seed=np_seed, B=B, L=L, S=S)
+         seed=seed, np_seed=np_seed, B=B, L=L, S=S, **extra)
 
 
 # ----------------------------------------------------------------------------- G10
@@ -466,18 +485,61 @@ def full_nets(seed=44, length=200, steps=128):
     return d, emb, head
 
 
-def g13_traj_mc_full(name, S, B, M, seed):
+def full_reward():
+    """The reward model synthetic.build creates right after (backbone, embedding, head): a second ConvGRU trunk + head drawn
+    from the same RNG stream (stand-in for the gReLU oracle, Enformer.py:103-131)."""
+    emb = En.ConvGRUTrunk(stem_in_channels=4, stem_channels=64, stem_kernel_size=15, n_conv=6, channel_init=64,
+                          channel_mult=1, kernel_size=5, act_func="relu", conv_norm=True, pool_func=None,
+                          pool_size=None, residual=True, crop_len=0, n_gru=1, dropout=0.1, gru_norm=True).eval()
+    head = En.ConvHead(n_tasks=1, in_channels=64, act_func=None, pool_func="avg", norm=False).eval()
+    return emb, head
+
+
+def g18_traj_pm_full_rna(seed=21):
+    """BASELINE configs[2]'s sampler (controlled_sample_tweedie, options="True": diffusion_gosai.py:1105-1145, 1373-1460) run by
+    the reference with FULL-SIZE nets at L = 50: per step one backbone call on x_t and M on the candidates, the reward model on
+    the x0-hat one-hots. Weights are not stored: seed 44 in synthetic.build("rna")'s order reproduces them (parameter sums kept)."""
+    L, S, B, M = 50, 16, 4, 4
+    d, emb_v, head_v = full_nets(length=L, steps=S)
+    emb_r, head_r = full_reward()
+    reward = RewardWrap(emb_r, head_r).eval()
+    rec = RecBackbone(d.backbone)
+    d.backbone = rec
+    rr = RecCallable(reward)
+    torch.manual_seed(seed)
+    x0 = d.controlled_sample_tweedie(rr, eval_sp_size=B, sample_M=M, options="True", task="dna")
+    calls = rec.calls
+    xs, logits, cx, cl = [], [], [], []
+    k = 0
+    for _ in range(S):
+        xs.append(calls[k][0]); logits.append(calls[k][1]); k += 1
+        cx.append(torch.stack([calls[k + m][0] for m in range(M)], 1))
+        cl.append(torch.stack([calls[k + m][1] for m in range(M)], 1))
+        k += M
+    xs.append(calls[k][0]); logits.append(calls[k][1])
+    assert k + 1 == len(calls)
+    scores = torch.stack([o[:, 0].squeeze() for o in rr.outputs]).view(S, M, B).permute(0, 2, 1).contiguous()
+    x0hat_oh = torch.stack(rr.inputs).view(S, M, B, 4, L).permute(0, 2, 1, 3, 4).contiguous()
+    d.backbone = rec.inner
+    arrs = {n_ + "_param_sums": np.array([float(p.double().sum()) for p in mod.state_dict().values()])
+            for n_, mod in (("backbone", d.backbone), ("embedding", emb_v), ("head", head_v), ("reward_embedding", emb_r),
+                            ("reward_head", head_r))}
+    save("g18_traj_pm_full_rna.npz", xs=torch.stack(xs).to(torch.uint8), logits=torch.stack(logits),
+         cand=torch.stack(cx).to(torch.uint8), cand_logits=torch.stack(cl), x0hat_onehot_t=x0hat_oh.to(torch.uint8),
+         scores=scores, x0=x0, seed=seed, net_seed=44, B=B, L=L, M=M, S=S, sched=sched_rows(d, S), **arrs)
+
+
+def g13_traj_mc_full(name, S, B, M, seed, L=200):
     """A whole reference controlled_sample run (diffusion_gosai.py:1021-1061, 1174-1228) with the FULL-SIZE random-init
     nets (the ones bench.py times), recording every step: the state x_t, the raw backbone output, the M candidates and
     their value scores. The -m gpu tests feed these states to the hand-written net kernels (teacher forcing) and compare
     every step's logits / scores; the weights are not stored: seed 44 in synthetic.build's order reproduces them (g12)."""
-    d, emb_m, head_m = full_nets(steps=S)
+    d, emb_m, head_m = full_nets(steps=S, length=L)
     rec = RecBackbone(d.backbone)
     d.backbone = rec
     emb, head = RecCallable(emb_m), RecCallable(head_m)
     torch.manual_seed(seed)
     x0 = d.controlled_sample(emb, head, eval_sp_size=B, sample_M=M)
-    L = 200
     xs = torch.stack([c[0] for c in rec.calls])
     logits = torch.stack([c[1] for c in rec.calls])
     onehots = torch.stack(emb.inputs).view(S, M, B, L, 4)
@@ -679,6 +741,12 @@ def g17_enformer_trunk(seed=71):
          shapes=np.array([list(sh) + [-1] * (maxr - len(sh)) for sh in shapes], dtype=np.int64))
 
 
+def g18():
+    g13_traj_mc_full("g18_traj_mc_full_rna.npz", S=24, B=6, M=5, seed=5, L=50)
+    g18_traj_pm_full_rna()
+    traj_tds(seed=31, np_seed=32, full=True)            # g19
+
+
 def new_round3():
     g13_traj_mc_full("g13_traj_mc_full_c1.npz", S=128, B=4, M=2, seed=0)
     g13_traj_mc_full("g13_traj_mc_full_m10.npz", S=32, B=4, M=10, seed=2)
@@ -688,11 +756,15 @@ def new_round3():
     g15_step(d, 20)
     g16_dit()
     g17_enformer_trunk()
+    g18()
 
 
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "g12":
         g12_fullsize_probe()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "g18":
+        g18()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "g17":
         g17_enformer_trunk()

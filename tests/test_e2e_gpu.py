@@ -112,3 +112,91 @@ def test_fullsize_free_running_decode_vs_reference_run(golden, full_nets, fixtur
         fd = rep["first_divergence"]
         assert max(abs(v) for v in fd["gpu_minus_ref_scores"]) <= TOL, rep
         assert fd["reference_score_gap_top2"] is None or fd["reference_score_gap_top2"] <= 2 * TOL, rep
+
+
+# ------------------------------------------------------------------ g18: full-size nets at L = 50 (the RNA configs' length)
+@pytest.fixture(scope="module")
+def rna_nets():
+    from svdd_amd import synthetic
+    return synthetic.build("rna", DEV)
+
+
+def _same_nets(g, pairs):
+    for name, mod in pairs:
+        sums = np.array([float(p.double().sum()) for p in mod.state_dict().values()])
+        assert np.allclose(sums, g[name + "_param_sums"], rtol=0, atol=1e-6), name
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3", "bf16x3"])
+def test_net_kernels_on_the_reference_trajectory_short_sequences(golden, rna_nets, precision):
+    """g18 (MC): the reference's full-size run at L = 50, where several sequences share a 208-row tile of the backbone /
+    tower kernels (the multi-sequence code paths g13's L = 200 never enters). Teacher-forced at every step, then
+    free-running in replay mode."""
+    from svdd_amd import e2e_parity
+    g = golden("g18_traj_mc_full_rna.npz")
+    model, emb, head, _ = rna_nets
+    _same_nets(g, (("backbone", model.backbone), ("embedding", emb), ("head", head)))
+    rep = e2e_parity.teacher_forced_report(g, model, emb, head, precision)
+    assert rep["steps_compared"] == int(g["S"]) + 1
+    assert rep["max_abs_logit_err"] <= TOL, rep
+    for k in ("whole_tower", "windows", "compact"):
+        assert rep["max_abs_score_err_" + k] <= TOL, rep
+    if rep["disagreeing_row_steps"]:
+        assert rep["max_reference_top2_gap_where_selection_differs"] <= 2 * TOL, rep
+    run = e2e_parity.compare_engine_with_reference_run(g, model, emb, head, True, "batched", precision)
+    assert run["hand_written_net_kernels"]
+    assert run["max_abs_logit_err_on_undiverged_rows"] <= TOL and run["max_abs_score_err_on_undiverged_rows"] <= TOL, run
+    if run["first_divergence_step"] is None:
+        assert run["x0_exact"], run
+    else:
+        fd = run["first_divergence"]
+        assert max(abs(v) for v in fd["gpu_minus_ref_scores"]) <= TOL, run
+        assert fd["reference_score_gap_top2"] is None or fd["reference_score_gap_top2"] <= 2 * TOL, run
+    print("g18 mc", precision, rep["max_abs_logit_err"], rep["max_abs_score_err_whole_tower"], rep["selection_agreement"],
+          run["first_divergence_step"], run["x0_exact"])
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3", "bf16x3"])
+def test_pm_sampler_on_the_reference_trajectory_full_size(golden, rna_nets, precision):
+    """g18 (PM): BASELINE configs[2]'s sampler — controlled_sample_tweedie(options="True") — as the reference ran it with
+    full-size nets and a full-size ConvGRU reward model: x_t and candidate logits through the one-launch backbone, the x0-hat
+    one-hots, the reward scores through the hand-written tower / GRU / tail kernels, at every step; then the free-running
+    decode (exact work-skipping on) in replay mode."""
+    from svdd_amd import e2e_parity
+    g = golden("g18_traj_pm_full_rna.npz")
+    model, emb, head, reward = rna_nets
+    _same_nets(g, (("backbone", model.backbone), ("embedding", emb), ("head", head), ("reward_embedding", reward.embedding),
+                   ("reward_head", reward.head)))
+    rep = e2e_parity.teacher_forced_pm_report(g, model, reward, precision)
+    assert rep["hand_written_net_kernels"]
+    assert rep["max_abs_logit_err"] <= TOL and rep["max_abs_candidate_logit_err"] <= TOL, rep
+    assert rep["max_abs_score_err"] <= TOL, rep
+    assert rep["x0hat_rows_identical"] >= 0.95, rep          # an argmax over 4 near-uniform logits may flip at a last-bit tie
+    if rep["disagreeing_row_steps"]:
+        assert rep["max_reference_top2_gap_where_selection_differs"] <= 2 * TOL, rep
+    run = e2e_parity.free_running_pm_report(g, model, reward, precision)
+    assert run["states_recorded"] >= int(g["S"])
+    if precision == "f32" and run["first_divergence_step"] is None:
+        assert run["x0_exact"], run
+    print("g18 pm", precision, rep["max_abs_logit_err"], rep["max_abs_candidate_logit_err"], rep["max_abs_score_err"],
+          rep["x0hat_rows_identical"], rep["selection_agreement"], run)
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3", "bf16x3"])
+def test_tds_on_the_reference_trajectory_full_size(golden, full_nets, precision):
+    """g19: BASELINE configs[4]'s SMC / TDS baseline as the reference ran it with full-size nets (L = 200, 8 particles, 10
+    steps): logits of states and proposals, numerator / denominator rewards at every step (teacher-forced), then the
+    engine's own decode — which reuses forward(sample) and the numerator reward across steps instead of recomputing them
+    as the reference does — against the reference's x_0."""
+    from svdd_amd import e2e_parity
+    g = golden("g19_traj_tds_full.npz")
+    model, emb, head, reward = full_nets
+    _same_nets(g, (("backbone", model.backbone), ("embedding", emb), ("head", head), ("reward_embedding", reward.embedding),
+                   ("reward_head", reward.head)))
+    rep = e2e_parity.tds_reference_run_report(g, model, reward, precision)
+    assert rep["hand_written_net_kernels"]
+    assert rep["max_abs_logit_err"] <= TOL and rep["max_abs_proposal_logit_err"] <= TOL, rep
+    assert rep["max_abs_reward_num_err"] <= TOL and rep["max_abs_reward_den_err"] <= TOL, rep
+    if precision == "f32":
+        assert rep["first_divergence_step"] is None and rep["x0_exact"], rep
+    print("g19 tds", rep)

@@ -111,7 +111,7 @@ def test_g6_trajectory_stepwise(golden, name):
     assert np.array_equal(orc.finalize(bvl(g["logits"][S]), x, layout=orc.BVL), g["x0"])
 
 
-@pytest.mark.parametrize("name", ["g13_traj_mc_full_c1.npz", "g13_traj_mc_full_m10.npz"])
+@pytest.mark.parametrize("name", ["g13_traj_mc_full_c1.npz", "g13_traj_mc_full_m10.npz", "g18_traj_mc_full_rna.npz"])
 def test_g13_fullsize_trajectory_stepwise(golden, name):
     """The reference's controlled_sample with its FULL-SIZE random-init nets (BASELINE configs[0], and an M = 10 run): the
     oracle, fed the recorded logits / scores, reproduces every candidate set, every x_t and x_0. With these nets the
@@ -169,8 +169,11 @@ def test_g15_step_at_reference_widths(golden, M):
     assert np.array_equal(x_next, g["x_next"])
 
 
-def test_g7_tweedie_trajectory_stepwise(golden):
-    g = golden("g7_traj_pm.npz")
+@pytest.mark.parametrize("name", ["g7_traj_pm.npz", "g18_traj_pm_full_rna.npz"])
+def test_g7_tweedie_trajectory_stepwise(golden, name):
+    """controlled_sample_tweedie(options="True") runs of the reference (g7: tiny nets; g18: full-size nets + full-size reward
+    model at L = 50): candidates, x0-hat one-hots, selections and x_0 from the recorded logits / scores."""
+    g = golden(name)
     S, B, L, M = int(g["S"]), int(g["B"]), int(g["L"]), int(g["M"])
     sched = golden("g3_schedule.npz")[f"S{S}"]
     mt = orc.MT19937(int(g["seed"]))
@@ -187,10 +190,12 @@ def test_g7_tweedie_trajectory_stepwise(golden):
     assert np.array_equal(orc.finalize(bvl(g["logits"][S]), x, layout=orc.BVL), g["x0"])
 
 
-def test_g8_tds_trajectory_stepwise(golden):
-    g = golden("g8_traj_tds.npz")
+@pytest.mark.parametrize("name", ["g8_traj_tds.npz", "g19_traj_tds_full.npz"])
+def test_g8_tds_trajectory_stepwise(golden, name):
+    """controlled_sample_TDS runs of the reference (g8: tiny nets, L = 50; g19: full-size nets + reward model, L = 200)."""
+    g = golden(name)
     S, B, L = int(g["S"]), int(g["B"]), int(g["L"])
-    sched = golden("g3_schedule.npz")[f"S{S}"]
+    sched = g["sched"] if "sched" in g else golden("g3_schedule.npz")[f"S{S}"]
     mt = orc.MT19937(int(g["seed"]))
     npmt = orc.MT19937(int(g["np_seed"]))
     x = np.full((B, L), 4, dtype=np.uint8)

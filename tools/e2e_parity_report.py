@@ -15,11 +15,25 @@ for name in ("g6_traj_mc_c1.npz", "g6_traj_mc_s16.npz"):
     g = dict(np.load(os.path.join(G, name)))
     out["tiny_nets_free_running"][name] = [e2e_parity.compare_with_reference_run(g, nets, fuse_nets=True, value_batching=vb)
                                            for vb in ("batched", "reference")]
-model, emb, head, _ = synthetic.build("dna", "cuda:0")
+model, emb, head, reward = synthetic.build("dna", "cuda:0")
 for name in ("g13_traj_mc_full_c1.npz", "g13_traj_mc_full_m10.npz"):
     g = dict(np.load(os.path.join(G, name)))
     out["fullsize_teacher_forced"][name] = [e2e_parity.teacher_forced_report(g, model, emb, head, p)
                                             for p in ("f32", "f16x3", "bf16x3", "f16", "bf16")]
     out["fullsize_free_running"][name] = [e2e_parity.compare_engine_with_reference_run(g, model, emb, head, True, "batched", p)
                                           for p in ("f32", "f16x3", "bf16x3")]
+# g19: the SMC / TDS baseline on the reference's full-size run (teacher-forced errors + the engine's free-running decode)
+g = dict(np.load(os.path.join(G, "g19_traj_tds_full.npz")))
+out["fullsize_tds"] = {"g19_traj_tds_full.npz": [e2e_parity.tds_reference_run_report(g, model, reward, p) for p in ("f32", "f16x3", "bf16x3")]}
+# g18: full-size nets at L = 50 (several sequences per kernel tile): SVDD-MC and SVDD-PM (Tweedie)
+rna, emb_r, head_r, reward_r = synthetic.build("rna", "cuda:0")
+g = dict(np.load(os.path.join(G, "g18_traj_mc_full_rna.npz")))
+out["fullsize_teacher_forced"]["g18_traj_mc_full_rna.npz"] = [e2e_parity.teacher_forced_report(g, rna, emb_r, head_r, p)
+                                                              for p in ("f32", "f16x3", "bf16x3", "f16", "bf16")]
+out["fullsize_free_running"]["g18_traj_mc_full_rna.npz"] = [
+    e2e_parity.compare_engine_with_reference_run(g, rna, emb_r, head_r, True, "batched", p) for p in ("f32", "f16x3", "bf16x3")]
+g = dict(np.load(os.path.join(G, "g18_traj_pm_full_rna.npz")))
+out["fullsize_pm"] = {"g18_traj_pm_full_rna.npz": [
+    {"teacher_forced": e2e_parity.teacher_forced_pm_report(g, rna, reward_r, p), "free_running": e2e_parity.free_running_pm_report(g, rna, reward_r, p)}
+    for p in ("f32", "f16x3", "bf16x3")]}
 print(json.dumps(out, indent=1))
