@@ -42,6 +42,8 @@ outputs are stored. Fixtures:
   g19_traj_tds_full.npz       controlled_sample_TDS (BASELINE configs[4]'s SMC baseline) with the FULL-SIZE nets and reward model at L = 200,
                               B=8, S=10, alpha=0.5: states, proposals, the three backbone outputs of a step, both reward vectors,
                               numpy's uniforms
+  g20_traj_dps_full.npz       controlled_sample_DPS (configs[4]'s gradient-guidance baseline) with the FULL-SIZE nets and reward model, L = 200,
+                              B=3, S=4, guidance scale 300 (factors up to 1.06): per step the guided q_xs, the uniforms, the gradient (as g11)
   g12_fullsize_probe.npz      FULL-SIZE reference nets (CNNModel hidden 128 x 4 stacks; ConvGRUTrunk 64 ch, n_conv 6 +
                               ConvHead) built at torch.manual_seed(44) in the order svdd_amd/synthetic.py builds them,
                               evaluated on 4 probe rows: logits, value scores, a checksum of every parameter tensor
@@ -393,12 +395,17 @@ def g10(seed=6):
 
 
 # ----------------------------------------------------------------------------- G11
-def traj_dps(seed=12, scale=50.0):
+def traj_dps(seed=12, scale=50.0, full=False):
     """controlled_sample_DPS (diffusion_gosai.py:980-1019, 1286-1330), S=6, B=3, L=50: per step the guided
-    q_xs handed to _sample_categorical, the uniforms it drew and the result."""
-    L, S, B = 50, 6, 3
-    d = tiny_diffusion(L, S)
-    emb_m, head_m = tiny_value()
+    q_xs handed to _sample_categorical, the uniforms it drew and the result. full: g20, the full-size classes at L = 200."""
+    if full:
+        L, S, B = 200, 4, 3
+        d, emb_v, head_v = full_nets(length=L, steps=S)
+        emb_m, head_m = full_reward()
+    else:
+        L, S, B = 50, 6, 3
+        d = tiny_diffusion(L, S)
+        emb_m, head_m = tiny_value()
     reward = RewardWrap(emb_m, head_m).eval()
     rec = {"q": [], "u": [], "x": [], "grad": []}
     orig_sc, orig_rl, orig_grad = dg._sample_categorical, torch.rand_like, d.compute_gradient_DPS
@@ -426,8 +433,14 @@ def traj_dps(seed=12, scale=50.0):
         dg._sample_categorical, torch.rand_like, d.compute_gradient_DPS = orig_sc, orig_rl, orig_grad
     q = torch.stack(rec["q"])
     print("DPS q_xs strides", rec["q"][0].stride(), "u strides", rec["u"][0].stride())
-    save("g11_traj_dps.npz", xs=torch.stack(rec["x"]).to(torch.uint8), q=q, q_is_bvl=int(rec["q"][0].stride()[1] == 1),
-         u=torch.stack(rec["u"]), grad=torch.stack(rec["grad"]), x0=x0, seed=seed, scale=scale, B=B, L=L, S=S)
+    extra = {}
+    if full:
+        extra = {n_ + "_param_sums": np.array([float(p.double().sum()) for p in mod.state_dict().values()])
+                 for n_, mod in (("backbone", d.backbone), ("embedding", emb_v), ("head", head_v), ("reward_embedding", emb_m),
+                                 ("reward_head", head_m))}
+    save("g20_traj_dps_full.npz" if full else "g11_traj_dps.npz", xs=torch.stack(rec["x"]).to(torch.uint8), q=q,
+         q_is_bvl=int(rec["q"][0].stride()[1] == 1), u=torch.stack(rec["u"]), grad=torch.stack(rec["grad"]), x0=x0, seed=seed,
+         scale=scale, B=B, L=L, S=S, **extra)
 
 
 def nets():
@@ -745,6 +758,7 @@ def g18():
     g13_traj_mc_full("g18_traj_mc_full_rna.npz", S=24, B=6, M=5, seed=5, L=50)
     g18_traj_pm_full_rna()
     traj_tds(seed=31, np_seed=32, full=True)            # g19
+    traj_dps(seed=41, scale=300.0, full=True)           # g20 (scale * autograd noise ~ 3e-5: q stays comparable at 1e-4)
 
 
 def new_round3():

@@ -147,6 +147,39 @@ def full_nets():
     return synthetic.build("dna", DEV)
 
 
+def test_dps_whole_step_full_size_reference_run(golden, full_nets):
+    """g20: the reference's controlled_sample_DPS with its FULL-SIZE nets and reward model (L = 200, B = 3, 4 steps, guidance
+    scale 300: factors up to 1.06. The gradient of a 20-layer fp32 backward differs between MIOpen and the CPU's MKL-DNN by
+    ~2e-7 absolute, 1e-3 of its size, so q = q0 * exp(scale * gradient) is comparable at 1e-4 only while scale * 2e-7 << 1e-4;
+    at scale 1e4 the same run differs by 2e-3 in q) on the GPU, step by step as for g11: the guided q_xs — exp(scale * gradient) of an
+    autograd pass through forward2 and the reward net (MIOpen's fused GRU backward) — within 1e-4 relative of the reference's
+    CPU autograd, the draw with the reference's uniforms gives its next state, the free-running decode its x_0."""
+    from svdd_amd import ops
+    g = golden("g20_traj_dps_full.npz")
+    S, B, L, scale = int(g["S"]), int(g["B"]), int(g["L"]), float(g["scale"])
+    model, emb, head, reward = full_nets
+    for name, mod in (("backbone", model.backbone), ("reward_embedding", reward.embedding), ("reward_head", reward.head)):
+        sums = np.array([float(p.double().sum()) for p in mod.state_dict().values()])
+        assert np.allclose(sums, g[name + "_param_sums"], rtol=0, atol=1e-6), name
+    sched = model._schedule(S, 1e-5)[0]
+    worst = 0.0
+    for i in range(S):
+        x = dev(g["xs"][i])
+        q = model._dps_guided_q(x, sched[i, 1], sched[i, 2], reward, scale)
+        ref = g["q"][i]
+        worst = max(worst, float(np.abs(q.cpu().numpy() - ref).max() / np.abs(ref).max()))
+        assert np.allclose(q.cpu().numpy(), ref, rtol=1e-4, atol=1e-4), np.abs(q.cpu().numpy() - ref).max()
+        u = dev(np.ascontiguousarray(np.swapaxes(g["u"][i], 1, 2))[None])
+        cand, _ = ops.sample_categorical(q, x, 1, ops.Rng(uniforms=u, uniforms_layout=ops.LAYOUT_BVL))
+        if i + 1 < S:
+            assert np.array_equal(cand.cpu().numpy()[:, 0], g["xs"][i + 1]), f"step {i}"
+    model.rng_mode = "replay"
+    torch.manual_seed(int(g["seed"]))
+    x0 = model.controlled_sample_DPS(reward, scale, num_steps=S, eval_sp_size=B)
+    assert np.array_equal(x0.cpu().numpy(), g["x0"])
+    print("g20 dps: max |q - q_ref| / max|q_ref| =", worst)
+
+
 def test_dps_at_config5_shape_full_size_nets(full_nets):
     """BASELINE configs[4], DPS half, at a shard slice: B = 32, L = 200, the full-size backbone (autograd through
     forward2) and reward net. Valid tokens; zero guidance is the un-guided ancestral decode (same Philox draws); guidance

@@ -310,3 +310,27 @@ def test_bench_starts_its_own_ranks_from_a_bare_shell():
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "0"],
                          capture_output=True, text=True, timeout=300, env=env, cwd="/tmp")
     assert bad.returncode != 0
+
+
+def test_dps_gradient_matches_reference_full_size(golden):
+    """g20: compute_gradient_DPS of the PyTorch mirrors (CNNModel.forward2 + ConvGRU reward model, seed 44 in synthetic.build's
+    order) against the gradients of the reference's own full-size controlled_sample_DPS run, on the CPU: same framework, same
+    kernels — the mirrors must reproduce the reference's autograd to rounding (this is what pins forward2 at full size; the
+    GPU test compares the guided q_xs)."""
+    from svdd_amd import synthetic
+    g = golden("g20_traj_dps_full.npz")
+    torch.set_num_threads(4)
+    model, _, _, reward = synthetic.build("dna", "cpu")
+    for name, mod in (("backbone", model.backbone), ("reward_embedding", reward.embedding), ("reward_head", reward.head)):
+        sums = np.array([float(p.double().sum()) for p in mod.state_dict().values()])
+        assert np.allclose(sums, g[name + "_param_sums"], rtol=0, atol=1e-6), name
+    for p in model.backbone.parameters():
+        p.requires_grad_(False)
+    for i in range(2):                                        # two of the four steps: a few seconds of CPU autograd
+        x = torch.from_numpy(g["xs"][i].astype(np.int64))
+        onehot = torch.nn.functional.one_hot(x, 5).float()
+        copy = (x != 4).to(x.dtype)
+        with torch.enable_grad():
+            grad = model.compute_gradient_DPS(onehot, x, reward, torch.zeros(x.shape[0]), copy)
+        ref = torch.from_numpy(g["grad"][i])
+        assert float((grad - ref).abs().max()) <= 1e-3 * float(ref.abs().max()), (i, float((grad - ref).abs().max()), float(ref.abs().max()))
