@@ -359,8 +359,8 @@ enum { SVDD_OPT_FORCE_EXACT = 0,
        SVDD_OPT_BACKBONE_LP_VERSION = 3 /* A/B: 1 = svdd_backbone_cnn_lp runs the round-2 kernel for every shape; 2 (default) = the
                                             transposed-accumulator kernel where one sequence fills a tile (104 < L <= 208) */,
        SVDD_OPT_TRUNK_GEMM_VERSION = 4 /* A/B: svdd_trunk_gemm kernel: 1 = 128 x 128 tiles everywhere, 2 (default) = 256 x 256 LDS-DMA
-                                           tiles from 128 tiles up, 3 = 256 x 256 everywhere (13 / 14: timing experiments with
-                                           wrong results: no epilogue / one K block) */ };
+                                           tiles from 128 tiles up, 3 = 256 x 256 everywhere (13 .. 16: timing experiments with
+                                           wrong results: no epilogue / one K block / no DMA / no fragment reads) */ };
 int svdd_set_option(int key, int value);
 
 /* Soak / profiling aid: while `device_counters2` (two zero-initialised uint64 on the device) is non-NULL, every

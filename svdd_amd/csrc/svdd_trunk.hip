@@ -29,9 +29,10 @@ extern "C" int svdd_internal_num_cus();      // svdd_nets.hip
 // svdd_set_option(SVDD_OPT_TRUNK_GEMM_VERSION, v): 1 = the 128 x 128 kernel everywhere (A/B), 2 = automatic (default),
 // 3 = the 256 x 256 kernel everywhere
 static int g_trunk_gemm_version = 2;
-static int g_trunk_gemm_dbg = 0;     // timing experiments only (value 13 / 14): 256 x 256 kernel without epilogue / without K loop
+static int g_trunk_gemm_dbg = 0;     // timing experiments only (13 / 14 / 15 / 16): 256 x 256 kernel without epilogue / with one K block /
+                                     // no epilogue + no LDS-DMA in the K loop / no epilogue + no fragment reads in the K loop
 extern "C" void svdd_internal_set_trunk_gemm_version(int v) {
-  g_trunk_gemm_dbg = (v == 13 || v == 14) ? v - 12 : 0;
+  g_trunk_gemm_dbg = (v >= 13 && v <= 16) ? v - 12 : 0;
   g_trunk_gemm_version = (v >= 1 && v <= 3) ? v : (g_trunk_gemm_dbg ? 3 : 2);
 }
 
@@ -217,8 +218,9 @@ __global__ __launch_bounds__(256, 2) void trunk_gemm_kernel(GemmArgs a) {
 //     MFMA fragment order and every fragment read is ds_read_b128 at base + 16 lane — conflict-free by construction
 //     (the 80-byte row pitch of the kernel above spent a third of its LDS cycles on bank conflicts); the weights are
 //     stored in that order by the host, their DMA is a straight copy;
-//   * LDS holds two K blocks (2 x 64 KB for hi + lo planes of both operands); K block s + 1 is requested while s is
-//     multiplied and waited for (vmcnt(0)) two segments later;
+//   * LDS holds three stages of the activation operand and two of the weights (5 x 32 KB for hi + lo planes: all 160 KB of
+//     a CU): the A tile of K block s + 2 and the W tile of s + 1 are requested while s is multiplied, the wait is counted
+//     (the first version had two stages of both and waited vmcnt(0): the DMA was a quarter of the K loop);
 //   * the two waves of a SIMD (wm = 0 / 1) run HALF A PHASE APART: a phase = [load segment: fragment reads (+ DMA
 //     issue)] barrier [compute segment: 48 MFMAs] barrier, and wave group 1 starts one barrier late, so that on every
 //     SIMD one wave multiplies while its partner reads (MI355X_MICROARCH.md, "Two waves per SIMD").
@@ -230,7 +232,7 @@ __global__ __launch_bounds__(512, 2) void trunk_gemm256_kernel(GemmArgs a) {
   extern __shared__ __attribute__((aligned(1024))) char hsm[];
   constexpr int SUB_B = 1024;                               // one 16 x 32 sub-tile of one part
   constexpr int OPER_B = 16 * NPARTS * SUB_B;               // the 16 sub-tiles of an operand: [sub][part][1 KB]
-  constexpr int BUF_B = 2 * OPER_B;                         // A operand, then W operand
+  constexpr int W_BASE = 3 * OPER_B;                        // LDS: three A stages, then two W stages (x3: 5 x 32 KB = all 160 KB)
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
   typedef const __attribute__((address_space(1))) void* glb_ptr_t;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -264,32 +266,39 @@ __global__ __launch_bounds__(512, 2) void trunk_gemm256_kernel(GemmArgs a) {
   const BV8* wsrc = a.w + ((size_t)(2 * nb + (w >> 2)) * 8 + ((2 * w) & 7)) * (NPARTS * 64) + lane;
   const size_t wstep = (size_t)NB128 * 8 * NPARTS * 64;      // V8s per K block
   char* const stage_a = hsm + (2 * w) * NPARTS * SUB_B;
-  char* const stage_w = hsm + OPER_B + (2 * w) * NPARTS * SUB_B;
-#define H_DMA(KB_, BUF)                                                                                      \
+  char* const stage_w = hsm + W_BASE + (2 * w) * NPARTS * SUB_B;
+  // The DMA of a K block is what the K loop waits for (timing experiments 13 / 15, profiles/r03_trunk_gemm_dma.txt: 30.4 ms of
+  // K loops with it, 22.8 ms without — 2.16 PFLOP/s): eight 1 KB pieces per wave cost the issuing wave ~150 cycles each
+  // inside a load segment, and with two stages in LDS the A tile (an HBM stream) had little more than one segment to land.
+  // So: the activation operand gets THREE stages and is requested a whole K block ahead, the weights (L2-resident) two; the
+  // four A pieces go out in a K block's second load segment, the four W pieces in its first, and the wait is counted
+  // (vmcnt(4): the pieces just issued stay in flight across the barrier).
+#define H_DMA_A(KB_, ABUF)                                                                                   \
   { const int kb_ = (KB_);                                                                                   \
     const int c_ = kb_ / a.T, t_ = kb_ - c_ * a.T;                                                           \
     const int64_t koff_ = (int64_t)(t_ - a.T / 2) * a.lda + 32 * c_;                                         \
     _Pragma("unroll") for (int q = 0; q < 2; ++q)                                                            \
       _Pragma("unroll") for (int p = 0; p < NPARTS; ++p)                                                     \
         __builtin_amdgcn_global_load_lds((glb_ptr_t)(asrc[q] + koff_ + p * lo_off),                          \
-                                         (lds_ptr_t)(stage_a + (BUF) * BUF_B + (q * NPARTS + p) * SUB_B), 16, 0, 0); \
-    if (wstage_ok) {                                                                                         \
-      const BV8* ws_ = wsrc + (size_t)kb_ * wstep;                                                           \
-      _Pragma("unroll") for (int q = 0; q < 2 * NPARTS; ++q)                                                 \
-        __builtin_amdgcn_global_load_lds((glb_ptr_t)(ws_ + q * 64),                                          \
-                                         (lds_ptr_t)(stage_w + (BUF) * BUF_B + q * SUB_B), 16, 0, 0);        \
-    } }
+                                         (lds_ptr_t)(stage_a + (ABUF) * OPER_B + (q * NPARTS + p) * SUB_B), 16, 0, 0); }
+#define H_DMA_W(KB_, WBUF)                                                                                   \
+  if (wstage_ok) {                                                                                           \
+    const BV8* ws_ = wsrc + (size_t)(KB_) * wstep;                                                           \
+    _Pragma("unroll") for (int q = 0; q < 2 * NPARTS; ++q)                                                   \
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(ws_ + q * 64),                                            \
+                                       (lds_ptr_t)(stage_w + (WBUF) * OPER_B + q * SUB_B), 16, 0, 0);        \
+  }
   const char* const frag_a = hsm + (8 * wm) * NPARTS * SUB_B + 16 * lane;
-  const char* const frag_w = hsm + OPER_B + (4 * wn) * NPARTS * SUB_B + 16 * lane;
+  const char* const frag_w = hsm + W_BASE + (4 * wn) * NPARTS * SUB_B + 16 * lane;
   BV8 bf[4][NPARTS], af[4][NPARTS];
-#define H_READ_W(BUF)                                                                                        \
+#define H_READ_W(WBUF)                                                                                       \
   _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                           \
     _Pragma("unroll") for (int p = 0; p < NPARTS; ++p)                                                       \
-      bf[nt][p] = *reinterpret_cast<const BV8*>(frag_w + (BUF) * BUF_B + (nt * NPARTS + p) * SUB_B);
-#define H_READ_A(BUF, H)                                                                                     \
+      bf[nt][p] = *reinterpret_cast<const BV8*>(frag_w + (WBUF) * OPER_B + (nt * NPARTS + p) * SUB_B);
+#define H_READ_A(ABUF, H)                                                                                    \
   _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                              \
     _Pragma("unroll") for (int p = 0; p < NPARTS; ++p)                                                       \
-      af[i][p] = *reinterpret_cast<const BV8*>(frag_a + (BUF) * BUF_B + ((4 * (H) + i) * NPARTS + p) * SUB_B);
+      af[i][p] = *reinterpret_cast<const BV8*>(frag_a + (ABUF) * OPER_B + ((4 * (H) + i) * NPARTS + p) * SUB_B);
   // the three passes of a product go to the same accumulator: 16 independent MFMAs between dependent ones
 #define H_MFMA(H)                                                                                            \
   if (cols_ok) {                                                                                             \
@@ -308,29 +317,44 @@ __global__ __launch_bounds__(512, 2) void trunk_gemm256_kernel(GemmArgs a) {
     __builtin_amdgcn_s_setprio(0);                                                                           \
   }
 #define H_BARRIER() { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
-  // K block S (LDS buffer BUF): two phases of [load segment | barrier | compute segment | barrier]
-#define H_KBLOCK(S, BUF)                                                                                     \
+  // K block S (A stage ABUF = S % 3, W stage WBUF = S % 2): two phases of [load segment | barrier | compute segment | barrier]
+#define H_KBLOCK(S, ABUF, WBUF)                                                                              \
   if ((S) < KB) {                                                                                            \
-    if (cols_ok) { H_READ_W(BUF) H_READ_A(BUF, 0) }                                                          \
-    if ((S) + 1 < KB) H_DMA((S) + 1, 1 - (BUF))                                                              \
+    if (cols_ok && (a.dbg != 4 || (S) == 0)) { H_READ_W(WBUF) H_READ_A(ABUF, 0) }                            \
+    if ((S) + 1 < KB && a.dbg != 3) H_DMA_W((S) + 1, 1 - (WBUF))                                             \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                       \
     H_BARRIER()                                                                                              \
     H_MFMA(0)                                                                                                \
     H_BARRIER()                                                                                              \
-    if (cols_ok) { H_READ_A(BUF, 1) }                                                                        \
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   /* K block S + 1 has landed (this wave's share) */ \
+    if (cols_ok && a.dbg != 4) { H_READ_A(ABUF, 1) }                                                         \
+    if ((S) + 2 < KB && a.dbg != 3) {                                                                        \
+      H_DMA_A((S) + 2, ((ABUF) + 2) % 3)                                                                     \
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(2 * NPARTS) : "memory");   /* K block S + 1 has landed; S + 2's A stays in flight */ \
+    } else {                                                                                                 \
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                            \
+    }                                                                                                        \
     H_BARRIER()                                                                                              \
     H_MFMA(1)                                                                                                \
     H_BARRIER()                                                                                              \
   }
   const int KB = a.dbg == 2 ? 1 : a.KB;
-  H_DMA(0, 0)
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  H_DMA_A(0, 0)
+  H_DMA_W(0, 0)
+  if (KB > 1) {
+    H_DMA_A(1, 1)
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NPARTS) : "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
   H_BARRIER()
   if (wm == 1) H_BARRIER()                                  // wave group 1 runs one segment behind group 0
-  for (int s = 0; s < KB; s += 2) {
-    H_KBLOCK(s, 0)
-    H_KBLOCK(s + 1, 1)
+  for (int s = 0; s < KB; s += 6) {
+    H_KBLOCK(s, 0, 0)
+    H_KBLOCK(s + 1, 1, 1)
+    H_KBLOCK(s + 2, 2, 0)
+    H_KBLOCK(s + 3, 0, 1)
+    H_KBLOCK(s + 4, 1, 0)
+    H_KBLOCK(s + 5, 2, 1)
   }
   if (wm == 0) H_BARRIER()
 #undef H_KBLOCK
@@ -338,14 +362,15 @@ __global__ __launch_bounds__(512, 2) void trunk_gemm256_kernel(GemmArgs a) {
 #undef H_MFMA
 #undef H_READ_A
 #undef H_READ_W
-#undef H_DMA
+#undef H_DMA_W
+#undef H_DMA_A
   // epilogue. Lane (j, g) holds row 16 i + j, columns 16 nt + 4 g .. + 3 of every tile of its wave: stored from there, a
   // wave instruction touches 16 rows x 64 B (fp32) or 16 rows x 32 B (planes) — partial cache lines, and the epilogues ran at
   // 1.9 - 3.5 TB/s (profiles/r03_trunk_gemm_epilogue.txt: 17.7 ms of the 45 ms of GEMMs). The accumulators are therefore
   // turned through a wave-private 64-row x 64-column LDS slab (the K-block buffers are dead by now; row pitch 68 floats:
   // conflict-free 16-byte writes and reads) and leave row-contiguously: 4 rows x 256 B per fp32 store, 4 rows x 128 B per
   // plane store, residual rows read the same way. Same arithmetic per element as gemm_store4 from the accumulator layout.
-  if (!cols_ok || a.dbg == 1) return;
+  if (!cols_ok || a.dbg == 1 || a.dbg >= 3) return;
   constexpr int SP = 68;
   float* const slab = reinterpret_cast<float*>(hsm) + w * (64 * SP);
   const int rsub = lane >> 4, c4 = (lane & 15) * 4;
@@ -631,11 +656,11 @@ int svdd_trunk_gemm(const void* a_hi, const void* a_lo, const void* w, const flo
   if (big) {
     const dim3 grid((unsigned)(((mb2 + 7) / 8) * 8 * nb2));
     if (a_lo) {
-      constexpr int lds = 8 * 64 * 68 * 4;                  // the epilogue's 8 wave slabs (139,264 B) > the two K-block buffers (131,072 B)
+      constexpr int lds = 5 * 16 * 2 * 1024;                // three A stages + two W stages = 163,840 B (all of a CU's LDS); the epilogue's 8 wave slabs take 139,264 B of it
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(trunk_gemm256_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       hipLaunchKernelGGL(trunk_gemm256_kernel<2>, grid, dim3(512), lds, (hipStream_t)stream, a);
     } else {
-      constexpr int lds = 8 * 64 * 68 * 4;
+      constexpr int lds = 8 * 64 * 68 * 4;                  // one-pass mode: the stages take 81,920 B, the epilogue slabs 139,264 B
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(trunk_gemm256_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       hipLaunchKernelGGL(trunk_gemm256_kernel<1>, grid, dim3(512), lds, (hipStream_t)stream, a);
     }

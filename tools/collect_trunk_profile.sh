@@ -14,8 +14,8 @@ for v in 1 2; do
   SVDD_TRUNK_GEMM=$v python3 /root/repo/tools/trunk_microbench.py 3840 bf16 2>/dev/null | tail -1 >> $OUT/${TAG}_trunk_gemm_versions.txt
 done
 : > $OUT/${TAG}_trunk_gemm_epilogue.txt
-for v in 13 14; do
-  echo "## debug version $v (13: no epilogue, 14: one K block + epilogue; results are garbage, timing only)" >> $OUT/${TAG}_trunk_gemm_epilogue.txt
+for v in 13 14 15 16; do
+  echo "## debug version $v (13: no epilogue, 14: one K block + epilogue, 15: no epilogue + no LDS-DMA in the K loop, 16: no epilogue + no fragment reads; results are garbage, timing only)" >> $OUT/${TAG}_trunk_gemm_epilogue.txt
   SVDD_TRUNK_GEMM=$v python3 /root/repo/tools/trunk_microbench.py 3840 bf16x3 --gemms 2>/dev/null >> $OUT/${TAG}_trunk_gemm_epilogue.txt
 done
 rm -rf /tmp/prof_trunk
