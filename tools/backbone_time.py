@@ -7,7 +7,10 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from svdd_amd import backbone, config, fused
+from svdd_amd import _lib, backbone, config, fused
+
+if os.environ.get("SVDD_BB_LP_VERSION"):               # A/B of the split-precision backbone kernels (SVDD_OPT_BACKBONE_LP_VERSION)
+    _lib.check(_lib.lib().svdd_set_option(3, int(os.environ["SVDD_BB_LP_VERSION"])), "svdd_set_option")
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 L = int(sys.argv[2]) if len(sys.argv) > 2 else 200
