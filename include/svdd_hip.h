@@ -201,6 +201,19 @@ int svdd_tds_resample(const float* reward_num, const float* reward_den, double a
  *   stay laid out for n rows); NULL = n. See "Exact work-skipping" above. */
 int svdd_gru_bidir_f32(const float* x, const float* wpack, const float* bpack, float* out, int n, int L,
                        const int32_t* count, void* stream);
+
+/* The same GRU with a backward pass to its INPUT (weights are frozen in every decode path) — for the gradient-guidance baseline
+ * of BASELINE.json configs[4] (reference diffusion_gosai.py:1321-1330 compute_gradient_DPS differentiates the reward model, whose
+ * trunk holds this GRU, Enformer.py:1595-1602, with respect to the one-hot input). csrc/svdd_gru_train.hip.
+ * svdd_gru_bidir_train_f32: forward as svdd_gru_bidir_f32 (same bits; no compaction), also writing
+ *   save [2 dirs][n][L][4][64] = r, z, n, W_hn h + b_hn per step.
+ * svdd_gru_bidir_bwd_f32: grad_out [2][n][L][64] (gradient of the per-direction outputs), out / save of the forward call,
+ *   wpack_bwd [2 dirs][4 waves][64 lanes][96] packed by svdd_amd.fused.pack_gru_bwd -> dx [2][n][L][64], each direction's
+ *   contribution to d loss / d x (the caller adds the two). */
+int svdd_gru_bidir_train_f32(const float* x, const float* wpack, const float* bpack, float* out, float* save, int n, int L,
+                             void* stream);
+int svdd_gru_bidir_bwd_f32(const float* grad_out, const float* out, const float* save, const float* wpack_bwd, float* dx, int n,
+                           int L, void* stream);
 /* svdd_value_tail_f32 — everything of the ConvGRU value net after the GRU, in one pass over the two GRU outputs:
  *   out[n][t] = b_eff[t] + mean_l sum_c w_eff[c][t] * relu(b1'[c] + sum_k W1'[c][k] * norm(h_fwd + h_bwd)[n][l][k])
  *   norm = LayerNorm over the 64 channels WITHOUT affine (eps 1e-5); the caller folds the LayerNorm affine into the
@@ -387,7 +400,7 @@ int svdd_device_info(char* arch, int arch_len, int* num_cu);
 
 /* ABI version of this header: bumped on any signature change. */
 int svdd_abi_version(void);
-#define SVDD_ABI_VERSION 4
+#define SVDD_ABI_VERSION 5
 
 /*
  * Enformer-shaped value trunk (BASELINE.json configs[3]; reference decode.py:78-80, Enformer.py:1271-1334 trunk, :1807-1884

@@ -13,7 +13,7 @@ CSRC = os.path.join(_HERE, "csrc")
 # SVDD_HIP_LIB: load another build of the library instead (the timing-experiment scripts under tools/ build patched
 # copies of the kernels in a scratch directory; the tracked sources are never edited in place)
 SO_PATH = os.environ.get("SVDD_HIP_LIB") or os.path.join(CSRC, "libsvdd_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 OK, E_ARG, E_LAUNCH, E_NODEVICE = 0, -1, -2, -3
 LAYOUT_BLV, LAYOUT_BVL = 0, 1
@@ -26,7 +26,7 @@ EXPORTS = (
     "svdd_abi_version", "svdd_device_info", "svdd_propose", "svdd_sample_categorical", "svdd_select", "svdd_x0hat",
     "svdd_finalize", "svdd_transform_samples", "svdd_subs_logp", "svdd_tds_resample",
     "svdd_set_option", "svdd_selftest_fastmath", "svdd_profile_enable", "svdd_profile_collect",
-    "svdd_gru_bidir_f32", "svdd_epilogue_ln_f32", "svdd_conv1d_cl_f32",
+    "svdd_gru_bidir_f32", "svdd_gru_bidir_train_f32", "svdd_gru_bidir_bwd_f32", "svdd_epilogue_ln_f32", "svdd_conv1d_cl_f32",
     "svdd_conv1d_set_dynamic", "svdd_gru_set_mode", "svdd_conv_tower_f32", "svdd_backbone_cnn_f32", "svdd_value_tail_f32",
     "svdd_candidate_windows", "svdd_conv_tower_windows_f32", "svdd_k1_stats",
     "svdd_backbone_cnn_lp", "svdd_conv_tower_lp", "svdd_conv_tower_windows_lp", "svdd_gru_bidir_lp", "svdd_value_tail_lp",
@@ -92,6 +92,8 @@ def lib():
     L.svdd_set_option.argtypes = [i32, i32]
     L.svdd_selftest_fastmath.argtypes = [ctypes.POINTER(ctypes.c_double)]
     L.svdd_gru_bidir_f32.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp]
+    L.svdd_gru_bidir_train_f32.argtypes = [vp, vp, vp, vp, vp, i32, i32, vp]
+    L.svdd_gru_bidir_bwd_f32.argtypes = [vp, vp, vp, vp, vp, i32, i32, vp]
     L.svdd_conv1d_set_dynamic.argtypes = [i32]
     L.svdd_gru_set_mode.argtypes = [i32]
     L.svdd_conv_tower_f32.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]

@@ -1,0 +1,233 @@
+// svdd_gru_train.hip — the bidirectional GRU of the ConvGRU reward net with a BACKWARD pass to its input
+// (reference Enformer.py:1595-1602 nn.GRU(64, 64, bidirectional=True, batch_first=True); used by the gradient-guidance baseline
+// of BASELINE.json configs[4]: diffusion_gosai.py:1321-1330 compute_gradient_DPS differentiates reward(softmax(E[x0 | x_t]))
+// with respect to the one-hot input, i.e. straight through this recurrence).
+//
+// Round 2/3a ran that through PyTorch autograd: per-timestep native cells (113 ms per gradient at B = 256), then MIOpen's fused
+// RNN (forward + backward 35.9 ms of a 54 ms gradient, tools/dps_split.py) — against 0.4 ms for the inference kernel of
+// svdd_nets.hip. The weights are frozen in every decode path, so only d/dx is needed:
+//
+//   svdd_gru_bidir_train_f32   the forward recurrence of gru_bidir_kernel<false> (same bits) that also SAVES, per direction,
+//                              sequence, step and unit, the gates r, z, the candidate n and the recurrent pre-activation
+//                              W_hn h + b_hn: what the backward pass needs besides the hidden states themselves
+//   svdd_gru_bidir_bwd_f32     back-propagation through time: per (tile of 16 sequences, direction) one workgroup walks the
+//                              steps in reverse; a step = gate derivatives (element-wise, in the MFMA C/D layout of the
+//                              forward kernel: lane (j, g) register rho <-> sequence 4 g + rho, unit 16 w + j) -> two 16 x 192
+//                              matrices in LDS -> 48 + 48 fp32 MFMAs: dh_{t-1} = [da_r | da_z | da_n r] W_hh and
+//                              dx_t = [da_r | da_z | da_n] W_ih, with both weight sets resident in registers
+//
+// GRU equations (PyTorch):  r = s(W_ir x + b_ir + W_hr h + b_hr) ; z = s(W_iz x + b_iz + W_hz h + b_hz)
+//                           n = tanh(W_in x + b_in + r (W_hn h + b_hn)) ; h' = (1 - z) n + z h
+// Backward, given dh' (output gradient of the step + recurrent gradient from the step after it in walking order):
+//   dn = dh' (1 - z) ; dz = dh' (h - n) ; da_n = dn (1 - n^2) ; da_r = da_n (W_hn h + b_hn) r (1 - r) ; da_z = dz z (1 - z)
+//   dx = W_ir^T da_r + W_iz^T da_z + W_in^T da_n ; dh = dh' z + W_hr^T da_r + W_hz^T da_z + W_hn^T (da_n r)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "svdd_hip.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int H = 64;          // hidden = input width
+constexpr int TS = 16;         // sequences per workgroup (MFMA M)
+constexpr int HPAD = H + 4;    // LDS row stride of the hidden state (floats)
+constexpr int DP = 3 * H + 4;  // LDS row stride of a gate-derivative matrix (floats): 196 = 4 mod 64 banks per row
+
+__device__ __forceinline__ float sigmoid_fast(float a) {        // as in svdd_nets.hip: the forward pass must give the same bits
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896f * a));
+}
+__device__ __forceinline__ float tanh_fast(float a) {
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008177793f * a));
+}
+
+// ---- forward with saved gates. x [n, L, 64]; wpack / bpack as svdd_gru_bidir_f32 (svdd_amd.fused.pack_gru);
+//      out [2][n][L][64]; save [2][n][L][4][64] = r, z, n, W_hn h + b_hn. One workgroup (4 waves) per (tile, direction).
+__global__ __launch_bounds__(256) void gru_train_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wpack,
+                                                            const float* __restrict__ bpack, float* __restrict__ out,
+                                                            float* __restrict__ save, int n, int L) {
+  __shared__ __attribute__((aligned(16))) float hbuf[2][TS][HPAD];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int dir = (int)(blockIdx.x & 1);
+  const int j = lane & 15, g = lane >> 4;
+  const int seq0 = (int)(blockIdx.x >> 1) * TS;
+  if (seq0 >= n) return;
+  float wr[96];
+  {
+    const float4* wp = reinterpret_cast<const float4*>(wpack + (((size_t)dir * 4 + w) * 64 + lane) * 96);
+#pragma unroll
+    for (int i = 0; i < 24; ++i) { const float4 v = wp[i]; wr[4 * i] = v.x; wr[4 * i + 1] = v.y; wr[4 * i + 2] = v.z; wr[4 * i + 3] = v.w; }
+  }
+  const int u = 16 * w + j;
+  const float b_r = bpack[(dir * 4 + 0) * H + u], b_z = bpack[(dir * 4 + 1) * H + u];
+  const float b_nx = bpack[(dir * 4 + 2) * H + u], b_nh = bpack[(dir * 4 + 3) * H + u];
+  const int arow = min(seq0 + j, n - 1);
+  const float* xrow = x + (size_t)arow * L * H + 16 * g;
+  float hprev[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  for (int i = threadIdx.x; i < TS * HPAD; i += 256) (&hbuf[0][0][0])[i] = 0.0f;
+  const int t0 = dir == 0 ? 0 : L - 1, dt = dir == 0 ? 1 : -1;
+  float xa[16], xn[16];
+  {
+    const float4* xp = reinterpret_cast<const float4*>(xrow + (size_t)t0 * H);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const float4 v = xp[i]; xa[4 * i] = v.x; xa[4 * i + 1] = v.y; xa[4 * i + 2] = v.z; xa[4 * i + 3] = v.w; }
+  }
+  f32x4 acc_r = {b_r, b_r, b_r, b_r}, acc_z = {b_z, b_z, b_z, b_z}, acc_nx = {b_nx, b_nx, b_nx, b_nx};
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    acc_r = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[s], wr[s], acc_r, 0, 0, 0);
+    acc_z = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[s], wr[32 + s], acc_z, 0, 0, 0);
+    acc_nx = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[s], wr[64 + s], acc_nx, 0, 0, 0);
+  }
+  __syncthreads();
+  for (int step = 0; step < L; ++step) {
+    const int t = t0 + dt * step;
+    const int cur = step & 1;
+    if (step + 1 < L) {
+      const float4* xp = reinterpret_cast<const float4*>(xrow + (size_t)(t + dt) * H);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { const float4 v = xp[i]; xn[4 * i] = v.x; xn[4 * i + 1] = v.y; xn[4 * i + 2] = v.z; xn[4 * i + 3] = v.w; }
+    }
+    float ha[16];
+    {
+      const float4* hp = reinterpret_cast<const float4*>(&hbuf[cur][j][16 * g]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { const float4 v = hp[i]; ha[4 * i] = v.x; ha[4 * i + 1] = v.y; ha[4 * i + 2] = v.z; ha[4 * i + 3] = v.w; }
+    }
+    f32x4 acc_nh = {b_nh, b_nh, b_nh, b_nh};
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      acc_nh = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[s], wr[80 + s], acc_nh, 0, 0, 0);
+      acc_r = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[s], wr[16 + s], acc_r, 0, 0, 0);
+      acc_z = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[s], wr[48 + s], acc_z, 0, 0, 0);
+    }
+#pragma unroll
+    for (int rho = 0; rho < 4; ++rho) {                // C/D layout: reg rho -> sequence 4g + rho, unit u
+      const float r = sigmoid_fast(acc_r[rho]);
+      const float z = sigmoid_fast(acc_z[rho]);
+      const float nn = tanh_fast(acc_nx[rho] + r * acc_nh[rho]);
+      const float hn = (1.0f - z) * nn + z * hprev[rho];
+      hprev[rho] = hn;
+      const int srow = 4 * g + rho;
+      hbuf[cur ^ 1][srow][u] = hn;
+      if (seq0 + srow < n) {
+        const size_t at = ((size_t)dir * n + seq0 + srow) * L + t;
+        out[at * H + u] = hn;
+        float* sv = save + at * (4 * H) + u;
+        sv[0] = r; sv[H] = z; sv[2 * H] = nn; sv[3 * H] = acc_nh[rho];
+      }
+    }
+    acc_r = f32x4{b_r, b_r, b_r, b_r}; acc_z = f32x4{b_z, b_z, b_z, b_z}; acc_nx = f32x4{b_nx, b_nx, b_nx, b_nx};
+    if (step + 1 < L) {
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        acc_r = __builtin_amdgcn_mfma_f32_16x16x4f32(xn[s], wr[s], acc_r, 0, 0, 0);
+        acc_z = __builtin_amdgcn_mfma_f32_16x16x4f32(xn[s], wr[32 + s], acc_z, 0, 0, 0);
+        acc_nx = __builtin_amdgcn_mfma_f32_16x16x4f32(xn[s], wr[64 + s], acc_nx, 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ---- backward through time. gout [2][n][L][64] (gradient of the per-direction outputs); out / save from the forward above;
+//      wpack_bwd [2 dirs][4 waves][64 lanes][96]: lane (j, g) of wave w holds, for output column c = 16 w + j and
+//      k' = 48 g + s (s = 0..47; k' = gate * 64 + unit, gates r, z, n): [0:48) W_hh[k'][c], [48:96) W_ih[k'][c]
+//      (the B operands of v_mfma_f32_16x16x4_f32 with the k axis permuted so that a lane's A operand is 48 contiguous floats);
+//      dx [2][n][L][64]: each direction's contribution to d/dx (the caller adds the two).
+__global__ __launch_bounds__(256) void gru_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ out,
+                                                      const float* __restrict__ save, const float* __restrict__ wpack_bwd,
+                                                      float* __restrict__ dx, int n, int L) {
+  __shared__ __attribute__((aligned(16))) float dh_m[2][TS][DP];      // [da_r | da_z | da_n r]  -> dh
+  __shared__ __attribute__((aligned(16))) float di_m[2][TS][DP];      // [da_r | da_z | da_n]    -> dx
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int dir = (int)(blockIdx.x & 1);
+  const int j = lane & 15, g = lane >> 4;
+  const int seq0 = (int)(blockIdx.x >> 1) * TS;
+  if (seq0 >= n) return;
+  float wh[48], wi[48];
+  {
+    const float4* wp = reinterpret_cast<const float4*>(wpack_bwd + (((size_t)dir * 4 + w) * 64 + lane) * 96);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      const float4 a = wp[i], b = wp[12 + i];
+      wh[4 * i] = a.x; wh[4 * i + 1] = a.y; wh[4 * i + 2] = a.z; wh[4 * i + 3] = a.w;
+      wi[4 * i] = b.x; wi[4 * i + 1] = b.y; wi[4 * i + 2] = b.z; wi[4 * i + 3] = b.w;
+    }
+  }
+  const int u = 16 * w + j;
+  const int t0 = dir == 0 ? 0 : L - 1, dt = dir == 0 ? 1 : -1;        // the FORWARD walk; this kernel walks it backwards
+  float dh_rec[4] = {0.0f, 0.0f, 0.0f, 0.0f};                         // recurrent gradient for (sequence 4 g + rho, unit u)
+  for (int step = L - 1; step >= 0; --step) {
+    const int t = t0 + dt * step;
+    const int cur = step & 1;
+#pragma unroll
+    for (int rho = 0; rho < 4; ++rho) {
+      const int srow = 4 * g + rho;
+      float da_r = 0.0f, da_z = 0.0f, da_n = 0.0f, da_hn = 0.0f, keep = 0.0f;
+      if (seq0 + srow < n) {
+        const size_t at = ((size_t)dir * n + seq0 + srow) * L + t;
+        const float dh = gout[at * H + u] + dh_rec[rho];
+        const float* sv = save + at * (4 * H) + u;
+        const float r = sv[0], z = sv[H], nn = sv[2 * H], hn_lin = sv[3 * H];
+        const float hp = step > 0 ? out[(at - dt) * H + u] : 0.0f;    // h of the previous forward step
+        const float dn = dh * (1.0f - z);
+        da_n = dn * (1.0f - nn * nn);
+        da_r = da_n * hn_lin * r * (1.0f - r);
+        da_z = dh * (hp - nn) * z * (1.0f - z);
+        da_hn = da_n * r;
+        keep = dh * z;
+      }
+      dh_rec[rho] = keep;
+      dh_m[cur][srow][u] = da_r; dh_m[cur][srow][H + u] = da_z; dh_m[cur][srow][2 * H + u] = da_hn;
+      di_m[cur][srow][u] = da_r; di_m[cur][srow][H + u] = da_z; di_m[cur][srow][2 * H + u] = da_n;
+    }
+    __syncthreads();                                                  // (two buffers: one barrier per step)
+    f32x4 acc_h = {0.0f, 0.0f, 0.0f, 0.0f}, acc_x = {0.0f, 0.0f, 0.0f, 0.0f};
+    {
+      const float4* ph = reinterpret_cast<const float4*>(&dh_m[cur][j][48 * g]);
+      const float4* pi = reinterpret_cast<const float4*>(&di_m[cur][j][48 * g]);
+#pragma unroll
+      for (int i = 0; i < 12; ++i) {
+        const float4 a = ph[i], b = pi[i];
+        acc_h = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, wh[4 * i], acc_h, 0, 0, 0);
+        acc_x = __builtin_amdgcn_mfma_f32_16x16x4f32(b.x, wi[4 * i], acc_x, 0, 0, 0);
+        acc_h = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, wh[4 * i + 1], acc_h, 0, 0, 0);
+        acc_x = __builtin_amdgcn_mfma_f32_16x16x4f32(b.y, wi[4 * i + 1], acc_x, 0, 0, 0);
+        acc_h = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, wh[4 * i + 2], acc_h, 0, 0, 0);
+        acc_x = __builtin_amdgcn_mfma_f32_16x16x4f32(b.z, wi[4 * i + 2], acc_x, 0, 0, 0);
+        acc_h = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, wh[4 * i + 3], acc_h, 0, 0, 0);
+        acc_x = __builtin_amdgcn_mfma_f32_16x16x4f32(b.w, wi[4 * i + 3], acc_x, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int rho = 0; rho < 4; ++rho) {                               // C/D layout: reg rho -> sequence 4 g + rho, column u
+      const int srow = 4 * g + rho;
+      dh_rec[rho] += acc_h[rho];
+      if (seq0 + srow < n) dx[(((size_t)dir * n + seq0 + srow) * L + t) * H + u] = acc_x[rho];
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int svdd_gru_bidir_train_f32(const float* x, const float* wpack, const float* bpack, float* out, float* save, int n, int L,
+                             void* stream) {
+  if (!x || !wpack || !bpack || !out || !save || n <= 0 || L <= 0) return SVDD_E_ARG;
+  hipLaunchKernelGGL(gru_train_fwd_kernel, dim3(2 * (unsigned)((n + TS - 1) / TS)), dim3(256), 0, (hipStream_t)stream, x, wpack,
+                     bpack, out, save, n, L);
+  return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
+}
+
+int svdd_gru_bidir_bwd_f32(const float* grad_out, const float* out, const float* save, const float* wpack_bwd, float* dx, int n,
+                           int L, void* stream) {
+  if (!grad_out || !out || !save || !wpack_bwd || !dx || n <= 0 || L <= 0) return SVDD_E_ARG;
+  hipLaunchKernelGGL(gru_bwd_kernel, dim3(2 * (unsigned)((n + TS - 1) / TS)), dim3(256), 0, (hipStream_t)stream, grad_out, out,
+                     save, wpack_bwd, dx, n, L);
+  return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
+}
+
+}  // extern "C"

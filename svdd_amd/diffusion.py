@@ -535,7 +535,11 @@ class Diffusion(nn.Module):
         # both modes, so only those modules are switched for the call (BatchNorm / Dropout stay in eval): 113 -> 54 ms per
         # gradient at B = 256 against the per-timestep native cells (400 cell launches forward + backward). Any other
         # recurrent module falls back to the native cells.
-        rnns = [m for m in reward_model.modules() if isinstance(m, torch.nn.RNNBase)]
+        # ... and where the GRU is the reward net's 64-unit bidirectional one, neither is used: the recurrence runs on the
+        # hand-written forward + BPTT kernels (csrc/svdd_gru_train.hip; 35.9 -> ~1 ms of the gradient at B = 256).
+        hip = self._hip_gru_blocks(reward_model) if (self.fuse_nets and x_onehot.is_cuda) else []
+        taken = {id(b.gru) for b in hip}
+        rnns = [m for m in reward_model.modules() if isinstance(m, torch.nn.RNNBase) and id(m) not in taken]
         flip = [m for m in rnns if isinstance(m, torch.nn.GRU) and m.dropout == 0 and not m.training]
         native = len(flip) != len([m for m in rnns if not m.training])
         for m in flip:
@@ -547,7 +551,35 @@ class Diffusion(nn.Module):
         finally:
             for m in flip:
                 m.eval()
+            for b in hip:
+                b._hip_gru = None
         return x_onehot.grad.clone()
+
+    def _hip_gru_blocks(self, reward_model):
+        """GRUBlocks of `reward_model` whose nn.GRU the kernels of csrc/svdd_gru_train.hip take (64 -> 64, one layer,
+        bidirectional, eval mode or no dropout), switched to them; weights re-packed when their fingerprint changes."""
+        from .fused import GruBidirFunction, pack_gru, pack_gru_bwd
+        from .value_nets import GRUBlock
+        blocks = []
+        for b in reward_model.modules():
+            g = getattr(b, "gru", None)
+            if not (isinstance(b, GRUBlock) and isinstance(g, torch.nn.GRU) and g.hidden_size == 64 and g.input_size == 64 and
+                    g.num_layers == 1 and g.bidirectional and g.bias and g.batch_first and not g.training):
+                continue
+            cache = self.__dict__.setdefault("_gru_train_packs", {})   # id(gru) -> (weak ref, fingerprint, packs)
+            fp = weight_fingerprint(g)
+            ent = cache.get(id(g))
+            if ent is None or ent[0]() is not g or not _same_weights(ent[1], fp):
+                wpack, bpack = pack_gru(g)
+                dev = next(g.parameters()).device
+                ent = (weakref.ref(g), fp, (wpack.to(dev), bpack.to(dev), pack_gru_bwd(g).to(dev)))
+                for k in [k for k, v in cache.items() if v[0]() is None]:
+                    del cache[k]
+                cache[id(g)] = ent
+            packs = ent[2]
+            b._hip_gru = lambda xx, p=packs: GruBidirFunction.apply(xx, *p)
+            blocks.append(b)
+        return blocks
 
     def _dps_guided_q(self, x_u8, mcs, dm, reward_model, guidance_scale):
         """The guided transition weights q_xs of one DPS step (:1306-1314) -> fp32 [B, L, 5]."""

@@ -71,6 +71,50 @@ def _ptr(t):
     return t.data_ptr() if t is not None else None
 
 
+def pack_gru_bwd(gru):
+    """nn.GRU(64, 64, bidirectional) -> wpack_bwd [2, 4, 64, 96] for svdd_gru_bidir_bwd_f32: lane (j, g) of wave w holds, for
+    output column c = 16 w + j and k' = 48 g + s (k' = gate * 64 + unit, gates r, z, n): [0:48) W_hh[k'][c], [48:96) W_ih[k'][c]."""
+    H = gru.hidden_size
+    assert H == 64 and gru.input_size == 64 and gru.bidirectional and gru.num_layers == 1 and gru.bias
+    packs = []
+    for sfx in ("", "_reverse"):
+        w_ih = getattr(gru, "weight_ih_l0" + sfx).detach().float()     # [3H (k'), 64 (c)]
+        w_hh = getattr(gru, "weight_hh_l0" + sfx).detach().float()
+        both = torch.stack([w_hh, w_ih])                                # [2, k' = (g, s), c = (w, j)]
+        packs.append(both.view(2, 4, 48, 4, 16).permute(3, 1, 4, 0, 2).reshape(4, 64, 96))   # [w][g][j][2][s] -> lanes = 16 g + j
+    return torch.stack(packs).contiguous()
+
+
+class GruBidirFunction(torch.autograd.Function):
+    """The bidirectional GRU on the hand-written kernels WITH a gradient to its input (csrc/svdd_gru_train.hip): forward =
+    svdd_gru_bidir_train_f32 (the inference kernel's bits + saved gates), backward = svdd_gru_bidir_bwd_f32 (BPTT, d/dx
+    only: the weights are frozen in every decode path). x [n, L, 64] -> [2, n, L, 64] per-direction hidden states."""
+
+    @staticmethod
+    def forward(ctx, x, wpack, bpack, wpack_bwd):
+        assert x.is_cuda and x.dtype == torch.float32 and x.shape[2] == 64
+        x = x.contiguous()
+        n, L, _ = x.shape
+        out = torch.empty((2, n, L, 64), dtype=torch.float32, device=x.device)
+        save = torch.empty((2, n, L, 4, 64), dtype=torch.float32, device=x.device)
+        rc = _lib.lib().svdd_gru_bidir_train_f32(x.data_ptr(), wpack.data_ptr(), bpack.data_ptr(), out.data_ptr(), save.data_ptr(),
+                                                 n, L, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        _lib.check(rc, "svdd_gru_bidir_train_f32")
+        ctx.save_for_backward(out, save, wpack_bwd)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        out, save, wpack_bwd = ctx.saved_tensors
+        _, n, L, _ = out.shape
+        g = grad_out.contiguous().float()
+        dx = torch.empty((2, n, L, 64), dtype=torch.float32, device=out.device)
+        rc = _lib.lib().svdd_gru_bidir_bwd_f32(g.data_ptr(), out.data_ptr(), save.data_ptr(), wpack_bwd.data_ptr(), dx.data_ptr(),
+                                               n, L, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        _lib.check(rc, "svdd_gru_bidir_bwd_f32")
+        return dx[0] + dx[1], None, None, None
+
+
 def pack_conv(weight):
     """Conv1d weight [cout, cin, taps] -> [taps][cin/32][cout][32] for svdd_conv1d_cl_f32."""
     co, ci, T = weight.shape

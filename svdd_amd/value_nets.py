@@ -114,10 +114,16 @@ class GRUBlock(nn.Module):
                           num_layers=n_layers, dropout=dropout if n_layers > 1 else 0)
         self.ffn = FeedForwardBlock(in_channels, dropout)
 
+    _hip_gru = None                            # set by Diffusion.compute_gradient_DPS: x [n, L, C] -> [2, n, L, C] with a gradient
+
     def forward(self, x):                     # [n, C, L]
-        y = self.gru(x.transpose(1, 2))[0]    # [n, L, 2C]
-        h = self.gru.hidden_size
-        y = y[:, :, :h] + y[:, :, h:]
+        if self._hip_gru is not None and x.is_cuda:
+            y2 = self._hip_gru(x.transpose(1, 2))          # hand-written forward + BPTT kernels (csrc/svdd_gru_train.hip)
+            y = y2[0] + y2[1]
+        else:
+            y = self.gru(x.transpose(1, 2))[0]    # [n, L, 2C]
+            h = self.gru.hidden_size
+            y = y[:, :, :h] + y[:, :, h:]
         return self.ffn(y).transpose(1, 2)
 
 

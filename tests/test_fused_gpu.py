@@ -372,3 +372,28 @@ def test_backbone_sequences_per_tile_choice_same_bits(n, L, mode):
     a, b, c = outs[1]
     assert torch.equal(b[:live], a[:live]) and float(b[live:].abs().max() if live < n else 0.0) == 0.0
     assert torch.equal(c[idx.long()], a[idx.long()])
+
+
+@pytest.mark.parametrize("n,L", [(16, 200), (37, 50), (5, 7), (300, 33), (1, 1)])
+def test_gru_train_forward_and_backward_kernels(n, L):
+    """csrc/svdd_gru_train.hip: the GRU with a gradient to its input (reward-net half of the DPS baseline, reference
+    diffusion_gosai.py:1321-1330 through Enformer.py:1595-1602). Forward = the inference kernel's bits; backward (BPTT, d/dx)
+    against torch autograd through nn.GRU on the same weights, for ragged tiles and degenerate lengths."""
+    from svdd_amd import fused
+    torch.manual_seed(n * 1000 + L)
+    gru = torch.nn.GRU(64, 64, bidirectional=True, batch_first=True).to(DEV)
+    x = torch.randn(n, L, 64, device=DEV)
+    gout = torch.randn(2, n, L, 64, device=DEV)
+    wpack, bpack = fused.pack_gru(gru)
+    wpack, bpack, wb = wpack.to(DEV), bpack.to(DEV), fused.pack_gru_bwd(gru).to(DEV)
+    xr = x.clone().requires_grad_(True)
+    out = fused.GruBidirFunction.apply(xr, wpack, bpack, wb)
+    assert torch.equal(out.detach(), fused.gru_bidir(x, wpack, bpack))           # the inference kernel's bits
+    (out * gout).sum().backward()
+    xt = x.clone().requires_grad_(True)
+    with torch.backends.cudnn.flags(enabled=False):                              # native cells: plain autograd
+        y = gru(xt)[0]                                                           # [n, L, 128] = fwd | bwd halves
+    (y[:, :, :64] * gout[0] + y[:, :, 64:] * gout[1]).sum().backward()
+    assert float((out.detach() - torch.stack([y[:, :, :64], y[:, :, 64:]]).detach()).abs().max()) <= 2e-5
+    scale = float(xt.grad.abs().max())
+    assert float((xr.grad - xt.grad).abs().max()) <= 2e-4 * max(scale, 1.0), (float((xr.grad - xt.grad).abs().max()), scale)

@@ -52,3 +52,26 @@ def whole():
 
 print(f"B={B}: backbone forward2 + backward {timed(backbone_half):.1f} ms ; reward net forward + backward {timed(reward_half):.1f} ms ; "
       f"compute_gradient_DPS {timed(whole):.1f} ms")
+
+
+# ---- inside the reward-net half: the bidirectional GRU (MIOpen's fused RNN, fwd + bwd) against the rest
+gru = [m for m in rew.modules() if isinstance(m, torch.nn.GRU)][0]
+xin = torch.randn(B, 200, gru.input_size, device="cuda:0")
+
+
+def gru_only():
+    gru.train()
+    try:
+        with torch.enable_grad():
+            xi = xin.clone().requires_grad_(True)
+            gru(xi)[0].sum().backward()
+    finally:
+        gru.eval()
+
+
+def gru_fwd_only():
+    with torch.no_grad():
+        gru(xin)
+
+
+print(f"      nn.GRU({gru.input_size}, {gru.hidden_size}, bidirectional) alone: forward + backward {timed(gru_only):.1f} ms, forward {timed(gru_fwd_only):.1f} ms")
