@@ -114,9 +114,46 @@ class CNNModel(nn.Module):
             tb = self._time_biases(t)
         return self.trunk(onehot.permute(0, 2, 1), tb).permute(0, 2, 1)
 
+    hip_convs = False      # set by Diffusion (fuse_nets): forward2 on the hand-written dilated-conv kernel in both directions
+
     def forward2(self, seq_onehot, t):
         """Differentiable entry on a one-hot/relaxed input [B,L,5] (reference dnaconv.py:212-247; DPS)."""
+        if self.hip_convs and seq_onehot.is_cuda and self.args.hidden_dim % 32 == 0 and not self.training:
+            return self._trunk_cl(seq_onehot, self._time_biases(t))
         return self.trunk(seq_onehot.permute(0, 2, 1), self._time_biases(t)).permute(0, 2, 1)
+
+    def _trunk_cl(self, onehot, time_biases):
+        """trunk() in channels-last rows [B, L, C] (no layout permutes; LayerNorm over the last axis as it lies), with every
+        dilated 9-tap convolution on svdd_conv1d_cl_f32 forward AND backward (fused.DilatedConvFunction); the 5-channel first
+        convolution is an unfold + matmul, the 1x1 convolutions are linear layers. Same function as trunk(); the
+        convolutions sum in the kernel's order, not MIOpen's (differences at fp32 round-off). Eval mode only (no dropout)."""
+        from . import fused
+        packs = self._conv_packs()
+        B, L, A = onehot.shape
+        w0 = self.linear.weight                                            # [H, A, 9]
+        xp = F.pad(onehot, (0, 0, 4, 4))                                   # rows -4 .. L + 3
+        cols = torch.cat([xp[:, k:k + L] for k in range(9)], dim=2)        # [B, L, 9 A], tap-major
+        feat = F.relu(cols @ w0.permute(2, 1, 0).reshape(9 * A, -1) + self.linear.bias)
+        H = feat.shape[2]
+        for i in range(self.num_layers):
+            h = F.layer_norm(feat + time_biases[i].transpose(1, 2), (H,), self.norms[i].weight, self.norms[i].bias, self.norms[i].eps)
+            wp, wpt, d = packs[i]
+            c = fused.DilatedConvFunction.apply(h, wp, wpt, H, H, 9, d) + self.convs[i].bias
+            feat = F.relu(c) + feat
+        f1, f2 = self.final_conv[0], self.final_conv[2]
+        return F.linear(F.relu(F.linear(feat, f1.weight[:, :, 0], f1.bias)), f2.weight[:, :, 0], f2.bias)
+
+    def _conv_packs(self):
+        """(forward pack, backward-data pack, dilation) of every dilated conv for svdd_conv1d_cl_f32, re-packed when a weight
+        tensor is replaced or modified in place."""
+        from . import fused
+        key = tuple((c.weight.data_ptr(), c.weight._version) for c in self.convs)
+        if getattr(self, "_cpk_key", None) != key:
+            with torch.no_grad():
+                self._cpk = [(fused.pack_conv(c.weight), fused.pack_conv(c.weight.flip(2).transpose(0, 1).contiguous()),
+                              c.dilation[0]) for c in self.convs]
+            self._cpk_key = key
+        return self._cpk
 
     @staticmethod
     def flops_per_position(hidden_dim=128, num_cnn_stacks=4, alphabet=5):

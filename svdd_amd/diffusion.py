@@ -381,6 +381,8 @@ class Diffusion(nn.Module):
         """Differentiable log score on a one-hot input (:359-377), used by the DPS baseline. Autograd
         must see every op, so the SUBS step is expressed in torch here."""
         sigma = self._process_sigma(sigma)
+        if isinstance(self.backbone, CNNModel):
+            self.backbone.hip_convs = bool(self.fuse_nets)        # dilated convs on the hand-written kernel, both directions
         logits = self.backbone.forward2(x_onehot, sigma)
         neg = torch.zeros(self.vocab_size, device=logits.device)
         neg[self.mask_index] = self.neg_infinity

@@ -115,6 +115,25 @@ class GruBidirFunction(torch.autograd.Function):
         return dx[0] + dx[1], None, None, None
 
 
+class DilatedConvFunction(torch.autograd.Function):
+    """One 'same'-padded stride-1 Conv1d (odd kernel, any dilation, no bias) on channels-last rows [n, L, cin] through
+    svdd_conv1d_cl_f32 in BOTH directions: its backward-data pass is the same convolution with the taps flipped and the
+    channel axes swapped (wpack_t = pack_conv(W.flip(2).transpose(0, 1))). Weights are frozen (no weight gradient): the
+    DPS baseline only differentiates with respect to the input (reference diffusion_gosai.py:1321-1330)."""
+
+    @staticmethod
+    def forward(ctx, x, wpack, wpack_t, cout, cin, taps, dilation):
+        ctx.cfg = (cin, taps, dilation)
+        ctx.save_for_backward(wpack_t)
+        return conv1d_cl(x.contiguous(), wpack, cout, taps, dilation)
+
+    @staticmethod
+    def backward(ctx, g):
+        cin, taps, dilation = ctx.cfg
+        (wpack_t,) = ctx.saved_tensors
+        return conv1d_cl(g.contiguous().float(), wpack_t, cin, taps, dilation), None, None, None, None, None, None
+
+
 def pack_conv(weight):
     """Conv1d weight [cout, cin, taps] -> [taps][cin/32][cout][32] for svdd_conv1d_cl_f32."""
     co, ci, T = weight.shape

@@ -397,3 +397,34 @@ def test_gru_train_forward_and_backward_kernels(n, L):
     assert float((out.detach() - torch.stack([y[:, :, :64], y[:, :, 64:]]).detach()).abs().max()) <= 2e-5
     scale = float(xt.grad.abs().max())
     assert float((xr.grad - xt.grad).abs().max()) <= 2e-4 * max(scale, 1.0), (float((xr.grad - xt.grad).abs().max()), scale)
+
+
+@pytest.mark.parametrize("B,L", [(5, 200), (3, 50)])
+def test_backbone_forward2_on_the_hip_conv_kernel_both_directions(B, L):
+    """CNNModel.forward2 (the differentiable backbone entry of the DPS baseline, reference dnaconv.py:212-247) in channels-last
+    rows with every dilated convolution on svdd_conv1d_cl_f32 forward AND backward (fused.DilatedConvFunction: backward-data =
+    the same convolution with flipped taps and swapped channel axes) against the plain PyTorch / MIOpen trunk: logits and the
+    gradient with respect to the relaxed one-hot input."""
+    from svdd_amd import backbone, config
+    torch.manual_seed(L)
+    cnn = backbone.CNNModel((config.dna_config() if L == 200 else config.rna_config()).model, alphabet_size=5).to(DEV).eval()
+    with torch.no_grad():
+        for nm in cnn.norms:
+            nm.weight.uniform_(0.5, 1.5)
+            nm.bias.uniform_(-0.3, 0.3)
+    for p in cnn.parameters():
+        p.requires_grad_(False)
+    x = torch.softmax(torch.randn(B, L, 5, device=DEV), dim=-1)
+    g = torch.randn(B, L, 5, device=DEV)
+    t = torch.zeros(B, device=DEV)
+    res = {}
+    for hip in (False, True):
+        cnn.hip_convs = hip
+        xi = x.clone().requires_grad_(True)
+        y = cnn.forward2(xi, t)
+        (y * g).sum().backward()
+        res[hip] = (y.detach(), xi.grad.clone())
+    cnn.hip_convs = False
+    assert float((res[True][0] - res[False][0]).abs().max()) <= 2e-5
+    scale = float(res[False][1].abs().max())
+    assert float((res[True][1] - res[False][1]).abs().max()) <= 1e-4 * max(scale, 1.0), (float((res[True][1] - res[False][1]).abs().max()), scale)
