@@ -70,7 +70,12 @@ def run(args):
         ref_model.load_state_dict(sd.get("state_dict", sd), strict=False)
     if args.load_checkpoint_path:
         sd = torch.load(args.load_checkpoint_path, map_location="cpu")["model_state_dict"]
-        load_reference_state_dict(embedding, {k[len("embedding."):]: v for k, v in sd.items() if k.startswith("embedding.")})
+        emb_sd = {k[len("embedding."):]: v for k, v in sd.items() if k.startswith("embedding.")}
+        if args.model == "enformer":                       # the reference's wrapper names -> this module's (enformer_value.py)
+            from .enformer_value import load_reference_state_dict as load_trunk
+            load_trunk(embedding, emb_sd)
+        else:
+            load_reference_state_dict(embedding, emb_sd)
         load_reference_state_dict(head, {k[len("head."):]: v for k, v in sd.items() if k.startswith("head.")})
     if args.reward_ckpt:
         sd = torch.load(args.reward_ckpt, map_location="cpu")

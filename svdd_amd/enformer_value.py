@@ -214,3 +214,27 @@ class EnformerTrunk(nn.Module):
         fl += n_transformers * (cur * per_tok + cur * cur * n_heads * (2 * key_len + dv))
         fl += cur * channels * 2 * channels
         return 2 * fl
+
+
+def reference_key(k):
+    """Parameter / buffer name of the reference's `EnformerTrunk` (Enformer.py:1271-1334: wrappers keep their layer in
+    `.layer`, the transformer tower keeps its blocks in `.blocks`, the feed-forward block is `ffn.dense1` (LayerNorm + Linear)
+    and `ffn.dense2` (Linear)) -> the name of the same tensor in this module; None for `ffn.dense.*`, which the reference
+    registers but never calls (Enformer.py:2029-2046)."""
+    if ".ffn.dense." in k:
+        return None
+    k = k.replace(".norm.layer.", ".norm.").replace(".pool.layer.", ".pool.")
+    k = k.replace("transformer_tower.blocks.", "transformer_tower.")
+    return k.replace(".ffn.dense1.norm.", ".ffn_norm.").replace(".ffn.dense1.linear.", ".ffn1.").replace(".ffn.dense2.linear.", ".ffn2.")
+
+
+def load_reference_state_dict(trunk, state_dict):
+    """Loads a reference `EnformerTrunk` state_dict (e.g. the `embedding.*` part of a value-function checkpoint,
+    decode.py:100-104) into `trunk`, strictly: every tensor this module has must be there, and nothing but the reference's
+    unused `ffn.dense.*` may be left over (fixture g17 checks the mapping end to end)."""
+    mapped = {}
+    for k, v in state_dict.items():
+        nk = reference_key(k)
+        if nk is not None:
+            mapped[nk] = v
+    return trunk.load_state_dict(mapped, strict=True)

@@ -183,14 +183,9 @@ def _g17_modules():
     trunk = EnformerTrunk(n_conv=n_conv, channels=ch, n_transformers=n_tf, n_heads=heads, key_len=key_len).eval()
     head = ConvHead(1, 2 * ch).eval()
 
-    def to_ours(k):
-        k = k.replace(".norm.layer.", ".norm.").replace(".pool.layer.", ".pool.")
-        k = k.replace("transformer_tower.blocks.", "transformer_tower.")
-        k = k.replace(".ffn.dense1.norm.", ".ffn_norm.").replace(".ffn.dense1.linear.", ".ffn1.").replace(".ffn.dense2.linear.", ".ffn2.")
-        return k
-    sd_t = {to_ours(k[6:]): v for k, v in ref.items() if k.startswith("trunk.") and ".ffn.dense." not in k}
+    from svdd_amd.enformer_value import load_reference_state_dict
+    load_reference_state_dict(trunk, {k[6:]: v for k, v in ref.items() if k.startswith("trunk.")})
     sd_h = {k[5:]: v for k, v in ref.items() if k.startswith("head.")}
-    trunk.load_state_dict(sd_t, strict=True)
     head.load_state_dict(sd_h, strict=True)
     tok = torch.from_numpy(g["tokens"]).long()
     x = torch.nn.functional.one_hot(tok.clamp(max=3), 4).float() * (tok < 4)[..., None]
