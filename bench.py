@@ -168,6 +168,38 @@ def tds_saturated(dev, L=200, B=65536, iters=10):
     return out
 
 
+def trunk_gemm_roofline(model, emb, head, dev, n, L):
+    """--value-net enformer: the dominant kernel of that workload is trunk_gemm256_kernel (csrc/svdd_trunk.hip), not the
+    backbone. One trunk forward (bf16x3) on n candidates (~ the live candidates of a step) with a HIP event pair around every
+    GEMM launch: multiply-adds of all GEMMs x 2 / summed launch time against the dense 16-bit MFMA peak — `frac` on the
+    fp32-equivalent FLOPs, `issued_frac` with the three passes of the split product counted."""
+    from svdd_amd.fused_trunk import FusedEnformerValueNet
+    model.precision = "bf16x3"
+    fn = model.value_callable(emb, head)
+    model.precision = "f32"
+    if not isinstance(fn, FusedEnformerValueNet):
+        return None
+    tok = torch.randint(0, 5, (n, L), device=dev, dtype=torch.uint8)
+    fn.forward_tokens(tok)
+    torch.cuda.synchronize()
+    fn.timing = []
+    fn.forward_tokens(tok)
+    torch.cuda.synchronize()
+    issued = sum(2.0 * Mr * N * C * T for Mr, N, C, T, _, _ in fn.timing)          # incl. the zero rows between sequences
+    ms = sum(e0.elapsed_time(e1) for _, _, _, _, e0, e1 in fn.timing)
+    launches = len(fn.timing)
+    fn.timing = None
+    flops = float(emb.flops_per_sequence(L)) * n                                   # algorithmic (SURVEY.md section 8a: 3.36 GFLOP / candidate)
+    tf = flops / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "trunk_gemm256_kernel (every convolution / projection of the Enformer-shaped value trunk; "
+                                       "bf16x3: 3 MFMA passes per product)",
+            "achieved": round(tf, 2), "peak": LP_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / LP_PEAK_TFLOPS, 5),
+            "issued_frac": round(3 * issued / (ms * 1e-3) / 1e12 / LP_PEAK_TFLOPS, 5), "flops_per_forward": round(flops),
+            "issued_flops_per_forward_incl_pad_rows": round(issued), "gemm_ms_per_forward": round(ms, 3),
+            "launches": launches, "workload": f"one trunk forward on {n} candidates of length {L}", "traffic": None,
+            "traffic_source": None}
+
+
 def cpu_baseline(B, L, M, S, sample_steps, seed=44, threads=16, states=None, passes=3):
     """Oracle (CPU port of the reference path: M value-net calls of batch B per step, like
     diffusion_gosai.py:1207-1209) on `sample_steps` diffusion steps of the same workload. `states`: the x_t of every
@@ -535,6 +567,7 @@ def main():
         if args.value_net != "convgru":
             line["config"]["workload"] += " [value net: Enformer-shaped trunk, 230M params — BASELINE configs[3] shape]"
             line["e2e_fp32_frac"] = None
+            line["roofline_trunk_gemm"] = trunk_gemm_roofline(model, emb, head, dev, int(0.75 * B * M), L)
         if args.cpu_steps > 0 and world == 1 and args.value_net == "convgru":
             model.state_trace = []                                  # one extra (untimed) decode: the trajectory's states
             model.controlled_sample(emb, head, num_steps=S, eval_sp_size=B, sample_M=M)
