@@ -406,8 +406,8 @@ int svdd_abi_version(void);
  * Enformer-shaped value trunk (BASELINE.json configs[3]; reference decode.py:78-80, Enformer.py:1271-1334 trunk, :1807-1884
  * conv tower, :1887-2007 transformer tower, :2176-2292 ConvBlock "NACDR") on the 16-bit matrix cores, split precision
  * bf16x3 (a_lo != NULL) or one-pass bf16 (a_lo == NULL). csrc/svdd_trunk.hip. Activations are channels-last rows
- * [n * rows_per_seq, C]; for the k = 5 convolutions rows_per_seq = L + 4 (two zero rows either side of a sequence), so that a
- * tap is a row shift of a plain GEMM. count (may be NULL): device scalar, number of live sequences of a compacted batch.
+ * [n * rows_per_seq, C]; for the k = 5 convolutions rows_per_seq = L + 2 (two zero rows behind every sequence, two guard rows in
+ * front of the first), so that a tap is a row shift of a plain GEMM. count (may be NULL): device scalar, number of live sequences of a compacted batch.
  *
  * svdd_trunk_gemm        out[M, N] = act(sum_{t < T} A[rows + t - T/2, Cin] W_t[Cin, N] + bias) (+ resid), fp32 [M, ldo].
  *                        a_hi / a_lo: bf16 operand planes [>= M + 128 + T rows, lda] with T/2 readable rows before row 0;
@@ -415,17 +415,17 @@ int svdd_abi_version(void);
  *                        T odd ; act 0 none, 1 relu, 2 x * sigmoid(1.702 x).
  *                        Fused second output (out_hi != NULL; out may then be NULL): the operand planes of the NEXT GEMM,
  *                        post_act(post_scale[c] y + post_shift[c]) -> (out_hi, out_lo) [M, N] (scale / shift NULL: identity), zero in
- *                        the `pad` rows at either end of every sequence — what svdd_trunk_act_split would write from `out`. The
+ *                        the last `pad` rows of every sequence — what svdd_trunk_act_split would write from `out`. The
  *                        output planes must not be the input planes. Two kernels behind it (SVDD_OPT_TRUNK_GEMM_VERSION).
  * svdd_trunk_act_split   x fp32 [rows, C] -> act(scale[c] x + shift[c]) (scale / shift NULL: identity) -> planes hi (lo may be
- *                        NULL) ; rows whose position in their sequence is within `pad` of either end are written as zeros.
+ *                        NULL) ; the last `pad` rows of every sequence are written as zeros.
  * svdd_trunk_layernorm_split   LayerNorm(x[row, :C]) gamma + beta -> planes (C % 8 == 0, C <= 4096).
- * svdd_trunk_attn_pool   softmax-weighted pooling over position pairs: x, logits fp32 [n, L + 4, C] -> out [n, ceil(L/2) + 4, C]
+ * svdd_trunk_attn_pool   softmax-weighted pooling over position pairs: x, logits fp32 [n, L + 2, C] -> out [n, ceil(L/2) + 2, C]
  *                        (may be NULL) and / or the next GEMM's operand planes post_act(post_scale o + post_shift), pad rows zeroed.
  * svdd_trunk_attn_small  relative-position attention on T <= 4 tokens per sequence (what the conv tower leaves of L <= 512): qkv fp32
  *                        [n T, heads (2 dk + dv)] = [q | k | v], rel_k [heads, 2 T - 1, dk] (positional keys), content / pos bias
  *                        [heads, dk] -> softmax(((q s + cb) k^T + shift((q s + pb) rel_k^T))) v as (hi, lo) planes [n T, heads dv].
- * svdd_trunk_stem_unfold tokens [n, L] u8 -> hi plane [n (L + 4), 64]: channel 4 t + token of position l + t - 7 (t < 15) set to 1.
+ * svdd_trunk_stem_unfold tokens [n, L] u8 -> hi plane [n (L + 2), 64]: channel 4 t + token of position l + t - 7 (t < 15) set to 1.
  */
 int svdd_trunk_gemm(const void* a_hi, const void* a_lo, const void* w, const float* bias, const float* resid, float* out,
                     int M, int N, int Cin, int T, int lda, int ldo, int act, const int32_t* count, int rows_per_seq,

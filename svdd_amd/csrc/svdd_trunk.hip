@@ -10,10 +10,12 @@
 // ~5e-7 of sum|a b|), or one pass on hi ("bf16"). bf16 keeps fp32's exponent range: no operand scaling is needed for
 // activations of unknown magnitude (that is why the trunk does not offer f16x3).
 //
-// Data layout: activations are channels-last rows [n * Lp, C], Lp = L + 4: every sequence carries two zero rows in
-// front and two behind. A k = 5 convolution is then FIVE PLAIN GEMMS ACCUMULATED IN ONE KERNEL — K block kb of tap t reads
-// the A tile shifted by t - 2 rows — with no boundary predicate anywhere in the GEMM. The pad rows of an output are
-// garbage; the element-wise pass that prepares the next GEMM's operands (BatchNorm + GELU + hi/lo split) writes zeros there.
+// Data layout: activations are channels-last rows [n * Lp, C], Lp = L + 2: every sequence is followed by two zero rows (the
+// two in front of the first sequence are guard rows of the buffer). A k = 5 convolution is then FIVE PLAIN GEMMS ACCUMULATED
+// IN ONE KERNEL — K block kb of tap t reads the A tile shifted by t - 2 rows — with no boundary predicate anywhere in the
+// GEMM. The pad rows of an fp32 output are garbage; whoever writes the next GEMM's operand planes (a GEMM / pooling epilogue or
+// the element-wise pass) writes zeros there. (Round 3a / 3b-1 had two zero rows on EITHER side of a sequence: 12 % of the
+// GEMM rows of a forward, half of them at the 4-position level.)
 //
 //   trunk_gemm_kernel         out[M, N] = act(A[M (+shift), K] W[K, N] + bias) (+ residual), fp32 out
 //   trunk_act_split_kernel    fp32 rows -> act(scale * x + shift) -> (hi, lo) planes, pad rows zeroed
@@ -85,7 +87,7 @@ __device__ __forceinline__ void gemm_store4(const GemmArgs& a, int row, int col,
 __device__ __forceinline__ bool gemm_pad_row(const GemmArgs& a, int row) {
   if (a.pad <= 0) return false;
   const int pos = row % a.rows_per_seq;
-  return pos < a.pad || pos >= a.rows_per_seq - a.pad;
+  return pos >= a.rows_per_seq - a.pad;
 }
 
 // One workgroup (4 waves) = a 128 x 128 output tile; wave (wm, wn) owns 64 x 64 = 4 x 4 MFMA tiles. A stage = one K block
@@ -391,7 +393,7 @@ __global__ __launch_bounds__(512, 2) void trunk_gemm256_kernel(GemmArgs a) {
     for (int p = 0; p < 16; ++p) {
       const int row = rbase + 4 * p;
       const f32x4 v = *reinterpret_cast<const f32x4*>(slab + (4 * p + rsub) * SP + c4);
-      const bool pad_row = a.pad > 0 && (pos < a.pad || pos >= a.rows_per_seq - a.pad);
+      const bool pad_row = a.pad > 0 && pos >= a.rows_per_seq - a.pad;
       if (row < m_live) gemm_store4(a, row, col, pad_row, v, b4, ps4, pb4);
       pos += 4;
       if (pos >= a.rows_per_seq) pos -= a.rows_per_seq;
@@ -400,7 +402,7 @@ __global__ __launch_bounds__(512, 2) void trunk_gemm256_kernel(GemmArgs a) {
 }
 
 // fp32 rows [rows, C] -> act(scale[c] x + shift[c]) -> (hi, lo) bf16 planes [rows, C]; rows whose position inside their
-// sequence (row % rows_per_seq) lies in the `pad` rows at either end become zero. One thread = 8 adjacent channels.
+// sequence (row % rows_per_seq) lies in its last `pad` rows become zero. One thread = 8 adjacent channels.
 struct ActArgs {
   const float* x; const float* scale; const float* shift; int act; int64_t rows; int C, rows_per_seq, pad;
   bf16_t* hi; bf16_t* lo; const int* count;
@@ -414,7 +416,7 @@ __global__ __launch_bounds__(256) void trunk_act_split_kernel(ActArgs a) {
   const int c = (int)(idx - row * c8) * 8;
   const int pos = (int)(row % a.rows_per_seq);
   f32x8_t v;
-  if (pos < a.pad || pos >= a.rows_per_seq - a.pad) {
+  if (pos >= a.rows_per_seq - a.pad) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = 0.0f;
   } else {
@@ -487,7 +489,7 @@ __global__ __launch_bounds__(256) void trunk_ln_split_kernel(LnArgs a) {
 }
 
 // AttentionPool(pool_size = 2): out[b, i, c] = sum_k x[b, 2 i + k, c] softmax_k(logits[b, 2 i + k, c]); an odd L is padded
-// with one masked position (weight 0). x / logits [n, L + 4, C] and out [n, ceil(L / 2) + 4, C] in the padded layout.
+// with one masked position (weight 0). x / logits [n, L + 2, C] and out [n, ceil(L / 2) + 2, C] in the padded layout.
 // Outputs (either may be NULL): the fp32 rows (their pad rows are left untouched) and / or the operand planes of the next
 // GEMM, act(scale o + shift) -> (hi, lo), INCLUDING zeroed pad rows (what svdd_trunk_act_split would write from the fp32 rows).
 struct PoolArgs { const float* x; const float* logits; int n, L, C; float* out; const int* count;
@@ -496,16 +498,16 @@ __global__ __launch_bounds__(256) void trunk_attn_pool_kernel(PoolArgs a) {
   const int nlive = a.count ? min(a.n, *a.count) : a.n;
   const int Lo = (a.L + 1) / 2, c4 = a.C >> 2;
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (int64_t)nlive * (Lo + 4) * c4) return;
+  if (idx >= (int64_t)nlive * (Lo + 2) * c4) return;
   const int c = (int)(idx % c4) * 4;
   const int64_t t = idx / c4;
-  const int i = (int)(t % (Lo + 4)) - 2;                     // output position; -2, -1, Lo, Lo + 1 are the pad rows
-  const int64_t b = t / (Lo + 4);
-  const int64_t orow = b * (Lo + 4) + 2 + i;
+  const int i = (int)(t % (Lo + 2));                         // output position; Lo, Lo + 1 are the pad rows
+  const int64_t b = t / (Lo + 2);
+  const int64_t orow = b * (Lo + 2) + i;
   f32x4 o = {0.0f, 0.0f, 0.0f, 0.0f};
-  const bool real = i >= 0 && i < Lo;
+  const bool real = i < Lo;
   if (real) {
-    const int64_t r0 = b * (a.L + 4) + 2 + 2 * i;
+    const int64_t r0 = b * (a.L + 2) + 2 * i;
     const f32x4 x0 = *reinterpret_cast<const f32x4*>(a.x + r0 * a.C + c), l0 = *reinterpret_cast<const f32x4*>(a.logits + r0 * a.C + c);
     o = x0;
     if (2 * i + 1 < a.L) {
@@ -610,12 +612,12 @@ __global__ __launch_bounds__(256) void trunk_attn_small_kernel(AttnArgs a) {
 struct StemArgs { const uint8_t* tok; int n, L; bf16_t* hi; const int* count; };
 __global__ __launch_bounds__(256) void trunk_stem_unfold_kernel(StemArgs a) {
   const int nlive = a.count ? min(a.n, *a.count) : a.n;
-  const int Lp = a.L + 4;
+  const int Lp = a.L + 2;
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;       // one thread = 8 channels (two taps) of one row
   if (idx >= (int64_t)nlive * Lp * 8) return;
   const int q = (int)(idx & 7);
   const int64_t row = idx >> 3;
-  const int pos = (int)(row % Lp) - 2;
+  const int pos = (int)(row % Lp);
   const int64_t b = row / Lp;
   BV8 v;
 #pragma unroll
@@ -698,7 +700,7 @@ int svdd_trunk_attn_pool(const float* x, const float* logits, int n, int L, int 
       ((post_scale == nullptr) != (post_shift == nullptr)) || post_act < 0 || post_act > 2)
     return SVDD_E_ARG;
   PoolArgs a{x, logits, n, L, C, out, count, (bf16_t*)out_hi, (bf16_t*)out_lo, post_scale, post_shift, post_act};
-  const int64_t nthr = (int64_t)n * ((L + 1) / 2 + 4) * (C >> 2);
+  const int64_t nthr = (int64_t)n * ((L + 1) / 2 + 2) * (C >> 2);
   hipLaunchKernelGGL(trunk_attn_pool_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
 }
@@ -722,7 +724,7 @@ int svdd_trunk_attn_small(const float* qkv, const float* rel_k, const float* con
 int svdd_trunk_stem_unfold(const uint8_t* tok, int n, int L, void* hi, const int32_t* count, void* stream) {
   if (!tok || !hi || n <= 0 || L <= 0) return SVDD_E_ARG;
   StemArgs a{tok, n, L, (bf16_t*)hi, count};
-  const int64_t nthr = (int64_t)n * (L + 4) * 8;
+  const int64_t nthr = (int64_t)n * (L + 2) * 8;
   hipLaunchKernelGGL(trunk_stem_unfold_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
 }

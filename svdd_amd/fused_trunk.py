@@ -8,8 +8,8 @@ matrix product on the 16-bit matrix cores in split precision:
     precision "bf16x3"  operands split hi + lo in bf16, 3 MFMAs per product, fp32 accumulate (fp32-class error);
               "bf16"    one pass on hi.
 
-Layout and kernels (see the header of svdd_trunk.hip): channels-last rows with two zero rows either side of every
-sequence, so a k = 5 convolution is five row-shifted GEMMs accumulated in one launch; BatchNorm (eval) + GELU + the hi / lo
+Layout and kernels (see the header of svdd_trunk.hip): channels-last rows with two zero rows behind every sequence (and two
+guard rows in front of the first), so a k = 5 convolution is five row-shifted GEMMs accumulated in one launch; BatchNorm (eval) + GELU + the hi / lo
 split are one element-wise pass that writes the next GEMM's operand planes; the attention pooling is a 1x1 GEMM for
 the logits plus one pair-softmax pass. The transformer tower works on the 2 tokens a 200-long sequence is pooled down to:
 its projections and FFNs are the same GEMM kernel (q, k, v fused into one launch), its 2 x 2 attention is a handful of
@@ -62,10 +62,14 @@ class _Planes:
     def __init__(self, max_elems, parts, dev):
         self.buf = [torch.zeros(max_elems, dtype=torch.bfloat16, device=dev) for _ in range(parts)]
 
+    FRONT = GUARD * 4096      # elements in front of row 0, the same for every channel count: the two rows a k = 5 tap reads in
+                              # front of the first sequence must be zero, and with a C-dependent offset they would alias the
+                              # data rows of a narrower view of the same buffer
+
     def view(self, rows, C):
-        need = (GUARD + rows + TAIL) * C
-        assert need <= self.buf[0].numel(), (rows, C, self.buf[0].numel())
-        return [b[GUARD * C:] for b in self.buf]
+        need = self.FRONT + (rows + TAIL) * C
+        assert C <= 4096 and need <= self.buf[0].numel(), (rows, C, self.buf[0].numel())
+        return [b[self.FRONT:] for b in self.buf]
 
 
 class FusedEnformerValueNet(nn.Module):
@@ -168,7 +172,7 @@ class FusedEnformerValueNet(nn.Module):
         key = (n, L, str(dev))
         ws = self._ws.get(key)
         if ws is None:
-            rows0 = n * (L + 4)
+            rows0 = n * (L + 2)
             Tf = L
             for _ in self.levels:
                 Tf = (Tf + 1) // 2                                # tokens left for the transformer tower
@@ -180,6 +184,7 @@ class FusedEnformerValueNet(nn.Module):
                        max((GUARD + n * ((L >> max(i - 1, 0)) + 5) + TAIL) * lv["C"] for i, lv in enumerate(self.levels)),
                        (GUARD + Tf * n + TAIL) * max(self.pw_out, 2 * self.C))
             # two sets of operand planes: a GEMM reads one and writes the next GEMM's operands into the other
+            pmax += _Planes.FRONT
             ws = {"f": [torch.empty(fmax, dtype=torch.float32, device=dev) for _ in range(4)],
                   "p": [_Planes(pmax, self.parts, dev), _Planes(pmax, self.parts, dev)], "cmax": cmax}
             self._ws = {key: ws}                                   # one workspace at a time (GBs at the C4 shard size)
@@ -211,7 +216,7 @@ class FusedEnformerValueNet(nn.Module):
 
         # ---- conv tower. Every GEMM / pooling epilogue writes the operand planes of the GEMM that follows it
         # (BatchNorm + GELU + hi / lo split fused; round 3a ran a separate element-wise pass per GEMM: 9 ms of 73).
-        Lc, rps = L, L + 4
+        Lc, rps = L, L + 2
         rows = n * rps
         ph = planes(rows, 64, side)
         _lib.check(lib.svdd_trunk_stem_unfold(tok.data_ptr(), n, L, ph[0].data_ptr(), _ptr(count), _stream()), "svdd_trunk_stem_unfold")
@@ -245,18 +250,18 @@ class FusedEnformerValueNet(nn.Module):
                 args = (xn.data_ptr(), _ptr(count), None, None, None, None, ACT_NONE)
             else:                                                 # the next level's k = 5 block takes gelu(bn(x)) as planes only
                 nx = self.levels[i + 1]
-                pn = planes(n * (Lo + 4), nx["a_cin"], 1 - side)
+                pn = planes(n * (Lo + 2), nx["a_cin"], 1 - side)
                 args = (None, _ptr(count), pn[0].data_ptr(), pn[1].data_ptr() if P == 2 else None, _ptr(nx["a_bn"][0]),
                         _ptr(nx["a_bn"][1]), ACT_GELU)
                 side = 1 - side
             _lib.check(lib.svdd_trunk_attn_pool(y.data_ptr(), lg.data_ptr(), n, Lc, C, *args, _stream()), "svdd_trunk_attn_pool")
             cur = (cur + 3) % 4
             Lc = Lo
-            rps = Lc + 4
+            rps = Lc + 2
         # ---- transformer tower on the Lc tokens left (2 for L = 200)
         C = self.C
         T = Lc
-        x = f[cur][: n * rps * C].view(n, rps, C)[:, 2:2 + T].reshape(n * T, C).contiguous()
+        x = f[cur][: n * rps * C].view(n, rps, C)[:, :T].reshape(n * T, C).contiguous()
         rows = n * T
         for d in self.tf:
             h, dk, dv, nq, nv = d["heads"], d["dk"], d["dv"], d["nq"], d["nv"]
