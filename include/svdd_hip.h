@@ -400,7 +400,7 @@ int svdd_device_info(char* arch, int arch_len, int* num_cu);
 
 /* ABI version of this header: bumped on any signature change. */
 int svdd_abi_version(void);
-#define SVDD_ABI_VERSION 5
+#define SVDD_ABI_VERSION 6
 
 /*
  * Enformer-shaped value trunk (BASELINE.json configs[3]; reference decode.py:78-80, Enformer.py:1271-1334 trunk, :1807-1884
@@ -426,6 +426,17 @@ int svdd_abi_version(void);
  *                        [n T, heads (2 dk + dv)] = [q | k | v], rel_k [heads, 2 T - 1, dk] (positional keys), content / pos bias
  *                        [heads, dk] -> softmax(((q s + cb) k^T + shift((q s + pb) rel_k^T))) v as (hi, lo) planes [n T, heads dv].
  * svdd_trunk_stem_unfold tokens [n, L] u8 -> hi plane [n (L + 2), 64]: channel 4 t + token of position l + t - 7 (t < 15) set to 1.
+ *
+ * First level shared between a candidate and its parent (exact; the SVDD-MC step of reference diffusion_gosai.py:1203-1209 scores
+ * M candidates that differ from x_t at a few positions, and the stem, the 1 x 1 block and the pooling of the first level are
+ * functions of a 15-token window): only the rows of one even-aligned window per candidate go through the level's GEMMs, as
+ * compact rows without pads; the rest of the level's output planes are copies of the parent's.
+ * svdd_trunk_windows         candidate c (cand [n, L] u8) vs row parent_idx[c] / div of parent [., L]: w0[c], wlen[c] = the even-aligned
+ *                            window that covers every position within `halo` of a difference (wlen 0: none, and for c >= count). L even.
+ * svdd_trunk_stem_unfold_win the stem operand of the window rows: row off[c] + r = position w0[c] + r of candidate c (off = exclusive
+ *                            prefix sum of wlen).
+ * svdd_trunk_attn_pool_win   x, logits fp32 [sum wlen, C] (compact rows) -> the next GEMM's operand planes [n, L/2 + 2, C]: pooled window
+ *                            rows where the window covers the pair, else the row of the parent's planes [., L/2 + 2, C]; pad rows zero.
  */
 int svdd_trunk_gemm(const void* a_hi, const void* a_lo, const void* w, const float* bias, const float* resid, float* out,
                     int M, int N, int Cin, int T, int lda, int ldo, int act, const int32_t* count, int rows_per_seq,
@@ -440,6 +451,14 @@ int svdd_trunk_attn_pool(const float* x, const float* logits, int n, int L, int 
 int svdd_trunk_attn_small(const float* qkv, const float* rel_k, const float* content_bias, const float* pos_bias, int n, int T,
                           int heads, int dk, int dv, void* hi, void* lo, const int32_t* count, void* stream);
 int svdd_trunk_stem_unfold(const uint8_t* tok, int n, int L, void* hi, const int32_t* count, void* stream);
+int svdd_trunk_windows(const uint8_t* cand, const uint8_t* parent, const int32_t* parent_idx, int div, int n, int L, int halo,
+                       const int32_t* count, int32_t* w0, int32_t* wlen, void* stream);
+int svdd_trunk_stem_unfold_win(const uint8_t* tok, int n, int L, const int32_t* w0, const int32_t* wlen, const int32_t* off,
+                               void* hi, const int32_t* count, void* stream);
+int svdd_trunk_attn_pool_win(const float* x, const float* logits, int n, int L, int C, const int32_t* w0, const int32_t* wlen,
+                             const int32_t* off, const int32_t* parent_idx, int div, const void* parent_hi, const void* parent_lo,
+                             const int32_t* count, void* out_hi, void* out_lo, const float* post_scale, const float* post_shift,
+                             int post_act, void* stream);
 
 #ifdef __cplusplus
 }

@@ -13,7 +13,7 @@ CSRC = os.path.join(_HERE, "csrc")
 # SVDD_HIP_LIB: load another build of the library instead (the timing-experiment scripts under tools/ build patched
 # copies of the kernels in a scratch directory; the tracked sources are never edited in place)
 SO_PATH = os.environ.get("SVDD_HIP_LIB") or os.path.join(CSRC, "libsvdd_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 OK, E_ARG, E_LAUNCH, E_NODEVICE = 0, -1, -2, -3
 LAYOUT_BLV, LAYOUT_BVL = 0, 1
@@ -32,6 +32,7 @@ EXPORTS = (
     "svdd_backbone_cnn_lp", "svdd_conv_tower_lp", "svdd_conv_tower_windows_lp", "svdd_gru_bidir_lp", "svdd_value_tail_lp",
     "svdd_compact_flags", "svdd_gather_rows", "svdd_advance_rows", "svdd_select_compact", "svdd_set_tower_version", "svdd_set_backbone_packing",
     "svdd_trunk_gemm", "svdd_trunk_act_split", "svdd_trunk_layernorm_split", "svdd_trunk_attn_pool", "svdd_trunk_stem_unfold", "svdd_trunk_attn_small",
+    "svdd_trunk_windows", "svdd_trunk_stem_unfold_win", "svdd_trunk_attn_pool_win",
 )
 OPT_FORCE_EXACT = 0
 
@@ -121,6 +122,9 @@ def lib():
     L.svdd_trunk_layernorm_split.argtypes = [vp, vp, vp, f32, i64, i32, vp, vp, vp, i32, vp]
     L.svdd_trunk_attn_pool.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp]
     L.svdd_trunk_stem_unfold.argtypes = [vp, i32, i32, vp, vp, vp]
+    L.svdd_trunk_windows.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]
+    L.svdd_trunk_stem_unfold_win.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp]
+    L.svdd_trunk_attn_pool_win.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp]
     L.svdd_trunk_attn_small.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp]
     L.svdd_profile_enable.argtypes = [i32]
     L.svdd_profile_collect.argtypes = [i32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]

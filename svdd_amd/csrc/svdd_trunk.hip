@@ -635,6 +635,95 @@ __global__ __launch_bounds__(256) void trunk_stem_unfold_kernel(StemArgs a) {
   *reinterpret_cast<BV8*>(a.hi + row * 64 + 8 * q) = v;
 }
 
+// ---- first level shared between a candidate and its parent (exact) ------------------------------------------------------
+// The stem (k = 15), the 1 x 1 residual block and the pooling logits of the first level make row p of a sequence a function
+// of tokens p - 7 .. p + 7 only, and a pooled row i a function of rows 2 i, 2 i + 1. A candidate of the SVDD-MC step differs
+// from its parent x_t at a few positions: only the rows of ONE even-aligned window [w0, w0 + wlen) around them are computed
+// (compact rows, no pads: every GEMM of the level is 1 x 1 over the unfolded stem operand), the rest of the level's output
+// planes are the parent's, copied. Same kernels and the same per-row arithmetic as the whole-sequence path: same bits.
+//   trunk_windows_kernel        one wave per live candidate: first / last position that differs from the parent -> w0, wlen
+//   trunk_stem_unfold_win_kernel  the stem operand of the window rows, at compact row off[c] + r
+//   trunk_attn_pool_win_kernel  pooling of the window rows + copy of the parent's planes elsewhere -> the next level's operands
+struct WinArgs { const uint8_t* cand; const uint8_t* parent; const int* pidx; int div, n, L, halo; const int* count; int* w0; int* wlen; };
+__global__ __launch_bounds__(256) void trunk_windows_kernel(WinArgs a) {
+  const int nlive = a.count ? min(a.n, *a.count) : a.n;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (c >= a.n) return;
+  if (c >= nlive) { if (lane == 0) { a.w0[c] = 0; a.wlen[c] = 0; } return; }
+  const uint8_t* cr = a.cand + (size_t)c * a.L;
+  const uint8_t* pr = a.parent + (size_t)(a.pidx[c] / a.div) * a.L;
+  int lo = a.L, hi = -1;
+  for (int p = lane; p < a.L; p += 64)
+    if (cr[p] != pr[p]) { lo = min(lo, p); hi = max(hi, p); }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { lo = min(lo, __shfl_xor(lo, off, 64)); hi = max(hi, __shfl_xor(hi, off, 64)); }
+  if (lane == 0) {
+    int w0 = 0, w1 = 0;
+    if (hi >= 0) { w0 = max(0, lo - a.halo) & ~1; w1 = min(a.L, (hi + a.halo + 2) & ~1); }
+    a.w0[c] = w0; a.wlen[c] = w1 - w0;
+  }
+}
+
+struct StemWinArgs { const uint8_t* tok; int n, L; const int* w0; const int* wlen; const int* off; bf16_t* hi; const int* count; };
+__global__ __launch_bounds__(256) void trunk_stem_unfold_win_kernel(StemWinArgs a) {
+  const int nlive = a.count ? min(a.n, *a.count) : a.n;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;       // one thread = 8 channels (two taps) of one row
+  const int q = (int)(idx & 7);
+  const int64_t t = idx >> 3;
+  const int r = (int)(t % a.L);
+  const int64_t b = t / a.L;
+  if (b >= nlive || r >= a.wlen[b]) return;
+  const int pos = a.w0[b] + r;
+  BV8 v;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = (bf16_t)0.0f;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int tp = 2 * q + h, p = pos + tp - 7;
+    if (tp < 15 && p >= 0 && p < a.L) {
+      const int tk = a.tok[b * a.L + p];
+      if (tk < 4) v[4 * h + tk] = (bf16_t)1.0f;
+    }
+  }
+  *reinterpret_cast<BV8*>(a.hi + ((int64_t)a.off[b] + r) * 64 + 8 * q) = v;
+}
+
+struct PoolWinArgs { const float* x; const float* logits; int n, L, C; const int* w0; const int* wlen; const int* off;
+                     const int* pidx; int div; const bf16_t* p_hi; const bf16_t* p_lo; const int* count;
+                     bf16_t* hi; bf16_t* lo; const float* scale; const float* shift; int act; };
+__global__ __launch_bounds__(256) void trunk_attn_pool_win_kernel(PoolWinArgs a) {
+  const int nlive = a.count ? min(a.n, *a.count) : a.n;
+  const int Lo = a.L / 2, c4 = a.C >> 2;                     // L is even here
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)nlive * (Lo + 2) * c4) return;
+  const int c = (int)(idx % c4) * 4;
+  const int64_t t = idx / c4;
+  const int i = (int)(t % (Lo + 2));                         // output position; Lo, Lo + 1 are the pad rows
+  const int64_t b = t / (Lo + 2);
+  const int64_t orow = b * (Lo + 2) + i;
+  const int w0 = a.w0[b], wl = a.wlen[b];
+  if (i < Lo && 2 * i >= w0 && 2 * i < w0 + wl) {
+    const int64_t r0 = (int64_t)a.off[b] + 2 * i - w0;
+    const f32x4 x0 = *reinterpret_cast<const f32x4*>(a.x + r0 * a.C + c), l0 = *reinterpret_cast<const f32x4*>(a.logits + r0 * a.C + c);
+    const f32x4 x1 = *reinterpret_cast<const f32x4*>(a.x + (r0 + 1) * a.C + c), l1 = *reinterpret_cast<const f32x4*>(a.logits + (r0 + 1) * a.C + c);
+    f32x4 tt;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float m = fmaxf(l0[e], l1[e]);
+      const float e0 = __expf(l0[e] - m), e1 = __expf(l1[e] - m);
+      const float o = (x0[e] * e0 + x1[e] * e1) / (e0 + e1);
+      tt[e] = apply_act(a.scale ? o * a.scale[c + e] + a.shift[c + e] : o, a.act);
+    }
+    const BV4 h = __builtin_convertvector(tt, BV4);
+    *reinterpret_cast<BV4*>(a.hi + orow * a.C + c) = h;
+    if (a.lo) *reinterpret_cast<BV4*>(a.lo + orow * a.C + c) = __builtin_convertvector(tt - __builtin_convertvector(h, f32x4), BV4);
+  } else {                                                   // the parent's row (its pad rows are zero)
+    const int64_t prow = (int64_t)(a.pidx[b] / a.div) * (Lo + 2) + i;
+    *reinterpret_cast<BV4*>(a.hi + orow * a.C + c) = *reinterpret_cast<const BV4*>(a.p_hi + prow * a.C + c);
+    if (a.lo) *reinterpret_cast<BV4*>(a.lo + orow * a.C + c) = *reinterpret_cast<const BV4*>(a.p_lo + prow * a.C + c);
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -726,6 +815,38 @@ int svdd_trunk_stem_unfold(const uint8_t* tok, int n, int L, void* hi, const int
   StemArgs a{tok, n, L, (bf16_t*)hi, count};
   const int64_t nthr = (int64_t)n * (L + 2) * 8;
   hipLaunchKernelGGL(trunk_stem_unfold_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
+}
+
+int svdd_trunk_windows(const uint8_t* cand, const uint8_t* parent, const int32_t* parent_idx, int div, int n, int L, int halo,
+                       const int32_t* count, int32_t* w0, int32_t* wlen, void* stream) {
+  if (!cand || !parent || !parent_idx || !w0 || !wlen || div <= 0 || n <= 0 || L <= 0 || (L & 1) || halo < 0) return SVDD_E_ARG;
+  WinArgs a{cand, parent, parent_idx, div, n, L, halo, count, w0, wlen};
+  hipLaunchKernelGGL(trunk_windows_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
+  return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
+}
+
+int svdd_trunk_stem_unfold_win(const uint8_t* tok, int n, int L, const int32_t* w0, const int32_t* wlen, const int32_t* off,
+                               void* hi, const int32_t* count, void* stream) {
+  if (!tok || !hi || !w0 || !wlen || !off || n <= 0 || L <= 0) return SVDD_E_ARG;
+  StemWinArgs a{tok, n, L, w0, wlen, off, (bf16_t*)hi, count};
+  const int64_t nthr = (int64_t)n * L * 8;
+  hipLaunchKernelGGL(trunk_stem_unfold_win_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
+}
+
+int svdd_trunk_attn_pool_win(const float* x, const float* logits, int n, int L, int C, const int32_t* w0, const int32_t* wlen,
+                             const int32_t* off, const int32_t* parent_idx, int div, const void* parent_hi, const void* parent_lo,
+                             const int32_t* count, void* out_hi, void* out_lo, const float* post_scale, const float* post_shift,
+                             int post_act, void* stream) {
+  if (!x || !logits || !w0 || !wlen || !off || !parent_idx || !parent_hi || !out_hi || n <= 0 || L <= 0 || (L & 1) || C <= 0 ||
+      (C & 3) || div <= 0 || ((out_lo == nullptr) != (parent_lo == nullptr)) || ((post_scale == nullptr) != (post_shift == nullptr)) ||
+      post_act < 0 || post_act > 2)
+    return SVDD_E_ARG;
+  PoolWinArgs a{x, logits, n, L, C, w0, wlen, off, parent_idx, div, (const bf16_t*)parent_hi, (const bf16_t*)parent_lo, count,
+                (bf16_t*)out_hi, (bf16_t*)out_lo, post_scale, post_shift, post_act};
+  const int64_t nthr = (int64_t)n * (L / 2 + 2) * (C >> 2);
+  hipLaunchKernelGGL(trunk_attn_pool_win_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
 }
 

@@ -773,7 +773,10 @@ class Diffusion(nn.Module):
                 candidate_windows(cand, x, margin=0, flags=ws.flags)
                 ops.compact_flags(ws.flags, ws.live_idx, ws.slot, ws.count)
                 ops.gather_rows(cand.view(B * M, L), ws.live_idx, ws.count, toks_c)
-                sc = fn.forward_tokens(toks_c, count=ws.count).reshape(-1)
+                if getattr(fn, "share_level0", False):                       # the Enformer-shaped trunk: first level on the changed windows only
+                    sc = fn.forward_tokens(toks_c, count=ws.count, shared=(x, ws.live_idx, M)).reshape(-1)
+                else:
+                    sc = fn.forward_tokens(toks_c, count=ws.count).reshape(-1)
             if self.trace is not None or self.state_trace is not None:
                 self._record(logits, self._dense_scores(sc, ws, B, M), x)
             x = self._select_compact(sc, ws, cand, i)

@@ -135,6 +135,8 @@ class FusedEnformerValueNet(nn.Module):
             self.head_b = hw.bias.detach().float()
         self._relk = {}
         self.timing = None
+        self.share_level0 = True        # forward_tokens(shared=...): first level on the changed windows only (exact)
+        self.last_window_rows = None
 
     # ------------------------------------------------------------------ thin kernel wrappers
     def _gemm(self, planes, w, bias, resid, out, M, N, Cin, T, act, count, rps, nxt=None, post=None, post_act=ACT_NONE, pad=0):
@@ -200,9 +202,74 @@ class FusedEnformerValueNet(nn.Module):
         return r
 
     # ------------------------------------------------------------------ forward
+    def _level0(self, ws, tok, count, target, win=None):
+        """Stem + 1 x 1 residual block + attention pooling of the first level -> `target`: the operand planes
+        [n, L/2 + 2, C] of the second level's k = 5 convolution. win = None: every row of every sequence (padded layout);
+        win = dict(w0, wlen, off, total, pidx, div, parent): only the window rows of each sequence, as compact rows
+        without pads (all three GEMMs are 1 x 1 over the unfolded stem operand), the other rows copied from `parent`."""
+        n, L = tok.shape
+        f, P = ws["f"], self.parts
+        lib = _lib.lib()
+        lv0, nx = self.levels[0], self.levels[1]
+        C = lv0["C"]
+        planes = lambda rows, C, which: ws["p"][which].view(rows, C)[:P]          # noqa: E731
+        if win is None:
+            rps, pad, rows, cnt = L + 2, 2, n * (L + 2), count
+            ph = planes(rows, 64, 0)
+            _lib.check(lib.svdd_trunk_stem_unfold(tok.data_ptr(), n, L, ph[0].data_ptr(), _ptr(count), _stream()), "svdd_trunk_stem_unfold")
+        else:
+            rps, pad, rows, cnt = 1, 0, n * L, win["total"]                       # rows: the bound the grids are sized for
+            ph = planes(rows, 64, 0)
+            _lib.check(lib.svdd_trunk_stem_unfold_win(tok.data_ptr(), n, L, win["w0"].data_ptr(), win["wlen"].data_ptr(), win["off"].data_ptr(),
+                                                      ph[0].data_ptr(), _ptr(count), _stream()), "svdd_trunk_stem_unfold_win")
+        if P == 2:
+            ph[1][: rows * 64].zero_()                           # the one-hot operand is exact: its lo plane is zero
+        self._gemm(ph, self.stem_w, self.stem_b, None, f[0], rows, C, 64, 1, ACT_NONE, cnt, rps,
+                   nxt=planes(rows, C, 1), post=lv0["b_bn"], post_act=ACT_GELU, pad=pad)
+        self._gemm(planes(rows, C, 1), lv0["b_w"], lv0["b_b"], f[0], f[1], rows, C, C, 1, ACT_NONE, cnt, rps,
+                   nxt=planes(rows, C, 0), post=None, post_act=ACT_NONE, pad=pad)
+        self._gemm(planes(rows, C, 0), lv0["pool_w"], None, None, f[2], rows, C, C, 1, ACT_NONE, cnt, rps)
+        t_hi, t_lo = target[0].data_ptr(), target[1].data_ptr() if P == 2 else None
+        if win is None:
+            rc = lib.svdd_trunk_attn_pool(f[1].data_ptr(), f[2].data_ptr(), n, L, C, None, _ptr(count), t_hi, t_lo,
+                                          _ptr(nx["a_bn"][0]), _ptr(nx["a_bn"][1]), ACT_GELU, _stream())
+            _lib.check(rc, "svdd_trunk_attn_pool")
+        else:
+            pp = win["parent"]
+            rc = lib.svdd_trunk_attn_pool_win(f[1].data_ptr(), f[2].data_ptr(), n, L, C, win["w0"].data_ptr(), win["wlen"].data_ptr(),
+                                              win["off"].data_ptr(), win["pidx"].data_ptr(), win["div"], pp[0].data_ptr(),
+                                              pp[1].data_ptr() if P == 2 else None, _ptr(count), t_hi, t_lo,
+                                              _ptr(nx["a_bn"][0]), _ptr(nx["a_bn"][1]), ACT_GELU, _stream())
+            _lib.check(rc, "svdd_trunk_attn_pool_win")
+
+    def _level0_shared(self, ws, tok, count, shared, target):
+        """First level of candidates `tok` that differ from their parents at a few positions (see svdd_trunk.hip, "first
+        level shared"): the parents' level once, then one window of rows per candidate. Bit-identical to _level0(tok)."""
+        parent_tok, pidx, div = shared
+        n, L = tok.shape
+        B = parent_tok.shape[0]
+        dev = tok.device
+        Lo, C1 = L // 2, self.levels[1]["a_cin"]
+        key = ("pp", B, L)
+        if key not in ws:
+            ws[key] = [torch.empty(B * (Lo + 2) * C1, dtype=torch.bfloat16, device=dev) for _ in range(self.parts)]
+            ws["win"] = [torch.empty(n, dtype=torch.int32, device=dev) for _ in range(2)]
+        pp = ws[key]
+        self._level0(ws, parent_tok, None, pp)
+        w0, wlen = ws["win"]
+        rc = _lib.lib().svdd_trunk_windows(tok.data_ptr(), parent_tok.data_ptr(), pidx.data_ptr(), div, n, L, 7, _ptr(count),
+                                           w0.data_ptr(), wlen.data_ptr(), _stream())
+        _lib.check(rc, "svdd_trunk_windows")
+        cs = torch.cumsum(wlen, 0, dtype=torch.int32)
+        win = {"w0": w0, "wlen": wlen, "off": cs - wlen, "total": cs[n - 1:], "pidx": pidx, "div": div, "parent": pp}
+        self.last_window_rows = cs[n - 1:]                        # device scalar (statistics only)
+        self._level0(ws, tok, count, target, win)
+
     @torch.no_grad()
-    def forward_tokens(self, tok, count=None):
-        """tok [n, L] u8 -> scores [n, n_tasks, 1]; count: int32 device scalar = live rows (rows beyond it are undefined)."""
+    def forward_tokens(self, tok, count=None, shared=None):
+        """tok [n, L] u8 -> scores [n, n_tasks, 1]; count: int32 device scalar = live rows (rows beyond it are undefined).
+        shared = (parent_tok [B, L] u8, parent_idx int32 [n], div): row c of tok is a candidate of row parent_idx[c] // div of
+        parent_tok and differs from it at a few positions; the first level is then computed on those windows only (exact)."""
         assert tok.is_cuda and tok.dtype == torch.uint8 and tok.is_contiguous()
         n, L = tok.shape
         dev = tok.device
@@ -217,18 +284,25 @@ class FusedEnformerValueNet(nn.Module):
         # ---- conv tower. Every GEMM / pooling epilogue writes the operand planes of the GEMM that follows it
         # (BatchNorm + GELU + hi / lo split fused; round 3a ran a separate element-wise pass per GEMM: 9 ms of 73).
         Lc, rps = L, L + 2
-        rows = n * rps
-        ph = planes(rows, 64, side)
-        _lib.check(lib.svdd_trunk_stem_unfold(tok.data_ptr(), n, L, ph[0].data_ptr(), _ptr(count), _stream()), "svdd_trunk_stem_unfold")
-        if P == 2:
-            ph[1][: rows * 64].zero_()                           # the one-hot operand is exact: its lo plane is zero
-        lv0 = self.levels[0]
-        C = lv0["C"]
         cur = 0                                                   # index of the fp32 buffer that holds x
-        self._gemm(ph, self.stem_w, self.stem_b, None, f[cur], rows, C, 64, 1, ACT_NONE, count, rps,
-                   nxt=planes(rows, C, 1 - side), post=lv0["b_bn"], post_act=ACT_GELU, pad=2)
-        side = 1 - side
+        first = 0
+        if shared is not None and self.share_level0 and L % 2 == 0 and len(self.levels) > 1 and shared[0].shape[0] <= n:
+            Lc, rps, first = L // 2, L // 2 + 2, 1
+            self._level0_shared(ws, tok, count, shared, planes(n * rps, self.levels[1]["a_cin"], side))
+        else:
+            rows = n * rps
+            ph = planes(rows, 64, side)
+            _lib.check(lib.svdd_trunk_stem_unfold(tok.data_ptr(), n, L, ph[0].data_ptr(), _ptr(count), _stream()), "svdd_trunk_stem_unfold")
+            if P == 2:
+                ph[1][: rows * 64].zero_()                       # the one-hot operand is exact: its lo plane is zero
+            lv0 = self.levels[0]
+            C = lv0["C"]
+            self._gemm(ph, self.stem_w, self.stem_b, None, f[cur], rows, C, 64, 1, ACT_NONE, count, rps,
+                       nxt=planes(rows, C, 1 - side), post=lv0["b_bn"], post_act=ACT_GELU, pad=2)
+            side = 1 - side
         for i, lv in enumerate(self.levels):
+            if i < first:
+                continue
             rows = n * rps
             if i > 0:                                             # k = 5 block: z = conv5(gelu(bn(x))); planes of x come from the pool
                 z = f[(cur + 1) % 4]

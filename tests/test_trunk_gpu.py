@@ -180,6 +180,52 @@ def test_gemm_256_tiles_equal_128_tiles(M, N, Cin, T, rps, live, parts):
         assert err <= (2e-5 if parts == 2 else 1e-4), err
 
 
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("kw", [dict(n_conv=4, channels=768, n_transformers=2, n_heads=4, key_len=16), None])
+def test_first_level_shared_with_the_parent_same_bits(precision, kw):
+    """forward_tokens(shared=...): stem, 1 x 1 block and pooling of the first level only on the window of rows around the
+    positions where a candidate differs from its parent, the parent's planes elsewhere — the same bits as the whole-sequence
+    path, for windows at both ends, single positions, differences spread over the whole sequence, copies of the parent
+    (empty window) and a device-side live count. kw None: the full-size trunk of BASELINE.json configs[3]."""
+    from svdd_amd import synthetic
+    from svdd_amd.fused_trunk import FusedEnformerValueNet
+    extra = dict(enformer_kwargs=kw) if kw else {}
+    small = dict(hidden_dim=32, num_cnn_stacks=1) if kw else {}
+    _, emb, head, _ = synthetic.build("dna", DEV, value="enformer", **small, **extra)
+    _randomise(emb, head, 3)
+    g = torch.Generator(device="cpu").manual_seed(11)
+    B, M, L = 5, 6, 200
+    x = torch.randint(0, 5, (B, L), generator=g, dtype=torch.uint8)
+    x[0] = 4
+    cand = x[:, None, :].repeat(1, M, 1)
+    edits = {(0, 0): [0], (0, 1): [199], (0, 2): [0, 199], (0, 3): [7, 8], (0, 4): [100], (1, 0): [6], (1, 1): [193], (1, 2): [14, 15, 16],
+             (1, 3): [1, 60, 120, 180], (2, 0): [99, 101], (2, 5): [198], (3, 1): list(range(0, 200, 9)), (3, 2): [50], (4, 0): [150, 151],
+             (4, 3): [8], (4, 4): [191], (4, 5): [33, 77]}
+    for (b, m), ps in edits.items():
+        for p in ps:
+            cand[b, m, p] = (int(cand[b, m, p]) + 1 + (p % 3)) % 5
+    ids = sorted(b * M + m for (b, m) in edits) + [2 * M + 1]              # one copy of its parent: an empty window
+    x, cand = x.to(DEV), cand.to(DEV)
+    n = B * M
+    toks = torch.zeros((n, L), dtype=torch.uint8, device=DEV)
+    live = len(ids)
+    idx = torch.zeros(n, dtype=torch.int32, device=DEV)
+    idx[:live] = torch.tensor(ids, dtype=torch.int32, device=DEV)
+    toks[:live] = cand.view(n, L)[idx[:live].long()]
+    cnt = torch.tensor([live], dtype=torch.int32, device=DEV)
+    with torch.no_grad():
+        fn = FusedEnformerValueNet(emb, head, precision)
+        whole = fn.forward_tokens(toks, count=cnt).reshape(n)[:live].clone()
+        shared = fn.forward_tokens(toks, count=cnt, shared=(x, idx, M)).reshape(n)[:live].clone()
+        rows = int(fn.last_window_rows)
+        fn.share_level0 = False
+        off = fn.forward_tokens(toks, count=cnt, shared=(x, idx, M)).reshape(n)[:live].clone()
+    assert torch.isfinite(whole).all() and whole.unique().numel() > live // 2
+    assert torch.equal(shared, whole)
+    assert torch.equal(off, whole)
+    assert 0 < rows < live * L // 2, rows                                  # the windows are a fraction of the rows
+
+
 def test_cli_mc_with_the_enformer_value_trunk(tmp_path):
     """decode.py --model enformer (reference decode.py:72-80,149: the Enformer-shaped trunk as value function) through the CLI
     mirror with --precision bf16x3: the hand-written trunk kernels score the candidates; npz contract of decode.py:117."""
