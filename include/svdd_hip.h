@@ -431,12 +431,19 @@ int svdd_abi_version(void);
  * M candidates that differ from x_t at a few positions, and the stem, the 1 x 1 block and the pooling of the first level are
  * functions of a 15-token window): only the rows of one even-aligned window per candidate go through the level's GEMMs, as
  * compact rows without pads; the rest of the level's output planes are copies of the parent's.
- * svdd_trunk_windows         candidate c (cand [n, L] u8) vs row parent_idx[c] / div of parent [., L]: w0[c], wlen[c] = the even-aligned
- *                            window that covers every position within `halo` of a difference (wlen 0: none, and for c >= count). L even.
+ * The next levels go the same way while their lengths are even: level d + 1 can differ in rows [w0/2 - 2, w1/2 + 2) (k = 5
+ * convolution); a level d >= 1 works on compact segments of window + 2 rows of context on each side.
+ * svdd_trunk_windows         candidate c (cand [n, L] u8) vs row parent_idx[c] / div of parent [., L]: for the `depth` shared levels
+ *                            (L % 2^depth == 0) w0[d n + c], wlen[d n + c] = the even-aligned window of level d (level 0: every position
+ *                            within `halo` of a difference; wlen 0: none, and for c >= count), seg[d n + c] = its compact rows
+ *                            (wlen, + 4 context rows for d >= 1).
  * svdd_trunk_stem_unfold_win the stem operand of the window rows: row off[c] + r = position w0[c] + r of candidate c (off = exclusive
- *                            prefix sum of wlen).
- * svdd_trunk_attn_pool_win   x, logits fp32 [sum wlen, C] (compact rows) -> the next GEMM's operand planes [n, L/2 + 2, C]: pooled window
- *                            rows where the window covers the pair, else the row of the parent's planes [., L/2 + 2, C]; pad rows zero.
+ *                            prefix sum of seg).
+ * svdd_trunk_attn_pool_win   x, logits fp32 (compact rows of a level of length L; segment c starts at off[c], its window in_halo rows
+ *                            further) -> the next GEMM's operand planes: pooled window rows where the window covers the pair, else
+ *                            the row of the parent's planes [., L/2 + 2, C] (zeros outside the sequence). v0 == NULL: whole sequences
+ *                            [n, L/2 + 2, C], pad rows zero; else the compact segments of the next level: rows v0[c] - 2 ..
+ *                            v0[c] + vlen[c] + 1 at off2[c].
  */
 int svdd_trunk_gemm(const void* a_hi, const void* a_lo, const void* w, const float* bias, const float* resid, float* out,
                     int M, int N, int Cin, int T, int lda, int ldo, int act, const int32_t* count, int rows_per_seq,
@@ -452,13 +459,14 @@ int svdd_trunk_attn_small(const float* qkv, const float* rel_k, const float* con
                           int heads, int dk, int dv, void* hi, void* lo, const int32_t* count, void* stream);
 int svdd_trunk_stem_unfold(const uint8_t* tok, int n, int L, void* hi, const int32_t* count, void* stream);
 int svdd_trunk_windows(const uint8_t* cand, const uint8_t* parent, const int32_t* parent_idx, int div, int n, int L, int halo,
-                       const int32_t* count, int32_t* w0, int32_t* wlen, void* stream);
+                       int depth, const int32_t* count, int32_t* w0, int32_t* wlen, int32_t* seg, void* stream);
 int svdd_trunk_stem_unfold_win(const uint8_t* tok, int n, int L, const int32_t* w0, const int32_t* wlen, const int32_t* off,
                                void* hi, const int32_t* count, void* stream);
-int svdd_trunk_attn_pool_win(const float* x, const float* logits, int n, int L, int C, const int32_t* w0, const int32_t* wlen,
-                             const int32_t* off, const int32_t* parent_idx, int div, const void* parent_hi, const void* parent_lo,
-                             const int32_t* count, void* out_hi, void* out_lo, const float* post_scale, const float* post_shift,
-                             int post_act, void* stream);
+int svdd_trunk_attn_pool_win(const float* x, const float* logits, int n, int L, int C, int in_halo, const int32_t* w0,
+                             const int32_t* wlen, const int32_t* off, const int32_t* parent_idx, int div, const void* parent_hi,
+                             const void* parent_lo, const int32_t* count, void* out_hi, void* out_lo, const float* post_scale,
+                             const float* post_shift, int post_act, const int32_t* v0, const int32_t* vlen, const int32_t* off2,
+                             void* stream);
 
 #ifdef __cplusplus
 }

@@ -641,26 +641,38 @@ __global__ __launch_bounds__(256) void trunk_stem_unfold_kernel(StemArgs a) {
 // from its parent x_t at a few positions: only the rows of ONE even-aligned window [w0, w0 + wlen) around them are computed
 // (compact rows, no pads: every GEMM of the level is 1 x 1 over the unfolded stem operand), the rest of the level's output
 // planes are the parent's, copied. Same kernels and the same per-row arithmetic as the whole-sequence path: same bits.
+// The next levels go the same way (depth levels in all, each of even length): the rows of level d + 1 that can differ are
+// [w0 / 2 - 2, w1 / 2 + 2) (k = 5 convolution), again even-aligned; a level d >= 1 works on compact SEGMENTS of window + 2 rows
+// of context on each side (what the k = 5 taps read: pooled window rows, the parent's rows, zeros outside the sequence —
+// the outputs at the context rows are garbage and never read). The last shared level writes whole-sequence planes.
 //   trunk_windows_kernel        one wave per live candidate: first / last position that differs from the parent -> w0, wlen
 //   trunk_stem_unfold_win_kernel  the stem operand of the window rows, at compact row off[c] + r
 //   trunk_attn_pool_win_kernel  pooling of the window rows + copy of the parent's planes elsewhere -> the next level's operands
-struct WinArgs { const uint8_t* cand; const uint8_t* parent; const int* pidx; int div, n, L, halo; const int* count; int* w0; int* wlen; };
+struct WinArgs { const uint8_t* cand; const uint8_t* parent; const int* pidx; int div, n, L, halo, depth; const int* count;
+                 int* w0; int* wlen; int* seg; };
 __global__ __launch_bounds__(256) void trunk_windows_kernel(WinArgs a) {
   const int nlive = a.count ? min(a.n, *a.count) : a.n;
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (c >= a.n) return;
-  if (c >= nlive) { if (lane == 0) { a.w0[c] = 0; a.wlen[c] = 0; } return; }
-  const uint8_t* cr = a.cand + (size_t)c * a.L;
-  const uint8_t* pr = a.parent + (size_t)(a.pidx[c] / a.div) * a.L;
   int lo = a.L, hi = -1;
-  for (int p = lane; p < a.L; p += 64)
-    if (cr[p] != pr[p]) { lo = min(lo, p); hi = max(hi, p); }
+  if (c < nlive) {
+    const uint8_t* cr = a.cand + (size_t)c * a.L;
+    const uint8_t* pr = a.parent + (size_t)(a.pidx[c] / a.div) * a.L;
+    for (int p = lane; p < a.L; p += 64)
+      if (cr[p] != pr[p]) { lo = min(lo, p); hi = max(hi, p); }
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) { lo = min(lo, __shfl_xor(lo, off, 64)); hi = max(hi, __shfl_xor(hi, off, 64)); }
+    for (int off = 32; off > 0; off >>= 1) { lo = min(lo, __shfl_xor(lo, off, 64)); hi = max(hi, __shfl_xor(hi, off, 64)); }
+  }
   if (lane == 0) {
-    int w0 = 0, w1 = 0;
+    int w0 = 0, w1 = 0, Lc = a.L;
     if (hi >= 0) { w0 = max(0, lo - a.halo) & ~1; w1 = min(a.L, (hi + a.halo + 2) & ~1); }
-    a.w0[c] = w0; a.wlen[c] = w1 - w0;
+    for (int d = 0; d < a.depth; ++d) {                      // level d + 1 from level d: rows / 2, two more on each side (k = 5)
+      const int wl = w1 - w0;
+      a.w0[d * a.n + c] = w0; a.wlen[d * a.n + c] = wl;
+      a.seg[d * a.n + c] = wl > 0 ? wl + (d ? 4 : 0) : 0;    // compact rows of the level: the window + 2 rows of context each side
+      Lc >>= 1;
+      if (wl > 0) { w0 = max(0, (w0 >> 1) - 2) & ~1; w1 = min(Lc, ((w1 >> 1) + 3) & ~1); }
+    }
   }
 }
 
@@ -688,22 +700,34 @@ __global__ __launch_bounds__(256) void trunk_stem_unfold_win_kernel(StemWinArgs 
   *reinterpret_cast<BV8*>(a.hi + ((int64_t)a.off[b] + r) * 64 + 8 * q) = v;
 }
 
-struct PoolWinArgs { const float* x; const float* logits; int n, L, C; const int* w0; const int* wlen; const int* off;
+struct PoolWinArgs { const float* x; const float* logits; int n, L, C, in_halo; const int* w0; const int* wlen; const int* off;
                      const int* pidx; int div; const bf16_t* p_hi; const bf16_t* p_lo; const int* count;
-                     bf16_t* hi; bf16_t* lo; const float* scale; const float* shift; int act; };
+                     bf16_t* hi; bf16_t* lo; const float* scale; const float* shift; int act;
+                     const int* v0; const int* vlen; const int* off2; };
 __global__ __launch_bounds__(256) void trunk_attn_pool_win_kernel(PoolWinArgs a) {
   const int nlive = a.count ? min(a.n, *a.count) : a.n;
   const int Lo = a.L / 2, c4 = a.C >> 2;                     // L is even here
+  const int per = a.v0 ? Lo + 4 : Lo + 2;                    // thread slots per sequence
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (int64_t)nlive * (Lo + 2) * c4) return;
+  if (idx >= (int64_t)nlive * per * c4) return;
   const int c = (int)(idx % c4) * 4;
   const int64_t t = idx / c4;
-  const int i = (int)(t % (Lo + 2));                         // output position; Lo, Lo + 1 are the pad rows
-  const int64_t b = t / (Lo + 2);
-  const int64_t orow = b * (Lo + 2) + i;
+  const int r = (int)(t % per);
+  const int64_t b = t / per;
+  int i;                                                     // output position: Lo, Lo + 1 are the pad rows of the whole-sequence layout
+  int64_t orow;
+  if (a.v0) {                                                // compact output: rows v0 - 2 .. v0 + vlen + 1 of the next level's input
+    const int vl = a.vlen[b];
+    if (vl == 0 || r >= vl + 4) return;
+    i = a.v0[b] - 2 + r;
+    orow = (int64_t)a.off2[b] + r;
+  } else {
+    i = r;
+    orow = b * (Lo + 2) + r;
+  }
   const int w0 = a.w0[b], wl = a.wlen[b];
-  if (i < Lo && 2 * i >= w0 && 2 * i < w0 + wl) {
-    const int64_t r0 = (int64_t)a.off[b] + 2 * i - w0;
+  if (i >= 0 && i < Lo && 2 * i >= w0 && 2 * i < w0 + wl) {
+    const int64_t r0 = (int64_t)a.off[b] + a.in_halo + 2 * i - w0;
     const f32x4 x0 = *reinterpret_cast<const f32x4*>(a.x + r0 * a.C + c), l0 = *reinterpret_cast<const f32x4*>(a.logits + r0 * a.C + c);
     const f32x4 x1 = *reinterpret_cast<const f32x4*>(a.x + (r0 + 1) * a.C + c), l1 = *reinterpret_cast<const f32x4*>(a.logits + (r0 + 1) * a.C + c);
     f32x4 tt;
@@ -717,8 +741,9 @@ __global__ __launch_bounds__(256) void trunk_attn_pool_win_kernel(PoolWinArgs a)
     const BV4 h = __builtin_convertvector(tt, BV4);
     *reinterpret_cast<BV4*>(a.hi + orow * a.C + c) = h;
     if (a.lo) *reinterpret_cast<BV4*>(a.lo + orow * a.C + c) = __builtin_convertvector(tt - __builtin_convertvector(h, f32x4), BV4);
-  } else {                                                   // the parent's row (its pad rows are zero)
-    const int64_t prow = (int64_t)(a.pidx[b] / a.div) * (Lo + 2) + i;
+  } else {                                                   // the parent's row (its pad rows are zero: also what lies outside the sequence)
+    const int ip = i < 0 ? Lo : min(i, Lo);
+    const int64_t prow = (int64_t)(a.pidx[b] / a.div) * (Lo + 2) + ip;
     *reinterpret_cast<BV4*>(a.hi + orow * a.C + c) = *reinterpret_cast<const BV4*>(a.p_hi + prow * a.C + c);
     if (a.lo) *reinterpret_cast<BV4*>(a.lo + orow * a.C + c) = *reinterpret_cast<const BV4*>(a.p_lo + prow * a.C + c);
   }
@@ -819,9 +844,11 @@ int svdd_trunk_stem_unfold(const uint8_t* tok, int n, int L, void* hi, const int
 }
 
 int svdd_trunk_windows(const uint8_t* cand, const uint8_t* parent, const int32_t* parent_idx, int div, int n, int L, int halo,
-                       const int32_t* count, int32_t* w0, int32_t* wlen, void* stream) {
-  if (!cand || !parent || !parent_idx || !w0 || !wlen || div <= 0 || n <= 0 || L <= 0 || (L & 1) || halo < 0) return SVDD_E_ARG;
-  WinArgs a{cand, parent, parent_idx, div, n, L, halo, count, w0, wlen};
+                       int depth, const int32_t* count, int32_t* w0, int32_t* wlen, int32_t* seg, void* stream) {
+  if (!cand || !parent || !parent_idx || !w0 || !wlen || !seg || div <= 0 || n <= 0 || L <= 0 || halo < 0 || depth < 1 || depth > 8 ||
+      (L & ((1 << depth) - 1)))
+    return SVDD_E_ARG;
+  WinArgs a{cand, parent, parent_idx, div, n, L, halo, depth, count, w0, wlen, seg};
   hipLaunchKernelGGL(trunk_windows_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
   return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
 }
@@ -835,17 +862,19 @@ int svdd_trunk_stem_unfold_win(const uint8_t* tok, int n, int L, const int32_t* 
   return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
 }
 
-int svdd_trunk_attn_pool_win(const float* x, const float* logits, int n, int L, int C, const int32_t* w0, const int32_t* wlen,
-                             const int32_t* off, const int32_t* parent_idx, int div, const void* parent_hi, const void* parent_lo,
-                             const int32_t* count, void* out_hi, void* out_lo, const float* post_scale, const float* post_shift,
-                             int post_act, void* stream) {
+int svdd_trunk_attn_pool_win(const float* x, const float* logits, int n, int L, int C, int in_halo, const int32_t* w0,
+                             const int32_t* wlen, const int32_t* off, const int32_t* parent_idx, int div, const void* parent_hi,
+                             const void* parent_lo, const int32_t* count, void* out_hi, void* out_lo, const float* post_scale,
+                             const float* post_shift, int post_act, const int32_t* v0, const int32_t* vlen, const int32_t* off2,
+                             void* stream) {
   if (!x || !logits || !w0 || !wlen || !off || !parent_idx || !parent_hi || !out_hi || n <= 0 || L <= 0 || (L & 1) || C <= 0 ||
-      (C & 3) || div <= 0 || ((out_lo == nullptr) != (parent_lo == nullptr)) || ((post_scale == nullptr) != (post_shift == nullptr)) ||
-      post_act < 0 || post_act > 2)
+      (C & 3) || div <= 0 || in_halo < 0 || ((out_lo == nullptr) != (parent_lo == nullptr)) ||
+      ((post_scale == nullptr) != (post_shift == nullptr)) || post_act < 0 || post_act > 2 ||
+      ((v0 == nullptr) != (vlen == nullptr)) || ((v0 == nullptr) != (off2 == nullptr)))
     return SVDD_E_ARG;
-  PoolWinArgs a{x, logits, n, L, C, w0, wlen, off, parent_idx, div, (const bf16_t*)parent_hi, (const bf16_t*)parent_lo, count,
-                (bf16_t*)out_hi, (bf16_t*)out_lo, post_scale, post_shift, post_act};
-  const int64_t nthr = (int64_t)n * (L / 2 + 2) * (C >> 2);
+  PoolWinArgs a{x, logits, n, L, C, in_halo, w0, wlen, off, parent_idx, div, (const bf16_t*)parent_hi, (const bf16_t*)parent_lo, count,
+                (bf16_t*)out_hi, (bf16_t*)out_lo, post_scale, post_shift, post_act, v0, vlen, off2};
+  const int64_t nthr = (int64_t)n * (L / 2 + (v0 ? 4 : 2)) * (C >> 2);
   hipLaunchKernelGGL(trunk_attn_pool_win_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
 }

@@ -135,7 +135,8 @@ class FusedEnformerValueNet(nn.Module):
             self.head_b = hw.bias.detach().float()
         self._relk = {}
         self.timing = None
-        self.share_level0 = True        # forward_tokens(shared=...): first level on the changed windows only (exact)
+        self.share_level0 = True        # forward_tokens(shared=...): the first levels on the changed windows only (exact)
+        self.share_levels = 3           # ... how many of them (each must have an even length: 200, 100, 50 at L = 200)
         self.last_window_rows = None
 
     # ------------------------------------------------------------------ thin kernel wrappers
@@ -202,74 +203,96 @@ class FusedEnformerValueNet(nn.Module):
         return r
 
     # ------------------------------------------------------------------ forward
-    def _level0(self, ws, tok, count, target, win=None):
-        """Stem + 1 x 1 residual block + attention pooling of the first level -> `target`: the operand planes
-        [n, L/2 + 2, C] of the second level's k = 5 convolution. win = None: every row of every sequence (padded layout);
-        win = dict(w0, wlen, off, total, pidx, div, parent): only the window rows of each sequence, as compact rows
-        without pads (all three GEMMs are 1 x 1 over the unfolded stem operand), the other rows copied from `parent`."""
-        n, L = tok.shape
+    def _convs(self, ws, i, src, rows, rps, pad, cnt):
+        """The three GEMMs of conv-tower level i on the operand planes `src` ([rows, C_in]: plane set 0 or a buffer of its own;
+        level 0: the unfolded stem operand): block output -> f[2], pooling logits -> f[3]."""
         f, P = ws["f"], self.parts
+        lv = self.levels[i]
+        C = lv["C"]
+        planes = lambda which: ws["p"][which].view(rows, C)[:P]                    # noqa: E731
+        w, b, cin, T = (self.stem_w, self.stem_b, 64, 1) if i == 0 else (lv["a_w"], lv["a_b"], lv["a_cin"], 5)
+        self._gemm(src, w, b, None, f[1], rows, C, cin, T, ACT_NONE, cnt, rps, nxt=planes(1), post=lv["b_bn"], post_act=ACT_GELU, pad=pad)
+        self._gemm(planes(1), lv["b_w"], lv["b_b"], f[1], f[2], rows, C, C, 1, ACT_NONE, cnt, rps, nxt=planes(0), post=None,
+                   post_act=ACT_NONE, pad=pad)
+        self._gemm(planes(0), lv["pool_w"], None, None, f[3], rows, C, C, 1, ACT_NONE, cnt, rps)
+
+    def _unfold(self, ws, tok, rows, count, win=None):
+        n, L = tok.shape
+        ph = ws["p"][0].view(rows, 64)[:self.parts]
         lib = _lib.lib()
-        lv0, nx = self.levels[0], self.levels[1]
-        C = lv0["C"]
-        planes = lambda rows, C, which: ws["p"][which].view(rows, C)[:P]          # noqa: E731
         if win is None:
-            rps, pad, rows, cnt = L + 2, 2, n * (L + 2), count
-            ph = planes(rows, 64, 0)
             _lib.check(lib.svdd_trunk_stem_unfold(tok.data_ptr(), n, L, ph[0].data_ptr(), _ptr(count), _stream()), "svdd_trunk_stem_unfold")
         else:
-            rps, pad, rows, cnt = 1, 0, n * L, win["total"]                       # rows: the bound the grids are sized for
-            ph = planes(rows, 64, 0)
-            _lib.check(lib.svdd_trunk_stem_unfold_win(tok.data_ptr(), n, L, win["w0"].data_ptr(), win["wlen"].data_ptr(), win["off"].data_ptr(),
+            _lib.check(lib.svdd_trunk_stem_unfold_win(tok.data_ptr(), n, L, win[0].data_ptr(), win[1].data_ptr(), win[2].data_ptr(),
                                                       ph[0].data_ptr(), _ptr(count), _stream()), "svdd_trunk_stem_unfold_win")
-        if P == 2:
+        if self.parts == 2:
             ph[1][: rows * 64].zero_()                           # the one-hot operand is exact: its lo plane is zero
-        self._gemm(ph, self.stem_w, self.stem_b, None, f[0], rows, C, 64, 1, ACT_NONE, cnt, rps,
-                   nxt=planes(rows, C, 1), post=lv0["b_bn"], post_act=ACT_GELU, pad=pad)
-        self._gemm(planes(rows, C, 1), lv0["b_w"], lv0["b_b"], f[0], f[1], rows, C, C, 1, ACT_NONE, cnt, rps,
-                   nxt=planes(rows, C, 0), post=None, post_act=ACT_NONE, pad=pad)
-        self._gemm(planes(rows, C, 0), lv0["pool_w"], None, None, f[2], rows, C, C, 1, ACT_NONE, cnt, rps)
-        t_hi, t_lo = target[0].data_ptr(), target[1].data_ptr() if P == 2 else None
-        if win is None:
-            rc = lib.svdd_trunk_attn_pool(f[1].data_ptr(), f[2].data_ptr(), n, L, C, None, _ptr(count), t_hi, t_lo,
-                                          _ptr(nx["a_bn"][0]), _ptr(nx["a_bn"][1]), ACT_GELU, _stream())
-            _lib.check(rc, "svdd_trunk_attn_pool")
-        else:
-            pp = win["parent"]
-            rc = lib.svdd_trunk_attn_pool_win(f[1].data_ptr(), f[2].data_ptr(), n, L, C, win["w0"].data_ptr(), win["wlen"].data_ptr(),
-                                              win["off"].data_ptr(), win["pidx"].data_ptr(), win["div"], pp[0].data_ptr(),
-                                              pp[1].data_ptr() if P == 2 else None, _ptr(count), t_hi, t_lo,
-                                              _ptr(nx["a_bn"][0]), _ptr(nx["a_bn"][1]), ACT_GELU, _stream())
-            _lib.check(rc, "svdd_trunk_attn_pool_win")
+        return ph
 
-    def _level0_shared(self, ws, tok, count, shared, target):
-        """First level of candidates `tok` that differ from their parents at a few positions (see svdd_trunk.hip, "first
-        level shared"): the parents' level once, then one window of rows per candidate. Bit-identical to _level0(tok)."""
+    def _shared_levels(self, ws, tok, count, shared, depth):
+        """The first `depth` levels of candidates `tok` that differ from their parents at a few positions (svdd_trunk.hip,
+        "first level shared"): the parents' levels once (whole sequences), then one window of rows per candidate and level.
+        Leaves the operand planes of level `depth` in plane set 0 — the same bits as the whole-sequence path."""
         parent_tok, pidx, div = shared
         n, L = tok.shape
         B = parent_tok.shape[0]
-        dev = tok.device
-        Lo, C1 = L // 2, self.levels[1]["a_cin"]
-        key = ("pp", B, L)
+        dev, P, f, lib = tok.device, self.parts, ws["f"], _lib.lib()
+        key = ("pp", B, L, depth)
         if key not in ws:
-            ws[key] = [torch.empty(B * (Lo + 2) * C1, dtype=torch.bfloat16, device=dev) for _ in range(self.parts)]
-            ws["win"] = [torch.empty(n, dtype=torch.int32, device=dev) for _ in range(2)]
+            ws[key] = [None] + [_Planes(_Planes.FRONT + (B * ((L >> d) + 2) + TAIL) * self.levels[d]["a_cin"], P, dev)
+                                for d in range(1, depth + 1)]
+            ws["win"] = torch.empty((3, depth, n), dtype=torch.int32, device=dev)
         pp = ws[key]
-        self._level0(ws, parent_tok, None, pp)
-        w0, wlen = ws["win"]
-        rc = _lib.lib().svdd_trunk_windows(tok.data_ptr(), parent_tok.data_ptr(), pidx.data_ptr(), div, n, L, 7, _ptr(count),
-                                           w0.data_ptr(), wlen.data_ptr(), _stream())
+        # ---- the parents: whole sequences, the pooled planes of every shared level kept
+        Lc = L
+        for d in range(depth):
+            rps = Lc + 2
+            rows = B * rps
+            src = self._unfold(ws, parent_tok, rows, None) if d == 0 else pp[d].view(rows, self.levels[d]["a_cin"])[:P]
+            self._convs(ws, d, src, rows, rps, 2, None)
+            nx = self.levels[d + 1]
+            tg = pp[d + 1].view(B * (Lc // 2 + 2), nx["a_cin"])[:P]
+            rc = lib.svdd_trunk_attn_pool(f[2].data_ptr(), f[3].data_ptr(), B, Lc, self.levels[d]["C"], None, None, tg[0].data_ptr(),
+                                          tg[1].data_ptr() if P == 2 else None, _ptr(nx["a_bn"][0]), _ptr(nx["a_bn"][1]), ACT_GELU, _stream())
+            _lib.check(rc, "svdd_trunk_attn_pool")
+            Lc //= 2
+        # ---- the candidates: windows
+        w0, wlen, seg = ws["win"]
+        rc = lib.svdd_trunk_windows(tok.data_ptr(), parent_tok.data_ptr(), pidx.data_ptr(), div, n, L, 7, depth, _ptr(count),
+                                    w0.data_ptr(), wlen.data_ptr(), seg.data_ptr(), _stream())
         _lib.check(rc, "svdd_trunk_windows")
-        cs = torch.cumsum(wlen, 0, dtype=torch.int32)
-        win = {"w0": w0, "wlen": wlen, "off": cs - wlen, "total": cs[n - 1:], "pidx": pidx, "div": div, "parent": pp}
-        self.last_window_rows = cs[n - 1:]                        # device scalar (statistics only)
-        self._level0(ws, tok, count, target, win)
+        cs = torch.cumsum(seg, 1, dtype=torch.int32)
+        off = cs - seg
+        self.last_window_rows = cs[:, n - 1]                      # device vector (statistics only): compact rows per shared level
+        Lc = L
+        for d in range(depth):
+            rows = n * (Lc + (4 if d else 0))                     # the bound the grids are sized for; live rows: cs[d, n - 1]
+            lv, nx = self.levels[d], self.levels[d + 1]
+            src = self._unfold(ws, tok, rows, count, (w0[0], wlen[0], off[0])) if d == 0 else ws["p"][0].view(rows, lv["a_cin"])[:P]
+            self._convs(ws, d, src, rows, 1, 0, cs[d, n - 1:])
+            last = d + 1 == depth
+            tg = ws["p"][0].view(n * (Lc // 2 + (2 if last else 4)), nx["a_cin"])[:P]
+            nxt_win = (None, None, None) if last else (w0[d + 1].data_ptr(), wlen[d + 1].data_ptr(), off[d + 1].data_ptr())
+            ppl = pp[d + 1].view(B * (Lc // 2 + 2), nx["a_cin"])[:P]
+            rc = lib.svdd_trunk_attn_pool_win(f[2].data_ptr(), f[3].data_ptr(), n, Lc, lv["C"], 2 if d else 0, w0[d].data_ptr(),
+                                              wlen[d].data_ptr(), off[d].data_ptr(), pidx.data_ptr(), div, ppl[0].data_ptr(),
+                                              ppl[1].data_ptr() if P == 2 else None, _ptr(count), tg[0].data_ptr(),
+                                              tg[1].data_ptr() if P == 2 else None, _ptr(nx["a_bn"][0]), _ptr(nx["a_bn"][1]), ACT_GELU,
+                                              *nxt_win, _stream())
+            _lib.check(rc, "svdd_trunk_attn_pool_win")
+            Lc //= 2
+
+    def _share_depth(self, L):
+        d = 0
+        while d < min(self.share_levels, len(self.levels) - 1) and (L >> d) % 2 == 0:
+            d += 1
+        return d
 
     @torch.no_grad()
     def forward_tokens(self, tok, count=None, shared=None):
         """tok [n, L] u8 -> scores [n, n_tasks, 1]; count: int32 device scalar = live rows (rows beyond it are undefined).
         shared = (parent_tok [B, L] u8, parent_idx int32 [n], div): row c of tok is a candidate of row parent_idx[c] // div of
-        parent_tok and differs from it at a few positions; the first level is then computed on those windows only (exact)."""
+        parent_tok and differs from it at a few positions; the first levels are then computed on those windows only (exact)."""
         assert tok.is_cuda and tok.dtype == torch.uint8 and tok.is_contiguous()
         n, L = tok.shape
         dev = tok.device
@@ -285,10 +308,11 @@ class FusedEnformerValueNet(nn.Module):
         # (BatchNorm + GELU + hi / lo split fused; round 3a ran a separate element-wise pass per GEMM: 9 ms of 73).
         Lc, rps = L, L + 2
         cur = 0                                                   # index of the fp32 buffer that holds x
-        first = 0
-        if shared is not None and self.share_level0 and L % 2 == 0 and len(self.levels) > 1 and shared[0].shape[0] <= n:
-            Lc, rps, first = L // 2, L // 2 + 2, 1
-            self._level0_shared(ws, tok, count, shared, planes(n * rps, self.levels[1]["a_cin"], side))
+        first = self._share_depth(L) if shared is not None and self.share_level0 and shared[0].shape[0] <= n else 0
+        if first:
+            self._shared_levels(ws, tok, count, shared, first)
+            Lc = L >> first
+            rps = Lc + 2
         else:
             rows = n * rps
             ph = planes(rows, 64, side)

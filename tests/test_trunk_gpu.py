@@ -182,8 +182,8 @@ def test_gemm_256_tiles_equal_128_tiles(M, N, Cin, T, rps, live, parts):
 
 @pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
 @pytest.mark.parametrize("kw", [dict(n_conv=4, channels=768, n_transformers=2, n_heads=4, key_len=16), None])
-def test_first_level_shared_with_the_parent_same_bits(precision, kw):
-    """forward_tokens(shared=...): stem, 1 x 1 block and pooling of the first level only on the window of rows around the
+def test_first_levels_shared_with_the_parent_same_bits(precision, kw):
+    """forward_tokens(shared=...): the first levels of the conv tower only on the window of rows around the
     positions where a candidate differs from its parent, the parent's planes elsewhere — the same bits as the whole-sequence
     path, for windows at both ends, single positions, differences spread over the whole sequence, copies of the parent
     (empty window) and a device-side live count. kw None: the full-size trunk of BASELINE.json configs[3]."""
@@ -216,14 +216,18 @@ def test_first_level_shared_with_the_parent_same_bits(precision, kw):
     with torch.no_grad():
         fn = FusedEnformerValueNet(emb, head, precision)
         whole = fn.forward_tokens(toks, count=cnt).reshape(n)[:live].clone()
-        shared = fn.forward_tokens(toks, count=cnt, shared=(x, idx, M)).reshape(n)[:live].clone()
-        rows = int(fn.last_window_rows)
+        rows = {}
+        for depth in (1, 2, 3):                                                # shared levels (lengths 200, 100, 50)
+            fn.share_levels = depth
+            shared = fn.forward_tokens(toks, count=cnt, shared=(x, idx, M)).reshape(n)[:live].clone()
+            assert torch.equal(shared, whole), depth
+            rows[depth] = fn.last_window_rows.tolist()
         fn.share_level0 = False
         off = fn.forward_tokens(toks, count=cnt, shared=(x, idx, M)).reshape(n)[:live].clone()
     assert torch.isfinite(whole).all() and whole.unique().numel() > live // 2
-    assert torch.equal(shared, whole)
     assert torch.equal(off, whole)
-    assert 0 < rows < live * L // 2, rows                                  # the windows are a fraction of the rows
+    assert len(rows[3]) == 3 and rows[3][0] == rows[1][0]
+    assert 0 < rows[3][0] < live * L // 2 and 0 < rows[3][2] < live * 54, rows   # the windows are a fraction of the rows
 
 
 def test_cli_mc_with_the_enformer_value_trunk(tmp_path):
