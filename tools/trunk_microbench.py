@@ -1,5 +1,7 @@
 """The fused Enformer-shaped value trunk (svdd_amd/fused_trunk.py) at the BASELINE configs[3] shard size: time per forward
-against the PyTorch module.  Usage: python tools/trunk_microbench.py [n] [precision] [--module]
+against the PyTorch module.  Usage: python tools/trunk_microbench.py [n] [precision] [--module] [--gemms] [--shared]
+--shared: the rows are candidates of n / 15 parents that differ from them at 1-4 positions (42 / 33 / 17 / 8 %: the mix of a C4
+decode, tools/window_stats.py), scored with the first levels shared with the parent (forward_tokens(shared=...))
 (run under `rocprofv3 --kernel-trace --stats` for the per-kernel split)"""
 import os
 import sys
@@ -30,8 +32,25 @@ def bench(f, it=3):
     return (time.perf_counter() - t) / it * 1e3
 
 
+shared = None
+if "--shared" in sys.argv:
+    M = 15
+    B = n // M
+    g = torch.Generator(device="cpu").manual_seed(1)
+    par = torch.randint(0, 5, (B, 200), generator=g, dtype=torch.uint8)
+    tok = par[:, None, :].repeat(1, M, 1).view(n, 200)
+    k = torch.multinomial(torch.tensor([0.42, 0.33, 0.17, 0.08]), n, replacement=True, generator=g) + 1
+    for c in range(n):
+        pos = torch.randint(0, 200, (int(k[c]),), generator=g)
+        tok[c, pos] = (tok[c, pos] + 1 + torch.randint(0, 4, (int(k[c]),), generator=g, dtype=torch.uint8)) % 5
+    tok = tok.to(dev).contiguous()
+    shared = (par.to(dev), torch.arange(n, dtype=torch.int32, device=dev), M)
+    if os.environ.get("SVDD_SHARE_LEVELS"):
+        fn.share_levels = int(os.environ["SVDD_SHARE_LEVELS"])
 fl = emb.flops_per_sequence() * n
-ms = bench(lambda: fn.forward_tokens(tok))
+ms = bench(lambda: fn.forward_tokens(tok, shared=shared))
+if shared:
+    print("compact rows per shared level:", fn.last_window_rows.tolist(), "of", [n * (200 >> d) for d in range(len(fn.last_window_rows))])
 print(f"fused trunk {prec} n={n}: {ms:.1f} ms  = {fl / ms / 1e9:.1f} TFLOP/s fp32-equivalent ({fl / 1e12:.2f} TFLOP per forward)")
 if "--module" in sys.argv:
     oh = (torch.nn.functional.one_hot(tok.long().clamp(max=3), 4) * (tok != 4)[..., None]).float()
@@ -41,7 +60,7 @@ if "--module" in sys.argv:
 
 if "--gemms" in sys.argv:
     fn.timing = []
-    fn.forward_tokens(tok)
+    fn.forward_tokens(tok, shared=shared)
     torch.cuda.synchronize()
     agg = {}
     for M, N, C, T, e0, e1 in fn.timing:
