@@ -236,6 +236,8 @@ class FusedEnformerValueNet(nn.Module):
         parent_tok, pidx, div = shared
         n, L = tok.shape
         B = parent_tok.shape[0]
+        assert parent_tok.dtype == torch.uint8 and parent_tok.is_contiguous() and parent_tok.shape[1] == L and parent_tok.device == tok.device
+        assert pidx.dtype == torch.int32 and pidx.is_contiguous() and pidx.numel() >= n and div >= 1
         dev, P, f, lib = tok.device, self.parts, ws["f"], _lib.lib()
         key = ("pp", B, L, depth)
         if key not in ws:
