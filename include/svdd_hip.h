@@ -429,21 +429,22 @@ int svdd_abi_version(void);
  *
  * First level shared between a candidate and its parent (exact; the SVDD-MC step of reference diffusion_gosai.py:1203-1209 scores
  * M candidates that differ from x_t at a few positions, and the stem, the 1 x 1 block and the pooling of the first level are
- * functions of a 15-token window): only the rows of one even-aligned window per candidate go through the level's GEMMs, as
- * compact rows without pads; the rest of the level's output planes are copies of the parent's.
+ * functions of a 15-token window): only the rows of up to `slots` (<= 4) even-aligned windows per candidate go through the
+ * level's GEMMs, as compact rows without pads; the rest of the level's output planes are copies of the parent's.
  * The next levels go the same way while their lengths are even: level d + 1 can differ in rows [w0/2 - 2, w1/2 + 2) (k = 5
  * convolution); a level d >= 1 works on compact segments of window + 2 rows of context on each side.
- * svdd_trunk_windows         candidate c (cand [n, L] u8) vs row parent_idx[c] / div of parent [., L]: for the `depth` shared levels
- *                            (L % 2^depth == 0) w0[d n + c], wlen[d n + c] = the even-aligned window of level d (level 0: every position
- *                            within `halo` of a difference; wlen 0: none, and for c >= count), seg[d n + c] = its compact rows
- *                            (wlen, + 4 context rows for d >= 1).
- * svdd_trunk_stem_unfold_win the stem operand of the window rows: row off[c] + r = position w0[c] + r of candidate c (off = exclusive
- *                            prefix sum of seg).
- * svdd_trunk_attn_pool_win   x, logits fp32 (compact rows of a level of length L; segment c starts at off[c], its window in_halo rows
- *                            further) -> the next GEMM's operand planes: pooled window rows where the window covers the pair, else
- *                            the row of the parent's planes [., L/2 + 2, C] (zeros outside the sequence). v0 == NULL: whole sequences
- *                            [n, L/2 + 2, C], pad rows zero; else the compact segments of the next level: rows v0[c] - 2 ..
- *                            v0[c] + vlen[c] + 1 at off2[c].
+ * svdd_trunk_windows         candidate c (cand [n, L] u8, L <= 256) vs row parent_idx[c] / div of parent [., L]: for the `depth`
+ *                            shared levels (L % 2^depth == 0) and window slot j: w0[(d n + c) slots + j], wlen[.] = the even-aligned
+ *                            windows of level d in ascending order (level 0: one per position that differs, +- halo, windows that
+ *                            touch merged, the last slot takes what is left; deeper: windows within 4 rows merged; wlen 0: unused
+ *                            slot, and for c >= count), seg[.] = its compact rows (wlen, + 4 context rows for d >= 1).
+ * svdd_trunk_stem_unfold_win the stem operand of the window rows: the r-th window row of candidate c at compact row off[c slots] + r
+ *                            (off = exclusive prefix sum of seg over [n slots]).
+ * svdd_trunk_attn_pool_win   x, logits fp32 (compact rows of a level of length L; the segment of slot s starts at off[s], its window
+ *                            in_halo rows further) -> the next GEMM's operand planes: pooled window rows where a window covers the
+ *                            pair, else the row of the parent's planes [., L/2 + 2, C] (zeros outside the sequence). v0 == NULL:
+ *                            whole sequences [n, L/2 + 2, C], pad rows zero; else the compact segments of the next level: rows
+ *                            v0[s] - 2 .. v0[s] + vlen[s] + 1 at off2[s].
  */
 int svdd_trunk_gemm(const void* a_hi, const void* a_lo, const void* w, const float* bias, const float* resid, float* out,
                     int M, int N, int Cin, int T, int lda, int ldo, int act, const int32_t* count, int rows_per_seq,
@@ -459,10 +460,10 @@ int svdd_trunk_attn_small(const float* qkv, const float* rel_k, const float* con
                           int heads, int dk, int dv, void* hi, void* lo, const int32_t* count, void* stream);
 int svdd_trunk_stem_unfold(const uint8_t* tok, int n, int L, void* hi, const int32_t* count, void* stream);
 int svdd_trunk_windows(const uint8_t* cand, const uint8_t* parent, const int32_t* parent_idx, int div, int n, int L, int halo,
-                       int depth, const int32_t* count, int32_t* w0, int32_t* wlen, int32_t* seg, void* stream);
-int svdd_trunk_stem_unfold_win(const uint8_t* tok, int n, int L, const int32_t* w0, const int32_t* wlen, const int32_t* off,
-                               void* hi, const int32_t* count, void* stream);
-int svdd_trunk_attn_pool_win(const float* x, const float* logits, int n, int L, int C, int in_halo, const int32_t* w0,
+                       int depth, int slots, const int32_t* count, int32_t* w0, int32_t* wlen, int32_t* seg, void* stream);
+int svdd_trunk_stem_unfold_win(const uint8_t* tok, int n, int L, int slots, const int32_t* w0, const int32_t* wlen,
+                               const int32_t* off, void* hi, const int32_t* count, void* stream);
+int svdd_trunk_attn_pool_win(const float* x, const float* logits, int n, int L, int C, int in_halo, int slots, const int32_t* w0,
                              const int32_t* wlen, const int32_t* off, const int32_t* parent_idx, int div, const void* parent_hi,
                              const void* parent_lo, const int32_t* count, void* out_hi, void* out_lo, const float* post_scale,
                              const float* post_shift, int post_act, const int32_t* v0, const int32_t* vlen, const int32_t* off2,

@@ -122,9 +122,9 @@ def lib():
     L.svdd_trunk_layernorm_split.argtypes = [vp, vp, vp, f32, i64, i32, vp, vp, vp, i32, vp]
     L.svdd_trunk_attn_pool.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp]
     L.svdd_trunk_stem_unfold.argtypes = [vp, i32, i32, vp, vp, vp]
-    L.svdd_trunk_windows.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp]
-    L.svdd_trunk_stem_unfold_win.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp]
-    L.svdd_trunk_attn_pool_win.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp]
+    L.svdd_trunk_windows.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp]
+    L.svdd_trunk_stem_unfold_win.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]
+    L.svdd_trunk_attn_pool_win.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp]
     L.svdd_trunk_attn_small.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp]
     L.svdd_profile_enable.argtypes = [i32]
     L.svdd_profile_collect.argtypes = [i32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]

@@ -648,44 +648,78 @@ __global__ __launch_bounds__(256) void trunk_stem_unfold_kernel(StemArgs a) {
 //   trunk_windows_kernel        one wave per live candidate: first / last position that differs from the parent -> w0, wlen
 //   trunk_stem_unfold_win_kernel  the stem operand of the window rows, at compact row off[c] + r
 //   trunk_attn_pool_win_kernel  pooling of the window rows + copy of the parent's planes elsewhere -> the next level's operands
-struct WinArgs { const uint8_t* cand; const uint8_t* parent; const int* pidx; int div, n, L, halo, depth; const int* count;
+constexpr int WIN_K = 4;                                     // window slots per candidate and level
+struct WinArgs { const uint8_t* cand; const uint8_t* parent; const int* pidx; int div, n, L, halo, depth, K; const int* count;
                  int* w0; int* wlen; int* seg; };
 __global__ __launch_bounds__(256) void trunk_windows_kernel(WinArgs a) {
   const int nlive = a.count ? min(a.n, *a.count) : a.n;
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (c >= a.n) return;
-  int lo = a.L, hi = -1;
+  // the positions that differ, as bit masks in ascending order: bit `lane` of mask r = position 64 r + lane
+  unsigned long long m[4] = {0ull, 0ull, 0ull, 0ull};
   if (c < nlive) {
     const uint8_t* cr = a.cand + (size_t)c * a.L;
     const uint8_t* pr = a.parent + (size_t)(a.pidx[c] / a.div) * a.L;
-    for (int p = lane; p < a.L; p += 64)
-      if (cr[p] != pr[p]) { lo = min(lo, p); hi = max(hi, p); }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { lo = min(lo, __shfl_xor(lo, off, 64)); hi = max(hi, __shfl_xor(hi, off, 64)); }
-  }
-  if (lane == 0) {
-    int w0 = 0, w1 = 0, Lc = a.L;
-    if (hi >= 0) { w0 = max(0, lo - a.halo) & ~1; w1 = min(a.L, (hi + a.halo + 2) & ~1); }
-    for (int d = 0; d < a.depth; ++d) {                      // level d + 1 from level d: rows / 2, two more on each side (k = 5)
-      const int wl = w1 - w0;
-      a.w0[d * a.n + c] = w0; a.wlen[d * a.n + c] = wl;
-      a.seg[d * a.n + c] = wl > 0 ? wl + (d ? 4 : 0) : 0;    // compact rows of the level: the window + 2 rows of context each side
-      Lc >>= 1;
-      if (wl > 0) { w0 = max(0, (w0 >> 1) - 2) & ~1; w1 = min(Lc, ((w1 >> 1) + 3) & ~1); }
+    for (int r = 0; r < 4; ++r) {
+      const int p = 64 * r + lane;
+      m[r] = __ballot(p < a.L && cr[p] != pr[p]);
     }
+  }
+  if (lane != 0) return;
+  const int K = a.K;
+  int s0[WIN_K], s1[WIN_K], ns = 0;
+  // level 0: one window [p - halo, p + halo] per changed position, even-aligned; windows that touch are merged, and from the
+  // K-th window on everything goes into the last slot
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    unsigned long long mm = m[r];
+    while (mm) {
+      const int p = 64 * r + __builtin_ctzll(mm);
+      mm &= mm - 1;
+      const int lo = max(0, p - a.halo) & ~1, hi = min(a.L, (p + a.halo + 2) & ~1);
+      if (ns && (lo <= s1[ns - 1] || ns == K)) s1[ns - 1] = max(s1[ns - 1], hi);
+      else { s0[ns] = lo; s1[ns] = hi; ++ns; }
+    }
+  }
+  int Lc = a.L;
+  for (int d = 0; d < a.depth; ++d) {
+    for (int j = 0; j < K; ++j) {
+      const int wl = j < ns ? s1[j] - s0[j] : 0;
+      const size_t at = ((size_t)d * a.n + c) * K + j;
+      a.w0[at] = j < ns ? s0[j] : 0; a.wlen[at] = wl;
+      a.seg[at] = wl > 0 ? wl + (d ? 4 : 0) : 0;             // compact rows: the window (+ 2 rows of context on each side)
+    }
+    // level d + 1: rows / 2, two more on each side (k = 5); a window within 4 rows of the one before joins it (two
+    // segments would cost 4 context rows more)
+    Lc >>= 1;
+    int nn = 0;
+    for (int j = 0; j < ns; ++j) {
+      const int lo = max(0, (s0[j] >> 1) - 2) & ~1, hi = min(Lc, ((s1[j] >> 1) + 3) & ~1);
+      if (nn && lo <= s1[nn - 1] + 4) s1[nn - 1] = max(s1[nn - 1], hi);
+      else { s0[nn] = lo; s1[nn] = hi; ++nn; }
+    }
+    ns = nn;
   }
 }
 
-struct StemWinArgs { const uint8_t* tok; int n, L; const int* w0; const int* wlen; const int* off; bf16_t* hi; const int* count; };
+struct StemWinArgs { const uint8_t* tok; int n, L, K; const int* w0; const int* wlen; const int* off; bf16_t* hi; const int* count; };
 __global__ __launch_bounds__(256) void trunk_stem_unfold_win_kernel(StemWinArgs a) {
   const int nlive = a.count ? min(a.n, *a.count) : a.n;
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;       // one thread = 8 channels (two taps) of one row
   const int q = (int)(idx & 7);
   const int64_t t = idx >> 3;
-  const int r = (int)(t % a.L);
+  int r = (int)(t % a.L);                                            // r-th window row of the candidate (its windows are disjoint)
   const int64_t b = t / a.L;
-  if (b >= nlive || r >= a.wlen[b]) return;
-  const int pos = a.w0[b] + r;
+  if (b >= nlive) return;
+  int pos = -1;
+  const int64_t row = (int64_t)a.off[b * a.K] + r;                   // level 0 has no context rows: the slots' rows are consecutive
+  for (int j = 0; j < a.K; ++j) {
+    const int wl = a.wlen[b * a.K + j];
+    if (r < wl) { pos = a.w0[b * a.K + j] + r; break; }
+    r -= wl;
+  }
+  if (pos < 0) return;
   BV8 v;
 #pragma unroll
   for (int e = 0; e < 8; ++e) v[e] = (bf16_t)0.0f;
@@ -697,37 +731,44 @@ __global__ __launch_bounds__(256) void trunk_stem_unfold_win_kernel(StemWinArgs 
       if (tk < 4) v[4 * h + tk] = (bf16_t)1.0f;
     }
   }
-  *reinterpret_cast<BV8*>(a.hi + ((int64_t)a.off[b] + r) * 64 + 8 * q) = v;
+  *reinterpret_cast<BV8*>(a.hi + row * 64 + 8 * q) = v;
 }
 
-struct PoolWinArgs { const float* x; const float* logits; int n, L, C, in_halo; const int* w0; const int* wlen; const int* off;
+struct PoolWinArgs { const float* x; const float* logits; int n, L, C, in_halo, K; const int* w0; const int* wlen; const int* off;
                      const int* pidx; int div; const bf16_t* p_hi; const bf16_t* p_lo; const int* count;
                      bf16_t* hi; bf16_t* lo; const float* scale; const float* shift; int act;
                      const int* v0; const int* vlen; const int* off2; };
 __global__ __launch_bounds__(256) void trunk_attn_pool_win_kernel(PoolWinArgs a) {
   const int nlive = a.count ? min(a.n, *a.count) : a.n;
   const int Lo = a.L / 2, c4 = a.C >> 2;                     // L is even here
-  const int per = a.v0 ? Lo + 4 : Lo + 2;                    // thread slots per sequence
+  const int per = a.v0 ? Lo + 4 * a.K : Lo + 2;              // thread slots per sequence
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (int64_t)nlive * per * c4) return;
   const int c = (int)(idx % c4) * 4;
   const int64_t t = idx / c4;
-  const int r = (int)(t % per);
+  int r = (int)(t % per);
   const int64_t b = t / per;
-  int i;                                                     // output position: Lo, Lo + 1 are the pad rows of the whole-sequence layout
-  int64_t orow;
-  if (a.v0) {                                                // compact output: rows v0 - 2 .. v0 + vlen + 1 of the next level's input
-    const int vl = a.vlen[b];
-    if (vl == 0 || r >= vl + 4) return;
-    i = a.v0[b] - 2 + r;
-    orow = (int64_t)a.off2[b] + r;
+  int i = -1000;                                             // output position: Lo, Lo + 1 are the pad rows of the whole-sequence layout
+  int64_t orow = 0;
+  if (a.v0) {                                                // compact output: rows v0 - 2 .. v0 + vlen + 1 of every window of the next level
+    for (int j = 0; j < a.K; ++j) {
+      const int vl = a.vlen[b * a.K + j];
+      const int len = vl > 0 ? vl + 4 : 0;
+      if (r < len) { i = a.v0[b * a.K + j] - 2 + r; orow = (int64_t)a.off2[b * a.K + j] + r; break; }
+      r -= len;
+    }
+    if (i == -1000) return;
   } else {
     i = r;
     orow = b * (Lo + 2) + r;
   }
-  const int w0 = a.w0[b], wl = a.wlen[b];
-  if (i >= 0 && i < Lo && 2 * i >= w0 && 2 * i < w0 + wl) {
-    const int64_t r0 = (int64_t)a.off[b] + a.in_halo + 2 * i - w0;
+  int64_t r0 = -1;                                           // the compact row of this level that holds row 2 i, if a window covers it
+  if (i >= 0 && i < Lo)
+    for (int j = 0; j < a.K; ++j) {
+      const int w0 = a.w0[b * a.K + j], wl = a.wlen[b * a.K + j];
+      if (2 * i >= w0 && 2 * i < w0 + wl) { r0 = (int64_t)a.off[b * a.K + j] + a.in_halo + 2 * i - w0; break; }
+    }
+  if (r0 >= 0) {
     const f32x4 x0 = *reinterpret_cast<const f32x4*>(a.x + r0 * a.C + c), l0 = *reinterpret_cast<const f32x4*>(a.logits + r0 * a.C + c);
     const f32x4 x1 = *reinterpret_cast<const f32x4*>(a.x + (r0 + 1) * a.C + c), l1 = *reinterpret_cast<const f32x4*>(a.logits + (r0 + 1) * a.C + c);
     f32x4 tt;
@@ -844,37 +885,37 @@ int svdd_trunk_stem_unfold(const uint8_t* tok, int n, int L, void* hi, const int
 }
 
 int svdd_trunk_windows(const uint8_t* cand, const uint8_t* parent, const int32_t* parent_idx, int div, int n, int L, int halo,
-                       int depth, const int32_t* count, int32_t* w0, int32_t* wlen, int32_t* seg, void* stream) {
-  if (!cand || !parent || !parent_idx || !w0 || !wlen || !seg || div <= 0 || n <= 0 || L <= 0 || halo < 0 || depth < 1 || depth > 8 ||
-      (L & ((1 << depth) - 1)))
+                       int depth, int slots, const int32_t* count, int32_t* w0, int32_t* wlen, int32_t* seg, void* stream) {
+  if (!cand || !parent || !parent_idx || !w0 || !wlen || !seg || div <= 0 || n <= 0 || L <= 0 || L > 256 || halo < 0 || depth < 1 ||
+      depth > 8 || (L & ((1 << depth) - 1)) || slots < 1 || slots > WIN_K)
     return SVDD_E_ARG;
-  WinArgs a{cand, parent, parent_idx, div, n, L, halo, depth, count, w0, wlen, seg};
+  WinArgs a{cand, parent, parent_idx, div, n, L, halo, depth, slots, count, w0, wlen, seg};
   hipLaunchKernelGGL(trunk_windows_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
   return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
 }
 
-int svdd_trunk_stem_unfold_win(const uint8_t* tok, int n, int L, const int32_t* w0, const int32_t* wlen, const int32_t* off,
-                               void* hi, const int32_t* count, void* stream) {
-  if (!tok || !hi || !w0 || !wlen || !off || n <= 0 || L <= 0) return SVDD_E_ARG;
-  StemWinArgs a{tok, n, L, w0, wlen, off, (bf16_t*)hi, count};
+int svdd_trunk_stem_unfold_win(const uint8_t* tok, int n, int L, int slots, const int32_t* w0, const int32_t* wlen,
+                               const int32_t* off, void* hi, const int32_t* count, void* stream) {
+  if (!tok || !hi || !w0 || !wlen || !off || n <= 0 || L <= 0 || slots < 1 || slots > WIN_K) return SVDD_E_ARG;
+  StemWinArgs a{tok, n, L, slots, w0, wlen, off, (bf16_t*)hi, count};
   const int64_t nthr = (int64_t)n * L * 8;
   hipLaunchKernelGGL(trunk_stem_unfold_win_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
 }
 
-int svdd_trunk_attn_pool_win(const float* x, const float* logits, int n, int L, int C, int in_halo, const int32_t* w0,
+int svdd_trunk_attn_pool_win(const float* x, const float* logits, int n, int L, int C, int in_halo, int slots, const int32_t* w0,
                              const int32_t* wlen, const int32_t* off, const int32_t* parent_idx, int div, const void* parent_hi,
                              const void* parent_lo, const int32_t* count, void* out_hi, void* out_lo, const float* post_scale,
                              const float* post_shift, int post_act, const int32_t* v0, const int32_t* vlen, const int32_t* off2,
                              void* stream) {
   if (!x || !logits || !w0 || !wlen || !off || !parent_idx || !parent_hi || !out_hi || n <= 0 || L <= 0 || (L & 1) || C <= 0 ||
-      (C & 3) || div <= 0 || in_halo < 0 || ((out_lo == nullptr) != (parent_lo == nullptr)) ||
+      (C & 3) || div <= 0 || in_halo < 0 || slots < 1 || slots > WIN_K || ((out_lo == nullptr) != (parent_lo == nullptr)) ||
       ((post_scale == nullptr) != (post_shift == nullptr)) || post_act < 0 || post_act > 2 ||
       ((v0 == nullptr) != (vlen == nullptr)) || ((v0 == nullptr) != (off2 == nullptr)))
     return SVDD_E_ARG;
-  PoolWinArgs a{x, logits, n, L, C, in_halo, w0, wlen, off, parent_idx, div, (const bf16_t*)parent_hi, (const bf16_t*)parent_lo, count,
-                (bf16_t*)out_hi, (bf16_t*)out_lo, post_scale, post_shift, post_act, v0, vlen, off2};
-  const int64_t nthr = (int64_t)n * (L / 2 + (v0 ? 4 : 2)) * (C >> 2);
+  PoolWinArgs a{x, logits, n, L, C, in_halo, slots, w0, wlen, off, parent_idx, div, (const bf16_t*)parent_hi, (const bf16_t*)parent_lo,
+                count, (bf16_t*)out_hi, (bf16_t*)out_lo, post_scale, post_shift, post_act, v0, vlen, off2};
+  const int64_t nthr = (int64_t)n * (L / 2 + (v0 ? 4 * slots : 2)) * (C >> 2);
   hipLaunchKernelGGL(trunk_attn_pool_win_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
 }

@@ -30,6 +30,7 @@ from .value_nets import ConvHead
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 GUARD = 4            # operand-plane rows in front of row 0 (a k = 5 tap reads rows -2 .. of the first tile)
 TAIL = 136           # ... and behind the last row (the last 128-row tile + 2 tap rows)
+WIN_K = 4            # window slots per candidate and level of the shared levels (svdd_trunk.hip)
 
 
 def _ptr(t):
@@ -137,6 +138,7 @@ class FusedEnformerValueNet(nn.Module):
         self.timing = None
         self.share_level0 = True        # forward_tokens(shared=...): the first levels on the changed windows only (exact)
         self.share_levels = 3           # ... how many of them (each must have an even length: 200, 100, 50 at L = 200)
+        self.share_slots = WIN_K        # ... windows per candidate and level (1: one window around every changed position)
         self.last_window_rows = None
 
     # ------------------------------------------------------------------ thin kernel wrappers
@@ -181,10 +183,10 @@ class FusedEnformerValueNet(nn.Module):
                 Tf = (Tf + 1) // 2                                # tokens left for the transformer tower
             cmax = max([lv["C"] for lv in self.levels])
             # the largest activation is at the first level (rows halve per level, channels at most double overall)
-            fmax = max(rows0 * self.levels[0]["C"], max((n * ((L >> i) + 5)) * lv["C"] for i, lv in enumerate(self.levels)),
+            fmax = max(rows0 * self.levels[0]["C"], max((n * ((L >> i) + 4 * WIN_K + 1)) * lv["C"] for i, lv in enumerate(self.levels)),
                        n * Tf * max(self.pw_out, 2 * self.C, 2 * self.tf[0]["nq"] + self.tf[0]["nv"] if self.tf else 0)) + 1024
             pmax = max((GUARD + rows0 + TAIL) * max(64, self.levels[0]["C"]),
-                       max((GUARD + n * ((L >> max(i - 1, 0)) + 5) + TAIL) * lv["C"] for i, lv in enumerate(self.levels)),
+                       max((GUARD + n * ((L >> max(i - 1, 0)) + 4 * WIN_K + 1) + TAIL) * lv["C"] for i, lv in enumerate(self.levels)),
                        (GUARD + Tf * n + TAIL) * max(self.pw_out, 2 * self.C))
             # two sets of operand planes: a GEMM reads one and writes the next GEMM's operands into the other
             pmax += _Planes.FRONT
@@ -223,7 +225,7 @@ class FusedEnformerValueNet(nn.Module):
         if win is None:
             _lib.check(lib.svdd_trunk_stem_unfold(tok.data_ptr(), n, L, ph[0].data_ptr(), _ptr(count), _stream()), "svdd_trunk_stem_unfold")
         else:
-            _lib.check(lib.svdd_trunk_stem_unfold_win(tok.data_ptr(), n, L, win[0].data_ptr(), win[1].data_ptr(), win[2].data_ptr(),
+            _lib.check(lib.svdd_trunk_stem_unfold_win(tok.data_ptr(), n, L, self.share_slots, win[0].data_ptr(), win[1].data_ptr(), win[2].data_ptr(),
                                                       ph[0].data_ptr(), _ptr(count), _stream()), "svdd_trunk_stem_unfold_win")
         if self.parts == 2:
             ph[1][: rows * 64].zero_()                           # the one-hot operand is exact: its lo plane is zero
@@ -231,7 +233,7 @@ class FusedEnformerValueNet(nn.Module):
 
     def _shared_levels(self, ws, tok, count, shared, depth):
         """The first `depth` levels of candidates `tok` that differ from their parents at a few positions (svdd_trunk.hip,
-        "first level shared"): the parents' levels once (whole sequences), then one window of rows per candidate and level.
+        "first level shared"): the parents' levels once (whole sequences), then up to share_slots windows of rows per candidate and level.
         Leaves the operand planes of level `depth` in plane set 0 — the same bits as the whole-sequence path."""
         parent_tok, pidx, div = shared
         n, L = tok.shape
@@ -243,7 +245,9 @@ class FusedEnformerValueNet(nn.Module):
         if key not in ws:
             ws[key] = [None] + [_Planes(_Planes.FRONT + (B * ((L >> d) + 2) + TAIL) * self.levels[d]["a_cin"], P, dev)
                                 for d in range(1, depth + 1)]
-            ws["win"] = torch.empty((3, depth, n), dtype=torch.int32, device=dev)
+        K = self.share_slots
+        if ws.get("win") is None or ws["win"].shape != (3, depth, n * K):
+            ws["win"] = torch.empty((3, depth, n * K), dtype=torch.int32, device=dev)
         pp = ws[key]
         # ---- the parents: whole sequences, the pooled planes of every shared level kept
         Lc = L
@@ -260,23 +264,23 @@ class FusedEnformerValueNet(nn.Module):
             Lc //= 2
         # ---- the candidates: windows
         w0, wlen, seg = ws["win"]
-        rc = lib.svdd_trunk_windows(tok.data_ptr(), parent_tok.data_ptr(), pidx.data_ptr(), div, n, L, 7, depth, _ptr(count),
+        rc = lib.svdd_trunk_windows(tok.data_ptr(), parent_tok.data_ptr(), pidx.data_ptr(), div, n, L, 7, depth, K, _ptr(count),
                                     w0.data_ptr(), wlen.data_ptr(), seg.data_ptr(), _stream())
         _lib.check(rc, "svdd_trunk_windows")
         cs = torch.cumsum(seg, 1, dtype=torch.int32)
         off = cs - seg
-        self.last_window_rows = cs[:, n - 1]                      # device vector (statistics only): compact rows per shared level
+        self.last_window_rows = cs[:, n * K - 1]                  # device vector (statistics only): compact rows per shared level
         Lc = L
         for d in range(depth):
-            rows = n * (Lc + (4 if d else 0))                     # the bound the grids are sized for; live rows: cs[d, n - 1]
+            rows = n * (Lc + (4 * K if d else 0))                 # the bound the grids are sized for; live rows: cs[d, n K - 1]
             lv, nx = self.levels[d], self.levels[d + 1]
             src = self._unfold(ws, tok, rows, count, (w0[0], wlen[0], off[0])) if d == 0 else ws["p"][0].view(rows, lv["a_cin"])[:P]
-            self._convs(ws, d, src, rows, 1, 0, cs[d, n - 1:])
+            self._convs(ws, d, src, rows, 1, 0, cs[d, n * K - 1:])
             last = d + 1 == depth
-            tg = ws["p"][0].view(n * (Lc // 2 + (2 if last else 4)), nx["a_cin"])[:P]
+            tg = ws["p"][0].view(n * (Lc // 2 + (2 if last else 4 * K)), nx["a_cin"])[:P]
             nxt_win = (None, None, None) if last else (w0[d + 1].data_ptr(), wlen[d + 1].data_ptr(), off[d + 1].data_ptr())
             ppl = pp[d + 1].view(B * (Lc // 2 + 2), nx["a_cin"])[:P]
-            rc = lib.svdd_trunk_attn_pool_win(f[2].data_ptr(), f[3].data_ptr(), n, Lc, lv["C"], 2 if d else 0, w0[d].data_ptr(),
+            rc = lib.svdd_trunk_attn_pool_win(f[2].data_ptr(), f[3].data_ptr(), n, Lc, lv["C"], 2 if d else 0, K, w0[d].data_ptr(),
                                               wlen[d].data_ptr(), off[d].data_ptr(), pidx.data_ptr(), div, ppl[0].data_ptr(),
                                               ppl[1].data_ptr() if P == 2 else None, _ptr(count), tg[0].data_ptr(),
                                               tg[1].data_ptr() if P == 2 else None, _ptr(nx["a_bn"][0]), _ptr(nx["a_bn"][1]), ACT_GELU,
@@ -286,7 +290,7 @@ class FusedEnformerValueNet(nn.Module):
 
     def _share_depth(self, L):
         d = 0
-        while d < min(self.share_levels, len(self.levels) - 1) and (L >> d) % 2 == 0:
+        while L <= 256 and d < min(self.share_levels, len(self.levels) - 1) and (L >> d) % 2 == 0:
             d += 1
         return d
 

@@ -185,8 +185,8 @@ def test_gemm_256_tiles_equal_128_tiles(M, N, Cin, T, rps, live, parts):
 def test_first_levels_shared_with_the_parent_same_bits(precision, kw):
     """forward_tokens(shared=...): the first levels of the conv tower only on the window of rows around the
     positions where a candidate differs from its parent, the parent's planes elsewhere — the same bits as the whole-sequence
-    path, for windows at both ends, single positions, differences spread over the whole sequence, copies of the parent
-    (empty window) and a device-side live count. kw None: the full-size trunk of BASELINE.json configs[3]."""
+    path, for windows at both ends, single positions, differences spread over the whole sequence (more of them than window
+    slots), copies of the parent (no window) and a device-side live count. kw None: the full-size trunk of BASELINE.json configs[3]."""
     from svdd_amd import synthetic
     from svdd_amd.fused_trunk import FusedEnformerValueNet
     extra = dict(enformer_kwargs=kw) if kw else {}
@@ -217,17 +217,18 @@ def test_first_levels_shared_with_the_parent_same_bits(precision, kw):
         fn = FusedEnformerValueNet(emb, head, precision)
         whole = fn.forward_tokens(toks, count=cnt).reshape(n)[:live].clone()
         rows = {}
-        for depth in (1, 2, 3):                                                # shared levels (lengths 200, 100, 50)
-            fn.share_levels = depth
+        for depth, slots in ((1, 1), (2, 1), (3, 1), (1, 4), (3, 2), (3, 4)):  # shared levels (lengths 200, 100, 50) x window slots
+            fn.share_levels, fn.share_slots = depth, slots
             shared = fn.forward_tokens(toks, count=cnt, shared=(x, idx, M)).reshape(n)[:live].clone()
-            assert torch.equal(shared, whole), depth
-            rows[depth] = fn.last_window_rows.tolist()
+            assert torch.equal(shared, whole), (depth, slots)
+            rows[depth, slots] = fn.last_window_rows.tolist()
         fn.share_level0 = False
         off = fn.forward_tokens(toks, count=cnt, shared=(x, idx, M)).reshape(n)[:live].clone()
     assert torch.isfinite(whole).all() and whole.unique().numel() > live // 2
     assert torch.equal(off, whole)
-    assert len(rows[3]) == 3 and rows[3][0] == rows[1][0]
-    assert 0 < rows[3][0] < live * L // 2 and 0 < rows[3][2] < live * 54, rows   # the windows are a fraction of the rows
+    assert len(rows[3, 1]) == 3 and rows[3, 1][0] == rows[1, 1][0]
+    assert 0 < rows[3, 1][0] < live * L // 2 and 0 < rows[3, 1][2] < live * 54, rows   # the windows are a fraction of the rows
+    assert rows[3, 4][0] < rows[3, 2][0] < rows[3, 1][0], rows                   # ... a smaller one with a window per changed position
 
 
 def test_cli_mc_with_the_enformer_value_trunk(tmp_path):
