@@ -434,7 +434,7 @@ int svdd_abi_version(void);
  * The next levels go the same way while their lengths are even: level d + 1 can differ in rows [w0/2 - 2, w1/2 + 2) (k = 5
  * convolution); a level d >= 1 works on compact segments of window + 2 rows of context on each side.
  * svdd_trunk_windows         candidate c (cand [n, L] u8, L <= 256) vs row parent_idx[c] / div of parent [., L]: for the `depth`
- *                            shared levels (L % 2^depth == 0) and window slot j: w0[(d n + c) slots + j], wlen[.] = the even-aligned
+ *                            shared levels (L % 2^(depth - 1) == 0: only the last may have an odd length) and window slot j: w0[(d n + c) slots + j], wlen[.] = the even-aligned
  *                            windows of level d in ascending order (level 0: one per position that differs, +- halo, windows that
  *                            touch merged, the last slot takes what is left; deeper: windows within 4 rows merged; wlen 0: unused
  *                            slot, and for c >= count), seg[.] = its compact rows (wlen, + 4 context rows for d >= 1).

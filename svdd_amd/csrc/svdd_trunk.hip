@@ -644,7 +644,8 @@ __global__ __launch_bounds__(256) void trunk_stem_unfold_kernel(StemArgs a) {
 // The next levels go the same way (depth levels in all, each of even length): the rows of level d + 1 that can differ are
 // [w0 / 2 - 2, w1 / 2 + 2) (k = 5 convolution), again even-aligned; a level d >= 1 works on compact SEGMENTS of window + 2 rows
 // of context on each side (what the k = 5 taps read: pooled window rows, the parent's rows, zeros outside the sequence —
-// the outputs at the context rows are garbage and never read). The last shared level writes whole-sequence planes.
+// the outputs at the context rows are garbage and never read). The last shared level writes whole-sequence planes (and may
+// have an odd length: its last row is then pooled alone, as in trunk_attn_pool_kernel).
 //   trunk_windows_kernel        one wave per live candidate: first / last position that differs from the parent -> w0, wlen
 //   trunk_stem_unfold_win_kernel  the stem operand of the window rows, at compact row off[c] + r
 //   trunk_attn_pool_win_kernel  pooling of the window rows + copy of the parent's planes elsewhere -> the next level's operands
@@ -740,7 +741,7 @@ struct PoolWinArgs { const float* x; const float* logits; int n, L, C, in_halo, 
                      const int* v0; const int* vlen; const int* off2; };
 __global__ __launch_bounds__(256) void trunk_attn_pool_win_kernel(PoolWinArgs a) {
   const int nlive = a.count ? min(a.n, *a.count) : a.n;
-  const int Lo = a.L / 2, c4 = a.C >> 2;                     // L is even here
+  const int Lo = (a.L + 1) / 2, c4 = a.C >> 2;               // an odd L (last shared level only) pairs its last row with a masked one
   const int per = a.v0 ? Lo + 4 * a.K : Lo + 2;              // thread slots per sequence
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (int64_t)nlive * per * c4) return;
@@ -770,15 +771,19 @@ __global__ __launch_bounds__(256) void trunk_attn_pool_win_kernel(PoolWinArgs a)
     }
   if (r0 >= 0) {
     const f32x4 x0 = *reinterpret_cast<const f32x4*>(a.x + r0 * a.C + c), l0 = *reinterpret_cast<const f32x4*>(a.logits + r0 * a.C + c);
-    const f32x4 x1 = *reinterpret_cast<const f32x4*>(a.x + (r0 + 1) * a.C + c), l1 = *reinterpret_cast<const f32x4*>(a.logits + (r0 + 1) * a.C + c);
+    f32x4 o = x0;
+    if (2 * i + 1 < a.L) {
+      const f32x4 x1 = *reinterpret_cast<const f32x4*>(a.x + (r0 + 1) * a.C + c), l1 = *reinterpret_cast<const f32x4*>(a.logits + (r0 + 1) * a.C + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float m = fmaxf(l0[e], l1[e]);
+        const float e0 = __expf(l0[e] - m), e1 = __expf(l1[e] - m);
+        o[e] = (x0[e] * e0 + x1[e] * e1) / (e0 + e1);
+      }
+    }
     f32x4 tt;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float m = fmaxf(l0[e], l1[e]);
-      const float e0 = __expf(l0[e] - m), e1 = __expf(l1[e] - m);
-      const float o = (x0[e] * e0 + x1[e] * e1) / (e0 + e1);
-      tt[e] = apply_act(a.scale ? o * a.scale[c + e] + a.shift[c + e] : o, a.act);
-    }
+    for (int e = 0; e < 4; ++e) tt[e] = apply_act(a.scale ? o[e] * a.scale[c + e] + a.shift[c + e] : o[e], a.act);
     const BV4 h = __builtin_convertvector(tt, BV4);
     *reinterpret_cast<BV4*>(a.hi + orow * a.C + c) = h;
     if (a.lo) *reinterpret_cast<BV4*>(a.lo + orow * a.C + c) = __builtin_convertvector(tt - __builtin_convertvector(h, f32x4), BV4);
@@ -887,7 +892,7 @@ int svdd_trunk_stem_unfold(const uint8_t* tok, int n, int L, void* hi, const int
 int svdd_trunk_windows(const uint8_t* cand, const uint8_t* parent, const int32_t* parent_idx, int div, int n, int L, int halo,
                        int depth, int slots, const int32_t* count, int32_t* w0, int32_t* wlen, int32_t* seg, void* stream) {
   if (!cand || !parent || !parent_idx || !w0 || !wlen || !seg || div <= 0 || n <= 0 || L <= 0 || L > 256 || halo < 0 || depth < 1 ||
-      depth > 8 || (L & ((1 << depth) - 1)) || slots < 1 || slots > WIN_K)
+      depth > 8 || (L & ((1 << (depth - 1)) - 1)) || slots < 1 || slots > WIN_K)
     return SVDD_E_ARG;
   WinArgs a{cand, parent, parent_idx, div, n, L, halo, depth, slots, count, w0, wlen, seg};
   hipLaunchKernelGGL(trunk_windows_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
@@ -908,14 +913,14 @@ int svdd_trunk_attn_pool_win(const float* x, const float* logits, int n, int L, 
                              const void* parent_lo, const int32_t* count, void* out_hi, void* out_lo, const float* post_scale,
                              const float* post_shift, int post_act, const int32_t* v0, const int32_t* vlen, const int32_t* off2,
                              void* stream) {
-  if (!x || !logits || !w0 || !wlen || !off || !parent_idx || !parent_hi || !out_hi || n <= 0 || L <= 0 || (L & 1) || C <= 0 ||
+  if (!x || !logits || !w0 || !wlen || !off || !parent_idx || !parent_hi || !out_hi || n <= 0 || L <= 0 || ((L & 1) && v0) || C <= 0 ||
       (C & 3) || div <= 0 || in_halo < 0 || slots < 1 || slots > WIN_K || ((out_lo == nullptr) != (parent_lo == nullptr)) ||
       ((post_scale == nullptr) != (post_shift == nullptr)) || post_act < 0 || post_act > 2 ||
       ((v0 == nullptr) != (vlen == nullptr)) || ((v0 == nullptr) != (off2 == nullptr)))
     return SVDD_E_ARG;
   PoolWinArgs a{x, logits, n, L, C, in_halo, slots, w0, wlen, off, parent_idx, div, (const bf16_t*)parent_hi, (const bf16_t*)parent_lo,
                 count, (bf16_t*)out_hi, (bf16_t*)out_lo, post_scale, post_shift, post_act, v0, vlen, off2};
-  const int64_t nthr = (int64_t)n * (L / 2 + (v0 ? 4 * slots : 2)) * (C >> 2);
+  const int64_t nthr = (int64_t)n * ((L + 1) / 2 + (v0 ? 4 * slots : 2)) * (C >> 2);
   hipLaunchKernelGGL(trunk_attn_pool_win_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
 }

@@ -33,6 +33,13 @@ TAIL = 136           # ... and behind the last row (the last 128-row tile + 2 ta
 WIN_K = 4            # window slots per candidate and level of the shared levels (svdd_trunk.hip)
 
 
+def _level_len(L, d):
+    """Sequence length at conv-tower level d (every level halves it, rounding up)."""
+    for _ in range(d):
+        L = (L + 1) // 2
+    return L
+
+
 def _ptr(t):
     return None if t is None else t.data_ptr()
 
@@ -137,7 +144,7 @@ class FusedEnformerValueNet(nn.Module):
         self._relk = {}
         self.timing = None
         self.share_level0 = True        # forward_tokens(shared=...): the first levels on the changed windows only (exact)
-        self.share_levels = 3           # ... how many of them (each must have an even length: 200, 100, 50 at L = 200)
+        self.share_levels = 4           # ... how many of them (all but the last must have an even length: 200, 100, 50, 25 at L = 200)
         self.share_slots = WIN_K        # ... windows per candidate and level (1: one window around every changed position)
         self.last_window_rows = None
 
@@ -243,7 +250,7 @@ class FusedEnformerValueNet(nn.Module):
         dev, P, f, lib = tok.device, self.parts, ws["f"], _lib.lib()
         key = ("pp", B, L, depth)
         if key not in ws:
-            ws[key] = [None] + [_Planes(_Planes.FRONT + (B * ((L >> d) + 2) + TAIL) * self.levels[d]["a_cin"], P, dev)
+            ws[key] = [None] + [_Planes(_Planes.FRONT + (B * (_level_len(L, d) + 2) + TAIL) * self.levels[d]["a_cin"], P, dev)
                                 for d in range(1, depth + 1)]
         K = self.share_slots
         if ws.get("win") is None or ws["win"].shape != (3, depth, n * K):
@@ -257,11 +264,11 @@ class FusedEnformerValueNet(nn.Module):
             src = self._unfold(ws, parent_tok, rows, None) if d == 0 else pp[d].view(rows, self.levels[d]["a_cin"])[:P]
             self._convs(ws, d, src, rows, rps, 2, None)
             nx = self.levels[d + 1]
-            tg = pp[d + 1].view(B * (Lc // 2 + 2), nx["a_cin"])[:P]
+            tg = pp[d + 1].view(B * ((Lc + 1) // 2 + 2), nx["a_cin"])[:P]
             rc = lib.svdd_trunk_attn_pool(f[2].data_ptr(), f[3].data_ptr(), B, Lc, self.levels[d]["C"], None, None, tg[0].data_ptr(),
                                           tg[1].data_ptr() if P == 2 else None, _ptr(nx["a_bn"][0]), _ptr(nx["a_bn"][1]), ACT_GELU, _stream())
             _lib.check(rc, "svdd_trunk_attn_pool")
-            Lc //= 2
+            Lc = (Lc + 1) // 2
         # ---- the candidates: windows
         w0, wlen, seg = ws["win"]
         rc = lib.svdd_trunk_windows(tok.data_ptr(), parent_tok.data_ptr(), pidx.data_ptr(), div, n, L, 7, depth, K, _ptr(count),
@@ -277,22 +284,25 @@ class FusedEnformerValueNet(nn.Module):
             src = self._unfold(ws, tok, rows, count, (w0[0], wlen[0], off[0])) if d == 0 else ws["p"][0].view(rows, lv["a_cin"])[:P]
             self._convs(ws, d, src, rows, 1, 0, cs[d, n * K - 1:])
             last = d + 1 == depth
-            tg = ws["p"][0].view(n * (Lc // 2 + (2 if last else 4 * K)), nx["a_cin"])[:P]
+            tg = ws["p"][0].view(n * ((Lc + 1) // 2 + (2 if last else 4 * K)), nx["a_cin"])[:P]
             nxt_win = (None, None, None) if last else (w0[d + 1].data_ptr(), wlen[d + 1].data_ptr(), off[d + 1].data_ptr())
-            ppl = pp[d + 1].view(B * (Lc // 2 + 2), nx["a_cin"])[:P]
+            ppl = pp[d + 1].view(B * ((Lc + 1) // 2 + 2), nx["a_cin"])[:P]
             rc = lib.svdd_trunk_attn_pool_win(f[2].data_ptr(), f[3].data_ptr(), n, Lc, lv["C"], 2 if d else 0, K, w0[d].data_ptr(),
                                               wlen[d].data_ptr(), off[d].data_ptr(), pidx.data_ptr(), div, ppl[0].data_ptr(),
                                               ppl[1].data_ptr() if P == 2 else None, _ptr(count), tg[0].data_ptr(),
                                               tg[1].data_ptr() if P == 2 else None, _ptr(nx["a_bn"][0]), _ptr(nx["a_bn"][1]), ACT_GELU,
                                               *nxt_win, _stream())
             _lib.check(rc, "svdd_trunk_attn_pool_win")
-            Lc //= 2
+            Lc = (Lc + 1) // 2
 
     def _share_depth(self, L):
-        d = 0
-        while L <= 256 and d < min(self.share_levels, len(self.levels) - 1) and (L >> d) % 2 == 0:
+        """Levels that can be shared: every level but the last shared one is pooled into compact segments and needs an even length."""
+        if L > 256 or L % 2:
+            return 0
+        d = 1
+        while d < min(self.share_levels, len(self.levels) - 1) and (L >> (d - 1)) % 2 == 0:
             d += 1
-        return d
+        return min(d, self.share_levels)
 
     @torch.no_grad()
     def forward_tokens(self, tok, count=None, shared=None):
@@ -317,7 +327,7 @@ class FusedEnformerValueNet(nn.Module):
         first = self._share_depth(L) if shared is not None and self.share_level0 and shared[0].shape[0] <= n else 0
         if first:
             self._shared_levels(ws, tok, count, shared, first)
-            Lc = L >> first
+            Lc = _level_len(L, first)
             rps = Lc + 2
         else:
             rows = n * rps

@@ -217,7 +217,7 @@ def test_first_levels_shared_with_the_parent_same_bits(precision, kw):
         fn = FusedEnformerValueNet(emb, head, precision)
         whole = fn.forward_tokens(toks, count=cnt).reshape(n)[:live].clone()
         rows = {}
-        for depth, slots in ((1, 1), (2, 1), (3, 1), (1, 4), (3, 2), (3, 4)):  # shared levels (lengths 200, 100, 50) x window slots
+        for depth, slots in ((1, 1), (2, 1), (3, 1), (1, 4), (3, 2), (3, 4), (4, 1), (4, 4)):  # shared levels (lengths 200, 100, 50, 25) x window slots
             fn.share_levels, fn.share_slots = depth, slots
             shared = fn.forward_tokens(toks, count=cnt, shared=(x, idx, M)).reshape(n)[:live].clone()
             assert torch.equal(shared, whole), (depth, slots)

@@ -47,10 +47,12 @@ if "--shared" in sys.argv:
     shared = (par.to(dev), torch.arange(n, dtype=torch.int32, device=dev), M)
     if os.environ.get("SVDD_SHARE_LEVELS"):
         fn.share_levels = int(os.environ["SVDD_SHARE_LEVELS"])
+    if os.environ.get("SVDD_SHARE_SLOTS"):
+        fn.share_slots = int(os.environ["SVDD_SHARE_SLOTS"])
 fl = emb.flops_per_sequence() * n
 ms = bench(lambda: fn.forward_tokens(tok, shared=shared))
 if shared:
-    print("compact rows per shared level:", fn.last_window_rows.tolist(), "of", [n * (200 >> d) for d in range(len(fn.last_window_rows))])
+    print("compact rows per shared level:", fn.last_window_rows.tolist(), "of", [n * (200 >> d) for d in range(len(fn.last_window_rows))], "windows per candidate <=", fn.share_slots)
 print(f"fused trunk {prec} n={n}: {ms:.1f} ms  = {fl / ms / 1e9:.1f} TFLOP/s fp32-equivalent ({fl / 1e12:.2f} TFLOP per forward)")
 if "--module" in sys.argv:
     oh = (torch.nn.functional.one_hot(tok.long().clamp(max=3), 4) * (tok != 4)[..., None]).float()
