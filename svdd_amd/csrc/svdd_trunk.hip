@@ -31,11 +31,13 @@ extern "C" int svdd_internal_num_cus();      // svdd_nets.hip
 // svdd_set_option(SVDD_OPT_TRUNK_GEMM_VERSION, v): 1 = the 128 x 128 kernel everywhere (A/B), 2 = automatic (default),
 // 3 = the 256 x 256 kernel everywhere
 static int g_trunk_gemm_version = 2;
+static int g_trunk_gemm_big_div = 4;   // automatic: the 256 x 256 kernel from num_cus / div tiles on (A/B: option values 21 .. 36 = div 1 .. 16)
 static int g_trunk_gemm_dbg = 0;     // timing experiments only (13 / 14 / 15 / 16): 256 x 256 kernel without epilogue / with one K block /
                                      // no epilogue + no LDS-DMA in the K loop / no epilogue + no fragment reads in the K loop
 extern "C" void svdd_internal_set_trunk_gemm_version(int v) {
   g_trunk_gemm_dbg = (v >= 13 && v <= 16) ? v - 12 : 0;
   g_trunk_gemm_version = (v >= 1 && v <= 3) ? v : (g_trunk_gemm_dbg ? 3 : 2);
+  if (v >= 21 && v <= 36) g_trunk_gemm_big_div = v - 20;
 }
 
 namespace {
@@ -740,15 +742,20 @@ struct PoolWinArgs { const float* x; const float* logits; int n, L, C, in_halo, 
                      bf16_t* hi; bf16_t* lo; const float* scale; const float* shift; int act;
                      const int* v0; const int* vlen; const int* off2; };
 __global__ __launch_bounds__(256) void trunk_attn_pool_win_kernel(PoolWinArgs a) {
+  // one workgroup per live candidate: it walks the candidate's output rows (a grid over the upper bound of rows per candidate
+  // was 85 M threads for 0.4 M rows at the first level: 0.33 ms per launch)
   const int nlive = a.count ? min(a.n, *a.count) : a.n;
+  const int64_t b = blockIdx.x;
+  if (b >= nlive) return;
   const int Lo = (a.L + 1) / 2, c4 = a.C >> 2;               // an odd L (last shared level only) pairs its last row with a masked one
-  const int per = a.v0 ? Lo + 4 * a.K : Lo + 2;              // thread slots per sequence
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (int64_t)nlive * per * c4) return;
-  const int c = (int)(idx % c4) * 4;
-  const int64_t t = idx / c4;
-  int r = (int)(t % per);
-  const int64_t b = t / per;
+  int nrows = Lo + 2;
+  if (a.v0) {
+    nrows = 0;
+    for (int j = 0; j < a.K; ++j) { const int vl = a.vlen[b * a.K + j]; nrows += vl > 0 ? vl + 4 : 0; }
+  }
+  for (int e = threadIdx.x; e < nrows * c4; e += 256) {
+  const int c = (e % c4) * 4;
+  int r = e / c4;
   int i = -1000;                                             // output position: Lo, Lo + 1 are the pad rows of the whole-sequence layout
   int64_t orow = 0;
   if (a.v0) {                                                // compact output: rows v0 - 2 .. v0 + vlen + 1 of every window of the next level
@@ -758,7 +765,6 @@ __global__ __launch_bounds__(256) void trunk_attn_pool_win_kernel(PoolWinArgs a)
       if (r < len) { i = a.v0[b * a.K + j] - 2 + r; orow = (int64_t)a.off2[b * a.K + j] + r; break; }
       r -= len;
     }
-    if (i == -1000) return;
   } else {
     i = r;
     orow = b * (Lo + 2) + r;
@@ -793,6 +799,7 @@ __global__ __launch_bounds__(256) void trunk_attn_pool_win_kernel(PoolWinArgs a)
     *reinterpret_cast<BV4*>(a.hi + orow * a.C + c) = *reinterpret_cast<const BV4*>(a.p_hi + prow * a.C + c);
     if (a.lo) *reinterpret_cast<BV4*>(a.lo + orow * a.C + c) = *reinterpret_cast<const BV4*>(a.p_lo + prow * a.C + c);
   }
+  }
 }
 
 }  // namespace
@@ -813,7 +820,7 @@ int svdd_trunk_gemm(const void* a_hi, const void* a_lo, const void* w, const flo
   // 256 x 256 tiles from half a chip's worth of tiles on (the 7680-row GEMMs of the transformer tower make 180 - 360 of them and
   // still run 2.3x faster than on 128 x 128 tiles: 0.79 - 0.98 vs 0.37 - 0.42 PFLOP/s); the 128 x 128 kernel below that
   const int mb2 = (M + H_BM - 1) / H_BM, nb2 = (N + H_BN - 1) / H_BN;
-  const bool big = g_trunk_gemm_version == 2 ? ((int64_t)mb2 * nb2 >= svdd_internal_num_cus() / 2)
+  const bool big = g_trunk_gemm_version == 2 ? ((int64_t)mb2 * nb2 >= svdd_internal_num_cus() / g_trunk_gemm_big_div)
                                               : g_trunk_gemm_version == 3;
   if (big) {
     const dim3 grid((unsigned)(((mb2 + 7) / 8) * 8 * nb2));
@@ -920,8 +927,7 @@ int svdd_trunk_attn_pool_win(const float* x, const float* logits, int n, int L, 
     return SVDD_E_ARG;
   PoolWinArgs a{x, logits, n, L, C, in_halo, slots, w0, wlen, off, parent_idx, div, (const bf16_t*)parent_hi, (const bf16_t*)parent_lo,
                 count, (bf16_t*)out_hi, (bf16_t*)out_lo, post_scale, post_shift, post_act, v0, vlen, off2};
-  const int64_t nthr = (int64_t)n * ((L + 1) / 2 + (v0 ? 4 * slots : 2)) * (C >> 2);
-  hipLaunchKernelGGL(trunk_attn_pool_win_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(trunk_attn_pool_win_kernel, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, a);
   return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
 }
 
