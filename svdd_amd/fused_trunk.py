@@ -146,6 +146,8 @@ class FusedEnformerValueNet(nn.Module):
         self.share_level0 = True        # forward_tokens(shared=...): the first levels on the changed windows only (exact)
         self.share_levels = 4           # ... how many of them (all but the last must have an even length: 200, 100, 50, 25 at L = 200)
         self.share_slots = WIN_K        # ... windows per candidate and level (1: one window around every changed position)
+        self.share_parent_steps = True  # ... and the parents' own levels from the previous call's, the same way
+        self.last_parent_rows = None
         self.last_window_rows = None
 
     # ------------------------------------------------------------------ thin kernel wrappers
@@ -238,25 +240,10 @@ class FusedEnformerValueNet(nn.Module):
             ph[1][: rows * 64].zero_()                           # the one-hot operand is exact: its lo plane is zero
         return ph
 
-    def _shared_levels(self, ws, tok, count, shared, depth):
-        """The first `depth` levels of candidates `tok` that differ from their parents at a few positions (svdd_trunk.hip,
-        "first level shared"): the parents' levels once (whole sequences), then up to share_slots windows of rows per candidate and level.
-        Leaves the operand planes of level `depth` in plane set 0 — the same bits as the whole-sequence path."""
-        parent_tok, pidx, div = shared
-        n, L = tok.shape
-        B = parent_tok.shape[0]
-        assert parent_tok.dtype == torch.uint8 and parent_tok.is_contiguous() and parent_tok.shape[1] == L and parent_tok.device == tok.device
-        assert pidx.dtype == torch.int32 and pidx.is_contiguous() and pidx.numel() >= n and div >= 1
-        dev, P, f, lib = tok.device, self.parts, ws["f"], _lib.lib()
-        key = ("pp", B, L, depth)
-        if key not in ws:
-            ws[key] = [None] + [_Planes(_Planes.FRONT + (B * (_level_len(L, d) + 2) + TAIL) * self.levels[d]["a_cin"], P, dev)
-                                for d in range(1, depth + 1)]
-        K = self.share_slots
-        if ws.get("win") is None or ws["win"].shape != (3, depth, n * K):
-            ws["win"] = torch.empty((3, depth, n * K), dtype=torch.int32, device=dev)
-        pp = ws[key]
-        # ---- the parents: whole sequences, the pooled planes of every shared level kept
+    def _parent_levels(self, ws, parent_tok, pp, depth):
+        """Whole sequences: the pooled operand planes of the first `depth` levels of `parent_tok` -> pp[1 .. depth]."""
+        B, L = parent_tok.shape
+        P, f, lib = self.parts, ws["f"], _lib.lib()
         Lc = L
         for d in range(depth):
             rps = Lc + 2
@@ -269,14 +256,20 @@ class FusedEnformerValueNet(nn.Module):
                                           tg[1].data_ptr() if P == 2 else None, _ptr(nx["a_bn"][0]), _ptr(nx["a_bn"][1]), ACT_GELU, _stream())
             _lib.check(rc, "svdd_trunk_attn_pool")
             Lc = (Lc + 1) // 2
-        # ---- the candidates: windows
-        w0, wlen, seg = ws["win"]
+
+    def _window_levels(self, ws, tok, count, parent_tok, pidx, div, pp, depth, win, whole):
+        """The first `depth` levels of `tok` on the windows of rows where a row differs from row pidx[c] // div of parent_tok,
+        whose pooled planes are pp[1 .. depth]. whole[d] (or None): where the whole-sequence operand planes of level d + 1 go
+        (pooled window rows + the parent's rows elsewhere); the last level's must be given."""
+        n, L = tok.shape
+        B = parent_tok.shape[0]
+        K, P, f, lib = self.share_slots, self.parts, ws["f"], _lib.lib()
+        w0, wlen, seg = win
         rc = lib.svdd_trunk_windows(tok.data_ptr(), parent_tok.data_ptr(), pidx.data_ptr(), div, n, L, 7, depth, K, _ptr(count),
                                     w0.data_ptr(), wlen.data_ptr(), seg.data_ptr(), _stream())
         _lib.check(rc, "svdd_trunk_windows")
         cs = torch.cumsum(seg, 1, dtype=torch.int32)
         off = cs - seg
-        self.last_window_rows = cs[:, n * K - 1]                  # device vector (statistics only): compact rows per shared level
         Lc = L
         for d in range(depth):
             rows = n * (Lc + (4 * K if d else 0))                 # the bound the grids are sized for; live rows: cs[d, n K - 1]
@@ -284,16 +277,60 @@ class FusedEnformerValueNet(nn.Module):
             src = self._unfold(ws, tok, rows, count, (w0[0], wlen[0], off[0])) if d == 0 else ws["p"][0].view(rows, lv["a_cin"])[:P]
             self._convs(ws, d, src, rows, 1, 0, cs[d, n * K - 1:])
             last = d + 1 == depth
-            tg = ws["p"][0].view(n * ((Lc + 1) // 2 + (2 if last else 4 * K)), nx["a_cin"])[:P]
-            nxt_win = (None, None, None) if last else (w0[d + 1].data_ptr(), wlen[d + 1].data_ptr(), off[d + 1].data_ptr())
-            ppl = pp[d + 1].view(B * ((Lc + 1) // 2 + 2), nx["a_cin"])[:P]
-            rc = lib.svdd_trunk_attn_pool_win(f[2].data_ptr(), f[3].data_ptr(), n, Lc, lv["C"], 2 if d else 0, K, w0[d].data_ptr(),
-                                              wlen[d].data_ptr(), off[d].data_ptr(), pidx.data_ptr(), div, ppl[0].data_ptr(),
-                                              ppl[1].data_ptr() if P == 2 else None, _ptr(count), tg[0].data_ptr(),
-                                              tg[1].data_ptr() if P == 2 else None, _ptr(nx["a_bn"][0]), _ptr(nx["a_bn"][1]), ACT_GELU,
-                                              *nxt_win, _stream())
-            _lib.check(rc, "svdd_trunk_attn_pool_win")
-            Lc = (Lc + 1) // 2
+            Lo = (Lc + 1) // 2
+            ppl = pp[d + 1].view(B * (Lo + 2), nx["a_cin"])[:P]
+            outs = []
+            if whole[d] is not None:
+                outs.append((whole[d], (None, None, None)))
+            if not last:                                          # the compact segments of the next level (plane set 0: its GEMMs are done with it)
+                outs.append((ws["p"][0].view(n * (Lo + 4 * K), nx["a_cin"])[:P],
+                             (w0[d + 1].data_ptr(), wlen[d + 1].data_ptr(), off[d + 1].data_ptr())))
+            for tg, nxt_win in outs:
+                rc = lib.svdd_trunk_attn_pool_win(f[2].data_ptr(), f[3].data_ptr(), n, Lc, lv["C"], 2 if d else 0, K, w0[d].data_ptr(),
+                                                  wlen[d].data_ptr(), off[d].data_ptr(), pidx.data_ptr(), div, ppl[0].data_ptr(),
+                                                  ppl[1].data_ptr() if P == 2 else None, _ptr(count), tg[0].data_ptr(),
+                                                  tg[1].data_ptr() if P == 2 else None, _ptr(nx["a_bn"][0]), _ptr(nx["a_bn"][1]), ACT_GELU,
+                                                  *nxt_win, _stream())
+                _lib.check(rc, "svdd_trunk_attn_pool_win")
+            Lc = Lo
+        return cs[:, n * K - 1]
+
+    def _shared_levels(self, ws, tok, count, shared, depth):
+        """The first `depth` levels of candidates `tok` that differ from their parents at a few positions (svdd_trunk.hip,
+        "first level shared"): the parents' levels once, then up to share_slots windows of rows per candidate and level.
+        The parents' own levels are updated the same way from the parents of the previous call (x_t differs from x_{t-1}
+        at the positions the last step unmasked) — whole sequences only when there is no previous call of this shape.
+        Leaves the operand planes of level `depth` in plane set 0 — the same bits as the whole-sequence path."""
+        parent_tok, pidx, div = shared
+        n, L = tok.shape
+        B = parent_tok.shape[0]
+        assert parent_tok.dtype == torch.uint8 and parent_tok.is_contiguous() and parent_tok.shape[1] == L and parent_tok.device == tok.device
+        assert pidx.dtype == torch.int32 and pidx.is_contiguous() and pidx.numel() >= n and div >= 1
+        dev, P, K = tok.device, self.parts, self.share_slots
+        key = ("pp", B, L, depth, K)
+        st = ws.get(key)
+        if st is None:
+            mk = lambda: [None] + [_Planes(_Planes.FRONT + (B * (_level_len(L, d) + 2) + TAIL) * self.levels[d]["a_cin"], P, dev)  # noqa: E731
+                                   for d in range(1, depth + 1)]
+            st = ws[key] = {"pp": [mk(), mk()], "cur": 0, "x": None, "ids": torch.arange(B, dtype=torch.int32, device=dev),
+                            "win": torch.empty((3, depth, n * K), dtype=torch.int32, device=dev),
+                            "pwin": torch.empty((3, depth, B * K), dtype=torch.int32, device=dev)}
+        lens = [_level_len(L, d) for d in range(depth + 1)]
+        # ---- the parents
+        if st["x"] is None or not self.share_parent_steps:
+            self._parent_levels(ws, parent_tok, st["pp"][st["cur"]], depth)
+            self.last_parent_rows = None
+        else:                                                      # from the previous parents' planes, on the windows that changed
+            old, new = st["pp"][st["cur"]], st["pp"][1 - st["cur"]]
+            whole = [new[d + 1].view(B * (lens[d + 1] + 2), self.levels[d + 1]["a_cin"])[:P] for d in range(depth)]
+            self.last_parent_rows = self._window_levels(ws, parent_tok, None, st["x"], st["ids"], 1, old, depth, st["pwin"], whole)
+            st["cur"] = 1 - st["cur"]
+        if st["x"] is None:
+            st["x"] = torch.empty_like(parent_tok)
+        st["x"].copy_(parent_tok)
+        # ---- the candidates
+        whole = [None] * (depth - 1) + [ws["p"][0].view(n * (lens[depth] + 2), self.levels[depth]["a_cin"])[:P]]
+        self.last_window_rows = self._window_levels(ws, tok, count, parent_tok, pidx, div, st["pp"][st["cur"]], depth, st["win"], whole)
 
     def _share_depth(self, L):
         """Levels that can be shared: every level but the last shared one is pooled into compact segments and needs an even length."""

@@ -224,8 +224,34 @@ def test_first_levels_shared_with_the_parent_same_bits(precision, kw):
             rows[depth, slots] = fn.last_window_rows.tolist()
         fn.share_level0 = False
         off = fn.forward_tokens(toks, count=cnt, shared=(x, idx, M)).reshape(n)[:live].clone()
+        assert torch.equal(off, whole)
+        fn.share_level0 = True
+        # the parents' own levels step by step: x_t from x_(t-1) on the windows that changed (a few positions per row, none in one
+        # row, then parents that have nothing to do with the previous ones), against parents computed whole
+        fn.share_levels, fn.share_slots = 4, 4
+        prows = []
+        for step in range(3):
+            x2 = x.clone()
+            if step < 2:
+                for b in range(B - 1):
+                    for p in (3 + 17 * b + 40 * step, 199 - 11 * b - step):
+                        x2[b, p] = (x2[b, p] + 1 + step) % 5
+            else:
+                x2 = torch.randint(0, 5, (B, L), generator=g, dtype=torch.uint8).to(DEV)
+            toks2 = toks.clone()
+            par = (idx[:live] // M).long()
+            toks2[:live] = torch.where(toks[:live] != x[par], toks[:live], x2[par])      # the same edits on the new parents
+            x = x2
+            want = fn.forward_tokens(toks2, count=cnt).reshape(n)[:live].clone()
+            fn.share_parent_steps = True
+            got = fn.forward_tokens(toks2, count=cnt, shared=(x, idx, M)).reshape(n)[:live].clone()
+            prows.append(None if fn.last_parent_rows is None else fn.last_parent_rows.tolist())
+            assert torch.equal(got, want), step
+            fn.share_parent_steps = False
+            got = fn.forward_tokens(toks2, count=cnt, shared=(x, idx, M)).reshape(n)[:live].clone()
+            assert torch.equal(got, want) and fn.last_parent_rows is None, step
+    assert prows[0] is not None and 0 < prows[0][0] < B * L // 2 and prows[2][0] == B * L, prows
     assert torch.isfinite(whole).all() and whole.unique().numel() > live // 2
-    assert torch.equal(off, whole)
     assert len(rows[3, 1]) == 3 and rows[3, 1][0] == rows[1, 1][0]
     assert 0 < rows[3, 1][0] < live * L // 2 and 0 < rows[3, 1][2] < live * 54, rows   # the windows are a fraction of the rows
     assert rows[3, 4][0] < rows[3, 2][0] < rows[3, 1][0], rows                   # ... a smaller one with a window per changed position
