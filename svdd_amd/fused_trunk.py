@@ -19,6 +19,7 @@ of the SVDD-MC loop needs no host round trip.
 The module takes TOKENS ([n, L] uint8, 4 = MASK): the engine's one-hot rows are exact, and the stem's k = 15 convolution
 over a one-hot input is a K = 60 GEMM whose A operand is exactly representable in bf16."""
 import ctypes
+import os
 
 import torch
 from torch import nn
@@ -146,7 +147,7 @@ class FusedEnformerValueNet(nn.Module):
         self.share_level0 = True        # forward_tokens(shared=...): the first levels on the changed windows only (exact)
         self.share_levels = 4           # ... how many of them (all but the last must have an even length: 200, 100, 50, 25 at L = 200)
         self.share_slots = WIN_K        # ... windows per candidate and level (1: one window around every changed position)
-        self.share_parent_steps = True  # ... and the parents' own levels from the previous call's, the same way
+        self.share_parent_steps = os.environ.get("SVDD_TRUNK_PARENT_STEPS", "1") != "0"   # ... and the parents' own levels from the previous call's, the same way (env: A/B runs)
         self.last_parent_rows = None
         self.last_window_rows = None
 

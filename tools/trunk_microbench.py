@@ -47,6 +47,8 @@ if "--shared" in sys.argv:
     shared = (par.to(dev), torch.arange(n, dtype=torch.int32, device=dev), M)
     if os.environ.get("SVDD_SHARE_LEVELS"):
         fn.share_levels = int(os.environ["SVDD_SHARE_LEVELS"])
+    if os.environ.get("SVDD_SHARE_PARENT_STEPS"):
+        fn.share_parent_steps = bool(int(os.environ["SVDD_SHARE_PARENT_STEPS"]))
     if os.environ.get("SVDD_SHARE_SLOTS"):
         fn.share_slots = int(os.environ["SVDD_SHARE_SLOTS"])
 fl = emb.flops_per_sequence() * n
