@@ -81,6 +81,18 @@ class _Planes:
         return [b[self.FRONT:] for b in self.buf]
 
 
+class _PlanesAt:
+    """A _Planes seen from `base` elements further on (the second half batch's region: the rows in front of its row 0 are
+    zeroed by the caller, the first half never writes them)."""
+
+    def __init__(self, planes, base):
+        self.buf = [b[base:] for b in planes.buf]
+
+    def view(self, rows, C):
+        assert _Planes.FRONT + (rows + TAIL) * C <= self.buf[0].numel(), (rows, C, self.buf[0].numel())
+        return [b[_Planes.FRONT:] for b in self.buf]
+
+
 class FusedEnformerValueNet(nn.Module):
     def __init__(self, trunk: EnformerTrunk, head: ConvHead, precision="bf16x3"):
         super().__init__()
@@ -149,6 +161,8 @@ class FusedEnformerValueNet(nn.Module):
         self.share_slots = WIN_K        # ... windows per candidate and level (1: one window around every changed position)
         self.share_parent_steps = os.environ.get("SVDD_TRUNK_PARENT_STEPS", "1") != "0"   # ... and the parents' own levels from the previous call's, the same way (env: A/B runs)
         self.last_parent_rows = None
+        self.tower_streams = int(os.environ.get("SVDD_TRUNK_TOWER_STREAMS", "2"))   # the transformer tower as two half batches on two streams (1: one chain)
+        self._side = None
         self.last_window_rows = None
 
     # ------------------------------------------------------------------ thin kernel wrappers
@@ -187,23 +201,27 @@ class FusedEnformerValueNet(nn.Module):
         key = (n, L, str(dev))
         ws = self._ws.get(key)
         if ws is None:
-            rows0 = n * (L + 2)
-            Tf = L
-            for _ in self.levels:
-                Tf = (Tf + 1) // 2                                # tokens left for the transformer tower
-            cmax = max([lv["C"] for lv in self.levels])
-            # the largest activation is at the first level (rows halve per level, channels at most double overall)
-            fmax = max(rows0 * self.levels[0]["C"], max((n * ((L >> i) + 4 * WIN_K + 1)) * lv["C"] for i, lv in enumerate(self.levels)),
-                       n * Tf * max(self.pw_out, 2 * self.C, 2 * self.tf[0]["nq"] + self.tf[0]["nv"] if self.tf else 0)) + 1024
-            pmax = max((GUARD + rows0 + TAIL) * max(64, self.levels[0]["C"]),
-                       max((GUARD + n * ((L >> max(i - 1, 0)) + 4 * WIN_K + 1) + TAIL) * lv["C"] for i, lv in enumerate(self.levels)),
-                       (GUARD + Tf * n + TAIL) * max(self.pw_out, 2 * self.C))
+            fmax, pmax = self._workspace_sizes(n, L)
+            fh, ph = self._workspace_sizes((n + 1) // 2, L)       # room for two half batches side by side (forward_tokens)
+            fmax, pmax = max(fmax, 2 * (fh + 4096)), max(pmax, 2 * (ph + 4 * 4096))
             # two sets of operand planes: a GEMM reads one and writes the next GEMM's operands into the other
             pmax += _Planes.FRONT
             ws = {"f": [torch.empty(fmax, dtype=torch.float32, device=dev) for _ in range(4)],
-                  "p": [_Planes(pmax, self.parts, dev), _Planes(pmax, self.parts, dev)], "cmax": cmax}
+                  "p": [_Planes(pmax, self.parts, dev), _Planes(pmax, self.parts, dev)]}
             self._ws = {key: ws}                                   # one workspace at a time (GBs at the C4 shard size)
         return ws
+
+    def _workspace_sizes(self, n, L):
+        """(elements of an fp32 buffer, elements of an operand plane behind its front guard) that n sequences of length L need."""
+        rows0 = n * (L + 2)
+        Tf = _level_len(L, len(self.levels))                      # tokens left for the transformer tower
+        # the largest activation is at the first level (rows halve per level, channels at most double overall)
+        fmax = max(rows0 * self.levels[0]["C"], max((n * ((L >> i) + 4 * WIN_K + 1)) * lv["C"] for i, lv in enumerate(self.levels)),
+                   n * Tf * max(self.pw_out, 2 * self.C, 2 * self.tf[0]["nq"] + self.tf[0]["nv"] if self.tf else 0)) + 1024
+        pmax = max((GUARD + rows0 + TAIL) * max(64, self.levels[0]["C"]),
+                   max((GUARD + n * ((L >> max(i - 1, 0)) + 4 * WIN_K + 1) + TAIL) * lv["C"] for i, lv in enumerate(self.levels)),
+                   (GUARD + Tf * n + TAIL) * max(self.pw_out, 2 * self.C))
+        return fmax, pmax
 
     def _rel_k(self, d, length, dev):
         key = (id(d), length)
@@ -296,28 +314,23 @@ class FusedEnformerValueNet(nn.Module):
             Lc = Lo
         return cs[:, n * K - 1]
 
-    def _shared_levels(self, ws, tok, count, shared, depth):
-        """The first `depth` levels of candidates `tok` that differ from their parents at a few positions (svdd_trunk.hip,
-        "first level shared"): the parents' levels once, then up to share_slots windows of rows per candidate and level.
-        The parents' own levels are updated the same way from the parents of the previous call (x_t differs from x_{t-1}
-        at the positions the last step unmasked) — whole sequences only when there is no previous call of this shape.
-        Leaves the operand planes of level `depth` in plane set 0 — the same bits as the whole-sequence path."""
+    def _parents(self, ws, shared, n, depth):
+        """The parents' first `depth` levels of this call (svdd_trunk.hip, "first level shared"), as pooled operand planes:
+        updated from the parents of the previous call on the windows that changed (x_t differs from x_{t-1} at the positions
+        the last step unmasked) — whole sequences when there is no previous call of this shape. -> the state dict."""
         parent_tok, pidx, div = shared
-        n, L = tok.shape
-        B = parent_tok.shape[0]
-        assert parent_tok.dtype == torch.uint8 and parent_tok.is_contiguous() and parent_tok.shape[1] == L and parent_tok.device == tok.device
+        B, L = parent_tok.shape
+        assert parent_tok.dtype == torch.uint8 and parent_tok.is_contiguous()
         assert pidx.dtype == torch.int32 and pidx.is_contiguous() and pidx.numel() >= n and div >= 1
-        dev, P, K = tok.device, self.parts, self.share_slots
+        dev, P, K = parent_tok.device, self.parts, self.share_slots
         key = ("pp", B, L, depth, K)
         st = ws.get(key)
         if st is None:
             mk = lambda: [None] + [_Planes(_Planes.FRONT + (B * (_level_len(L, d) + 2) + TAIL) * self.levels[d]["a_cin"], P, dev)  # noqa: E731
                                    for d in range(1, depth + 1)]
             st = ws[key] = {"pp": [mk(), mk()], "cur": 0, "x": None, "ids": torch.arange(B, dtype=torch.int32, device=dev),
-                            "win": torch.empty((3, depth, n * K), dtype=torch.int32, device=dev),
-                            "pwin": torch.empty((3, depth, B * K), dtype=torch.int32, device=dev)}
+                            "win": {}, "pwin": torch.empty((3, depth, B * K), dtype=torch.int32, device=dev)}
         lens = [_level_len(L, d) for d in range(depth + 1)]
-        # ---- the parents
         if st["x"] is None or not self.share_parent_steps:
             self._parent_levels(ws, parent_tok, st["pp"][st["cur"]], depth)
             self.last_parent_rows = None
@@ -329,9 +342,20 @@ class FusedEnformerValueNet(nn.Module):
         if st["x"] is None:
             st["x"] = torch.empty_like(parent_tok)
         st["x"].copy_(parent_tok)
-        # ---- the candidates
-        whole = [None] * (depth - 1) + [ws["p"][0].view(n * (lens[depth] + 2), self.levels[depth]["a_cin"])[:P]]
-        self.last_window_rows = self._window_levels(ws, tok, count, parent_tok, pidx, div, st["pp"][st["cur"]], depth, st["win"], whole)
+        return st
+
+    def _shared_levels(self, ws, st, tok, count, shared, depth, half):
+        """The first `depth` levels of candidates `tok` that differ from their parents at a few positions: up to share_slots
+        windows of rows per candidate and level, the parents' planes (st, _parents) elsewhere. Leaves the operand planes of
+        level `depth` in plane set 0 — the same bits as the whole-sequence path."""
+        parent_tok, pidx, div = shared
+        n, L = tok.shape
+        K, P = self.share_slots, self.parts
+        win = st["win"].get((half, n))
+        if win is None:
+            win = st["win"][half, n] = torch.empty((3, depth, n * K), dtype=torch.int32, device=tok.device)
+        whole = [None] * (depth - 1) + [ws["p"][0].view(n * (_level_len(L, depth) + 2), self.levels[depth]["a_cin"])[:P]]
+        return self._window_levels(ws, tok, count, parent_tok, pidx, div, st["pp"][st["cur"]], depth, win, whole)
 
     def _share_depth(self, L):
         """Levels that can be shared: every level but the last shared one is pooled into compact segments and needs an even length."""
@@ -351,6 +375,51 @@ class FusedEnformerValueNet(nn.Module):
         n, L = tok.shape
         dev = tok.device
         ws = self._workspace(n, L, dev)
+        depth = self._share_depth(L) if shared is not None and self.share_level0 and shared[0].shape[0] <= n else 0
+        st = self._parents(ws, shared, n, depth) if depth else None
+        T = _level_len(L, len(self.levels))
+        zs = torch.empty((n * T, self.pw_out), dtype=torch.float32, device=dev)
+        for d in self.tf:
+            self._rel_k(d, T, dev)                                # cached tensors: made before the streams fork
+        # Two halves of the candidates on two streams: rows are independent, and one dependent chain of kernels leaves the tail
+        # of every GEMM round idle (the tower's 7680-row GEMMs at a C4 step are 180 to 384 tiles of 256 x 256 on 256 CUs: 0.7 to
+        # 1.5 rounds) and nothing running under the pooling / LayerNorm / attention kernels; two chains fill each other's gaps.
+        # Each half works in its own region of every workspace buffer. Same kernels per row: same bits.
+        nA = (n + 1) // 2
+        reg_f = (ws["f"][0].numel() // 2) & ~4095
+        reg_p = ((ws["p"][0].buf[0].numel() - _Planes.FRONT) // 2) & ~4095
+        need_f, need_p = self._workspace_sizes(nA, L)
+        two = self.tower_streams == 2 and n * T >= 2048 and need_f <= reg_f and need_p + 2 * 4096 <= reg_p
+        self.last_streams = 2 if two else 1
+        if not two:
+            self.last_window_rows = self._candidates(ws, st, tok, count, shared, depth, zs, 0)
+        else:
+            cnts = (None, None) if count is None else (count.clamp(max=nA), (count - nA).clamp(min=0))
+            wsB = dict(ws)
+            wsB["f"] = [b[reg_f:] for b in ws["f"]]
+            wsB["p"] = [_PlanesAt(pl, reg_p) for pl in ws["p"]]
+            for pl in wsB["p"]:
+                for b in pl.buf:
+                    b[_Planes.FRONT - 2 * 4096: _Planes.FRONT].zero_()     # the rows in front of the second half's first sequence
+            main = torch.cuda.current_stream()
+            if self._side is None:
+                self._side = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+            stats = []
+            for k, sd in enumerate(self._side):
+                sd.wait_stream(main)
+                with torch.cuda.stream(sd):
+                    lo, hi = (0, nA) if k == 0 else (nA, n)
+                    sh = None if shared is None else (shared[0], shared[1][lo:], shared[2])
+                    stats.append(self._candidates(ws if k == 0 else wsB, st, tok[lo:hi], cnts[k], sh, depth, zs[lo * T: hi * T], k))
+            for sd in self._side:
+                main.wait_stream(sd)
+            self.last_window_rows = None if stats[0] is None else stats[0] + stats[1]
+        s = (zs @ self.head_w + self.head_b).view(n, T, -1).mean(dim=1)
+        return s[:, :, None]
+
+    def _candidates(self, ws, st, tok, count, shared, depth, zs, half):
+        """Conv tower (the first `depth` levels on windows), transformer tower and pointwise block of the rows `tok` -> zs."""
+        n, L = tok.shape
         f, P = ws["f"], self.parts
         lib = _lib.lib()
         side = 0                                                  # the plane set the NEXT GEMM reads
@@ -362,24 +431,21 @@ class FusedEnformerValueNet(nn.Module):
         # (BatchNorm + GELU + hi / lo split fused; round 3a ran a separate element-wise pass per GEMM: 9 ms of 73).
         Lc, rps = L, L + 2
         cur = 0                                                   # index of the fp32 buffer that holds x
-        first = self._share_depth(L) if shared is not None and self.share_level0 and shared[0].shape[0] <= n else 0
-        if first:
-            self._shared_levels(ws, tok, count, shared, first)
-            Lc = _level_len(L, first)
+        stats = None
+        if depth:
+            stats = self._shared_levels(ws, st, tok, count, shared, depth, half)
+            Lc = _level_len(L, depth)
             rps = Lc + 2
         else:
             rows = n * rps
-            ph = planes(rows, 64, side)
-            _lib.check(lib.svdd_trunk_stem_unfold(tok.data_ptr(), n, L, ph[0].data_ptr(), _ptr(count), _stream()), "svdd_trunk_stem_unfold")
-            if P == 2:
-                ph[1][: rows * 64].zero_()                       # the one-hot operand is exact: its lo plane is zero
+            ph = self._unfold(ws, tok, rows, count)
             lv0 = self.levels[0]
             C = lv0["C"]
             self._gemm(ph, self.stem_w, self.stem_b, None, f[cur], rows, C, 64, 1, ACT_NONE, count, rps,
                        nxt=planes(rows, C, 1 - side), post=lv0["b_bn"], post_act=ACT_GELU, pad=2)
             side = 1 - side
         for i, lv in enumerate(self.levels):
-            if i < first:
+            if i < depth:
                 continue
             rows = n * rps
             if i > 0:                                             # k = 5 block: z = conv5(gelu(bn(x))); planes of x come from the pool
@@ -410,11 +476,22 @@ class FusedEnformerValueNet(nn.Module):
             cur = (cur + 3) % 4
             Lc = Lo
             rps = Lc + 2
-        # ---- transformer tower on the Lc tokens left (2 for L = 200)
+        # ---- transformer tower on the Lc tokens left (2 for L = 200), pointwise block
         C = self.C
         T = Lc
         x = f[cur][: n * rps * C].view(n, rps, C)[:, :T].reshape(n * T, C).contiguous()
+        self._tower(ws, x, zs, n, T, count)
+        return stats
+
+    def _tower(self, ws, x, zs, n, T, count):
+        """Transformer tower + pointwise block on rows x [n T, C] (fp32) -> zs [n T, pw_out]."""
+        f, P, lib, dev, C = ws["f"], self.parts, _lib.lib(), x.device, self.C
         rows = n * T
+        cur = 0
+
+        def planes(rows, C, which):
+            return ws["p"][which].view(rows, C)[:P]
+
         for d in self.tf:
             h, dk, dv, nq, nv = d["heads"], d["dk"], d["dv"], d["nq"], d["nv"]
             pl = planes(rows, C, 0)
@@ -447,13 +524,10 @@ class FusedEnformerValueNet(nn.Module):
             self._gemm(hid, d["f2_w"], d["f2_b"], x2, x3, rows, C, 2 * C, 1, ACT_NONE, count, T)
             x = x3
             cur = (cur + 3) % 4
-        # ---- pointwise block (no residual, no pool) + trunk GELU, then the head: 1x1 conv + mean over length
+        # ---- pointwise block (no residual, no pool) + trunk GELU
         pl = planes(rows, C, 0)
         self._act(x, self.pw_bn, ACT_GELU, rows, C, T, 0, pl, count)
-        z = f[(cur + 1) % 4][: rows * self.pw_out].view(rows, self.pw_out)
-        self._gemm(pl, self.pw_w, self.pw_b, None, z, rows, self.pw_out, C, 1, ACT_GELU, count, T)
-        s = (z @ self.head_w + self.head_b).view(n, T, -1).mean(dim=1)
-        return s[:, :, None]
+        self._gemm(pl, self.pw_w, self.pw_b, None, zs, rows, self.pw_out, C, 1, ACT_GELU, count, T)
 
     def forward(self, onehot):
         """Value-function interface: one-hot fp32 [n, L, 4] (or the reward-model layout [n, 4, L]) -> [n, n_tasks, 1]."""

@@ -82,6 +82,38 @@ def test_fused_trunk_full_size_c4():
     assert err1 <= 5e-2 * scale
 
 
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+def test_tower_on_two_streams_same_bits(precision):
+    """The transformer tower as two half batches on two streams (fused_trunk.tower_streams, from 2048 token rows on) against
+    one chain: the same bits, with and without a device-side live count (one that leaves the second half partly / wholly
+    empty included), and twice in a row (the streams join before the next forward touches the buffers)."""
+    from svdd_amd import synthetic
+    from svdd_amd.fused_trunk import FusedEnformerValueNet
+    kw = dict(n_conv=7, channels=768, n_transformers=3, n_heads=4, key_len=16)
+    _, emb, head, _ = synthetic.build("dna", DEV, hidden_dim=32, num_cnn_stacks=1, value="enformer", enformer_kwargs=kw)
+    _randomise(emb, head, 9)
+    g = torch.Generator(device=DEV).manual_seed(2)
+    n, L = 1100, 200                                                       # 2200 token rows
+    tok = torch.randint(0, 5, (n, L), device=DEV, generator=g, dtype=torch.uint8)
+    with torch.no_grad():
+        fn = FusedEnformerValueNet(emb, head, precision)
+        assert fn.tower_streams == 2
+        outs = {}
+        for live in (None, 1100, 901, 550, 300):
+            cnt = None if live is None else torch.tensor([live], dtype=torch.int32, device=DEV)
+            k = n if live is None else live
+            fn.tower_streams = 2
+            a = fn.forward_tokens(tok, count=cnt).reshape(n)[:k].clone()
+            assert fn.last_streams == 2
+            b = fn.forward_tokens(tok, count=cnt).reshape(n)[:k].clone()
+            fn.tower_streams = 1
+            c = fn.forward_tokens(tok, count=cnt).reshape(n)[:k].clone()
+            assert fn.last_streams == 1
+            assert torch.isfinite(c).all() and torch.equal(a, c) and torch.equal(b, c), live
+            outs[live] = c
+    assert torch.equal(outs[None][:300], outs[300]) and outs[None].unique().numel() > n // 2
+
+
 def test_mc_decode_with_the_fused_trunk_vs_oracle():
     """SVDD-MC (M = 20, L = 200) with the fused trunk as value function, precision bf16x3: the work-skipping loop (live
     candidates gathered on the device, `count` fed to every trunk kernel) against the plain loop, and the oracle's replay of
