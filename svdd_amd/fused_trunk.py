@@ -394,7 +394,12 @@ class FusedEnformerValueNet(nn.Module):
         if not two:
             self.last_window_rows = self._candidates(ws, st, tok, count, shared, depth, zs, 0)
         else:
-            cnts = (None, None) if count is None else (count.clamp(max=nA), (count - nA).clamp(min=0))
+            # even rows / odd rows: the halves stay balanced whatever the (device-side) live count is
+            cnts = (None, None) if count is None else (torch.div(count + 1, 2, rounding_mode="floor").to(torch.int32),
+                                                       torch.div(count, 2, rounding_mode="floor").to(torch.int32))
+            toks = (tok[0::2].contiguous(), tok[1::2].contiguous())
+            pids = (None, None) if shared is None else (shared[1][:n][0::2].contiguous(), shared[1][:n][1::2].contiguous())
+            zh = (zs[: nA * T], zs[nA * T:])
             wsB = dict(ws)
             wsB["f"] = [b[reg_f:] for b in ws["f"]]
             wsB["p"] = [_PlanesAt(pl, reg_p) for pl in ws["p"]]
@@ -408,12 +413,15 @@ class FusedEnformerValueNet(nn.Module):
             for k, sd in enumerate(self._side):
                 sd.wait_stream(main)
                 with torch.cuda.stream(sd):
-                    lo, hi = (0, nA) if k == 0 else (nA, n)
-                    sh = None if shared is None else (shared[0], shared[1][lo:], shared[2])
-                    stats.append(self._candidates(ws if k == 0 else wsB, st, tok[lo:hi], cnts[k], sh, depth, zs[lo * T: hi * T], k))
+                    sh = None if shared is None else (shared[0], pids[k], shared[2])
+                    stats.append(self._candidates(ws if k == 0 else wsB, st, toks[k], cnts[k], sh, depth, zh[k], k))
             for sd in self._side:
                 main.wait_stream(sd)
             self.last_window_rows = None if stats[0] is None else stats[0] + stats[1]
+            sc = (zs @ self.head_w + self.head_b).view(n, T, -1).mean(dim=1)
+            s = torch.empty_like(sc)
+            s[0::2], s[1::2] = sc[:nA], sc[nA:]
+            return s[:, :, None]
         s = (zs @ self.head_w + self.head_b).view(n, T, -1).mean(dim=1)
         return s[:, :, None]
 

@@ -51,8 +51,11 @@ if "--shared" in sys.argv:
         fn.share_parent_steps = bool(int(os.environ["SVDD_SHARE_PARENT_STEPS"]))
     if os.environ.get("SVDD_SHARE_SLOTS"):
         fn.share_slots = int(os.environ["SVDD_SHARE_SLOTS"])
-fl = emb.flops_per_sequence() * n
-ms = bench(lambda: fn.forward_tokens(tok, shared=shared))
+count = None
+if os.environ.get("SVDD_LIVE"):                           # a compacted batch: only the first SVDD_LIVE rows are live (device scalar)
+    count = torch.tensor([int(os.environ["SVDD_LIVE"])], dtype=torch.int32, device=dev)
+fl = emb.flops_per_sequence() * (n if count is None else int(count))
+ms = bench(lambda: fn.forward_tokens(tok, count=count, shared=shared))
 if shared:
     print("compact rows per shared level:", fn.last_window_rows.tolist(), "of", [n * (200 >> d) for d in range(len(fn.last_window_rows))], "windows per candidate <=", fn.share_slots)
 print(f"fused trunk {prec} n={n}: {ms:.1f} ms  = {fl / ms / 1e9:.1f} TFLOP/s fp32-equivalent ({fl / 1e12:.2f} TFLOP per forward)")
@@ -64,7 +67,7 @@ if "--module" in sys.argv:
 
 if "--gemms" in sys.argv:
     fn.timing = []
-    fn.forward_tokens(tok, shared=shared)
+    fn.forward_tokens(tok, count=count, shared=shared)
     torch.cuda.synchronize()
     agg = {}
     for M, N, C, T, e0, e1 in fn.timing:
