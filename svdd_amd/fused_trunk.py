@@ -161,7 +161,7 @@ class FusedEnformerValueNet(nn.Module):
         self.share_slots = WIN_K        # ... windows per candidate and level (1: one window around every changed position)
         self.share_parent_steps = os.environ.get("SVDD_TRUNK_PARENT_STEPS", "1") != "0"   # ... and the parents' own levels from the previous call's, the same way (env: A/B runs)
         self.last_parent_rows = None
-        self.tower_streams = int(os.environ.get("SVDD_TRUNK_TOWER_STREAMS", "2"))   # the transformer tower as two half batches on two streams (1: one chain)
+        self.tower_streams = int(os.environ.get("SVDD_TRUNK_TOWER_STREAMS", "2"))   # the candidates as this many parts on as many streams (1: one chain of kernels; at most 4)
         self._side = None
         self.last_window_rows = None
 
@@ -202,8 +202,9 @@ class FusedEnformerValueNet(nn.Module):
         ws = self._ws.get(key)
         if ws is None:
             fmax, pmax = self._workspace_sizes(n, L)
-            fh, ph = self._workspace_sizes((n + 1) // 2, L)       # room for two half batches side by side (forward_tokens)
-            fmax, pmax = max(fmax, 2 * (fh + 4096)), max(pmax, 2 * (ph + 4 * 4096))
+            for S in (2, 3, 4):                                   # room for S parts of the batch side by side (forward_tokens)
+                fh, ph = self._workspace_sizes((n + S - 1) // S, L)
+                fmax, pmax = max(fmax, S * (fh + 4096)), max(pmax, S * (ph + 4 * 4096))
             # two sets of operand planes: a GEMM reads one and writes the next GEMM's operands into the other
             pmax += _Planes.FRONT
             ws = {"f": [torch.empty(fmax, dtype=torch.float32, device=dev) for _ in range(4)],
@@ -385,42 +386,50 @@ class FusedEnformerValueNet(nn.Module):
         # of every GEMM round idle (the tower's 7680-row GEMMs at a C4 step are 180 to 384 tiles of 256 x 256 on 256 CUs: 0.7 to
         # 1.5 rounds) and nothing running under the pooling / LayerNorm / attention kernels; two chains fill each other's gaps.
         # Each half works in its own region of every workspace buffer. Same kernels per row: same bits.
-        nA = (n + 1) // 2
-        reg_f = (ws["f"][0].numel() // 2) & ~4095
-        reg_p = ((ws["p"][0].buf[0].numel() - _Planes.FRONT) // 2) & ~4095
+        S = max(1, min(self.tower_streams, 4))
+        nA = (n + S - 1) // S                                     # rows of the largest part
+        reg_f = (ws["f"][0].numel() // S) & ~4095
+        reg_p = ((ws["p"][0].buf[0].numel() - _Planes.FRONT) // S) & ~4095
         need_f, need_p = self._workspace_sizes(nA, L)
-        two = self.tower_streams == 2 and n * T >= 2048 and need_f <= reg_f and need_p + 2 * 4096 <= reg_p
-        self.last_streams = 2 if two else 1
-        if not two:
+        if S > 1 and not (n * T >= 2048 and need_f <= reg_f and need_p + 2 * 4096 <= reg_p):
+            S = 1
+        self.last_streams = S
+        if S == 1:
             self.last_window_rows = self._candidates(ws, st, tok, count, shared, depth, zs, 0)
         else:
-            # even rows / odd rows: the halves stay balanced whatever the (device-side) live count is
-            cnts = (None, None) if count is None else (torch.div(count + 1, 2, rounding_mode="floor").to(torch.int32),
-                                                       torch.div(count, 2, rounding_mode="floor").to(torch.int32))
-            toks = (tok[0::2].contiguous(), tok[1::2].contiguous())
-            pids = (None, None) if shared is None else (shared[1][:n][0::2].contiguous(), shared[1][:n][1::2].contiguous())
-            zh = (zs[: nA * T], zs[nA * T:])
-            wsB = dict(ws)
-            wsB["f"] = [b[reg_f:] for b in ws["f"]]
-            wsB["p"] = [_PlanesAt(pl, reg_p) for pl in ws["p"]]
-            for pl in wsB["p"]:
-                for b in pl.buf:
-                    b[_Planes.FRONT - 2 * 4096: _Planes.FRONT].zero_()     # the rows in front of the second half's first sequence
+            # rows k, k + S, k + 2 S, ...: the parts stay balanced whatever the (device-side) live count is
+            cnts = [None if count is None else torch.div(count + (S - 1 - k), S, rounding_mode="floor").to(torch.int32) for k in range(S)]
+            toks = [tok[k::S].contiguous() for k in range(S)]
+            pids = [None if shared is None else shared[1][:n][k::S].contiguous() for k in range(S)]
+            zoff = [0]
+            for k in range(S):
+                zoff.append(zoff[-1] + toks[k].shape[0] * T)
+            wss = [ws]
+            for k in range(1, S):
+                w = dict(ws)
+                w["f"] = [b[k * reg_f:] for b in ws["f"]]
+                w["p"] = [_PlanesAt(pl, k * reg_p) for pl in ws["p"]]
+                for pl in w["p"]:
+                    for b in pl.buf:
+                        b[_Planes.FRONT - 2 * 4096: _Planes.FRONT].zero_()  # the rows in front of this part's first sequence
+                wss.append(w)
             main = torch.cuda.current_stream()
-            if self._side is None:
-                self._side = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+            if self._side is None or len(self._side) < S:
+                self._side = tuple(torch.cuda.Stream(device=dev) for _ in range(S))
             stats = []
-            for k, sd in enumerate(self._side):
+            for k in range(S):
+                sd = self._side[k]
                 sd.wait_stream(main)
                 with torch.cuda.stream(sd):
                     sh = None if shared is None else (shared[0], pids[k], shared[2])
-                    stats.append(self._candidates(ws if k == 0 else wsB, st, toks[k], cnts[k], sh, depth, zh[k], k))
-            for sd in self._side:
-                main.wait_stream(sd)
-            self.last_window_rows = None if stats[0] is None else stats[0] + stats[1]
+                    stats.append(self._candidates(wss[k], st, toks[k], cnts[k], sh, depth, zs[zoff[k]: zoff[k + 1]], k))
+            for k in range(S):
+                main.wait_stream(self._side[k])
+            self.last_window_rows = None if stats[0] is None else sum(stats[1:], stats[0])
             sc = (zs @ self.head_w + self.head_b).view(n, T, -1).mean(dim=1)
             s = torch.empty_like(sc)
-            s[0::2], s[1::2] = sc[:nA], sc[nA:]
+            for k in range(S):
+                s[k::S] = sc[zoff[k] // T: zoff[k + 1] // T]
             return s[:, :, None]
         s = (zs @ self.head_w + self.head_b).view(n, T, -1).mean(dim=1)
         return s[:, :, None]

@@ -84,9 +84,8 @@ def test_fused_trunk_full_size_c4():
 
 @pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
 def test_tower_on_two_streams_same_bits(precision):
-    """The transformer tower as two half batches on two streams (fused_trunk.tower_streams, from 2048 token rows on) against
-    one chain: the same bits, with and without a device-side live count (one that leaves the second half partly / wholly
-    empty included), and twice in a row (the streams join before the next forward touches the buffers)."""
+    """The candidates as 2 / 3 / 4 parts on as many streams (fused_trunk.tower_streams, from 2048 token rows on) against
+    one chain of kernels: the same bits, with and without a device-side live count (small ones included), and twice in a row (the streams join before the next forward touches the buffers)."""
     from svdd_amd import synthetic
     from svdd_amd.fused_trunk import FusedEnformerValueNet
     kw = dict(n_conv=7, channels=768, n_transformers=3, n_heads=4, key_len=16)
@@ -102,14 +101,15 @@ def test_tower_on_two_streams_same_bits(precision):
         for live in (None, 1100, 901, 550, 300):
             cnt = None if live is None else torch.tensor([live], dtype=torch.int32, device=DEV)
             k = n if live is None else live
-            fn.tower_streams = 2
-            a = fn.forward_tokens(tok, count=cnt).reshape(n)[:k].clone()
-            assert fn.last_streams == 2
-            b = fn.forward_tokens(tok, count=cnt).reshape(n)[:k].clone()
+            got = []
+            for streams in (2, 2, 3, 4):
+                fn.tower_streams = streams
+                got.append(fn.forward_tokens(tok, count=cnt).reshape(n)[:k].clone())
+                assert fn.last_streams == streams
             fn.tower_streams = 1
             c = fn.forward_tokens(tok, count=cnt).reshape(n)[:k].clone()
             assert fn.last_streams == 1
-            assert torch.isfinite(c).all() and torch.equal(a, c) and torch.equal(b, c), live
+            assert torch.isfinite(c).all() and all(torch.equal(a, c) for a in got), live
             outs[live] = c
     assert torch.equal(outs[None][:300], outs[300]) and outs[None].unique().numel() > n // 2
 
