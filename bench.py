@@ -180,11 +180,13 @@ def trunk_gemm_roofline(model, emb, head, dev, n, L):
     if not isinstance(fn, FusedEnformerValueNet):
         return None
     tok = torch.randint(0, 5, (n, L), device=dev, dtype=torch.uint8)
-    fn.forward_tokens(tok)
+    streams, fn.tower_streams = fn.tower_streams, 1        # one chain of kernels: on two streams the GEMMs of the two half batches
+    fn.forward_tokens(tok)                                 # overlap, and per-launch event pairs would count the shared time twice
     torch.cuda.synchronize()
     fn.timing = []
     fn.forward_tokens(tok)
     torch.cuda.synchronize()
+    fn.tower_streams = streams
     issued = sum(2.0 * Mr * N * C * T for Mr, N, C, T, _, _ in fn.timing)          # incl. the zero rows between sequences
     ms = sum(e0.elapsed_time(e1) for _, _, _, _, e0, e1 in fn.timing)
     launches = len(fn.timing)
