@@ -210,6 +210,19 @@ int svdd_gru_bidir_f32(const float* x, const float* wpack, const float* bpack, f
  * svdd_gru_bidir_bwd_f32: grad_out [2][n][L][64] (gradient of the per-direction outputs), out / save of the forward call,
  *   wpack_bwd [2 dirs][4 waves][64 lanes][96] packed by svdd_amd.fused.pack_gru_bwd -> dx [2][n][L][64], each direction's
  *   contribution to d loss / d x (the caller adds the two). */
+/* The element-wise half of a dilated-CNN backbone layer under autograd (reference models/dnaconv.py:212-247 CNNModel.forward2:
+ * feat' = relu(conv(LayerNorm(feat + time_bias)) + b) + feat; differentiated with respect to its input by the DPS baseline,
+ * diffusion_gosai.py:1321-1330). Rows [rows, channels] fp32 channels-last, channels in {64, 128, 256}; tb [rows / rows_per_seq,
+ * channels] = the time bias per sequence. Weights are frozen: input gradients only.
+ * svdd_bb_layer_fwd_f32: f_out = relu(y + bias) + f_prev, mask = (y + bias > 0) (y NULL: f_out = f_prev, nothing written), then
+ *   hn = LayerNorm(f_out + tb) gamma + beta (gamma NULL: none).
+ * svdd_bb_layer_bwd_f32: g_out = g_in + dLayerNorm(g_hn) at h = f_in + tb ; gt_out = g_out where mask_prev else 0 (both NULL: none). */
+int svdd_bb_layer_fwd_f32(const float* y, const float* bias, const float* f_prev, const float* tb, const float* gamma,
+                          const float* beta, float eps, float* f_out, uint8_t* mask, float* hn, int64_t rows, int rows_per_seq,
+                          int channels, void* stream);
+int svdd_bb_layer_bwd_f32(const float* g_hn, const float* f_in, const float* tb, const float* gamma, float eps, const float* g_in,
+                          const uint8_t* mask_prev, float* g_out, float* gt_out, int64_t rows, int rows_per_seq, int channels,
+                          void* stream);
 int svdd_gru_bidir_train_f32(const float* x, const float* wpack, const float* bpack, float* out, float* save, int n, int L,
                              void* stream);
 int svdd_gru_bidir_bwd_f32(const float* grad_out, const float* out, const float* save, const float* wpack_bwd, float* dx, int n,
@@ -400,7 +413,7 @@ int svdd_device_info(char* arch, int arch_len, int* num_cu);
 
 /* ABI version of this header: bumped on any signature change. */
 int svdd_abi_version(void);
-#define SVDD_ABI_VERSION 6
+#define SVDD_ABI_VERSION 7
 
 /*
  * Enformer-shaped value trunk (BASELINE.json configs[3]; reference decode.py:78-80, Enformer.py:1271-1334 trunk, :1807-1884

@@ -114,6 +114,7 @@ class CNNModel(nn.Module):
             tb = self._time_biases(t)
         return self.trunk(onehot.permute(0, 2, 1), tb).permute(0, 2, 1)
 
+    fused_layers = True    # _trunk_cl: the element-wise ops between two convolutions as one hand-written pass per direction
     hip_convs = False      # set by Diffusion (fuse_nets): forward2 on the hand-written dilated-conv kernel in both directions
 
     def forward2(self, seq_onehot, t):
@@ -135,11 +136,21 @@ class CNNModel(nn.Module):
         cols = torch.cat([xp[:, k:k + L] for k in range(9)], dim=2)        # [B, L, 9 A], tap-major
         feat = F.relu(cols @ w0.permute(2, 1, 0).reshape(9 * A, -1) + self.linear.bias)
         H = feat.shape[2]
-        for i in range(self.num_layers):
-            h = F.layer_norm(feat + time_biases[i].transpose(1, 2), (H,), self.norms[i].weight, self.norms[i].bias, self.norms[i].eps)
-            wp, wpt, d = packs[i]
-            c = fused.DilatedConvFunction.apply(h, wp, wpt, H, H, 9, d) + self.convs[i].bias
-            feat = F.relu(c) + feat
+        eps = self.norms[0].eps
+        if self.fused_layers and H in (64, 128, 256) and all(n.eps == eps for n in self.norms) and all(c.kernel_size[0] == 9 for c in self.convs):
+            # every layer as one convolution + one element-wise pass per direction (fused.BackboneLayersFunction): input gradient only
+            with torch.no_grad():
+                tb = torch.stack([t[:, :, 0] for t in time_biases]).float().contiguous()                 # [n, B, H]
+                gamma = torch.stack([n.weight for n in self.norms]).float().contiguous()
+                beta = torch.stack([n.bias for n in self.norms]).float().contiguous()
+                bias = torch.stack([c.bias for c in self.convs]).float().contiguous()
+            feat = fused.BackboneLayersFunction.apply(feat, tb, gamma, beta, bias, float(eps), packs)
+        else:
+            for i in range(self.num_layers):
+                h = F.layer_norm(feat + time_biases[i].transpose(1, 2), (H,), self.norms[i].weight, self.norms[i].bias, self.norms[i].eps)
+                wp, wpt, d = packs[i]
+                c = fused.DilatedConvFunction.apply(h, wp, wpt, H, H, 9, d) + self.convs[i].bias
+                feat = F.relu(c) + feat
         f1, f2 = self.final_conv[0], self.final_conv[2]
         return F.linear(F.relu(F.linear(feat, f1.weight[:, :, 0], f1.bias)), f2.weight[:, :, 0], f2.bias)
 

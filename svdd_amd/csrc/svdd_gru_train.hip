@@ -210,9 +210,129 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(const float* __restrict__ 
   }
 }
 
+// ---- the element-wise half of a dilated-CNN backbone layer under autograd (reference dnaconv.py:212-247 forward2, the DPS
+// gradient of diffusion_gosai.py:1321-1330): feat' = relu(conv(LayerNorm(feat + tb)) + b) + feat. The convolution runs on
+// svdd_conv1d_cl_f32 in both directions; everything between two convolutions is ONE pass here, forward and backward
+// (PyTorch autograd ran ~9 element-wise kernels per layer: add, LayerNorm, ReLU, add, and their backward twins).
+//   bb_layer_fwd_kernel   f_out = relu(y + b) + f_prev, mask = (y + b > 0), hn = LayerNorm(f_out + tb_next) gamma + beta
+//                         (y == NULL: f_out = f_prev, the first layer's LayerNorm only; gamma == NULL: no LayerNorm, last layer)
+//   bb_layer_bwd_kernel   G_out = G_in + LayerNorm-backward(g_hn) at h = f_in + tb, and gt_out = G_out * mask_prev: the gradient
+//                         the previous layer's convolution backward takes
+// One wave per row, lane owns VPL = C / 64 adjacent channels; two-pass moments like epilogue_ln_kernel / ATen.
+__device__ __forceinline__ float wave_sum64(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+struct BbFwdArgs { const float* y; const float* bias; const float* f_prev; const float* tb; const float* gamma; const float* beta;
+                   float eps; float* f_out; uint8_t* mask; float* hn; int64_t R; int rows_per_seq; };
+template <int VPL>
+__global__ __launch_bounds__(256) void bb_layer_fwd_kernel(BbFwdArgs a) {
+  constexpr int C = 64 * VPL;
+  const int lane = threadIdx.x & 63;
+  const int c0 = lane * VPL;
+  for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < a.R; r += (int64_t)gridDim.x * 4) {
+    const int64_t base = r * C + c0;
+    float v[VPL];
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      v[i] = a.f_prev[base + i];
+      if (a.y) {
+        const float t = a.y[base + i] + a.bias[c0 + i];
+        v[i] += fmaxf(t, 0.0f);
+        a.mask[base + i] = t > 0.0f;
+        a.f_out[base + i] = v[i];
+      }
+      if (a.gamma) { v[i] += a.tb[(r / a.rows_per_seq) * C + c0 + i]; s += v[i]; }
+    }
+    if (a.gamma) {
+      const float mean = wave_sum64(s) * (1.0f / C);
+      float q = 0.0f;
+#pragma unroll
+      for (int i = 0; i < VPL; ++i) { const float d = v[i] - mean; q += d * d; }
+      const float rstd = rsqrtf(wave_sum64(q) * (1.0f / C) + a.eps);
+#pragma unroll
+      for (int i = 0; i < VPL; ++i) a.hn[base + i] = (v[i] - mean) * rstd * a.gamma[c0 + i] + a.beta[c0 + i];
+    }
+  }
+}
+
+struct BbBwdArgs { const float* g_hn; const float* f_in; const float* tb; const float* gamma; float eps; const float* g_in;
+                   const uint8_t* mask_prev; float* g_out; float* gt_out; int64_t R; int rows_per_seq; };
+template <int VPL>
+__global__ __launch_bounds__(256) void bb_layer_bwd_kernel(BbBwdArgs a) {
+  constexpr int C = 64 * VPL;
+  const int lane = threadIdx.x & 63;
+  const int c0 = lane * VPL;
+  for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < a.R; r += (int64_t)gridDim.x * 4) {
+    const int64_t base = r * C + c0;
+    float h[VPL], ga[VPL];
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) { h[i] = a.f_in[base + i] + a.tb[(r / a.rows_per_seq) * C + c0 + i]; s += h[i]; }
+    const float mean = wave_sum64(s) * (1.0f / C);
+    float q = 0.0f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) { h[i] -= mean; q += h[i] * h[i]; }
+    const float rstd = rsqrtf(wave_sum64(q) * (1.0f / C) + a.eps);
+    float m1 = 0.0f, m2 = 0.0f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      h[i] *= rstd;                                            // x-hat
+      ga[i] = a.g_hn[base + i] * a.gamma[c0 + i];
+      m1 += ga[i]; m2 += ga[i] * h[i];
+    }
+    m1 = wave_sum64(m1) * (1.0f / C);
+    m2 = wave_sum64(m2) * (1.0f / C);
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const float g = a.g_in[base + i] + rstd * (ga[i] - m1 - h[i] * m2);
+      a.g_out[base + i] = g;
+      if (a.gt_out) a.gt_out[base + i] = a.mask_prev[base + i] ? g : 0.0f;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+int svdd_bb_layer_fwd_f32(const float* y, const float* bias, const float* f_prev, const float* tb, const float* gamma,
+                          const float* beta, float eps, float* f_out, uint8_t* mask, float* hn, int64_t rows, int rows_per_seq,
+                          int channels, void* stream) {
+  if (!f_prev || rows <= 0 || rows_per_seq <= 0 || (y && (!bias || !f_out || !mask)) || (gamma && (!beta || !tb || !hn)) ||
+      (!y && !gamma))
+    return SVDD_E_ARG;
+  BbFwdArgs a{y, bias, f_prev, tb, gamma, beta, eps, f_out, mask, hn, rows, rows_per_seq};
+  const int64_t nb = (rows + 3) / 4;
+  const dim3 grid((unsigned)(nb < 8192 ? nb : 8192));
+  switch (channels) {
+    case 64: hipLaunchKernelGGL(bb_layer_fwd_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a); break;
+    case 128: hipLaunchKernelGGL(bb_layer_fwd_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, a); break;
+    case 256: hipLaunchKernelGGL(bb_layer_fwd_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, a); break;
+    default: return SVDD_E_ARG;
+  }
+  return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
+}
+
+int svdd_bb_layer_bwd_f32(const float* g_hn, const float* f_in, const float* tb, const float* gamma, float eps, const float* g_in,
+                          const uint8_t* mask_prev, float* g_out, float* gt_out, int64_t rows, int rows_per_seq, int channels,
+                          void* stream) {
+  if (!g_hn || !f_in || !tb || !gamma || !g_in || !g_out || rows <= 0 || rows_per_seq <= 0 || ((gt_out == nullptr) != (mask_prev == nullptr)))
+    return SVDD_E_ARG;
+  BbBwdArgs a{g_hn, f_in, tb, gamma, eps, g_in, mask_prev, g_out, gt_out, rows, rows_per_seq};
+  const int64_t nb = (rows + 3) / 4;
+  const dim3 grid((unsigned)(nb < 8192 ? nb : 8192));
+  switch (channels) {
+    case 64: hipLaunchKernelGGL(bb_layer_bwd_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a); break;
+    case 128: hipLaunchKernelGGL(bb_layer_bwd_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, a); break;
+    case 256: hipLaunchKernelGGL(bb_layer_bwd_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, a); break;
+    default: return SVDD_E_ARG;
+  }
+  return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
+}
 
 int svdd_gru_bidir_train_f32(const float* x, const float* wpack, const float* bpack, float* out, float* save, int n, int L,
                              void* stream) {

@@ -134,6 +134,64 @@ class DilatedConvFunction(torch.autograd.Function):
         return conv1d_cl(g.contiguous().float(), wpack_t, cin, taps, dilation), None, None, None, None, None, None
 
 
+class BackboneLayersFunction(torch.autograd.Function):
+    """The residual layers of the dilated-CNN backbone on channels-last rows (reference models/dnaconv.py:212-247 forward2:
+    feat' = relu(conv_i(LayerNorm_i(feat + time_bias_i)) + b_i) + feat, i = 0 .. n - 1) with a hand-written backward to the
+    INPUT: per layer and direction one convolution (svdd_conv1d_cl_f32; backward-data = the same kernel on flipped /
+    transposed taps) and ONE element-wise pass (svdd_bb_layer_fwd_f32 / svdd_bb_layer_bwd_f32) instead of PyTorch's add,
+    LayerNorm, ReLU, add and their four backward kernels. Saves every layer's input rows and ReLU mask. Weights are frozen
+    (no weight gradients): the DPS baseline differentiates with respect to the input only (diffusion_gosai.py:1321-1330)."""
+
+    keep_masks, last_masks = False, None
+
+    @staticmethod
+    def forward(ctx, feat, tb, gamma, beta, bias, eps, packs):
+        """feat [B, L, C] ; tb [n, B, C] time biases ; gamma, beta, bias [n, C] ; packs: n x (wpack, wpack_t, dilation)."""
+        feat = feat.contiguous().float()
+        B, L, C = feat.shape
+        n = len(packs)
+        lib, st = _lib.lib(), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        rows = B * L
+        feats = torch.empty((n + 1, B, L, C), dtype=torch.float32, device=feat.device)
+        masks = torch.empty((n, B, L, C), dtype=torch.uint8, device=feat.device)
+        hn = torch.empty_like(feat)
+        feats[0].copy_(feat)
+        _lib.check(lib.svdd_bb_layer_fwd_f32(None, None, feats[0].data_ptr(), tb[0].data_ptr(), gamma[0].data_ptr(), beta[0].data_ptr(),
+                                             eps, None, None, hn.data_ptr(), rows, L, C, st), "svdd_bb_layer_fwd_f32")
+        for i, (wp, _, d) in enumerate(packs):
+            y = conv1d_cl(hn, wp, C, 9, d)
+            last = i + 1 == n
+            _lib.check(lib.svdd_bb_layer_fwd_f32(y.data_ptr(), bias[i].data_ptr(), feats[i].data_ptr(),
+                                                 None if last else tb[i + 1].data_ptr(), None if last else gamma[i + 1].data_ptr(),
+                                                 None if last else beta[i + 1].data_ptr(), eps, feats[i + 1].data_ptr(),
+                                                 masks[i].data_ptr(), None if last else hn.data_ptr(), rows, L, C, st),
+                       "svdd_bb_layer_fwd_f32")
+        ctx.save_for_backward(feats, masks, tb, gamma)
+        ctx.cfg = (eps, packs)
+        if BackboneLayersFunction.keep_masks:                     # tests: the ReLU decisions of this forward pass
+            BackboneLayersFunction.last_masks = masks
+        return feats[n].clone()
+
+    @staticmethod
+    def backward(ctx, G):
+        feats, masks, tb, gamma = ctx.saved_tensors
+        eps, packs = ctx.cfg
+        n, B, L, C = masks.shape
+        lib, st = _lib.lib(), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        rows = B * L
+        G = G.contiguous().float()
+        gt = G * masks[n - 1]                                      # gradient at the last layer's pre-activation
+        for i in range(n - 1, -1, -1):
+            g_hn = conv1d_cl(gt, packs[i][1], C, 9, packs[i][2])
+            G_new = torch.empty_like(G)
+            gt = torch.empty_like(G) if i else None
+            _lib.check(lib.svdd_bb_layer_bwd_f32(g_hn.data_ptr(), feats[i].data_ptr(), tb[i].data_ptr(), gamma[i].data_ptr(), eps,
+                                                 G.data_ptr(), masks[i - 1].data_ptr() if i else None, G_new.data_ptr(),
+                                                 gt.data_ptr() if i else None, rows, L, C, st), "svdd_bb_layer_bwd_f32")
+            G = G_new
+        return G, None, None, None, None, None, None
+
+
 def pack_conv(weight):
     """Conv1d weight [cout, cin, taps] -> [taps][cin/32][cout][32] for svdd_conv1d_cl_f32."""
     co, ci, T = weight.shape
