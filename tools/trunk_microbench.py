@@ -1,7 +1,7 @@
 """The fused Enformer-shaped value trunk (svdd_amd/fused_trunk.py) at the BASELINE configs[3] shard size: time per forward
 against the PyTorch module.  Usage: python tools/trunk_microbench.py [n] [precision] [--module] [--gemms] [--shared]
---shared: the rows are candidates of n / 15 parents that differ from them at 1-4 positions (42 / 33 / 17 / 8 %: the mix of a C4
-decode, tools/window_stats.py), scored with the first levels shared with the parent (forward_tokens(shared=...))
+--shared: the rows are candidates of n / 15 parents that differ from them at 1-4 positions (42 / 33 / 17 / 8 %: a Poisson-like
+mix that reproduces the compact-row fractions of a real C4 decode, tools/trunk_window_stats.py), scored with the first levels shared with the parent (forward_tokens(shared=...))
 (run under `rocprofv3 --kernel-trace --stats` for the per-kernel split)"""
 import os
 import sys
