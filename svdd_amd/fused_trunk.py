@@ -430,13 +430,22 @@ class FusedEnformerValueNet(nn.Module):
             for k in range(S):
                 main.wait_stream(self._side[k])
             self.last_window_rows = None if stats[0] is None else sum(stats[1:], stats[0])
-            sc = (zs @ self.head_w + self.head_b).view(n, T, -1).mean(dim=1)
+            sc = self._head(zs, n, T)
             s = torch.empty_like(sc)
             for k in range(S):
                 s[k::S] = sc[zoff[k] // T: zoff[k + 1] // T]
             return s[:, :, None]
-        s = (zs @ self.head_w + self.head_b).view(n, T, -1).mean(dim=1)
+        s = self._head(zs, n, T)
         return s[:, :, None]
+
+    def _head(self, zs, n, T):
+        """ConvHead: 1 x 1 convolution to n_tasks + mean over the T tokens, [n T, pw_out] -> [n, n_tasks]. A row-wise reduction, not
+        a library GEMM: hipBLASLt's result for a row changed in the last bit with the row's position in the batch (the compacted /
+        interleaved orders of the two-stream path gave 1e-7 differences against one chain), and a candidate's score must not
+        depend on where the compaction put it."""
+        z = zs.view(n, T, -1)
+        cols = [(z * self.head_w[:, j]).sum(dim=(1, 2)) for j in range(self.head_w.shape[1])]
+        return torch.stack(cols, dim=1) / T + self.head_b
 
     def _candidates(self, ws, st, tok, count, shared, depth, zs, half):
         """Conv tower (the first `depth` levels on windows), transformer tower and pointwise block of the rows `tok` -> zs."""

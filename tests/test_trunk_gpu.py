@@ -114,6 +114,31 @@ def test_tower_on_two_streams_same_bits(precision):
     assert torch.equal(outs[None][:300], outs[300]) and outs[None].unique().numel() > n // 2
 
 
+def test_scores_do_not_depend_on_the_row_position_full_size():
+    """A candidate's score must be the same bits wherever the compaction / the two-stream interleave puts its row: full-size
+    trunk, 2048 candidates scored in order, in reversed order, and as two half batches on two streams. (Caught by
+    tools/trunk_shared_soak.py: the head's 1 x 1 convolution as a hipBLASLt GEMM changed the last bit of a row's result with the
+    row's position; it is a row-wise reduction now.)"""
+    from svdd_amd import synthetic
+    from svdd_amd.fused_trunk import FusedEnformerValueNet
+    _, emb, head, _ = synthetic.build("dna", DEV, value="enformer")
+    _randomise(emb, head, 4)
+    g = torch.Generator(device=DEV).manual_seed(3)
+    n, L = 2048, 200
+    tok = torch.randint(0, 5, (n, L), device=DEV, generator=g, dtype=torch.uint8)
+    with torch.no_grad():
+        fn = FusedEnformerValueNet(emb, head, "bf16x3")
+        fn.tower_streams = 1
+        a = fn.forward_tokens(tok).reshape(n).clone()
+        b = fn.forward_tokens(tok.flip(0).contiguous()).reshape(n).flip(0).clone()
+        fn.tower_streams = 2
+        c = fn.forward_tokens(tok).reshape(n).clone()
+        assert fn.last_streams == 2
+    assert torch.isfinite(a).all() and a.unique().numel() > n // 2
+    assert torch.equal(a, b)
+    assert torch.equal(a, c)
+
+
 def test_mc_decode_with_the_fused_trunk_vs_oracle():
     """SVDD-MC (M = 20, L = 200) with the fused trunk as value function, precision bf16x3: the work-skipping loop (live
     candidates gathered on the device, `count` fed to every trunk kernel) against the plain loop, and the oracle's replay of
