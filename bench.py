@@ -202,6 +202,38 @@ def trunk_gemm_roofline(model, emb, head, dev, n, L):
             "traffic_source": None}
 
 
+def config4_leg(dev, steps, B=256, L=200, M=20, S=128):
+    """BASELINE.json configs[3] at its per-GPU shard size (B = 256 of the 2048, M = 20, the Enformer-shaped 230 M-parameter
+    value trunk) as an extra object of the default line: one warm-up decode + `steps` timed decodes in bf16x3 (split bf16
+    operands, fp32-class error: the trunk has no fp32 hand-written path — `--value-net enformer` times the PyTorch fp32 module).
+    Reported beside the headline, never in it; a failure here is recorded, not raised."""
+    try:
+        from svdd_amd import synthetic
+        from svdd_amd.fused_trunk import FusedEnformerValueNet
+        model, emb, head, _ = synthetic.build("dna", dev, value="enformer")
+        model.rng_mode, model.philox_seed, model.precision = "philox", 0, "bf16x3"
+        assert isinstance(model.value_callable(emb, head), FusedEnformerValueNet)
+        run = lambda: model.controlled_sample(emb, head, num_steps=S, eval_sp_size=B, sample_M=M)   # noqa: E731
+        run()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = run()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        assert out.shape == (B, L) and int(out.max()) <= 3
+        res = {"workload": f"DNA enhancer SVDD-MC, batch={B}/GPU, L={L}, M={M}, {S} steps, Enformer-shaped value trunk "
+                           "(230M params) — BASELINE.json configs[3] per-GPU shard", "value": round(B * steps / el, 3),
+               "unit": "sequences/s", "n_gpus": 1, "steps": steps, "ms_per_step": round(el / steps * 1e3, 3), "dtype": "bf16x3",
+               "arithmetic": "value trunk: fp32 operands split hi+lo in bf16, 3 MFMA passes, fp32 accumulate; backbone: the same split "
+                             "(backbone_lp_t_kernel)", "data": "synthetic (random-init nets, all-MASK prior)"}
+        del model, emb, head
+        torch.cuda.empty_cache()
+        return res
+    except Exception as e:                                     # noqa: BLE001
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
 def cpu_baseline(B, L, M, S, sample_steps, seed=44, threads=16, states=None, passes=3):
     """Oracle (CPU port of the reference path: M value-net calls of batch B per step, like
     diffusion_gosai.py:1207-1209) on `sample_steps` diffusion steps of the same workload. `states`: the x_t of every
@@ -353,6 +385,7 @@ def main():
     ap.add_argument("--alt-steps", type=int, default=2, help="timed decodes per alt-precision mode")
     ap.add_argument("--value-net", default="convgru", choices=["convgru", "enformer"],
                     help="enformer: the 230M-parameter Enformer-shaped value trunk of BASELINE config 4 (not the headline config)")
+    ap.add_argument("--c4-steps", type=int, default=1, help="decodes timed for the config4_enformer object of the default line (0 = skip)")
     ap.add_argument("--cpu-passes", type=int, default=3, help="cpu_baseline passes; the median is reported (BASELINE.md section 2)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch / rendezvous / all-gather skeleton with a stand-in decode on the host (no GPU, gloo)")
@@ -570,6 +603,8 @@ def main():
             line["config"]["workload"] += " [value net: Enformer-shaped trunk, 230M params — BASELINE configs[3] shape]"
             line["e2e_fp32_frac"] = None
             line["roofline_trunk_gemm"] = trunk_gemm_roofline(model, emb, head, dev, int(0.75 * B * M), L)
+        if args.c4_steps > 0 and world == 1 and args.value_net == "convgru" and (B, L, M) == (256, 200, 10):
+            line["config4_enformer"] = config4_leg(dev, args.c4_steps)
         if args.cpu_steps > 0 and world == 1 and args.value_net == "convgru":
             model.state_trace = []                                  # one extra (untimed) decode: the trajectory's states
             model.controlled_sample(emb, head, num_steps=S, eval_sp_size=B, sample_M=M)

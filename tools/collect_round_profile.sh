@@ -9,13 +9,13 @@ cd /tmp && export TMPDIR=/tmp
 OURS="backbone_kernel backbone_lp_kernel backbone_lp_t_kernel conv_tower tower_lp gru_bidir gru_pc gru_lp value_tail tail_lp candidate_windows compact_flags propose_kernel select_kernel select_rows_kernel tds_cdf tds_gather transform advance_rows gather_rows x0hat epilogue_ln conv1d_cl"
 python3 /root/repo/bench.py --steps 3 --warmup 1 2>/dev/null | tail -1 > $OUT/${TAG}_bench.json
 rm -rf /tmp/prof_$TAG
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o $TAG -- python3 /root/repo/bench.py --steps 2 --warmup 1 --cpu-steps 0 > /tmp/prof_$TAG.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o $TAG -- python3 /root/repo/bench.py --steps 2 --warmup 1 --cpu-steps 0 --c4-steps 0 > /tmp/prof_$TAG.log 2>&1
 cp $(find /tmp/prof_$TAG -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_bench_kernel_stats.csv
 python3 /root/repo/tools/trace_summary.py $(find /tmp/prof_$TAG -name "*kernel_trace.csv" | head -1) $OURS > $OUT/${TAG}_own_kernels_trace_summary.txt
 : > $OUT/${TAG}_pmc.txt
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -- python3 /root/repo/bench.py --steps 1 --warmup 0 --cpu-steps 0 --alt-precision f16x3,bf16x3,bf16 --alt-steps 1 > /tmp/pmc_$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -- python3 /root/repo/bench.py --steps 1 --warmup 0 --cpu-steps 0 --c4-steps 0 --alt-precision f16x3,bf16x3,bf16 --alt-steps 1 > /tmp/pmc_$c.log 2>&1
   python3 - $(find /tmp/pmc_$c -name "*counter_collection.csv" | head -1) $c >> $OUT/${TAG}_pmc.txt <<'PY'
 import csv, sys, collections
 agg = collections.defaultdict(list)
