@@ -42,6 +42,19 @@ def test_argument_validation_without_gpu():
     assert L.svdd_finalize(None, None, 1, 1, 0, None, None, None) == _lib.E_ARG
     assert L.svdd_x0hat(None, None, 1, 1, 0, None, None, None) == _lib.E_ARG
     assert L.svdd_tds_resample(None, None, 1.0, None, None, 1, 1, None, None, None, None) == _lib.E_ARG
+    # net-side entry points added in round 3: the config-4 trunk's GEMM / window kernels, the DPS backbone's layer passes
+    one = ctypes.c_void_p(64)                                              # a non-NULL pointer that is never dereferenced
+    assert L.svdd_trunk_gemm(None, None, None, None, None, None, 1, 128, 32, 1, 32, 128, 0, None, 0, None, None, None, None, 0, 0, None) == _lib.E_ARG
+    assert L.svdd_trunk_gemm(one, None, one, None, None, one, 1, 100, 32, 1, 32, 100, 0, None, 0, None, None, None, None, 0, 0, None) == _lib.E_ARG   # N % 128
+    assert L.svdd_trunk_windows(one, one, one, 1, 4, 201, 7, 2, 4, None, one, one, one, None) == _lib.E_ARG      # an odd length below the last shared level
+    assert L.svdd_trunk_windows(one, one, one, 1, 4, 200, 7, 1, 5, None, one, one, one, None) == _lib.E_ARG      # more window slots than the kernels hold
+    assert L.svdd_trunk_windows(one, one, one, 1, 4, 300, 7, 1, 4, None, one, one, one, None) == _lib.E_ARG      # L > 256
+    assert L.svdd_trunk_stem_unfold_win(None, 1, 200, 4, one, one, one, one, None, None) == _lib.E_ARG
+    assert L.svdd_trunk_attn_pool_win(one, one, 1, 200, 768, 0, 4, one, one, one, one, 1, one, None, None, one, one, None, None, 0, None, None, None,
+                                      None) == _lib.E_ARG                  # lo plane without the parent's lo plane
+    assert L.svdd_bb_layer_fwd_f32(None, None, None, None, None, None, 1e-5, None, None, None, 1, 1, 128, None) == _lib.E_ARG
+    assert L.svdd_bb_layer_fwd_f32(one, one, one, None, None, None, 1e-5, one, one, None, 1, 1, 96, None) == _lib.E_ARG    # channels not 64 / 128 / 256
+    assert L.svdd_bb_layer_bwd_f32(one, one, one, one, 1e-5, one, one, one, None, 1, 1, 128, None) == _lib.E_ARG          # mask without its output
 
 
 def test_schedule_table_equals_reference(golden):
