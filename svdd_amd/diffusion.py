@@ -44,6 +44,10 @@ Engine knobs (attributes; defaults reproduce the reference's observable behaviou
   logits_cache     "auto" (default): SVDD-MC keeps a per-row logits cache when several sequences share a backbone tile
                    (L <= 104; at L = 200 one workgroup owns one sequence and skipping rows frees CUs but saves no
                    time); "on" / "off". (SVDD-PM always carries the selected candidate's logits forward.)
+  dps_single_forward  False (default): a DPS step runs the no-grad forward for q_xs AND the differentiable pass for the gradient,
+                   like the reference (:1306 and :1324 evaluate one function twice). True (opt-in): the differentiable pass
+                   (forward2) also supplies the log-probs of q_xs — equal to round-off (~1e-6), so zero guidance is no longer
+                   bit-for-bit the un-guided decode at near-ties.
   skip_stats       None, or a dict the samplers fill with device-side hit counters (live candidates, changed rows).
   skip_generic     False (default). True: SVDD-MC also skips the copies of the parent for an OPAQUE value function (any
                    nn.Module, e.g. the Enformer-shaped trunk): the live candidates are gathered into a smaller batch whose
@@ -153,6 +157,7 @@ class Diffusion(nn.Module):
         self.fuse_nets = True
         self.precision = "f32"
         self.skip_unchanged = True
+        self.dps_single_forward = False  # DPS opt-in: q_xs from the differentiable pass's log-probs, not from a second backbone forward per step
         self.logits_cache = "auto"
         self.skip_stats = None
         self.skip_generic = False
@@ -531,7 +536,9 @@ class Diffusion(nn.Module):
         differentiable backbone entry `forward2` and the reward net are run as plain torch modules."""
         x_onehot.requires_grad_(True)
         keep = copy_flag[:, :, None]
-        expected_x0 = keep * x_onehot + (1 - keep) * self.forward2(x_onehot, x, sigma_s)
+        logp = self.forward2(x_onehot, x, sigma_s)
+        self._dps_logp = logp.detach()                            # log p(x0 | x_t): _dps_guided_q takes its q_xs from it
+        expected_x0 = keep * x_onehot + (1 - keep) * logp
         probs = torch.softmax(expected_x0, dim=2)
         # MIOpen's fused RNN backward insists on train(). A GRU without inter-layer dropout computes the same function in
         # both modes, so only those modules are switched for the call (BatchNorm / Dropout stay in eval): 113 -> 54 ms per
@@ -586,8 +593,9 @@ class Diffusion(nn.Module):
     def _dps_guided_q(self, x_u8, mcs, dm, reward_model, guidance_scale):
         """The guided transition weights q_xs of one DPS step (:1306-1314) -> fp32 [B, L, 5]."""
         B, L = x_u8.shape
-        with torch.no_grad():
-            q_xs = torch.exp(ops.subs_logp(self._backbone_logits(x_u8), x_u8)) * float(dm)   # :1306-1307
+        if not self.dps_single_forward:
+            with torch.no_grad():
+                q_xs = torch.exp(ops.subs_logp(self._backbone_logits(x_u8), x_u8)) * float(dm)   # :1306-1307
         x = x_u8.long()
         copy_flag = (x != self.mask_index).to(x.dtype)
         x_onehot = F.one_hot(x, num_classes=self.vocab_size).float()                          # :1308
@@ -595,6 +603,13 @@ class Diffusion(nn.Module):
         with torch.enable_grad():
             x_grad = self.compute_gradient_DPS(x_onehot, x, reward_model, sigma, copy_flag)   # :1310
         with torch.no_grad():
+            if self.dps_single_forward:
+                # The reference evaluates the backbone twice per step on the same x_t with the same (zeroed) sigma: forward() for
+                # q_xs (:1306) and forward2() inside the gradient (:1324). They are one function; the differentiable pass's log-probs
+                # are taken for both (round-off apart: ~1e-6, far inside the 1e-3 .. 1e-2 that the gradient's own ReLU decisions
+                # move it by). dps_single_forward = False (the default) runs the second forward like the reference.
+                q_xs = torch.exp(self._dps_logp) * float(dm)
+                self._dps_logp = None
             guidance = guidance_scale * (x_grad - x_grad[:, :, self.mask_index][:, :, None])   # :1311
             q_xs[:, :, self.mask_index] = float(mcs)                                          # :1312
             return q_xs * guidance.exp()                                                      # :1314

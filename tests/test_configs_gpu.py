@@ -194,8 +194,15 @@ def test_dps_at_config5_shape_full_size_nets(full_nets):
         x = torch.full((B, 200), 4, dtype=torch.uint8, device=DEV)
         sched = model._schedule(S, 1e-5)[0]
         q = model._dps_guided_q(x, sched[0, 1], sched[0, 2], reward, 50.0)
+        model.dps_single_forward = True            # opt-in: q_xs from the differentiable pass's log-probs (one backbone forward per step)
+        q1 = model._dps_guided_q(x, sched[0, 1], sched[0, 2], reward, 0.0)
+        e = model.controlled_sample_DPS(reward, 0.0, num_steps=S, eval_sp_size=B)
+        model.dps_single_forward = False
+        q2 = model._dps_guided_q(x, sched[0, 1], sched[0, 2], reward, 0.0)
     finally:
-        model.rng_mode = "replay"
+        model.rng_mode, model.dps_single_forward = "replay", False
+    assert float((q1 - q2).abs().max()) <= 1e-5 * float(q2.abs().max())
+    assert float((e != d).float().mean()) <= 1e-3
     assert a.shape == (B, 200) and a.dtype == torch.int64 and int(a.max()) <= 3 and int(a.min()) >= 0
     assert torch.equal(c, d)
     assert bool(torch.isfinite(q).all()) and float(q.min()) >= 0.0
