@@ -289,17 +289,36 @@ def cpu_baseline(B, L, M, S, sample_steps, seed=44, threads=16, states=None, pas
     }
 
 
+def _gpu_count_without_hip():
+    """GPUs this process may use, counted WITHOUT a HIP / HSA call (torch.cuda.device_count() can fall through to
+    hipGetDeviceCount, which initialises the runtime in this — the launching — process): the visibility variables if set,
+    else the KFD topology in sysfs (a node with simd_count > 0 is a GPU)."""
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([x for x in v.split(",") if x.strip() != ""])
+    n, root = 0, "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        for node in os.listdir(root):
+            with open(os.path.join(root, node, "properties")) as f:
+                props = dict(ln.split()[:2] for ln in f if len(ln.split()) >= 2)
+            n += int(props.get("simd_count", "0")) > 0
+    except OSError:
+        return 0
+    return n
+
+
 def self_launch(n):
     """`python bench.py --gpus N` from a bare shell: start the N ranks as a child `torch.distributed.run` (one process per
-    GPU, rendezvous on 127.0.0.1) and return its exit code. Runs BEFORE this process has touched the GPU — a process that
-    initialised the GPU must never replace itself with another program on this pool, so nothing is exec'd here either."""
+    GPU, rendezvous on 127.0.0.1) and return its exit code. This process never touches the GPU (devices are counted from sysfs / the visibility variables, not through HIP), and
+    nothing is exec'd: the launcher runs as a child whose exit code is returned."""
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "8")
-    if "--dry-run" not in sys.argv and torch.cuda.device_count() < n:     # (device_count does not initialise the GPU)
+    if "--dry-run" not in sys.argv and _gpu_count_without_hip() < n:
         # fewer GPUs than ranks: the ranks share devices, which RCCL refuses — host-side collectives, labelled in the line
         env.setdefault("SVDD_DIST_BACKEND", "gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",

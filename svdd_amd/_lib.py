@@ -50,16 +50,15 @@ class SvddError(RuntimeError):
 
 
 def build(force=False):
-    """Compile csrc/svdd_kernels.hip for gfx950 (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, "svdd_kernels.hip"), os.path.join(CSRC, "svdd_nets.hip"), os.path.join(CSRC, "svdd_trunk.hip"),
-            os.path.join(CSRC, "svdd_lp_backbone.hip"), os.path.join(CSRC, "svdd_lp_tower.hip"),
-            os.path.join(CSRC, "svdd_lp_gru_tail.hip"), os.path.join(CSRC, "svdd_lp_common.h"),
-            os.path.join(os.path.dirname(_HERE), "include", "svdd_hip.h")]
+    """Compile every csrc/*.hip for gfx950 (hipcc cross-compiles without a GPU); stale = any *.hip / *.h / Makefile newer."""
+    import glob
+    srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(CSRC, "Makefile")])
+    srcs.append(os.path.join(os.path.dirname(_HERE), "include", "svdd_hip.h"))
     if os.environ.get("SVDD_HIP_LIB"):
         return SO_PATH                                   # an explicitly chosen build is used as it is
     stale = not os.path.exists(SO_PATH) or os.path.getmtime(SO_PATH) < max(os.path.getmtime(f) for f in srcs)
     if force or stale:
-        subprocess.check_call(["make", "-C", CSRC, "-B", "-j", str(min(6, os.cpu_count() or 1))])   # 6 translation units
+        subprocess.check_call(["make", "-C", CSRC, "-B", "-j", str(min(8, os.cpu_count() or 1))])   # one job per translation unit
     return SO_PATH
 
 

@@ -119,9 +119,17 @@ class CNNModel(nn.Module):
 
     def forward2(self, seq_onehot, t):
         """Differentiable entry on a one-hot/relaxed input [B,L,5] (reference dnaconv.py:212-247; DPS)."""
-        if self.hip_convs and seq_onehot.is_cuda and self.args.hidden_dim % 32 == 0 and not self.training:
+        if (self.hip_convs and seq_onehot.is_cuda and self.args.hidden_dim % 32 == 0 and not self.training
+                and not (torch.is_grad_enabled() and self._trunk_wants_weight_grads())):
             return self._trunk_cl(seq_onehot, self._time_biases(t))
         return self.trunk(seq_onehot.permute(0, 2, 1), self._time_biases(t)).permute(0, 2, 1)
+
+    def _trunk_wants_weight_grads(self):
+        """The hand-written layer passes of _trunk_cl return the INPUT gradient only (the weights are frozen in every
+        decode path). A caller who differentiates with respect to a conv / norm / time-embedding parameter gets the plain
+        autograd trunk instead of silently partial gradients."""
+        inner = [p for n, p in self.named_parameters() if not (n.startswith("linear.") or n.startswith("final_conv."))]
+        return any(p.requires_grad for p in inner)
 
     def _trunk_cl(self, onehot, time_biases):
         """trunk() in channels-last rows [B, L, C] (no layout permutes; LayerNorm over the last axis as it lies), with every

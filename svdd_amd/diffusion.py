@@ -193,8 +193,23 @@ class Diffusion(nn.Module):
         `.data` / EMA swaps are caught too) and is rebuilt at the next decode when that no longer matches; call this to
         force it, or after changing weights in the middle of a per-step loop inside one sampler call."""
         self._fused = {}
+        self._cpk_fp = None
         if isinstance(self.backbone, CNNModel):
             self.backbone.clear_time_bias_cache()
+            self.backbone._cpk_key = None
+
+    def _validate_conv_packs(self):
+        """The packed dilated-conv weights of CNNModel._trunk_cl (DPS gradient path) are keyed by tensor identity + version
+        inside the backbone; a `.data` / EMA swap changes neither. Validate them like the fused nets: content fingerprint,
+        once per decode scope (every call outside one)."""
+        bb = self.backbone
+        if self._checked_now(getattr(self, "_cpk_stamp", None)):
+            return
+        fp = weight_fingerprint(*bb.convs)
+        old = getattr(self, "_cpk_fp", None)
+        if old is None or not _same_weights(old, fp):
+            bb._cpk_key = None
+        self._cpk_fp, self._cpk_stamp = fp, self._scope_id
 
     def _checked_now(self, stamp):
         return self._scope_depth > 0 and stamp == self._scope_id
@@ -387,8 +402,18 @@ class Diffusion(nn.Module):
         must see every op, so the SUBS step is expressed in torch here."""
         sigma = self._process_sigma(sigma)
         if isinstance(self.backbone, CNNModel):
-            self.backbone.hip_convs = bool(self.fuse_nets)        # dilated convs on the hand-written kernel, both directions
-        logits = self.backbone.forward2(x_onehot, sigma)
+            # dilated convs on the hand-written kernel, both directions — for this call only (the flag does not outlive it:
+            # a later backbone.forward2 by the user gets plain autograd unless asked otherwise)
+            was = self.backbone.hip_convs
+            self.backbone.hip_convs = bool(self.fuse_nets)
+            if self.backbone.hip_convs:
+                self._validate_conv_packs()
+            try:
+                logits = self.backbone.forward2(x_onehot, sigma)
+            finally:
+                self.backbone.hip_convs = was
+        else:
+            logits = self.backbone.forward2(x_onehot, sigma)
         neg = torch.zeros(self.vocab_size, device=logits.device)
         neg[self.mask_index] = self.neg_infinity
         logits = logits + neg

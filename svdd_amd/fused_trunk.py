@@ -101,7 +101,6 @@ class FusedEnformerValueNet(nn.Module):
         assert precision in ("bf16x3", "bf16")
         self.precision = precision
         self.parts = 2 if precision == "bf16x3" else 1
-        self._src = (trunk, head)
         self._ws = {}
         dev = next(trunk.parameters()).device
         P = self.parts
@@ -200,9 +199,15 @@ class FusedEnformerValueNet(nn.Module):
         _lib.check(rc, "svdd_trunk_layernorm_split")
 
     def _workspace(self, n, L, dev):
-        key = (n, L, str(dev))
+        """ONE workspace per (L, device), sized for the largest batch seen so far and reused for smaller ones (an SVDD-MC decode
+        scores n = B parents once and then n = B * M candidates at every step: keyed by n, the GB-sized buffers and the parents'
+        carried state were freed and reallocated at every switch, with both copies alive during the swap). A larger batch drops
+        the old buffers BEFORE allocating the new ones."""
+        key = (L, str(dev))
         ws = self._ws.get(key)
-        if ws is None:
+        if ws is None or ws["cap"] < n:
+            ws = None
+            self._ws = {}                                          # free first: never two GB-sized workspaces at once
             fmax, pmax = self._workspace_sizes(n, L)
             for S in (2, 3, 4):                                   # room for S parts of the batch side by side (forward_tokens)
                 fh, ph = self._workspace_sizes((n + S - 1) // S, L)
@@ -210,8 +215,8 @@ class FusedEnformerValueNet(nn.Module):
             # two sets of operand planes: a GEMM reads one and writes the next GEMM's operands into the other
             pmax += _Planes.FRONT
             ws = {"f": [torch.empty(fmax, dtype=torch.float32, device=dev) for _ in range(4)],
-                  "p": [_Planes(pmax, self.parts, dev), _Planes(pmax, self.parts, dev)]}
-            self._ws = {key: ws}                                   # one workspace at a time (GBs at the C4 shard size)
+                  "p": [_Planes(pmax, self.parts, dev), _Planes(pmax, self.parts, dev)], "cap": n}
+            self._ws = {key: ws}
         return ws
 
     def _workspace_sizes(self, n, L):

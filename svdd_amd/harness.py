@@ -87,20 +87,27 @@ class BaseModel(nn.Module):
             m.philox_seed = batch_seed(self._seed_base, self._batch_index)
         self._batch_index += 1
 
-    def _decode(self, gen_batch_num, sample_M, guided):
+    def _decode(self, gen_batch_num, sample_M, guided, tweedie_quirks=False):
         self._seed_base, self._batch_index = int(getattr(self.ref_model, "philox_seed", 0)), 0
         try:
-            return self._decode_inner(gen_batch_num, sample_M, guided)
+            return self._decode_inner(gen_batch_num, sample_M, guided, tweedie_quirks)
         finally:
             if hasattr(self.ref_model, "philox_seed"):
                 self.ref_model.philox_seed = self._seed_base
 
-    def _decode_inner(self, gen_batch_num, sample_M, guided):
+    def _decode_inner(self, gen_batch_num, sample_M, guided, tweedie_quirks=False):
+        """`tweedie_quirks`: what `controlled_decode_tweedie` does differently from its three siblings (pinned by
+        tests/golden/g22_harness.npz, recorded from the reference's own method): `samples.extend(batch)` — a flat list of
+        [L] rows instead of a list of [B, L] batches (Enformer.py:766 vs :441) — and `top_k_values = cat(baseline_preds)`,
+        the top-k being commented out there (:802-811)."""
         samples, value_func_preds, reward_model_preds = [], [], []
         for _ in range(gen_batch_num):
             self._next_batch_seed()
             batch = guided()
-            samples.append(batch)
+            if tweedie_quirks:
+                samples.extend(batch)
+            else:
+                samples.append(batch)
             value_func_preds.extend(self._value(batch))
             reward_model_preds.extend(self._reward(batch))
         print("Value-weighted sampling done.")
@@ -112,10 +119,13 @@ class BaseModel(nn.Module):
             if i < gen_batch_num:
                 baseline_preds.extend(pred)
             all_preds.extend(pred)
-        print("Baseline sampling done.")
-        all_values = torch.cat(all_preds)
-        k = int(len(all_values) / sample_M)                                    # Enformer.py:471-475
-        top_k_values, _ = torch.topk(all_values, k)
+        if tweedie_quirks:
+            top_k_values = torch.cat(baseline_preds)                           # Enformer.py:802
+        else:
+            print("Baseline sampling done.")
+            all_values = torch.cat(all_preds)
+            k = int(len(all_values) / sample_M)                                # Enformer.py:471-475
+            top_k_values, _ = torch.topk(all_values, k)
         return (samples, torch.cat(value_func_preds), torch.cat(reward_model_preds), top_k_values,
                 torch.cat(baseline_preds))
 
@@ -130,7 +140,7 @@ class BaseModel(nn.Module):
         """SVDD-PM (reference Enformer.py:719-813)."""
         return self._decode(gen_batch_num, sample_M, lambda: self.ref_model.controlled_sample_tweedie(
             self.reward_model, eval_sp_size=self.NUM_SAMPLES_PER_BATCH, sample_M=sample_M, options=options,
-            task=self.task))
+            task=self.task), tweedie_quirks=True)
 
     @torch.no_grad()
     def controlled_decode_TDS(self, gen_batch_num, sample_M, alpha):

@@ -7,14 +7,15 @@ argmax is discontinuous, so a last-bit difference between MIOpen / our kernels a
 a token at a near-tie, after which that ROW's trajectory differs (rows are independent). The report therefore gives, per
 run: the first step at which any state differs, the error of logits and scores up to that step (north-star tolerance
 1e-4), the fraction of rows / tokens of x_0 that still agree, and for the first diverging row how close the deciding
-quantities were in the reference run. Used by tests/test_e2e_gpu.py and tools/e2e_parity_report.py."""
+quantities were in the reference run. Used by tests/test_e2e_gpu.py and tools/e2e_parity_report.py.
+Test infrastructure: lives under tests/, not in the product package."""
 import numpy as np
 import torch
 
-from .backbone import CNNModel
-from .config import Config, ModelConfig, SamplingConfig
-from .diffusion import Diffusion
-from .value_nets import ConvGRUTrunk, ConvHead
+from svdd_amd.backbone import CNNModel
+from svdd_amd.config import Config, ModelConfig, SamplingConfig
+from svdd_amd.diffusion import Diffusion
+from svdd_amd.value_nets import ConvGRUTrunk, ConvHead
 
 
 def _sd(g, prefix):
@@ -49,7 +50,7 @@ def compare_with_reference_run(g, nets, device="cuda:0", fuse_nets=True, value_b
 def uses_hand_written_kernels(model, emb, head, L):
     """True when this engine evaluates (backbone, value net) through the one-launch backbone kernel and the
     tower / GRU / tail kernels of svdd_amd/csrc — i.e. the kernels that are 99 % of a decode's time."""
-    from .fused import FusedValueNet
+    from svdd_amd.fused import FusedValueNet
     fb = model._fused_backbone_or_none(L)
     fn = model.value_callable(emb, head)
     return fb is not None and isinstance(fn, FusedValueNet) and fn.kernels_ok(L)
@@ -104,8 +105,8 @@ def teacher_forced_report(g, model, emb, head, precision="f32"):
     reference computed on the CPU at that step, so an error cannot hide behind an earlier divergence. Also: the select
     kernel applied to the GPU scores against the reference's next state (selection agreement), and the gap between the
     two best reference scores where a selection differs."""
-    from . import ops
-    from .fused import FusedBackbone, FusedValueNet
+    from svdd_amd import ops
+    from svdd_amd.fused import FusedBackbone, FusedValueNet
     S, B, L, M = int(g["S"]), int(g["B"]), int(g["L"]), int(g["M"])
     dev = model.device
     model.fuse_nets, model.precision = True, precision
@@ -155,7 +156,7 @@ def teacher_forced_pm_report(g, model, reward_model, precision="f32"):
     state x_t and every candidate set goes through the one-launch backbone kernel (L = 50: several sequences per tile), the
     x0-hat one-hots (:1415-1419) are rebuilt from the GPU's candidate logits and compared with what the reward model saw in
     the reference run, and the reward model (hand-written tower / GRU / tail kernels) scores the REFERENCE's one-hots."""
-    from . import ops
+    from svdd_amd import ops
     S, B, L, M = int(g["S"]), int(g["B"]), int(g["L"]), int(g["M"])
     dev = model.device
     model.fuse_nets, model.precision = True, precision
@@ -222,7 +223,7 @@ def tds_reference_run_report(g, model, reward_model, precision="f32"):
     numerator / denominator rewards (:1263-1277) through the hand-written reward kernels on the x0-hat of the GPU's logits.
     Free-running: the engine's decode in replay mode (torch + numpy streams seeded as in the reference run; exact reuse of
     forward(sample) and of the numerator reward across steps) against the reference's states and x_0."""
-    from . import ops
+    from svdd_amd import ops
     S, B, L = int(g["S"]), int(g["B"]), int(g["L"])
     dev = model.device
     model.fuse_nets, model.precision = True, precision
@@ -265,3 +266,218 @@ def tds_reference_run_report(g, model, reward_model, precision="f32"):
             "max_abs_reward_num_err": float(dnum.max()), "max_abs_reward_den_err": float(dden.max()),
             "x0hat_rows_identical": oh_same / max(oh_total, 1), "states_recorded": len(xs), "first_divergence_step": first, "x0_exact": bool(np.array_equal(x0n, g["x0"])),
             "x0_rows_identical": float((x0n == g["x0"]).all(axis=1).mean())}
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# g21: the reference's own runs AT the headline configs (BASELINE.json configs[1] = C2: controlled_sample, B = 256,
+# L = 200, M = 10, 128 steps; configs[2] = C3: controlled_sample_tweedie(options="True"), B = 256, L = 50, M = 10).
+# The fixtures are lean (states, delta-coded candidates, scores, selections; raw logits of a few calls only), so the
+# candidates are RE-PROPOSED on the GPU from the replayed uniforms and must equal the reference's: at full occupancy that
+# checks the fp32 backbone kernel on all 256 rows of every step through K1's argmaxes.
+def cand_of(g, i):
+    """Step i's candidates u8 [B, M, L] (stored in full, or as 255 = 'the parent's token' deltas)."""
+    if "cand" in g:
+        return g["cand"][i]
+    d = g["cand_delta"][i]
+    return np.where(d == 255, g["xs"][i][:, None, :], d)
+
+
+def race_margin(logit_row, dm, mcs, u5):
+    """Relative lead of the winner of ONE categorical draw of a MASKed position (diffusion_gosai.py:30-34 on q_xs of
+    :1194-1196) over the runner-up, evaluated in float64 from the raw backbone output of that position."""
+    l4 = np.asarray(logit_row[:4], dtype=np.float64)
+    logp = l4 - (l4.max() + np.log(np.exp(l4 - l4.max()).sum()))
+    q = np.concatenate([np.exp(logp) * float(dm), [float(mcs)]])
+    r = np.sort(q / (1e-10 - np.log(np.asarray(u5, dtype=np.float64) + 1e-10)))[::-1]
+    return float((r[0] - r[1]) / r[0])
+
+
+def _explain_candidate_diffs(mine, ref, lg, u, dm, mcs):
+    """Every (b, m, l) where the re-proposed candidates differ from the reference's -> its race margin (GPU logits)."""
+    out = []
+    for b, m, l in zip(*np.nonzero(mine != ref)):
+        out.append(race_margin(lg[b, l], dm, mcs, u[m, b, :, l]))
+    return out
+
+
+def _replay_uniforms(model, M, B, L, logits):
+    rng = model._rng(0, M, B, L, logits)                       # replay mode: M x rand_like(q_xs) of torch's CPU stream
+    return rng, rng.uniforms
+
+
+def teacher_forced_lean_report(g, model, emb, head, precision="f32"):
+    """C2, teacher-forced on the reference's states: per step x_t -> one-launch backbone -> K1 with the replayed uniforms ->
+    candidates (vs the reference's) ; the reference's candidates -> value kernels (compacted, parent-sharing path the
+    decode takes, and the whole-sequence path) -> scores (vs the reference's, 1e-4) -> K2 -> next state (vs the reference's)."""
+    from svdd_amd import ops
+    from svdd_amd.fused import FusedBackbone, FusedValueNet
+    S, B, L, M = int(g["S"]), int(g["B"]), int(g["L"]), int(g["M"])
+    dev = model.device
+    model.fuse_nets, model.precision, model.rng_mode = True, precision, "replay"
+    fb, fn = model._fused_backbone_or_none(L), model.value_callable(emb, head)
+    if not (isinstance(fb, FusedBackbone) and isinstance(fn, FusedValueNet) and fn.kernels_ok(L)):
+        raise ops.SvddError("needs nets the hand-written kernels take (full-size CNN + ConvGRU)")
+    sched, _, _ = model._schedule(S, 1e-5)
+    kept = {int(s): k for k, s in enumerate(g["logits_steps"])} if "logits_steps" in g else {}
+    dl, ds = [], np.zeros((S, 2))
+    cand_rows_same, cand_margins, gaps = 0, [], []
+    agree = np.zeros((S, B), dtype=bool)
+    torch.manual_seed(int(g["seed"]))
+    with torch.no_grad():
+        for i in range(S + 1):
+            x = torch.from_numpy(g["xs"][i]).to(dev).contiguous()
+            lg = model._backbone_logits(x)
+            if i in kept:
+                dl.append(float((lg.cpu() - torch.from_numpy(g["logits"][kept[i]])).abs().max()))
+            if i == S:
+                break
+            ref_cand = cand_of(g, i)
+            rng, u = _replay_uniforms(model, M, B, L, lg)
+            mine, _, _ = ops.propose(lg, x, sched[i, 2], sched[i, 1], M, rng)
+            mine = mine.cpu().numpy()
+            same = (mine == ref_cand).all(axis=2)
+            cand_rows_same += int(same.sum())
+            if not same.all():
+                cand_margins += _explain_candidate_diffs(mine, ref_cand, lg.cpu().numpy(), u.cpu().numpy(), sched[i, 2], sched[i, 1])
+            cand = torch.from_numpy(ref_cand).to(dev).contiguous()
+            onehot = ops.transform_samples(cand.view(B * M, L))
+            ref = torch.from_numpy(g["scores"][i])
+            whole = fn(onehot).reshape(B, M).float()
+            if fn.candidates_ok(L, M):
+                ws = model._SkipWorkspace(B, M, dev)
+                ws.parent_score.copy_(fn.forward_tokens(x).reshape(B))
+                compact = model._dense_scores(fn.candidate_scores_compact(onehot, cand, x, ws).reshape(-1), ws, B, M)
+            else:
+                compact = whole
+            ds[i] = [float((whole.cpu() - ref).abs().max()), float((compact.cpu() - ref).abs().max())]
+            x_next, _, _ = ops.select(compact.contiguous(), cand, mode=ops.SELECT_ARGMAX, want_soft=False)
+            agree[i] = (x_next.cpu().numpy() == g["xs"][i + 1]).all(axis=1)
+            for b in np.nonzero(~agree[i])[0]:
+                top = np.sort(g["scores"][i][b])[::-1]
+                gaps.append(float(top[0] - top[1]))
+    model.precision = "f32"
+    return {"S": S, "B": B, "L": L, "M": M, "precision": precision, "steps_compared": S + 1,
+            "max_abs_logit_err_kept_calls": max(dl) if dl else None, "logit_calls_compared": len(dl),
+            "candidate_rows": S * B * M, "candidate_rows_identical": cand_rows_same,
+            "candidate_tokens_differing": len(cand_margins),
+            "max_race_margin_where_candidates_differ": max(cand_margins) if cand_margins else None,
+            "max_abs_score_err_whole_tower": float(ds[:, 0].max()), "max_abs_score_err_compact": float(ds[:, 1].max()),
+            "selection_agreement": float(agree.mean()), "row_steps": int(agree.size),
+            "disagreeing_row_steps": int((~agree).sum()),
+            "max_reference_top2_gap_where_selection_differs": max(gaps) if gaps else None}
+
+
+def teacher_forced_lean_pm_report(g, model, reward_model, precision="f32"):
+    """C3, teacher-forced: x_t -> backbone -> K1 (replayed uniforms) -> candidates vs the reference's; the reference's
+    candidates -> backbone -> x0-hat rows vs what the reference's reward model was handed (:1415-1419; a differing position
+    must be a near-tie of the GPU's two best real-token logits); reward kernels on the REFERENCE's x0-hat -> scores (1e-4)
+    -> K2 -> next state."""
+    from svdd_amd import ops
+    S, B, L, M = int(g["S"]), int(g["B"]), int(g["L"]), int(g["M"])
+    dev = model.device
+    model.fuse_nets, model.precision, model.rng_mode = True, precision, "replay"
+    fn = model.reward_callable(reward_model)
+    sched, _, _ = model._schedule(S, 1e-5)
+    kept = {int(s): k for k, s in enumerate(g["logits_calls"])}
+    dl, ds = [], np.zeros(S)
+    cand_rows_same, cand_margins, gaps, xh_gaps = 0, [], [], []
+    xh_same = 0
+    agree = np.zeros((S, B), dtype=bool)
+    torch.manual_seed(int(g["seed"]))
+    with torch.no_grad():
+        for i in range(S + 1):
+            x = torch.from_numpy(g["xs"][i]).to(dev).contiguous()
+            lg = model._backbone_logits(x)
+            if i * (1 + M) in kept:
+                dl.append(float((lg.cpu() - torch.from_numpy(g["logits"][kept[i * (1 + M)]])).abs().max()))
+            if i == S:
+                break
+            ref_cand = cand_of(g, i)
+            rng, u = _replay_uniforms(model, M, B, L, lg)
+            mine, _, _ = ops.propose(lg, x, sched[i, 2], sched[i, 1], M, rng)
+            mine = mine.cpu().numpy()
+            same = (mine == ref_cand).all(axis=2)
+            cand_rows_same += int(same.sum())
+            if not same.all():
+                cand_margins += _explain_candidate_diffs(mine, ref_cand, lg.cpu().numpy(), u.cpu().numpy(), sched[i, 2], sched[i, 1])
+            cand = torch.from_numpy(ref_cand).to(dev).contiguous()
+            flat = cand.view(B * M, L)
+            cl = model._backbone_logits(flat)
+            _, xh = ops.x0hat(cl, flat, want_tokens=True, want_onehot=False)
+            d = g["x0hat_delta"][i]
+            ref_xh = np.where(d == 255, ref_cand, d).reshape(B * M, L)
+            xh_np = xh.cpu().numpy()
+            xh_same += int((xh_np == ref_xh).all(axis=1).sum())
+            if not np.array_equal(xh_np, ref_xh):
+                cln = cl.cpu().numpy()
+                for r, l in zip(*np.nonzero(xh_np != ref_xh)):
+                    top = np.sort(cln[r, l, :4])[::-1]
+                    xh_gaps.append(float(top[0] - top[1]))
+            ref_oh = torch.nn.functional.one_hot(torch.from_numpy(ref_xh).long(), 4).permute(0, 2, 1).float().contiguous()
+            sc = fn(ref_oh.to(dev))[:, 0].reshape(B, M).float()
+            ref = torch.from_numpy(g["scores"][i])
+            ds[i] = float((sc.cpu() - ref).abs().max())
+            x_next, _, _ = ops.select(sc.contiguous(), cand, mode=ops.SELECT_ARGMAX, want_soft=False)
+            agree[i] = (x_next.cpu().numpy() == g["xs"][i + 1]).all(axis=1)
+            for b in np.nonzero(~agree[i])[0]:
+                top = np.sort(g["scores"][i][b])[::-1]
+                gaps.append(float(top[0] - top[1]))
+    model.precision = "f32"
+    return {"S": S, "B": B, "L": L, "M": M, "precision": precision, "steps_compared": S + 1,
+            "hand_written_net_kernels": bool(isinstance(fn, torch.nn.Module) and fn is not reward_model),
+            "max_abs_logit_err_kept_calls": max(dl) if dl else None, "logit_calls_compared": len(dl),
+            "candidate_rows": S * B * M, "candidate_rows_identical": cand_rows_same,
+            "candidate_tokens_differing": len(cand_margins),
+            "max_race_margin_where_candidates_differ": max(cand_margins) if cand_margins else None,
+            "x0hat_rows_identical": xh_same, "x0hat_tokens_differing": len(xh_gaps),
+            "max_logit_top2_gap_where_x0hat_differs": max(xh_gaps) if xh_gaps else None,
+            "max_abs_score_err": float(ds.max()), "selection_agreement": float(agree.mean()), "row_steps": int(agree.size),
+            "disagreeing_row_steps": int((~agree).sum()),
+            "max_reference_top2_gap_where_selection_differs": max(gaps) if gaps else None}
+
+
+def free_running_lean_report(g, model, run, precision="f32"):
+    """Free-running replay decode at a headline config against the reference's run. `run(model)` calls the sampler. Rows are
+    independent, so every row is followed to ITS first divergence: there the state the engine chose must be one of the
+    reference's own candidates of that step whose REFERENCE score is within 2e-4 of the reference's best (a selection
+    near-tie), or — a candidate the reference did not have — a proposal flip, which the teacher-forced report explains;
+    scores are compared (1e-4) on every row-step whose input state is still the reference's."""
+    S, B, L, M = int(g["S"]), int(g["B"]), int(g["L"]), int(g["M"])
+    model.fuse_nets, model.rng_mode, model.precision = True, "replay", precision
+    model.trace, model.state_trace = [], []
+    torch.manual_seed(int(g["seed"]))
+    with torch.no_grad():
+        x0 = run(model)
+    torch.cuda.synchronize()
+    xs = np.stack([x.cpu().numpy() for x in model.state_trace])[:S + 1]
+    scores = [t[1].cpu().numpy() for t in model.trace[:S]]
+    model.trace = model.state_trace = None
+    model.precision = "f32"
+    same = (xs == g["xs"][:len(xs)]).all(axis=2)                                       # [S + 1, B]
+    first_row = np.array([next((i for i in range(len(xs)) if not same[i, b]), -1) for b in range(B)])
+    ds = max(float(np.abs(scores[i][same[i]] - g["scores"][i][same[i]]).max()) for i in range(S) if same[i].any())
+    near_tie, proposal, unexplained, gaps = 0, 0, [], []
+    for b in np.nonzero(first_row >= 0)[0]:
+        i = int(first_row[b]) - 1                                                      # the step that produced the differing state
+        refc = cand_of(g, i)[b]                                                        # [M, L]
+        hit = np.nonzero((refc == xs[i + 1, b]).all(axis=1))[0]
+        if len(hit):
+            gap = float(g["scores"][i][b].max() - g["scores"][i][b][hit].max())
+            gaps.append(gap)
+            if gap <= 2e-4:
+                near_tie += 1
+            else:
+                unexplained.append({"row": int(b), "step": i, "reference_score_gap": gap})
+        else:
+            proposal += 1
+    x0n = x0.cpu().numpy()
+    diverged = first_row[first_row >= 0]
+    return {"S": S, "B": B, "L": L, "M": M, "precision": precision,
+            "first_divergence_step": int(diverged.min()) if len(diverged) else None,
+            "rows_diverged": int(len(diverged)), "rows_following_the_reference_to_the_end": int((first_row < 0).sum()),
+            "divergences_at_selection_near_ties": near_tie, "divergences_by_proposal_flip": proposal,
+            "divergences_unexplained": unexplained, "max_reference_score_gap_at_a_selection_divergence": max(gaps) if gaps else None,
+            "max_abs_score_err_on_undiverged_rows": ds,
+            "x0_exact": bool(np.array_equal(x0n, g["x0"])),
+            "x0_rows_identical": float((x0n == g["x0"]).all(axis=1).mean()),
+            "x0_tokens_identical": float((x0n == g["x0"]).mean())}

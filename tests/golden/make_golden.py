@@ -754,6 +754,159 @@ def g17_enformer_trunk(seed=71):
          shapes=np.array([list(sh) + [-1] * (maxr - len(sh)) for sh in shapes], dtype=np.int64))
 
 
+# ------------------------------------------------------------------ g21: the headline configs themselves (round 4)
+def _delta(cand, parent):
+    """cand u8 [B, M, L] against its parent x_t [B, L]: 255 where the candidate kept the parent's token (most positions)."""
+    return torch.where(cand == parent[:, None, :], torch.full_like(cand, 255), cand)
+
+
+class LeanRecBackbone(torch.nn.Module):
+    """Records every call's input tokens as u8 and, for the call numbers in `keep`, the raw output."""
+
+    def __init__(self, inner, keep=()):
+        super().__init__()
+        self.inner, self.keep = inner, set(keep)
+        self.xs, self.logits = [], {}
+
+    def forward(self, x, sigma, *a, **k):
+        out = self.inner(x, sigma, *a, **k)
+        n = len(self.xs)
+        self.xs.append(x.to(torch.uint8))
+        if n in self.keep:
+            self.logits[n] = out.detach().clone()
+        return out
+
+
+def g21_traj_mc_c2(seed=0, B=256, L=200, M=10, S=128):
+    """BASELINE.json configs[1] — the headline — run by the reference itself: controlled_sample (diffusion_gosai.py:1021-1061,
+    1174-1228) with the full-size seed-44 nets at B = 256, L = 200, M = 10, 128 steps (≈ 5 min on the 8 build cores). Kept small:
+    every step's state (u8), candidates (delta-coded against the state), value scores and selections; raw backbone outputs of
+    three calls only (first, middle, the noise-removal call). Weights are not stored (seed 44 in synthetic.build's order; sums kept)."""
+    d, emb_m, head_m = full_nets(steps=S, length=L)
+    rec = LeanRecBackbone(d.backbone, keep=(0, S // 2, S))
+    d.backbone = rec
+    cands, scores = [], []
+
+    def emb(x):                                                       # x: one-hot float [B, L, 4] of one candidate set
+        s = x.sum(-1)
+        cands.append(torch.where(s > 0, x.argmax(-1), torch.full_like(x.argmax(-1), 4)).to(torch.uint8))
+        return emb_m(x)
+
+    def head(h):
+        y = head_m(h)
+        scores.append(y.detach().squeeze().clone())
+        return y
+
+    torch.manual_seed(seed)
+    x0 = d.controlled_sample(emb, head, eval_sp_size=B, sample_M=M)
+    d.backbone = rec.inner
+    xs = torch.stack(rec.xs)                                          # [S + 1, B, L]
+    cand = torch.stack(cands).view(S, M, B, L).permute(0, 2, 1, 3).contiguous()
+    sc = torch.stack(scores).view(S, M, B).permute(0, 2, 1).contiguous()
+    idx = torch.softmax(sc, dim=2).argmax(dim=2).to(torch.uint8)      # :1219-1225
+    assert torch.equal(torch.gather(cand, 2, idx.long()[:, :, None, None].expand(S, B, 1, L))[:, :, 0], xs[1:])
+    arrs = {n_ + "_param_sums": np.array([float(p.double().sum()) for p in mod.state_dict().values()])
+            for n_, mod in (("backbone", d.backbone), ("embedding", emb_m), ("head", head_m))}
+    kept = sorted(rec.logits)
+    save("g21_traj_mc_c2.npz", xs=xs, cand_delta=torch.stack([_delta(cand[s], xs[s]) for s in range(S)]), scores=sc, idx=idx,
+         x0=x0.to(torch.uint8), logits_steps=np.array(kept), logits=torch.stack([rec.logits[k] for k in kept]),
+         seed=seed, net_seed=44, B=B, L=L, M=M, S=S, threads=torch.get_num_threads(), sched=sched_rows(d, S), **arrs)
+
+
+def g21_traj_pm_c3(seed=0, B=256, L=50, M=10, S=128):
+    """BASELINE.json configs[2] run by the reference: controlled_sample_tweedie(options="True") (diffusion_gosai.py:1105-1145,
+    1373-1460), full-size seed-44 nets + reward model at B = 256, L = 50, M = 10, 128 steps. Per step: state, candidates
+    (delta-coded), the x0-hat rows handed to the reward model (as tokens), reward scores, selections."""
+    d, emb_v, head_v = full_nets(length=L, steps=S)
+    emb_r, head_r = full_reward()
+    reward = RewardWrap(emb_r, head_r).eval()
+    rec = LeanRecBackbone(d.backbone, keep=(0, S * (1 + M)))
+    d.backbone = rec
+    x0hats, scores = [], []
+
+    class Rew:
+        def __call__(self, x):                                        # [B, 4, L] one-hot float
+            x0hats.append(x.argmax(1).to(torch.uint8))
+            assert bool((x.sum(1) == 1).all())
+            y = reward(x)
+            scores.append(y[:, 0].detach().squeeze().clone())
+            return y
+
+        def eval(self):
+            return self
+
+    torch.manual_seed(seed)
+    x0 = d.controlled_sample_tweedie(Rew(), eval_sp_size=B, sample_M=M, options="True", task="dna")
+    d.backbone = rec.inner
+    calls = rec.xs
+    assert len(calls) == S * (1 + M) + 1
+    xs = torch.stack([calls[s * (1 + M)] for s in range(S)] + [calls[-1]])
+    cand = torch.stack([torch.stack([calls[s * (1 + M) + 1 + m] for m in range(M)], 1) for s in range(S)])   # [S, B, M, L]
+    x0hat = torch.stack(x0hats).view(S, M, B, L).permute(0, 2, 1, 3).contiguous()
+    sc = torch.stack(scores).view(S, M, B).permute(0, 2, 1).contiguous()
+    idx = torch.softmax(sc, dim=2).argmax(dim=2).to(torch.uint8)
+    assert torch.equal(torch.gather(cand, 2, idx.long()[:, :, None, None].expand(S, B, 1, L))[:, :, 0], xs[1:])
+    arrs = {n_ + "_param_sums": np.array([float(p.double().sum()) for p in mod.state_dict().values()])
+            for n_, mod in (("backbone", d.backbone), ("embedding", emb_v), ("head", head_v), ("reward_embedding", emb_r),
+                            ("reward_head", head_r))}
+    kept = sorted(rec.logits)
+    save("g21_traj_pm_c3.npz", xs=xs, cand_delta=torch.stack([_delta(cand[s], xs[s]) for s in range(S)]),
+         x0hat_delta=torch.where(x0hat == cand, torch.full_like(x0hat, 255), x0hat), scores=sc, idx=idx, x0=x0.to(torch.uint8),
+         logits_calls=np.array(kept), logits=torch.stack([rec.logits[k] for k in kept]),
+         seed=seed, net_seed=44, B=B, L=L, M=M, S=S, threads=torch.get_num_threads(), sched=sched_rows(d, S), **arrs)
+
+
+def g21():
+    # full-size batches: all build cores (the small fixtures above are generated single-threaded; g21 records the thread count)
+    torch.set_num_threads(int(os.environ.get("SVDD_GOLDEN_THREADS", "8")))
+    g21_traj_mc_c2()
+    g21_traj_pm_c3()
+
+
+# ------------------------------------------------------------------ g22: the reference's own harness (round 4)
+def g22_harness(seed=17, L=50, S=16, B=3, G=2, M=3, alpha=0.5):
+    """`Enformer.BaseModel.controlled_decode` (Enformer.py:399-477), `controlled_decode_tweedie` (:719-813) and
+    `controlled_decode_TDS` (:479-557) THEMSELVES, with the tiny fixture nets (nets_tiny.npz's backbone / value net; a second
+    tiny ConvGRU as the reward oracle, weights stored here). `BaseModel.__init__` hard-wires checkpoint paths, Hydra and
+    `.cuda()` (:76-131), so the object is made with object.__new__ + the attributes the methods read; the gReLU checkpoint
+    loader (`LightningModel.load_from_checkpoint`, :429-432) returns the fixture reward net and its `.cuda()` is a no-op on
+    this CPU-only build. Records the 5-tuples: the RNG order (guided batches, then gen_batch_num * sample_M baseline batches),
+    the `samples` container shape (a list of batches for MC / TDS, a flat list of rows for tweedie: `samples.extend`, :766)
+    and `top_k_values` (a real top-k for MC / TDS, `cat(baseline_preds)` for tweedie, :802)."""
+    d = tiny_diffusion(L, S)
+    emb_m, head_m = tiny_value()
+    emb_r, head_r = tiny_value(seed=46)
+    reward = RewardWrap(emb_r, head_r).eval()
+    reward.cuda = lambda *a, **k: reward
+    En.LightningModel.load_from_checkpoint = staticmethod(lambda *a, **k: reward)
+    bm = object.__new__(En.BaseModel)
+    torch.nn.Module.__init__(bm)
+    bm.task, bm.n_tasks, bm.saluki_body = "dna", 1, 0
+    bm.embedding, bm.head, bm.ref_model, bm.reward_model = emb_m, head_m, d, reward
+    bm.NUM_SAMPLES_PER_BATCH = B
+    bm.eval()
+    arrs = {}
+    arrs.update(sd_np("reward_embedding", emb_r))
+    arrs.update(sd_np("reward_head", head_r))
+    for kind, call in (("mc", lambda: bm.controlled_decode(G, M)),
+                       ("pm", lambda: bm.controlled_decode_tweedie(G, M, "True")),
+                       ("pmh", lambda: bm.controlled_decode_tweedie(G, M, True)),
+                       ("tds", lambda: bm.controlled_decode_TDS(G, M, alpha))):
+        torch.manual_seed(seed)
+        np.random.seed(seed + 1)
+        samples, vf, rm, topk, base = call()
+        arrs[kind + "_samples_len"] = len(samples)
+        arrs[kind + "_samples_item_shape"] = np.array(samples[0].shape)
+        arrs[kind + "_samples"] = torch.stack([s_ for s_ in samples]).to(torch.uint8)
+        arrs[kind + "_value_func_preds"] = vf
+        arrs[kind + "_reward_model_preds"] = rm
+        arrs[kind + "_top_k"] = topk
+        arrs[kind + "_baseline_preds"] = base
+        for k_ in ("value_func_preds", "reward_model_preds", "top_k", "baseline_preds"):
+            arrs[kind + "_" + k_ + "_shape"] = np.array(arrs[kind + "_" + k_].shape)
+    save("g22_harness.npz", seed=seed, np_seed=seed + 1, L=L, S=S, B=B, G=G, M=M, alpha=alpha, **arrs)
+
+
 def g18():
     g13_traj_mc_full("g18_traj_mc_full_rna.npz", S=24, B=6, M=5, seed=5, L=50)
     g18_traj_pm_full_rna()
@@ -779,6 +932,13 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "g18":
         g18()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "g22":
+        g22_harness()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] in ("g21", "g21_c2", "g21_c3"):
+        torch.set_num_threads(int(os.environ.get("SVDD_GOLDEN_THREADS", "8")))
+        {"g21": g21, "g21_c2": g21_traj_mc_c2, "g21_c3": g21_traj_pm_c3}[sys.argv[1]]()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "g17":
         g17_enformer_trunk()

@@ -95,7 +95,7 @@ def test_tweedie_heuristic_branch_replays_reference_run(golden):
 
 def test_tweedie_heuristic_branch_real_tiny_nets_follow_the_reference(golden):
     """Same run with the reference's real (tiny) nets on the GPU, free-running in replay mode."""
-    from svdd_amd import e2e_parity
+    from tests import e2e_parity
     from svdd_amd.value_nets import RewardModel
     g = golden("g14_traj_pm_heuristic.npz")
     S, B, L, M = int(g["S"]), int(g["B"]), int(g["L"]), int(g["M"])
@@ -119,7 +119,8 @@ def test_dps_whole_step_replays_reference_run(golden):
     """The reference's controlled_sample_DPS run (g11) on the GPU, step by step: backbone -> SUBS -> q, autograd through
     forward2 and the reward net -> guidance -> guided q_xs within 1e-4 of the reference's; the draw with the reference's
     uniforms gives the reference's next state exactly; then the free-running decode (replay RNG) gives its x_0."""
-    from svdd_amd import e2e_parity, ops
+    from svdd_amd import ops
+    from tests import e2e_parity
     from svdd_amd.value_nets import RewardModel
     g = golden("g11_traj_dps.npz")
     S, B, L, scale = int(g["S"]), int(g["B"]), int(g["L"]), float(g["scale"])

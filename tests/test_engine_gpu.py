@@ -352,6 +352,40 @@ def test_fused_net_cache_follows_weight_changes():
         assert len(model._fused) <= n_before + 1
 
 
+def test_dps_gradient_follows_a_data_swap_of_the_conv_weights():
+    """the DPS gradient runs through re-packed COPIES of the dilated-conv weights
+    (CNNModel._conv_packs). A `.data.copy_` (the reference's EMA swap, models/ema.py:62,87) bumps neither the data pointer
+    nor the version: the packs must still follow it, or the guidance differentiates a stale network. Checked against the
+    plain autograd trunk (MIOpen convolutions) on the same weights, before and after the swap; the flag that routes
+    forward2 onto the hand-written kernels must not outlive the call."""
+    from svdd_amd import synthetic
+    model, _, _, reward = synthetic.build("dna", DEV)
+    x = torch.randint(0, 5, (4, 200), device=DEV)
+    sigma = torch.zeros(4, device=DEV)
+
+    def grad(fused):
+        model.fuse_nets = fused
+        oh = torch.nn.functional.one_hot(x, 5).float().requires_grad_(True)
+        with torch.enable_grad():
+            logp = model.forward2(oh, x, sigma)
+            (logp[..., :4].exp() * torch.arange(1.0, 5.0, device=DEV)).sum().backward()
+        model.fuse_nets = True
+        return oh.grad.clone()
+
+    assert model.backbone.hip_convs is False
+    g_hip, g_ref = grad(True), grad(False)
+    assert model.backbone.hip_convs is False                                   # scoped to the call
+    scale = float(g_ref.abs().max())
+    assert float((g_hip - g_ref).abs().max()) <= 3e-2 * scale                  # same function (ReLU decisions may differ, DESIGN 4)
+    w = model.backbone.convs[7].weight
+    v = w._version
+    w.data.copy_(w.data * -1.5)                                                # EMA-style swap: no version bump
+    assert w._version == v
+    g_hip2, g_ref2 = grad(True), grad(False)
+    assert float((g_ref2 - g_ref).abs().max()) > 0.15 * scale                  # the swap matters ...
+    assert float((g_hip2 - g_ref2).abs().max()) <= 3e-2 * float(g_ref2.abs().max())    # ... and the packs followed it
+
+
 def test_per_step_api_draws_fresh_uniforms_every_step():
     """Driving the per-step API in Philox mode (the reference's loop body, diffusion_gosai.py:1041-1047): the Philox
     counter follows t, so a position that stays MASK sees different noise at every step, and the per-step loop

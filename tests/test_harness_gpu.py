@@ -4,7 +4,9 @@ un-guided `_sample` / `_presample` paths (reference diffusion_gosai.py:820-886, 
 The 5-tuple (samples, value_func_preds, reward_model_preds, top_k_values, baseline_preds) is recomputed independently
 from the engine's primitives: batch k of a harness call is the sampler run with Philox seed base + k (guided batches
 first, then gen_batch_num * sample_M baseline batches); predictions are the plain modules on the batch's one-hot;
-baseline_preds are the first gen_batch_num baseline batches; top-k is the best len / sample_M of ALL baseline rewards."""
+baseline_preds are the first gen_batch_num baseline batches; top-k is the best len / sample_M of ALL baseline rewards.
+And against the REFERENCE's own harness methods (g22_harness.npz, recorded by tests/golden/make_golden.py g22): the same
+5-tuples in replay mode, including the tweedie variant's flat `samples` list and its baseline-as-top-k."""
 import numpy as np
 import pytest
 import torch
@@ -57,6 +59,9 @@ def test_controlled_decode_values(small, method):
             b = model.decode_sample(eval_sp_size=Bsz)
             all_base.append(reward(_onehot(b).transpose(1, 2))[:, 0].reshape(Bsz))
     model.philox_seed = 40
+    if method == "tweedie":            # the reference's tweedie harness `extend`s: a flat list of rows (Enformer.py:766; g22)
+        assert len(samples) == G * Bsz and samples[0].shape == (model.config.model.length,)
+        samples = [torch.stack(samples[k * Bsz:(k + 1) * Bsz]) for k in range(G)]
     assert len(samples) == G
     for a, b in zip(samples, exp_samples):
         assert a.dtype == torch.int64 and torch.equal(a, b)
@@ -64,11 +69,55 @@ def test_controlled_decode_values(small, method):
     assert torch.allclose(vpred.reshape(-1), torch.cat(exp_v), atol=1e-6)
     assert torch.allclose(rpred.reshape(-1), torch.cat(exp_r), atol=1e-6)
     assert torch.allclose(base.reshape(-1), torch.cat(all_base[:G]), atol=1e-6)          # slice i < gen_batch_num
+    if method == "tweedie":            # ... and returns cat(baseline_preds) in the top-k slot (Enformer.py:802; g22)
+        assert torch.equal(topk, base)
+        return
     allv = torch.cat(all_base)
     k = int(len(allv) / M)
     exp_topk = torch.sort(allv, descending=True).values[:k]
     assert topk.shape == (k,) and torch.allclose(topk, exp_topk, atol=1e-6)
     assert bool((topk[:-1] >= topk[1:]).all())                         # descending
+
+
+@pytest.mark.parametrize("kind", ["mc", "pm", "pmh", "tds"])
+def test_harness_5_tuple_equals_the_references_own_harness(golden, kind):
+    """g22: the reference's `BaseModel.controlled_decode` / `controlled_decode_tweedie` (options "True" and the default-like
+    bool True -> heuristic branch) / `controlled_decode_TDS` (Enformer.py:399-477, 719-813, 479-557) run by the reference
+    itself with the tiny fixture nets. This harness in replay mode must return the same 5-tuple: the same decoded samples in
+    the same container shape (token-exact: guided batches and all gen_batch_num * sample_M baseline batches consume the global
+    RNG stream in the reference's order), predictions / top-k / baseline within 1e-4."""
+    from svdd_amd.harness import BaseModel
+    from svdd_amd.value_nets import ConvGRUTrunk, ConvHead, RewardModel
+    from tests import e2e_parity
+    g = golden("g22_harness.npz")
+    L, S, B, G, M = (int(g[k]) for k in ("L", "S", "B", "G", "M"))
+    model, emb, head = e2e_parity.tiny_engine(golden("nets_tiny.npz"), L, S, DEV)
+    emb_r = ConvGRUTrunk(stem_in_channels=4, stem_channels=8, stem_kernel_size=15, n_conv=3, channel_init=8, kernel_size=5,
+                         dropout=0.1)
+    emb_r.load_state_dict(e2e_parity._sd(g, "reward_embedding"), strict=True)
+    head_r = ConvHead(1, 8)
+    head_r.load_state_dict(e2e_parity._sd(g, "reward_head"), strict=True)
+    reward = RewardModel(emb_r, head_r).to(DEV).eval()
+    model.rng_mode = "replay"
+    hm = BaseModel(emb, head, model, reward, batch_size=B, task="dna")
+    torch.manual_seed(int(g["seed"]))
+    np.random.seed(int(g["np_seed"]))
+    with torch.no_grad():
+        if kind == "mc":
+            out = hm.controlled_decode(gen_batch_num=G, sample_M=M)
+        elif kind == "tds":
+            out = hm.controlled_decode_TDS(gen_batch_num=G, sample_M=M, alpha=float(g["alpha"]))
+        else:
+            out = hm.controlled_decode_tweedie(gen_batch_num=G, sample_M=M, options="True" if kind == "pm" else True)
+    samples, vpred, rpred, topk, base = out
+    assert len(samples) == int(g[kind + "_samples_len"])
+    assert tuple(samples[0].shape) == tuple(g[kind + "_samples_item_shape"])
+    assert samples[0].dtype == torch.int64
+    assert np.array_equal(torch.stack(list(samples)).cpu().numpy(), g[kind + "_samples"])
+    for name, t in (("value_func_preds", vpred), ("reward_model_preds", rpred), ("top_k", topk), ("baseline_preds", base)):
+        ref = g[kind + "_" + name]
+        assert tuple(t.shape) == tuple(g[kind + "_" + name + "_shape"]), name
+        assert np.abs(t.cpu().numpy() - ref).max() <= 1e-4, name
 
 
 class _Replay(torch.nn.Module):

@@ -469,3 +469,41 @@ def test_propose_select_fuzz_vs_oracle(ops):
         x_next, soft, idx = ops.select(dev(scores), cand)
         assert np.array_equal(idx.cpu().numpy(), idx_ref) and np.array_equal(x_next.cpu().numpy(), x_ref), (case, B, L, M)
         assert np.abs(soft.cpu().numpy() - soft_ref).max() <= 1e-6
+
+
+# ------------------------------------------------------------------ the reference's primitive fixtures, straight into the kernels
+def test_g1_reference_sample_categorical_on_the_kernel(ops, golden):
+    """g1: `_sample_categorical(q)` as the reference computed it (diffusion_gosai.py:30-34: q incl. rows in the unmasked
+    pattern, its own `rand_like` uniforms) -> `svdd_sample_categorical` with the recorded uniforms. x is all-MASK so that no
+    position takes the copy branch (:1203 is the caller's, not this primitive's); both memory layouts. Tokens bit-exact."""
+    g = golden("g1_sample_categorical.npz")
+    q, u, tok = g["q"], g["u"], g["tokens"]
+    B, L = tok.shape
+    x = dev(np.full((B, L), 4, dtype=np.uint8))
+    cand, onehot = ops.sample_categorical(dev(q), x, 1, ops.Rng(uniforms=dev(u[None])))
+    assert np.array_equal(cand.cpu().numpy()[:, 0], tok)
+    assert np.array_equal(onehot.cpu().numpy().reshape(B, L, 4), orc.transform_samples(tok))
+    cand2, _ = ops.sample_categorical(bvl_view(q), x, 1, ops.Rng(uniforms=dev(np.ascontiguousarray(np.swapaxes(u, 1, 2))[None])))
+    assert np.array_equal(cand2.cpu().numpy()[:, 0], tok)
+
+
+def test_g2_reference_subs_parameterization_on_the_kernel(ops, golden):
+    """g2: `_subs_parameterization` outputs of the reference (:286-304, incl. exact ties) -> `svdd_subs_logp`: unmasked rows
+    are exact constants, masked rows within 1 ulp (correctly-rounded exp / log here, SLEEF u10 there — DESIGN section 2)."""
+    g = golden("g2_subs.npz")
+    x = g["xt"].astype(np.uint8)
+    for lg in (dev(g["logits"]), bvl_view(g["logits"])):
+        lp = ops.subs_logp(lg, dev(x)).cpu().numpy()
+        un = x != 4
+        assert np.array_equal(lp[un], g["logp"][un])
+        d = ulp_diff(lp, g["logp"])
+        assert d.max() <= 1 and (d == 0).mean() > 0.99
+
+
+def test_g4_reference_transform_samples_on_the_kernel(ops, golden):
+    """g4: `transform_samples` of the reference (:1462-1470; MASK rows all-zero) -> `svdd_transform_samples`, both outputs."""
+    g = golden("g4_transform.npz")
+    tok = dev(g["tokens"].astype(np.uint8))
+    assert np.array_equal(ops.transform_samples(tok).cpu().numpy(), g["onehot"].astype(np.float32))
+    assert np.array_equal(ops.transform_samples(tok, transposed=True).cpu().numpy(),
+                          g["onehot"].astype(np.float32).transpose(0, 2, 1))

@@ -1,4 +1,4 @@
-"""Prints the end-to-end GPU-vs-reference-trajectory report (svdd_amd/e2e_parity.py) as JSON for profiles/.
+"""Prints the end-to-end GPU-vs-reference-trajectory report (tests/e2e_parity.py) as JSON for profiles/.
 Usage: python tools/e2e_parity_report.py > profiles/rNN_e2e_parity.json"""
 import json
 import os
@@ -6,7 +6,8 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-from svdd_amd import e2e_parity, synthetic
+from svdd_amd import synthetic
+from tests import e2e_parity
 
 G = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 nets = dict(np.load(os.path.join(G, "nets_tiny.npz")))
