@@ -202,7 +202,7 @@ def trunk_gemm_roofline(model, emb, head, dev, n, L):
             "traffic_source": None}
 
 
-def config4_leg(dev, steps, B=256, L=200, M=20, S=128):
+def config4_leg(dev, steps, B=256, L=200, M=20, S=128, f32_steps=1):
     """BASELINE.json configs[3] at its per-GPU shard size (B = 256 of the 2048, M = 20, the Enformer-shaped 230 M-parameter
     value trunk) as an extra object of the default line: one warm-up decode + `steps` timed decodes in bf16x3 (split bf16
     operands, fp32-class error: the trunk has no fp32 hand-written path — `--value-net enformer` times the PyTorch fp32 module).
@@ -227,9 +227,40 @@ def config4_leg(dev, steps, B=256, L=200, M=20, S=128):
                "unit": "sequences/s", "n_gpus": 1, "steps": steps, "ms_per_step": round(el / steps * 1e3, 3), "dtype": "bf16x3",
                "arithmetic": "value trunk: fp32 operands split hi+lo in bf16, 3 MFMA passes, fp32 accumulate; backbone: the same split "
                              "(backbone_lp_t_kernel)", "data": "synthetic (random-init nets, all-MASK prior)"}
+        try:                                                   # the dominant kernel of THIS workload, measured in this run
+            res["roofline_trunk_gemm"] = trunk_gemm_roofline(model, emb, head, dev, int(0.75 * B * M), L)
+        except Exception as e:                                 # noqa: BLE001
+            res["roofline_trunk_gemm"] = {"error": f"{type(e).__name__}: {e}"}
+        if f32_steps > 0:
+            res["f32"] = config4_f32(model, emb, head, dev, f32_steps, B, L, M, S)
         del model, emb, head
         torch.cuda.empty_cache()
         return res
+    except Exception as e:                                     # noqa: BLE001
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
+def config4_f32(model, emb, head, dev, steps, B, L, M, S):
+    """configs[3]'s shard at the REFERENCE's precision (fp32 value trunk): `steps` timed decodes after one warm-up. Which
+    implementation ran is stated: the hand-written fp32 trunk kernels when Diffusion routes precision="f32" to them, else the
+    PyTorch-ROCm modules (MIOpen / hipBLASLt)."""
+    try:
+        from svdd_amd.fused_trunk import FusedEnformerValueNet
+        model.precision = "f32"
+        fn = model.value_callable(emb, head)
+        impl = ("hand-written fp32 trunk kernels (svdd_trunk.hip, v_mfma_f32_32x32x2_f32)" if isinstance(fn, FusedEnformerValueNet)
+                else "PyTorch-ROCm modules (MIOpen / hipBLASLt), one [B*M] forward per step")
+        run = lambda: model.controlled_sample(emb, head, num_steps=S, eval_sp_size=B, sample_M=M)   # noqa: E731
+        run()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = run()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        assert out.shape == (B, L) and int(out.max()) <= 3
+        return {"value": round(B * steps / el, 3), "unit": "sequences/s", "steps": steps, "ms_per_step": round(el / steps * 1e3, 3),
+                "dtype": "f32", "value_trunk": impl}
     except Exception as e:                                     # noqa: BLE001
         return {"error": f"{type(e).__name__}: {e}"}
 
@@ -287,6 +318,99 @@ def cpu_baseline(B, L, M, S, sample_steps, seed=44, threads=16, states=None, pas
                   f"at full batch (B={B}, L={L}, M={M}) + the noise-removal forward, scaled by {S}/{sample_steps} to one decode; "
                   f"{work_s:.1f} s of CPU work in all",
     }
+
+
+def value_net_roofline(model, emb, head, dev, B, L, M, S, tower_ms, tower_launches, gru_ms, gru_launches):
+    """The #2 / #3 kernels of the headline decode (conv_tower2_kernel, gru_pc_kernel: the value net's conv tower and its
+    bidirectional GRU, ~29 % of the decode) against the fp32-MFMA peak, two ways:
+      decode  EXECUTED FLOPs of one decode / the kernels' summed HIP-event time in the profiled timed decode. The work-skipping
+              decode runs the tower only on the candidates' row windows and the GRU only on the live candidates; both counts are
+              summed on the device (Diffusion.skip_stats: tower_window_rows, live_candidates) in one extra, untimed decode of the
+              same Philox stream (= the same work as the timed one).
+      dense   the same kernels on B*M whole sequences (n = 2560 at config 2: every row tile live, 320 GRU units on 256 CUs) —
+              the figures DESIGN.md section 4 quotes."""
+    from svdd_amd import _lib, ops
+    from svdd_amd.fused import FusedValueNet
+    fn = model.value_callable(emb, head)
+    if not (isinstance(fn, FusedValueNet) and fn.kernels_ok(L)):
+        return None
+    C = 64
+    tower_row = 2.0 * (4 * C * 15 + 5 * C * C * 5)             # stem 4->64 x 15 taps + five 64->64 x 5-tap blocks, per sequence row
+    gru_row = 2.0 * 2 * 3 * (C * C + C * C)                    # 2 directions x 3 gates x (W_ih + W_hh), per row
+    model.skip_stats = {}
+    model.controlled_sample(emb, head, num_steps=S, eval_sp_size=B, sample_M=M)
+    torch.cuda.synchronize()
+    st, model.skip_stats = model.skip_stats, None
+    out = {}
+    rows_t = (st.get("tower_window_rows") or 0) + B * L        # + the one whole-sequence pass on the all-MASK parents
+    rows_g = (st["live_candidates"] + B) * L                   # + the parents' pass
+    for key, kern, flops, ms, n in (("conv_tower", "conv_tower2_kernel (value net: stem + 5 residual conv blocks; candidates' row windows)",
+                                     tower_row * rows_t, tower_ms, tower_launches),
+                                    ("gru", "gru_pc_kernel (value net: bidirectional GRU 64 -> 64; live candidates only)",
+                                     gru_row * rows_g, gru_ms, gru_launches)):
+        tf = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        out[key] = {"bound": "mfma", "kernel": kern, "decode": {
+            "achieved": round(tf, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / FP32_PEAK_TFLOPS, 5),
+            "executed_flops_per_decode": round(flops), "kernel_ms_per_decode": round(ms, 3), "launches": n}}
+    out["executed"] = {"tower_rows": int(rows_t), "gru_rows": int(rows_g), "nominal_rows": B * M * L * S,
+                       "live_candidates": st["live_candidates"], "candidates": st["candidates"],
+                       "flops_per_tower_row": tower_row, "flops_per_gru_row": gru_row}
+    # dense: whole sequences
+    n = B * M
+    tok = torch.randint(0, 5, (n, L), device=dev, dtype=torch.uint8)
+    for _ in range(3):
+        fn.forward_tokens(tok)
+    torch.cuda.synchronize()
+    for k in (3, 5):
+        _lib.profile_collect(k)
+    _lib.profile_enable(True)
+    for _ in range(10):
+        fn.forward_tokens(tok)
+    torch.cuda.synchronize()
+    _lib.profile_enable(False)
+    for key, slot, per_row in (("conv_tower", 5, tower_row), ("gru", 3, gru_row)):
+        tot, k = _lib.profile_collect(slot)
+        ms = tot / max(k, 1)
+        tf = per_row * n * L / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        out[key]["dense"] = {"achieved": round(tf, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": round(tf / FP32_PEAK_TFLOPS, 5), "flops_per_launch": round(per_row * n * L),
+                             "avg_launch_us": round(ms * 1e3, 2), "launches": k, "workload": f"{n} whole sequences of length {L}"}
+    return out
+
+
+def cpu_baseline_c1(passes=3, threads=8):
+    """BASELINE.md section 2's stated CPU baseline: the WHOLE decode of BASELINE.json configs[0] (B = 4, L = 200, M = 2, 128
+    steps + noise removal) by the oracle port (CPU restatement of the reference path, PyTorch CPU modules for the nets), median
+    of `passes`; cores stated. (The C2 sample in `cpu_baseline` is the same code at the headline batch.)"""
+    from oracle import svdd_oracle as orc
+    from svdd_amd import synthetic
+    B, L, M, S = 4, 200, 2, 128
+    threads = max(1, min(threads, os.cpu_count() or 1))
+    torch.set_num_threads(threads)
+    model, emb, head, _ = synthetic.build("dna", "cpu")
+    sched = model._schedule(S, 1e-5)[0]
+    bb = lambda x: model.backbone(x, torch.zeros(x.shape[0]))                               # noqa: E731
+    val = lambda oh: head(emb(oh)).reshape(-1)                                              # noqa: E731
+    times = []
+    for p in range(passes):
+        x = np.full((B, L), orc.MASK, np.uint8)
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            for i in range(S):
+                logits = bb(torch.from_numpy(x.astype(np.int64))).contiguous().numpy()
+                cand, onehot, _ = orc.propose(logits, x, sched[i, 2], sched[i, 1], M, seed=p, step=i, want_q=False)
+                oh = onehot.reshape(B, M, L, 4)
+                sc = np.stack([val(torch.from_numpy(np.ascontiguousarray(oh[:, m]))).numpy() for m in range(M)], 1)
+                x = orc.select(sc, cand)[0]
+            logits = bb(torch.from_numpy(x.astype(np.int64))).contiguous().numpy()
+            x0 = orc.finalize(logits, x)
+        times.append(time.perf_counter() - t0)
+        assert x0.shape == (B, L) and int(x0.max()) <= 3
+    cpu_model, cpu_total = host_cpu()
+    med = float(np.median(times))
+    return {"value": round(B / med, 4), "unit": "sequences/s", "cores": threads, "cpu_model": cpu_model, "cores_total": cpu_total,
+            "kind": "port", "passes": passes, "s_per_decode_each_pass": [round(t, 3) for t in times],
+            "sample": f"whole decodes of BASELINE.json configs[0] (B={B}, L={L}, M={M}, {S} steps + noise removal), median of {passes}"}
 
 
 def _gpu_count_without_hip():
@@ -405,6 +529,7 @@ def main():
     ap.add_argument("--value-net", default="convgru", choices=["convgru", "enformer"],
                     help="enformer: the 230M-parameter Enformer-shaped value trunk of BASELINE config 4 (not the headline config)")
     ap.add_argument("--c4-steps", type=int, default=1, help="decodes timed for the config4_enformer object of the default line (0 = skip)")
+    ap.add_argument("--c4-f32-steps", type=int, default=1, help="decodes of the config-4 shard timed at fp32 (the reference's precision) inside config4_enformer (0 = skip)")
     ap.add_argument("--cpu-passes", type=int, default=3, help="cpu_baseline passes; the median is reported (BASELINE.md section 2)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch / rendezvous / all-gather skeleton with a stand-in decode on the host (no GPU, gloo)")
@@ -618,12 +743,14 @@ def main():
             line["roofline_select_saturated"] = [select_saturated(dev, L=L, M=M), select_saturated(dev, L=L, M=M, near_uniform=True),
                                                  select_saturated(dev, L=L, M=20)]
             line["roofline_tds_resample"] = tds_saturated(dev, L=L)
+            line["roofline_value_net"] = value_net_roofline(model, emb, head, dev, B, L, M, S, tower_total_ms, tower_launches,
+                                                            gru_total_ms, gru_launches)
         if args.value_net != "convgru":
             line["config"]["workload"] += " [value net: Enformer-shaped trunk, 230M params — BASELINE configs[3] shape]"
             line["e2e_fp32_frac"] = None
             line["roofline_trunk_gemm"] = trunk_gemm_roofline(model, emb, head, dev, int(0.75 * B * M), L)
         if args.c4_steps > 0 and world == 1 and args.value_net == "convgru" and (B, L, M) == (256, 200, 10):
-            line["config4_enformer"] = config4_leg(dev, args.c4_steps)
+            line["config4_enformer"] = config4_leg(dev, args.c4_steps, f32_steps=args.c4_f32_steps)
         if args.cpu_steps > 0 and world == 1 and args.value_net == "convgru":
             model.state_trace = []                                  # one extra (untimed) decode: the trajectory's states
             model.controlled_sample(emb, head, num_steps=S, eval_sp_size=B, sample_M=M)
@@ -631,6 +758,7 @@ def main():
             states = [x.cpu().numpy() for x in model.state_trace]
             model.state_trace = None
             line["cpu_baseline"] = cpu_baseline(B, L, M, S, args.cpu_steps, states=states, passes=args.cpu_passes)
+            line["cpu_baseline_c1"] = cpu_baseline_c1(passes=args.cpu_passes)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line))

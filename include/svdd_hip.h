@@ -189,6 +189,18 @@ int svdd_tds_resample(const float* reward_num, const float* reward_den, double a
                       const uint8_t* sample, const double* u, int B, int L,
                       uint8_t* x_next, int32_t* idx, double* work, void* stream);
 
+/*
+ * svdd_mt19937_uniform_f32 — torch's CPU generator stream on the device (parity-mode RNG without host traffic)
+ *   replaces torch.rand / rand_like on the global CPU generator: diffusion_gosai.py:33 (`torch.rand_like(categorical_probs)`),
+ *   i.e. at::mt19937 (std::mt19937) + uniform_real_distribution<float>: out[i] = (y_i & 0xFFFFFF) * 2^-24, y_i the i-th
+ *   tempered 32-bit output, strictly in sequence.
+ *  state [625] u32 in device memory: the 624 state words + the index of the next output (624 = twist first, as
+ *  torch.manual_seed leaves it); advanced in place by n outputs (any rotation of the word window is a valid state: the
+ *  recurrence is shift-invariant; svdd_amd/ops.py converts from / to torch.get_rng_state()'s layout).
+ *  out [n] fp32. One workgroup (the recurrence is serial): ~0.3 ns per output; launch it on a side stream a step ahead.
+ */
+int svdd_mt19937_uniform_f32(uint32_t* state, float* out, long long n, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Net kernels — internals of the value network (reference Enformer.py), not of the sampler. They are
  * optional accelerations of PyTorch modules (svdd_amd/fused.py); the sampler API above never needs them.
@@ -386,7 +398,9 @@ enum { SVDD_OPT_FORCE_EXACT = 0,
                                             transposed-accumulator kernel where one sequence fills a tile (104 < L <= 208) */,
        SVDD_OPT_TRUNK_GEMM_VERSION = 4 /* A/B: svdd_trunk_gemm kernel: 1 = 128 x 128 tiles everywhere, 2 (default) = 256 x 256 LDS-DMA
                                            tiles from 128 tiles up, 3 = 256 x 256 everywhere (13 .. 16: timing experiments with
-                                           wrong results: no epilogue / one K block / no DMA / no fragment reads) */ };
+                                           wrong results: no epilogue / one K block / no DMA / no fragment reads) */,
+       SVDD_OPT_CAND_ROW_STRIDE = 5 /* layout experiment (round 4): bytes between two candidate rows of `cand` as svdd_select /
+                                        svdd_select_compact read it (0 = L, the default): rows padded to whole 128-byte lines */ };
 int svdd_set_option(int key, int value);
 
 /* Soak / profiling aid: while `device_counters2` (two zero-initialised uint64 on the device) is non-NULL, every
@@ -413,7 +427,7 @@ int svdd_device_info(char* arch, int arch_len, int* num_cu);
 
 /* ABI version of this header: bumped on any signature change. */
 int svdd_abi_version(void);
-#define SVDD_ABI_VERSION 7
+#define SVDD_ABI_VERSION 8
 
 /*
  * Enformer-shaped value trunk (BASELINE.json configs[3]; reference decode.py:78-80, Enformer.py:1271-1334 trunk, :1807-1884

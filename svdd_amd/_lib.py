@@ -13,7 +13,7 @@ CSRC = os.path.join(_HERE, "csrc")
 # SVDD_HIP_LIB: load another build of the library instead (the timing-experiment scripts under tools/ build patched
 # copies of the kernels in a scratch directory; the tracked sources are never edited in place)
 SO_PATH = os.environ.get("SVDD_HIP_LIB") or os.path.join(CSRC, "libsvdd_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 OK, E_ARG, E_LAUNCH, E_NODEVICE = 0, -1, -2, -3
 LAYOUT_BLV, LAYOUT_BVL = 0, 1
@@ -33,7 +33,7 @@ EXPORTS = (
     "svdd_compact_flags", "svdd_gather_rows", "svdd_advance_rows", "svdd_select_compact", "svdd_set_tower_version", "svdd_set_backbone_packing",
     "svdd_trunk_gemm", "svdd_trunk_act_split", "svdd_trunk_layernorm_split", "svdd_trunk_attn_pool", "svdd_trunk_stem_unfold", "svdd_trunk_attn_small",
     "svdd_trunk_windows", "svdd_trunk_stem_unfold_win", "svdd_trunk_attn_pool_win",
-    "svdd_bb_layer_fwd_f32", "svdd_bb_layer_bwd_f32",
+    "svdd_bb_layer_fwd_f32", "svdd_bb_layer_bwd_f32", "svdd_mt19937_uniform_f32",
 )
 OPT_FORCE_EXACT = 0
 
@@ -91,6 +91,7 @@ def lib():
     L.svdd_subs_logp.argtypes = [vp, vp, i32, i32, i32, vp, vp]
     L.svdd_tds_resample.argtypes = [vp, vp, ctypes.c_double, vp, vp, i32, i32, vp, vp, vp, vp]
     L.svdd_set_option.argtypes = [i32, i32]
+    L.svdd_mt19937_uniform_f32.argtypes = [vp, vp, ctypes.c_longlong, vp]
     L.svdd_selftest_fastmath.argtypes = [ctypes.POINTER(ctypes.c_double)]
     L.svdd_gru_bidir_f32.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp]
     L.svdd_gru_bidir_train_f32.argtypes = [vp, vp, vp, vp, vp, i32, i32, vp]

@@ -394,6 +394,7 @@ struct SelectArgs {
   // exact work-skipping (svdd_select_compact): scores holds only the LIVE candidates, slot[b*M + m] is a candidate's
   // position in it or -1 for a candidate that is a copy of its parent (its score is the parent's)
   const int32_t* slot; const float* parent_score; float* sel_score; int32_t* changed;
+  int ld;   // bytes between two candidate rows of `cand` (L, or more: SVDD_OPT_CAND_ROW_STRIDE — rows padded to whole cache lines)
 };
 
 __device__ __forceinline__ float wave_max(float v) {
@@ -513,7 +514,7 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
   }
 
   // gather the winning candidate row (index-gather compaction, diffusion_gosai.py:1226-1227)
-  const uint8_t* src = a.cand + ((int64_t)row * a.M + best) * a.L;
+  const uint8_t* src = a.cand + ((int64_t)row * a.M + best) * a.ld;
   uint8_t* dst = a.x_next + (int64_t)row * a.L;
   if ((a.L & 3) == 0 && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 3) == 0) {
     const uint32_t* s4 = reinterpret_cast<const uint32_t*>(src);
@@ -624,7 +625,8 @@ __global__ __launch_bounds__(256) void select_rows_kernel(SelectArgs a) {
   }
   // index-gather compaction (diffusion_gosai.py:1226-1227): the G winning rows, in units of ub bytes spread over the wave
   const uintptr_t both = reinterpret_cast<uintptr_t>(a.cand) | reinterpret_cast<uintptr_t>(a.x_next);
-  const int ub = ((a.L | both) & 7) == 0 ? 8 : ((a.L | both) & 3) == 0 ? 4 : ((a.L | both) & 1) == 0 ? 2 : 1;
+  const uintptr_t al = (uintptr_t)(a.L | a.ld) | both;
+  const int ub = (al & 7) == 0 ? 8 : (al & 3) == 0 ? 4 : (al & 1) == 0 ? 2 : 1;
   const int U = a.L / ub, total = G * U;
   const float inv_u = 1.0f / (float)U;
   for (int i0 = 0; i0 < total; i0 += WAVE) {
@@ -635,7 +637,7 @@ __global__ __launch_bounds__(256) void select_rows_kernel(SelectArgs a) {
     const int64_t rq = row0 + gq;
     if (i < total && rq < a.B) {
       const int c = i - gq * U;
-      const uint8_t* src = a.cand + (rq * a.M + bq) * a.L + (int64_t)c * ub;
+      const uint8_t* src = a.cand + (rq * a.M + bq) * a.ld + (int64_t)c * ub;
       uint8_t* dst = a.x_next + rq * a.L + (int64_t)c * ub;
       if (ub == 8) *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<const uint2*>(src);
       else if (ub == 4) *reinterpret_cast<uint32_t*>(dst) = *reinterpret_cast<const uint32_t*>(src);
@@ -947,11 +949,80 @@ __global__ __launch_bounds__(256) void advance_rows_kernel(const uint8_t* __rest
   }
 }
 
+
+// ======================================================================== K8 mt19937 ====
+// torch's CPU generator stream ON THE DEVICE (parity-mode RNG at speed). The reference draws its categorical uniforms with
+// rand_like(q_xs) (diffusion_gosai.py:33) from torch's global CPU generator: at::mt19937 (= std::mt19937) + ATen's
+// uniform_real_distribution<float>, u = (y & 0xFFFFFF) * 2^-24, one 32-bit output per float, sequentially. Round 3 replayed it
+// on the host (torch.rand + a 10 MB upload per diffusion step). Here the 624-word state crosses once per decode and the stream
+// is produced by ONE workgroup (the recurrence is serial):
+//   as an infinite sequence x[n + 624] = x[n + 397] ^ tw(x[n], x[n + 1]), the saved state being x[0 .. 623] and the outputs
+//   temper(x[pos + i]). x[n + 624] depends on nothing younger than x[n + 397], so 227 consecutive elements are independent:
+//   one GENERATION = 227 lanes. Lane j's x[n + 397] is its own result of the generation before (a register); x[n], x[n + 1]
+//   were written 2 to 3 generations earlier by other lanes (LDS ring), so ONE barrier per TWO generations orders everything;
+//   each lane tempers, converts and stores its own element (coalesced 4-byte stores).
+// state [625] u32 = 624 words + pos (next output index, 624 = "twist first", what torch.manual_seed leaves). On return the state
+// is the last 624 words of the sequence and the matching pos (any window of the sequence is a valid state: the recurrence is
+// shift-invariant), i.e. what the host generator would hold after drawing n floats, up to that rotation.
+constexpr int MT_N = 624, MT_M = 397, MT_GEN = MT_N - MT_M /* 227 */, MT_RING = 2048;
+
+__device__ __forceinline__ uint32_t mt_tw(uint32_t a, uint32_t b) {
+  const uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
+  return (y >> 1) ^ ((b & 1u) ? 0x9908b0dfu : 0u);
+}
+__device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
+  y ^= (y >> 11);
+  y ^= (y << 7) & 0x9d2c5680u;
+  y ^= (y << 15) & 0xefc60000u;
+  y ^= (y >> 18);
+  return y;
+}
+__device__ __forceinline__ float mt_float(uint32_t x) { return (float)(mt_temper(x) & 0xFFFFFFu) * (1.0f / 16777216.0f); }
+
+__global__ __launch_bounds__(256) void mt19937_kernel(uint32_t* __restrict__ state, float* __restrict__ out, long long n) {
+  __shared__ uint32_t ring[MT_RING];
+  const int j = threadIdx.x;
+  const long long pos = (long long)state[MT_N];
+  const long long total = pos + n;                        // one past the last element consumed
+  for (int k = j; k < MT_N; k += 256) {
+    const uint32_t v = state[k];
+    ring[k] = v;
+    if (k >= pos && k < total) out[k - pos] = mt_float(v);  // what is left of the current block
+  }
+  __syncthreads();
+  // generations come in pairs; G = generations needed so that 624 + 227 G >= total
+  long long G = total > MT_N ? (total - MT_N + MT_GEN - 1) / MT_GEN : 0;
+  G += (G & 1);
+  const bool lane = j < MT_GEN;
+  uint32_t prev = lane ? ring[MT_M + j] : 0u;             // x[397 + j]: "generation -1" of this lane
+  long long base = 0;                                     // generation g reads x[base + j], x[base + j + 1], base = 227 g
+  for (long long g = 0; g < G; g += 2, base += 2 * MT_GEN) {
+    if (lane) {
+      const int r0 = (int)((base + j) & (MT_RING - 1)), r1 = (int)((base + MT_GEN + j) & (MT_RING - 1));
+      const uint32_t a0 = ring[r0], b0 = ring[(r0 + 1) & (MT_RING - 1)];
+      const uint32_t a1 = ring[r1], b1 = ring[(r1 + 1) & (MT_RING - 1)];
+      const uint32_t x0 = prev ^ mt_tw(a0, b0);           // x[base + 624 + j]
+      const uint32_t x1 = x0 ^ mt_tw(a1, b1);             // x[base + 227 + 624 + j]   (its x[n + 397] is x0)
+      prev = x1;
+      const long long m0 = base + MT_N + j, m1 = m0 + MT_GEN;
+      ring[(int)(m0 & (MT_RING - 1))] = x0;
+      ring[(int)(m1 & (MT_RING - 1))] = x1;
+      if (m0 >= pos && m0 < total) out[m0 - pos] = mt_float(x0);
+      if (m1 >= pos && m1 < total) out[m1 - pos] = mt_float(x1);
+    }
+    __syncthreads();
+  }
+  // new state: the window x[E .. E + 623], E = 227 G ; pos' = total - E (0 <= pos' <= 624)
+  const long long E = G * MT_GEN;
+  for (int k = j; k < MT_N; k += 256) state[k] = ring[(int)((E + k) & (MT_RING - 1))];
+  if (j == 0) state[MT_N] = (uint32_t)(total - E);
+}
+
 // Optional per-launch timing (bench.py's roofline leg): when enabled, K1/K2 are launched with
 // hipExtLaunchKernelGGL start/stop events, i.e. HIP events bound to the dispatch itself on the launch
 // stream; svdd_profile_collect() sums hipEventElapsedTime over the recorded launches.
 struct TimedLaunch { hipEvent_t start, stop; };
-constexpr int PROFILE_KERNELS = 9;            // 0 propose (K1), 1 select (K2), 2 conv1d, 3 gru, 4 epilogue_ln, 5 conv_tower, 6 backbone_cnn, 7 value_tail, 8 tds_resample (K4, both phases)
+constexpr int PROFILE_KERNELS = 10;           // 0 propose (K1), 1 select (K2), 2 conv1d, 3 gru, 4 epilogue_ln, 5 conv_tower, 6 backbone_cnn, 7 value_tail, 8 tds_resample (K4, both phases), 9 mt19937 (K8)
 bool g_profile = false;
 TimedLaunch* g_timed[PROFILE_KERNELS] = {};
 int g_timed_n[PROFILE_KERNELS] = {}, g_timed_cap[PROFILE_KERNELS] = {};
@@ -973,6 +1044,7 @@ TimedLaunch* timed_slot(int k) {
 
 int g_msplit = 0;        // svdd_set_option(SVDD_OPT_MSPLIT, k): override K1's candidate split (0 = auto)
 int g_force_exact = 0;   // svdd_set_option(SVDD_OPT_FORCE_EXACT, 1): K1 takes the exact path for every draw
+int g_cand_ld = 0;        // svdd_set_option(SVDD_OPT_CAND_ROW_STRIDE, bytes): row stride of `cand` in svdd_select* (0 = L)
 int g_select_one_row_per_wave = 0;   // svdd_set_option(SVDD_OPT_SELECT_ONE_ROW, 1): K2 as one wave per row for every M (A/B)
 unsigned long long* g_k1_stats = nullptr;   // svdd_k1_stats: device counters K1 adds to
 
@@ -993,6 +1065,7 @@ int svdd_set_option(int key, int value) {
   if (key == SVDD_OPT_FORCE_EXACT) { g_force_exact = value ? 1 : 0; return SVDD_OK; }
   if (key == SVDD_OPT_MSPLIT && value >= 0 && value <= 64) { g_msplit = value; return SVDD_OK; }
   if (key == SVDD_OPT_SELECT_ONE_ROW) { g_select_one_row_per_wave = value ? 1 : 0; return SVDD_OK; }
+  if (key == SVDD_OPT_CAND_ROW_STRIDE && value >= 0) { g_cand_ld = value; return SVDD_OK; }
   if (key == SVDD_OPT_BACKBONE_LP_VERSION) { svdd_internal_set_bb_lp_version(value); return SVDD_OK; }
   if (key == SVDD_OPT_TRUNK_GEMM_VERSION) { svdd_internal_set_trunk_gemm_version(value); return SVDD_OK; }
   return SVDD_E_ARG;
@@ -1136,7 +1209,8 @@ int svdd_select_compact(const float* scores, const int32_t* slot, const float* p
   if (mode == SVDD_SELECT_MULTINOMIAL && (!rng || rng->kind != SVDD_RNG_PHILOX)) return SVDD_E_ARG;
   if (slot && !parent_score) return SVDD_E_ARG;
   SelectArgs a{scores, cand, B, L, M, mode, rng ? rng->step : 0u, rng ? rng->seed : 0ull,
-               rng ? rng->row_offset : 0ull, x_next, soft, idx, slot, parent_score, sel_score, changed};
+               rng ? rng->row_offset : 0ull, x_next, soft, idx, slot, parent_score, sel_score, changed,
+               g_cand_ld >= L ? g_cand_ld : L};
   TimedLaunch* t = timed_slot(1);
   hipEvent_t e0 = t ? t->start : nullptr, e1 = t ? t->stop : nullptr;
   if (M <= WAVE && !g_select_one_row_per_wave) {
@@ -1218,6 +1292,15 @@ int svdd_tds_resample(const float* reward_num, const float* reward_den, double a
   if (check_launch() != SVDD_OK) return SVDD_E_LAUNCH;
   hipExtLaunchKernelGGL(tds_gather_kernel, dim3((unsigned)(((int64_t)B + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                         nullptr, t ? t->stop : nullptr, 0, a);
+  return check_launch();
+}
+
+int svdd_mt19937_uniform_f32(uint32_t* state, float* out, long long n, void* stream) {
+  if (!state || !out || n < 0) return SVDD_E_ARG;
+  if (n == 0) return SVDD_OK;
+  TimedLaunch* t = timed_slot(9);
+  hipExtLaunchKernelGGL(mt19937_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, t ? t->start : nullptr, t ? t->stop : nullptr, 0,
+                        state, out, n);
   return check_launch();
 }
 

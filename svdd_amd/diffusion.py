@@ -16,7 +16,10 @@ There is no CPU fallback: the sampler methods need a gfx950 GPU and raise otherw
 Engine knobs (attributes; defaults reproduce the reference's observable behaviour):
   rng_mode         "replay": the categorical uniforms are drawn from torch's global CPU mt19937
                    generator in exactly the order the reference's CPU path consumes them
-                   (M x rand_like(q_xs), in q_xs' memory order) and uploaded — token-exact parity.
+                   (M x rand_like(q_xs), in q_xs' memory order) — token-exact parity. replay_rng = "device" (default):
+                   the generator's 624-word state is uploaded once per sampler call, the stream is produced on the GPU by
+                   svdd_mt19937_uniform_f32 a step ahead on a side stream, and the advanced state is written back into
+                   torch's generator when the call returns; "host": torch.rand on the host + a 10 MB upload per step.
                    "philox": generated in-kernel from (seed, step, global row, m, l) — no host
                    traffic, identical results for any sharding of the batch over GPUs.
   value_batching   "batched": one value-net forward over all B*M candidates (default);
@@ -116,6 +119,9 @@ def _decode_scope(fn):
             return fn(self, *a, **k)
         finally:
             self._scope_depth -= 1
+            if self._scope_depth == 0 and self._replay_stream is not None:
+                st, self._replay_stream = self._replay_stream, None
+                st.close()                 # the advanced mt19937 state goes back into torch's global CPU generator
     return wrapped
 
 
@@ -166,6 +172,8 @@ class Diffusion(nn.Module):
         self._sched_cache = {}
         self._fused = {}
         self._scope_depth, self._scope_id = 0, 0
+        self.replay_rng = "device"       # rng_mode "replay": "device" = torch's CPU mt19937 stream continued by K8 on the GPU for
+        self._replay_stream = None       # the span of a sampler call; "host" = torch.rand on the host + upload (round 1-3)
 
     # ------------------------------------------------------------------ plumbing ----
     @property
@@ -330,7 +338,14 @@ class Diffusion(nn.Module):
         if self.rng_mode == "replay":
             ul = self._replay_layout(logits)
             shape = (M, B, L, 5) if ul == ops.LAYOUT_BLV else (M, B, 5, L)
-            u = torch.rand(shape).to(logits.device, non_blocking=True)   # torch's global CPU generator
+            if self.replay_rng == "device" and self._scope_depth > 0 and logits.is_cuda and not _capturing():
+                # the same stream, generated on the device (svdd_mt19937_uniform_f32): the generator's state is uploaded at the
+                # first draw of a sampler call and written back into torch's global generator when the call returns
+                if self._replay_stream is None:
+                    self._replay_stream = ops.DeviceReplayStream(logits.device)
+                u = self._replay_stream.uniforms(M * B * L * 5).view(shape)
+            else:
+                u = torch.rand(shape).to(logits.device, non_blocking=True)   # torch's global CPU generator
             return ops.Rng(uniforms=u, uniforms_layout=ul)
         if self.rng_mode == "philox":
             return ops.Rng(seed=self.philox_seed, row_offset=self.row_offset, step=step)
@@ -756,6 +771,7 @@ class Diffusion(nn.Module):
             self.M = M
             self.n_live = torch.zeros(1, dtype=torch.int64, device=dev)
             self.n_changed = torch.zeros(1, dtype=torch.int64, device=dev)
+            self.n_win_rows = None          # with skip_stats: rows the value net's tower computed (the candidates' row windows)
 
     def _select_compact(self, sc, ws, cand, step):
         mode = {"argmax": ops.SELECT_ARGMAX, "multinomial": ops.SELECT_MULTINOMIAL}[self.select_mode]
@@ -782,7 +798,8 @@ class Diffusion(nn.Module):
     def _finish_stats(self, ws, B, M, S, kind):
         if self.skip_stats is not None:
             self.skip_stats.update(kind=kind, steps=S, candidates=B * M * S, live_candidates=int(ws.n_live),
-                                   row_steps=B * S, changed_row_steps=int(ws.n_changed))
+                                   row_steps=B * S, changed_row_steps=int(ws.n_changed),
+                                   tower_window_rows=None if ws.n_win_rows is None else int(ws.n_win_rows))
 
     def _use_logits_cache(self, L):
         """Per-row logits cache of the SVDD-MC skipping loop. "auto": where several sequences share a backbone tile
@@ -795,6 +812,8 @@ class Diffusion(nn.Module):
         live candidates' token rows are gathered into a compact batch and scored whole (forward_tokens)."""
         from .fused import candidate_windows
         ws = self._SkipWorkspace(B, M, self.device)
+        if self.skip_stats is not None:
+            ws.n_win_rows = torch.zeros(1, dtype=torch.int64, device=self.device)
         ws.parent_score.copy_(fn.forward_tokens(x).reshape(B))               # scores of the all-MASK parents
         fb = self._fused_backbone_or_none(L) if self._use_logits_cache(L) else None
         share = hasattr(fn, "candidates_ok") and fn.candidates_ok(L, M)

@@ -661,6 +661,8 @@ class FusedValueNet(nn.Module):
         B, M, L = cand.shape
         win = candidate_windows(cand, x, flags=ws.flags)
         ops.compact_flags(ws.flags, ws.live_idx, ws.slot, ws.count)
+        if getattr(ws, "n_win_rows", None) is not None:                     # Diffusion.skip_stats: rows the tower computes this step
+            ws.n_win_rows += (win[:, 1] - win[:, 0]).sum()
         # The parents' tower output is carried from step to step: the next parent IS the selected candidate, whose tower
         # output this step computes (bit-identical to a full tower pass on it) — ws.advance_parent copies it over after
         # the select. Only the first step runs the tower on the parents.

@@ -235,3 +235,114 @@ def tds_resample(reward_num, reward_den, alpha, sample, u):
                                       B, L, x_next.data_ptr(), idx.data_ptr(), work.data_ptr(), _stream())
     _lib.check(rc, "svdd_tds_resample")
     return x_next, idx
+
+
+# ------------------------------------------------------------------------------------------------ replay RNG on the device
+_TORCH_STATE_BYTES = 5056       # THGeneratorState: u64 seed | i32 left | i32 seeded | u64 next | u64 state[624] | 3 doubles + i32 (Box-Muller cache)
+
+
+def mt_state_from_torch(state_u8):
+    """torch.get_rng_state() (CPU generator, the legacy 5056-byte layout) -> int64 numpy [625]: 624 words + pos.
+    at::mt19937 draws with `if (--left == 0) next_state(); y = state[next++]`: pos = 625 - left (manual_seed leaves left = 1:
+    pos = 624, twist first)."""
+    import numpy as np
+    a = state_u8.numpy() if isinstance(state_u8, torch.Tensor) else np.asarray(state_u8)
+    if a.size != _TORCH_STATE_BYTES or not int(a[12:16].view(np.int32)[0]):
+        raise SvddError("unexpected torch CPU generator state layout (want the 5056-byte mt19937 state, seeded)")
+    left = int(a[8:12].view(np.int32)[0])
+    words = a[24:24 + 624 * 8].view(np.uint64)
+    if not (1 <= left <= 624) or int(words.max()) >> 32:
+        raise SvddError("unexpected torch CPU generator state contents")
+    out = np.empty(625, dtype=np.int64)
+    out[:624] = words
+    out[624] = 625 - left
+    return out
+
+
+def mt_state_to_torch(words_pos, template_u8):
+    """Inverse: [625] (624 words + pos) -> a 5056-byte torch CPU generator state (seed and the Box-Muller cache of
+    `template_u8` kept)."""
+    import numpy as np
+    a = np.array(template_u8.numpy() if isinstance(template_u8, torch.Tensor) else template_u8, dtype=np.uint8, copy=True)
+    pos = int(words_pos[624])
+    if not 1 <= pos <= 624:      # (the kernel returns pos in [1, 624] whenever it drew anything: left = 625 - pos in [1, 624])
+        raise SvddError(f"mt19937 state with pos = {pos} has no torch representation")
+    a[8:12].view(np.int32)[0] = 625 - pos
+    a[16:24].view(np.uint64)[0] = pos
+    a[24:24 + 624 * 8].view(np.uint64)[:] = np.asarray(words_pos[:624], dtype=np.uint64)
+    return torch.from_numpy(a)
+
+
+class DeviceReplayStream:
+    """torch's global CPU generator continued ON THE DEVICE for the span of one decode (rng_mode = "replay"): the state
+    (2.5 KB) is uploaded at open(), `uniforms(n)` returns the next n floats of the stream as a device tensor (K8
+    `svdd_mt19937_uniform_f32`: one workgroup, launched on a side stream ONE CALL AHEAD so that it runs under the nets of the
+    current diffusion step), and close() writes the advanced state back into torch's generator — after it, torch.rand() on
+    the host continues exactly where the reference's run would. Token-exact with the host replay (tests/test_kernels_gpu.py)."""
+
+    def __init__(self, device):
+        self.dev = torch.device(device)
+        self.template = torch.get_rng_state()
+        import numpy as np
+        st = mt_state_from_torch(self.template)
+        self.state = torch.from_numpy(st.astype(np.uint32).view(np.int32).copy()).to(self.dev)          # [625] u32 bits
+        self.side = torch.cuda.Stream(device=self.dev)
+        self.side.wait_stream(torch.cuda.current_stream(self.dev))
+        self.bufs = {}            # n -> [two device buffers]
+        self.flip = 0
+        self.ahead = None         # (n, tensor, state snapshot before it was drawn, event) of the block generated ahead of need
+        self.drawn = 0
+
+    def _launch(self, n, out):
+        rc = _lib.lib().svdd_mt19937_uniform_f32(self.state.data_ptr(), out.data_ptr(), n,
+                                                 ctypes.c_void_p(self.side.cuda_stream))
+        _lib.check(rc, "svdd_mt19937_uniform_f32")
+
+    def _generate(self, n, snapshot):
+        """Enqueue the next n floats on the side stream -> (tensor, snapshot | None, event)."""
+        pair = self.bufs.setdefault(n, [torch.empty(n, dtype=torch.float32, device=self.dev) for _ in range(2)])
+        out = pair[self.flip]
+        self.flip ^= 1
+        with torch.cuda.stream(self.side):
+            snap = self.state.clone() if snapshot else None
+            self._launch(n, out)
+            ev = torch.cuda.Event()
+            ev.record(self.side)
+        return out, snap, ev
+
+    def uniforms(self, n, prefetch=True):
+        """The next n floats of the stream, usable on the CURRENT stream. prefetch: also start the n after them (a decode asks
+        for the same n at every step); an unused prefetch is rolled back at close()."""
+        cur = torch.cuda.current_stream(self.dev)
+        if self.ahead is not None and self.ahead[0] == n:
+            _, out, _, ev = self.ahead
+            self.ahead = None
+        else:
+            self._rollback()
+            self.side.wait_stream(cur)          # the buffer about to be overwritten may still be read by an earlier K1
+            out, _, ev = self._generate(n, False)
+        cur.wait_event(ev)
+        self.drawn += n
+        if prefetch:
+            # the prefetch overwrites the OTHER buffer of the pair, last read by the K1 of the previous call: order after it
+            self.side.wait_stream(cur)
+            o2, snap, e2 = self._generate(n, True)
+            self.ahead = (n, o2, snap, e2)
+        return out
+
+    def _rollback(self):
+        if self.ahead is not None:
+            _, _, snap, _ = self.ahead
+            with torch.cuda.stream(self.side):
+                self.state.copy_(snap)
+            self.ahead = None
+
+    def close(self):
+        """Write the advanced state back into torch's global CPU generator (one small D2H copy + sync)."""
+        self._rollback()
+        self.side.synchronize()
+        if self.drawn:
+            import numpy as np
+            st = self.state.cpu().numpy().view(np.uint32).astype(np.int64)
+            torch.set_rng_state(mt_state_to_torch(st, self.template))
+        torch.cuda.current_stream(self.dev).wait_stream(self.side)

@@ -455,7 +455,7 @@ def free_running_lean_report(g, model, run, precision="f32"):
     model.precision = "f32"
     same = (xs == g["xs"][:len(xs)]).all(axis=2)                                       # [S + 1, B]
     first_row = np.array([next((i for i in range(len(xs)) if not same[i, b]), -1) for b in range(B)])
-    ds = max(float(np.abs(scores[i][same[i]] - g["scores"][i][same[i]]).max()) for i in range(S) if same[i].any())
+    comparable = same[:S].copy()                                                      # row-steps whose candidates are the reference's
     near_tie, proposal, unexplained, gaps = 0, 0, [], []
     for b in np.nonzero(first_row >= 0)[0]:
         i = int(first_row[b]) - 1                                                      # the step that produced the differing state
@@ -470,6 +470,8 @@ def free_running_lean_report(g, model, run, precision="f32"):
                 unexplained.append({"row": int(b), "step": i, "reference_score_gap": gap})
         else:
             proposal += 1
+            comparable[i, b] = False                                                   # same x_t, but a candidate the reference did not have
+    ds = max(float(np.abs(scores[i][comparable[i]] - g["scores"][i][comparable[i]]).max()) for i in range(S) if comparable[i].any())
     x0n = x0.cpu().numpy()
     diverged = first_row[first_row >= 0]
     return {"S": S, "B": B, "L": L, "M": M, "precision": precision,

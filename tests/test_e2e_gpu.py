@@ -198,3 +198,76 @@ def test_tds_on_the_reference_trajectory_full_size(golden, full_nets, precision)
     if precision == "f32":
         assert rep["first_divergence_step"] is None and rep["x0_exact"], rep
     print("g19 tds", rep)
+
+
+# ------------------------------------------------------------------ g21: the reference's own run AT the headline configs
+def _assert_teacher_forced_lean(rep):
+    # scores: the north star's tolerance, on all S x B x M scores of the reference's run
+    for k in ("max_abs_score_err_whole_tower", "max_abs_score_err_compact", "max_abs_score_err"):
+        if k in rep:
+            assert rep[k] <= TOL, rep
+    if rep["max_abs_logit_err_kept_calls"] is not None:
+        assert rep["max_abs_logit_err_kept_calls"] <= TOL, rep
+    # candidates: re-proposed on the GPU from the replayed uniforms. A token may differ from the reference's only where the
+    # categorical draw is a near-tie (relative lead of the winner <= 1e-4, i.e. inside the logits' tolerance) — and hardly ever
+    assert rep["candidate_rows_identical"] >= 0.9999 * rep["candidate_rows"], rep
+    if rep["candidate_tokens_differing"]:
+        assert rep["max_race_margin_where_candidates_differ"] <= TOL, rep
+    # selections: may differ only at a near-tie of the reference's two best scores
+    if rep["disagreeing_row_steps"]:
+        assert rep["max_reference_top2_gap_where_selection_differs"] <= 2 * TOL, rep
+    assert rep["selection_agreement"] >= 0.99, rep
+
+
+def _assert_free_running_lean(run):
+    assert run["max_abs_score_err_on_undiverged_rows"] <= TOL, run
+    assert run["divergences_unexplained"] == [], run                     # every divergence is a near-tie (<= 2e-4) or a proposal flip
+    assert run["divergences_by_proposal_flip"] <= max(2, run["B"] // 50), run
+    if run["first_divergence_step"] is None:
+        assert run["x0_exact"], run
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_headline_config_c2_against_the_reference_run(golden, full_nets, precision):
+    """g21 (C2 = BASELINE configs[1], the config `metric` is quoted on): the reference's controlled_sample at B = 256, L = 200,
+    M = 10, 128 steps with the full-size seed-44 nets. Teacher-forced on all 128 x 256 row-steps (backbone at full occupancy ->
+    K1 with the replayed uniforms -> candidates == the reference's; value kernels on all 327,680 candidates -> scores within
+    1e-4; K2 -> the reference's next state), then the free-running replay decode (reference diffusion_gosai.py:1021-1061,
+    1174-1228). Numbers of the last run: profiles/r04_e2e_parity.json."""
+    from tests import e2e_parity
+    g = golden("g21_traj_mc_c2.npz")
+    model, emb, head, _ = full_nets
+    _same_nets(g, (("backbone", model.backbone), ("embedding", emb), ("head", head)))
+    rep = e2e_parity.teacher_forced_lean_report(g, model, emb, head, precision)
+    print("g21 c2 teacher-forced", rep)
+    _assert_teacher_forced_lean(rep)
+    B, M, S = int(g["B"]), int(g["M"]), int(g["S"])
+    run = e2e_parity.free_running_lean_report(
+        g, model, lambda m: m.controlled_sample(emb, head, num_steps=S, eval_sp_size=B, sample_M=M), precision)
+    print("g21 c2 free-running", run)
+    _assert_free_running_lean(run)
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_headline_config_c3_against_the_reference_run(golden, rna_nets, precision):
+    """g21 (C3 = BASELINE configs[2]): the reference's controlled_sample_tweedie(options="True") at B = 256, L = 50, M = 10,
+    128 steps, full-size nets + reward model (reference diffusion_gosai.py:1105-1145, 1373-1460): teacher-forced (candidates,
+    x0-hat rows, reward scores, selections at every step) and free-running with the exact work-skipping on."""
+    from tests import e2e_parity
+    g = golden("g21_traj_pm_c3.npz")
+    model, emb, head, reward = rna_nets
+    _same_nets(g, (("backbone", model.backbone), ("embedding", emb), ("head", head), ("reward_embedding", reward.embedding),
+                   ("reward_head", reward.head)))
+    rep = e2e_parity.teacher_forced_lean_pm_report(g, model, reward, precision)
+    print("g21 c3 teacher-forced", rep)
+    assert rep["hand_written_net_kernels"]
+    _assert_teacher_forced_lean(rep)
+    # an x0-hat token (argmax over the 4 real-token logits, :1415) may differ only at a near-tie of the two best logits
+    assert rep["x0hat_rows_identical"] >= 0.999 * rep["candidate_rows"], rep
+    if rep["x0hat_tokens_differing"]:
+        assert rep["max_logit_top2_gap_where_x0hat_differs"] <= 2 * TOL, rep
+    B, M, S = int(g["B"]), int(g["M"]), int(g["S"])
+    run = e2e_parity.free_running_lean_report(
+        g, model, lambda m: m.controlled_sample_tweedie(reward, num_steps=S, eval_sp_size=B, sample_M=M, options="True"), precision)
+    print("g21 c3 free-running", run)
+    _assert_free_running_lean(run)

@@ -455,3 +455,30 @@ def test_tds_config5_size_equals_oracle_loop_on_the_gpu_nets():
     x_orc = orc.controlled_sample_tds(bb, rw, sched, alpha, B, L, uf, lambda i, B_: us[i])
     assert x_gpu.shape == (B, L) and int(x_gpu.max()) <= 3
     assert np.array_equal(x_gpu, x_orc)
+
+
+def test_replay_rng_on_the_device_equals_the_host_replay():
+    """rng_mode = "replay" with the mt19937 stream generated on the GPU (replay_rng = "device", the default) against the
+    round-1..3 host replay (torch.rand + upload): the same decode token for token — MC with work-skipping, PM, the un-guided
+    decode — and torch's global generator left in the same state (the next host draw agrees)."""
+    from svdd_amd import synthetic
+    model, emb, head, reward = synthetic.build("rna", DEV)
+    model.rng_mode = "replay"
+    runs = {"mc": lambda: model.controlled_sample(emb, head, num_steps=12, eval_sp_size=9, sample_M=4),
+            "pm": lambda: model.controlled_sample_tweedie(reward, num_steps=8, eval_sp_size=5, sample_M=3, options="True"),
+            "plain": lambda: model.decode_sample(num_steps=10, eval_sp_size=7),
+            "step": lambda: model._ddpm_update_finetune_controlled(torch.full((6, 50), 4, device=DEV), torch.ones(6, 1, device=DEV),
+                                                                   0.1, emb, head, repeats=3)[0]}
+    for name, run in runs.items():
+        out = {}
+        for how in ("host", "device"):
+            model.replay_rng = how
+            torch.manual_seed(99)
+            with torch.no_grad():
+                x = run()
+            torch.cuda.synchronize()
+            out[how] = (x.cpu(), torch.rand(16))
+        assert torch.equal(out["host"][0], out["device"][0]), name
+        assert torch.equal(out["host"][1], out["device"][1]), name          # the generator went back in the same state
+        assert model._replay_stream is None
+    model.replay_rng = "device"

@@ -347,3 +347,45 @@ def test_dps_gradient_matches_reference_full_size(golden):
             grad = model.compute_gradient_DPS(onehot, x, reward, torch.zeros(x.shape[0]), copy)
         ref = torch.from_numpy(g["grad"][i])
         assert float((grad - ref).abs().max()) <= 1e-3 * float(ref.abs().max()), (i, float((grad - ref).abs().max()), float(ref.abs().max()))
+
+
+def test_torch_generator_state_conversion_for_the_device_mt19937():
+    """ops.mt_state_from_torch / mt_state_to_torch (the bridge between torch's global CPU generator and the device mt19937 of
+    rng_mode = "replay"): the parsed (624 words, pos) continue torch's stream when run by the oracle's mt19937, and ANY window
+    of the x[n + 624] = x[n + 397] ^ tw(x[n], x[n + 1]) sequence written back as a state makes torch continue that sequence —
+    the device kernel returns such a rotated window (include/svdd_hip.h, svdd_mt19937_uniform_f32)."""
+    from oracle import svdd_oracle as orc
+    from svdd_amd import ops
+    for seed, drawn in ((0, 0), (5, 10), (44, 1010), (7, 624), (9, 623)):
+        torch.manual_seed(seed)
+        if drawn:
+            torch.rand(drawn)
+        st = torch.get_rng_state()
+        wp = ops.mt_state_from_torch(st)
+        assert wp[624] == (624 if drawn in (0, 624) else drawn % 624)
+        m = orc.MT19937(0)
+        for k in range(624):
+            m.mt[k] = int(wp[k])
+        m.pos = int(wp[624])
+        assert np.array_equal(m.torch_rand(2000), torch.rand(2000).numpy())
+    # a rotated window: x = the raw (untempered) sequence, from the oracle's successive state arrays
+    torch.manual_seed(3)
+    st = torch.get_rng_state()
+    m = orc.MT19937(3)
+    m.torch_rand(1)                                  # forces the first twist: m.mt = x[624 .. 1247] of the sequence seeded at x[0 .. 623]
+    blocks = [np.array(m.mt[:], dtype=np.int64)]
+    for _ in range(3):
+        m.pos = 624
+        m.torch_rand(1)
+        blocks.append(np.array(m.mt[:], dtype=np.int64))
+    x = np.concatenate(blocks)                       # x[624 ..] relative to the seed block; index 0 here = output #0
+    expect = torch.rand(4 * 624).numpy()             # the outputs of exactly these words
+    for E, pos in ((227, 170), (454, 624), (100, 1), (681, 333)):
+        wp = np.concatenate([x[E:E + 624], [pos]])
+        torch.set_rng_state(ops.mt_state_to_torch(wp, st))
+        got = torch.rand(500).numpy()
+        assert np.array_equal(got, expect[E + pos:E + pos + 500]), (E, pos)
+    with pytest.raises(ops.SvddError):
+        ops.mt_state_to_torch(np.concatenate([x[:624], [0]]), st)
+    with pytest.raises(ops.SvddError):
+        ops.mt_state_from_torch(torch.zeros(100, dtype=torch.uint8))

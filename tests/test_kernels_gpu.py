@@ -507,3 +507,71 @@ def test_g4_reference_transform_samples_on_the_kernel(ops, golden):
     assert np.array_equal(ops.transform_samples(tok).cpu().numpy(), g["onehot"].astype(np.float32))
     assert np.array_equal(ops.transform_samples(tok, transposed=True).cpu().numpy(),
                           g["onehot"].astype(np.float32).transpose(0, 2, 1))
+
+
+# ------------------------------------------------------------------ K8: torch's CPU mt19937 stream on the device
+def _mt_device_state(seed, drawn):
+    """(device state [625] of torch.manual_seed(seed) after `drawn` floats, oracle generator in the same state)."""
+    from svdd_amd import ops as _ops
+    torch.manual_seed(seed)
+    if drawn:
+        torch.rand(drawn)
+    wp = _ops.mt_state_from_torch(torch.get_rng_state())
+    m = orc.MT19937(0)
+    for k in range(624):
+        m.mt[k] = int(wp[k])
+    m.pos = int(wp[624])
+    return torch.from_numpy(wp.astype(np.uint32).view(np.int32).copy()).to(DEV), m
+
+
+@pytest.mark.parametrize("seed,drawn,ns", [(0, 0, (10, 1, 700, 5)), (44, 1010, (624,)), (7, 623, (1, 1, 2)), (3, 0, (227, 454, 681, 9999)),
+                                          (11, 17, (2_560_000, 3, 256_000)), (1, 624, (1247,))])
+def test_mt19937_device_stream_equals_the_host_generator(ops, seed, drawn, ns):
+    """svdd_mt19937_uniform_f32 against the oracle's restatement of at::mt19937 + uniform_real_distribution<float> (pinned to
+    torch by g9): consecutive calls of every length class — inside a block, across one, across many generations, the config-2
+    step size (M*B*5*L = 2.56 M) — from every kind of start (fresh seed: twist first; mid-block; last word of a block)."""
+    import ctypes
+    from svdd_amd import _lib
+    state, m = _mt_device_state(seed, drawn)
+    for n in ns:
+        out = torch.empty(n, dtype=torch.float32, device=DEV)
+        rc = _lib.lib().svdd_mt19937_uniform_f32(state.data_ptr(), out.data_ptr(), n,
+                                                 ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc == 0
+        assert np.array_equal(out.cpu().numpy(), m.torch_rand(n)), (seed, drawn, n)
+        pos = int(state[624].item())
+        assert 1 <= pos <= 624
+
+
+def test_mt19937_device_stream_g9_and_state_write_back(ops, golden):
+    """g9 (torch.manual_seed(s); torch.rand(n) recorded from torch itself) through DeviceReplayStream, and the write-back: after
+    close() torch's own generator continues the stream exactly where a host-only run would be."""
+    g = golden("g9_rng.npz")
+    for seed, n in [(0, 140), (44, 5000), (123456789, 256000)]:
+        torch.manual_seed(seed)
+        st = ops.DeviceReplayStream(DEV)
+        a = st.uniforms(n // 2, prefetch=True).clone()              # a prefetch of the wrong size is rolled back
+        b = st.uniforms(n - n // 2, prefetch=False).clone()
+        st.close()
+        r = torch.cat([a, b]).cpu().numpy()
+        assert np.array_equal(r[:256], g[f"torch_s{seed}_n{n}_head"][: min(256, n)])
+        assert np.array_equal(r[-256:], g[f"torch_s{seed}_n{n}_tail"])
+        assert r.astype(np.float64).sum() == g[f"torch_s{seed}_n{n}_sum"]
+        after = torch.rand(1000)
+        torch.manual_seed(seed)
+        torch.rand(n)
+        assert torch.equal(after, torch.rand(1000))
+    torch.manual_seed(7)
+    st = ops.DeviceReplayStream(DEV)
+    r = st.uniforms(3 * 50 * 5, prefetch=False).clone()
+    st.close()
+    assert np.array_equal(r.cpu().numpy().reshape(3, 50, 5), g["torch_s7_randlike_3_50_5"])
+    # an unused prefetch of the RIGHT size is rolled back too
+    torch.manual_seed(123)
+    st = ops.DeviceReplayStream(DEV)
+    a = st.uniforms(5000).clone()
+    st.close()
+    after = torch.rand(10)
+    torch.manual_seed(123)
+    ref = torch.rand(5010)
+    assert torch.equal(a.cpu(), ref[:5000]) and torch.equal(after, ref[5000:])

@@ -37,4 +37,19 @@ g = dict(np.load(os.path.join(G, "g18_traj_pm_full_rna.npz")))
 out["fullsize_pm"] = {"g18_traj_pm_full_rna.npz": [
     {"teacher_forced": e2e_parity.teacher_forced_pm_report(g, rna, reward_r, p), "free_running": e2e_parity.free_running_pm_report(g, rna, reward_r, p)}
     for p in ("f32", "f16x3", "bf16x3")]}
+# g21: the reference's runs AT the headline configs (C2: B = 256, L = 200, M = 10, 128 steps; C3: tweedie, B = 256, L = 50, M = 10)
+g = dict(np.load(os.path.join(G, "g21_traj_mc_c2.npz")))
+B, M, S = int(g["B"]), int(g["M"]), int(g["S"])
+out["headline_c2"] = {"fixture": "g21_traj_mc_c2.npz", "runs": [
+    {"teacher_forced": e2e_parity.teacher_forced_lean_report(g, model, emb, head, p),
+     "free_running": e2e_parity.free_running_lean_report(
+         g, model, lambda m: m.controlled_sample(emb, head, num_steps=S, eval_sp_size=B, sample_M=M), p)}
+    for p in ("f32", "f16x3", "bf16x3")]}
+g = dict(np.load(os.path.join(G, "g21_traj_pm_c3.npz")))
+B, M, S = int(g["B"]), int(g["M"]), int(g["S"])
+out["headline_c3"] = {"fixture": "g21_traj_pm_c3.npz", "runs": [
+    {"teacher_forced": e2e_parity.teacher_forced_lean_pm_report(g, rna, reward_r, p),
+     "free_running": e2e_parity.free_running_lean_report(
+         g, rna, lambda m: m.controlled_sample_tweedie(reward_r, num_steps=S, eval_sp_size=B, sample_M=M, options="True"), p)}
+    for p in ("f32", "f16x3", "bf16x3")]}
 print(json.dumps(out, indent=1))

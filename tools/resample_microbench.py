@@ -25,11 +25,21 @@ def timed(fn, iters=20, warm=5):
     return e0.elapsed_time(e1) / iters * 1e3          # us
 
 
-def k2(B, M, L=200, compact=False):
+def k2(B, M, L=200, compact=False, ld=0, scale=1e-3):
+    """ld: candidate rows at a stride of `ld` bytes (SVDD_OPT_CAND_ROW_STRIDE; the round-4 layout experiment: 256 = whole lines).
+    The padded case is checked against the dense one (same scores, same candidates -> same x_next)."""
+    from svdd_amd import _lib
     g = torch.Generator(device=DEV).manual_seed(0)
-    scores = torch.randn(B, M, device=DEV, generator=g) * 1e-3
+    scores = torch.randn(B, M, device=DEV, generator=g) * scale
     cand = torch.randint(0, 5, (B, M, L), device=DEV, generator=g, dtype=torch.uint8)
     x_next = torch.empty(B, L, dtype=torch.uint8, device=DEV)
+    if ld:
+        ref, _, _ = ops.select(scores, cand, want_soft=False)
+        wide = torch.zeros(B, M, ld, dtype=torch.uint8, device=DEV)
+        wide[:, :, :L] = cand
+        cand_dense, cand = cand, wide
+        assert _lib.lib().svdd_set_option(5, ld) == 0
+
     if compact:
         live = torch.rand(B * M, device=DEV, generator=g) < 0.77
         slot = torch.where(live, torch.cumsum(live.int(), 0) - 1, -1).int()
@@ -39,11 +49,22 @@ def k2(B, M, L=200, compact=False):
         fn = lambda: ops.select_compact(sc, slot, parent, cand, x_next=x_next, sel_score=sel, changed=ch, idx=idx)   # noqa: E731
         nbytes = B * (4 * M + 4 * M + 2 * L + 4 + 12)
     else:
-        fn = lambda: ops.select(scores, cand, want_soft=False, x_next=x_next)   # noqa: E731
+        idx = torch.empty(B, dtype=torch.int32, device=DEV)
+        import ctypes
+
+        def fn():      # the C ABI directly: L stays 200 while the rows of `cand` sit at the option's stride
+            rc = _lib.lib().svdd_select(scores.data_ptr(), cand.data_ptr(), B, L, M, ops.SELECT_ARGMAX, None, x_next.data_ptr(), None,
+                                        idx.data_ptr(), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+            assert rc == 0
         nbytes = B * (4 * M + 2 * L + 4)
     us = timed(fn)
+    if ld:
+        torch.cuda.synchronize()
+        if not compact:
+            assert torch.equal(x_next, ref), "padded-row select differs from the dense one"
+        assert _lib.lib().svdd_set_option(5, 0) == 0
     gbs = nbytes / us / 1e3
-    print(f"K2 select{'_compact' if compact else ''} B={B} M={M} L={L}: {us:9.1f} us  {gbs:8.1f} GB/s  frac {gbs / PEAK:.3f}  ({nbytes / 1e6:.1f} MB)")
+    print(f"K2 select{'_compact' if compact else ''} B={B} M={M} L={L} ld={ld or L} scores~{scale:g}: {us:9.1f} us  {gbs:8.1f} GB/s  frac {gbs / PEAK:.3f}  ({nbytes / 1e6:.1f} MB)")
 
 
 def k4(B, L=200):
@@ -58,6 +79,15 @@ def k4(B, L=200):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "ld":        # the padded-row layout experiment: near-tied leg first
+        for scale in (1e-7, 1e-2):
+            for M in (10, 20):
+                for ld in (0, 208, 256):
+                    k2(1 << 18, M, ld=ld, scale=scale)
+        sys.exit(0)
+    if len(sys.argv) > 2 and sys.argv[1] == "one":       # one case, for a PMC pass: one <M> <ld>
+        k2(1 << 18, int(sys.argv[2]), ld=int(sys.argv[3]), scale=1e-2)
+        sys.exit(0)
     for M in (10, 20):
         k2(1 << 18, M)
     k2(1 << 18, 10, compact=True)
