@@ -332,6 +332,13 @@ int svdd_conv_tower_windows_f32(const float* onehot, const float* tiles, const f
 int svdd_backbone_cnn_f32(const uint8_t* x, const float* table0, const float* tiles, const float* vec,
                           const float* w2, float* out, int n, int L, int nlayers, const int* dilations,
                           const int32_t* count, const int32_t* row_idx, int out_scatter, void* stream);
+/* svdd_backbone_set_workspace — caller-owned scratch for the small-batch form of svdd_backbone_cnn_f32 (several workgroups per
+ * sequence exchange the LayerNorm'd image of every layer through it): ws = device memory of `bytes` >= n_max * (2 * 208 * 128 * 4
+ * + 4) + 4 bytes for batches of up to n_max sequences (n_max = 128 covers every case the split is used for); NULL: none (one
+ * workgroup per sequence at every batch size). Launches that use it must not overlap. svdd_backbone_split_status: *err = 1 if a
+ * group barrier ever timed out (never in a correct launch: the launcher only splits when every workgroup is resident). */
+int svdd_backbone_set_workspace(void* ws, long long bytes);
+int svdd_backbone_split_status(int* err);
 
 /* ------------------------------------------------------------------------------------------------
  * Split-precision net kernels (svdd_amd/csrc/svdd_lp_*.hip) — the same functions as the *_f32 net kernels above
@@ -393,14 +400,21 @@ int svdd_value_tail_lp(const float* h_fwd, const float* h_bwd, const void* w1pac
  * to A/B the filter. */
 enum { SVDD_OPT_FORCE_EXACT = 0,
        SVDD_OPT_MSPLIT = 1 /* tuning: waves per 64-position tile in svdd_propose, 0 = auto */,
-       SVDD_OPT_SELECT_ONE_ROW = 2 /* A/B: svdd_select as one wave per row for every M (default: several rows per wave for M <= 64) */,
+       SVDD_OPT_SELECT_ONE_ROW = 2 /* A/B: 1 = svdd_select as one wave per row for every M (default 0: several rows per wave for M <= 64,
+                                      4 row groups per wave from 2^21 (row, candidate) slots on); 2 / 3 = force 4 / 1 row groups per wave */,
        SVDD_OPT_BACKBONE_LP_VERSION = 3 /* A/B: 1 = svdd_backbone_cnn_lp runs the round-2 kernel for every shape; 2 (default) = the
                                             transposed-accumulator kernel where one sequence fills a tile (104 < L <= 208) */,
        SVDD_OPT_TRUNK_GEMM_VERSION = 4 /* A/B: svdd_trunk_gemm kernel: 1 = 128 x 128 tiles everywhere, 2 (default) = 256 x 256 LDS-DMA
                                            tiles from 128 tiles up, 3 = 256 x 256 everywhere (13 .. 16: timing experiments with
                                            wrong results: no epilogue / one K block / no DMA / no fragment reads) */,
        SVDD_OPT_CAND_ROW_STRIDE = 5 /* layout experiment (round 4): bytes between two candidate rows of `cand` as svdd_select /
-                                        svdd_select_compact read it (0 = L, the default): rows padded to whole 128-byte lines */ };
+                                        svdd_select_compact read it (0 = L, the default): rows padded to whole 128-byte lines */,
+       SVDD_OPT_TRUNK_PLANES_F32 = 6 /* the svdd_trunk_* entry points take ONE fp32 operand plane (the *_hi pointers are float*, the
+                                         *_lo pointers NULL) and svdd_trunk_gemm multiplies on v_mfma_f32_16x16x4_f32: the Enformer-shaped
+                                         trunk at the reference's precision (weights packed by fused_trunk.pack_gemm_weight_f32) */,
+       SVDD_OPT_BACKBONE_SPLIT = 7 /* svdd_backbone_cnn_f32 on several workgroups per sequence (small batches; same bits): 0 = automatic
+                                       (4 workgroups per sequence while 4 n <= CUs, 2 while 2 n <= CUs; needs
+                                       svdd_backbone_set_workspace), 1 = never, 2 / 4 = that many wherever n R <= CUs */ };
 int svdd_set_option(int key, int value);
 
 /* Soak / profiling aid: while `device_counters2` (two zero-initialised uint64 on the device) is non-NULL, every

@@ -34,6 +34,7 @@ EXPORTS = (
     "svdd_trunk_gemm", "svdd_trunk_act_split", "svdd_trunk_layernorm_split", "svdd_trunk_attn_pool", "svdd_trunk_stem_unfold", "svdd_trunk_attn_small",
     "svdd_trunk_windows", "svdd_trunk_stem_unfold_win", "svdd_trunk_attn_pool_win",
     "svdd_bb_layer_fwd_f32", "svdd_bb_layer_bwd_f32", "svdd_mt19937_uniform_f32",
+    "svdd_backbone_set_workspace", "svdd_backbone_split_status",
 )
 OPT_FORCE_EXACT = 0
 
@@ -92,6 +93,8 @@ def lib():
     L.svdd_tds_resample.argtypes = [vp, vp, ctypes.c_double, vp, vp, i32, i32, vp, vp, vp, vp]
     L.svdd_set_option.argtypes = [i32, i32]
     L.svdd_mt19937_uniform_f32.argtypes = [vp, vp, ctypes.c_longlong, vp]
+    L.svdd_backbone_set_workspace.argtypes = [vp, ctypes.c_longlong]
+    L.svdd_backbone_split_status.argtypes = [ctypes.POINTER(ctypes.c_int)]
     L.svdd_selftest_fastmath.argtypes = [ctypes.POINTER(ctypes.c_double)]
     L.svdd_gru_bidir_f32.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp]
     L.svdd_gru_bidir_train_f32.argtypes = [vp, vp, vp, vp, vp, i32, i32, vp]

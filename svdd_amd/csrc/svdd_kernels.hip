@@ -560,20 +560,34 @@ __device__ __forceinline__ int group_first(bool pred, int base) {
   return __ffsll((long long)(mask & GM)) - 1;
 }
 
-template <int MP>
+template <int MP, int R>
 __global__ __launch_bounds__(256) void select_rows_kernel(SelectArgs a) {
+  // R row GROUPS per wave (round 4): with one group a wave had one 512-byte gather in flight at a time, 8192 waves on the chip
+  // = 4 MB in flight against the ~12 MB that 5.8 TB/s x 2 us of latency need (the padded-row layout experiment showed the
+  // kernel is not traffic-bound: 151 -> 131 MB moved, 26.7 -> 25.6 us). A wave now loads the scores of its R groups back to
+  // back, decides them, and issues the row gathers of all R * G winners in batches of four loads before the first store.
   constexpr int G = WAVE / MP;
+  static_assert(R * G <= WAVE, "one lane per winning row");
   const int lane = threadIdx.x & (WAVE - 1);
   const int g = lane / MP, m = lane % MP, base = lane & ~(MP - 1);
-  const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * G;
+  const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * (G * R);
   if (row0 >= a.B) return;
-  const int64_t row = row0 + g;
-  const bool rv = row < a.B, valid = rv & (m < a.M);
-  float sv = -INFINITY;
-  if (valid) {
-    if (a.slot) { const int sl = a.slot[row * a.M + m]; sv = sl >= 0 ? a.scores[sl] : a.parent_score[row]; }
-    else sv = a.scores[row * a.M + m];
+  float svr[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int64_t row = row0 + r * G + g;
+    svr[r] = -INFINITY;
+    if (row < a.B && m < a.M) {
+      if (a.slot) { const int sl = a.slot[row * a.M + m]; svr[r] = sl >= 0 ? a.scores[sl] : a.parent_score[row]; }
+      else svr[r] = a.scores[row * a.M + m];
+    }
   }
+  int wbest = 0;                                            // lane q < R * G: the winning candidate of row row0 + q
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+  const int64_t row = row0 + r * G + g;
+  const bool rv = row < a.B, valid = rv & (m < a.M);
+  const float sv = svr[r];
   // first-index argmax of the raw scores, and the runner-up
   const float mx = group_max<MP>(sv);
   const int bi = group_first<MP>(valid & (sv == mx), base);
@@ -588,8 +602,8 @@ __global__ __launch_bounds__(256) void select_rows_kernel(SelectArgs a) {
       const float ej = __shfl(e, base + j, WAVE);
       sum = j == 0 ? ej : sum + ej;
     }
-    const float r = __fdiv_rn(1.0f, sum);
-    const float p = e * r;                                                    // ATen CPU softmax: e * (1 / sum)
+    const float rr = __fdiv_rn(1.0f, sum);
+    const float p = e * rr;                                                   // ATen CPU softmax: e * (1 / sum)
     if (a.mode == SVDD_SELECT_ARGMAX) {
       const float pm = group_max<MP>(valid ? p : -INFINITY);
       best = group_first<MP>(valid & (p == pm), base);
@@ -623,24 +637,49 @@ __global__ __launch_bounds__(256) void select_rows_kernel(SelectArgs a) {
       if (a.changed) a.changed[row] = sl >= 0 ? 1 : 0;                                      // x_next != x
     }
   }
-  // index-gather compaction (diffusion_gosai.py:1226-1227): the G winning rows, in units of ub bytes spread over the wave
-  const uintptr_t both = reinterpret_cast<uintptr_t>(a.cand) | reinterpret_cast<uintptr_t>(a.x_next);
-  const uintptr_t al = (uintptr_t)(a.L | a.ld) | both;
+  const int q = lane - r * G;                               // lane r G + q' takes the winner of group q' of round r
+  const int bq = __shfl(best, (q >= 0 && q < G ? q : 0) * MP, WAVE);
+  wbest = (q >= 0 && q < G) ? bq : wbest;
+  }
+  // index-gather compaction (diffusion_gosai.py:1226-1227): the R * G winning rows, in units of ub bytes spread over the wave
+  const uintptr_t al = (uintptr_t)(a.L | a.ld) | reinterpret_cast<uintptr_t>(a.cand) | reinterpret_cast<uintptr_t>(a.x_next);
   const int ub = (al & 7) == 0 ? 8 : (al & 3) == 0 ? 4 : (al & 1) == 0 ? 2 : 1;
-  const int U = a.L / ub, total = G * U;
+  const int U = a.L / ub, total = R * G * U;
   const float inv_u = 1.0f / (float)U;
+  if (ub == 8) {
+    // four gathers in flight per lane before the first store
+    for (int i0 = 0; i0 < total; i0 += 4 * WAVE) {
+      uint2 v[4]; uint8_t* dst[4]; bool ok[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int i = i0 + k * WAVE + lane;
+        int gq = (int)(((float)i + 0.5f) * inv_u);          // i / U (i < 2^22: exact after the half-unit offset)
+        gq = gq < R * G ? gq : R * G - 1;
+        const int bq = __shfl(wbest, gq, WAVE);
+        const int64_t rq = row0 + gq;
+        ok[k] = i < total && rq < a.B;
+        const int c = i - gq * U;
+        dst[k] = a.x_next + rq * a.L + (int64_t)c * 8;
+        v[k] = uint2{0u, 0u};
+        if (ok[k]) v[k] = *reinterpret_cast<const uint2*>(a.cand + (rq * a.M + bq) * a.ld + (int64_t)c * 8);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (ok[k]) *reinterpret_cast<uint2*>(dst[k]) = v[k];
+    }
+    return;
+  }
   for (int i0 = 0; i0 < total; i0 += WAVE) {
     const int i = i0 + lane;
-    int gq = (int)(((float)i + 0.5f) * inv_u);              // i / U (i < 2^22: exact after the half-unit offset)
-    gq = gq < G ? gq : G - 1;
-    const int bq = __shfl(best, gq * MP, WAVE);
+    int gq = (int)(((float)i + 0.5f) * inv_u);
+    gq = gq < R * G ? gq : R * G - 1;
+    const int bq = __shfl(wbest, gq, WAVE);
     const int64_t rq = row0 + gq;
     if (i < total && rq < a.B) {
       const int c = i - gq * U;
       const uint8_t* src = a.cand + (rq * a.M + bq) * a.ld + (int64_t)c * ub;
       uint8_t* dst = a.x_next + rq * a.L + (int64_t)c * ub;
-      if (ub == 8) *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<const uint2*>(src);
-      else if (ub == 4) *reinterpret_cast<uint32_t*>(dst) = *reinterpret_cast<const uint32_t*>(src);
+      if (ub == 4) *reinterpret_cast<uint32_t*>(dst) = *reinterpret_cast<const uint32_t*>(src);
       else if (ub == 2) *reinterpret_cast<uint16_t*>(dst) = *reinterpret_cast<const uint16_t*>(src);
       else *dst = *src;
     }
@@ -1045,7 +1084,7 @@ TimedLaunch* timed_slot(int k) {
 int g_msplit = 0;        // svdd_set_option(SVDD_OPT_MSPLIT, k): override K1's candidate split (0 = auto)
 int g_force_exact = 0;   // svdd_set_option(SVDD_OPT_FORCE_EXACT, 1): K1 takes the exact path for every draw
 int g_cand_ld = 0;        // svdd_set_option(SVDD_OPT_CAND_ROW_STRIDE, bytes): row stride of `cand` in svdd_select* (0 = L)
-int g_select_one_row_per_wave = 0;   // svdd_set_option(SVDD_OPT_SELECT_ONE_ROW, 1): K2 as one wave per row for every M (A/B)
+int g_select_one_row_per_wave = 0;   // svdd_set_option(SVDD_OPT_SELECT_ONE_ROW, v): 1 = K2 as one wave per row for every M (A/B); 2 / 3 = the rows-per-wave kernel with 4 / 1 row groups per wave whatever the batch (0: by size)
 unsigned long long* g_k1_stats = nullptr;   // svdd_k1_stats: device counters K1 adds to
 
 inline int check_launch() { return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH; }
@@ -1055,6 +1094,8 @@ inline bool bad_layout(int layout) { return layout != SVDD_LAYOUT_BLV && layout 
 
 extern "C" void svdd_internal_set_bb_lp_version(int v);      // svdd_lp_backbone.hip
 extern "C" void svdd_internal_set_trunk_gemm_version(int v); // svdd_trunk.hip
+extern "C" void svdd_internal_set_trunk_planes_f32(int v);   // svdd_trunk.hip
+extern "C" void svdd_internal_set_bb_split(int v);           // svdd_nets.hip
 
 // ================================================================================ C ABI ====
 extern "C" {
@@ -1064,8 +1105,10 @@ int svdd_abi_version(void) { return SVDD_ABI_VERSION; }
 int svdd_set_option(int key, int value) {
   if (key == SVDD_OPT_FORCE_EXACT) { g_force_exact = value ? 1 : 0; return SVDD_OK; }
   if (key == SVDD_OPT_MSPLIT && value >= 0 && value <= 64) { g_msplit = value; return SVDD_OK; }
-  if (key == SVDD_OPT_SELECT_ONE_ROW) { g_select_one_row_per_wave = value ? 1 : 0; return SVDD_OK; }
+  if (key == SVDD_OPT_SELECT_ONE_ROW && value >= 0 && value <= 3) { g_select_one_row_per_wave = value; return SVDD_OK; }
   if (key == SVDD_OPT_CAND_ROW_STRIDE && value >= 0) { g_cand_ld = value; return SVDD_OK; }
+  if (key == SVDD_OPT_TRUNK_PLANES_F32) { svdd_internal_set_trunk_planes_f32(value); return SVDD_OK; }
+  if (key == SVDD_OPT_BACKBONE_SPLIT) { svdd_internal_set_bb_split(value); return SVDD_OK; }
   if (key == SVDD_OPT_BACKBONE_LP_VERSION) { svdd_internal_set_bb_lp_version(value); return SVDD_OK; }
   if (key == SVDD_OPT_TRUNK_GEMM_VERSION) { svdd_internal_set_trunk_gemm_version(value); return SVDD_OK; }
   return SVDD_E_ARG;
@@ -1213,20 +1256,29 @@ int svdd_select_compact(const float* scores, const int32_t* slot, const float* p
                g_cand_ld >= L ? g_cand_ld : L};
   TimedLaunch* t = timed_slot(1);
   hipEvent_t e0 = t ? t->start : nullptr, e1 = t ? t->stop : nullptr;
-  if (M <= WAVE && !g_select_one_row_per_wave) {
+  if (M <= WAVE && g_select_one_row_per_wave != 1) {
     int mp = 1;
     while (mp < M) mp <<= 1;
-    const int64_t waves = ((int64_t)B + WAVE / mp - 1) / (WAVE / mp);
+    // row groups per wave: 4 once there are enough rows to fill the chip several times over (memory-level parallelism),
+    // 1 at the decode's own sizes (a few hundred rows: latency, spread over as many waves as possible)
+    // (the winners of a wave's R * G rows travel in one lane each: R * G <= 64, i.e. R <= MP)
+    const int Rw = g_select_one_row_per_wave == 2 ? 4 : g_select_one_row_per_wave == 3 ? 1 : ((int64_t)B * mp >= (int64_t)1 << 21 ? 4 : 1);
+    const int R = Rw > mp ? mp : Rw;
+    const int64_t waves = ((int64_t)B + (WAVE / mp) * R - 1) / ((WAVE / mp) * R);
     const dim3 grid((unsigned)((waves + 3) / 4));
+#define SVDD_SEL_LAUNCH(MP_)                                                                                                     \
+    if (R > 1) hipExtLaunchKernelGGL((select_rows_kernel<MP_, (MP_ >= 4 ? 4 : MP_)>), grid, dim3(256), 0, (hipStream_t)stream, e0, e1, 0, a); \
+    else hipExtLaunchKernelGGL((select_rows_kernel<MP_, 1>), grid, dim3(256), 0, (hipStream_t)stream, e0, e1, 0, a);
     switch (mp) {
-      case 1: hipExtLaunchKernelGGL(select_rows_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, e0, e1, 0, a); break;
-      case 2: hipExtLaunchKernelGGL(select_rows_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, e0, e1, 0, a); break;
-      case 4: hipExtLaunchKernelGGL(select_rows_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, e0, e1, 0, a); break;
-      case 8: hipExtLaunchKernelGGL(select_rows_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, e0, e1, 0, a); break;
-      case 16: hipExtLaunchKernelGGL(select_rows_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, e0, e1, 0, a); break;
-      case 32: hipExtLaunchKernelGGL(select_rows_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, e0, e1, 0, a); break;
-      default: hipExtLaunchKernelGGL(select_rows_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, e0, e1, 0, a); break;
+      case 1: SVDD_SEL_LAUNCH(1) break;
+      case 2: SVDD_SEL_LAUNCH(2) break;
+      case 4: SVDD_SEL_LAUNCH(4) break;
+      case 8: SVDD_SEL_LAUNCH(8) break;
+      case 16: SVDD_SEL_LAUNCH(16) break;
+      case 32: SVDD_SEL_LAUNCH(32) break;
+      default: SVDD_SEL_LAUNCH(64) break;
     }
+#undef SVDD_SEL_LAUNCH
     return check_launch();
   }
   hipExtLaunchKernelGGL(select_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, e0, e1, 0, a);

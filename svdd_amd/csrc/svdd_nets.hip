@@ -1742,6 +1742,322 @@ __global__ __launch_bounds__(512, 2) void backbone_kernel(BackboneArgs a) {
   }
 }
 
+// ---------------------------------------------------- the same forward on SEVERAL workgroups per sequence (round 4) ----
+// backbone_kernel takes ~2.1 ms per workgroup whatever the batch: 4 sequences (BASELINE.json configs[0]) used 4 of 256 CUs
+// for as long as 256 sequences use all of them. Here R = 2 or 4 workgroups share one sequence (104 < L <= 208), split BY ROWS:
+// workgroup q owns the row tiles {2 q, 2 q + 1} + 2 R r (wave (cg, rh): tiles rh + 2 q + 2 R r), all 128 channels of them —
+// so the residual stream, the LayerNorm statistics (a row's 128 channels live in one workgroup), the first-layer lookup and
+// both 1 x 1 convolutions stay workgroup-local, every accumulator sees the products of backbone_kernel in the same order
+// (SAME BITS, tests/test_fused_gpu.py), and the only exchange is the LayerNorm'd image: a dilated tap reads rows up to 256
+// away, so each workgroup publishes its 32-row blocks of hn to a global scratch image after the LayerNorm of a layer, the R
+// workgroups meet at an agent-scope counter, and each copies the blocks it does not own into its LDS image (106 KB per
+// sequence and layer through the L2: the members of a group are given workgroup ids 8 apart = the same XCD). The scratch
+// image is double-buffered by layer parity (a fast workgroup may publish layer l + 1 while a slow one still reads layer l).
+// All R workgroups of a group must be resident: the launcher only uses this kernel when n R <= CUs.
+struct BackboneSplitWs { float* xchg; int* cnt; int* err; int groups; };
+
+template <int R>
+__global__ __launch_bounds__(512, 2) void backbone_split_kernel(BackboneArgs a, BackboneSplitWs ws) {
+  constexpr int TS = 2 * R;                               // stride of a wave's row tiles
+  constexpr int NR = (TW_RT + TS - 1) / TS;               // R = 2: 4 ; R = 4: 2
+  static_assert(NR % 2 == 0, "the two A-fragment sets keep their roles from entry to entry");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* img = smem + BB_AP;
+  float* Bs = smem + (TW_ROWS + 2) * BB_AP;
+  float* psum = Bs + 9 * 5 * BB_C;
+  float* rstat = psum + 8 * TW_ROWS;
+  int* toks = reinterpret_cast<int*>(rstat + TW_ROWS);
+  int* rpos = toks + TW_ROWS;
+  int* sdil = rpos + TW_ROWS;
+  int* sched = sdil + BB_MAXL + 1;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cg = w & 3, rh = w >> 2;
+  const int j = lane & 15, g = lane >> 4;
+  const int col0 = 32 * cg + j;
+  const int L = a.L;
+  // workgroup -> (group = sequence, member q): the R members of a group sit 8 workgroup ids apart (one XCD, one L2)
+  const int bid = blockIdx.x, kq = bid >> 3;
+  const int q = kq % R, grp = (kq / R) * 8 + (bid & 7);
+  if (grp >= a.n) return;                                 // (the whole group leaves together)
+  const int t0 = rh + 2 * q;                              // this wave's row tiles: t0 + TS r
+  const int tile_rows = L;
+  const int64_t row0 = (int64_t)grp * L;
+  const int nl = a.nl;
+  const int it_end = (nl + 1) * 36;
+
+  for (int e = tid; e < TW_ROWS; e += 512) {
+    toks[e] = e < tile_rows ? (int)a.x[row0 + e] : -1;
+    rpos[e] = e < tile_rows ? e : -(1 << 20);
+  }
+  for (int e = tid; e < BB_AP; e += 512) { smem[e] = 0.0f; img[TW_ROWS * BB_AP + e] = 0.0f; }
+  if (tid == 0) {
+#pragma unroll
+    for (int i = 0; i < BB_MAXL; ++i) sdil[i] = a.dil[i];
+    sdil[BB_MAXL] = 1;
+  }
+  for (int e = tid; e < 9 * 5 * BB_C; e += 512) Bs[e] = a.table0[e];
+  __syncthreads();
+  for (int k = tid; k < it_end; k += 512) {               // the schedule of backbone_kernel<true>
+    auto entry = [&](int kk) {
+      const int layer = kk / 36, t = kk % 9;
+      if (layer >= nl) return t == 4 ? 0x1fff : 0;
+      const int d = (t - 4) * sdil[layer];
+      const int lo = d < 0 ? -d : 0, hi = d > 0 ? L - d : L;
+      if (lo >= hi) return 0;
+      int m = 0;
+      for (int r = 0; r < TW_RT; ++r) if (lo < 16 * r + 16 && hi > 16 * r) m |= 1 << r;
+      return m;
+    };
+    const int m = entry(k);
+    int nx = k + 1;
+    while (nx < it_end && entry(nx) == 0) ++nx;
+    sched[k] = m ? (m | ((k % 36) / 9) << 13 | (k % 9) << 15 | nx << 19) : 0;
+  }
+
+  f32x4 f[NR][2], acc[NR][2];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    const int col = col0 + 16 * ct;
+    const float b0 = a.vec[col];
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int row = 16 * (t0 + TS * r) + 4 * g + e;
+        float v = b0;
+        if (row < TW_ROWS) {
+          const int pos = rpos[row];
+#pragma unroll
+          for (int t = 0; t < 9; ++t) {
+            const int pp = pos + t - 4;
+            const int tk = (pp >= 0 && pp < L) ? toks[row + t - 4] : -1;
+            if (tk >= 0) v += Bs[(t * 5 + tk) * BB_C + col];
+          }
+        }
+        f[r][ct][e] = row < tile_rows ? fmaxf(v, 0.0f) : 0.0f;
+      }
+  }
+  __syncthreads();
+
+  const int arow0 = ((16 * t0 + j) * BB_AP + 8 * g) * 4;
+  const int a_lo = arow0 - (16 * t0 + j + 1) * BB_AP * 4;
+  const int a_hi = arow0 + (TW_ROWS - 16 * t0 - j) * BB_AP * 4;
+  const char* imgb = reinterpret_cast<const char*>(img);
+  const float* wsrc = a.tiles + col0 * CH + 8 * g;
+  auto tile_of = [&](int k) { return k < nl * 36 ? k : nl * 36 + (k - nl * 36) / 9; };
+  int it = 0;
+  while (it < it_end && sched[it] == 0) ++it;
+  it = __builtin_amdgcn_readfirstlane(it);
+  int en = __builtin_amdgcn_readfirstlane(sched[it]);
+  float4 bn[4];
+  {
+    const float* src = wsrc + (size_t)tile_of(it) * BB_C * CH;
+    bn[0] = *reinterpret_cast<const float4*>(src);
+    bn[1] = *reinterpret_cast<const float4*>(src + 4);
+    bn[2] = *reinterpret_cast<const float4*>(src + 16 * CH);
+    bn[3] = *reinterpret_cast<const float4*>(src + 16 * CH + 4);
+  }
+  float* const xg = ws.xchg + (size_t)grp * 2 * TW_ROWS * BB_C;      // this group's two scratch images
+  int* const gcnt = ws.cnt + grp;
+
+  for (int layer = 0; layer <= nl; ++layer) {
+    const float* vl = a.vec + (size_t)(layer + 1) * 4 * BB_C;
+    if (layer < nl) {
+      const float tb0 = vl[BB_C + col0], tb1 = vl[BB_C + col0 + 16];
+#pragma unroll
+      for (int r = 0; r < NR; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int row = 16 * (t0 + TS * r) + 4 * g + e;
+          const float sm = group16_sum((f[r][0][e] + tb0) + (f[r][1][e] + tb1));
+          if (j == 0 && row < TW_ROWS) psum[cg * TW_ROWS + row] = sm;
+        }
+      __syncthreads();
+      if (tid < TW_ROWS)
+        rstat[tid] = ((psum[tid] + psum[TW_ROWS + tid]) + (psum[2 * TW_ROWS + tid] + psum[3 * TW_ROWS + tid])) * (1.0f / BB_C);
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        const float4 cur4 = *reinterpret_cast<const float4*>(rstat + min(16 * (t0 + TS * r) + 4 * g, TW_ROWS - 4));
+        const float mean4[4] = {cur4.x, cur4.y, cur4.z, cur4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int row = 16 * (t0 + TS * r) + 4 * g + e;
+          const float mean = mean4[e];
+          const float d0 = f[r][0][e] + tb0 - mean, d1 = f[r][1][e] + tb1 - mean;
+          acc[r][0][e] = d0; acc[r][1][e] = d1;
+          const float sq = group16_sum(d0 * d0 + d1 * d1);
+          if (j == 0 && row < TW_ROWS) psum[cg * TW_ROWS + row] = sq;
+        }
+      }
+      __syncthreads();
+      if (tid < TW_ROWS)
+        rstat[tid] = rsqrtf(((psum[tid] + psum[TW_ROWS + tid]) + (psum[2 * TW_ROWS + tid] + psum[3 * TW_ROWS + tid])) *
+                            (1.0f / BB_C) + 1e-5f);
+      __syncthreads();
+      const float gm0 = vl[2 * BB_C + col0], gm1 = vl[2 * BB_C + col0 + 16];
+      const float bt0 = vl[3 * BB_C + col0], bt1 = vl[3 * BB_C + col0 + 16];
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        const float4 cur4 = *reinterpret_cast<const float4*>(rstat + min(16 * (t0 + TS * r) + 4 * g, TW_ROWS - 4));
+        const float rs4[4] = {cur4.x, cur4.y, cur4.z, cur4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int row = 16 * (t0 + TS * r) + 4 * g + e;
+          if (row < TW_ROWS) {
+            const float rs = rs4[e];
+            img[row * BB_AP + col0] = row < tile_rows ? acc[r][0][e] * rs * gm0 + bt0 : 0.0f;
+            img[row * BB_AP + col0 + 16] = row < tile_rows ? acc[r][1][e] * rs * gm1 + bt1 : 0.0f;
+          }
+        }
+      }
+      // ---- exchange of the LayerNorm'd image: publish the 32-row blocks this workgroup owns (blocks q, q + R, ...), meet,
+      //      fetch the others'. 32 float4 per row; one row per 32 lanes.
+      __syncthreads();
+      float* const xb = xg + (size_t)(layer & 1) * TW_ROWS * BB_C;
+      for (int e = tid; e < NR * 32 * 32; e += 512) {
+        const int c4 = e & 31, rr = e >> 5;
+        const int row = 32 * (q + R * (rr >> 5)) + (rr & 31);
+        if (row < TW_ROWS)
+          *reinterpret_cast<float4*>(xb + (size_t)row * BB_C + 4 * c4) = *reinterpret_cast<const float4*>(img + row * BB_AP + 4 * c4);
+      }
+      __threadfence();                                    // release: the blocks are visible device-wide before the arrival below
+      __syncthreads();
+      if (tid == 0) {
+        __hip_atomic_fetch_add(gcnt, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        const int target = R * (layer + 1);
+        int spins = 0;
+        while (__hip_atomic_load(gcnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+          __builtin_amdgcn_s_sleep(2);
+          if (++spins > (1 << 24)) { *ws.err = 1; break; }  // a member is not resident (a launcher bug): give up, never hang
+        }
+      }
+      __syncthreads();
+      __threadfence();                                    // acquire: no stale lines of the scratch image in this CU's caches
+      for (int e = tid; e < (TW_ROWS / 32 + 1) * 32 * 32; e += 512) {
+        const int c4 = e & 31, row = e >> 5;
+        if (row < TW_ROWS && ((row >> 5) % R) != q)
+          *reinterpret_cast<f32x4*>(img + row * BB_AP + 4 * c4) =
+              __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xb + (size_t)row * BB_C + 4 * c4));
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < NR; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int row = 16 * (t0 + TS * r) + 4 * g + e;
+          if (row < TW_ROWS) { img[row * BB_AP + col0] = f[r][0][e]; img[row * BB_AP + col0 + 16] = f[r][1][e]; }
+        }
+    }
+    const float bl0 = vl[col0], bl1 = vl[col0 + 16];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) { acc[r][0] = f32x4{bl0, bl0, bl0, bl0}; acc[r][1] = f32x4{bl1, bl1, bl1, bl1}; }
+    const int dil = __builtin_amdgcn_readfirstlane(sdil[layer < nl ? layer : BB_MAXL]);
+    const int layer_end = (layer + 1) * 36;
+    __syncthreads();                                      // the image is complete
+#define S_ALOAD(R_, V, COFF, DBYTES)                                                                         \
+      { const int o_ = min(max(arow0 + (DBYTES) + (R_) * (16 * TS * BB_AP * 4), a_lo + (COFF)), a_hi + (COFF)); \
+        const float4* ap_ = reinterpret_cast<const float4*>(imgb + o_);                                      \
+        V[0] = ap_[0]; V[1] = ap_[1]; }
+#define S_MM(R_, U)                                                                                          \
+      __builtin_amdgcn_sched_barrier(0);                                                                     \
+      __builtin_amdgcn_s_waitcnt(0xC07F | (2 << 8));      /* at least two LDS reads (the other set's) were issued after U's */ \
+      if (live & (1 << (TS * (R_)))) {                                                                       \
+        _Pragma("unroll") for (int qq = 0; qq < 2; ++qq) {                                                   \
+          acc[R_][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(U[qq].x, bf0[4 * qq], acc[R_][0], 0, 0, 0);      \
+          acc[R_][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(U[qq].x, bf1[4 * qq], acc[R_][1], 0, 0, 0);      \
+          acc[R_][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(U[qq].y, bf0[4 * qq + 1], acc[R_][0], 0, 0, 0);  \
+          acc[R_][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(U[qq].y, bf1[4 * qq + 1], acc[R_][1], 0, 0, 0);  \
+          acc[R_][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(U[qq].z, bf0[4 * qq + 2], acc[R_][0], 0, 0, 0);  \
+          acc[R_][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(U[qq].z, bf1[4 * qq + 2], acc[R_][1], 0, 0, 0);  \
+          acc[R_][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(U[qq].w, bf0[4 * qq + 3], acc[R_][0], 0, 0, 0);  \
+          acc[R_][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(U[qq].w, bf1[4 * qq + 3], acc[R_][1], 0, 0, 0);  \
+        }                                                                                                    \
+      }                                                                                                      \
+      __builtin_amdgcn_sched_barrier(0);
+#define S_PARAMS(EN, COFF, DBYTES)                                                                           \
+      const int COFF = (((EN) >> 13) & 3) * (CH * 4);                                                        \
+      const int DBYTES = ((((EN) >> 15) & 15) - 4) * dil * (BB_AP * 4) + COFF;
+    float4 ua[2], ub[2];
+    if (it < layer_end) {
+      S_PARAMS(en, coff0, dbytes0)
+      S_ALOAD(0, ua, coff0, dbytes0)
+      S_ALOAD(1, ub, coff0, dbytes0)
+    }
+    while (it < layer_end) {
+      const int nxt = en >> 19;
+      const int en_next_v = sched[nxt < it_end ? nxt : it];
+      const float bf0[8] = {bn[0].x, bn[0].y, bn[0].z, bn[0].w, bn[1].x, bn[1].y, bn[1].z, bn[1].w};
+      const float bf1[8] = {bn[2].x, bn[2].y, bn[2].z, bn[2].w, bn[3].x, bn[3].y, bn[3].z, bn[3].w};
+      if (nxt < it_end) {
+        const float* src = wsrc + (size_t)tile_of(nxt) * BB_C * CH;
+        bn[0] = *reinterpret_cast<const float4*>(src);
+        bn[1] = *reinterpret_cast<const float4*>(src + 4);
+        bn[2] = *reinterpret_cast<const float4*>(src + 16 * CH);
+        bn[3] = *reinterpret_cast<const float4*>(src + 16 * CH + 4);
+      }
+      S_PARAMS(en, coff, dbytes)
+      const int live = (en & 0x1fff) >> t0;               // bit TS r = owned tile r (tiles >= 13 do not exist)
+      S_MM(0, ua)
+      const int en2 = __builtin_amdgcn_readfirstlane(en_next_v);
+      S_PARAMS(en2, coff2, dbytes2)
+      if constexpr (NR == 2) {
+        S_ALOAD(0, ua, coff2, dbytes2)
+        S_MM(1, ub)
+        S_ALOAD(1, ub, coff2, dbytes2)
+      } else {
+        S_ALOAD(2, ua, coff, dbytes)
+        S_MM(1, ub)
+        S_ALOAD(3, ub, coff, dbytes)
+        S_MM(2, ua)
+        S_ALOAD(0, ua, coff2, dbytes2)
+        S_MM(3, ub)
+        S_ALOAD(1, ub, coff2, dbytes2)
+      }
+      it = nxt;
+      en = en2;
+    }
+#undef S_PARAMS
+#undef S_MM
+#undef S_ALOAD
+    __syncthreads();
+    if (layer < nl) {
+#pragma unroll
+      for (int r = 0; r < NR; ++r)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) f[r][ct][e] = fmaxf(acc[r][ct][e], 0.0f) + f[r][ct][e];
+    } else {
+#pragma unroll
+      for (int r = 0; r < NR; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int row = 16 * (t0 + TS * r) + 4 * g + e;
+          if (row < TW_ROWS) {
+            img[row * BB_AP + col0] = fmaxf(acc[r][0][e], 0.0f);
+            img[row * BB_AP + col0 + 16] = fmaxf(acc[r][1][e], 0.0f);
+          }
+        }
+    }
+  }
+  __syncthreads();
+  // ---- last 1x1 conv 128 -> 5 on the rows this workgroup owns
+  for (int e = tid; e < NR * 32 * 5; e += 512) {
+    const int rr = e / 5, v = e - 5 * rr;
+    const int row = 32 * (q + R * (rr >> 5)) + (rr & 31);
+    if (row >= tile_rows) continue;
+    const float* hr = img + row * BB_AP;
+    const float* wv = a.w2 + v * BB_C;
+    float sm = a.w2[5 * BB_C + v];
+#pragma unroll 8
+    for (int k = 0; k < BB_C; ++k) sm += hr[k] * wv[k];
+    a.out[(row0 + row) * 5 + v] = sm;
+  }
+}
+
 // ------------------------------------------------------- value-net tail: everything after the GRU in one pass ----
 // score[n][t] = b_eff[t] + mean_l sum_c w_eff[c][t] * relu(b1[c] + sum_k W1[c][k] * LayerNorm(h_fwd + h_bwd)[n][l][k])
 // (reference Enformer.py:1617 direction sum, :2010-2047 FeedForwardBlock LayerNorm -> Linear 64->128 -> ReLU ->
@@ -1978,6 +2294,30 @@ extern "C" int svdd_conv_tower_f32(const float* onehot, const float* tiles, cons
   return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
 }
 
+// Scratch of backbone_split_kernel, owned by the caller (the library never allocates): `bytes` of device memory =
+// groups * (2 * 208 * 128 floats) for the double-buffered LayerNorm images + groups + 1 ints (arrival counters, error flag).
+// One workspace per process: launches that use it must not overlap (the engine issues its backbone forwards on one stream).
+static BackboneSplitWs g_bb_ws = {nullptr, nullptr, nullptr, 0};
+static int g_bb_split = 0;            // svdd_set_option(SVDD_OPT_BACKBONE_SPLIT): 0 auto, 1 off, 2 / 4 force R where it fits
+extern "C" void svdd_internal_set_bb_split(int v) { g_bb_split = (v == 1 || v == 2 || v == 4) ? v : 0; }
+extern "C" int svdd_backbone_set_workspace(void* ws, long long bytes) {
+  const long long per = (long long)2 * TW_ROWS * BB_C * sizeof(float) + sizeof(int);
+  if (!ws || bytes < per + (long long)sizeof(int)) { g_bb_ws = {nullptr, nullptr, nullptr, 0}; return ws ? SVDD_E_ARG : SVDD_OK; }
+  const int groups = (int)((bytes - (long long)sizeof(int)) / per);
+  g_bb_ws.xchg = reinterpret_cast<float*>(ws);
+  g_bb_ws.cnt = reinterpret_cast<int*>(reinterpret_cast<char*>(ws) + (size_t)groups * 2 * TW_ROWS * BB_C * sizeof(float));
+  g_bb_ws.err = g_bb_ws.cnt + groups;
+  g_bb_ws.groups = groups;
+  return hipMemset(g_bb_ws.err, 0, sizeof(int)) == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
+}
+// 0 = every group barrier of every split launch so far was met; 1 = one timed out (results of that launch are invalid). Synchronises.
+extern "C" int svdd_backbone_split_status(int* err_out) {
+  if (!err_out) return SVDD_E_ARG;
+  *err_out = 0;
+  if (!g_bb_ws.err) return SVDD_OK;
+  return hipMemcpy(err_out, g_bb_ws.err, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
+}
+
 extern "C" int svdd_backbone_cnn_f32(const uint8_t* x, const float* table0, const float* tiles, const float* vec,
                                      const float* w2, float* out, int n, int L, int nlayers, const int* dilations,
                                      const int32_t* count, const int32_t* row_idx, int out_scatter, void* stream) {
@@ -2000,6 +2340,24 @@ extern "C" int svdd_backbone_cnn_f32(const uint8_t* x, const float* table0, cons
                                       3 * (size_t)TW_ROWS + BB_MAXL + 1 + (size_t)(nlayers + 1) * 36);
   hipEvent_t e0, e1;
   svdd_internal_timed_events(6, &e0, &e1);
+  // Small batches of one-sequence tiles: R = 2 / 4 workgroups per sequence (backbone_split_kernel; same bits). Needs the scratch
+  // image of svdd_backbone_set_workspace, a row count known on the host (no device-side count / index list) and n R <= CUs
+  // (every member of a group must be resident: they wait for each other).
+  if (a.spt == 1 && !a.auto_spt && TW_ROWS / L == 1 && !count && !row_idx && g_bb_ws.xchg && g_bb_split != 1) {
+    int R = g_bb_split == 2 || g_bb_split == 4 ? g_bb_split : (4 * n <= a.ncu ? 4 : 2 * n <= a.ncu ? 2 : 1);
+    if (R > 1 && (int64_t)R * n <= a.ncu && n <= g_bb_ws.groups) {
+      if (hipMemsetAsync(g_bb_ws.cnt, 0, sizeof(int) * (size_t)n, (hipStream_t)stream) != hipSuccess) return SVDD_E_LAUNCH;
+      const dim3 sgrid((unsigned)(((n + 7) / 8) * 8 * R));
+      if (R == 2) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(backbone_split_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipExtLaunchKernelGGL(backbone_split_kernel<2>, sgrid, dim3(512), lds, (hipStream_t)stream, e0, e1, 0, a, g_bb_ws);
+      } else {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(backbone_split_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipExtLaunchKernelGGL(backbone_split_kernel<4>, sgrid, dim3(512), lds, (hipStream_t)stream, e0, e1, 0, a, g_bb_ws);
+      }
+      return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
+    }
+  }
   const dim3 grid(nwg);
   if (a.spt == 1 && !a.auto_spt) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(backbone_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -40,11 +40,15 @@ extern "C" void svdd_internal_set_trunk_gemm_version(int v) {
   if (v >= 21 && v <= 36) g_trunk_gemm_big_div = v - 20;
 }
 
+// svdd_set_option(SVDD_OPT_TRUNK_PLANES_F32, 1): the operand planes are ONE fp32 plane (a_hi / out_hi point at floats, a_lo / out_lo
+// must be NULL) and the GEMM multiplies on v_mfma_f32_16x16x4_f32 — the trunk at the reference's own precision (round 4).
+static int g_trunk_planes_f32 = 0;
+extern "C" void svdd_internal_set_trunk_planes_f32(int v) { g_trunk_planes_f32 = v ? 1 : 0; }
+
 namespace {
 
 typedef __bf16 bf16_t;
 typedef b8 BV8;
-typedef float f32x8_t __attribute__((ext_vector_type(8)));
 
 constexpr int G_BM = 128, G_BN = 128, G_BK = 32;
 constexpr int G_AS = 40;                   // halves per LDS row of the A tile (80 B: 64 B of data + 16 B pad)
@@ -65,9 +69,53 @@ struct GemmArgs {
   // rows at either end of every sequence (what a separate svdd_trunk_act_split pass over y would write)
   bf16_t* o_hi; bf16_t* o_lo; const float* p_scale; const float* p_shift; int p_act, pad;
   int dbg;
+  int f32;                                 // planes are fp32 (a_hi / o_hi are float*, no lo planes; lda / N in floats)
 };
 
+// ---- operand-plane stores, by plane format: (hi, lo) bf16 halves of an fp32 value, or the fp32 value itself
+typedef float f32x8_t __attribute__((ext_vector_type(8)));
 typedef bf16_t BV4 __attribute__((ext_vector_type(4)));
+template <bool F32>
+__device__ __forceinline__ void plane_store8(bf16_t* hi, bf16_t* lo, size_t at, f32x8_t v) {
+  if constexpr (F32) {
+    float* p = reinterpret_cast<float*>(hi) + at;
+    *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
+  } else {
+    const BV8 h = __builtin_convertvector(v, BV8);
+    *reinterpret_cast<BV8*>(hi + at) = h;
+    if (lo) *reinterpret_cast<BV8*>(lo + at) = __builtin_convertvector(v - __builtin_convertvector(h, f32x8_t), BV8);
+  }
+}
+template <bool F32>
+__device__ __forceinline__ void plane_store4(bf16_t* hi, bf16_t* lo, size_t at, f32x4 v) {
+  if constexpr (F32) {
+    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(hi) + at) = v;
+  } else {
+    const BV4 h = __builtin_convertvector(v, BV4);
+    *reinterpret_cast<BV4*>(hi + at) = h;
+    if (lo) *reinterpret_cast<BV4*>(lo + at) = __builtin_convertvector(v - __builtin_convertvector(h, f32x4), BV4);
+  }
+}
+template <bool F32>
+__device__ __forceinline__ void plane_store1(bf16_t* hi, bf16_t* lo, size_t at, float o) {
+  if constexpr (F32) {
+    reinterpret_cast<float*>(hi)[at] = o;
+  } else {
+    const bf16_t hb = (bf16_t)o;
+    hi[at] = hb;
+    if (lo) lo[at] = (bf16_t)(o - (float)hb);
+  }
+}
+template <bool F32>
+__device__ __forceinline__ void plane_copy4(bf16_t* hi, bf16_t* lo, size_t at, const bf16_t* shi, const bf16_t* slo, size_t sat) {
+  if constexpr (F32) {
+    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(hi) + at) = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(shi) + sat);
+  } else {
+    *reinterpret_cast<BV4*>(hi + at) = *reinterpret_cast<const BV4*>(shi + sat);
+    if (lo) *reinterpret_cast<BV4*>(lo + at) = *reinterpret_cast<const BV4*>(slo + sat);
+  }
+}
 
 // Epilogue of four adjacent columns of one row, shared by both GEMM kernels: y = act(acc + bias) (+ resid) -> fp32 out
 // (if any) and / or the operand planes of the next GEMM.
@@ -81,9 +129,8 @@ __device__ __forceinline__ void gemm_store4(const GemmArgs& a, int row, int col,
     f32x4 t = v * ps4 + pb4;
 #pragma unroll
     for (int e = 0; e < 4; ++e) t[e] = pad_row ? 0.0f : apply_act(a.p_scale ? t[e] : v[e], a.p_act);
-    const BV4 h = __builtin_convertvector(t, BV4);
-    *reinterpret_cast<BV4*>(a.o_hi + (size_t)row * a.N + col) = h;
-    if (a.o_lo) *reinterpret_cast<BV4*>(a.o_lo + (size_t)row * a.N + col) = __builtin_convertvector(t - __builtin_convertvector(h, f32x4), BV4);
+    if (a.f32) plane_store4<true>(a.o_hi, nullptr, (size_t)row * a.N + col, t);
+    else plane_store4<false>(a.o_hi, a.o_lo, (size_t)row * a.N + col, t);
   }
 }
 __device__ __forceinline__ bool gemm_pad_row(const GemmArgs& a, int row) {
@@ -231,8 +278,15 @@ __global__ __launch_bounds__(256, 2) void trunk_gemm_kernel(GemmArgs a) {
 // N need not be a multiple of 256: in a last, half-wide column block the waves with wn >= 2 only stage and synchronise.
 constexpr int H_BM = 256, H_BN = 256;
 
-template <int NPARTS>
+// F32 (round 4; NPARTS = 2): the operand is ONE fp32 plane. A 16-row x 32-column fp32 sub-tile is 2 KB = the two 1 KB pieces
+// that the (hi, lo) pair of a bf16 sub-tile occupies, so stages, DMA and barriers are the x3 kernel's; piece p of lane (j, g)
+// holds floats 8 g + 4 p .. + 3 of row j (the weights are packed the same way), and the 8 MFMA steps of a 32-wide K block
+// multiply k = 8 g + 4 p + e on v_mfma_f32_16x16x4_f32 (the instruction sums over the four lane groups g: every k once).
+// 128 MFMAs of 32 cycles per compute segment instead of 48 of 16: the K loop is matrix-pipe bound.
+template <int NPARTS, bool F32 = false>
 __global__ __launch_bounds__(512, 2) void trunk_gemm256_kernel(GemmArgs a) {
+  static_assert(!F32 || NPARTS == 2, "fp32 planes: two 16-byte pieces per lane");
+  constexpr int ES = F32 ? 4 : 2;                            // bytes per operand element
   extern __shared__ __attribute__((aligned(1024))) char hsm[];
   constexpr int SUB_B = 1024;                               // one 16 x 32 sub-tile of one part
   constexpr int OPER_B = 16 * NPARTS * SUB_B;               // the 16 sub-tiles of an operand: [sub][part][1 KB]
@@ -260,13 +314,13 @@ __global__ __launch_bounds__(512, 2) void trunk_gemm256_kernel(GemmArgs a) {
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) acc[i][nt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
   // DMA sources: wave w stages the A sub-tiles 2 w, 2 w + 1 (rows m0 + 32 w ..) and the W sub-tiles 2 w, 2 w + 1
-  const bf16_t* asrc[2];
+  const char* asrc[2];
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     const int row = min(m0 + 16 * (2 * w + q) + j, a.M - 1);
-    asrc[q] = a.a_hi + (int64_t)row * a.lda + 8 * g;
+    asrc[q] = reinterpret_cast<const char*>(a.a_hi) + ((int64_t)row * a.lda + 8 * g) * ES;
   }
-  const int64_t lo_off = NPARTS == 2 ? a.a_lo - a.a_hi : 0;
+  const int64_t lo_off = F32 ? 16 : (NPARTS == 2 ? (a.a_lo - a.a_hi) * 2 : 0);   // bytes from part / piece 0 to 1
   const BV8* wsrc = a.w + ((size_t)(2 * nb + (w >> 2)) * 8 + ((2 * w) & 7)) * (NPARTS * 64) + lane;
   const size_t wstep = (size_t)NB128 * 8 * NPARTS * 64;      // V8s per K block
   char* const stage_a = hsm + (2 * w) * NPARTS * SUB_B;
@@ -280,7 +334,7 @@ __global__ __launch_bounds__(512, 2) void trunk_gemm256_kernel(GemmArgs a) {
 #define H_DMA_A(KB_, ABUF)                                                                                   \
   { const int kb_ = (KB_);                                                                                   \
     const int c_ = kb_ / a.T, t_ = kb_ - c_ * a.T;                                                           \
-    const int64_t koff_ = (int64_t)(t_ - a.T / 2) * a.lda + 32 * c_;                                         \
+    const int64_t koff_ = ((int64_t)(t_ - a.T / 2) * a.lda + 32 * c_) * ES;                                  \
     _Pragma("unroll") for (int q = 0; q < 2; ++q)                                                            \
       _Pragma("unroll") for (int p = 0; p < NPARTS; ++p)                                                     \
         __builtin_amdgcn_global_load_lds((glb_ptr_t)(asrc[q] + koff_ + p * lo_off),                          \
@@ -294,29 +348,38 @@ __global__ __launch_bounds__(512, 2) void trunk_gemm256_kernel(GemmArgs a) {
   }
   const char* const frag_a = hsm + (8 * wm) * NPARTS * SUB_B + 16 * lane;
   const char* const frag_w = hsm + W_BASE + (4 * wn) * NPARTS * SUB_B + 16 * lane;
-  BV8 bf[4][NPARTS], af[4][NPARTS];
+  f32x4 bf[4][NPARTS], af[4][NPARTS];                       // 16-byte fragments: 8 bf16, or 4 floats (F32)
 #define H_READ_W(WBUF)                                                                                       \
   _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                           \
     _Pragma("unroll") for (int p = 0; p < NPARTS; ++p)                                                       \
-      bf[nt][p] = *reinterpret_cast<const BV8*>(frag_w + (WBUF) * OPER_B + (nt * NPARTS + p) * SUB_B);
+      bf[nt][p] = *reinterpret_cast<const f32x4*>(frag_w + (WBUF) * OPER_B + (nt * NPARTS + p) * SUB_B);
 #define H_READ_A(ABUF, H)                                                                                    \
   _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                              \
     _Pragma("unroll") for (int p = 0; p < NPARTS; ++p)                                                       \
-      af[i][p] = *reinterpret_cast<const BV8*>(frag_a + (ABUF) * OPER_B + ((4 * (H) + i) * NPARTS + p) * SUB_B);
+      af[i][p] = *reinterpret_cast<const f32x4*>(frag_a + (ABUF) * OPER_B + ((4 * (H) + i) * NPARTS + p) * SUB_B);
   // the three passes of a product go to the same accumulator: 16 independent MFMAs between dependent ones
+#define H_BF(V) __builtin_bit_cast(BV8, V)
 #define H_MFMA(H)                                                                                            \
   if (cols_ok) {                                                                                             \
     __builtin_amdgcn_s_setprio(1);                                                                           \
+    if constexpr (F32) {                                                                                     \
+      _Pragma("unroll") for (int p = 0; p < 2; ++p)                                                          \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                        \
+          _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                      \
+            _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                 \
+              acc[4 * (H) + i][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[nt][p][e], af[i][p][e], acc[4 * (H) + i][nt], 0, 0, 0); \
+    } else {                                                                                                 \
     _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                            \
       _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                       \
-        acc[4 * (H) + i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[nt][0], af[i][0], acc[4 * (H) + i][nt], 0, 0, 0); \
+        acc[4 * (H) + i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(H_BF(bf[nt][0]), H_BF(af[i][0]), acc[4 * (H) + i][nt], 0, 0, 0); \
     if constexpr (NPARTS == 2) {                                                                             \
       _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                          \
         _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                     \
-          acc[4 * (H) + i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[nt][1], af[i][0], acc[4 * (H) + i][nt], 0, 0, 0); \
+          acc[4 * (H) + i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(H_BF(bf[nt][1]), H_BF(af[i][0]), acc[4 * (H) + i][nt], 0, 0, 0); \
       _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                          \
         _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                     \
-          acc[4 * (H) + i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[nt][0], af[i][1], acc[4 * (H) + i][nt], 0, 0, 0); \
+          acc[4 * (H) + i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(H_BF(bf[nt][0]), H_BF(af[i][1]), acc[4 * (H) + i][nt], 0, 0, 0); \
+    }                                                                                                        \
     }                                                                                                        \
     __builtin_amdgcn_s_setprio(0);                                                                           \
   }
@@ -364,6 +427,7 @@ __global__ __launch_bounds__(512, 2) void trunk_gemm256_kernel(GemmArgs a) {
 #undef H_KBLOCK
 #undef H_BARRIER
 #undef H_MFMA
+#undef H_BF
 #undef H_READ_A
 #undef H_READ_W
 #undef H_DMA_W
@@ -409,6 +473,7 @@ struct ActArgs {
   const float* x; const float* scale; const float* shift; int act; int64_t rows; int C, rows_per_seq, pad;
   bf16_t* hi; bf16_t* lo; const int* count;
 };
+template <bool F32>
 __global__ __launch_bounds__(256) void trunk_act_split_kernel(ActArgs a) {
   const int64_t live = a.count ? min(a.rows, (int64_t)*a.count * a.rows_per_seq) : a.rows;
   const int c8 = a.C >> 3;
@@ -431,14 +496,13 @@ __global__ __launch_bounds__(256) void trunk_act_split_kernel(ActArgs a) {
       v[e] = apply_act(t, a.act);
     }
   }
-  const BV8 h = __builtin_convertvector(v, BV8);
-  *reinterpret_cast<BV8*>(a.hi + row * a.C + c) = h;
-  if (a.lo) *reinterpret_cast<BV8*>(a.lo + row * a.C + c) = __builtin_convertvector(v - __builtin_convertvector(h, f32x8_t), BV8);
+  plane_store8<F32>(a.hi, a.lo, (size_t)(row * a.C + c), v);
 }
 
 // LayerNorm over a row of C <= 4096 channels (two-pass mean / centred variance, like ATen) -> (hi, lo) planes.
 // One wave per row; lane l holds channels 8 (l + 64 q) .. + 7.
 struct LnArgs { const float* x; const float* gamma; const float* beta; float eps; int64_t rows; int C; bf16_t* hi; bf16_t* lo; const int* count; int rows_per_seq; };
+template <bool F32>
 __global__ __launch_bounds__(256) void trunk_ln_split_kernel(LnArgs a) {
   const int64_t live = a.count ? min(a.rows, (int64_t)*a.count * a.rows_per_seq) : a.rows;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -483,9 +547,7 @@ __global__ __launch_bounds__(256) void trunk_ln_split_kernel(LnArgs a) {
       f32x8_t o;
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] = (v[q][e] - mean) * rs * a.gamma[c + e] + a.beta[c + e];
-      const BV8 h = __builtin_convertvector(o, BV8);
-      *reinterpret_cast<BV8*>(a.hi + row * a.C + c) = h;
-      if (a.lo) *reinterpret_cast<BV8*>(a.lo + row * a.C + c) = __builtin_convertvector(o - __builtin_convertvector(h, f32x8_t), BV8);
+      plane_store8<F32>(a.hi, a.lo, (size_t)(row * a.C + c), o);
     }
   }
 }
@@ -496,6 +558,7 @@ __global__ __launch_bounds__(256) void trunk_ln_split_kernel(LnArgs a) {
 // GEMM, act(scale o + shift) -> (hi, lo), INCLUDING zeroed pad rows (what svdd_trunk_act_split would write from the fp32 rows).
 struct PoolArgs { const float* x; const float* logits; int n, L, C; float* out; const int* count;
                   bf16_t* hi; bf16_t* lo; const float* scale; const float* shift; int act; };
+template <bool F32>
 __global__ __launch_bounds__(256) void trunk_attn_pool_kernel(PoolArgs a) {
   const int nlive = a.count ? min(a.n, *a.count) : a.n;
   const int Lo = (a.L + 1) / 2, c4 = a.C >> 2;
@@ -529,9 +592,7 @@ __global__ __launch_bounds__(256) void trunk_attn_pool_kernel(PoolArgs a) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) tt[e] = apply_act(a.scale ? o[e] * a.scale[c + e] + a.shift[c + e] : o[e], a.act);
     }
-    const BV4 h = __builtin_convertvector(tt, BV4);
-    *reinterpret_cast<BV4*>(a.hi + orow * a.C + c) = h;
-    if (a.lo) *reinterpret_cast<BV4*>(a.lo + orow * a.C + c) = __builtin_convertvector(tt - __builtin_convertvector(h, f32x4), BV4);
+    plane_store4<F32>(a.hi, a.lo, (size_t)(orow * a.C + c), tt);
   }
 }
 
@@ -545,7 +606,7 @@ struct AttnArgs {
   const float* qkv; const float* rel_k; const float* content_bias; const float* pos_bias;
   int n, h, dk, dv, ld; float scale; bf16_t* hi; bf16_t* lo; const int* count;
 };
-template <int T>
+template <int T, bool F32>
 __global__ __launch_bounds__(256) void trunk_attn_small_kernel(AttnArgs a) {
   const int nlive = a.count ? min(a.n, *a.count) : a.n;
   const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -602,9 +663,7 @@ __global__ __launch_bounds__(256) void trunk_attn_small_kernel(AttnArgs a) {
 #pragma unroll
       for (int jj = 0; jj < T; ++jj) o += pr[i][jj] * vv[jj];
       const size_t at = ((size_t)b * T + i) * ldo + hd * a.dv + c;
-      const bf16_t hb = (bf16_t)o;
-      a.hi[at] = hb;
-      if (a.lo) a.lo[at] = (bf16_t)(o - (float)hb);
+      plane_store1<F32>(a.hi, a.lo, at, o);
     }
   }
 }
@@ -612,6 +671,7 @@ __global__ __launch_bounds__(256) void trunk_attn_small_kernel(AttnArgs a) {
 // Stem operand: row (b, l) of the padded layout gets the 64 channels [tap t = 0..14][one-hot 4] (+ 4 zeros) of the k = 15
 // convolution: channel 4 t + tok[l + t - 7]. Exact in bf16, so the stem GEMM needs A_hi x (W_hi + W_lo) only.
 struct StemArgs { const uint8_t* tok; int n, L; bf16_t* hi; const int* count; };
+template <bool F32>
 __global__ __launch_bounds__(256) void trunk_stem_unfold_kernel(StemArgs a) {
   const int nlive = a.count ? min(a.n, *a.count) : a.n;
   const int Lp = a.L + 2;
@@ -621,20 +681,20 @@ __global__ __launch_bounds__(256) void trunk_stem_unfold_kernel(StemArgs a) {
   const int64_t row = idx >> 3;
   const int pos = (int)(row % Lp);
   const int64_t b = row / Lp;
-  BV8 v;
+  f32x8_t v;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) v[e] = (bf16_t)0.0f;
+  for (int e = 0; e < 8; ++e) v[e] = 0.0f;
   if (pos >= 0 && pos < a.L) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int t = 2 * q + h, p = pos + t - 7;
       if (t < 15 && p >= 0 && p < a.L) {
         const int tk = a.tok[b * a.L + p];
-        if (tk < 4) v[4 * h + tk] = (bf16_t)1.0f;
+        if (tk < 4) v[4 * h + tk] = 1.0f;
       }
     }
   }
-  *reinterpret_cast<BV8*>(a.hi + row * 64 + 8 * q) = v;
+  plane_store8<F32>(a.hi, nullptr, (size_t)(row * 64 + 8 * q), v);
 }
 
 // ---- first level shared between a candidate and its parent (exact) ------------------------------------------------------
@@ -707,6 +767,7 @@ __global__ __launch_bounds__(256) void trunk_windows_kernel(WinArgs a) {
 }
 
 struct StemWinArgs { const uint8_t* tok; int n, L, K; const int* w0; const int* wlen; const int* off; bf16_t* hi; const int* count; };
+template <bool F32>
 __global__ __launch_bounds__(256) void trunk_stem_unfold_win_kernel(StemWinArgs a) {
   const int nlive = a.count ? min(a.n, *a.count) : a.n;
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;       // one thread = 8 channels (two taps) of one row
@@ -723,24 +784,25 @@ __global__ __launch_bounds__(256) void trunk_stem_unfold_win_kernel(StemWinArgs 
     r -= wl;
   }
   if (pos < 0) return;
-  BV8 v;
+  f32x8_t v;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) v[e] = (bf16_t)0.0f;
+  for (int e = 0; e < 8; ++e) v[e] = 0.0f;
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const int tp = 2 * q + h, p = pos + tp - 7;
     if (tp < 15 && p >= 0 && p < a.L) {
       const int tk = a.tok[b * a.L + p];
-      if (tk < 4) v[4 * h + tk] = (bf16_t)1.0f;
+      if (tk < 4) v[4 * h + tk] = 1.0f;
     }
   }
-  *reinterpret_cast<BV8*>(a.hi + row * 64 + 8 * q) = v;
+  plane_store8<F32>(a.hi, nullptr, (size_t)(row * 64 + 8 * q), v);
 }
 
 struct PoolWinArgs { const float* x; const float* logits; int n, L, C, in_halo, K; const int* w0; const int* wlen; const int* off;
                      const int* pidx; int div; const bf16_t* p_hi; const bf16_t* p_lo; const int* count;
                      bf16_t* hi; bf16_t* lo; const float* scale; const float* shift; int act;
                      const int* v0; const int* vlen; const int* off2; };
+template <bool F32>
 __global__ __launch_bounds__(256) void trunk_attn_pool_win_kernel(PoolWinArgs a) {
   // one workgroup per live candidate: it walks the candidate's output rows (a grid over the upper bound of rows per candidate
   // was 85 M threads for 0.4 M rows at the first level: 0.33 ms per launch)
@@ -790,14 +852,11 @@ __global__ __launch_bounds__(256) void trunk_attn_pool_win_kernel(PoolWinArgs a)
     f32x4 tt;
 #pragma unroll
     for (int e = 0; e < 4; ++e) tt[e] = apply_act(a.scale ? o[e] * a.scale[c + e] + a.shift[c + e] : o[e], a.act);
-    const BV4 h = __builtin_convertvector(tt, BV4);
-    *reinterpret_cast<BV4*>(a.hi + orow * a.C + c) = h;
-    if (a.lo) *reinterpret_cast<BV4*>(a.lo + orow * a.C + c) = __builtin_convertvector(tt - __builtin_convertvector(h, f32x4), BV4);
+    plane_store4<F32>(a.hi, a.lo, (size_t)(orow * a.C + c), tt);
   } else {                                                   // the parent's row (its pad rows are zero: also what lies outside the sequence)
     const int ip = i < 0 ? Lo : min(i, Lo);
     const int64_t prow = (int64_t)(a.pidx[b] / a.div) * (Lo + 2) + ip;
-    *reinterpret_cast<BV4*>(a.hi + orow * a.C + c) = *reinterpret_cast<const BV4*>(a.p_hi + prow * a.C + c);
-    if (a.lo) *reinterpret_cast<BV4*>(a.lo + orow * a.C + c) = *reinterpret_cast<const BV4*>(a.p_lo + prow * a.C + c);
+    plane_copy4<F32>(a.hi, a.lo, (size_t)(orow * a.C + c), a.p_hi, a.p_lo, (size_t)(prow * a.C + c));
   }
   }
 }
@@ -816,7 +875,18 @@ int svdd_trunk_gemm(const void* a_hi, const void* a_lo, const void* w, const flo
       out_hi == a_hi || (out_lo && out_lo == a_lo))
     return SVDD_E_ARG;
   GemmArgs a{(const bf16_t*)a_hi, (const bf16_t*)a_lo, (const BV8*)w, bias, resid, out, M, N, T * (Cin / G_BK), Cin / G_BK, T,
-             lda, ldo, act, count, rows_per_seq, (bf16_t*)out_hi, (bf16_t*)out_lo, post_scale, post_shift, post_act, pad, g_trunk_gemm_dbg};
+             lda, ldo, act, count, rows_per_seq, (bf16_t*)out_hi, (bf16_t*)out_lo, post_scale, post_shift, post_act, pad, g_trunk_gemm_dbg,
+             g_trunk_planes_f32};
+  if (g_trunk_planes_f32) {
+    // fp32 planes: one plane, fp32 MFMA, always the 256 x 256 LDS-DMA kernel (its K loop is matrix-pipe bound at any tile count)
+    if (a_lo || out_lo) return SVDD_E_ARG;
+    const int mb2 = (M + H_BM - 1) / H_BM, nb2 = (N + H_BN - 1) / H_BN;
+    const dim3 grid((unsigned)(((mb2 + 7) / 8) * 8 * nb2));
+    constexpr int lds = 5 * 16 * 2 * 1024;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(trunk_gemm256_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL((trunk_gemm256_kernel<2, true>), grid, dim3(512), lds, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
+  }
   // 256 x 256 tiles from half a chip's worth of tiles on (the 7680-row GEMMs of the transformer tower make 180 - 360 of them and
   // still run 2.3x faster than on 128 x 128 tiles: 0.79 - 0.98 vs 0.37 - 0.42 PFLOP/s); the 128 x 128 kernel below that
   const int mb2 = (M + H_BM - 1) / H_BM, nb2 = (N + H_BN - 1) / H_BN;
@@ -849,7 +919,8 @@ int svdd_trunk_act_split(const float* x, const float* scale, const float* shift,
     return SVDD_E_ARG;
   ActArgs a{x, scale, shift, act, rows, C, rows_per_seq, pad, (bf16_t*)hi, (bf16_t*)lo, count};
   const int64_t nthr = rows * (C >> 3);
-  hipLaunchKernelGGL(trunk_act_split_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  if (g_trunk_planes_f32) hipLaunchKernelGGL(trunk_act_split_kernel<true>, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(trunk_act_split_kernel<false>, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
 }
 
@@ -857,7 +928,8 @@ int svdd_trunk_layernorm_split(const float* x, const float* gamma, const float* 
                                void* hi, void* lo, const int32_t* count, int rows_per_seq, void* stream) {
   if (!x || !gamma || !beta || !hi || rows <= 0 || C <= 0 || (C & 7) || C > 4096 || (count && rows_per_seq <= 0)) return SVDD_E_ARG;
   LnArgs a{x, gamma, beta, eps, rows, C, (bf16_t*)hi, (bf16_t*)lo, count, rows_per_seq};
-  hipLaunchKernelGGL(trunk_ln_split_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
+  if (g_trunk_planes_f32) hipLaunchKernelGGL(trunk_ln_split_kernel<true>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(trunk_ln_split_kernel<false>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
   return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
 }
 
@@ -868,7 +940,8 @@ int svdd_trunk_attn_pool(const float* x, const float* logits, int n, int L, int 
     return SVDD_E_ARG;
   PoolArgs a{x, logits, n, L, C, out, count, (bf16_t*)out_hi, (bf16_t*)out_lo, post_scale, post_shift, post_act};
   const int64_t nthr = (int64_t)n * ((L + 1) / 2 + 2) * (C >> 2);
-  hipLaunchKernelGGL(trunk_attn_pool_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  if (g_trunk_planes_f32) hipLaunchKernelGGL(trunk_attn_pool_kernel<true>, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(trunk_attn_pool_kernel<false>, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
 }
 
@@ -879,12 +952,16 @@ int svdd_trunk_attn_small(const float* qkv, const float* rel_k, const float* con
   AttnArgs a{qkv, rel_k, content_bias, pos_bias, n, heads, dk, dv, heads * (2 * dk + dv), 1.0f / sqrtf((float)dk),
              (bf16_t*)hi, (bf16_t*)lo, count};
   const dim3 grid((unsigned)(((int64_t)n * heads + 3) / 4));
+#define SVDD_ATTN(T_)                                                                                                  \
+  if (g_trunk_planes_f32) hipLaunchKernelGGL((trunk_attn_small_kernel<T_, true>), grid, dim3(256), 0, (hipStream_t)stream, a);  \
+  else hipLaunchKernelGGL((trunk_attn_small_kernel<T_, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
   switch (T) {
-    case 1: hipLaunchKernelGGL(trunk_attn_small_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a); break;
-    case 2: hipLaunchKernelGGL(trunk_attn_small_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, a); break;
-    case 3: hipLaunchKernelGGL(trunk_attn_small_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, a); break;
-    default: hipLaunchKernelGGL(trunk_attn_small_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, a); break;
+    case 1: SVDD_ATTN(1) break;
+    case 2: SVDD_ATTN(2) break;
+    case 3: SVDD_ATTN(3) break;
+    default: SVDD_ATTN(4) break;
   }
+#undef SVDD_ATTN
   return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
 }
 
@@ -892,7 +969,8 @@ int svdd_trunk_stem_unfold(const uint8_t* tok, int n, int L, void* hi, const int
   if (!tok || !hi || n <= 0 || L <= 0) return SVDD_E_ARG;
   StemArgs a{tok, n, L, (bf16_t*)hi, count};
   const int64_t nthr = (int64_t)n * (L + 2) * 8;
-  hipLaunchKernelGGL(trunk_stem_unfold_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  if (g_trunk_planes_f32) hipLaunchKernelGGL(trunk_stem_unfold_kernel<true>, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(trunk_stem_unfold_kernel<false>, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
 }
 
@@ -911,7 +989,8 @@ int svdd_trunk_stem_unfold_win(const uint8_t* tok, int n, int L, int slots, cons
   if (!tok || !hi || !w0 || !wlen || !off || n <= 0 || L <= 0 || slots < 1 || slots > WIN_K) return SVDD_E_ARG;
   StemWinArgs a{tok, n, L, slots, w0, wlen, off, (bf16_t*)hi, count};
   const int64_t nthr = (int64_t)n * L * 8;
-  hipLaunchKernelGGL(trunk_stem_unfold_win_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  if (g_trunk_planes_f32) hipLaunchKernelGGL(trunk_stem_unfold_win_kernel<true>, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(trunk_stem_unfold_win_kernel<false>, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
 }
 
@@ -927,7 +1006,8 @@ int svdd_trunk_attn_pool_win(const float* x, const float* logits, int n, int L, 
     return SVDD_E_ARG;
   PoolWinArgs a{x, logits, n, L, C, in_halo, slots, w0, wlen, off, parent_idx, div, (const bf16_t*)parent_hi, (const bf16_t*)parent_lo,
                 count, (bf16_t*)out_hi, (bf16_t*)out_lo, post_scale, post_shift, post_act, v0, vlen, off2};
-  hipLaunchKernelGGL(trunk_attn_pool_win_kernel, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, a);
+  if (g_trunk_planes_f32) hipLaunchKernelGGL(trunk_attn_pool_win_kernel<true>, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(trunk_attn_pool_win_kernel<false>, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, a);
   return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
 }
 

@@ -172,6 +172,7 @@ class Diffusion(nn.Module):
         self._sched_cache = {}
         self._fused = {}
         self._scope_depth, self._scope_id = 0, 0
+        self.fuse_trunk_f32 = True       # precision "f32" + Enformer-shaped value trunk: the hand-written fp32 trunk kernels (False: the PyTorch modules)
         self.replay_rng = "device"       # rng_mode "replay": "device" = torch's CPU mt19937 stream continued by K8 on the GPU for
         self._replay_stream = None       # the span of a sampler call; "host" = torch.rand on the host + upload (round 1-3)
 
@@ -262,11 +263,12 @@ class Diffusion(nn.Module):
             ent[3].precision = self.precision
             return ent[3]
         from .enformer_value import EnformerTrunk
-        if (self.fuse_nets and self.precision != "f32" and isinstance(embedding, EnformerTrunk) and isinstance(head, ConvHead)
-                and next(embedding.parameters()).is_cuda):
-            # BASELINE configs[3]'s Enformer-shaped trunk on the hand-written split-precision kernels (svdd_trunk.hip): the x3
-            # modes map to bf16x3 (bf16 keeps fp32's exponent range: no operand scaling needed), the one-pass modes to bf16
-            tp = "bf16x3" if self.precision.endswith("x3") else "bf16"
+        if (self.fuse_nets and (self.precision != "f32" or self.fuse_trunk_f32) and isinstance(embedding, EnformerTrunk)
+                and isinstance(head, ConvHead) and next(embedding.parameters()).is_cuda):
+            # BASELINE configs[3]'s Enformer-shaped trunk on the hand-written kernels (svdd_trunk.hip): "f32" = one fp32 operand
+            # plane, fp32 MFMAs (the reference's precision; round 4); the x3 modes map to bf16x3 (bf16 keeps fp32's exponent
+            # range: no operand scaling needed), the one-pass modes to bf16
+            tp = "f32" if self.precision == "f32" else "bf16x3" if self.precision.endswith("x3") else "bf16"
             key = ("trunk", id(embedding), id(head), tp)
             ent = self._fused.get(key)
             alive = ent is not None and ent[0]() is embedding and ent[1]() is head

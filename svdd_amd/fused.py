@@ -303,11 +303,29 @@ def pack_backbone(cnn):
     return dict(table0=table0, tiles=tiles, vec=vec.contiguous(), w2=w2, dil=[c.dilation[0] for c in cnn.convs])
 
 
+_BB_SPLIT_WS = {}          # device -> the scratch tensor registered with svdd_backbone_set_workspace (kept alive here)
+BB_SPLIT_MAX_SEQ = 128     # the small-batch form splits a sequence over 2 workgroups up to 128 sequences, over 4 up to 64
+
+
+def _backbone_split_workspace(dev):
+    """Caller-owned scratch of the small-batch backbone (svdd_backbone_cnn_f32 on 2 / 4 workgroups per sequence, same bits):
+    the double-buffered LayerNorm images of up to 128 sequences + arrival counters (27 MB), registered once per process."""
+    key = str(dev)
+    if key not in _BB_SPLIT_WS:
+        nbytes = BB_SPLIT_MAX_SEQ * (2 * 208 * 128 * 4 + 4) + 4
+        ws = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+        _lib.check(_lib.lib().svdd_backbone_set_workspace(ws.data_ptr(), nbytes), "svdd_backbone_set_workspace")
+        _BB_SPLIT_WS[key] = ws
+    return _BB_SPLIT_WS[key]
+
+
 def backbone_cnn(tokens, pk, count=None, out=None, row_idx=None, scatter=False):
     """tokens [n, L] uint8 -> raw logits fp32 [n, L, 5]: the whole backbone forward in ONE launch
     (HIP kernel svdd_backbone_cnn_f32)."""
     assert tokens.is_cuda and tokens.dtype == torch.uint8 and tokens.is_contiguous()
     n, L = tokens.shape
+    if n <= BB_SPLIT_MAX_SEQ and 104 < L <= 208 and count is None and row_idx is None:
+        _backbone_split_workspace(tokens.device)
     if out is None:
         out = torch.empty((n, L, 5), dtype=torch.float32, device=tokens.device)
     dil = (ctypes.c_int * len(pk["dil"]))(*pk["dil"])

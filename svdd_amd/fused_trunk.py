@@ -66,12 +66,25 @@ def pack_gemm_weight(w, parts):
     return v.permute(4, 7, 1, 2, 0, 5, 3, 6).contiguous().reshape(-1)                  # [c][t][nb][nt][p][g][j][e]
 
 
-class _Planes:
-    """(hi, lo) bf16 operand planes inside one allocation, with guard rows so that shifted / overrunning tile reads stay
-    inside it."""
+def pack_gemm_weight_f32(w, parts=1):
+    """The fp32 twin (precision "f32": one fp32 operand plane, v_mfma_f32_16x16x4_f32): Conv1d / Linear weight [N, Cin, T] ->
+    [KB = T * Cin/32][N/128][8 n-tiles][2 pieces][64 lanes = 16 g + j][4 e] = W[128 nb + 16 nt + j][32 c + 8 g + 4 p + e][t] —
+    the 16-byte pieces svdd_trunk_gemm's LDS-DMA copies straight into fragment order (a K block's 32 channels are dealt
+    8 to a lane group: MFMA step (p, e) multiplies channel 8 g + 4 p + e)."""
+    if w.dim() == 2:
+        w = w[:, :, None]
+    N, Cin, T = w.shape
+    assert N % 128 == 0 and Cin % 32 == 0, (N, Cin)
+    v = w.detach().float().reshape(N // 128, 8, 16, Cin // 32, 4, 2, 4, T)             # [nb][nt][j][c][g][p][e][t]
+    return v.permute(3, 7, 0, 1, 5, 4, 2, 6).contiguous().reshape(-1)                  # [c][t][nb][nt][p][g][j][e]
 
-    def __init__(self, max_elems, parts, dev):
-        self.buf = [torch.zeros(max_elems, dtype=torch.bfloat16, device=dev) for _ in range(parts)]
+
+class _Planes:
+    """(hi, lo) bf16 operand planes (or the one fp32 plane of precision "f32") inside one allocation, with guard rows so that
+    shifted / overrunning tile reads stay inside it."""
+
+    def __init__(self, max_elems, parts, dev, dtype=torch.bfloat16):
+        self.buf = [torch.zeros(max_elems, dtype=dtype, device=dev) for _ in range(parts)]
 
     FRONT = GUARD * 4096      # elements in front of row 0, the same for every channel count: the two rows a k = 5 tap reads in
                               # front of the first sequence must be zero, and with a C-dependent offset they would alias the
@@ -98,13 +111,18 @@ class _PlanesAt:
 class FusedEnformerValueNet(nn.Module):
     def __init__(self, trunk: EnformerTrunk, head: ConvHead, precision="bf16x3"):
         super().__init__()
-        assert precision in ("bf16x3", "bf16")
+        assert precision in ("bf16x3", "bf16", "f32")
         self.precision = precision
         self.parts = 2 if precision == "bf16x3" else 1
+        # "f32" (round 4): ONE fp32 operand plane and fp32 MFMAs — the trunk at the reference's precision (decode.py:78-80 runs it
+        # in fp32). Same kernels (svdd_set_option(SVDD_OPT_TRUNK_PLANES_F32) selects their fp32-plane instantiations), same
+        # layout, same exact work-skipping; element counts are the bf16 modes', bytes those of bf16x3.
+        self.f32 = precision == "f32"
+        self.plane_dtype = torch.float32 if self.f32 else torch.bfloat16
         self._ws = {}
         dev = next(trunk.parameters()).device
         P = self.parts
-        pk = lambda w: pack_gemm_weight(w, P).to(dev)                                  # noqa: E731
+        pk = (lambda w: pack_gemm_weight_f32(w).to(dev)) if self.f32 else (lambda w: pack_gemm_weight(w, P).to(dev))   # noqa: E731
 
         def bn_affine(bn):
             s = (bn.weight.detach() / torch.sqrt(bn.running_var + bn.eps)).float()
@@ -215,7 +233,7 @@ class FusedEnformerValueNet(nn.Module):
             # two sets of operand planes: a GEMM reads one and writes the next GEMM's operands into the other
             pmax += _Planes.FRONT
             ws = {"f": [torch.empty(fmax, dtype=torch.float32, device=dev) for _ in range(4)],
-                  "p": [_Planes(pmax, self.parts, dev), _Planes(pmax, self.parts, dev)], "cap": n}
+                  "p": [_Planes(pmax, self.parts, dev, self.plane_dtype), _Planes(pmax, self.parts, dev, self.plane_dtype)], "cap": n}
             self._ws = {key: ws}
         return ws
 
@@ -334,7 +352,7 @@ class FusedEnformerValueNet(nn.Module):
         key = ("pp", B, L, depth, K)
         st = ws.get(key)
         if st is None:
-            mk = lambda: [None] + [_Planes(_Planes.FRONT + (B * (_level_len(L, d) + 2) + TAIL) * self.levels[d]["a_cin"], P, dev)  # noqa: E731
+            mk = lambda: [None] + [_Planes(_Planes.FRONT + (B * (_level_len(L, d) + 2) + TAIL) * self.levels[d]["a_cin"], P, dev, self.plane_dtype)  # noqa: E731
                                    for d in range(1, depth + 1)]
             st = ws[key] = {"pp": [mk(), mk()], "cur": 0, "x": None, "ids": torch.arange(B, dtype=torch.int32, device=dev),
                             "win": {}, "pwin": torch.empty((3, depth, B * K), dtype=torch.int32, device=dev)}
@@ -376,6 +394,16 @@ class FusedEnformerValueNet(nn.Module):
 
     @torch.no_grad()
     def forward_tokens(self, tok, count=None, shared=None):
+        """See _forward_tokens. The plane format is a host-side switch of the library (svdd_set_option): set for the span of the
+        call (every launch of the call is enqueued inside it), restored on the way out."""
+        lib = _lib.lib()
+        _lib.check(lib.svdd_set_option(6, 1 if self.f32 else 0), "svdd_set_option(SVDD_OPT_TRUNK_PLANES_F32)")
+        try:
+            return self._forward_tokens(tok, count, shared)
+        finally:
+            lib.svdd_set_option(6, 0)
+
+    def _forward_tokens(self, tok, count=None, shared=None):
         """tok [n, L] u8 -> scores [n, n_tasks, 1]; count: int32 device scalar = live rows (rows beyond it are undefined).
         shared = (parent_tok [B, L] u8, parent_idx int32 [n], div): row c of tok is a candidate of row parent_idx[c] // div of
         parent_tok and differs from it at a few positions; the first levels are then computed on those windows only (exact)."""

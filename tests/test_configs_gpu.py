@@ -223,6 +223,16 @@ def test_c4_full_enformer_trunk_slice_vs_oracle(skip_generic):
     assert n_params > 2.0e8, n_params
     B, L, M, S = 8, 200, 20, 3
     sched = model._schedule(S, 1e-5)[0]
+    # round 4: at the reference's precision (fp32) the trunk runs on the hand-written fp32 kernels (svdd_trunk.hip, fp32 planes +
+    # v_mfma_f32_16x16x4_f32), not on the PyTorch modules: scores within 1e-4 of the module on the same weights
+    from svdd_amd.fused_trunk import FusedEnformerValueNet
+    fn = model.value_callable(emb, head)
+    assert model.precision == "f32" and isinstance(fn, FusedEnformerValueNet) and fn.precision == "f32"
+    tok = torch.randint(0, 5, (24, L), device=DEV, dtype=torch.uint8)
+    onehot = (torch.nn.functional.one_hot(tok.long().clamp(max=3), 4) * (tok != 4)[..., None]).float()
+    with torch.no_grad():
+        ref, got = head(emb(onehot)).reshape(-1), fn.forward_tokens(tok).reshape(-1)
+    assert float((ref - got).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max()))
     model.rng_mode, model.philox_seed, model.row_offset, model.skip_generic, model.trace = "philox", 4, 512, skip_generic, []
     x_gpu = model.controlled_sample(emb, head, num_steps=S, eval_sp_size=B, sample_M=M).cpu().numpy()
     trace = _trace_np(model)

@@ -232,7 +232,11 @@ def test_cli_writes_reference_npz(tmp_path, method, suffix):
     z = np.load(path)
     assert set(z.files) == {"decoding", "baseline"} and z["decoding"].shape == (8,) and z["baseline"].shape == (8,)
     samples, vpred, rpred, topk, base = out
-    assert len(samples) == 2 and samples[0].shape == (4, 50) and vpred.shape == (8,) and topk.shape == (8,)
+    if method == "tweedie":        # the reference's tweedie harness returns a flat list of rows (Enformer.py:766; tests/golden/g22)
+        assert len(samples) == 8 and samples[0].shape == (50,)
+    else:
+        assert len(samples) == 2 and samples[0].shape == (4, 50)
+    assert vpred.shape == (8,) and topk.shape == (8,)
 
 
 def test_mc_decode_with_enformer_shaped_value_net():

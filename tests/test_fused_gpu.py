@@ -224,6 +224,51 @@ def test_one_launch_backbone_vs_plain(n, L):
         assert torch.equal(out[2:5], fused.backbone_cnn(x[2:5].contiguous(), pk))
 
 
+@pytest.mark.parametrize("n,L", [(4, 200), (1, 208), (33, 200), (64, 200), (65, 187), (128, 200), (7, 105)])
+def test_backbone_on_several_workgroups_per_sequence_same_bits(n, L):
+    """Round 4: small batches of one-sequence tiles run svdd_backbone_cnn_f32 on 2 / 4 workgroups per sequence (row-split,
+    the LayerNorm'd image of every layer exchanged through a caller-owned scratch, agent-scope group barriers). Same bits as
+    the one-workgroup kernel (A/B through SVDD_OPT_BACKBONE_SPLIT), for every split that fits, repeated launches (the
+    arrival counters are reset per launch), and no group barrier ever timed out."""
+    import ctypes
+    from svdd_amd import _lib, backbone, config, fused
+    torch.manual_seed(6)
+    cnn = backbone.CNNModel(config.dna_config().model, alphabet_size=5).to(DEV).eval()
+    with torch.no_grad():
+        for nm in cnn.norms:
+            nm.weight.uniform_(0.5, 1.5)
+            nm.bias.uniform_(-0.3, 0.3)
+    x = torch.randint(0, 5, (n, L), device=DEV, dtype=torch.uint8)
+    x[0, L // 2:] = 4
+    pk = fused.pack_backbone(cnn)
+    lib = _lib.lib()
+    try:
+        _lib.check(lib.svdd_set_option(7, 1), "split off")
+        one = fused.backbone_cnn(x, pk).clone()
+        outs = {}
+        for R in (2, 4):
+            if R * n > 256:
+                continue
+            _lib.check(lib.svdd_set_option(7, R), "split forced")
+            outs[R] = [fused.backbone_cnn(x, pk).clone() for _ in range(3)]
+        _lib.check(lib.svdd_set_option(7, 0), "split auto")
+        auto = fused.backbone_cnn(x, pk).clone()
+        torch.cuda.synchronize()
+    finally:
+        lib.svdd_set_option(7, 0)
+    err = ctypes.c_int(-1)
+    _lib.check(lib.svdd_backbone_split_status(ctypes.byref(err)), "status")
+    assert err.value == 0
+    assert torch.isfinite(one).all()
+    for R, got in outs.items():
+        for o in got:
+            assert torch.equal(o, one), (R, float((o - one).abs().max()))
+    assert torch.equal(auto, one)
+    with torch.no_grad():
+        ref = cnn(x, torch.zeros(n, device=DEV), zero_sigma=True).contiguous()
+    assert (one - ref).abs().max().item() <= 2e-5
+
+
 @pytest.mark.parametrize("n,L,T", [(5, 200, 1), (64, 200, 1), (7, 50, 1), (3, 33, 2), (9, 17, 4), (2, 1, 3)])
 def test_value_tail_vs_torch(n, L, T):
     """svdd_value_tail_f32 (direction sum + LayerNorm + dense1 + ReLU + collapsed dense2/head + mean over length)

@@ -196,6 +196,16 @@ def test_select_rows_per_wave_equals_one_row_per_wave_and_oracle(ops, M, L, mode
     assert torch.equal(fast[2], slow[2]) and torch.equal(fast_soft[2], slow[2])        # idx
     assert torch.equal(fast[0], slow[0]) and torch.equal(fast_soft[0], slow[0])        # gathered rows
     assert torch.equal(fast_soft[1], slow[1])                                          # soft values, bit for bit
+    # round 4: four row groups per wave with the gathers batched (what batches of >= 2^21 (row, candidate) slots take)
+    _lib.check(_lib.lib().svdd_set_option(2, 2), "four row groups per wave")
+    try:
+        wide = ops.select(sc_d, cand_d, mode=mode, rng=r, want_soft=False)
+        wide_soft = ops.select(sc_d, cand_d, mode=mode, rng=r, want_soft=True)
+        torch.cuda.synchronize()
+    finally:
+        _lib.check(_lib.lib().svdd_set_option(2, 0), "rows per wave")
+    assert torch.equal(wide[2], slow[2]) and torch.equal(wide[0], slow[0])
+    assert torch.equal(wide_soft[2], slow[2]) and torch.equal(wide_soft[0], slow[0]) and torch.equal(wide_soft[1], slow[1])
     sl = np.r_[0:300, 9990:15100:7, 20000:20050, 21000:21300, B - 70:B]
     x_ref, soft_ref, idx_ref = orc.select(scores[sl], cand[sl], mode=mode, seed=11, row_offset=0, step=9)
     if mode == 0:                                                                      # (Philox is keyed by the row: argmax only)

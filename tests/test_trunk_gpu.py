@@ -29,7 +29,7 @@ def _randomise(emb, head, seed):
             pw.add_((torch.randn(pw.shape, generator=g) * 0.05).to(pw.device))
 
 
-@pytest.mark.parametrize("precision,tol", [("bf16x3", 1e-4), ("bf16", 3e-2)])
+@pytest.mark.parametrize("precision,tol", [("f32", 2e-5), ("bf16x3", 1e-4), ("bf16", 3e-2)])
 @pytest.mark.parametrize("L,kw", [(200, dict(n_conv=4, channels=768, n_transformers=2, n_heads=4, key_len=16)),
                                   (50, dict(n_conv=4, channels=768, n_transformers=2, n_heads=4, key_len=16)),
                                   (37, dict(n_conv=3, channels=768, n_transformers=1, n_heads=2, key_len=32))])
@@ -75,14 +75,16 @@ def test_fused_trunk_full_size_c4():
         ref = head(emb(onehot)).reshape(n)
         out = FusedEnformerValueNet(emb, head, "bf16x3").forward_tokens(tok).reshape(n)
         one = FusedEnformerValueNet(emb, head, "bf16").forward_tokens(tok).reshape(n)
+        f32 = FusedEnformerValueNet(emb, head, "f32").forward_tokens(tok).reshape(n)
     scale = max(1.0, float(ref.abs().max()))
-    err3, err1 = float((out - ref).abs().max()), float((one - ref).abs().max())
-    print(f"full-size trunk: |score| max {float(ref.abs().max()):.3f}  bf16x3 err {err3:.2e}  bf16 err {err1:.2e}")
+    err3, err1, err32 = float((out - ref).abs().max()), float((one - ref).abs().max()), float((f32 - ref).abs().max())
+    print(f"full-size trunk: |score| max {float(ref.abs().max()):.3f}  f32 err {err32:.2e}  bf16x3 err {err3:.2e}  bf16 err {err1:.2e}")
+    assert err32 <= 2e-5 * scale          # fp32 MFMAs against the fp32 modules: summation order only
     assert err3 <= 1e-4 * scale
     assert err1 <= 5e-2 * scale
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16", "f32"])
 def test_tower_on_two_streams_same_bits(precision):
     """The candidates as 2 / 3 / 4 parts on as many streams (fused_trunk.tower_streams, from 2048 token rows on) against
     one chain of kernels: the same bits, with and without a device-side live count (small ones included), and twice in a row (the streams join before the next forward touches the buffers)."""
@@ -237,7 +239,7 @@ def test_gemm_256_tiles_equal_128_tiles(M, N, Cin, T, rps, live, parts):
         assert err <= (2e-5 if parts == 2 else 1e-4), err
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16", "f32"])
 @pytest.mark.parametrize("kw", [dict(n_conv=4, channels=768, n_transformers=2, n_heads=4, key_len=16), None])
 def test_first_levels_shared_with_the_parent_same_bits(precision, kw):
     """forward_tokens(shared=...): the first levels of the conv tower only on the window of rows around the
