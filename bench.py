@@ -168,17 +168,19 @@ def tds_saturated(dev, L=200, B=65536, iters=10):
     return out
 
 
-def trunk_gemm_roofline(model, emb, head, dev, n, L):
+def trunk_gemm_roofline(model, emb, head, dev, n, L, precision="bf16x3"):
     """--value-net enformer: the dominant kernel of that workload is trunk_gemm256_kernel (csrc/svdd_trunk.hip), not the
     backbone. One trunk forward (bf16x3) on n candidates (~ the live candidates of a step) with a HIP event pair around every
     GEMM launch: multiply-adds of all GEMMs x 2 / summed launch time against the dense 16-bit MFMA peak — `frac` on the
     fp32-equivalent FLOPs, `issued_frac` with the three passes of the split product counted."""
     from svdd_amd.fused_trunk import FusedEnformerValueNet
-    model.precision = "bf16x3"
+    model.precision = precision
     fn = model.value_callable(emb, head)
     model.precision = "f32"
     if not isinstance(fn, FusedEnformerValueNet):
         return None
+    f32 = precision == "f32"
+    peak, passes = (FP32_PEAK_TFLOPS, 1) if f32 else (LP_PEAK_TFLOPS, 3)
     tok = torch.randint(0, 5, (n, L), device=dev, dtype=torch.uint8)
     streams, fn.tower_streams = fn.tower_streams, 1        # one chain of kernels: on two streams the GEMMs of the two half batches
     fn.forward_tokens(tok)                                 # overlap, and per-launch event pairs would count the shared time twice
@@ -193,10 +195,10 @@ def trunk_gemm_roofline(model, emb, head, dev, n, L):
     fn.timing = None
     flops = float(emb.flops_per_sequence(L)) * n                                   # algorithmic (3.36 GFLOP / candidate)
     tf = flops / (ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "trunk_gemm256_kernel (every convolution / projection of the Enformer-shaped value trunk; "
-                                       "bf16x3: 3 MFMA passes per product)",
-            "achieved": round(tf, 2), "peak": LP_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / LP_PEAK_TFLOPS, 5),
-            "issued_frac": round(3 * issued / (ms * 1e-3) / 1e12 / LP_PEAK_TFLOPS, 5), "flops_per_forward": round(flops),
+    return {"bound": "mfma", "kernel": "trunk_gemm256_kernel (every convolution / projection of the Enformer-shaped value trunk; " +
+                                       ("fp32 operand plane, v_mfma_f32_16x16x4_f32)" if f32 else "bf16x3: 3 MFMA passes per product)"),
+            "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 5),
+            "issued_frac": round(passes * issued / (ms * 1e-3) / 1e12 / peak, 5), "flops_per_forward": round(flops),
             "issued_flops_per_forward_incl_pad_rows": round(issued), "gemm_ms_per_forward": round(ms, 3),
             "launches": launches, "workload": f"one trunk forward on {n} candidates of length {L}", "traffic": None,
             "traffic_source": None}
@@ -248,7 +250,7 @@ def config4_f32(model, emb, head, dev, steps, B, L, M, S):
         from svdd_amd.fused_trunk import FusedEnformerValueNet
         model.precision = "f32"
         fn = model.value_callable(emb, head)
-        impl = ("hand-written fp32 trunk kernels (svdd_trunk.hip, v_mfma_f32_32x32x2_f32)" if isinstance(fn, FusedEnformerValueNet)
+        impl = ("hand-written fp32 trunk kernels (svdd_trunk.hip: one fp32 operand plane, v_mfma_f32_16x16x4_f32)" if isinstance(fn, FusedEnformerValueNet)
                 else "PyTorch-ROCm modules (MIOpen / hipBLASLt), one [B*M] forward per step")
         run = lambda: model.controlled_sample(emb, head, num_steps=S, eval_sp_size=B, sample_M=M)   # noqa: E731
         run()
@@ -259,8 +261,11 @@ def config4_f32(model, emb, head, dev, steps, B, L, M, S):
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
         assert out.shape == (B, L) and int(out.max()) <= 3
-        return {"value": round(B * steps / el, 3), "unit": "sequences/s", "steps": steps, "ms_per_step": round(el / steps * 1e3, 3),
-                "dtype": "f32", "value_trunk": impl}
+        res = {"value": round(B * steps / el, 3), "unit": "sequences/s", "steps": steps, "ms_per_step": round(el / steps * 1e3, 3),
+               "dtype": "f32", "value_trunk": impl}
+        if isinstance(fn, FusedEnformerValueNet):
+            res["roofline_trunk_gemm"] = trunk_gemm_roofline(model, emb, head, dev, int(0.75 * B * M), L, precision="f32")
+        return res
     except Exception as e:                                     # noqa: BLE001
         return {"error": f"{type(e).__name__}: {e}"}
 
@@ -375,6 +380,74 @@ def value_net_roofline(model, emb, head, dev, B, L, M, S, tower_ms, tower_launch
         out[key]["dense"] = {"achieved": round(tf, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                              "frac": round(tf / FP32_PEAK_TFLOPS, 5), "flops_per_launch": round(per_row * n * L),
                              "avg_launch_us": round(ms * 1e3, 2), "launches": k, "workload": f"{n} whole sequences of length {L}"}
+    # the GRU at one (tile of 16 sequences, direction) unit per CU: 2048 sequences = 256 units (n = 2560 makes 320 units on 256 CUs:
+    # 64 CUs run two); most steps of the work-skipping decode have <= 2048 live candidates
+    n2 = 2048
+    for _ in range(3):
+        fn.forward_tokens(tok[:n2].contiguous())
+    torch.cuda.synchronize()
+    _lib.profile_collect(3)
+    _lib.profile_enable(True)
+    for _ in range(10):
+        fn.forward_tokens(tok[:n2].contiguous())
+    torch.cuda.synchronize()
+    _lib.profile_enable(False)
+    tot, k = _lib.profile_collect(3)
+    ms = tot / max(k, 1)
+    tf = gru_row * n2 * L / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    out["gru"]["dense_2048"] = {"achieved": round(tf, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / FP32_PEAK_TFLOPS, 5),
+                                "flops_per_launch": round(gru_row * n2 * L), "avg_launch_us": round(ms * 1e3, 2), "launches": k,
+                                "workload": f"{n2} whole sequences of length {L} (one unit per CU)"}
+    _lib.profile_collect(5)
+    return out
+
+
+def replay_leg(model, emb, head, B, L, M, S, decodes=2):
+    """The parity mode at speed: the SAME workload with rng_mode = "replay" — the categorical uniforms are torch's global CPU
+    mt19937 stream (what the reference's rand_like consumes, diffusion_gosai.py:33), continued on the device by
+    svdd_mt19937_uniform_f32 for the span of a decode. Token-exact against the reference's own runs (tests/test_e2e_gpu.py);
+    here only its throughput, next to the host replay of rounds 1-3 (torch.rand + a 10 MB upload per step)."""
+    out = {}
+    keep = (model.rng_mode, model.replay_rng)
+    try:
+        for how in ("device", "host"):
+            model.rng_mode, model.replay_rng = "replay", how
+            torch.manual_seed(0)
+            model.controlled_sample(emb, head, num_steps=S, eval_sp_size=B, sample_M=M)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(decodes):
+                model.controlled_sample(emb, head, num_steps=S, eval_sp_size=B, sample_M=M)
+            torch.cuda.synchronize()
+            el = (time.perf_counter() - t0) / decodes
+            out[how] = {"value": round(B / el, 3), "unit": "sequences/s", "ms_per_step": round(el * 1e3, 3), "steps": decodes}
+    finally:
+        model.rng_mode, model.replay_rng = keep
+    out["note"] = ("device: torch's CPU generator state uploaded once per decode, stream generated by one workgroup a step ahead on a "
+                   "side stream, state written back at the end; host: torch.rand(M, B, 5, L) + upload every step")
+    return out
+
+
+def small_batch_leg(model, emb, head, L, S, decodes=3):
+    """BASELINE.json configs[0]'s shape on the GPU (B = 4, M = 2: the reference's own CPU-runnable case): a batch this small
+    runs the backbone on 4 workgroups per sequence (svdd_backbone_cnn_f32's small-batch form, same bits); the one-workgroup
+    form is timed beside it (svdd_set_option(SVDD_OPT_BACKBONE_SPLIT, 1))."""
+    from svdd_amd import _lib
+    B, M = 4, 2
+    out = {"workload": f"DNA enhancer SVDD-MC, batch={B}, L={L}, M={M}, {S} steps (BASELINE.json configs[0]) on one MI355X"}
+    try:
+        for name, opt in (("backbone_on_4_workgroups_per_sequence", 0), ("backbone_on_1_workgroup_per_sequence", 1)):
+            _lib.lib().svdd_set_option(7, opt)
+            model.controlled_sample(emb, head, num_steps=S, eval_sp_size=B, sample_M=M)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(decodes):
+                model.controlled_sample(emb, head, num_steps=S, eval_sp_size=B, sample_M=M)
+            torch.cuda.synchronize()
+            el = (time.perf_counter() - t0) / decodes
+            out[name] = {"value": round(B / el, 3), "unit": "sequences/s", "ms_per_step": round(el * 1e3, 3), "steps": decodes}
+    finally:
+        _lib.lib().svdd_set_option(7, 0)
     return out
 
 
@@ -625,8 +698,10 @@ def main():
     bb_flops = conv_flops_fwd + 2.0 * B * L * (5 * H * 9 + H * H + H * 5)
     alt = {}
     pmc_lp, pmc_lp_src = {}, None                # HBM bytes per backbone_lp_kernel launch, from separate --pmc passes
-    for name in ("r03_pmc.json",):
+    for name in ("r04_pmc.json", "r03_pmc.json"):
         pth = os.path.join(ROOT, "profiles", name)
+        if pmc_lp:
+            break
         if os.path.exists(pth) and (B, L, M) == (256, 200, 10):
             pmc_lp = json.load(open(pth)).get("backbone_lp_traffic_bytes_per_launch", {})
             pmc_lp_src = f"profiles/{name} (separate rocprofv3 --pmc passes, not measured in this run)"
@@ -680,7 +755,7 @@ def main():
         conv_ms = conv_total_ms / max(conv_launches, 1)
         conv_tf = (conv_flops_fwd / 20.0) / (conv_ms * 1e-3) / 1e12 if conv_launches else 0.0
         pmc, pmc_src = {}, None
-        for name in ("r03_pmc.json", "r02_pmc.json", "r01_pmc.json"):   # separate --pmc passes of this workload, see the file
+        for name in ("r04_pmc.json", "r03_pmc.json", "r02_pmc.json", "r01_pmc.json"):   # separate --pmc passes of this workload, see the file
             pmc_path = os.path.join(ROOT, "profiles", name)
             if os.path.exists(pmc_path) and (B, L, M) == (256, 200, 10):
                 pmc = json.load(open(pmc_path))
@@ -740,8 +815,14 @@ def main():
             line["per_rank"] = per_rank
         if world == 1 and args.value_net == "convgru":
             line["roofline_sampler_saturated"] = sampler_saturated(dev, L=L, M=M)
-            line["roofline_select_saturated"] = [select_saturated(dev, L=L, M=M), select_saturated(dev, L=L, M=M, near_uniform=True),
+            if pmc.get("k1_saturated_traffic_bytes_per_launch"):      # HBM bytes of THAT launch size, from the separate PMC passes
+                line["roofline_sampler_saturated"]["traffic"] = pmc["k1_saturated_traffic_bytes_per_launch"]
+                line["roofline_sampler_saturated"]["traffic_source"] = pmc_src
+            # (the near-tied leg first: scores ~1e-7 apart are what the random-init value nets of this workload actually produce)
+            line["roofline_select_saturated"] = [select_saturated(dev, L=L, M=M, near_uniform=True), select_saturated(dev, L=L, M=M),
                                                  select_saturated(dev, L=L, M=20)]
+            line["replay_rng"] = replay_leg(model, emb, head, B, L, M, S)
+            line["config1_b4"] = small_batch_leg(model, emb, head, L, S)
             line["roofline_tds_resample"] = tds_saturated(dev, L=L)
             line["roofline_value_net"] = value_net_roofline(model, emb, head, dev, B, L, M, S, tower_total_ms, tower_launches,
                                                             gru_total_ms, gru_launches)

@@ -1018,12 +1018,17 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
 }
 __device__ __forceinline__ float mt_float(uint32_t x) { return (float)(mt_temper(x) & 0xFFFFFFu) * (1.0f / 16777216.0f); }
 
-__global__ __launch_bounds__(256) void mt19937_kernel(uint32_t* __restrict__ state, float* __restrict__ out, long long n) {
+// Two roles (round 4, second version: 0.58 -> see DESIGN ns per output): waves 0-3 only advance the recurrence (4 LDS reads, two
+// twists, 2 LDS writes per pair of generations), waves 4-7 temper, convert and store the pair of generations of the interval
+// BEFORE, read back from the ring — the serial chain no longer carries the 25 instructions of the output path.
+__global__ __launch_bounds__(512) void mt19937_kernel(uint32_t* __restrict__ state, float* __restrict__ out, long long n) {
   __shared__ uint32_t ring[MT_RING];
-  const int j = threadIdx.x;
+  const int tid = threadIdx.x;
+  const bool twister = tid < 256;
+  const int j = tid & 255;
   const long long pos = (long long)state[MT_N];
   const long long total = pos + n;                        // one past the last element consumed
-  for (int k = j; k < MT_N; k += 256) {
+  for (int k = tid; k < MT_N; k += 512) {
     const uint32_t v = state[k];
     ring[k] = v;
     if (k >= pos && k < total) out[k - pos] = mt_float(v);  // what is left of the current block
@@ -1033,28 +1038,38 @@ __global__ __launch_bounds__(256) void mt19937_kernel(uint32_t* __restrict__ sta
   long long G = total > MT_N ? (total - MT_N + MT_GEN - 1) / MT_GEN : 0;
   G += (G & 1);
   const bool lane = j < MT_GEN;
-  uint32_t prev = lane ? ring[MT_M + j] : 0u;             // x[397 + j]: "generation -1" of this lane
-  long long base = 0;                                     // generation g reads x[base + j], x[base + j + 1], base = 227 g
-  for (long long g = 0; g < G; g += 2, base += 2 * MT_GEN) {
-    if (lane) {
-      const int r0 = (int)((base + j) & (MT_RING - 1)), r1 = (int)((base + MT_GEN + j) & (MT_RING - 1));
-      const uint32_t a0 = ring[r0], b0 = ring[(r0 + 1) & (MT_RING - 1)];
-      const uint32_t a1 = ring[r1], b1 = ring[(r1 + 1) & (MT_RING - 1)];
-      const uint32_t x0 = prev ^ mt_tw(a0, b0);           // x[base + 624 + j]
-      const uint32_t x1 = x0 ^ mt_tw(a1, b1);             // x[base + 227 + 624 + j]   (its x[n + 397] is x0)
-      prev = x1;
-      const long long m0 = base + MT_N + j, m1 = m0 + MT_GEN;
-      ring[(int)(m0 & (MT_RING - 1))] = x0;
-      ring[(int)(m1 & (MT_RING - 1))] = x1;
-      if (m0 >= pos && m0 < total) out[m0 - pos] = mt_float(x0);
+  uint32_t prev = (twister && lane) ? ring[MT_M + j] : 0u; // x[397 + j]: "generation -1" of this lane
+  int r0 = j;                                             // ring slot of x[base + j], base = 227 g
+  // the output lanes run one interval behind: element m = 624 + base_o + j (+ 227)
+  long long mo = (long long)MT_N - 2 * MT_GEN + j;        // first interval: nothing to emit yet (mo + 2 * 227 = 624 + j next time)
+  int ro = (MT_N - 2 * MT_GEN + j) & (MT_RING - 1);
+  for (long long g = 0; g <= G; g += 2) {                 // one extra pass: the output lanes drain the last pair
+    if (twister) {
+      if (lane && g < G) {
+        const int r1 = (r0 + MT_GEN) & (MT_RING - 1);
+        const uint32_t a0 = ring[r0], b0 = ring[(r0 + 1) & (MT_RING - 1)];
+        const uint32_t a1 = ring[r1], b1 = ring[(r1 + 1) & (MT_RING - 1)];
+        const uint32_t x0 = prev ^ mt_tw(a0, b0);         // x[base + 624 + j]
+        const uint32_t x1 = x0 ^ mt_tw(a1, b1);           // x[base + 227 + 624 + j]   (its x[n + 397] is x0)
+        prev = x1;
+        ring[(r0 + MT_N) & (MT_RING - 1)] = x0;
+        ring[(r0 + MT_N + MT_GEN) & (MT_RING - 1)] = x1;
+        r0 = (r0 + 2 * MT_GEN) & (MT_RING - 1);
+      }
+    } else if (lane && g > 0) {
+      const uint32_t x0 = ring[ro], x1 = ring[(ro + MT_GEN) & (MT_RING - 1)];
+      const long long m1 = mo + MT_GEN;
+      if (mo >= pos && mo < total) out[mo - pos] = mt_float(x0);
       if (m1 >= pos && m1 < total) out[m1 - pos] = mt_float(x1);
     }
+    mo += 2 * MT_GEN;
+    ro = (ro + 2 * MT_GEN) & (MT_RING - 1);
     __syncthreads();
   }
   // new state: the window x[E .. E + 623], E = 227 G ; pos' = total - E (0 <= pos' <= 624)
   const long long E = G * MT_GEN;
-  for (int k = j; k < MT_N; k += 256) state[k] = ring[(int)((E + k) & (MT_RING - 1))];
-  if (j == 0) state[MT_N] = (uint32_t)(total - E);
+  for (int k = tid; k < MT_N; k += 512) state[k] = ring[(int)((E + k) & (MT_RING - 1))];
+  if (tid == 0) state[MT_N] = (uint32_t)(total - E);
 }
 
 // Optional per-launch timing (bench.py's roofline leg): when enabled, K1/K2 are launched with
@@ -1351,7 +1366,7 @@ int svdd_mt19937_uniform_f32(uint32_t* state, float* out, long long n, void* str
   if (!state || !out || n < 0) return SVDD_E_ARG;
   if (n == 0) return SVDD_OK;
   TimedLaunch* t = timed_slot(9);
-  hipExtLaunchKernelGGL(mt19937_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, t ? t->start : nullptr, t ? t->stop : nullptr, 0,
+  hipExtLaunchKernelGGL(mt19937_kernel, dim3(1), dim3(512), 0, (hipStream_t)stream, t ? t->start : nullptr, t ? t->stop : nullptr, 0,
                         state, out, n);
   return check_launch();
 }

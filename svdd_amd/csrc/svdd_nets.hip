@@ -1917,30 +1917,50 @@ __global__ __launch_bounds__(512, 2) void backbone_split_kernel(BackboneArgs a, 
       //      fetch the others'. 32 float4 per row; one row per 32 lanes.
       __syncthreads();
       float* const xb = xg + (size_t)(layer & 1) * TW_ROWS * BB_C;
+      // The scratch image is written and read with SYSTEM-SCOPE accesses (sc0 sc1: write-through to memory, reads past every
+      // cache) and the counter with relaxed agent-scope atomics. The first version used ordinary stores / loads between
+      // __threadfence()s: an agent-scope release / acquire on this part writes back and invalidates the XCD's whole L2 — the
+      // 13 MB of weights every workgroup streams from it went with it, 25 us per layer (B = 64: slower than one workgroup per
+      // sequence). Nothing but these 106 KB per layer needs to be coherent between the workgroups.
       for (int e = tid; e < NR * 32 * 32; e += 512) {
         const int c4 = e & 31, rr = e >> 5;
         const int row = 32 * (q + R * (rr >> 5)) + (rr & 31);
-        if (row < TW_ROWS)
-          *reinterpret_cast<float4*>(xb + (size_t)row * BB_C + 4 * c4) = *reinterpret_cast<const float4*>(img + row * BB_AP + 4 * c4);
+        if (row < TW_ROWS) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(img + row * BB_AP + 4 * c4);
+          asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(xb + (size_t)row * BB_C + 4 * c4), "v"(v) : "memory");
+        }
       }
-      __threadfence();                                    // release: the blocks are visible device-wide before the arrival below
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this thread's blocks have reached memory
       __syncthreads();
       if (tid == 0) {
-        __hip_atomic_fetch_add(gcnt, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(gcnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int target = R * (layer + 1);
         int spins = 0;
-        while (__hip_atomic_load(gcnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
-          __builtin_amdgcn_s_sleep(2);
+        while (__hip_atomic_load(gcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+          __builtin_amdgcn_s_sleep(1);
           if (++spins > (1 << 24)) { *ws.err = 1; break; }  // a member is not resident (a launcher bug): give up, never hang
         }
       }
       __syncthreads();
-      __threadfence();                                    // acquire: no stale lines of the scratch image in this CU's caches
-      for (int e = tid; e < (TW_ROWS / 32 + 1) * 32 * 32; e += 512) {
-        const int c4 = e & 31, row = e >> 5;
-        if (row < TW_ROWS && ((row >> 5) % R) != q)
-          *reinterpret_cast<f32x4*>(img + row * BB_AP + 4 * c4) =
-              __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xb + (size_t)row * BB_C + 4 * c4));
+      // every foreign block of the image in ONE batch of loads per lane (14 slots of 512 lanes x 16 B cover the 208 x 512 B
+      // image; the slots of the blocks this workgroup owns stay empty): one memory latency per layer, not one per four loads
+      {
+        f32x4 v[14];
+        bool ok[14];
+#define S_XLD(K)                                                                                             \
+        { const int e_ = (K) * 512 + tid; const int row_ = e_ >> 5;                                          \
+          ok[K] = row_ < TW_ROWS && ((row_ >> 5) % R) != q;                                                  \
+          v[K] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};                                                              \
+          if (ok[K]) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v[K]) : "v"(xb + (size_t)row_ * BB_C + 4 * (e_ & 31)) : "memory"); }
+        S_XLD(0) S_XLD(1) S_XLD(2) S_XLD(3) S_XLD(4) S_XLD(5) S_XLD(6) S_XLD(7) S_XLD(8) S_XLD(9) S_XLD(10) S_XLD(11) S_XLD(12) S_XLD(13)
+#undef S_XLD
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
+                     "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]) :: "memory");
+#pragma unroll
+        for (int k = 0; k < 14; ++k) {
+          const int e_ = k * 512 + tid;
+          if (ok[k]) *reinterpret_cast<f32x4*>(img + (e_ >> 5) * BB_AP + 4 * (e_ & 31)) = v[k];
+        }
       }
     } else {
 #pragma unroll
@@ -2344,10 +2364,23 @@ extern "C" int svdd_backbone_cnn_f32(const uint8_t* x, const float* table0, cons
   // image of svdd_backbone_set_workspace, a row count known on the host (no device-side count / index list) and n R <= CUs
   // (every member of a group must be resident: they wait for each other).
   if (a.spt == 1 && !a.auto_spt && TW_ROWS / L == 1 && !count && !row_idx && g_bb_ws.xchg && g_bb_split != 1) {
-    int R = g_bb_split == 2 || g_bb_split == 4 ? g_bb_split : (4 * n <= a.ncu ? 4 : 2 * n <= a.ncu ? 2 : 1);
-    if (R > 1 && (int64_t)R * n <= a.ncu && n <= g_bb_ws.groups) {
-      if (hipMemsetAsync(g_bb_ws.cnt, 0, sizeof(int) * (size_t)n, (hipStream_t)stream) != hipSuccess) return SVDD_E_LAUNCH;
-      const dim3 sgrid((unsigned)(((n + 7) / 8) * 8 * R));
+    // ... and the TAIL ROUND of a batch that is not a multiple of the CU count (257 .. 384 sequences took two full rounds of
+    // one-workgroup tiles): whole rounds on backbone_kernel, the remainder — when it is at most half a round — split.
+    const int rem = n % a.ncu, n_main = n - rem;
+    const int ns = n_main == 0 ? n : rem;                 // sequences that go to the split kernel
+    int R = g_bb_split == 2 || g_bb_split == 4 ? g_bb_split : (4 * ns <= a.ncu ? 4 : 2 * ns <= a.ncu ? 2 : 1);
+    if (ns > 0 && R > 1 && (int64_t)R * ns <= a.ncu && ns <= g_bb_ws.groups) {
+      if (n_main > 0) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(backbone_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        BackboneArgs am = a;
+        am.n = n_main;
+        hipExtLaunchKernelGGL(backbone_kernel<true>, dim3((unsigned)n_main), dim3(512), lds, (hipStream_t)stream, e0, nullptr, 0, am);
+        if (hipGetLastError() != hipSuccess) return SVDD_E_LAUNCH;
+        a.x += (size_t)n_main * L; a.out += (size_t)n_main * L * 5; a.n = ns;
+        e0 = nullptr;                                     // one timed span over both launches
+      }
+      if (hipMemsetAsync(g_bb_ws.cnt, 0, sizeof(int) * (size_t)ns, (hipStream_t)stream) != hipSuccess) return SVDD_E_LAUNCH;
+      const dim3 sgrid((unsigned)(((ns + 7) / 8) * 8 * R));
       if (R == 2) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(backbone_split_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipExtLaunchKernelGGL(backbone_split_kernel<2>, sgrid, dim3(512), lds, (hipStream_t)stream, e0, e1, 0, a, g_bb_ws);

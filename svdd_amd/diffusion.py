@@ -278,11 +278,18 @@ class Diffusion(nn.Module):
                     from .fused_trunk import FusedEnformerValueNet
                     for k in [k for k, v in self._fused.items() if k != "backbone" and (v[0]() is None or v[1]() is None)]:
                         del self._fused[k]
-                    ent = (weakref.ref(embedding), weakref.ref(head), fp, FusedEnformerValueNet(embedding, head, tp), self._scope_id)
+                    try:
+                        fused_net = FusedEnformerValueNet(embedding, head, tp)
+                    except AssertionError:
+                        # a trunk whose GEMM shapes the kernels do not take (output channels must come in 128s, input channels
+                        # in 32s: a 384-channel toy trunk has a 192-channel stem) stays on the PyTorch modules
+                        fused_net = None
+                    ent = (weakref.ref(embedding), weakref.ref(head), fp, fused_net, self._scope_id)
                 else:
                     ent = ent[:4] + (self._scope_id,)
                 self._fused[key] = ent
-            return ent[3]
+            if ent[3] is not None:
+                return ent[3]
         if self.precision in ("bf16", "f16"):                       # opaque nets: PyTorch-ROCm's own 16-bit kernels
             dt = torch.bfloat16 if self.precision == "bf16" else torch.float16
 

@@ -324,8 +324,8 @@ def backbone_cnn(tokens, pk, count=None, out=None, row_idx=None, scatter=False):
     (HIP kernel svdd_backbone_cnn_f32)."""
     assert tokens.is_cuda and tokens.dtype == torch.uint8 and tokens.is_contiguous()
     n, L = tokens.shape
-    if n <= BB_SPLIT_MAX_SEQ and 104 < L <= 208 and count is None and row_idx is None:
-        _backbone_split_workspace(tokens.device)
+    if 104 < L <= 208 and count is None and row_idx is None and (n <= BB_SPLIT_MAX_SEQ or 0 < n % 256 <= BB_SPLIT_MAX_SEQ):
+        _backbone_split_workspace(tokens.device)       # small batches, and the tail round of a batch that is not a multiple of the CUs
     if out is None:
         out = torch.empty((n, L, 5), dtype=torch.float32, device=tokens.device)
     dil = (ctypes.c_int * len(pk["dil"]))(*pk["dil"])

@@ -2,7 +2,7 @@
 # Collects the judged evidence of a round on the GPU box into gpurun_out/<tag>_*:
 #   bench JSON line, rocprofv3 --kernel-trace --stats summary of the same command, per-kernel trace summary of our
 #   kernels, and FETCH_SIZE / WRITE_SIZE PMC passes (separate runs, --kernel-trace only) for the roofline kernels.
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=/root/repo/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
@@ -32,13 +32,13 @@ python3 - $OUT/${TAG}_pmc.txt $OUT/${TAG}_pmc.json $TAG <<'PY'
 import json, re, sys
 rows = {}
 for ln in open(sys.argv[1]):
-    m = re.match(r"(FETCH_SIZE|WRITE_SIZE) per dispatch \(KB\) (.*?)\s+grid=\s*\S*\s+n=(\d+) mean=([\d.]+) min=([\d.]+)", ln)
+    m = re.match(r"(FETCH_SIZE|WRITE_SIZE) per dispatch \(KB\) (.*?)\s+grid=\s*\S*\s+n=(\d+) mean=([\d.]+) min=([\d.]+) max=([\d.]+)", ln)
     if m:
-        rows.setdefault(m.group(2).strip(), {})[m.group(1)] = (float(m.group(4)), float(m.group(5)), int(m.group(3)))
-def traffic(pat, use_min=False):
+        rows.setdefault(m.group(2).strip(), {})[m.group(1)] = (float(m.group(4)), float(m.group(5)), int(m.group(3)), float(m.group(6)))
+def traffic(pat, use_min=False, use_max=False):
     for name, d in rows.items():
         if re.search(pat, name) and "FETCH_SIZE" in d and "WRITE_SIZE" in d:
-            k = 1 if use_min else 0
+            k = 3 if use_max else 1 if use_min else 0
             return int(2 * d["FETCH_SIZE"][k] * 1024 + d["WRITE_SIZE"][k] * 1024), name, d
     return None, None, None
 out = {"how": "two separate passes per counter (tools/collect_round_profile.sh %s): rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace "
@@ -49,6 +49,8 @@ t, name, d = traffic(r"backbone_kernel<true>")
 if t: out["backbone_traffic_bytes_per_launch"] = t; out["backbone"] = {"kernel": name, "FETCH_SIZE_KB": d["FETCH_SIZE"][0], "WRITE_SIZE_KB": d["WRITE_SIZE"][0], "algorithmic_bytes_per_launch": 14405104}
 t, name, d = traffic(r"propose_kernel<false, false>", use_min=True)
 if t: out["k1_traffic_bytes_per_launch"] = t; out["k1"] = {"kernel": name + " (min over the dispatches: the list also holds bench.py's saturated launches)", "FETCH_SIZE_KB": d["FETCH_SIZE"][1], "WRITE_SIZE_KB": d["WRITE_SIZE"][1], "algorithmic_bytes_per_launch": 9779200}
+t, name, d = traffic(r"propose_kernel<false, false>", use_max=True)
+if t: out["k1_saturated_traffic_bytes_per_launch"] = t; out["k1_saturated"] = {"kernel": name + " (max over the dispatches: bench.py's saturated launches, B = 16384)", "FETCH_SIZE_KB": d["FETCH_SIZE"][3], "WRITE_SIZE_KB": d["WRITE_SIZE"][3], "algorithmic_bytes_per_launch": 16384 * 200 * (21 + 17 * 10)}
 lp = {}
 for mode, pat in (("f16x3", r"backbone_lp_t_kernelIDF16_Li3E"), ("bf16x3", r"backbone_lp_t_kernelIDF16bLi3E"), ("bf16", r"backbone_lp_t_kernelIDF16bLi1E|backbone_lp_t_kernel<bool _Accum")):
     t, name, d = traffic(pat)
@@ -60,7 +62,7 @@ PY
 : > $OUT/${TAG}_pmc_k2_raw.txt
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_k2
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_k2 -- python3 /root/repo/tools/resample_microbench.py > /dev/null 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_k2 -- python3 /root/repo/tools/resample_microbench.py ld > /dev/null 2>&1
   python3 - $(find /tmp/pmc_k2 -name "*counter_collection.csv" | head -1) $c >> $OUT/${TAG}_pmc_k2_raw.txt <<'PY'
 import csv, sys, collections
 agg = collections.defaultdict(list)
