@@ -602,6 +602,10 @@ def main():
     ap.add_argument("--value-net", default="convgru", choices=["convgru", "enformer"],
                     help="enformer: the 230M-parameter Enformer-shaped value trunk of BASELINE config 4 (not the headline config)")
     ap.add_argument("--c4-steps", type=int, default=1, help="decodes timed for the config4_enformer object of the default line (0 = skip)")
+    ap.add_argument("--extra-legs", type=int, default=1,
+                    help="0: skip the legs that launch the headline's kernels under other conditions (replay_rng: the backbone with the "
+                         "mt19937 workgroup beside it; config1_b4: 4-sequence launches) — used for the rocprofv3 --stats pass, whose "
+                         "per-kernel averages should be the headline workload's")
     ap.add_argument("--c4-f32-steps", type=int, default=1, help="decodes of the config-4 shard timed at fp32 (the reference's precision) inside config4_enformer (0 = skip)")
     ap.add_argument("--cpu-passes", type=int, default=3, help="cpu_baseline passes; the median is reported (BASELINE.md section 2)")
     ap.add_argument("--dry-run", action="store_true",
@@ -821,8 +825,9 @@ def main():
             # (the near-tied leg first: scores ~1e-7 apart are what the random-init value nets of this workload actually produce)
             line["roofline_select_saturated"] = [select_saturated(dev, L=L, M=M, near_uniform=True), select_saturated(dev, L=L, M=M),
                                                  select_saturated(dev, L=L, M=20)]
-            line["replay_rng"] = replay_leg(model, emb, head, B, L, M, S)
-            line["config1_b4"] = small_batch_leg(model, emb, head, L, S)
+            if args.extra_legs:
+                line["replay_rng"] = replay_leg(model, emb, head, B, L, M, S)
+                line["config1_b4"] = small_batch_leg(model, emb, head, L, S)
             line["roofline_tds_resample"] = tds_saturated(dev, L=L)
             line["roofline_value_net"] = value_net_roofline(model, emb, head, dev, B, L, M, S, tower_total_ms, tower_launches,
                                                             gru_total_ms, gru_launches)

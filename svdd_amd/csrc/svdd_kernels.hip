@@ -1018,17 +1018,17 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
 }
 __device__ __forceinline__ float mt_float(uint32_t x) { return (float)(mt_temper(x) & 0xFFFFFFu) * (1.0f / 16777216.0f); }
 
-// Two roles (round 4, second version: 0.58 -> see DESIGN ns per output): waves 0-3 only advance the recurrence (4 LDS reads, two
-// twists, 2 LDS writes per pair of generations), waves 4-7 temper, convert and store the pair of generations of the interval
-// BEFORE, read back from the ring — the serial chain no longer carries the 25 instructions of the output path.
-__global__ __launch_bounds__(512) void mt19937_kernel(uint32_t* __restrict__ state, float* __restrict__ out, long long n) {
+// 256 threads and <= 16 VGPRs ON PURPOSE: the backbone's 256 workgroups take every CU for 2.1 of a step's 3.2 ms with 2 x 248
+// VGPRs per SIMD, which leaves 16 per SIMD and 16 KB of LDS — exactly enough for this kernel's four waves to run UNDER a backbone
+// workgroup instead of waiting for a CU. (A second version with separate twister / output waves was no faster alone — 0.565 vs
+// 0.579 ns per output: the interval is bound by its LDS round trip + barrier, not by the output path — and, needing 2 waves per
+// SIMD, could no longer co-reside: the replay decode went from 1.17x to 1.29x of the Philox decode. profiles/r04_mt_microbench.txt)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(16))) void mt19937_kernel(uint32_t* __restrict__ state, float* __restrict__ out, long long n) {
   __shared__ uint32_t ring[MT_RING];
-  const int tid = threadIdx.x;
-  const bool twister = tid < 256;
-  const int j = tid & 255;
+  const int j = threadIdx.x;
   const long long pos = (long long)state[MT_N];
   const long long total = pos + n;                        // one past the last element consumed
-  for (int k = tid; k < MT_N; k += 512) {
+  for (int k = j; k < MT_N; k += 256) {
     const uint32_t v = state[k];
     ring[k] = v;
     if (k >= pos && k < total) out[k - pos] = mt_float(v);  // what is left of the current block
@@ -1038,38 +1038,39 @@ __global__ __launch_bounds__(512) void mt19937_kernel(uint32_t* __restrict__ sta
   long long G = total > MT_N ? (total - MT_N + MT_GEN - 1) / MT_GEN : 0;
   G += (G & 1);
   const bool lane = j < MT_GEN;
-  uint32_t prev = (twister && lane) ? ring[MT_M + j] : 0u; // x[397 + j]: "generation -1" of this lane
+  uint32_t prev = lane ? ring[MT_M + j] : 0u;             // x[397 + j]: "generation -1" of this lane
   int r0 = j;                                             // ring slot of x[base + j], base = 227 g
-  // the output lanes run one interval behind: element m = 624 + base_o + j (+ 227)
-  long long mo = (long long)MT_N - 2 * MT_GEN + j;        // first interval: nothing to emit yet (mo + 2 * 227 = 624 + j next time)
-  int ro = (MT_N - 2 * MT_GEN + j) & (MT_RING - 1);
-  for (long long g = 0; g <= G; g += 2) {                 // one extra pass: the output lanes drain the last pair
-    if (twister) {
-      if (lane && g < G) {
-        const int r1 = (r0 + MT_GEN) & (MT_RING - 1);
-        const uint32_t a0 = ring[r0], b0 = ring[(r0 + 1) & (MT_RING - 1)];
-        const uint32_t a1 = ring[r1], b1 = ring[(r1 + 1) & (MT_RING - 1)];
-        const uint32_t x0 = prev ^ mt_tw(a0, b0);         // x[base + 624 + j]
-        const uint32_t x1 = x0 ^ mt_tw(a1, b1);           // x[base + 227 + 624 + j]   (its x[n + 397] is x0)
-        prev = x1;
-        ring[(r0 + MT_N) & (MT_RING - 1)] = x0;
-        ring[(r0 + MT_N + MT_GEN) & (MT_RING - 1)] = x1;
-        r0 = (r0 + 2 * MT_GEN) & (MT_RING - 1);
+  // element index of this lane's first output of the pair, relative to the first element wanted: i0 = 624 + base + j - pos
+  long long sbase = (long long)MT_N - pos;                // wave-uniform (scalar registers): this lane's i0 = sbase + j
+  for (long long g = 0; g < G; g += 2) {
+    if (lane) {
+      const int r1 = (r0 + MT_GEN) & (MT_RING - 1);
+      const uint32_t a0 = ring[r0], b0 = ring[(r0 + 1) & (MT_RING - 1)];
+      const uint32_t a1 = ring[r1], b1 = ring[(r1 + 1) & (MT_RING - 1)];
+      const uint32_t x0 = prev ^ mt_tw(a0, b0);           // x[base + 624 + j]
+      const uint32_t x1 = x0 ^ mt_tw(a1, b1);             // x[base + 227 + 624 + j]   (its x[n + 397] is x0)
+      prev = x1;
+      ring[(r0 + MT_N) & (MT_RING - 1)] = x0;
+      ring[(r0 + MT_N + MT_GEN) & (MT_RING - 1)] = x1;
+      r0 = (r0 + 2 * MT_GEN) & (MT_RING - 1);
+      // the whole pair inside [0, n) (every interval but the first and the last few): no per-lane range arithmetic
+      if (sbase >= 0 && sbase + 2 * MT_GEN <= n) {
+        float* o = out + sbase;
+        o[j] = mt_float(x0);
+        o[j + MT_GEN] = mt_float(x1);
+      } else {
+        const long long i0 = sbase + j, i1 = i0 + MT_GEN;
+        if (i0 >= 0 && i0 < n) out[i0] = mt_float(x0);
+        if (i1 >= 0 && i1 < n) out[i1] = mt_float(x1);
       }
-    } else if (lane && g > 0) {
-      const uint32_t x0 = ring[ro], x1 = ring[(ro + MT_GEN) & (MT_RING - 1)];
-      const long long m1 = mo + MT_GEN;
-      if (mo >= pos && mo < total) out[mo - pos] = mt_float(x0);
-      if (m1 >= pos && m1 < total) out[m1 - pos] = mt_float(x1);
     }
-    mo += 2 * MT_GEN;
-    ro = (ro + 2 * MT_GEN) & (MT_RING - 1);
+    sbase += 2 * MT_GEN;
     __syncthreads();
   }
   // new state: the window x[E .. E + 623], E = 227 G ; pos' = total - E (0 <= pos' <= 624)
   const long long E = G * MT_GEN;
-  for (int k = tid; k < MT_N; k += 512) state[k] = ring[(int)((E + k) & (MT_RING - 1))];
-  if (tid == 0) state[MT_N] = (uint32_t)(total - E);
+  for (int k = j; k < MT_N; k += 256) state[k] = ring[(int)((E + k) & (MT_RING - 1))];
+  if (j == 0) state[MT_N] = (uint32_t)(total - E);
 }
 
 // Optional per-launch timing (bench.py's roofline leg): when enabled, K1/K2 are launched with
@@ -1366,7 +1367,7 @@ int svdd_mt19937_uniform_f32(uint32_t* state, float* out, long long n, void* str
   if (!state || !out || n < 0) return SVDD_E_ARG;
   if (n == 0) return SVDD_OK;
   TimedLaunch* t = timed_slot(9);
-  hipExtLaunchKernelGGL(mt19937_kernel, dim3(1), dim3(512), 0, (hipStream_t)stream, t ? t->start : nullptr, t ? t->stop : nullptr, 0,
+  hipExtLaunchKernelGGL(mt19937_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, t ? t->start : nullptr, t ? t->stop : nullptr, 0,
                         state, out, n);
   return check_launch();
 }

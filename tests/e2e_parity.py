@@ -497,3 +497,91 @@ def free_running_lean_report(g, model, run, precision="f32"):
             "x0_exact": bool(np.array_equal(x0n, g["x0"])),
             "x0_rows_identical": float((x0n == g["x0"]).all(axis=1).mean()),
             "x0_tokens_identical": float((x0n == g["x0"]).mean())}
+
+
+def teacher_forced_lean_tds_report(g, model, reward_model, precision="f32"):
+    """g23: the reference's controlled_sample_TDS at BASELINE configs[4]'s per-GPU shard size (256 particles, L = 200, 128 steps;
+    reference diffusion_gosai.py:938-978, 1230-1284), teacher-forced: x_t -> backbone -> K1 (replayed uniforms, one proposal per
+    particle) -> proposals vs the reference's; the reference's proposals -> backbone -> x0-hat rows vs what its reward model was
+    handed; the reward kernels on the REFERENCE's x0-hat rows -> numerator rewards (1e-4); K4 on the reference's own reward vectors
+    and numpy's replayed uniforms -> ancestor indices and next state, exact. Then the free-running decode (torch + numpy streams
+    replayed; forward(sample) and the numerator reward reused across steps) against the reference's states."""
+    from svdd_amd import ops
+    S, B, L = int(g["S"]), int(g["B"]), int(g["L"])
+    dev = model.device
+    alpha = float(g["alpha"])
+    model.fuse_nets, model.precision, model.rng_mode = True, precision, "replay"
+    fn = model.reward_callable(reward_model)
+    sched, _, _ = model._schedule(S, 1e-5)
+    kept = {int(s): k for k, s in enumerate(g["logits_calls"])}
+    dl, dnum = [], np.zeros(S)
+    prop_same, prop_margins, xh_same, xh_gaps, idx_same, next_same, den_ok, den_n = 0, [], 0, [], 0, 0, 0, 0
+    torch.manual_seed(int(g["seed"]))
+    with torch.no_grad():
+        for i in range(S + 1):
+            x_np = g["xs"][i]
+            x = torch.from_numpy(x_np).to(dev).contiguous()
+            lg = model._backbone_logits(x)
+            if 3 * i in kept:
+                dl.append(float((lg.cpu() - torch.from_numpy(g["logits"][kept[3 * i]])).abs().max()))
+            if i == S:
+                break
+            sd = g["sample_delta"][i]
+            ref_sample = np.where(sd == 255, x_np, sd)
+            rng, u = _replay_uniforms(model, 1, B, L, lg)
+            mine, _, _ = ops.propose(lg, x, sched[i, 2], sched[i, 1], 1, rng)
+            mine = mine.cpu().numpy()[:, 0]
+            same = (mine == ref_sample).all(axis=1)
+            prop_same += int(same.sum())
+            if not same.all():
+                prop_margins += _explain_candidate_diffs(mine[:, None], ref_sample[:, None], lg.cpu().numpy(), u.cpu().numpy(), sched[i, 2], sched[i, 1])
+            smp = torch.from_numpy(ref_sample).to(dev).contiguous()
+            ls = model._backbone_logits(smp)
+            _, xh = ops.x0hat(ls, smp, want_tokens=True, want_onehot=False)
+            xd = g["x0hat_num_delta"][i]
+            ref_xh = np.where(xd == 255, ref_sample, xd)
+            xh_np = xh.cpu().numpy()
+            xh_same += int((xh_np == ref_xh).all(axis=1).sum())
+            if not np.array_equal(xh_np, ref_xh):
+                lsn = ls.cpu().numpy()
+                for r, l in zip(*np.nonzero(xh_np != ref_xh)):
+                    top = np.sort(lsn[r, l, :4])[::-1]
+                    xh_gaps.append(float(top[0] - top[1]))
+            ref_oh = torch.nn.functional.one_hot(torch.from_numpy(ref_xh).long(), 4).permute(0, 2, 1).float().contiguous().to(dev)
+            num = fn(ref_oh)[:, 0][:, 0].float()
+            dnum[i] = float((num.cpu() - torch.from_numpy(g["num"][i])).abs().max())
+            oh_den, _ = ops.x0hat(lg, x)
+            den = fn(oh_den)[:, 0][:, 0].float().cpu().numpy()
+            den_ok += int((np.abs(den - g["den"][i]) <= 1e-4).sum())
+            den_n += B
+            # K4 on the reference's own reward vectors: ancestors and next state exact
+            x_next, idx = ops.tds_resample(torch.from_numpy(g["num"][i]).to(dev), torch.from_numpy(g["den"][i]).to(dev), alpha, smp,
+                                           torch.from_numpy(g["choice_u"][i]).to(dev))
+            idx_same += int((idx.cpu().numpy() == g["idx"][i]).sum())
+            next_same += int((x_next.cpu().numpy() == g["xs"][i + 1]).all(axis=1).sum())
+    # free-running
+    model.state_trace = []
+    torch.manual_seed(int(g["seed"]))
+    np.random.seed(int(g["np_seed"]))
+    with torch.no_grad():
+        x0 = model.controlled_sample_TDS(reward_model, alpha, num_steps=S, eval_sp_size=B)
+    torch.cuda.synchronize()
+    xs = [t.cpu().numpy() for t in model.state_trace]
+    model.state_trace = None
+    model.precision = "f32"
+    n = min(len(xs), S + 1)
+    first = next((i for i in range(n) if not np.array_equal(xs[i], g["xs"][i])), None)
+    x0n = x0.cpu().numpy()
+    return {"S": S, "B": B, "L": L, "precision": precision,
+            "hand_written_net_kernels": bool(isinstance(fn, torch.nn.Module) and fn is not reward_model),
+            "max_abs_logit_err_kept_calls": max(dl) if dl else None,
+            "proposals": S * B, "proposals_identical": prop_same, "proposal_tokens_differing": len(prop_margins),
+            "max_race_margin_where_proposals_differ": max(prop_margins) if prop_margins else None,
+            "x0hat_rows_identical": xh_same, "x0hat_tokens_differing": len(xh_gaps),
+            "max_logit_top2_gap_where_x0hat_differs": max(xh_gaps) if xh_gaps else None,
+            "max_abs_reward_num_err": float(dnum.max()), "reward_den_within_1e-4": den_ok / max(den_n, 1),
+            "resample_indices_identical": idx_same, "resample_next_rows_identical": next_same,
+            "free_running": {"states_recorded": len(xs), "first_divergence_step": first,
+                             "x0_exact": bool(np.array_equal(x0n, g["x0"])),
+                             "x0_rows_identical": float((x0n == g["x0"]).all(axis=1).mean()),
+                             "x0_tokens_identical": float((x0n == g["x0"]).mean())}}

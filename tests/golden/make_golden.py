@@ -856,6 +856,66 @@ def g21_traj_pm_c3(seed=0, B=256, L=50, M=10, S=128):
          seed=seed, net_seed=44, B=B, L=L, M=M, S=S, threads=torch.get_num_threads(), sched=sched_rows(d, S), **arrs)
 
 
+def g23_traj_tds_c5(seed=0, np_seed=1, alpha=0.5, B=256, L=200, S=128):
+    """BASELINE.json configs[4]'s SMC / TDS baseline at its per-GPU shard size, run by the reference: controlled_sample_TDS
+    (diffusion_gosai.py:938-978, 1230-1284) with the full-size seed-44 nets + reward model, 256 particles, 128 steps (3 backbone
+    forwards + 2 reward calls per step; ~8 min on the 8 build cores). Lean: states, proposals (delta-coded), the x0-hat rows handed
+    to the reward model for the numerator (as tokens; the denominator's are the previous numerator's resampled), both reward
+    vectors, the ancestor indices np.random.choice drew, x_0."""
+    d, emb_v, head_v = full_nets(length=L, steps=S)
+    emb_r, head_r = full_reward()
+    reward = RewardWrap(emb_r, head_r).eval()
+    rec = LeanRecBackbone(d.backbone, keep=(0, 3 * S))
+    d.backbone = rec
+    xh, outs, choices = [], [], []
+
+    class Rew:
+        def __call__(self, x):                                        # [B, 4, L] one-hot float
+            assert bool((x.sum(1) == 1).all())
+            xh.append(x.argmax(1).to(torch.uint8))
+            y = reward(x)
+            outs.append(y[:, 0][:, 0].detach().clone())
+            return y
+
+        def eval(self):
+            return self
+
+    real_choice = np.random.choice
+
+    def choice(*a, **k):
+        r = real_choice(*a, **k)
+        choices.append(np.asarray(r).copy())
+        return r
+
+    torch.manual_seed(seed)
+    np.random.seed(np_seed)
+    np.random.choice = choice
+    try:
+        x0 = d.controlled_sample_TDS(Rew(), alpha, eval_sp_size=B)
+    finally:
+        np.random.choice = real_choice
+    d.backbone = rec.inner
+    calls = rec.xs
+    assert len(calls) == 3 * S + 1 and len(outs) == 2 * S and len(choices) == S
+    xs = torch.stack([calls[3 * i] for i in range(S)] + [calls[3 * S]])
+    samples = torch.stack([calls[3 * i + 1] for i in range(S)])
+    x0hat_num = torch.stack([xh[2 * i] for i in range(S)])
+    num = torch.stack([outs[2 * i] for i in range(S)])
+    den = torch.stack([outs[2 * i + 1] for i in range(S)])
+    idx = np.stack(choices).astype(np.int32)
+    assert torch.equal(torch.stack([samples[i][torch.from_numpy(idx[i]).long()] for i in range(S)]), xs[1:])
+    np.random.seed(np_seed)
+    choice_u = np.random.random_sample(S * B).reshape(S, B)
+    arrs = {n_ + "_param_sums": np.array([float(p.double().sum()) for p in mod.state_dict().values()])
+            for n_, mod in (("backbone", d.backbone), ("embedding", emb_v), ("head", head_v), ("reward_embedding", emb_r),
+                            ("reward_head", head_r))}
+    kept = sorted(rec.logits)
+    save("g23_traj_tds_c5.npz", xs=xs, sample_delta=torch.where(samples == xs[:-1], torch.full_like(samples, 255), samples),
+         x0hat_num_delta=torch.where(x0hat_num == samples, torch.full_like(samples, 255), x0hat_num), num=num, den=den, idx=idx,
+         choice_u=choice_u, x0=x0.to(torch.uint8), logits_calls=np.array(kept), logits=torch.stack([rec.logits[k] for k in kept]),
+         alpha=alpha, seed=seed, np_seed=np_seed, net_seed=44, B=B, L=L, S=S, threads=torch.get_num_threads(), sched=sched_rows(d, S), **arrs)
+
+
 def g21():
     # full-size batches: all build cores (the small fixtures above are generated single-threaded; g21 records the thread count)
     torch.set_num_threads(int(os.environ.get("SVDD_GOLDEN_THREADS", "8")))
@@ -932,6 +992,10 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "g18":
         g18()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "g23":
+        torch.set_num_threads(int(os.environ.get("SVDD_GOLDEN_THREADS", "8")))
+        g23_traj_tds_c5()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "g22":
         g22_harness()

@@ -275,3 +275,33 @@ def test_headline_config_c3_against_the_reference_run(golden, rna_nets, precisio
         g, model, lambda m: m.controlled_sample_tweedie(reward, num_steps=S, eval_sp_size=B, sample_M=M, options="True"), precision)
     print("g21 c3 free-running", run)
     _assert_free_running_lean(run, pm=True)
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_tds_baseline_at_the_c5_shard_size_against_the_reference_run(golden, full_nets, precision):
+    """g23: BASELINE configs[4]'s SMC / TDS baseline as the reference ran it at the per-GPU shard size (256 particles, L = 200,
+    128 steps, full-size nets + reward model): proposals re-drawn from the replayed stream, x0-hat rows, numerator rewards
+    (1e-4), K4's ancestors on the reference's own weights (exact), then the free-running decode."""
+    from tests import e2e_parity
+    g = golden("g23_traj_tds_c5.npz")
+    model, emb, head, reward = full_nets
+    _same_nets(g, (("backbone", model.backbone), ("embedding", emb), ("head", head), ("reward_embedding", reward.embedding),
+                   ("reward_head", reward.head)))
+    rep = e2e_parity.teacher_forced_lean_tds_report(g, model, reward, precision)
+    print("g23 tds", rep)
+    S, B = int(g["S"]), int(g["B"])
+    assert rep["hand_written_net_kernels"]
+    assert rep["max_abs_logit_err_kept_calls"] <= TOL, rep
+    assert rep["max_abs_reward_num_err"] <= TOL, rep
+    assert rep["reward_den_within_1e-4"] >= 0.999, rep
+    assert rep["proposals_identical"] >= S * B - 4, rep
+    if rep["proposal_tokens_differing"]:
+        assert rep["max_race_margin_where_proposals_differ"] <= TOL, rep
+    assert rep["x0hat_rows_identical"] >= S * B - 8, rep
+    if rep["x0hat_tokens_differing"]:
+        assert rep["max_logit_top2_gap_where_x0hat_differs"] <= 2 * TOL, rep
+    assert rep["resample_indices_identical"] == S * B and rep["resample_next_rows_identical"] == S * B, rep      # K4: exact
+    fr = rep["free_running"]
+    assert fr["states_recorded"] >= S
+    if fr["first_divergence_step"] is None:
+        assert fr["x0_exact"], rep

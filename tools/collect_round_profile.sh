@@ -9,13 +9,13 @@ cd /tmp && export TMPDIR=/tmp
 OURS="backbone_kernel backbone_lp_kernel backbone_lp_t_kernel conv_tower tower_lp gru_bidir gru_pc gru_lp value_tail tail_lp candidate_windows compact_flags propose_kernel select_kernel select_rows_kernel tds_cdf tds_gather transform advance_rows gather_rows x0hat epilogue_ln conv1d_cl"
 python3 /root/repo/bench.py --steps 3 --warmup 1 2>/dev/null | tail -1 > $OUT/${TAG}_bench.json
 rm -rf /tmp/prof_$TAG
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o $TAG -- python3 /root/repo/bench.py --steps 2 --warmup 1 --cpu-steps 0 --c4-steps 0 > /tmp/prof_$TAG.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o $TAG -- python3 /root/repo/bench.py --steps 2 --warmup 1 --cpu-steps 0 --c4-steps 0 --extra-legs 0 > /tmp/prof_$TAG.log 2>&1
 cp $(find /tmp/prof_$TAG -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_bench_kernel_stats.csv
 python3 /root/repo/tools/trace_summary.py $(find /tmp/prof_$TAG -name "*kernel_trace.csv" | head -1) $OURS > $OUT/${TAG}_own_kernels_trace_summary.txt
 : > $OUT/${TAG}_pmc.txt
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -- python3 /root/repo/bench.py --steps 1 --warmup 0 --cpu-steps 0 --c4-steps 0 --alt-precision f16x3,bf16x3,bf16 --alt-steps 1 > /tmp/pmc_$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -- python3 /root/repo/bench.py --steps 1 --warmup 0 --cpu-steps 0 --c4-steps 0 --extra-legs 0 --alt-precision f16x3,bf16x3,bf16 --alt-steps 1 > /tmp/pmc_$c.log 2>&1
   python3 - $(find /tmp/pmc_$c -name "*counter_collection.csv" | head -1) $c >> $OUT/${TAG}_pmc.txt <<'PY'
 import csv, sys, collections
 agg = collections.defaultdict(list)
@@ -42,7 +42,7 @@ def traffic(pat, use_min=False, use_max=False):
             return int(2 * d["FETCH_SIZE"][k] * 1024 + d["WRITE_SIZE"][k] * 1024), name, d
     return None, None, None
 out = {"how": "two separate passes per counter (tools/collect_round_profile.sh %s): rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace "
-              "--output-format csv -- python3 bench.py --steps 1 --warmup 0 --cpu-steps 0 --alt-precision f16x3,bf16x3,bf16 --alt-steps 1 ; "
+              "--output-format csv -- python3 bench.py --steps 1 --warmup 0 --cpu-steps 0 --c4-steps 0 --extra-legs 0 --alt-precision f16x3,bf16x3,bf16 --alt-steps 1 ; "
               "per-dispatch means in profiles/%s_pmc.txt (rocprofv3 reports KB)" % (sys.argv[3], sys.argv[3]),
        "fetch_correction": "x2: on gfx950 FETCH_SIZE tallies 128-B requests as 64 B for wide coalesced streams (MI355X_MICROARCH.md, HBM section)"}
 t, name, d = traffic(r"backbone_kernel<true>")
@@ -58,20 +58,23 @@ for mode, pat in (("f16x3", r"backbone_lp_t_kernelIDF16_Li3E"), ("bf16x3", r"bac
 out["backbone_lp_traffic_bytes_per_launch"] = lp
 json.dump(out, open(sys.argv[2], "w"), indent=1)
 PY
-# K2 / K4 at saturation: HBM bytes actually moved (the gather of 200-byte rows over-fetches) -> ${TAG}_pmc_k2_raw.txt
+# K2 at saturation: HBM bytes actually moved, one pass per counter and candidate-row stride (200 = dense: the gather of 200-byte rows
+# over-fetches; 256 = whole lines) -> ${TAG}_pmc_k2_raw.txt
 : > $OUT/${TAG}_pmc_k2_raw.txt
+for ld in 0 256; do
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_k2
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_k2 -- python3 /root/repo/tools/resample_microbench.py ld > /dev/null 2>&1
-  python3 - $(find /tmp/pmc_k2 -name "*counter_collection.csv" | head -1) $c >> $OUT/${TAG}_pmc_k2_raw.txt <<'PY'
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_k2 -- python3 /root/repo/tools/resample_microbench.py one 10 $ld > /dev/null 2>&1
+  python3 - $(find /tmp/pmc_k2 -name "*counter_collection.csv" | head -1) $c $ld >> $OUT/${TAG}_pmc_k2_raw.txt <<'PY'
 import csv, sys, collections
 agg = collections.defaultdict(list)
 for r in csv.DictReader(open(sys.argv[1])):
     n = r["Kernel_Name"]
-    if "select_rows" in n or "tds_" in n:
+    if "select_rows" in n:
         agg[(n[:70], r["Grid_Size"])].append(float(r["Counter_Value"]))
 for k, v in sorted(agg.items()):
-    print("%s per dispatch (KB) %-72s grid=%-8s n=%d mean=%.1f" % (sys.argv[2], k[0], k[1], len(v), sum(v) / len(v)))
+    print("row stride %s: %s per dispatch (KB) %-72s grid=%-8s n=%d mean=%.1f" % (sys.argv[3] if sys.argv[3] != "0" else "200", sys.argv[2], k[0], k[1], len(v), sum(v) / len(v)))
 PY
+done
 done
 cat $OUT/${TAG}_bench.json | cut -c1-400; cat $OUT/${TAG}_pmc.txt; cat $OUT/${TAG}_own_kernels_trace_summary.txt
