@@ -124,12 +124,13 @@ def select_saturated(dev, L=200, M=10, B=1 << 18, iters=50, near_uniform=False):
     gbs = nbytes / (tot / n * 1e-3) / 1e9
     del cand, scores
     torch.cuda.empty_cache()
-    # HBM bytes actually moved per launch, from the separate PMC pass of tools/resample_microbench.py (FETCH_SIZE x 2 + WRITE_SIZE,
-    # MI355X_MICROARCH.md HBM section): the 200-byte rows gathered at arbitrary offsets over-fetch 1.56x
+    # HBM bytes actually moved per launch, from the separate PMC passes of tools/resample_microbench.py (FETCH_SIZE x 2 + WRITE_SIZE,
+    # rocprofv3 reports KB = 1024 B; MI355X_MICROARCH.md HBM section): the 200-byte rows gathered at arbitrary offsets over-fetch
     traffic, src = None, None
-    if (B, L) == (1 << 18, 200) and M in (10, 20):
-        traffic = {10: 2 * 48944.7e3 + 53274.9e3, 20: 2 * 51210.6e3 + 52225.0e3}[M]
-        src = "profiles/r03_pmc_k2_saturated.txt (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, not measured in this run)"
+    if (B, L, M) == (1 << 18, 200, 10):
+        traffic = (2 * 46149.5 + 52275.1) * 1024
+        src = ("profiles/r04_pmc_k2_raw.txt, row stride 200 (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+               "tools/resample_microbench.py one 10 0, not measured in this run)")
     return {"bound": "hbm", "kernel": "select_rows_kernel (K2: softmax over M, argmax, index-gather compaction), saturated",
             "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5),
             "bytes_per_launch": nbytes, "traffic": None if traffic is None else round(traffic), "traffic_source": src,
