@@ -278,7 +278,10 @@ class DeviceReplayStream:
     (2.5 KB) is uploaded at open(), `uniforms(n)` returns the next n floats of the stream as a device tensor (K8
     `svdd_mt19937_uniform_f32`: one workgroup, launched on a side stream ONE CALL AHEAD so that it runs under the nets of the
     current diffusion step), and close() writes the advanced state back into torch's generator — after it, torch.rand() on
-    the host continues exactly where the reference's run would. Token-exact with the host replay (tests/test_kernels_gpu.py)."""
+    the host continues exactly where the reference's run would. Token-exact with the host replay (tests/test_kernels_gpu.py).
+    Contract: between open and close() nothing else may draw from torch's CPU generator (the reference's eval-mode hot path does
+    not either: rand_like in _sample_categorical is its only consumer); a value function that did (dropout in
+    train mode) would see the pre-decode state — use Diffusion.replay_rng = "host" for such a net."""
 
     def __init__(self, device):
         self.dev = torch.device(device)

@@ -52,4 +52,7 @@ out["headline_c3"] = {"fixture": "g21_traj_pm_c3.npz", "runs": [
      "free_running": e2e_parity.free_running_lean_report(
          g, rna, lambda m: m.controlled_sample_tweedie(reward_r, num_steps=S, eval_sp_size=B, sample_M=M, options="True"), p)}
     for p in ("f32", "f16x3", "bf16x3")]}
+# g23: the reference's SMC / TDS run at the configs[4] per-GPU shard size (256 particles, 128 steps)
+g = dict(np.load(os.path.join(G, "g23_traj_tds_c5.npz")))
+out["tds_c5_shard"] = {"fixture": "g23_traj_tds_c5.npz", "runs": [e2e_parity.teacher_forced_lean_tds_report(g, model, reward, p) for p in ("f32", "f16x3", "bf16x3")]}
 print(json.dumps(out, indent=1))
