@@ -585,3 +585,53 @@ def teacher_forced_lean_tds_report(g, model, reward_model, precision="f32"):
                              "x0_exact": bool(np.array_equal(x0n, g["x0"])),
                              "x0_rows_identical": float((x0n == g["x0"]).all(axis=1).mean()),
                              "x0_tokens_identical": float((x0n == g["x0"]).mean())}}
+
+
+def unguided_lean_report(g, model, precision="f32"):
+    """g24: the reference's un-guided `decode_sample` (diffusion_gosai.py:888-936, 1147-1172) at B = 256, L = 200, 128 steps.
+    Teacher-forced: x_t -> backbone -> K1 (one draw per position from the replayed stream) -> the reference's next state; the
+    noise-removal argmax (:1049-1060) on the last state -> x_0. A differing token must be a near-tie of the categorical draw /
+    of the two best real-token logits. Free-running: the engine's decode_sample in replay mode against the reference's x_0."""
+    from svdd_amd import ops
+    S, B, L = int(g["S"]), int(g["B"]), int(g["L"])
+    dev = model.device
+    model.fuse_nets, model.precision, model.rng_mode = True, precision, "replay"
+    sched, _, _ = model._schedule(S, 1e-5)
+    kept = {int(s): k for k, s in enumerate(g["logits_steps"])}
+    dl, margins, fgaps = [], [], []
+    rows_same = 0
+    torch.manual_seed(int(g["seed"]))
+    with torch.no_grad():
+        for i in range(S + 1):
+            x = torch.from_numpy(g["xs"][i]).to(dev).contiguous()
+            lg = model._backbone_logits(x)
+            if i in kept:
+                dl.append(float((lg.cpu() - torch.from_numpy(g["logits"][kept[i]])).abs().max()))
+            if i == S:
+                x0 = ops.finalize(lg, x).cpu().numpy()
+                fin_same = int((x0 == g["x0"]).all(axis=1).sum())
+                if fin_same != B:
+                    lgn = lg.cpu().numpy()
+                    for b, l in zip(*np.nonzero(x0 != g["x0"])):
+                        top = np.sort(lgn[b, l, :4])[::-1]
+                        fgaps.append(float(top[0] - top[1]))
+                break
+            rng, u = _replay_uniforms(model, 1, B, L, lg)
+            mine, _, _ = ops.propose(lg, x, sched[i, 2], sched[i, 1], 1, rng)
+            mine = mine.cpu().numpy()[:, 0]
+            ref = g["xs"][i + 1]
+            same = (mine == ref).all(axis=1)
+            rows_same += int(same.sum())
+            if not same.all():
+                margins += _explain_candidate_diffs(mine[:, None], ref[:, None], lg.cpu().numpy(), u.cpu().numpy(), sched[i, 2], sched[i, 1])
+    torch.manual_seed(int(g["seed"]))
+    with torch.no_grad():
+        x0f = model.decode_sample(num_steps=S, eval_sp_size=B).cpu().numpy()
+    model.precision = "f32"
+    return {"S": S, "B": B, "L": L, "precision": precision, "max_abs_logit_err_kept_calls": max(dl) if dl else None,
+            "row_steps": S * B, "next_states_identical": rows_same, "tokens_differing": len(margins),
+            "max_race_margin_where_tokens_differ": max(margins) if margins else None,
+            "noise_removal_rows_identical": fin_same, "max_logit_top2_gap_where_x0_differs": max(fgaps) if fgaps else None,
+            "free_running": {"x0_exact": bool(np.array_equal(x0f, g["x0"])),
+                             "x0_rows_identical": float((x0f == g["x0"]).all(axis=1).mean()),
+                             "x0_tokens_identical": float((x0f == g["x0"]).mean())}}

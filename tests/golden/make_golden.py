@@ -916,6 +916,60 @@ def g23_traj_tds_c5(seed=0, np_seed=1, alpha=0.5, B=256, L=200, S=128):
          alpha=alpha, seed=seed, np_seed=np_seed, net_seed=44, B=B, L=L, S=S, threads=torch.get_num_threads(), sched=sched_rows(d, S), **arrs)
 
 
+def g24_decode_sample_c2(seed=0, B=256, L=200, S=128):
+    """The un-guided ancestral decode (`decode_sample`, diffusion_gosai.py:888-936, 1147-1172: what the harness's baseline loop
+    runs gen_batch_num * sample_M times) by the reference at the headline batch: B = 256, L = 200, 128 steps, full-size seed-44
+    backbone. Every state + x_0 (+ the raw logits of the first and the noise-removal call)."""
+    d, _, _ = full_nets(steps=S, length=L)
+    rec = LeanRecBackbone(d.backbone, keep=(0, S))
+    d.backbone = rec
+    torch.manual_seed(seed)
+    x0 = d.decode_sample(eval_sp_size=B)
+    d.backbone = rec.inner
+    assert len(rec.xs) == S + 1
+    kept = sorted(rec.logits)
+    save("g24_decode_sample_c2.npz", xs=torch.stack(rec.xs), x0=x0.to(torch.uint8), logits_steps=np.array(kept),
+         logits=torch.stack([rec.logits[k] for k in kept]), seed=seed, net_seed=44, B=B, L=L, S=S, threads=torch.get_num_threads(),
+         backbone_param_sums=np.array([float(p.double().sum()) for p in d.backbone.state_dict().values()]), sched=sched_rows(d, S))
+
+
+def g25_traj_mc_m20():
+    """BASELINE configs[3]'s sampler shape — SVDD-MC with M = 20 candidates per row — at the shard batch (B = 256, L = 200) by the
+    reference, with the ConvGRU value net (the Enformer-shaped trunk of that config cannot be imported: enformer_pytorch is absent),
+    48 steps of a 48-step schedule: K1 / K2 at M = 20 (the 32-lane candidate groups of the select kernel) on 245,760 reference
+    candidates."""
+    d, emb_m, head_m = full_nets(steps=48, length=200)
+    S, B, L, M, seed = 48, 256, 200, 20, 3
+    rec = LeanRecBackbone(d.backbone, keep=(0, S))
+    d.backbone = rec
+    cands, scores = [], []
+
+    def emb(x):
+        s_ = x.sum(-1)
+        cands.append(torch.where(s_ > 0, x.argmax(-1), torch.full_like(x.argmax(-1), 4)).to(torch.uint8))
+        return emb_m(x)
+
+    def head(h):
+        y = head_m(h)
+        scores.append(y.detach().squeeze().clone())
+        return y
+
+    torch.manual_seed(seed)
+    x0 = d.controlled_sample(emb, head, eval_sp_size=B, sample_M=M)
+    d.backbone = rec.inner
+    xs = torch.stack(rec.xs)
+    cand = torch.stack(cands).view(S, M, B, L).permute(0, 2, 1, 3).contiguous()
+    sc = torch.stack(scores).view(S, M, B).permute(0, 2, 1).contiguous()
+    idx = torch.softmax(sc, dim=2).argmax(dim=2).to(torch.uint8)
+    assert torch.equal(torch.gather(cand, 2, idx.long()[:, :, None, None].expand(S, B, 1, L))[:, :, 0], xs[1:])
+    arrs = {n_ + "_param_sums": np.array([float(p.double().sum()) for p in mod.state_dict().values()])
+            for n_, mod in (("backbone", d.backbone), ("embedding", emb_m), ("head", head_m))}
+    kept = sorted(rec.logits)
+    save("g25_traj_mc_m20.npz", xs=xs, cand_delta=torch.stack([_delta(cand[s_], xs[s_]) for s_ in range(S)]), scores=sc, idx=idx,
+         x0=x0.to(torch.uint8), logits_steps=np.array(kept), logits=torch.stack([rec.logits[k] for k in kept]),
+         seed=seed, net_seed=44, B=B, L=L, M=M, S=S, threads=torch.get_num_threads(), sched=sched_rows(d, S), **arrs)
+
+
 def g21():
     # full-size batches: all build cores (the small fixtures above are generated single-threaded; g21 records the thread count)
     torch.set_num_threads(int(os.environ.get("SVDD_GOLDEN_THREADS", "8")))
@@ -992,6 +1046,10 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "g18":
         g18()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] in ("g24", "g25"):
+        torch.set_num_threads(int(os.environ.get("SVDD_GOLDEN_THREADS", "8")))
+        {"g24": g24_decode_sample_c2, "g25": g25_traj_mc_m20}[sys.argv[1]]()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "g23":
         torch.set_num_threads(int(os.environ.get("SVDD_GOLDEN_THREADS", "8")))

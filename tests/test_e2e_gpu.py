@@ -305,3 +305,44 @@ def test_tds_baseline_at_the_c5_shard_size_against_the_reference_run(golden, ful
     assert fr["states_recorded"] >= S
     if fr["first_divergence_step"] is None:
         assert fr["x0_exact"], rep
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_unguided_decode_at_the_headline_batch_against_the_reference_run(golden, full_nets, precision):
+    """g24: `decode_sample` (the harness's baseline loop, reference diffusion_gosai.py:888-936) as the reference ran it at B = 256,
+    L = 200, 128 steps with the full-size backbone: every transition re-drawn from the replayed stream, the noise-removal argmax,
+    and the free-running decode."""
+    from tests import e2e_parity
+    g = golden("g24_decode_sample_c2.npz")
+    model = full_nets[0]
+    sums = np.array([float(p.double().sum()) for p in model.backbone.state_dict().values()])
+    assert np.allclose(sums, g["backbone_param_sums"], rtol=0, atol=1e-6)
+    rep = e2e_parity.unguided_lean_report(g, model, precision)
+    print("g24 unguided", rep)
+    assert rep["max_abs_logit_err_kept_calls"] <= TOL, rep
+    assert rep["next_states_identical"] >= rep["row_steps"] - 4, rep
+    if rep["tokens_differing"]:
+        assert rep["max_race_margin_where_tokens_differ"] <= TOL, rep
+    assert rep["noise_removal_rows_identical"] >= int(g["B"]) - 2, rep
+    if rep["max_logit_top2_gap_where_x0_differs"] is not None:
+        assert rep["max_logit_top2_gap_where_x0_differs"] <= 2 * TOL, rep
+    assert rep["free_running"]["x0_rows_identical"] >= 0.97, rep          # a flipped draw changes that row's later states
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_mc_with_20_candidates_at_the_shard_batch_against_the_reference_run(golden, full_nets, precision):
+    """g25: BASELINE configs[3]'s sampler shape (M = 20) at the shard batch B = 256 with the ConvGRU value net, 48 steps, run by
+    the reference: K1 / K2 with 20 candidates per row (the select kernel's 32-lane groups) on 245,760 reference candidates,
+    teacher-forced and free-running."""
+    from tests import e2e_parity
+    g = golden("g25_traj_mc_m20.npz")
+    model, emb, head, _ = full_nets
+    _same_nets(g, (("backbone", model.backbone), ("embedding", emb), ("head", head)))
+    rep = e2e_parity.teacher_forced_lean_report(g, model, emb, head, precision)
+    print("g25 m20 teacher-forced", rep)
+    _assert_teacher_forced_lean(rep)
+    B, M, S = int(g["B"]), int(g["M"]), int(g["S"])
+    run = e2e_parity.free_running_lean_report(
+        g, model, lambda m: m.controlled_sample(emb, head, num_steps=S, eval_sp_size=B, sample_M=M), precision)
+    print("g25 m20 free-running", run)
+    _assert_free_running_lean(run)

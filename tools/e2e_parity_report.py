@@ -55,4 +55,14 @@ out["headline_c3"] = {"fixture": "g21_traj_pm_c3.npz", "runs": [
 # g23: the reference's SMC / TDS run at the configs[4] per-GPU shard size (256 particles, 128 steps)
 g = dict(np.load(os.path.join(G, "g23_traj_tds_c5.npz")))
 out["tds_c5_shard"] = {"fixture": "g23_traj_tds_c5.npz", "runs": [e2e_parity.teacher_forced_lean_tds_report(g, model, reward, p) for p in ("f32", "f16x3", "bf16x3")]}
+# g24 / g25: the un-guided decode at B = 256 and SVDD-MC with M = 20 at the shard batch
+g = dict(np.load(os.path.join(G, "g24_decode_sample_c2.npz")))
+out["unguided_c2_batch"] = {"fixture": "g24_decode_sample_c2.npz", "runs": [e2e_parity.unguided_lean_report(g, model, p) for p in ("f32", "f16x3", "bf16x3")]}
+g = dict(np.load(os.path.join(G, "g25_traj_mc_m20.npz")))
+B, M, S = int(g["B"]), int(g["M"]), int(g["S"])
+out["mc_m20_shard_batch"] = {"fixture": "g25_traj_mc_m20.npz", "runs": [
+    {"teacher_forced": e2e_parity.teacher_forced_lean_report(g, model, emb, head, p),
+     "free_running": e2e_parity.free_running_lean_report(
+         g, model, lambda m: m.controlled_sample(emb, head, num_steps=S, eval_sp_size=B, sample_M=M), p)}
+    for p in ("f32", "f16x3", "bf16x3")]}
 print(json.dumps(out, indent=1))
