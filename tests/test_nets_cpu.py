@@ -206,3 +206,19 @@ def test_enformer_trunk_equals_reference_wiring_fixture():
     assert y.shape == g["trunk_out"].shape and float(np.abs(g["trunk_out"]).max()) > 0.05
     assert float((y - torch.from_numpy(g["trunk_out"])).abs().max()) <= 2e-5
     assert float((v - torch.from_numpy(g["value"])).abs().max()) <= 2e-5
+
+
+def test_trunk_fp32_weight_packing_is_the_documented_fragment_order():
+    """fused_trunk.pack_gemm_weight_f32 (the fp32-plane form of svdd_trunk_gemm, include/svdd_hip.h SVDD_OPT_TRUNK_PLANES_F32):
+    [KB = c * T + t][N/128][8 n-tiles][2 pieces][64 lanes = 16 g + j][4 e] = W[128 nb + 16 nt + j][32 c + 8 g + 4 p + e][t] —
+    what the kernel's LDS-DMA copies verbatim into MFMA fragment order. Checked element by element, k = 1 and k = 5."""
+    from svdd_amd.fused_trunk import pack_gemm_weight_f32
+    g = torch.Generator().manual_seed(0)
+    for N, Cin, T in ((256, 64, 5), (128, 96, 1)):
+        w = torch.randn(N, Cin, T, generator=g)
+        pk = pack_gemm_weight_f32(w if T > 1 else w[:, :, 0]).view(Cin // 32, T, N // 128, 8, 2, 4, 16, 4)   # [c][t][nb][nt][p][g][j][e]
+        assert pk.dtype == torch.float32 and pk.numel() == w.numel()
+        idx = torch.randint(0, 10 ** 9, (200, 8), generator=g)
+        for c, t, nb, nt, p, gg, j, e in idx.tolist():
+            c, t, nb, nt, p, gg, j, e = c % (Cin // 32), t % T, nb % (N // 128), nt % 8, p % 2, gg % 4, j % 16, e % 4
+            assert pk[c, t, nb, nt, p, gg, j, e] == w[128 * nb + 16 * nt + j, 32 * c + 8 * gg + 4 * p + e, t]
