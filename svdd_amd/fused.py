@@ -311,11 +311,12 @@ def _backbone_split_workspace(dev):
     """Caller-owned scratch of the small-batch backbone (svdd_backbone_cnn_f32 on 2 / 4 workgroups per sequence, same bits):
     the double-buffered LayerNorm images of up to 128 sequences + arrival counters (27 MB), registered once per process."""
     key = str(dev)
+    nbytes = BB_SPLIT_MAX_SEQ * (2 * 208 * 128 * 4 + 4) + 4
     if key not in _BB_SPLIT_WS:
-        nbytes = BB_SPLIT_MAX_SEQ * (2 * 208 * 128 * 4 + 4) + 4
-        ws = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
-        _lib.check(_lib.lib().svdd_backbone_set_workspace(ws.data_ptr(), nbytes), "svdd_backbone_set_workspace")
-        _BB_SPLIT_WS[key] = ws
+        _BB_SPLIT_WS[key] = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+    if _BB_SPLIT_WS.get("registered") != key:          # the library holds ONE workspace pointer: follow the device in use
+        _lib.check(_lib.lib().svdd_backbone_set_workspace(_BB_SPLIT_WS[key].data_ptr(), nbytes), "svdd_backbone_set_workspace")
+        _BB_SPLIT_WS["registered"] = key
     return _BB_SPLIT_WS[key]
 
 

@@ -273,6 +273,9 @@ def mt_state_to_torch(words_pos, template_u8):
     return torch.from_numpy(a)
 
 
+_REPLAY_SIDE_STREAMS = {}
+
+
 class DeviceReplayStream:
     """torch's global CPU generator continued ON THE DEVICE for the span of one decode (rng_mode = "replay"): the state
     (2.5 KB) is uploaded at open(), `uniforms(n)` returns the next n floats of the stream as a device tensor (K8
@@ -289,7 +292,10 @@ class DeviceReplayStream:
         import numpy as np
         st = mt_state_from_torch(self.template)
         self.state = torch.from_numpy(st.astype(np.uint32).view(np.int32).copy()).to(self.dev)          # [625] u32 bits
-        self.side = torch.cuda.Stream(device=self.dev)
+        key = self.dev.index if self.dev.index is not None else torch.cuda.current_device()
+        if key not in _REPLAY_SIDE_STREAMS:        # one side stream per device for the life of the process (a decode opens one of
+            _REPLAY_SIDE_STREAMS[key] = torch.cuda.Stream(device=self.dev)   # these objects per sampler call; HIP has few hardware queues)
+        self.side = _REPLAY_SIDE_STREAMS[key]
         self.side.wait_stream(torch.cuda.current_stream(self.dev))
         self.bufs = {}            # n -> [two device buffers]
         self.flip = 0

@@ -380,14 +380,14 @@ def test_dps_gradient_follows_a_data_swap_of_the_conv_weights():
     g_hip, g_ref = grad(True), grad(False)
     assert model.backbone.hip_convs is False                                   # scoped to the call
     scale = float(g_ref.abs().max())
-    assert float((g_hip - g_ref).abs().max()) <= 3e-2 * scale                  # same function (ReLU decisions may differ)
+    assert float((g_hip - g_ref).abs().max()) <= 5e-2 * scale                  # same function (ReLU decisions may differ)
     w = model.backbone.convs[7].weight
     v = w._version
     w.data.copy_(w.data * -1.5)                                                # EMA-style swap: no version bump
     assert w._version == v
     g_hip2, g_ref2 = grad(True), grad(False)
     assert float((g_ref2 - g_ref).abs().max()) > 0.15 * scale                  # the swap matters ...
-    assert float((g_hip2 - g_ref2).abs().max()) <= 3e-2 * float(g_ref2.abs().max())    # ... and the packs followed it
+    assert float((g_hip2 - g_ref2).abs().max()) <= 5e-2 * float(g_ref2.abs().max())    # ... and the packs followed it
 
 
 def test_per_step_api_draws_fresh_uniforms_every_step():
