@@ -24,7 +24,11 @@ def init_from_env(backend=None):
         if backend is None:
             # "nccl" is RCCL on ROCm. SVDD_DIST_BACKEND=gloo: dry runs of the N > 1 code path on a box with fewer GPUs
             # than ranks (several ranks share a device; RCCL refuses that) — never for measurements.
-            backend = os.environ.get("SVDD_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+            # The ranks decide for themselves when there are fewer GPUs than local ranks (each rank is a fresh process: counting
+            # devices here is free of the launcher's "never touch the GPU before spawning" constraint).
+            local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+            shared = torch.cuda.is_available() and torch.cuda.device_count() < local_world
+            backend = os.environ.get("SVDD_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() and not shared else "gloo")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 
