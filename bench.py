@@ -208,7 +208,7 @@ def trunk_gemm_roofline(model, emb, head, dev, n, L, precision="bf16x3"):
 def config4_leg(dev, steps, B=256, L=200, M=20, S=128, f32_steps=1):
     """BASELINE.json configs[3] at its per-GPU shard size (B = 256 of the 2048, M = 20, the Enformer-shaped 230 M-parameter
     value trunk) as an extra object of the default line: one warm-up decode + `steps` timed decodes in bf16x3 (split bf16
-    operands, fp32-class error: the trunk has no fp32 hand-written path — `--value-net enformer` times the PyTorch fp32 module).
+    operands, fp32-class error) and, beside it (`f32`), at the reference's own precision on the fp32-plane form of the same kernels (round 4).
     Reported beside the headline, never in it; a failure here is recorded, not raised."""
     try:
         from svdd_amd import synthetic
@@ -835,7 +835,9 @@ def main():
         if args.value_net != "convgru":
             line["config"]["workload"] += " [value net: Enformer-shaped trunk, 230M params — BASELINE configs[3] shape]"
             line["e2e_fp32_frac"] = None
-            line["roofline_trunk_gemm"] = trunk_gemm_roofline(model, emb, head, dev, int(0.75 * B * M), L)
+            # (the headline line of this workload is fp32: the trunk runs on the fp32-plane kernels; the split modes are in alt_precision)
+            line["roofline_trunk_gemm"] = trunk_gemm_roofline(model, emb, head, dev, int(0.75 * B * M), L, precision="f32")
+            line["roofline_trunk_gemm_bf16x3"] = trunk_gemm_roofline(model, emb, head, dev, int(0.75 * B * M), L)
         if args.c4_steps > 0 and world == 1 and args.value_net == "convgru" and (B, L, M) == (256, 200, 10):
             line["config4_enformer"] = config4_leg(dev, args.c4_steps, f32_steps=args.c4_f32_steps)
         if args.cpu_steps > 0 and world == 1 and args.value_net == "convgru":
