@@ -1065,7 +1065,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(16))) void mt19
       }
     }
     sbase += 2 * MT_GEN;
-    __syncthreads();
+    // LDS-only barrier: __syncthreads() also waits for this interval's GLOBAL stores to be acknowledged (s_waitcnt vmcnt(0)) —
+    // a memory round trip per 454 outputs, which is what all three kernel variants were actually measuring (0.58 - 0.62 ns per
+    // output whatever the instruction count). Nobody reads `out` inside the kernel: the stores may stay in flight.
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   }
   // new state: the window x[E .. E + 623], E = 227 G ; pos' = total - E (0 <= pos' <= 624)
   const long long E = G * MT_GEN;
