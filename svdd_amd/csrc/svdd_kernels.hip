@@ -32,6 +32,21 @@ constexpr int WAVE = 64;
 // exp/log correctly rounded to fp32: evaluate in fp64 (ocml, <=1 ulp in double) and round once.
 __device__ __forceinline__ float expf_cr(float x) { return (float)exp((double)x); }
 __device__ __forceinline__ float logf_cr(float x) { return (float)log((double)x); }
+// exp of a SMALL non-positive argument (-2^-7 < x <= 0), the same contract (fp64 value within an ulp of double, rounded once to
+// fp32): degree-6 Taylor in fp64 (the next term is < 2^-61): 7 fp64 FMAs instead of ocml's range reduction + degree-11 kernel.
+// K2's exact softmax path evaluates exp(s - max) of scores that lie ~1e-7 apart — the regime random-init value nets produce.
+__device__ __forceinline__ float expf_cr_small(float x) {
+  const double d = (double)x;
+  double p = 1.0 / 720.0;
+  p = __builtin_fma(p, d, 1.0 / 120.0);
+  p = __builtin_fma(p, d, 1.0 / 24.0);
+  p = __builtin_fma(p, d, 1.0 / 6.0);
+  p = __builtin_fma(p, d, 0.5);
+  p = __builtin_fma(p, d, 1.0);
+  p = __builtin_fma(p, d, 1.0);
+  return (float)p;
+}
+__device__ __forceinline__ float expf_cr_nonpos(float x) { return x > -0.0078125f ? expf_cr_small(x) : expf_cr(x); }
 
 __device__ __forceinline__ int64_t at(int layout, int64_t b, int64_t l, int v, int64_t L) {
   return layout == SVDD_LAYOUT_BLV ? (b * L + l) * V + v : (b * V + v) * L + l;
@@ -596,7 +611,7 @@ __global__ __launch_bounds__(256) void select_rows_kernel(SelectArgs a) {
   const bool clear = !rv | (mx - s2 >= 3.814697265625e-06f);                  // 2^-18; also M == 1 (s2 = -inf)
   const bool exact = (a.mode != SVDD_SELECT_ARGMAX) | (a.soft != nullptr) | !clear;
   if (__any(exact)) {
-    const float e = valid ? expf_cr(sv - mx) : 0.0f;
+    const float e = valid ? expf_cr_nonpos(sv - mx) : 0.0f;
     float sum = 0.0f;
     for (int j = 0; j < a.M; ++j) {                                           // candidate order: ((e0 + e1) + e2) + ...
       const float ej = __shfl(e, base + j, WAVE);
