@@ -51,4 +51,17 @@ for mode, how in (("philox", None), ("replay", "device"), ("replay", "host")):
     el = (time.perf_counter() - t0) / args.decodes
     res[(mode, how)] = el
     print(f"C2 decode rng={mode}{'/' + how if how else ''}: {el * 1e3:.1f} ms = {B / el:.1f} seq/s")
+# the double-buffered side-stream generation against the host replay at the full config-2 size: same tokens, same generator state after
+same = []
+for seed in range(4):
+    outs = []
+    for how in ("device", "host"):
+        model.rng_mode, model.replay_rng = "replay", how
+        torch.manual_seed(100 + seed)
+        with torch.no_grad():
+            x = model.controlled_sample(emb, head, num_steps=S, eval_sp_size=B, sample_M=M)
+        torch.cuda.synchronize()
+        outs.append((x.cpu(), torch.rand(4)))
+    same.append(bool(torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])))
+print("device replay == host replay on 4 seeded C2 decodes (tokens and generator state):", same)
 print(f"replay(device) / philox = {res[('replay', 'device')] / res[('philox', None)]:.3f} ; replay(host) / philox = {res[('replay', 'host')] / res[('philox', None)]:.3f}")
