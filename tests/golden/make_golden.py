@@ -44,6 +44,16 @@ outputs are stored. Fixtures:
                               numpy's uniforms
   g20_traj_dps_full.npz       controlled_sample_DPS (configs[4]'s gradient-guidance baseline) with the FULL-SIZE nets and reward model, L = 200,
                               B=3, S=4, guidance scale 300 (factors up to 1.06): per step the guided q_xs, the uniforms, the gradient (as g11)
+  -- round 4: reference runs AT the BASELINE batch sizes (lean: states, delta-coded candidates, scores; `python make_golden.py g21|g22|g23|g24|g25`,
+     8 torch threads, 2 - 10 min each on the build container's 8 cores) --
+  g21_traj_mc_c2.npz          controlled_sample at BASELINE configs[1] (the headline): B=256, L=200, M=10, S=128, full-size seed-44 nets
+  g21_traj_pm_c3.npz          controlled_sample_tweedie(options="True") at configs[2]: B=256, L=50, M=10, S=128 (+ the x0-hat rows, reward scores)
+  g22_harness.npz             Enformer.BaseModel.controlled_decode / _tweedie (both options) / _TDS THEMSELVES (object.__new__, stubbed gReLU
+                              loader), tiny nets, gen_batch_num=2, sample_M=3: the 5-tuples
+  g23_traj_tds_c5.npz         controlled_sample_TDS at configs[4]'s per-GPU shard: 256 particles, L=200, S=128 (proposals, x0-hat rows, rewards,
+                              np.random.choice's ancestor indices)
+  g24_decode_sample_c2.npz    decode_sample (un-guided) at B=256, L=200, S=128
+  g25_traj_mc_m20.npz         controlled_sample with M=20 (configs[3]'s sampler shape, ConvGRU value net) at B=256, L=200, S=48
   g12_fullsize_probe.npz      FULL-SIZE reference nets (CNNModel hidden 128 x 4 stacks; ConvGRUTrunk 64 ch, n_conv 6 +
                               ConvHead) built at torch.manual_seed(44) in the order svdd_amd/synthetic.py builds them,
                               evaluated on 4 probe rows: logits, value scores, a checksum of every parameter tensor

@@ -15,7 +15,12 @@
      profiles/r03_e2e_parity.json.
  (2) Full-size nets: the reference's classes, random-initialised at torch.manual_seed(44) in the order synthetic.build
      uses, gave tests/golden/g12_fullsize_probe.npz; the HIP kernels (exact fp32 and the x3 split modes) must reproduce
-     its logits / log-probabilities / value scores within 1e-4 on the GPU."""
+     its logits / log-probabilities / value scores within 1e-4 on the GPU.
+ (4) Round 4 — the reference's own runs AT the BASELINE batch sizes (g21: configs[1] and configs[2] at B = 256, 128 steps; g23: the TDS
+     baseline at its 256-particle shard; g24: the un-guided decode at B = 256; g25: M = 20 at B = 256): teacher-forced on every
+     row-step with the candidates RE-PROPOSED from the replayed mt19937 stream (device generator), scores within 1e-4, then the
+     free-running replay decode; every divergence from the reference's trajectory must be a near-tie the report identifies
+     (tests/e2e_parity.py, numbers of the last run in profiles/r04_e2e_parity.json)."""
 import numpy as np
 import pytest
 import torch
