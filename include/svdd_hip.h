@@ -66,9 +66,11 @@ typedef struct svdd_rng {
                               `uniforms_layout` — the order M rand_like(q_xs) calls consume, i.e. the
                               memory order of the REFERENCE backbone's output (BVL for its CNN) */
   uint64_t seed;           /* PHILOX: 64-bit key */
-  uint64_t row_offset;     /* PHILOX: global index of this shard's row 0 */
+  uint64_t row_offset;     /* PHILOX: global index of this shard's row 0 ; REPLAY with uniforms_rows > 0: likewise */
   int32_t uniforms_layout; /* REPLAY: SVDD_LAYOUT_* of each uniforms block (independent of `layout`) */
-  int32_t reserved;
+  int32_t uniforms_rows;   /* REPLAY: 0 = each block holds B rows (this batch's own uniforms); > 0 = each block holds the uniforms of
+                              a WHOLE batch of that many rows, of which this call's B rows start at `row_offset` — a rank of a
+                              batch-sharded decode replays the global stream and reads its slice */
 } svdd_rng_t;
 
 /* Selection rule of svdd_select. */

@@ -43,7 +43,7 @@ class SvddRng(ctypes.Structure):
     """struct svdd_rng (include/svdd_hip.h)."""
     _fields_ = [("kind", ctypes.c_int32), ("step", ctypes.c_uint32), ("uniforms", ctypes.c_void_p),
                 ("seed", ctypes.c_uint64), ("row_offset", ctypes.c_uint64),
-                ("uniforms_layout", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("uniforms_layout", ctypes.c_int32), ("uniforms_rows", ctypes.c_int32)]
 
 
 class SvddError(RuntimeError):

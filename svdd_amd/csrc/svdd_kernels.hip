@@ -135,6 +135,7 @@ struct ProposeArgs {
   uint8_t* cand; float* onehot; float* q_xs; int force_exact; int msplit; int ulayout;
   unsigned long long* stats;     // optional device counters {masked draws, draws sent to the exact path} (svdd_k1_stats)
   int tok_rows;                  // candidates per chunk of the LDS token table = min(64, candidates of a unit)
+  int u_rows;                    // REPLAY: rows of the WHOLE batch the uniform blocks hold (>= B; this shard's row 0 = row_offset)
 };
 
 constexpr float LOG2E_HI = 1.44269502162933349609375f;        // fl32(log2 e)
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(256) void propose_kernel(ProposeArgs a) {
       pw[5 * WAVE + rank] = fast_ok ? margin : -1.0f;                    // < 0: this position always takes the exact path
       pw[6 * WAVE + rank] = __int_as_float(lane);
       if (REPLAY) {
-        pw[12 * WAVE + rank] = __int_as_float((int)b); pw[13 * WAVE + rank] = __int_as_float((int)l);
+        pw[12 * WAVE + rank] = __int_as_float((int)b + (int)a.row_offset); pw[13 * WAVE + rank] = __int_as_float((int)l);
       } else {
         const uint64_t pos = (a.row_offset + (uint64_t)b) * (uint64_t)a.L + (uint64_t)l;
         pw[12 * WAVE + rank] = __int_as_float((int)(uint32_t)pos); pw[13 * WAVE + rank] = __int_as_float((int)(uint32_t)(pos >> 32));
@@ -318,7 +319,7 @@ __global__ __launch_bounds__(256) void propose_kernel(ProposeArgs a) {
           const uint32_t key0 = (uint32_t)__float_as_int(pw[12 * WAVE + p]), key1 = (uint32_t)__float_as_int(pw[13 * WAVE + p]);
           float u[V];
           if (REPLAY) {
-            const float* ub = a.uniforms + (uint64_t)m * N * V;
+            const float* ub = a.uniforms + (uint64_t)m * ((uint64_t)a.u_rows * (uint64_t)a.L) * V;
 #pragma unroll
             for (int v = 0; v < V; ++v) u[v] = ub[at(a.ulayout, key0, key1, v, a.L)];
           } else {
@@ -1216,6 +1217,8 @@ int svdd_device_info(char* arch, int arch_len, int* num_cu) {
   return SVDD_OK;
 }
 
+static inline int replay_rows(const svdd_rng_t* rng, int B) { return rng->uniforms_rows > 0 ? rng->uniforms_rows : B; }
+
 static int launch_propose(bool q_given, const float* logits, const uint8_t* x, float dm, float mcs, int B, int L, int M,
                           int layout, const svdd_rng_t* rng, uint8_t* cand, float* onehot, float* q_xs, void* stream);
 
@@ -1244,7 +1247,11 @@ static int launch_propose(bool q_given, const float* logits, const uint8_t* x, f
   const int mloc = (M + msplit - 1) / msplit;
   const int tok_rows = mloc < WAVE ? mloc : WAVE;
   ProposeArgs a{logits, x, dm, mcs, B, L, M, layout, rng->kind, rng->step, rng->uniforms, rng->seed,
-                rng->row_offset, cand, onehot, q_xs, g_force_exact, msplit, rng->uniforms_layout, g_k1_stats, tok_rows};
+                rng->row_offset, cand, onehot, q_xs, g_force_exact, msplit, rng->uniforms_layout, g_k1_stats, tok_rows,
+                (replay_rows(rng, B))};
+  if (rng->kind == SVDD_RNG_REPLAY && (a.u_rows < B || rng->row_offset + (uint64_t)B > (uint64_t)a.u_rows ||
+                                        (int64_t)a.u_rows * L >= (int64_t)1 << 31)) return SVDD_E_ARG;
+  if (rng->kind == SVDD_RNG_REPLAY && rng->uniforms_rows <= 0) a.row_offset = 0;   // plain replay: the blocks are this batch's own
   const size_t lds = (size_t)4 * tok_rows * WAVE;
   const bool replay = rng->kind == SVDD_RNG_REPLAY;
   auto k = q_given ? (replay ? propose_kernel<true, true> : propose_kernel<false, true>)

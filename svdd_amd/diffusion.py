@@ -126,6 +126,8 @@ def _decode_scope(fn):
 
 
 class Diffusion(nn.Module):
+    replays_global_stream = True     # distributed.sharded_sample: replay mode shards by replaying the whole batch's stream per rank
+
     def __init__(self, config, backbone=None):
         super().__init__()
         self.config = config
@@ -346,16 +348,20 @@ class Diffusion(nn.Module):
     def _rng(self, step, M, B, L, logits):
         if self.rng_mode == "replay":
             ul = self._replay_layout(logits)
-            shape = (M, B, L, 5) if ul == ops.LAYOUT_BLV else (M, B, 5, L)
+            # a rank of a batch-sharded decode replays the WHOLE batch's stream and reads its rows (svdd_rng.uniforms_rows)
+            shard = self._shard if (self._shard is not None and self._shard[3] > 1) else None
+            rows = shard[2] if shard else B
+            shape = (M, rows, L, 5) if ul == ops.LAYOUT_BLV else (M, rows, 5, L)
+            extra = dict(row_offset=shard[0], uniforms_rows=rows) if shard else {}
             if self.replay_rng == "device" and self._scope_depth > 0 and logits.is_cuda and not _capturing():
                 # the same stream, generated on the device (svdd_mt19937_uniform_f32): the generator's state is uploaded at the
                 # first draw of a sampler call and written back into torch's global generator when the call returns
                 if self._replay_stream is None:
                     self._replay_stream = ops.DeviceReplayStream(logits.device)
-                u = self._replay_stream.uniforms(M * B * L * 5).view(shape)
+                u = self._replay_stream.uniforms(M * rows * L * 5).view(shape)
             else:
                 u = torch.rand(shape).to(logits.device, non_blocking=True)   # torch's global CPU generator
-            return ops.Rng(uniforms=u, uniforms_layout=ul)
+            return ops.Rng(uniforms=u, uniforms_layout=ul, **extra)
         if self.rng_mode == "philox":
             return ops.Rng(seed=self.philox_seed, row_offset=self.row_offset, step=step)
         raise ValueError(f"rng_mode {self.rng_mode!r}")

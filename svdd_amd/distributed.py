@@ -1,8 +1,10 @@
 """Batch-sharded decode over the GPUs of one node: one process per GPU, RCCL only for the single
 all-gather of the final decoded tokens. Rows of the batch are independent in
 SVDD-MC / SVDD-PM / un-guided decode, so nothing is exchanged per step; Philox draws are keyed by
-the GLOBAL row index, so the decoded batch is identical for any number of GPUs (rng_mode="philox" only: the replay
-mode's mt19937 stream is per process, and sharded_sample refuses it for world > 1).
+the GLOBAL row index, so the decoded batch is identical for any number of GPUs. rng_mode="replay" (parity mode) shards too:
+every rank — seeded identically, like the reference's single process — generates the WHOLE batch's uniforms of a step from
+torch's mt19937 stream (on the device) and K1 reads the rows of its shard, so the gathered batch is token for token the
+unsharded replay decode, i.e. the reference's run at the total batch size.
 
 The SMC/TDS baseline is the one sampler whose step couples rows (the resample draws ancestors from the WHOLE batch,
 reference diffusion_gosai.py:1279-1284): `tds_exchange` all-gathers each rank's proposals, both reward vectors and its
@@ -99,9 +101,11 @@ def sharded_sample(model, total_rows, sampler, rank=None, world=None):
     if rank is None:
         rank = dist.get_rank() if dist.is_initialized() else 0
         world = dist.get_world_size() if dist.is_initialized() else 1
-    if world > 1 and getattr(model, "rng_mode", "philox") != "philox":
+    if world > 1 and getattr(model, "rng_mode", "philox") != "philox" and not getattr(model, "replays_global_stream", False):
         # replay mode draws from each process's own CPU mt19937 stream: with the usual identical manual_seed every rank
-        # would decode the SAME rows and the gathered batch would be `world` copies of one shard
+        # would decode the SAME rows and the gathered batch would be `world` copies of one shard. svdd_amd.Diffusion does it
+        # properly (replays_global_stream): every rank generates the WHOLE batch's uniforms from its (identically seeded)
+        # generator and K1 reads the rank's row slice (svdd_rng.uniforms_rows / row_offset) — SURVEY.md section 8e's parity mode
         raise ValueError("sharded_sample needs rng_mode='philox' when world > 1 (Philox is keyed by the global row; the "
                          "replay stream is per process)")
     lo, hi = shard_rows(total_rows, rank, world)

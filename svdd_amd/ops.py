@@ -31,11 +31,13 @@ class Rng:
     row_offset: int = 0
     step: int = 0
     uniforms_layout: Optional[int] = None      # None: same layout as the logits passed to propose()
+    uniforms_rows: int = 0                     # replay: > 0 = the blocks hold a WHOLE batch of that many rows; ours start at row_offset
 
     def c_struct(self, logits_layout=LAYOUT_BLV):
         if self.uniforms is not None:
             ul = logits_layout if self.uniforms_layout is None else self.uniforms_layout
-            return SvddRng(RNG_REPLAY, 0, self.uniforms.data_ptr(), 0, 0, ul, 0)
+            return SvddRng(RNG_REPLAY, 0, self.uniforms.data_ptr(), 0, self.row_offset if self.uniforms_rows else 0, ul,
+                           self.uniforms_rows)
         return SvddRng(RNG_PHILOX, self.step, None, self.seed & 0xFFFFFFFFFFFFFFFF, self.row_offset, 0, 0)
 
 
@@ -82,7 +84,8 @@ def propose(logits, x, dm, mcs, M, rng, want_q=False, cand=None, onehot=None):
     q = _empty_like_layout(logits, layout) if want_q else None
     if rng.uniforms is not None:
         u = _need(rng.uniforms, torch.float32, "uniforms")
-        assert u.is_contiguous() and u.numel() == M * B * L * 5, (u.shape, M, B, L)
+        rows = rng.uniforms_rows if rng.uniforms_rows else B       # (a shard of a batch of uniforms_rows rows: the whole batch's blocks)
+        assert u.is_contiguous() and u.numel() == M * rows * L * 5 and rng.row_offset * bool(rng.uniforms_rows) + B <= rows, (u.shape, M, B, L)
     rs = rng.c_struct(layout)
     rc = _lib.lib().svdd_propose(logits.data_ptr(), x.data_ptr(), float(dm), float(mcs), B, L, M, layout,
                                  ctypes.byref(rs), cand.data_ptr(), onehot.data_ptr(),

@@ -196,6 +196,47 @@ def test_sharded_decode_equals_unsharded_with_the_fused_nets():
     assert model.row_offset == 0
 
 
+@pytest.mark.parametrize("replay_rng", ["device", "host"])
+def test_sharded_replay_decode_equals_the_unsharded_replay_decode(golden, replay_rng):
+    """SURVEY.md section 8e, parity mode: "each rank replays the global mt19937 stream and slices its rows". Every rank — seeded
+    like the reference's single process — generates the WHOLE batch's uniforms of a step and K1 reads the rows of its shard
+    (svdd_rng.uniforms_rows / row_offset): the shards of 2 and of 5 (ragged) ranks, concatenated, are token for token the
+    unsharded replay decode — which for g13's seed and size is the REFERENCE's own run — and every rank's generator ends in the
+    state the unsharded decode leaves. SVDD-MC with the work-skipping loop, SVDD-PM, the un-guided decode."""
+    from svdd_amd import distributed, synthetic
+    model, emb, head, _ = synthetic.build("dna", DEV)
+    model.rng_mode, model.replay_rng = "replay", replay_rng
+    g = golden("g13_traj_mc_full_m10.npz")                           # the reference's run: B = 4, M = 10, 32 steps, seed 2
+    B, M, S, seed = int(g["B"]), int(g["M"]), int(g["S"]), int(g["seed"])
+    sampler = lambda **kw: model.controlled_sample(emb, head, num_steps=S, sample_M=M, **kw)   # noqa: E731
+    torch.manual_seed(seed)
+    whole = sampler(eval_sp_size=B)
+    after = torch.rand(8)
+    assert np.array_equal(whole.cpu().numpy(), g["x0"])              # = the reference's x_0
+    for world in (2, 3):
+        parts = []
+        for r in range(world):
+            torch.manual_seed(seed)
+            parts.append(distributed.sharded_sample(model, B, sampler, rank=r, world=world))
+            assert torch.equal(torch.rand(8), after)                 # the rank consumed the whole batch's stream
+        assert torch.equal(torch.cat(parts), whole), world
+    # a larger, ragged case on the RNA nets: MC (skipping loop), PM, un-guided
+    rna, emb_r, head_r, reward_r = synthetic.build("rna", DEV)
+    rna.rng_mode, rna.replay_rng = "replay", replay_rng
+    runs = {"mc": lambda **kw: rna.controlled_sample(emb_r, head_r, num_steps=10, sample_M=4, **kw),
+            "pm": lambda **kw: rna.controlled_sample_tweedie(reward_r, num_steps=8, sample_M=3, options="True", **kw),
+            "plain": lambda **kw: rna.decode_sample(num_steps=10, **kw)}
+    for name, run in runs.items():
+        torch.manual_seed(77)
+        whole = run(eval_sp_size=23)
+        parts = []
+        for r in range(4):
+            torch.manual_seed(77)
+            parts.append(distributed.sharded_sample(rna, 23, run, rank=r, world=4))
+        assert torch.equal(torch.cat(parts), whole), name
+    assert model.row_offset == 0 and model._shard is None
+
+
 _TDS_RANKS = r"""
 import os, sys, numpy as np, torch
 sys.path.insert(0, {root!r})

@@ -202,6 +202,12 @@ def test_sharded_sample_refuses_replay_rng_across_ranks():
     m = M()
     with pytest.raises(ValueError, match="philox"):
         distributed.sharded_sample(m, 8, lambda **kw: None, rank=0, world=2)
+    # ... unless the sampler replays the WHOLE batch's stream on every rank and reads its rows (svdd_amd.Diffusion does, round 4)
+    M.replays_global_stream = True
+    shards = []
+    distributed.sharded_sample(m, 8, lambda eval_sp_size: shards.append(m._shard) or torch.zeros(eval_sp_size, 3, dtype=torch.uint8), rank=1, world=2)
+    assert shards == [(4, 8, 8, 2)]
+    del M.replays_global_stream
     out = distributed.sharded_sample(m, 8, lambda eval_sp_size: torch.zeros(eval_sp_size, 3, dtype=torch.uint8), rank=0, world=1)
     assert out.shape == (8, 3) and m.row_offset == 0
     m.rng_mode = "philox"
