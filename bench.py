@@ -645,7 +645,13 @@ def main():
 
     rank_times = []                # (decode s, all-gather s) of every timed decode of this rank
 
+    if args.rng == "replay" and world > 1:
+        # parity mode over ranks: every rank replays the WHOLE batch's mt19937 stream and K1 reads its rows
+        model._shard = (rank * B, (rank + 1) * B, B * world, world)
+
     def one_decode():
+        if args.rng == "replay":
+            torch.manual_seed(0)               # every rank (and every decode) from the same generator state, like the reference's process
         t_a = time.perf_counter()
         x0 = model.controlled_sample(emb, head, num_steps=S, eval_sp_size=B, sample_M=M)
         if world > 1:
