@@ -281,6 +281,49 @@ def test_tds_sharded_over_two_ranks_equals_unsharded(tmp_path, total):
     assert res.stdout.count("ok") == 2
 
 
+_TDS_REPLAY_RANKS = r"""
+import os, sys, numpy as np, torch
+sys.path.insert(0, {root!r})
+import torch.distributed as dist
+from svdd_amd import distributed, synthetic
+rank, world, local = distributed.init_from_env("gloo")      # two ranks share the box's one GPU: gloo through the host
+g = dict(np.load({fixture!r}))
+model, emb, head, reward = synthetic.build("dna", "cuda:0")
+model.rng_mode = "replay"                                    # every rank replays the WHOLE population's stream, K1 reads its rows
+S, B, alpha = int(g["S"]), int(g["B"]), float(g["alpha"])
+sampler = lambda **kw: model.controlled_sample_TDS(reward, alpha, num_steps=S, **kw)
+torch.manual_seed(int(g["seed"]))                            # both ranks: the reference process's seeds
+np.random.seed(int(g["np_seed"]))
+out = distributed.sharded_sample(model, B, sampler)         # per step: one all-gather + the whole-population resample on each rank
+assert out.shape == (B, 200) and model._shard is None
+same = float((out.cpu().numpy() == g["x0"]).all(axis=1).mean())
+print("rank", rank, "rows identical to the reference's x_0:", same)
+assert same == 1.0
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_tds_two_ranks_in_replay_mode_reproduce_the_references_run(tmp_path):
+    """The strongest multi-rank statement that can be checked on one GPU: the reference's own SMC / TDS run at the configs[4]
+    shard size (g23: 256 particles, 128 steps) decoded by TWO ranks of 128 particles each in parity mode — each rank replays the
+    whole population's mt19937 stream (K1 reads its rows), the per-step exchange assembles the population, every rank resamples it
+    identically — and the gathered x_0 is the REFERENCE's x_0, row for row."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "tds_replay_ranks.py"
+    script.write_text(_TDS_REPLAY_RANKS.format(root=root, fixture=os.path.join(root, "tests", "golden", "g23_traj_tds_c5.npz")))
+    port = 35500 + os.getpid() % 2000
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)]
+    env = dict(os.environ, OMP_NUM_THREADS="1", SVDD_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    assert res.stdout.count("ok") == 2
+
+
 _RCCL_PROBE = r'''
 import os, sys, torch
 sys.path.insert(0, sys.argv[1])
