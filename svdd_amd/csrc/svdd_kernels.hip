@@ -576,6 +576,30 @@ __device__ __forceinline__ int group_first(bool pred, int base) {
   return __ffsll((long long)(mask & GM)) - 1;
 }
 
+// Value of lane J of the lane's own MP-lane group, J a compile-time constant: ds_swizzle in bit-mask mode (lane' = (lane & AND) | J
+// inside each half wave; no LDS memory is touched) — or v_readlane when the group is the whole wave.
+template <int MP, int J>
+__device__ __forceinline__ float group_lane(float v) {
+  if constexpr (MP == 64) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), J));
+  } else {
+    constexpr int AND = 0x1F & ~(MP - 1);
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), AND | (J << 5)));
+  }
+}
+// ((e_0 + e_1) + e_2) + ... over the MP lanes of the group, strictly in candidate order (the oracle's fp32 sequence). Lanes beyond
+// the row's M candidates hold +0, and adding +0 to a non-negative sum is exact. The MP broadcasts are independent of each other
+// and issue back to back; only the MP - 1 adds are a chain (round 4: the loop `for j < M: sum += __shfl(e, base + j)` paid one
+// ds_bpermute round trip per candidate, which is what made the near-tied leg of the saturated K2 benchmark 30 % slower).
+template <int MP, int J>
+struct OrderedSum {
+  static __device__ __forceinline__ float run(float e) { return OrderedSum<MP, J - 1>::run(e) + group_lane<MP, J>(e); }
+};
+template <int MP>
+struct OrderedSum<MP, 0> {
+  static __device__ __forceinline__ float run(float e) { return group_lane<MP, 0>(e); }
+};
+
 template <int MP, int R>
 __global__ __launch_bounds__(256) void select_rows_kernel(SelectArgs a) {
   // R row GROUPS per wave (round 4): with one group a wave had one 512-byte gather in flight at a time, 8192 waves on the chip
@@ -613,11 +637,7 @@ __global__ __launch_bounds__(256) void select_rows_kernel(SelectArgs a) {
   const bool exact = (a.mode != SVDD_SELECT_ARGMAX) | (a.soft != nullptr) | !clear;
   if (__any(exact)) {
     const float e = valid ? expf_cr_nonpos(sv - mx) : 0.0f;
-    float sum = 0.0f;
-    for (int j = 0; j < a.M; ++j) {                                           // candidate order: ((e0 + e1) + e2) + ...
-      const float ej = __shfl(e, base + j, WAVE);
-      sum = j == 0 ? ej : sum + ej;
-    }
+    const float sum = OrderedSum<MP, MP - 1>::run(e);                         // candidate order: ((e0 + e1) + e2) + ...
     const float rr = __fdiv_rn(1.0f, sum);
     const float p = e * rr;                                                   // ATen CPU softmax: e * (1 / sum)
     if (a.mode == SVDD_SELECT_ARGMAX) {
