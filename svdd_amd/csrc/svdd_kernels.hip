@@ -564,7 +564,8 @@ __device__ __forceinline__ float group_max(float v) {
   if constexpr (MP >= 4) v = fmaxf(v, dpp_mov<0x4E>(v));        // quad_perm [2,3,0,1]
   if constexpr (MP >= 8) v = fmaxf(v, dpp_mov<0x141>(v));       // row_half_mirror
   if constexpr (MP >= 16) v = fmaxf(v, dpp_mov<0x140>(v));      // row_mirror
-  if constexpr (MP >= 32) v = fmaxf(v, __shfl_xor(v, 16, WAVE));
+  if constexpr (MP >= 32)                                      // lane ^ 16: ds_swizzle (xor mask 0x10), no bpermute address / LDS round trip
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x1F | (0x10 << 10))));
   if constexpr (MP >= 64) v = fmaxf(v, __shfl_xor(v, 32, WAVE));
   return v;
 }
