@@ -11,7 +11,7 @@ from svdd_amd.fused_trunk import FusedEnformerValueNet
 dev = "cuda:0"
 B, M, L, S = 256, 20, 200, 128
 model, emb, head, _ = synthetic.build("dna", dev, value="enformer")
-model.rng_mode, model.philox_seed, model.precision = "philox", 5, "bf16x3"
+model.rng_mode, model.philox_seed, model.precision = "philox", 5, (sys.argv[1] if len(sys.argv) > 1 else "bf16x3")   # precision: bf16x3 (default) | f32 | bf16
 fn = model.value_callable(emb, head)
 assert isinstance(fn, FusedEnformerValueNet)
 acc = {"rows": None, "live": torch.zeros(1, dtype=torch.int64, device=dev), "prow": None, "calls": 0}
