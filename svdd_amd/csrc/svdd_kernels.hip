@@ -601,7 +601,9 @@ struct OrderedSum<MP, 0> {
   static __device__ __forceinline__ float run(float e) { return group_lane<MP, 0>(e); }
 };
 
-template <int MP, int R>
+// MS = how many lanes of the group the ordered sum visits: MP in general (lanes beyond M hold +0), exactly M for the widths
+// the BASELINE configs run (M = 10, 20): 6 / 12 fewer broadcast + add pairs on the exact path.
+template <int MP, int R, int MS = MP>
 __global__ __launch_bounds__(256) void select_rows_kernel(SelectArgs a) {
   // R row GROUPS per wave (round 4): with one group a wave had one 512-byte gather in flight at a time, 8192 waves on the chip
   // = 4 MB in flight against the ~12 MB that 5.8 TB/s x 2 us of latency need (the padded-row layout experiment showed the
@@ -638,7 +640,7 @@ __global__ __launch_bounds__(256) void select_rows_kernel(SelectArgs a) {
   const bool exact = (a.mode != SVDD_SELECT_ARGMAX) | (a.soft != nullptr) | !clear;
   if (__any(exact)) {
     const float e = valid ? expf_cr_nonpos(sv - mx) : 0.0f;
-    const float sum = OrderedSum<MP, MP - 1>::run(e);                         // candidate order: ((e0 + e1) + e2) + ...
+    const float sum = OrderedSum<MP, MS - 1>::run(e);                         // candidate order: ((e0 + e1) + e2) + ...
     const float rr = __fdiv_rn(1.0f, sum);
     const float p = e * rr;                                                   // ATen CPU softmax: e * (1 / sum)
     if (a.mode == SVDD_SELECT_ARGMAX) {
@@ -1331,6 +1333,16 @@ int svdd_select_compact(const float* scores, const int32_t* slot, const float* p
 #define SVDD_SEL_LAUNCH(MP_)                                                                                                     \
     if (R > 1) hipExtLaunchKernelGGL((select_rows_kernel<MP_, (MP_ >= 4 ? 4 : MP_)>), grid, dim3(256), 0, (hipStream_t)stream, e0, e1, 0, a); \
     else hipExtLaunchKernelGGL((select_rows_kernel<MP_, 1>), grid, dim3(256), 0, (hipStream_t)stream, e0, e1, 0, a);
+    if (M == 10 || M == 20) {                               // the BASELINE widths: the ordered sum stops at M
+      if (M == 10) {
+        if (R > 1) hipExtLaunchKernelGGL((select_rows_kernel<16, 4, 10>), grid, dim3(256), 0, (hipStream_t)stream, e0, e1, 0, a);
+        else hipExtLaunchKernelGGL((select_rows_kernel<16, 1, 10>), grid, dim3(256), 0, (hipStream_t)stream, e0, e1, 0, a);
+      } else {
+        if (R > 1) hipExtLaunchKernelGGL((select_rows_kernel<32, 4, 20>), grid, dim3(256), 0, (hipStream_t)stream, e0, e1, 0, a);
+        else hipExtLaunchKernelGGL((select_rows_kernel<32, 1, 20>), grid, dim3(256), 0, (hipStream_t)stream, e0, e1, 0, a);
+      }
+      return check_launch();
+    }
     switch (mp) {
       case 1: SVDD_SEL_LAUNCH(1) break;
       case 2: SVDD_SEL_LAUNCH(2) break;
