@@ -32,12 +32,14 @@ extern "C" int svdd_internal_num_cus();      // svdd_nets.hip
 // 3 = the 256 x 256 kernel everywhere
 static int g_trunk_gemm_version = 2;
 static int g_trunk_gemm_big_div = 4;   // automatic: the 256 x 256 kernel from num_cus / div tiles on (A/B: option values 21 .. 36 = div 1 .. 16)
+static int g_trunk_gemm_bm = 0;      // A/B (option values 41 / 42 / 40): LDS-DMA tiles 256 rows high everywhere / 192 everywhere / by cost (default)
 static int g_trunk_gemm_dbg = 0;     // timing experiments only (13 / 14 / 15 / 16): 256 x 256 kernel without epilogue / with one K block /
                                      // no epilogue + no LDS-DMA in the K loop / no epilogue + no fragment reads in the K loop
 extern "C" void svdd_internal_set_trunk_gemm_version(int v) {
   g_trunk_gemm_dbg = (v >= 13 && v <= 16) ? v - 12 : 0;
   g_trunk_gemm_version = (v >= 1 && v <= 3) ? v : (g_trunk_gemm_dbg ? 3 : 2);
   if (v >= 21 && v <= 36) g_trunk_gemm_big_div = v - 20;
+  if (v >= 40 && v <= 42) g_trunk_gemm_bm = v == 41 ? 256 : v == 42 ? 192 : 0;
 }
 
 // svdd_set_option(SVDD_OPT_TRUNK_PLANES_F32, 1): the operand planes are ONE fp32 plane (a_hi / out_hi point at floats, a_lo / out_lo
@@ -283,8 +285,13 @@ constexpr int H_BM = 256, H_BN = 256;
 // holds floats 8 g + 4 p .. + 3 of row j (the weights are packed the same way), and the 8 MFMA steps of a 32-wide K block
 // multiply k = 8 g + 4 p + e on v_mfma_f32_16x16x4_f32 (the instruction sums over the four lane groups g: every k once).
 // 128 MFMAs of 32 cycles per compute segment instead of 48 of 16: the K loop is matrix-pipe bound.
-template <int NPARTS, bool F32 = false>
+// HT = row sub-tiles of a wave per compute segment: 4 -> a 256-row tile (8 sub-tiles per wave), 3 -> a 192-row tile (6 per wave).
+// The 192-row form exists for the GEMMs whose 256-row tiles fill the chip badly (round 4): the transformer tower works on 7680 rows
+// at a config-4 step, 30 tiles high — x 6 column tiles = 180 workgroups on 256 CUs (0.70 of a round), x 12 = 360 (1.41 rounds: 2);
+// 40 tiles of 192 rows make 240 / 480: 0.94 / 1.88 rounds. The launcher takes whichever height costs fewer round x rows.
+template <int NPARTS, bool F32 = false, int HT = 4>
 __global__ __launch_bounds__(512, 2) void trunk_gemm256_kernel(GemmArgs a) {
+  constexpr int BM = 64 * HT;
   static_assert(!F32 || NPARTS == 2, "fp32 planes: two 16-byte pieces per lane");
   constexpr int ES = F32 ? 4 : 2;                            // bytes per operand element
   extern __shared__ __attribute__((aligned(1024))) char hsm[];
@@ -299,18 +306,19 @@ __global__ __launch_bounds__(512, 2) void trunk_gemm256_kernel(GemmArgs a) {
   const int m_live = a.count ? min(a.M, *a.count * a.rows_per_seq) : a.M;
   const int NB128 = a.N / 128;
   const int NB = (a.N + H_BN - 1) / H_BN;
-  const int MB = (a.M + H_BM - 1) / H_BM;
+  const int MB = (a.M + BM - 1) / BM;
   const int lid = blockIdx.x;                               // XCD-aware tile order (as above)
   const int grp = lid / (8 * NB), rem = lid - grp * 8 * NB;
   const int by = grp * 8 + (rem & 7), nb = rem >> 3;
   if (by >= MB) return;
-  const int m0 = by * H_BM;
+  const int m0 = by * BM;
   if (m0 >= m_live) return;
   const bool cols_ok = 256 * nb + 64 * wn < a.N;            // this wave's 64 columns exist
   const bool wstage_ok = 2 * nb + (w >> 2) < NB128;         // ... and so do the weight sub-tiles it stages
-  f32x4 acc[8][4];
+  const bool astage_ok = 2 * w < 4 * HT;                    // the A sub-tiles 2 w, 2 w + 1 exist (HT = 3: waves 0 - 5 stage A)
+  f32x4 acc[2 * HT][4];
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < 2 * HT; ++i)
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) acc[i][nt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
   // DMA sources: wave w stages the A sub-tiles 2 w, 2 w + 1 (rows m0 + 32 w ..) and the W sub-tiles 2 w, 2 w + 1
@@ -332,7 +340,7 @@ __global__ __launch_bounds__(512, 2) void trunk_gemm256_kernel(GemmArgs a) {
   // four A pieces go out in a K block's second load segment, the four W pieces in its first, and the wait is counted
   // (vmcnt(4): the pieces just issued stay in flight across the barrier).
 #define H_DMA_A(KB_, ABUF)                                                                                   \
-  { const int kb_ = (KB_);                                                                                   \
+  if (astage_ok) { const int kb_ = (KB_);                                                                    \
     const int c_ = kb_ / a.T, t_ = kb_ - c_ * a.T;                                                           \
     const int64_t koff_ = ((int64_t)(t_ - a.T / 2) * a.lda + 32 * c_) * ES;                                  \
     _Pragma("unroll") for (int q = 0; q < 2; ++q)                                                            \
@@ -346,7 +354,7 @@ __global__ __launch_bounds__(512, 2) void trunk_gemm256_kernel(GemmArgs a) {
       __builtin_amdgcn_global_load_lds((glb_ptr_t)(ws_ + q * 64),                                            \
                                        (lds_ptr_t)(stage_w + (WBUF) * OPER_B + q * SUB_B), 16, 0, 0);        \
   }
-  const char* const frag_a = hsm + (8 * wm) * NPARTS * SUB_B + 16 * lane;
+  const char* const frag_a = hsm + (2 * HT * wm) * NPARTS * SUB_B + 16 * lane;
   const char* const frag_w = hsm + W_BASE + (4 * wn) * NPARTS * SUB_B + 16 * lane;
   f32x4 bf[4][NPARTS], af[4][NPARTS];                       // 16-byte fragments: 8 bf16, or 4 floats (F32)
 #define H_READ_W(WBUF)                                                                                       \
@@ -354,9 +362,9 @@ __global__ __launch_bounds__(512, 2) void trunk_gemm256_kernel(GemmArgs a) {
     _Pragma("unroll") for (int p = 0; p < NPARTS; ++p)                                                       \
       bf[nt][p] = *reinterpret_cast<const f32x4*>(frag_w + (WBUF) * OPER_B + (nt * NPARTS + p) * SUB_B);
 #define H_READ_A(ABUF, H)                                                                                    \
-  _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                              \
+  _Pragma("unroll") for (int i = 0; i < HT; ++i)                                                             \
     _Pragma("unroll") for (int p = 0; p < NPARTS; ++p)                                                       \
-      af[i][p] = *reinterpret_cast<const f32x4*>(frag_a + (ABUF) * OPER_B + ((4 * (H) + i) * NPARTS + p) * SUB_B);
+      af[i][p] = *reinterpret_cast<const f32x4*>(frag_a + (ABUF) * OPER_B + ((HT * (H) + i) * NPARTS + p) * SUB_B);
   // the three passes of a product go to the same accumulator: 16 independent MFMAs between dependent ones
 #define H_BF(V) __builtin_bit_cast(BV8, V)
 #define H_MFMA(H)                                                                                            \
@@ -365,20 +373,20 @@ __global__ __launch_bounds__(512, 2) void trunk_gemm256_kernel(GemmArgs a) {
     if constexpr (F32) {                                                                                     \
       _Pragma("unroll") for (int p = 0; p < 2; ++p)                                                          \
         _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                        \
-          _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                      \
+          _Pragma("unroll") for (int i = 0; i < HT; ++i)                                                      \
             _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                 \
-              acc[4 * (H) + i][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[nt][p][e], af[i][p][e], acc[4 * (H) + i][nt], 0, 0, 0); \
+              acc[HT * (H) + i][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[nt][p][e], af[i][p][e], acc[HT * (H) + i][nt], 0, 0, 0); \
     } else {                                                                                                 \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                            \
+    _Pragma("unroll") for (int i = 0; i < HT; ++i)                                                            \
       _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                       \
-        acc[4 * (H) + i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(H_BF(bf[nt][0]), H_BF(af[i][0]), acc[4 * (H) + i][nt], 0, 0, 0); \
+        acc[HT * (H) + i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(H_BF(bf[nt][0]), H_BF(af[i][0]), acc[HT * (H) + i][nt], 0, 0, 0); \
     if constexpr (NPARTS == 2) {                                                                             \
-      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                          \
+      _Pragma("unroll") for (int i = 0; i < HT; ++i)                                                          \
         _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                     \
-          acc[4 * (H) + i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(H_BF(bf[nt][1]), H_BF(af[i][0]), acc[4 * (H) + i][nt], 0, 0, 0); \
-      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                          \
+          acc[HT * (H) + i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(H_BF(bf[nt][1]), H_BF(af[i][0]), acc[HT * (H) + i][nt], 0, 0, 0); \
+      _Pragma("unroll") for (int i = 0; i < HT; ++i)                                                          \
         _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                     \
-          acc[4 * (H) + i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(H_BF(bf[nt][0]), H_BF(af[i][1]), acc[4 * (H) + i][nt], 0, 0, 0); \
+          acc[HT * (H) + i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(H_BF(bf[nt][0]), H_BF(af[i][1]), acc[HT * (H) + i][nt], 0, 0, 0); \
     }                                                                                                        \
     }                                                                                                        \
     __builtin_amdgcn_s_setprio(0);                                                                           \
@@ -396,7 +404,8 @@ __global__ __launch_bounds__(512, 2) void trunk_gemm256_kernel(GemmArgs a) {
     if (cols_ok && a.dbg != 4) { H_READ_A(ABUF, 1) }                                                         \
     if ((S) + 2 < KB && a.dbg != 3) {                                                                        \
       H_DMA_A((S) + 2, ((ABUF) + 2) % 3)                                                                     \
-      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(2 * NPARTS) : "memory");   /* K block S + 1 has landed; S + 2's A stays in flight */ \
+      if (astage_ok) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(2 * NPARTS) : "memory");   /* K block S + 1 has landed; S + 2's A stays in flight */ \
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                /* (a wave without A pieces: only its W pieces are out) */ \
     } else {                                                                                                 \
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                            \
     }                                                                                                        \
@@ -409,7 +418,8 @@ __global__ __launch_bounds__(512, 2) void trunk_gemm256_kernel(GemmArgs a) {
   H_DMA_W(0, 0)
   if (KB > 1) {
     H_DMA_A(1, 1)
-    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NPARTS) : "memory");
+    if (astage_ok) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NPARTS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   } else {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
@@ -449,14 +459,14 @@ __global__ __launch_bounds__(512, 2) void trunk_gemm256_kernel(GemmArgs a) {
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < HT; ++i)
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt)
-        *reinterpret_cast<f32x4*>(slab + (16 * i + j) * SP + 16 * nt + 4 * g) = acc[4 * h + i][nt];
-    const int rbase = m0 + 128 * wm + 64 * h + rsub;
+        *reinterpret_cast<f32x4*>(slab + (16 * i + j) * SP + 16 * nt + 4 * g) = acc[HT * h + i][nt];
+    const int rbase = m0 + 32 * HT * wm + 16 * HT * h + rsub;
     int pos = a.pad > 0 ? rbase % a.rows_per_seq : 0;
 #pragma unroll
-    for (int p = 0; p < 16; ++p) {
+    for (int p = 0; p < 4 * HT; ++p) {
       const int row = rbase + 4 * p;
       const f32x4 v = *reinterpret_cast<const f32x4*>(slab + (4 * p + rsub) * SP + c4);
       const bool pad_row = a.pad > 0 && pos >= a.rows_per_seq - a.pad;
@@ -877,34 +887,38 @@ int svdd_trunk_gemm(const void* a_hi, const void* a_lo, const void* w, const flo
   GemmArgs a{(const bf16_t*)a_hi, (const bf16_t*)a_lo, (const BV8*)w, bias, resid, out, M, N, T * (Cin / G_BK), Cin / G_BK, T,
              lda, ldo, act, count, rows_per_seq, (bf16_t*)out_hi, (bf16_t*)out_lo, post_scale, post_shift, post_act, pad, g_trunk_gemm_dbg,
              g_trunk_planes_f32};
+  // tile height of the LDS-DMA kernel: 256 rows, or 192 where that costs fewer (rounds of the chip) x (rows per tile)
+  const int ncu = svdd_internal_num_cus();
+  const int nb2 = (N + H_BN - 1) / H_BN;
+  auto cost = [&](int bm) { const int64_t tiles = (int64_t)((M + bm - 1) / bm) * nb2; return ((tiles + ncu - 1) / ncu) * bm; };
+  const bool short_tiles = g_trunk_gemm_bm == 192 || (g_trunk_gemm_bm == 0 && cost(192) < cost(256));
+  const int bm = short_tiles ? 192 : 256;
+  const int mb2 = (M + bm - 1) / bm;
+  const dim3 grid2((unsigned)(((mb2 + 7) / 8) * 8 * nb2));
+#define SVDD_GEMM256(NP_, F32_, LDS_)                                                                                        \
+  { if (short_tiles) {                                                                                                      \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(trunk_gemm256_kernel<NP_, F32_, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_); \
+      hipLaunchKernelGGL((trunk_gemm256_kernel<NP_, F32_, 3>), grid2, dim3(512), LDS_, (hipStream_t)stream, a);              \
+    } else {                                                                                                                \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(trunk_gemm256_kernel<NP_, F32_, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_); \
+      hipLaunchKernelGGL((trunk_gemm256_kernel<NP_, F32_, 4>), grid2, dim3(512), LDS_, (hipStream_t)stream, a);              \
+    } }
   if (g_trunk_planes_f32) {
-    // fp32 planes: one plane, fp32 MFMA, always the 256 x 256 LDS-DMA kernel (its K loop is matrix-pipe bound at any tile count)
+    // fp32 planes: one plane, fp32 MFMA, always the LDS-DMA kernel (its K loop is matrix-pipe bound at any tile count)
     if (a_lo || out_lo) return SVDD_E_ARG;
-    const int mb2 = (M + H_BM - 1) / H_BM, nb2 = (N + H_BN - 1) / H_BN;
-    const dim3 grid((unsigned)(((mb2 + 7) / 8) * 8 * nb2));
-    constexpr int lds = 5 * 16 * 2 * 1024;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(trunk_gemm256_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipLaunchKernelGGL((trunk_gemm256_kernel<2, true>), grid, dim3(512), lds, (hipStream_t)stream, a);
+    SVDD_GEMM256(2, true, 5 * 16 * 2 * 1024)
     return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
   }
   // 256 x 256 tiles from half a chip's worth of tiles on (the 7680-row GEMMs of the transformer tower make 180 - 360 of them and
   // still run 2.3x faster than on 128 x 128 tiles: 0.79 - 0.98 vs 0.37 - 0.42 PFLOP/s); the 128 x 128 kernel below that
-  const int mb2 = (M + H_BM - 1) / H_BM, nb2 = (N + H_BN - 1) / H_BN;
-  const bool big = g_trunk_gemm_version == 2 ? ((int64_t)mb2 * nb2 >= svdd_internal_num_cus() / g_trunk_gemm_big_div)
+  const bool big = g_trunk_gemm_version == 2 ? ((int64_t)((M + 255) / 256) * nb2 >= ncu / g_trunk_gemm_big_div)
                                               : g_trunk_gemm_version == 3;
   if (big) {
-    const dim3 grid((unsigned)(((mb2 + 7) / 8) * 8 * nb2));
-    if (a_lo) {
-      constexpr int lds = 5 * 16 * 2 * 1024;                // three A stages + two W stages = 163,840 B (all of a CU's LDS); the epilogue's 8 wave slabs take 139,264 B of it
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(trunk_gemm256_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-      hipLaunchKernelGGL(trunk_gemm256_kernel<2>, grid, dim3(512), lds, (hipStream_t)stream, a);
-    } else {
-      constexpr int lds = 8 * 64 * 68 * 4;                  // one-pass mode: the stages take 81,920 B, the epilogue slabs 139,264 B
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(trunk_gemm256_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-      hipLaunchKernelGGL(trunk_gemm256_kernel<1>, grid, dim3(512), lds, (hipStream_t)stream, a);
-    }
+    if (a_lo) SVDD_GEMM256(2, false, 5 * 16 * 2 * 1024)     // three A stages + two W stages = 163,840 B (all of a CU's LDS); the epilogue's 8 wave slabs take 139,264 B of it
+    else SVDD_GEMM256(1, false, 8 * 64 * 68 * 4)            // one-pass mode: the stages take 81,920 B, the epilogue slabs 139,264 B
     return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
   }
+#undef SVDD_GEMM256
   const int mb = (M + G_BM - 1) / G_BM;
   const dim3 grid((unsigned)(((mb + 7) / 8) * 8 * (N / G_BN)));         // groups of 8 row tiles x N / 128 column tiles
   if (a_lo) hipLaunchKernelGGL(trunk_gemm_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, a);

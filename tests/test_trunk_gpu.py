@@ -199,8 +199,9 @@ def test_gemm_256_tiles_equal_128_tiles(M, N, Cin, T, rps, live, parts):
     m_live = M if live is None else min(M, live * rps)
     outs, pls = {}, {}
     ps, pb = (1.0 + 0.1 * torch.randn(N, generator=g)).to(DEV), (0.1 * torch.randn(N, generator=g)).to(DEV)
-    for ver in (1, 3):
-        _lib.check(lib.svdd_set_option(4, ver), "svdd_set_option")
+    for ver in (1, 3, 42):                                 # 42: the LDS-DMA kernel with 192-row tiles everywhere (round 4)
+        _lib.check(lib.svdd_set_option(4, 3 if ver == 42 else ver), "svdd_set_option")
+        _lib.check(lib.svdd_set_option(4, 42 if ver == 42 else 41), "svdd_set_option")
         out = torch.full((M, N), 7.0, device=DEV)
         o_hi = torch.full((M, N), 3.0, device=DEV, dtype=torch.bfloat16)
         o_lo = torch.full((M, N), 3.0, device=DEV, dtype=torch.bfloat16)
@@ -219,12 +220,14 @@ def test_gemm_256_tiles_equal_128_tiles(M, N, Cin, T, rps, live, parts):
                                   r_hi.data_ptr(), r_lo.data_ptr() if parts == 2 else None, None if cnt is None else cnt.data_ptr(), None)
     _lib.check(rc, "svdd_trunk_act_split")
     torch.cuda.synchronize()
-    for ver in (1, 3):
+    for ver in (1, 3, 42):
         assert torch.equal(pls[ver][0], r_hi.float().cpu())
         if parts == 2:
             assert torch.equal(pls[ver][1], r_lo.float().cpu())
     _lib.check(lib.svdd_set_option(4, 2), "svdd_set_option")
+    _lib.check(lib.svdd_set_option(4, 40), "svdd_set_option")           # tile height by cost again
     assert torch.equal(outs[1][:m_live], outs[3][:m_live])
+    assert torch.equal(outs[42][:m_live], outs[3][:m_live]) and bool((outs[42][m_live:] == 7.0).all())
     assert bool((outs[3][m_live:] == 7.0).all())                       # rows beyond the live count are not written
     # fp64 reference on the operands the kernels see (x3: hi + lo of both; dropped lo * lo term ~ 2^-16 relative)
     a_eff = (a_hi.double() + (a_lo.double() if parts == 2 else 0.0))
