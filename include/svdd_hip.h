@@ -408,7 +408,9 @@ enum { SVDD_OPT_FORCE_EXACT = 0,
                                             transposed-accumulator kernel where one sequence fills a tile (104 < L <= 208) */,
        SVDD_OPT_TRUNK_GEMM_VERSION = 4 /* A/B: svdd_trunk_gemm kernel: 1 = 128 x 128 tiles everywhere, 2 (default) = 256 x 256 LDS-DMA
                                            tiles from 128 tiles up, 3 = 256 x 256 everywhere (13 .. 16: timing experiments with
-                                           wrong results: no epilogue / one K block / no DMA / no fragment reads) */,
+                                           wrong results: no epilogue / one K block / no DMA / no fragment reads); 40 / 41 / 42: the
+                                           LDS-DMA kernel's tile height by cost (default) / 256 rows / 192 rows; 51 .. 54: how many
+                                           chains of GEMMs share the chip (the cost model prices a launch against CUs / that) */,
        SVDD_OPT_CAND_ROW_STRIDE = 5 /* layout experiment (round 4): bytes between two candidate rows of `cand` as svdd_select /
                                         svdd_select_compact read it (0 = L, the default): rows padded to whole 128-byte lines */,
        SVDD_OPT_TRUNK_PLANES_F32 = 6 /* the svdd_trunk_* entry points take ONE fp32 operand plane (the *_hi pointers are float*, the

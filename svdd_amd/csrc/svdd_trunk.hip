@@ -32,6 +32,8 @@ extern "C" int svdd_internal_num_cus();      // svdd_nets.hip
 // 3 = the 256 x 256 kernel everywhere
 static int g_trunk_gemm_version = 2;
 static int g_trunk_gemm_big_div = 4;   // automatic: the 256 x 256 kernel from num_cus / div tiles on (A/B: option values 21 .. 36 = div 1 .. 16)
+static int g_trunk_gemm_conc = 1;    // option values 51 .. 54: how many chains of GEMMs share the chip (fused_trunk's tower streams): the tile-height
+                                     // choice prices a GEMM against CUs / conc
 static int g_trunk_gemm_bm = 0;      // A/B (option values 41 / 42 / 40): LDS-DMA tiles 256 rows high everywhere / 192 everywhere / by cost (default)
 static int g_trunk_gemm_dbg = 0;     // timing experiments only (13 / 14 / 15 / 16): 256 x 256 kernel without epilogue / with one K block /
                                      // no epilogue + no LDS-DMA in the K loop / no epilogue + no fragment reads in the K loop
@@ -40,6 +42,7 @@ extern "C" void svdd_internal_set_trunk_gemm_version(int v) {
   g_trunk_gemm_version = (v >= 1 && v <= 3) ? v : (g_trunk_gemm_dbg ? 3 : 2);
   if (v >= 21 && v <= 36) g_trunk_gemm_big_div = v - 20;
   if (v >= 40 && v <= 42) g_trunk_gemm_bm = v == 41 ? 256 : v == 42 ? 192 : 0;
+  if (v >= 51 && v <= 54) g_trunk_gemm_conc = v - 50;
 }
 
 // svdd_set_option(SVDD_OPT_TRUNK_PLANES_F32, 1): the operand planes are ONE fp32 plane (a_hi / out_hi point at floats, a_lo / out_lo
@@ -890,7 +893,8 @@ int svdd_trunk_gemm(const void* a_hi, const void* a_lo, const void* w, const flo
   // tile height of the LDS-DMA kernel: 256 rows, or 192 where that costs fewer (rounds of the chip) x (rows per tile)
   const int ncu = svdd_internal_num_cus();
   const int nb2 = (N + H_BN - 1) / H_BN;
-  auto cost = [&](int bm) { const int64_t tiles = (int64_t)((M + bm - 1) / bm) * nb2; return ((tiles + ncu - 1) / ncu) * bm; };
+  const int ncu_eff = ncu / g_trunk_gemm_conc > 0 ? ncu / g_trunk_gemm_conc : 1;
+  auto cost = [&](int bm) { const int64_t tiles = (int64_t)((M + bm - 1) / bm) * nb2; return ((tiles + ncu_eff - 1) / ncu_eff) * bm; };
   const bool short_tiles = g_trunk_gemm_bm == 192 || (g_trunk_gemm_bm == 0 && cost(192) < cost(256));
   const int bm = short_tiles ? 192 : 256;
   const int mb2 = (M + bm - 1) / bm;

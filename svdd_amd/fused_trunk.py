@@ -180,6 +180,8 @@ class FusedEnformerValueNet(nn.Module):
         self.share_slots = WIN_K        # ... windows per candidate and level (1: one window around every changed position)
         self.share_parent_steps = os.environ.get("SVDD_TRUNK_PARENT_STEPS", "1") != "0"   # ... and the parents' own levels from the previous call's, the same way (env: A/B runs)
         self.last_parent_rows = None
+        self.gemm_conc_hint = False     # tell svdd_trunk_gemm how many chains share the chip (A/B knob; measured: pricing a launch
+                                        # against the WHOLE chip picks better tile heights even with two chains — tools/trunk_tile_ab.py)
         self.tower_streams = int(os.environ.get("SVDD_TRUNK_TOWER_STREAMS", "2"))   # the candidates as this many parts on as many streams (1: one chain of kernels; at most 4)
         self._side = None
         self.last_window_rows = None
@@ -402,6 +404,7 @@ class FusedEnformerValueNet(nn.Module):
             return self._forward_tokens(tok, count, shared)
         finally:
             lib.svdd_set_option(6, 0)
+            lib.svdd_set_option(4, 51)
 
     def _forward_tokens(self, tok, count=None, shared=None):
         """tok [n, L] u8 -> scores [n, n_tasks, 1]; count: int32 device scalar = live rows (rows beyond it are undefined).
@@ -429,6 +432,7 @@ class FusedEnformerValueNet(nn.Module):
         if S > 1 and not (n * T >= 2048 and need_f <= reg_f and need_p + 2 * 4096 <= reg_p):
             S = 1
         self.last_streams = S
+        _lib.lib().svdd_set_option(4, 50 + (S if self.gemm_conc_hint else 1))   # the GEMMs' tile-height choice prices a launch against CUs / S
         if S == 1:
             self.last_window_rows = self._candidates(ws, st, tok, count, shared, depth, zs, 0)
         else:
