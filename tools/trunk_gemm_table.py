@@ -1,3 +1,5 @@
+"""Per-GEMM table of one forward of the config-4 value trunk (3840 candidates, one chain of kernels): shape, launches, time, TFLOP/s
+(fp32-equivalent), 256-row tiles and rounds of the chip. Usage: python tools/trunk_gemm_table.py [f32|bf16x3|bf16]"""
 import os, sys, torch
 sys.path.insert(0, "/root/repo")
 from svdd_amd import synthetic
@@ -5,7 +7,7 @@ from svdd_amd.fused_trunk import FusedEnformerValueNet
 model, emb, head, _ = synthetic.build("dna", "cuda:0", value="enformer")
 n, L = 3840, 200
 tok = torch.randint(0, 5, (n, L), device="cuda:0", dtype=torch.uint8)
-fn = FusedEnformerValueNet(emb, head, "f32")
+fn = FusedEnformerValueNet(emb, head, sys.argv[1] if len(sys.argv) > 1 else "f32")
 fn.tower_streams = 1
 fn.forward_tokens(tok); torch.cuda.synchronize()
 fn.timing = []

@@ -1,3 +1,5 @@
+"""A/B of svdd_trunk_gemm's tile-height policy inside whole config-4 shard decodes (B = 256, M = 20, 128 steps), same process:
+256-row tiles only (option 41), by cost (40) without / with the concurrency hint. Usage: python tools/trunk_tile_ab.py"""
 import sys, time, torch
 sys.path.insert(0, "/root/repo")
 from svdd_amd import _lib, synthetic
