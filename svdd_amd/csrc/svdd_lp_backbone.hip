@@ -10,7 +10,7 @@ static int g_bb_lp_version = 2;     // svdd_set_option(SVDD_OPT_BACKBONE_LP_VERS
 static int g_bb_lp_rg = 2;          // ... 22 / 23 / 24: the transposed kernel with 2 / 3 / 4 row groups (waves per SIMD); measured
                                     // (f16x3 / bf16, B = 256, L = 200): 2: 0.718 / 0.384 ms ; 3: 0.886 / 0.381 ms (x3 spills at 168 VGPRs) ; 4: spills
 extern "C" void svdd_internal_set_bb_lp_version(int v) {
-  if (v >= 22 && v <= 23) { g_bb_lp_version = 2; g_bb_lp_rg = v - 20; }
+  if (v >= 21 && v <= 23) { g_bb_lp_version = 2; g_bb_lp_rg = v - 20; }
   else g_bb_lp_version = v == 1 ? 1 : 2;
 }
 
@@ -363,15 +363,173 @@ __global__ __launch_bounds__(512, 2) void backbone_lp_kernel(BackboneLpArgs a) {
 // One sequence per tile only (104 < L <= 208); shorter sequences keep the kernel above.
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 
-// RG = row groups = waves per SIMD (2, 3 or 4): wave w = (column group w & 3, row group w >> 2) owns the row tiles
-// rg, rg + RG, rg + 2 RG, ... With 2 the waves spent 43 % of their time in s_waitcnt and the matrix pipe was busy 48 %
-// (profiles/r03_pmc_bb_lpt.txt): two waves per SIMD do not cover the LDS / L2 latencies of each other's loads.
-template <typename T, int NP, int RG>
-__global__ __launch_bounds__(256 * RG, RG) void backbone_lp_t_kernel(BackboneLpArgs a) {
+// bits RG r, r < n: the row tiles a wave that owns n of them sees in the schedule's live mask (shifted by its row group)
+constexpr int lpt_own_mask(int n, int rgs) { int m = 0; for (int r = 0; r < n; ++r) m |= 1 << (rgs * r); return m; }
+
+// BEGIN generated by tools/gen_lpt_taps.py (do not edit by hand)
+#define LPT_TAP13(S)                                                                                              \
+      LPT_XLOAD(0, 0, ua)                                                                                         \
+      S(0, ua, wA, LPT_XLOAD(0, 1, ub), LPT_WLD0(wB, t0 + 1 * tstep))                                             \
+      S(1, ub, wA, LPT_XLOAD(0, 2, ua), LPT_WLD(wB, 1))                                                           \
+      S(2, ua, wA, LPT_XLOAD(0, 3, ub), LPT_WLD(wB, 2))                                                           \
+      S(3, ub, wA, LPT_XLOAD(0, 4, ua), LPT_WLD(wB, 3))                                                           \
+      S(4, ua, wA, LPT_XLOAD(0, 5, ub), )                                                                         \
+      S(5, ub, wA, LPT_XLOAD(0, 6, ua), )                                                                         \
+      S(6, ua, wA, LPT_XLOAD(0, 7, ub), )                                                                         \
+      S(7, ub, wA, LPT_XLOAD(0, 8, ua), )                                                                         \
+      S(8, ua, wA, LPT_XLOAD(0, 9, ub), )                                                                         \
+      S(9, ub, wA, LPT_XLOAD(0, 10, ua), )                                                                        \
+      S(10, ua, wA, LPT_XLOAD(0, 11, ub), )                                                                       \
+      S(11, ub, wA, LPT_XLOAD(0, 12, ua), )                                                                       \
+      S(12, ua, wA, LPT_XLOAD(1, 0, ub), )                                                                        \
+      S(0, ub, wB, LPT_XLOAD(1, 1, ua), LPT_WLD0(wA, t0 + 2 * tstep))                                             \
+      S(1, ua, wB, LPT_XLOAD(1, 2, ub), LPT_WLD(wA, 1))                                                           \
+      S(2, ub, wB, LPT_XLOAD(1, 3, ua), LPT_WLD(wA, 2))                                                           \
+      S(3, ua, wB, LPT_XLOAD(1, 4, ub), LPT_WLD(wA, 3))                                                           \
+      S(4, ub, wB, LPT_XLOAD(1, 5, ua), )                                                                         \
+      S(5, ua, wB, LPT_XLOAD(1, 6, ub), )                                                                         \
+      S(6, ub, wB, LPT_XLOAD(1, 7, ua), )                                                                         \
+      S(7, ua, wB, LPT_XLOAD(1, 8, ub), )                                                                         \
+      S(8, ub, wB, LPT_XLOAD(1, 9, ua), )                                                                         \
+      S(9, ua, wB, LPT_XLOAD(1, 10, ub), )                                                                        \
+      S(10, ub, wB, LPT_XLOAD(1, 11, ua), )                                                                       \
+      S(11, ua, wB, LPT_XLOAD(1, 12, ub), )                                                                       \
+      S(12, ub, wB, LPT_XLOAD(2, 0, ua), )                                                                        \
+      S(0, ua, wA, LPT_XLOAD(2, 1, ub), LPT_WLD0(wB, t0 + 3 * tstep))                                             \
+      S(1, ub, wA, LPT_XLOAD(2, 2, ua), LPT_WLD(wB, 1))                                                           \
+      S(2, ua, wA, LPT_XLOAD(2, 3, ub), LPT_WLD(wB, 2))                                                           \
+      S(3, ub, wA, LPT_XLOAD(2, 4, ua), LPT_WLD(wB, 3))                                                           \
+      S(4, ua, wA, LPT_XLOAD(2, 5, ub), )                                                                         \
+      S(5, ub, wA, LPT_XLOAD(2, 6, ua), )                                                                         \
+      S(6, ua, wA, LPT_XLOAD(2, 7, ub), )                                                                         \
+      S(7, ub, wA, LPT_XLOAD(2, 8, ua), )                                                                         \
+      S(8, ua, wA, LPT_XLOAD(2, 9, ub), )                                                                         \
+      S(9, ub, wA, LPT_XLOAD(2, 10, ua), )                                                                        \
+      S(10, ua, wA, LPT_XLOAD(2, 11, ub), )                                                                       \
+      S(11, ub, wA, LPT_XLOAD(2, 12, ua), )                                                                       \
+      S(12, ua, wA, LPT_XLOAD(3, 0, ub), )                                                                        \
+      S(0, ub, wB, LPT_XLOAD(3, 1, ua), LPT_WLD0(wA, t1))                                                         \
+      S(1, ua, wB, LPT_XLOAD(3, 2, ub), LPT_WLD(wA, 1))                                                           \
+      S(2, ub, wB, LPT_XLOAD(3, 3, ua), LPT_WLD(wA, 2))                                                           \
+      S(3, ua, wB, LPT_XLOAD(3, 4, ub), LPT_WLD(wA, 3))                                                           \
+      S(4, ub, wB, LPT_XLOAD(3, 5, ua), )                                                                         \
+      S(5, ua, wB, LPT_XLOAD(3, 6, ub), )                                                                         \
+      S(6, ub, wB, LPT_XLOAD(3, 7, ua), )                                                                         \
+      S(7, ua, wB, LPT_XLOAD(3, 8, ub), )                                                                         \
+      S(8, ub, wB, LPT_XLOAD(3, 9, ua), )                                                                         \
+      S(9, ua, wB, LPT_XLOAD(3, 10, ub), )                                                                        \
+      S(10, ub, wB, LPT_XLOAD(3, 11, ua), )                                                                       \
+      S(11, ua, wB, LPT_XLOAD(3, 12, ub), )                                                                       \
+      S(12, ub, wB, , )
+#define LPT_TAP7(S)                                                                                               \
+      LPT_XLOAD(0, 0, ua)                                                                                         \
+      S(0, ua, wA, LPT_XLOAD(0, 1, ub), LPT_WLD0(wB, t0 + 1 * tstep))                                             \
+      S(1, ub, wA, LPT_XLOAD(0, 2, ua), LPT_WLD(wB, 1))                                                           \
+      S(2, ua, wA, LPT_XLOAD(0, 3, ub), LPT_WLD(wB, 2))                                                           \
+      S(3, ub, wA, LPT_XLOAD(0, 4, ua), LPT_WLD(wB, 3))                                                           \
+      S(4, ua, wA, LPT_XLOAD(0, 5, ub), )                                                                         \
+      S(5, ub, wA, LPT_XLOAD(0, 6, ua), )                                                                         \
+      S(6, ua, wA, LPT_XLOAD(1, 0, ub), )                                                                         \
+      S(0, ub, wB, LPT_XLOAD(1, 1, ua), LPT_WLD0(wA, t0 + 2 * tstep))                                             \
+      S(1, ua, wB, LPT_XLOAD(1, 2, ub), LPT_WLD(wA, 1))                                                           \
+      S(2, ub, wB, LPT_XLOAD(1, 3, ua), LPT_WLD(wA, 2))                                                           \
+      S(3, ua, wB, LPT_XLOAD(1, 4, ub), LPT_WLD(wA, 3))                                                           \
+      S(4, ub, wB, LPT_XLOAD(1, 5, ua), )                                                                         \
+      S(5, ua, wB, LPT_XLOAD(1, 6, ub), )                                                                         \
+      S(6, ub, wB, LPT_XLOAD(2, 0, ua), )                                                                         \
+      S(0, ua, wA, LPT_XLOAD(2, 1, ub), LPT_WLD0(wB, t0 + 3 * tstep))                                             \
+      S(1, ub, wA, LPT_XLOAD(2, 2, ua), LPT_WLD(wB, 1))                                                           \
+      S(2, ua, wA, LPT_XLOAD(2, 3, ub), LPT_WLD(wB, 2))                                                           \
+      S(3, ub, wA, LPT_XLOAD(2, 4, ua), LPT_WLD(wB, 3))                                                           \
+      S(4, ua, wA, LPT_XLOAD(2, 5, ub), )                                                                         \
+      S(5, ub, wA, LPT_XLOAD(2, 6, ua), )                                                                         \
+      S(6, ua, wA, LPT_XLOAD(3, 0, ub), )                                                                         \
+      S(0, ub, wB, LPT_XLOAD(3, 1, ua), LPT_WLD0(wA, t1))                                                         \
+      S(1, ua, wB, LPT_XLOAD(3, 2, ub), LPT_WLD(wA, 1))                                                           \
+      S(2, ub, wB, LPT_XLOAD(3, 3, ua), LPT_WLD(wA, 2))                                                           \
+      S(3, ua, wB, LPT_XLOAD(3, 4, ub), LPT_WLD(wA, 3))                                                           \
+      S(4, ub, wB, LPT_XLOAD(3, 5, ua), )                                                                         \
+      S(5, ua, wB, LPT_XLOAD(3, 6, ub), )                                                                         \
+      S(6, ub, wB, , )
+#define LPT_TAP6(S)                                                                                               \
+      LPT_XLOAD(0, 0, ua)                                                                                         \
+      S(0, ua, wA, LPT_XLOAD(0, 1, ub), LPT_WLD0(wB, t0 + 1 * tstep))                                             \
+      S(1, ub, wA, LPT_XLOAD(0, 2, ua), LPT_WLD(wB, 1))                                                           \
+      S(2, ua, wA, LPT_XLOAD(0, 3, ub), LPT_WLD(wB, 2))                                                           \
+      S(3, ub, wA, LPT_XLOAD(0, 4, ua), LPT_WLD(wB, 3))                                                           \
+      S(4, ua, wA, LPT_XLOAD(0, 5, ub), )                                                                         \
+      S(5, ub, wA, LPT_XLOAD(1, 0, ua), )                                                                         \
+      S(0, ua, wB, LPT_XLOAD(1, 1, ub), LPT_WLD0(wA, t0 + 2 * tstep))                                             \
+      S(1, ub, wB, LPT_XLOAD(1, 2, ua), LPT_WLD(wA, 1))                                                           \
+      S(2, ua, wB, LPT_XLOAD(1, 3, ub), LPT_WLD(wA, 2))                                                           \
+      S(3, ub, wB, LPT_XLOAD(1, 4, ua), LPT_WLD(wA, 3))                                                           \
+      S(4, ua, wB, LPT_XLOAD(1, 5, ub), )                                                                         \
+      S(5, ub, wB, LPT_XLOAD(2, 0, ua), )                                                                         \
+      S(0, ua, wA, LPT_XLOAD(2, 1, ub), LPT_WLD0(wB, t0 + 3 * tstep))                                             \
+      S(1, ub, wA, LPT_XLOAD(2, 2, ua), LPT_WLD(wB, 1))                                                           \
+      S(2, ua, wA, LPT_XLOAD(2, 3, ub), LPT_WLD(wB, 2))                                                           \
+      S(3, ub, wA, LPT_XLOAD(2, 4, ua), LPT_WLD(wB, 3))                                                           \
+      S(4, ua, wA, LPT_XLOAD(2, 5, ub), )                                                                         \
+      S(5, ub, wA, LPT_XLOAD(3, 0, ua), )                                                                         \
+      S(0, ua, wB, LPT_XLOAD(3, 1, ub), LPT_WLD0(wA, t1))                                                         \
+      S(1, ub, wB, LPT_XLOAD(3, 2, ua), LPT_WLD(wA, 1))                                                           \
+      S(2, ua, wB, LPT_XLOAD(3, 3, ub), LPT_WLD(wA, 2))                                                           \
+      S(3, ub, wB, LPT_XLOAD(3, 4, ua), LPT_WLD(wA, 3))                                                           \
+      S(4, ua, wB, LPT_XLOAD(3, 5, ub), )                                                                         \
+      S(5, ub, wB, , )
+#define LPT_TAP5(S)                                                                                               \
+      LPT_XLOAD(0, 0, ua)                                                                                         \
+      S(0, ua, wA, LPT_XLOAD(0, 1, ub), LPT_WLD0(wB, t0 + 1 * tstep))                                             \
+      S(1, ub, wA, LPT_XLOAD(0, 2, ua), LPT_WLD(wB, 1))                                                           \
+      S(2, ua, wA, LPT_XLOAD(0, 3, ub), LPT_WLD(wB, 2))                                                           \
+      S(3, ub, wA, LPT_XLOAD(0, 4, ua), LPT_WLD(wB, 3))                                                           \
+      S(4, ua, wA, LPT_XLOAD(1, 0, ub), )                                                                         \
+      S(0, ub, wB, LPT_XLOAD(1, 1, ua), LPT_WLD0(wA, t0 + 2 * tstep))                                             \
+      S(1, ua, wB, LPT_XLOAD(1, 2, ub), LPT_WLD(wA, 1))                                                           \
+      S(2, ub, wB, LPT_XLOAD(1, 3, ua), LPT_WLD(wA, 2))                                                           \
+      S(3, ua, wB, LPT_XLOAD(1, 4, ub), LPT_WLD(wA, 3))                                                           \
+      S(4, ub, wB, LPT_XLOAD(2, 0, ua), )                                                                         \
+      S(0, ua, wA, LPT_XLOAD(2, 1, ub), LPT_WLD0(wB, t0 + 3 * tstep))                                             \
+      S(1, ub, wA, LPT_XLOAD(2, 2, ua), LPT_WLD(wB, 1))                                                           \
+      S(2, ua, wA, LPT_XLOAD(2, 3, ub), LPT_WLD(wB, 2))                                                           \
+      S(3, ub, wA, LPT_XLOAD(2, 4, ua), LPT_WLD(wB, 3))                                                           \
+      S(4, ua, wA, LPT_XLOAD(3, 0, ub), )                                                                         \
+      S(0, ub, wB, LPT_XLOAD(3, 1, ua), LPT_WLD0(wA, t1))                                                         \
+      S(1, ua, wB, LPT_XLOAD(3, 2, ub), LPT_WLD(wA, 1))                                                           \
+      S(2, ub, wB, LPT_XLOAD(3, 3, ua), LPT_WLD(wA, 2))                                                           \
+      S(3, ua, wB, LPT_XLOAD(3, 4, ub), LPT_WLD(wA, 3))                                                           \
+      S(4, ub, wB, , )
+#define LPT_TAP4(S)                                                                                               \
+      LPT_XLOAD(0, 0, ua)                                                                                         \
+      S(0, ua, wA, LPT_XLOAD(0, 1, ub), LPT_WLD0(wB, t0 + 1 * tstep))                                             \
+      S(1, ub, wA, LPT_XLOAD(0, 2, ua), LPT_WLD(wB, 1))                                                           \
+      S(2, ua, wA, LPT_XLOAD(0, 3, ub), LPT_WLD(wB, 2))                                                           \
+      S(3, ub, wA, LPT_XLOAD(1, 0, ua), LPT_WLD(wB, 3))                                                           \
+      S(0, ua, wB, LPT_XLOAD(1, 1, ub), LPT_WLD0(wA, t0 + 2 * tstep))                                             \
+      S(1, ub, wB, LPT_XLOAD(1, 2, ua), LPT_WLD(wA, 1))                                                           \
+      S(2, ua, wB, LPT_XLOAD(1, 3, ub), LPT_WLD(wA, 2))                                                           \
+      S(3, ub, wB, LPT_XLOAD(2, 0, ua), LPT_WLD(wA, 3))                                                           \
+      S(0, ua, wA, LPT_XLOAD(2, 1, ub), LPT_WLD0(wB, t0 + 3 * tstep))                                             \
+      S(1, ub, wA, LPT_XLOAD(2, 2, ua), LPT_WLD(wB, 1))                                                           \
+      S(2, ua, wA, LPT_XLOAD(2, 3, ub), LPT_WLD(wB, 2))                                                           \
+      S(3, ub, wA, LPT_XLOAD(3, 0, ua), LPT_WLD(wB, 3))                                                           \
+      S(0, ua, wB, LPT_XLOAD(3, 1, ub), LPT_WLD0(wA, t1))                                                         \
+      S(1, ub, wB, LPT_XLOAD(3, 2, ua), LPT_WLD(wA, 1))                                                           \
+      S(2, ua, wB, LPT_XLOAD(3, 3, ub), LPT_WLD(wA, 2))                                                           \
+      S(3, ub, wB, , LPT_WLD(wA, 3))
+// END generated by tools/gen_lpt_taps.py
+
+// RG = row groups = waves per SIMD (1, 2 or 3): wave w = (column group w & 3, row group w >> 2) owns the row tiles
+// rg, rg + RG, rg + 2 RG, ... The body is compiled once per row group (MYRG is the wave's own, the kernel below branches on
+// it once): a row group's tile count is then a constant and its code a region of its own. As ONE body with run-time
+// "if (rg == 0) 7 tiles else 6 tiles" blocks in the tap loop, times the all-live / partly-live variants of a tap, the
+// register allocator gave the 14 accumulators different registers in different blocks (52 v_mov_b64 per tap to reconcile
+// them) and spilled a quarter of the residual stream around the loop.
+template <typename T, int NP, int RG, int MYRG>
+__device__ __forceinline__ void backbone_lp_t_body(const BackboneLpArgs& a, char* smem_b) {
   constexpr int NTH = 256 * RG;
   typedef typename Lp<T>::V8 V8;
   constexpr int NPARTS = NP == 3 ? 2 : 1;
-  extern __shared__ __attribute__((aligned(16))) char smem_b[];
   char* plane = smem_b + LPSB;                               // byte address of (row 0, channel 0) of the hi plane
   float* img32 = reinterpret_cast<float*>(smem_b);           // final stage: fp32 image [TW_ROWS][BB_AP] over the planes
   float* Bs = reinterpret_cast<float*>(smem_b + IMG_REGION_B);   // [9][5][128] the first layer's lookup table
@@ -384,7 +542,9 @@ __global__ __launch_bounds__(256 * RG, RG) void backbone_lp_t_kernel(BackboneLpA
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int cg = w & 3, rg = w >> 2;
+  const int cg = w & 3;
+  int rg = MYRG;                                             // opaque: as a constant it lets the scheduler hoist every row tile's loads of a phase at once (spills)
+  asm volatile("" : "+s"(rg));
   const int j = lane & 15, g = lane >> 4;
   const int cb = 32 * cg + 8 * g;                            // this lane's channels cb .. cb + 7: (ct, e) <-> cb + 2 e + ct
   const int L = a.L;
@@ -393,7 +553,7 @@ __global__ __launch_bounds__(256 * RG, RG) void backbone_lp_t_kernel(BackboneLpA
   const int64_t seq = a.row_idx ? a.row_idx[blockIdx.x] : (int64_t)blockIdx.x;
   const int nl = a.nl;
   const int it_end = (nl + 1) * 9;                           // (layer, tap) entries
-  constexpr int NR = (TW_RT + RG - 1) / RG;                  // row tiles of row group 0 (the others may own one less)
+  constexpr int NR = (TW_RT - MYRG + RG - 1) / RG;           // row tiles of this row group: MYRG, MYRG + RG, ...
 
   for (int e = tid; e < TW_ROWS; e += NTH) {
     toks[e] = e < L ? (int)a.x[seq * L + e] : -1;
@@ -561,151 +721,82 @@ __global__ __launch_bounds__(256 * RG, RG) void backbone_lp_t_kernel(BackboneLpA
       int xa[NR];                                         // clamped fragment address of every owned tile, chunk 0
 #pragma unroll
       for (int r = 0; r < NR; ++r) xa[r] = min(max(arow0 + delta * LPSB + r * (16 * RG * LPSB), a_lo), a_hi);
+      // weight tiles of this tap: chunk c is tile t0 + c tstep; t1 = chunk 0 of the next live tap (after the last one: this tap's,
+      // requested and never used — a request behind a branch makes the compiler's counter model merge "requested" with "not
+      // requested", and it then waits for vmcnt(0), the request just made, in every step of the chunk)
+      const int t0 = tile_of(it, 0), tstep = it < nl * 9 ? 9 : 1, t1 = tile_of(nxt < it_end ? nxt : it, 0);
+      const V8* wn_;
       // the chunk's 64-byte step is an immediate offset of the LDS read
 #define LPT_XLOAD(C, R, V)                                                                                   \
       { V[0] = *reinterpret_cast<const V8*>(plane + xa[R] + 64 * (C));                                       \
         if constexpr (NP == 3) V[1] = *reinterpret_cast<const V8*>(plane + PLANE_B + xa[R] + 64 * (C)); }
-#define LPT_WPF(WN, TILE, COND)                                                                              \
-      if (COND) { const V8* src_ = wsrc + (size_t)(TILE) * TILE_V8;                                          \
-        _Pragma("unroll") for (int q = 0; q < 2 * NPARTS; ++q) WN[q] = src_[q]; }
-#define LPT_WAIT(NOUT) __builtin_amdgcn_s_waitcnt(0xC07F | ((NOUT) << 8));
+      // the next chunk's weight tile, one 16-byte piece per step into the idle set (no wait here: the compiler counts them)
+#define LPT_WLD0(WN, TILE) { wn_ = wsrc + (size_t)(TILE) * TILE_V8; WN[0] = wn_[0]; }
+#define LPT_WLD(WN, Q) { if constexpr ((Q) < 2 * NPARTS) WN[Q] = wn_[Q]; }
+      // One step = the 6 (2) MFMAs of one (chunk, row tile) on fragments requested during the step before it. What is not an
+      // MFMA sits BETWEEN the MFMAs, where it issues while the matrix pipe is busy: the request for the next step's fragments
+      // after the first, the piece of the next weight tile after the third. A wave alone on its SIMD then issues an MFMA every
+      // 16.6 cycles (tools/ubench/mfma_step_stream.hip); behind the group the same instructions cost it a third of the pipe,
+      // and the SIMD's other wave cannot make that up: MFMA issue goes to the OLDER wave whenever it is ready.
       // W: [ct][part] -> W[ct * NPARTS + part]; pass order as in the kernel above: hi hi, w_lo x_hi, w_hi x_lo
-#define LPT_MM(R, U, W, NOUT)                                                                                \
+      // LPT_STEP_ALL: every row tile of the tap is live (all of them in the dilation 1 / 4 layers, the inner taps elsewhere).
+#define LPT_STEP_ALL(R, U, W, LOADNEXT, EXTRA)                                                               \
       __builtin_amdgcn_sched_barrier(0);                                                                     \
-      LPT_WAIT(NOUT)                                                                                         \
-      if (live & (1 << (RG * (R)))) {                                                                         \
-        acc[R][0] = Lp<T>::mfma(W[0], U[0], acc[R][0]);                                                      \
-        acc[R][1] = Lp<T>::mfma(W[NPARTS], U[0], acc[R][1]);                                                 \
-        if constexpr (NP == 3) {                                                                             \
-          acc[R][0] = Lp<T>::mfma(W[1], U[0], acc[R][0]);                                                    \
-          acc[R][1] = Lp<T>::mfma(W[NPARTS + 1], U[0], acc[R][1]);                                           \
-          acc[R][0] = Lp<T>::mfma(W[0], U[1], acc[R][0]);                                                    \
-          acc[R][1] = Lp<T>::mfma(W[NPARTS], U[1], acc[R][1]);                                               \
-        }                                                                                                    \
+      __builtin_amdgcn_s_waitcnt(0xC07F);                   /* lgkmcnt(0): this step's fragments */          \
+      acc[R][0] = Lp<T>::mfma(W[0], U[0], acc[R][0]);                                                        \
+      __builtin_amdgcn_sched_barrier(0);                                                                     \
+      LOADNEXT                                                                                               \
+      __builtin_amdgcn_sched_barrier(0);                                                                     \
+      acc[R][1] = Lp<T>::mfma(W[NPARTS], U[0], acc[R][1]);                                                   \
+      if constexpr (NP == 3) acc[R][0] = Lp<T>::mfma(W[1], U[0], acc[R][0]);                                 \
+      __builtin_amdgcn_sched_barrier(0);                                                                     \
+      EXTRA                                                                                                  \
+      __builtin_amdgcn_sched_barrier(0);                                                                     \
+      if constexpr (NP == 3) {                                                                               \
+        acc[R][1] = Lp<T>::mfma(W[NPARTS + 1], U[0], acc[R][1]);                                             \
+        acc[R][0] = Lp<T>::mfma(W[0], U[1], acc[R][0]);                                                      \
+        acc[R][1] = Lp<T>::mfma(W[NPARTS], U[1], acc[R][1]);                                                 \
       }                                                                                                      \
       __builtin_amdgcn_sched_barrier(0);
+      // LPT_STEP_LIVE: some row tiles of the tap only see zero padding and are skipped. The tests read an SGPR copy of the mask
+      // that the compiler cannot see through: otherwise it hoists them out of the chunk loop as lane masks and re-materialises
+      // each through a VGPR (v_cndmask + v_cmp per step). The requests stay unconditional.
+#define LPT_STEP_LIVE(R, U, W, LOADNEXT, EXTRA)                                                              \
+      __builtin_amdgcn_sched_barrier(0);                                                                     \
+      __builtin_amdgcn_s_waitcnt(0xC07F);                                                                    \
+      { int lv_ = live;                                                                                      \
+        asm volatile("" : "+s"(lv_));                                                                        \
+        if (lv_ & (1 << (RG * (R)))) acc[R][0] = Lp<T>::mfma(W[0], U[0], acc[R][0]);                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        LOADNEXT                                                                                             \
+        EXTRA                                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        asm volatile("" : "+s"(lv_));                                                                        \
+        if (lv_ & (1 << (RG * (R)))) {                                                                       \
+          acc[R][1] = Lp<T>::mfma(W[NPARTS], U[0], acc[R][1]);                                               \
+          if constexpr (NP == 3) {                                                                           \
+            acc[R][0] = Lp<T>::mfma(W[1], U[0], acc[R][0]);                                                  \
+            acc[R][1] = Lp<T>::mfma(W[NPARTS + 1], U[0], acc[R][1]);                                         \
+            acc[R][0] = Lp<T>::mfma(W[0], U[1], acc[R][0]);                                                  \
+            acc[R][1] = Lp<T>::mfma(W[NPARTS], U[1], acc[R][1]);                                             \
+          }                                                                                                  \
+        } }                                                                                                  \
+      __builtin_amdgcn_sched_barrier(0);
+#define LPT_TAP(N)                                                                                           \
+      { constexpr int all_ = lpt_own_mask(N, RG);                                                            \
+        if ((live & all_) == all_) { LPT_TAP##N(LPT_STEP_ALL) } else { LPT_TAP##N(LPT_STEP_LIVE) } }
       V8 ua[2], ub[2];                                    // activation fragments, one (chunk, row tile) step ahead of the MFMAs
-      if constexpr (RG == 2) {
-        if (rg == 0) {                          // 7 row tiles
-          LPT_XLOAD(0, 0, ua)
-          LPT_WPF(wB, tile_of(it, 1), true)
-          LPT_XLOAD(0, 1, ub) LPT_MM(0, ua, wA, NPARTS)
-          LPT_XLOAD(0, 2, ua) LPT_MM(1, ub, wA, NPARTS)
-          LPT_XLOAD(0, 3, ub) LPT_MM(2, ua, wA, NPARTS)
-          LPT_XLOAD(0, 4, ua) LPT_MM(3, ub, wA, NPARTS)
-          LPT_XLOAD(0, 5, ub) LPT_MM(4, ua, wA, NPARTS)
-          LPT_XLOAD(0, 6, ua) LPT_MM(5, ub, wA, NPARTS)
-          LPT_XLOAD(1, 0, ub) LPT_MM(6, ua, wA, NPARTS)
-          LPT_WPF(wA, tile_of(it, 2), true)
-          LPT_XLOAD(1, 1, ua) LPT_MM(0, ub, wB, NPARTS)
-          LPT_XLOAD(1, 2, ub) LPT_MM(1, ua, wB, NPARTS)
-          LPT_XLOAD(1, 3, ua) LPT_MM(2, ub, wB, NPARTS)
-          LPT_XLOAD(1, 4, ub) LPT_MM(3, ua, wB, NPARTS)
-          LPT_XLOAD(1, 5, ua) LPT_MM(4, ub, wB, NPARTS)
-          LPT_XLOAD(1, 6, ub) LPT_MM(5, ua, wB, NPARTS)
-          LPT_XLOAD(2, 0, ua) LPT_MM(6, ub, wB, NPARTS)
-          LPT_WPF(wB, tile_of(it, 3), true)
-          LPT_XLOAD(2, 1, ub) LPT_MM(0, ua, wA, NPARTS)
-          LPT_XLOAD(2, 2, ua) LPT_MM(1, ub, wA, NPARTS)
-          LPT_XLOAD(2, 3, ub) LPT_MM(2, ua, wA, NPARTS)
-          LPT_XLOAD(2, 4, ua) LPT_MM(3, ub, wA, NPARTS)
-          LPT_XLOAD(2, 5, ub) LPT_MM(4, ua, wA, NPARTS)
-          LPT_XLOAD(2, 6, ua) LPT_MM(5, ub, wA, NPARTS)
-          LPT_XLOAD(3, 0, ub) LPT_MM(6, ua, wA, NPARTS)
-          LPT_WPF(wA, tile_of(nxt, 0), nxt < it_end)
-          LPT_XLOAD(3, 1, ua) LPT_MM(0, ub, wB, NPARTS)
-          LPT_XLOAD(3, 2, ub) LPT_MM(1, ua, wB, NPARTS)
-          LPT_XLOAD(3, 3, ua) LPT_MM(2, ub, wB, NPARTS)
-          LPT_XLOAD(3, 4, ub) LPT_MM(3, ua, wB, NPARTS)
-          LPT_XLOAD(3, 5, ua) LPT_MM(4, ub, wB, NPARTS)
-          LPT_XLOAD(3, 6, ub) LPT_MM(5, ua, wB, NPARTS)
-          LPT_MM(6, ub, wB, 0)
-        } else if (rg == 1) {                          // 6 row tiles
-          LPT_XLOAD(0, 0, ua)
-          LPT_WPF(wB, tile_of(it, 1), true)
-          LPT_XLOAD(0, 1, ub) LPT_MM(0, ua, wA, NPARTS)
-          LPT_XLOAD(0, 2, ua) LPT_MM(1, ub, wA, NPARTS)
-          LPT_XLOAD(0, 3, ub) LPT_MM(2, ua, wA, NPARTS)
-          LPT_XLOAD(0, 4, ua) LPT_MM(3, ub, wA, NPARTS)
-          LPT_XLOAD(0, 5, ub) LPT_MM(4, ua, wA, NPARTS)
-          LPT_XLOAD(1, 0, ua) LPT_MM(5, ub, wA, NPARTS)
-          LPT_WPF(wA, tile_of(it, 2), true)
-          LPT_XLOAD(1, 1, ub) LPT_MM(0, ua, wB, NPARTS)
-          LPT_XLOAD(1, 2, ua) LPT_MM(1, ub, wB, NPARTS)
-          LPT_XLOAD(1, 3, ub) LPT_MM(2, ua, wB, NPARTS)
-          LPT_XLOAD(1, 4, ua) LPT_MM(3, ub, wB, NPARTS)
-          LPT_XLOAD(1, 5, ub) LPT_MM(4, ua, wB, NPARTS)
-          LPT_XLOAD(2, 0, ua) LPT_MM(5, ub, wB, NPARTS)
-          LPT_WPF(wB, tile_of(it, 3), true)
-          LPT_XLOAD(2, 1, ub) LPT_MM(0, ua, wA, NPARTS)
-          LPT_XLOAD(2, 2, ua) LPT_MM(1, ub, wA, NPARTS)
-          LPT_XLOAD(2, 3, ub) LPT_MM(2, ua, wA, NPARTS)
-          LPT_XLOAD(2, 4, ua) LPT_MM(3, ub, wA, NPARTS)
-          LPT_XLOAD(2, 5, ub) LPT_MM(4, ua, wA, NPARTS)
-          LPT_XLOAD(3, 0, ua) LPT_MM(5, ub, wA, NPARTS)
-          LPT_WPF(wA, tile_of(nxt, 0), nxt < it_end)
-          LPT_XLOAD(3, 1, ub) LPT_MM(0, ua, wB, NPARTS)
-          LPT_XLOAD(3, 2, ua) LPT_MM(1, ub, wB, NPARTS)
-          LPT_XLOAD(3, 3, ub) LPT_MM(2, ua, wB, NPARTS)
-          LPT_XLOAD(3, 4, ua) LPT_MM(3, ub, wB, NPARTS)
-          LPT_XLOAD(3, 5, ub) LPT_MM(4, ua, wB, NPARTS)
-          LPT_MM(5, ub, wB, 0)
-        }
-      }
-      if constexpr (RG == 3) {
-        if (rg == 0) {                          // 5 row tiles
-          LPT_XLOAD(0, 0, ua)
-          LPT_WPF(wB, tile_of(it, 1), true)
-          LPT_XLOAD(0, 1, ub) LPT_MM(0, ua, wA, NPARTS)
-          LPT_XLOAD(0, 2, ua) LPT_MM(1, ub, wA, NPARTS)
-          LPT_XLOAD(0, 3, ub) LPT_MM(2, ua, wA, NPARTS)
-          LPT_XLOAD(0, 4, ua) LPT_MM(3, ub, wA, NPARTS)
-          LPT_XLOAD(1, 0, ub) LPT_MM(4, ua, wA, NPARTS)
-          LPT_WPF(wA, tile_of(it, 2), true)
-          LPT_XLOAD(1, 1, ua) LPT_MM(0, ub, wB, NPARTS)
-          LPT_XLOAD(1, 2, ub) LPT_MM(1, ua, wB, NPARTS)
-          LPT_XLOAD(1, 3, ua) LPT_MM(2, ub, wB, NPARTS)
-          LPT_XLOAD(1, 4, ub) LPT_MM(3, ua, wB, NPARTS)
-          LPT_XLOAD(2, 0, ua) LPT_MM(4, ub, wB, NPARTS)
-          LPT_WPF(wB, tile_of(it, 3), true)
-          LPT_XLOAD(2, 1, ub) LPT_MM(0, ua, wA, NPARTS)
-          LPT_XLOAD(2, 2, ua) LPT_MM(1, ub, wA, NPARTS)
-          LPT_XLOAD(2, 3, ub) LPT_MM(2, ua, wA, NPARTS)
-          LPT_XLOAD(2, 4, ua) LPT_MM(3, ub, wA, NPARTS)
-          LPT_XLOAD(3, 0, ub) LPT_MM(4, ua, wA, NPARTS)
-          LPT_WPF(wA, tile_of(nxt, 0), nxt < it_end)
-          LPT_XLOAD(3, 1, ua) LPT_MM(0, ub, wB, NPARTS)
-          LPT_XLOAD(3, 2, ub) LPT_MM(1, ua, wB, NPARTS)
-          LPT_XLOAD(3, 3, ua) LPT_MM(2, ub, wB, NPARTS)
-          LPT_XLOAD(3, 4, ub) LPT_MM(3, ua, wB, NPARTS)
-          LPT_MM(4, ub, wB, 0)
-        } else if (rg == 1 || rg == 2) {                          // 4 row tiles
-          LPT_XLOAD(0, 0, ua)
-          LPT_WPF(wB, tile_of(it, 1), true)
-          LPT_XLOAD(0, 1, ub) LPT_MM(0, ua, wA, NPARTS)
-          LPT_XLOAD(0, 2, ua) LPT_MM(1, ub, wA, NPARTS)
-          LPT_XLOAD(0, 3, ub) LPT_MM(2, ua, wA, NPARTS)
-          LPT_XLOAD(1, 0, ua) LPT_MM(3, ub, wA, NPARTS)
-          LPT_WPF(wA, tile_of(it, 2), true)
-          LPT_XLOAD(1, 1, ub) LPT_MM(0, ua, wB, NPARTS)
-          LPT_XLOAD(1, 2, ua) LPT_MM(1, ub, wB, NPARTS)
-          LPT_XLOAD(1, 3, ub) LPT_MM(2, ua, wB, NPARTS)
-          LPT_XLOAD(2, 0, ua) LPT_MM(3, ub, wB, NPARTS)
-          LPT_WPF(wB, tile_of(it, 3), true)
-          LPT_XLOAD(2, 1, ub) LPT_MM(0, ua, wA, NPARTS)
-          LPT_XLOAD(2, 2, ua) LPT_MM(1, ub, wA, NPARTS)
-          LPT_XLOAD(2, 3, ub) LPT_MM(2, ua, wA, NPARTS)
-          LPT_XLOAD(3, 0, ua) LPT_MM(3, ub, wA, NPARTS)
-          LPT_WPF(wA, tile_of(nxt, 0), nxt < it_end)
-          LPT_XLOAD(3, 1, ub) LPT_MM(0, ua, wB, NPARTS)
-          LPT_XLOAD(3, 2, ua) LPT_MM(1, ub, wB, NPARTS)
-          LPT_XLOAD(3, 3, ub) LPT_MM(2, ua, wB, NPARTS)
-          LPT_MM(3, ub, wB, 0)
-        }
-      }
-#undef LPT_MM
-#undef LPT_WAIT
-#undef LPT_WPF
+      static_assert(TW_RT == 13, "the generated listings are for 13 row tiles");
+      if constexpr (NR == 13) LPT_TAP(13)                 // one wave per SIMD: all 13 row tiles
+      if constexpr (NR == 7) LPT_TAP(7)
+      if constexpr (NR == 6) LPT_TAP(6)
+      if constexpr (NR == 5) LPT_TAP(5)
+      if constexpr (NR == 4) LPT_TAP(4)
+#undef LPT_TAP
+#undef LPT_STEP_LIVE
+#undef LPT_STEP_ALL
+#undef LPT_WLD
+#undef LPT_WLD0
 #undef LPT_XLOAD
       it = nxt;
       en = __builtin_amdgcn_readfirstlane(en_next_v);
@@ -746,6 +837,20 @@ __global__ __launch_bounds__(256 * RG, RG) void backbone_lp_t_kernel(BackboneLpA
   }
 }
 
+template <typename T, int NP, int RG>
+__global__ __launch_bounds__(256 * RG, RG) void backbone_lp_t_kernel(BackboneLpArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_b[];
+  const int rg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);     // wave w = (column group w & 3, row group w >> 2)
+  // every row group executes the same sequence of workgroup barriers (the bodies differ in tile counts only)
+  if constexpr (RG == 1) backbone_lp_t_body<T, NP, RG, 0>(a, smem_b);
+  if constexpr (RG == 2) { if (rg == 0) backbone_lp_t_body<T, NP, RG, 0>(a, smem_b); else backbone_lp_t_body<T, NP, RG, 1>(a, smem_b); }
+  if constexpr (RG == 3) {
+    if (rg == 0) backbone_lp_t_body<T, NP, RG, 0>(a, smem_b);
+    else if (rg == 1) backbone_lp_t_body<T, NP, RG, 1>(a, smem_b);
+    else backbone_lp_t_body<T, NP, RG, 2>(a, smem_b);
+  }
+}
+
 }  // namespace
 
 extern "C" int svdd_backbone_cnn_lp(const uint8_t* x, const float* table0, const void* tiles, const float* vec,
@@ -782,7 +887,7 @@ extern "C" int svdd_backbone_cnn_lp(const uint8_t* x, const float* table0, const
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                 \
     hipExtLaunchKernelGGL((backbone_lp_t_kernel<TT, NPP, RGG>), grid, dim3(256 * RGG), lds, (hipStream_t)stream, e0, e1, 0, a); }
 #define LPT_LAUNCH_RG(TT, NPP)                                                                                      \
-  if (g_bb_lp_rg == 3) LPT_LAUNCH_ONE(TT, NPP, 3) else LPT_LAUNCH_ONE(TT, NPP, 2)
+  if (g_bb_lp_rg == 3) LPT_LAUNCH_ONE(TT, NPP, 3) else if (g_bb_lp_rg == 1) LPT_LAUNCH_ONE(TT, NPP, 1) else LPT_LAUNCH_ONE(TT, NPP, 2)
 #define LP_LAUNCH(TT, NPP)                                                                                          \
   do {                                                                                                               \
     if (transposed) {                                                                                                \

@@ -176,7 +176,70 @@ BB_LPT["variants"]["x_nofence"] = [("      __builtin_amdgcn_sched_barrier(0);   
 BB_LPT["variants"]["nomfma_noX_noW"] = BB_LPT["variants"]["nomfma"] + BB_LPT["variants"]["noX"] + BB_LPT["variants"]["noW"]
 BB_LPT["variants"]["nostats_nomfma_noX_noW"] = BB_LPT["variants"]["nostats"] + BB_LPT["variants"]["nomfma_noX_noW"]
 BB_LPT["variants"]["noX_noW"] = BB_LPT["variants"]["noX"] + BB_LPT["variants"]["noW"]
-SETS = {"bb_lpt": BB_LPT, "gru_pc": GRU_PC, "gru_lp": GRU_LP, "tower_lp": TOWER_LP, "bb_lp": BB_LP, "k1": K1, "tower2": TOWER2}
+# cycle counters at the phase boundaries of backbone_lp_t_kernel (correct results; read back by tools/lpt_phase_timing.py):
+# per wave [0] LayerNorm phases incl. the "image complete" barrier, [1] the (tap, chunk) loop, [2] the wait at the barrier
+# after it, [3] epilogue + first layer + last conv, [8 + layer] the loop of each layer
+_TICK = "{ const unsigned long long t_ = __builtin_readcyclecounter(); tacc[%d] += t_ - tprev; tprev = t_; }"
+BB_LPT_TIMING = {
+    "file": "svdd_lp_backbone.hip",
+    "bench": ["python", "tools/lpt_phase_timing.py"],
+    "variants": {"timing": [
+        ("typedef float f32x8 __attribute__((ext_vector_type(8)));",
+         "typedef float f32x8 __attribute__((ext_vector_type(8)));\n__device__ unsigned long long g_lpt_dbg[256 * 8 * 32];"),
+        ("  for (int layer = 0; layer <= nl; ++layer) {             // layer == nl: the first 1x1 conv of final_conv\n    const float* vl = a.vec + (size_t)(layer + 1) * 4 * BB_C;\n    const float sa = a.lscale[2 * layer], inv = a.lscale[2 * layer + 1];\n    // The phase code below",
+         "  unsigned long long tacc[4] = {0, 0, 0, 0}, tprev = __builtin_readcyclecounter();\n  for (int layer = 0; layer <= nl; ++layer) {             // layer == nl: the first 1x1 conv of final_conv\n    " + _TICK % 3 + "\n    const float* vl = a.vec + (size_t)(layer + 1) * 4 * BB_C;\n    const float sa = a.lscale[2 * layer], inv = a.lscale[2 * layer + 1];\n    // The phase code below"),
+        ("    __syncthreads();                                      // the image is complete\n    while (it < layer_end) {                              // one live tap",
+         "    __syncthreads();                                      // the image is complete\n    " + _TICK % 0 + "\n    const unsigned long long tl0 = tprev;\n    while (it < layer_end) {                              // one live tap"),
+        ("      it = nxt;\n      en = __builtin_amdgcn_readfirstlane(en_next_v);\n    }\n    __syncthreads();                                      // every wave is done reading the image\n    f32x4 bl0, bl1;",
+         "      it = nxt;\n      en = __builtin_amdgcn_readfirstlane(en_next_v);\n    }\n    " + _TICK % 1 + "\n    if (lane == 0 && blockIdx.x < 256) g_lpt_dbg[(blockIdx.x * 8 + w) * 32 + 8 + layer] = tprev - tl0;\n    __syncthreads();                                      // every wave is done reading the image\n    " + _TICK % 2 + "\n    f32x4 bl0, bl1;"),
+        ("  __syncthreads();\n  // ---- last 1x1 conv 128 -> 5 in fp32\n  for (int e = tid; e < L * 5; e += NTH) {",
+         "  __syncthreads();\n  " + _TICK % 3 + "\n  if (lane == 0 && blockIdx.x < 256) for (int k = 0; k < 4; ++k) g_lpt_dbg[(blockIdx.x * 8 + w) * 32 + k] = tacc[k];\n  // ---- last 1x1 conv 128 -> 5 in fp32\n  for (int e = tid; e < L * 5; e += NTH) {"),
+        ("}  // namespace\n\nextern \"C\" int svdd_backbone_cnn_lp(",
+         "}  // namespace\n\nextern \"C\" int svdd_internal_lpt_dbg(void* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_lpt_dbg), sizeof(g_lpt_dbg)); }\n\nextern \"C\" int svdd_backbone_cnn_lp("),
+    ]},
+}
+_T = BB_LPT_TIMING["variants"]
+_T["timing_noX"] = _T["timing"] + [("      { V[0] = *reinterpret_cast<const V8*>(plane + xa[R] + 64 * (C));", "      if (a.n == 12345) { V[0] = *reinterpret_cast<const V8*>(plane + xa[R] + 64 * (C));")]
+_T["timing_noW"] = _T["timing"] + [("      if (COND) { const V8* src_ = wsrc + (size_t)(TILE) * TILE_V8;", "      if ((COND) && a.n == 12345) { const V8* src_ = wsrc + (size_t)(TILE) * TILE_V8;")]
+_T["timing_noX_noW"] = _T["timing_noX"] + _T["timing_noW"][-1:]
+_T["timing_solo0"] = _T["timing"] + [("        } else if (rg == 1) {                          // 6 row tiles", "        } else if (rg == 1 && a.n == 12345) {                          // 6 row tiles")]
+_T["timing_solo1"] = _T["timing"] + [("        if (rg == 0) {                          // 7 row tiles", "        if (rg == 0 && a.n == 12345) {                          // 7 row tiles"),
+                                      ("        } else if (rg == 1) {                          // 6 row tiles", "        } else if (rg == 1) { if (a.n != 12345) {                         // 6 row tiles"),
+                                      ("          LPT_STEP(5, ub, wB, )\n        }\n      }\n      if constexpr (RG == 3) {", "          LPT_STEP(5, ub, wB, )\n        } }\n      }\n      if constexpr (RG == 3) {")]
+# every step's MFMAs unconditional (dead tiles read the zero rows: same results, more MFMAs in the dilation-64 layers)
+_NOBR = [("        if (lv_ & (1 << (RG * (R)))) acc[R][0] = Lp<T>::mfma(W[0], U[0], acc[R][0]);", "        acc[R][0] = Lp<T>::mfma(W[0], U[0], acc[R][0]);"),
+         ("        asm volatile(\"\" : \"+s\"(lv_));                                                                        \\\n        if (lv_ & (1 << (RG * (R)))) {", "        {")]
+_T["timing_nobranch"] = _T["timing"] + _NOBR
+_T["timing_nobranch_solo0"] = _T["timing_solo0"] + _NOBR
+_T["timing_nowait"] = _T["timing"] + [("      __builtin_amdgcn_s_waitcnt(0xC07F);                   /* lgkmcnt(0): this step's fragments */          \\\n", "")]
+_T["timing_nobranch_noX_solo0"] = _T["timing_solo0"] + _NOBR + _T["timing_noX"][-1:]
+# finer: [4] cycles in the steps between two weight prefetches, [5] in the prefetch (address + 4 loads + counted wait), [6] per tap before the first fragment request
+_FINE = [("      if (COND) { const V8* src_ = wsrc + (size_t)(TILE) * TILE_V8;", "      { const unsigned long long t_ = __builtin_readcyclecounter(); tf[0] += t_ - tfp; tfp = t_; }                            \\\n      if (COND) { const V8* src_ = wsrc + (size_t)(TILE) * TILE_V8;"),
+         ("      __builtin_amdgcn_s_waitcnt(0x0F70 | (2 * NPARTS));\n", "      __builtin_amdgcn_s_waitcnt(0x0F70 | (2 * NPARTS));                                                     \\\n      { const unsigned long long t_ = __builtin_readcyclecounter(); tf[1] += t_ - tfp; tfp = t_; }\n"),
+         ("      const int nxt = en >> 19;\n      const int en_next_v = sched[nxt < it_end ? nxt : it];\n      const int delta = (((en >> 15) & 15) - 4) * dil;\n      const int live = en >> rg;",
+          "      { const unsigned long long t_ = __builtin_readcyclecounter(); tf[0] += t_ - tfp; tfp = t_; }\n      const int nxt = en >> 19;\n      const int en_next_v = sched[nxt < it_end ? nxt : it];\n      const int delta = (((en >> 15) & 15) - 4) * dil;\n      const int live = en >> rg;"),
+         ("      V8 ua[2], ub[2];                                    // activation fragments", "      { const unsigned long long t_ = __builtin_readcyclecounter(); tf[2] += t_ - tfp; tfp = t_; }\n      V8 ua[2], ub[2];                                    // activation fragments"),
+         ("  unsigned long long tacc[4] = {0, 0, 0, 0}, tprev = __builtin_readcyclecounter();", "  unsigned long long tacc[4] = {0, 0, 0, 0}, tprev = __builtin_readcyclecounter(), tf[3] = {0, 0, 0}, tfp = 0;"),
+         ("    const unsigned long long tl0 = tprev;", "    const unsigned long long tl0 = tprev; tfp = tprev;"),
+         ("for (int k = 0; k < 4; ++k) g_lpt_dbg[(blockIdx.x * 8 + w) * 32 + k] = tacc[k];", "for (int k = 0; k < 7; ++k) g_lpt_dbg[(blockIdx.x * 8 + w) * 32 + k] = k < 4 ? tacc[k] : tf[k - 4];")]
+_T["fine"] = _T["timing"] + _FINE
+_T["fine_solo0"] = _T["timing_solo0"] + _FINE
+_T["fine_nobranch_solo0"] = _T["timing_solo0"] + _NOBR + _FINE
+# time stamps of every step of one tap (layer 2, tap 4, workgroups 0 and 1): slot 64 * wave + n in g_lpt_dbg[8192 ...]
+_STAMP = "if (dbg_on) { const unsigned long long t_ = __builtin_readcyclecounter(); if (lane == 0 && cnt < 60) g_lpt_dbg[8192 + (blockIdx.x * 8 + w) * 64 + cnt] = t_; ++cnt; }"
+_STAMPS = [("      __builtin_amdgcn_s_waitcnt(0xC07F);                   /* lgkmcnt(0): this step's fragments */          \\\n",
+            "      __builtin_amdgcn_s_waitcnt(0xC07F);                   /* lgkmcnt(0): this step's fragments */          \\\n      " + _STAMP + "  \\\n"),
+           ("      __builtin_amdgcn_s_waitcnt(0x0F70 | (2 * NPARTS));\n", "      __builtin_amdgcn_s_waitcnt(0x0F70 | (2 * NPARTS));                                                     \\\n      " + _STAMP + "\n"),
+           ("      V8 ua[2], ub[2];                                    // activation fragments", "      const bool dbg_on = blockIdx.x < 2 && layer == 2 && ((en >> 15) & 15) == 4;\n      int cnt = 0;\n      " + _STAMP + "\n      V8 ua[2], ub[2];                                    // activation fragments"),
+           ("      it = nxt;\n      en = __builtin_amdgcn_readfirstlane(en_next_v);\n    }\n    __syncthreads();                                      // every wave is done reading the image\n    f32x4 bl0, bl1;",
+            "      " + _STAMP + "\n      it = nxt;\n      en = __builtin_amdgcn_readfirstlane(en_next_v);\n    }\n    __syncthreads();                                      // every wave is done reading the image\n    f32x4 bl0, bl1;")]
+_T["stamps"] = [_T["timing"][0], _T["timing"][-1]] + _STAMPS
+_T["stamps_solo0"] = _T["stamps"] + _T["timing_solo0"][-1:]
+_T["timing_prio1"] = _T["timing"] + [("    const unsigned long long tl0 = tprev;", "    const unsigned long long tl0 = tprev;\n    if (rg == 1) __builtin_amdgcn_s_setprio(1);"),
+                                    ("    if (lane == 0 && blockIdx.x < 256) g_lpt_dbg[(blockIdx.x * 8 + w) * 32 + 8 + layer] = tprev - tl0;", "    __builtin_amdgcn_s_setprio(0);\n    if (lane == 0 && blockIdx.x < 256) g_lpt_dbg[(blockIdx.x * 8 + w) * 32 + 8 + layer] = tprev - tl0;")]
+_T["timing_prio_alt"] = _T["timing"] + [("      const int live = en >> rg;                          // bit RG r = owned tile r\n", "      const int live = en >> rg;                          // bit RG r = owned tile r\n      if ((it ^ rg) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);\n"),
+                                    ("    if (lane == 0 && blockIdx.x < 256) g_lpt_dbg[(blockIdx.x * 8 + w) * 32 + 8 + layer] = tprev - tl0;", "    __builtin_amdgcn_s_setprio(0);\n    if (lane == 0 && blockIdx.x < 256) g_lpt_dbg[(blockIdx.x * 8 + w) * 32 + 8 + layer] = tprev - tl0;")]
+SETS = {"bb_lpt_timing": BB_LPT_TIMING, "bb_lpt": BB_LPT, "gru_pc": GRU_PC, "gru_lp": GRU_LP, "tower_lp": TOWER_LP, "bb_lp": BB_LP, "k1": K1, "tower2": TOWER2}
 
 
 def build_variant(setname, name, spec):

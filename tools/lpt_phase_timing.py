@@ -1,0 +1,65 @@
+"""Where a workgroup of backbone_lp_t_kernel spends its cycles (instrumented build: tools/exp_variants.py build bb_lpt_timing,
+run with SVDD_HIP_LIB=build/exp/bb_lpt_timing/timing/libsvdd_hip.so): per wave the LayerNorm phases, the (tap, chunk) loop,
+the barrier wait after it and the epilogues, and the loop of every layer against its MFMA floor.
+Usage: python tools/lpt_phase_timing.py [mode] [B]"""
+import ctypes
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from svdd_amd import _lib, backbone, config, fused
+
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+mode = args[0] if args else "f16x3"
+B = int(args[1]) if len(args) > 1 else 256
+L = 200
+dev = "cuda:0"
+if os.environ.get("SVDD_BB_LP_VERSION"):               # 21 / 22 / 23: waves per SIMD of the transposed kernel
+    _lib.check(_lib.lib().svdd_set_option(3, int(os.environ["SVDD_BB_LP_VERSION"])), "svdd_set_option")
+torch.manual_seed(0)
+cnn = backbone.CNNModel(config.dna_config().model, alphabet_size=5).to(dev).eval()
+x = torch.randint(0, 5, (B, L), device=dev, dtype=torch.uint8)
+pk = fused.pack_backbone_lp(cnn, mode)
+for _ in range(30):                                    # clocks ramp for tens of ms after idle
+    fused.backbone_cnn_lp(x, pk)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(20):
+    fused.backbone_cnn_lp(x, pk)
+e1.record(); torch.cuda.synchronize()
+buf = np.zeros(256 * 8 * 32, dtype=np.uint64)
+rc = _lib.lib().svdd_internal_lpt_dbg(ctypes.c_void_p(buf.ctypes.data))
+assert rc == 0, rc
+d = buf.reshape(256, 8, 32).astype(np.float64)[:min(B, 256)]
+tot = d[:, :, :4].sum(-1)
+us = e0.elapsed_time(e1) * 1e3 / 20
+print(f"{mode} B={B}: launch {us:.1f} us (20 back to back); cycles per wave (mean over workgroups): total {tot.mean():.0f} = {tot.mean() / us / 1e3:.2f} GHz if the launch were all of it")
+for k, name in enumerate(("LayerNorm phases + image barrier", "(tap, chunk) loop", "barrier wait after the loop", "epilogues, first layer")):
+    print(f"  {name:34s} rg0 {d[:, :4, k].mean():9.0f}  rg1 {d[:, 4:, k].mean():9.0f}   ({d[:, :, k].mean() / tot.mean() * 100:4.1f} %)")
+if d[:, :, 4:7].sum() > 0:
+    for k, name in ((4, "steps between weight prefetches"), (5, "weight prefetch + counted wait"), (6, "tap head (schedule, addresses)")):
+        print(f"  {name:34s} rg0 {d[:, :4, k].mean():9.0f}  rg1 {d[:, 4:, k].mean():9.0f}")
+if "--brief" in sys.argv:
+    print("  loop cycles rg0 / rg1 at layers 0, 8, 12, 16: " + "   ".join(f"{d[:, :4, 8 + ly].mean():7.0f} / {d[:, 4:, 8 + ly].mean():7.0f}" for ly in (0, 8, 12, 16)))
+    sys.exit(0)
+dil = [1] * 4 + [1] * 4 + [4] * 4 + [16] * 4 + [64] * 4
+nl = len(cnn.convs)
+print("  layer  dilation  loop cycles rg0 / rg1   MFMA floor of the SIMD (16 cycles each)   occupancy while rg0 is in the loop")
+for ly in range(nl + 1):
+    dl = cnn.convs[ly].dilation[0] if ly < nl else 0
+    # live (tap, row tile) pairs of both row groups
+    live = [0, 0]
+    for t in range(9 if ly < nl else 1):
+        dd = (t - 4) * dl if ly < nl else 0
+        lo, hi = max(0, -dd), min(L, L - dd)
+        for r in range(13):
+            if lo < hi and lo < 16 * r + 16 and hi > 16 * r:
+                live[r & 1] += 1
+    if ly == nl:
+        live = [7, 6]
+    npass = 3 if mode.endswith("x3") else 1
+    floor = (live[0] + live[1]) * 4 * 2 * npass * 16
+    print(f"  {ly:5d}  {dl:8d}  {d[:, :4, 8 + ly].mean():9.0f} / {d[:, 4:, 8 + ly].mean():9.0f}   {floor:9d}   {floor / d[:, :4, 8 + ly].mean():.2f}")

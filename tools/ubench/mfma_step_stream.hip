@@ -1,0 +1,174 @@
+// mfma_step_stream.hip — what one step of backbone_lp_t_kernel's (tap, chunk) loop costs a wave, piece by piece.
+// A step = the 6 v_mfma_f32_16x16x32_f16 of one (chunk, row tile): two accumulators x three split passes, on weight
+// fragments W[0..3] (registers) and activation fragments U[0..1] (LDS, requested one step ahead into the other buffer).
+// Cycles per MFMA by s_memtime (shader cycles), one workgroup per CU, 1 or 2 waves per SIMD, for the streams
+//   0  bare: 6 MFMAs per step, 14 accumulators rotating (7 row tiles x 2 column tiles)
+//   1  + s_waitcnt lgkmcnt(0) at the head and two ds_read_b128 after the first MFMA
+//   2  + two scalar liveness tests (s_bitcmp + s_cbranch, never taken)
+//   3  stream 1 with the ds_reads BEFORE the first MFMA (the round-3 order)
+//   4  stream 1 with the MFMAs of two row tiles interleaved (4 accumulators per step of 12)
+//   5  stream 2 + the weight prefetch of the kernel every 7 steps (4 global_load_dwordx4 into the other W set, vmcnt(4))
+//   6  stream 5 where the second wave of each SIMD owns 6 row tiles (6 steps per chunk), like row group 1
+//   7  stream 5 without the liveness tests
+// Standalone: hipcc --offload-arch=gfx950 -O3 -o mfma_step_stream mfma_step_stream.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+#define MF(A, B, C) C = __builtin_amdgcn_mfma_f32_16x16x32_f16(A, B, C, 0, 0, 0)
+#define FENCE __builtin_amdgcn_sched_barrier(0);
+
+template <int STREAM>
+__global__ __launch_bounds__(512) void stream_kernel(float* out, unsigned long long* cyc, int iters, int live, const h8* wts) {
+  __shared__ __attribute__((aligned(16))) char lds[2 * 210 * 272];
+  for (int e = threadIdx.x; e < (int)sizeof(lds) / 4; e += blockDim.x) reinterpret_cast<float*>(lds)[e] = 0.001f * (e & 255);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+  const char* xa = lds + j * 272 + 16 * g;
+  h8 W[4];
+  for (int q = 0; q < 4; ++q) for (int e = 0; e < 8; ++e) W[q][e] = (_Float16)(0.01f * (q + 1) + 0.001f * e + 0.0001f * lane);
+  f4 acc[7][2];
+  for (int r = 0; r < 7; ++r) { acc[r][0] = f4{0, 0, 0, 0}; acc[r][1] = f4{0, 0, 0, 0}; }
+  h8 ua[2], ub[2];
+  ua[0] = *reinterpret_cast<const h8*>(xa); ua[1] = *reinterpret_cast<const h8*>(xa + 57120);
+  ub[0] = ua[0]; ub[1] = ua[1];
+  int lv = __builtin_amdgcn_readfirstlane(live);
+  const unsigned long long t0 = __builtin_readcyclecounter();
+#define XLOAD(R, V) { V[0] = *reinterpret_cast<const h8*>(xa + (R) * 32 * 272); V[1] = *reinterpret_cast<const h8*>(xa + 57120 + (R) * 32 * 272); }
+#define SIX_TAIL(R, U) MF(W[2], U[0], acc[R][1]); MF(W[1], U[0], acc[R][0]); MF(W[3], U[0], acc[R][1]); MF(W[0], U[1], acc[R][0]); MF(W[2], U[1], acc[R][1]);
+#define STEP(R, U, LOADNEXT)                                                                  \
+  FENCE                                                                                       \
+  if constexpr (STREAM >= 1) __builtin_amdgcn_s_waitcnt(0xC07F);                              \
+  if constexpr (STREAM == 3) { LOADNEXT FENCE }                                               \
+  if constexpr (STREAM == 2) {                                                                \
+    int l_ = lv; asm volatile("" : "+s"(l_));                                                 \
+    if (l_ & (1 << (R))) MF(W[0], U[0], acc[R][0]);                                           \
+    FENCE LOADNEXT FENCE                                                                      \
+    asm volatile("" : "+s"(l_));                                                              \
+    if (l_ & (1 << (R))) { SIX_TAIL(R, U) }                                                   \
+  } else {                                                                                    \
+    MF(W[0], U[0], acc[R][0]);                                                                \
+    FENCE if constexpr (STREAM == 1) { LOADNEXT } FENCE                                       \
+    SIX_TAIL(R, U)                                                                            \
+  }                                                                                           \
+  FENCE
+#define PAIR(R, U, V, LOADNEXT)                                                               \
+  FENCE __builtin_amdgcn_s_waitcnt(0xC07F);                                                   \
+  MF(W[0], U[0], acc[R][0]); MF(W[2], U[0], acc[R][1]); MF(W[0], V[0], acc[R + 1][0]); MF(W[2], V[0], acc[R + 1][1]); \
+  MF(W[1], U[0], acc[R][0]); MF(W[3], U[0], acc[R][1]); MF(W[1], V[0], acc[R + 1][0]); MF(W[3], V[0], acc[R + 1][1]); \
+  MF(W[0], U[1], acc[R][0]); MF(W[2], U[1], acc[R][1]); MF(W[0], V[1], acc[R + 1][0]); MF(W[2], V[1], acc[R + 1][1]); \
+  FENCE LOADNEXT FENCE
+  if constexpr (STREAM >= 5) {
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const h8* wsrc = wts + ((w & 3) * 64 + lane) * 4;
+    h8 WB[4];
+    for (int q = 0; q < 4; ++q) WB[q] = W[q];
+    int tile = 0;
+#define WPF(WN) { const h8* src_ = wsrc + (size_t)tile * 1024; _Pragma("unroll") for (int q = 0; q < 4; ++q) WN[q] = src_[q]; \
+                  tile = tile + 9 < 700 ? tile + 9 : tile - 690; } __builtin_amdgcn_s_waitcnt(0x0F74);
+#define STEPW(R, U, WS, LOADNEXT)                                                             \
+  FENCE __builtin_amdgcn_s_waitcnt(0xC07F);                                                   \
+  if constexpr (STREAM == 7) {                                                                \
+    MF(WS[0], U[0], acc[R][0]); FENCE LOADNEXT FENCE                                          \
+    MF(WS[2], U[0], acc[R][1]); MF(WS[1], U[0], acc[R][0]); MF(WS[3], U[0], acc[R][1]); MF(WS[0], U[1], acc[R][0]); MF(WS[2], U[1], acc[R][1]); \
+  } else {                                                                                    \
+    int l_ = lv; asm volatile("" : "+s"(l_));                                                 \
+    if (l_ & (1 << (R))) MF(WS[0], U[0], acc[R][0]);                                          \
+    FENCE LOADNEXT FENCE                                                                      \
+    asm volatile("" : "+s"(l_));                                                              \
+    if (l_ & (1 << (R))) { MF(WS[2], U[0], acc[R][1]); MF(WS[1], U[0], acc[R][0]); MF(WS[3], U[0], acc[R][1]); MF(WS[0], U[1], acc[R][0]); MF(WS[2], U[1], acc[R][1]); } \
+  }                                                                                           \
+  FENCE
+    const bool six = STREAM == 6 && w >= 4;
+    for (int it = 0; it < iters; ++it) {
+      if (!six) {
+        WPF(WB)
+        STEPW(0, ua, W, XLOAD(1, ub)) STEPW(1, ub, W, XLOAD(2, ua)) STEPW(2, ua, W, XLOAD(3, ub)) STEPW(3, ub, W, XLOAD(4, ua))
+        STEPW(4, ua, W, XLOAD(5, ub)) STEPW(5, ub, W, XLOAD(6, ua)) STEPW(6, ua, W, XLOAD(0, ub))
+        WPF(W)
+        STEPW(0, ub, WB, XLOAD(1, ua)) STEPW(1, ua, WB, XLOAD(2, ub)) STEPW(2, ub, WB, XLOAD(3, ua)) STEPW(3, ua, WB, XLOAD(4, ub))
+        STEPW(4, ub, WB, XLOAD(5, ua)) STEPW(5, ua, WB, XLOAD(6, ub)) STEPW(6, ub, WB, XLOAD(0, ua))
+      } else {
+        WPF(WB)
+        STEPW(0, ua, W, XLOAD(1, ub)) STEPW(1, ub, W, XLOAD(2, ua)) STEPW(2, ua, W, XLOAD(3, ub)) STEPW(3, ub, W, XLOAD(4, ua))
+        STEPW(4, ua, W, XLOAD(5, ub)) STEPW(5, ub, W, XLOAD(0, ua))
+        WPF(W)
+        STEPW(0, ua, WB, XLOAD(1, ub)) STEPW(1, ub, WB, XLOAD(2, ua)) STEPW(2, ua, WB, XLOAD(3, ub)) STEPW(3, ub, WB, XLOAD(4, ua))
+        STEPW(4, ua, WB, XLOAD(5, ub)) STEPW(5, ub, WB, XLOAD(0, ua))
+      }
+    }
+  } else
+  for (int it = 0; it < iters; ++it) {
+    if constexpr (STREAM == 4) {
+      h8 uc[2] = {ua[0], ua[1]}, ud[2] = {ub[0], ub[1]};
+      PAIR(0, ua, ub, XLOAD(2, uc) XLOAD(3, ud))
+      PAIR(2, uc, ud, XLOAD(4, ua) XLOAD(5, ub))
+      PAIR(4, ua, ub, XLOAD(0, uc) XLOAD(1, ud))
+      PAIR(0, uc, ud, XLOAD(2, ua) XLOAD(3, ub))
+      PAIR(2, ua, ub, XLOAD(4, uc) XLOAD(5, ud))
+      PAIR(4, uc, ud, XLOAD(0, ua) XLOAD(1, ub))
+    } else {
+      STEP(0, ua, XLOAD(1, ub))
+      STEP(1, ub, XLOAD(2, ua))
+      STEP(2, ua, XLOAD(3, ub))
+      STEP(3, ub, XLOAD(4, ua))
+      STEP(4, ua, XLOAD(5, ub))
+      STEP(5, ub, XLOAD(6, ua))
+      STEP(6, ua, XLOAD(0, ub))
+      STEP(0, ub, XLOAD(1, ua))
+      STEP(1, ua, XLOAD(2, ub))
+      STEP(2, ub, XLOAD(3, ua))
+      STEP(3, ua, XLOAD(4, ub))
+      STEP(4, ub, XLOAD(5, ua))
+      STEP(5, ua, XLOAD(6, ub))
+      STEP(6, ub, XLOAD(0, ua))
+    }
+  }
+  const unsigned long long t1 = __builtin_readcyclecounter();
+  float s = 0.0f;
+  for (int r = 0; r < 7; ++r) s += acc[r][0][0] + acc[r][1][1] + acc[r][0][2] + acc[r][1][3];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  if (lane == 0) cyc[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;
+}
+
+template <int STREAM>
+void run(const char* name, int threads) {
+  float* out; unsigned long long* cyc; h8* wts;
+  CK(hipMalloc(&wts, 720 * 1024 * sizeof(h8))); CK(hipMemset(wts, 0, 720 * 1024 * sizeof(h8)));
+  const int iters = 4000, nw = threads / 64;
+  CK(hipMalloc(&out, 256 * 512 * 4)); CK(hipMalloc(&cyc, 256 * 8 * 8));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  stream_kernel<STREAM><<<256, threads>>>(out, cyc, iters, 0x7f, wts);
+  CK(hipEventRecord(e0));
+  stream_kernel<STREAM><<<256, threads>>>(out, cyc, iters, 0x7f, wts);
+  CK(hipEventRecord(e1));
+  CK(hipDeviceSynchronize());
+  float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+  unsigned long long h[256 * 8];
+  CK(hipMemcpy(h, cyc, 256 * nw * 8, hipMemcpyDeviceToHost));
+  double mean = 0.0, m0 = 0.0, m1 = 0.0;
+  for (int i = 0; i < 256 * nw; ++i) { mean += (double)h[i]; if (i % nw < 4) m0 += (double)h[i]; else m1 += (double)h[i]; }
+  mean /= 256 * nw; m0 /= 256 * 4; m1 /= 256 * 4;
+  const double mfma_per_wave = (double)iters * (STREAM == 4 ? 72 : STREAM == 6 ? 78 : 84);
+  if (nw == 8) printf("    waves 0-3 %.0f ticks, waves 4-7 %.0f ticks\n", m0, m1);
+  printf("%-58s %d wave(s)/SIMD: %6.1f ticks per MFMA of the wave, %5.1f per MFMA of the SIMD ; launch %.3f ms = %.2f ns per MFMA of the SIMD, tick rate %.2f GHz\n",
+         name, nw / 4, mean / mfma_per_wave, mean / mfma_per_wave / (nw / 4), ms, ms * 1e6 / (mfma_per_wave * (nw / 4)), mean / (ms * 1e6));
+  CK(hipFree(out)); CK(hipFree(cyc)); CK(hipFree(wts));
+}
+
+int main() {
+  for (int threads = 256; threads <= 512; threads += 256) {
+    run<0>("0 bare 6-MFMA steps, 14 accumulators", threads);
+    run<1>("1 + lgkmcnt(0) + 2 ds_read_b128 after the first MFMA", threads);
+    run<2>("2 + two scalar liveness tests per step", threads);
+    run<3>("3 as 1, ds_reads before the first MFMA", threads);
+    run<4>("4 two row tiles per step (4 accumulators, 12 MFMAs)", threads);
+    run<5>("5 stream 2 + weight prefetch per 7 steps", threads);
+    run<6>("6 stream 5, waves 4-7 with 6 steps per chunk", threads);
+    run<7>("7 stream 5 without liveness tests", threads);
+  }
+  return 0;
+}
