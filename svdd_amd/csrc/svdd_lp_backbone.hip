@@ -758,21 +758,23 @@ __device__ __forceinline__ void backbone_lp_t_body(const BackboneLpArgs& a, char
         acc[R][1] = Lp<T>::mfma(W[NPARTS], U[1], acc[R][1]);                                                 \
       }                                                                                                      \
       __builtin_amdgcn_sched_barrier(0);
-      // LPT_STEP_LIVE: some row tiles of the tap only see zero padding and are skipped. The tests read an SGPR copy of the mask
-      // that the compiler cannot see through: otherwise it hoists them out of the chunk loop as lane masks and re-materialises
-      // each through a VGPR (v_cndmask + v_cmp per step). The requests stay unconditional.
+      // LPT_STEP_LIVE: for taps that leave two or more of the wave's row tiles in the zero padding (dilation 16 / 64). A dead
+      // step requests the next step's fragments and nothing else — no wait (a wait without MFMAs to hide it is a whole LDS round
+      // trip: the version that waited in every step spent as long in a dead step as in a live one) and ONE scalar test, on an
+      // SGPR copy of the mask that the compiler cannot see through (else it hoists the tests out of the chunk loop as lane
+      // masks and re-materialises each through a VGPR). The requests go out BEFORE the MFMAs here, so a live step waits with
+      // the next step's two (one) reads still outstanding.
 #define LPT_STEP_LIVE(R, U, W, LOADNEXT, EXTRA)                                                              \
       __builtin_amdgcn_sched_barrier(0);                                                                     \
-      __builtin_amdgcn_s_waitcnt(0xC07F);                                                                    \
+      LOADNEXT                                                                                               \
+      EXTRA                                                                                                  \
+      __builtin_amdgcn_sched_barrier(0);                                                                     \
       { int lv_ = live;                                                                                      \
         asm volatile("" : "+s"(lv_));                                                                        \
-        if (lv_ & (1 << (RG * (R)))) acc[R][0] = Lp<T>::mfma(W[0], U[0], acc[R][0]);                         \
-        __builtin_amdgcn_sched_barrier(0);                                                                   \
-        LOADNEXT                                                                                             \
-        EXTRA                                                                                                \
-        __builtin_amdgcn_sched_barrier(0);                                                                   \
-        asm volatile("" : "+s"(lv_));                                                                        \
         if (lv_ & (1 << (RG * (R)))) {                                                                       \
+          if constexpr (sizeof(#LOADNEXT) > 1) __builtin_amdgcn_s_waitcnt(0xC07F | (NPARTS << 8));           \
+          else __builtin_amdgcn_s_waitcnt(0xC07F);                                                           \
+          acc[R][0] = Lp<T>::mfma(W[0], U[0], acc[R][0]);                                                    \
           acc[R][1] = Lp<T>::mfma(W[NPARTS], U[0], acc[R][1]);                                               \
           if constexpr (NP == 3) {                                                                           \
             acc[R][0] = Lp<T>::mfma(W[1], U[0], acc[R][0]);                                                  \
@@ -782,9 +784,11 @@ __device__ __forceinline__ void backbone_lp_t_body(const BackboneLpArgs& a, char
           }                                                                                                  \
         } }                                                                                                  \
       __builtin_amdgcn_sched_barrier(0);
+      // a tap with at most one dead tile takes the all-live path: the dead tile's fragments are the zero rows, its MFMAs add
+      // +0 to accumulators that are never -0 — the same bits, and six MFMAs are cheaper than a test in each of the tap's steps
 #define LPT_TAP(N)                                                                                           \
       { constexpr int all_ = lpt_own_mask(N, RG);                                                            \
-        if ((live & all_) == all_) { LPT_TAP##N(LPT_STEP_ALL) } else { LPT_TAP##N(LPT_STEP_LIVE) } }
+        if (__builtin_popcount(all_ & ~live) <= 1) { LPT_TAP##N(LPT_STEP_ALL) } else { LPT_TAP##N(LPT_STEP_LIVE) } }
       V8 ua[2], ub[2];                                    // activation fragments, one (chunk, row tile) step ahead of the MFMAs
       static_assert(TW_RT == 13, "the generated listings are for 13 row tiles");
       if constexpr (NR == 13) LPT_TAP(13)                 // one wave per SIMD: all 13 row tiles
@@ -801,7 +805,11 @@ __device__ __forceinline__ void backbone_lp_t_body(const BackboneLpArgs& a, char
       it = nxt;
       en = __builtin_amdgcn_readfirstlane(en_next_v);
     }
-    __syncthreads();                                      // every wave is done reading the image
+    // No barrier here between conv layers: what follows (epilogue, the next layer's statistics) touches registers and psum
+    // only; the image is not written before the two barriers of the LayerNorm, which every wave reaches after its loop. The
+    // row group that wins the matrix pipe (the older wave of each SIMD) leaves the loop ~30 % earlier than its partner and used
+    // to wait here; now its VALU phases run under the partner's remaining MFMAs.
+    if (layer == nl) __syncthreads();                     // the fp32 image below overwrites planes that other waves may still read
     f32x4 bl0, bl1;
     chan8(vl, cbo, bl0, bl1, 1.0f);
     const f32x4 z4 = {0.0f, 0.0f, 0.0f, 0.0f};

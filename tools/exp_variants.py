@@ -177,8 +177,8 @@ BB_LPT["variants"]["nomfma_noX_noW"] = BB_LPT["variants"]["nomfma"] + BB_LPT["va
 BB_LPT["variants"]["nostats_nomfma_noX_noW"] = BB_LPT["variants"]["nostats"] + BB_LPT["variants"]["nomfma_noX_noW"]
 BB_LPT["variants"]["noX_noW"] = BB_LPT["variants"]["noX"] + BB_LPT["variants"]["noW"]
 # cycle counters at the phase boundaries of backbone_lp_t_kernel (correct results; read back by tools/lpt_phase_timing.py):
-# per wave [0] LayerNorm phases incl. the "image complete" barrier, [1] the (tap, chunk) loop, [2] the wait at the barrier
-# after it, [3] epilogue + first layer + last conv, [8 + layer] the loop of each layer
+# per wave [0] LayerNorm finalize + image write incl. the "image complete" barrier, [1] the (tap, chunk) loop, [2] the wait at the
+# first LayerNorm barrier (where the row groups meet again), [3] epilogue + statistics + first layer + last conv, [8 + layer] the loop of each layer
 _TICK = "{ const unsigned long long t_ = __builtin_readcyclecounter(); tacc[%d] += t_ - tprev; tprev = t_; }"
 BB_LPT_TIMING = {
     "file": "svdd_lp_backbone.hip",
@@ -190,8 +190,10 @@ BB_LPT_TIMING = {
          "  unsigned long long tacc[4] = {0, 0, 0, 0}, tprev = __builtin_readcyclecounter();\n  for (int layer = 0; layer <= nl; ++layer) {             // layer == nl: the first 1x1 conv of final_conv\n    " + _TICK % 3 + "\n    const float* vl = a.vec + (size_t)(layer + 1) * 4 * BB_C;\n    const float sa = a.lscale[2 * layer], inv = a.lscale[2 * layer + 1];\n    // The phase code below"),
         ("    __syncthreads();                                      // the image is complete\n    while (it < layer_end) {                              // one live tap",
          "    __syncthreads();                                      // the image is complete\n    " + _TICK % 0 + "\n    const unsigned long long tl0 = tprev;\n    while (it < layer_end) {                              // one live tap"),
-        ("      it = nxt;\n      en = __builtin_amdgcn_readfirstlane(en_next_v);\n    }\n    __syncthreads();                                      // every wave is done reading the image\n    f32x4 bl0, bl1;",
-         "      it = nxt;\n      en = __builtin_amdgcn_readfirstlane(en_next_v);\n    }\n    " + _TICK % 1 + "\n    if (lane == 0 && blockIdx.x < 256) g_lpt_dbg[(blockIdx.x * 8 + w) * 32 + 8 + layer] = tprev - tl0;\n    __syncthreads();                                      // every wave is done reading the image\n    " + _TICK % 2 + "\n    f32x4 bl0, bl1;"),
+        ("      it = nxt;\n      en = __builtin_amdgcn_readfirstlane(en_next_v);\n    }\n    // No barrier here between conv layers",
+         "      it = nxt;\n      en = __builtin_amdgcn_readfirstlane(en_next_v);\n    }\n    " + _TICK % 1 + "\n    if (lane == 0 && blockIdx.x < 256) g_lpt_dbg[(blockIdx.x * 8 + w) * 32 + 8 + layer] = tprev - tl0;\n    // No barrier here between conv layers"),
+        ("not seven (VGPR pressure)\n      }\n      __syncthreads();\n      if (tid < TW_ROWS) {",
+         "not seven (VGPR pressure)\n      }\n      " + _TICK % 3 + "\n      __syncthreads();\n      " + _TICK % 2 + "\n      if (tid < TW_ROWS) {"),
         ("  __syncthreads();\n  // ---- last 1x1 conv 128 -> 5 in fp32\n  for (int e = tid; e < L * 5; e += NTH) {",
          "  __syncthreads();\n  " + _TICK % 3 + "\n  if (lane == 0 && blockIdx.x < 256) for (int k = 0; k < 4; ++k) g_lpt_dbg[(blockIdx.x * 8 + w) * 32 + k] = tacc[k];\n  // ---- last 1x1 conv 128 -> 5 in fp32\n  for (int e = tid; e < L * 5; e += NTH) {"),
         ("}  // namespace\n\nextern \"C\" int svdd_backbone_cnn_lp(",
@@ -225,20 +227,19 @@ _FINE = [("      if (COND) { const V8* src_ = wsrc + (size_t)(TILE) * TILE_V8;",
 _T["fine"] = _T["timing"] + _FINE
 _T["fine_solo0"] = _T["timing_solo0"] + _FINE
 _T["fine_nobranch_solo0"] = _T["timing_solo0"] + _NOBR + _FINE
-# time stamps of every step of one tap (layer 2, tap 4, workgroups 0 and 1): slot 64 * wave + n in g_lpt_dbg[8192 ...]
-_STAMP = "if (dbg_on) { const unsigned long long t_ = __builtin_readcyclecounter(); if (lane == 0 && cnt < 60) g_lpt_dbg[8192 + (blockIdx.x * 8 + w) * 64 + cnt] = t_; ++cnt; }"
-_STAMPS = [("      __builtin_amdgcn_s_waitcnt(0xC07F);                   /* lgkmcnt(0): this step's fragments */          \\\n",
-            "      __builtin_amdgcn_s_waitcnt(0xC07F);                   /* lgkmcnt(0): this step's fragments */          \\\n      " + _STAMP + "  \\\n"),
-           ("      __builtin_amdgcn_s_waitcnt(0x0F70 | (2 * NPARTS));\n", "      __builtin_amdgcn_s_waitcnt(0x0F70 | (2 * NPARTS));                                                     \\\n      " + _STAMP + "\n"),
-           ("      V8 ua[2], ub[2];                                    // activation fragments", "      const bool dbg_on = blockIdx.x < 2 && layer == 2 && ((en >> 15) & 15) == 4;\n      int cnt = 0;\n      " + _STAMP + "\n      V8 ua[2], ub[2];                                    // activation fragments"),
-           ("      it = nxt;\n      en = __builtin_amdgcn_readfirstlane(en_next_v);\n    }\n    __syncthreads();                                      // every wave is done reading the image\n    f32x4 bl0, bl1;",
-            "      " + _STAMP + "\n      it = nxt;\n      en = __builtin_amdgcn_readfirstlane(en_next_v);\n    }\n    __syncthreads();                                      // every wave is done reading the image\n    f32x4 bl0, bl1;")]
-_T["stamps"] = [_T["timing"][0], _T["timing"][-1]] + _STAMPS
-_T["stamps_solo0"] = _T["stamps"] + _T["timing_solo0"][-1:]
-_T["timing_prio1"] = _T["timing"] + [("    const unsigned long long tl0 = tprev;", "    const unsigned long long tl0 = tprev;\n    if (rg == 1) __builtin_amdgcn_s_setprio(1);"),
-                                    ("    if (lane == 0 && blockIdx.x < 256) g_lpt_dbg[(blockIdx.x * 8 + w) * 32 + 8 + layer] = tprev - tl0;", "    __builtin_amdgcn_s_setprio(0);\n    if (lane == 0 && blockIdx.x < 256) g_lpt_dbg[(blockIdx.x * 8 + w) * 32 + 8 + layer] = tprev - tl0;")]
-_T["timing_prio_alt"] = _T["timing"] + [("      const int live = en >> rg;                          // bit RG r = owned tile r\n", "      const int live = en >> rg;                          // bit RG r = owned tile r\n      if ((it ^ rg) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);\n"),
-                                    ("    if (lane == 0 && blockIdx.x < 256) g_lpt_dbg[(blockIdx.x * 8 + w) * 32 + 8 + layer] = tprev - tl0;", "    __builtin_amdgcn_s_setprio(0);\n    if (lane == 0 && blockIdx.x < 256) g_lpt_dbg[(blockIdx.x * 8 + w) * 32 + 8 + layer] = tprev - tl0;")]
+# time stamps of every step of one tap (SVDD_STAMP_LAYER / SVDD_STAMP_TAP at build time, workgroups 0 and 1): slot 64 * wave + n in g_lpt_dbg[8192 ...]
+_STAMP = "if (dbg_on) { const unsigned long long t_ = __builtin_readcyclecounter(); if (lane == 0 && cnt < 62) g_lpt_dbg[8192 + (blockIdx.x * 8 + w) * 64 + cnt] = t_; ++cnt; }"
+def _stamps(layer, tap):
+    return [("#define LPT_STEP_ALL(R, U, W, LOADNEXT, EXTRA)                                                               \\\n      __builtin_amdgcn_sched_barrier(0);                                                                     \\\n      __builtin_amdgcn_s_waitcnt(0xC07F);                   /* lgkmcnt(0): this step's fragments */          \\\n",
+             "#define LPT_STEP_ALL(R, U, W, LOADNEXT, EXTRA)                                                               \\\n      __builtin_amdgcn_sched_barrier(0);                                                                     \\\n      __builtin_amdgcn_s_waitcnt(0xC07F);                   /* lgkmcnt(0): this step's fragments */          \\\n      " + _STAMP + " \\\n"),
+            ("#define LPT_STEP_LIVE(R, U, W, LOADNEXT, EXTRA)                                                              \\\n      __builtin_amdgcn_sched_barrier(0);                                                                     \\\n",
+             "#define LPT_STEP_LIVE(R, U, W, LOADNEXT, EXTRA)                                                              \\\n      __builtin_amdgcn_sched_barrier(0);                                                                     \\\n      " + _STAMP + " \\\n"),
+            ("      V8 ua[2], ub[2];                                    // activation fragments", "      const bool dbg_on = blockIdx.x < 2 && layer == %d && ((en >> 15) & 15) == %d;\n      int cnt = 0;\n      " % (layer, tap) + _STAMP + "\n      V8 ua[2], ub[2];                                    // activation fragments"),
+            ("      it = nxt;\n      en = __builtin_amdgcn_readfirstlane(en_next_v);\n    }\n    __syncthreads();                                      // every wave is done reading the image\n    f32x4 bl0, bl1;",
+             "      " + _STAMP + "\n      it = nxt;\n      en = __builtin_amdgcn_readfirstlane(en_next_v);\n    }\n    __syncthreads();                                      // every wave is done reading the image\n    f32x4 bl0, bl1;")]
+_T["stamps_d1"] = [_T["timing"][0], _T["timing"][-1]] + _stamps(2, 4)
+_T["stamps_d64"] = [_T["timing"][0], _T["timing"][-1]] + _stamps(17, 5)
+_T["stamps_d64b"] = [_T["timing"][0], _T["timing"][-1]] + _stamps(17, 6)
 SETS = {"bb_lpt_timing": BB_LPT_TIMING, "bb_lpt": BB_LPT, "gru_pc": GRU_PC, "gru_lp": GRU_LP, "tower_lp": TOWER_LP, "bb_lp": BB_LP, "k1": K1, "tower2": TOWER2}
 
 

@@ -37,7 +37,7 @@ d = buf.reshape(256, 8, 32).astype(np.float64)[:min(B, 256)]
 tot = d[:, :, :4].sum(-1)
 us = e0.elapsed_time(e1) * 1e3 / 20
 print(f"{mode} B={B}: launch {us:.1f} us (20 back to back); cycles per wave (mean over workgroups): total {tot.mean():.0f} = {tot.mean() / us / 1e3:.2f} GHz if the launch were all of it")
-for k, name in enumerate(("LayerNorm phases + image barrier", "(tap, chunk) loop", "barrier wait after the loop", "epilogues, first layer")):
+for k, name in enumerate(("LayerNorm finalize + image write", "(tap, chunk) loop", "wait at the first LayerNorm barrier", "epilogue, statistics, first layer")):
     print(f"  {name:34s} rg0 {d[:, :4, k].mean():9.0f}  rg1 {d[:, 4:, k].mean():9.0f}   ({d[:, :, k].mean() / tot.mean() * 100:4.1f} %)")
 if d[:, :, 4:7].sum() > 0:
     for k, name in ((4, "steps between weight prefetches"), (5, "weight prefetch + counted wait"), (6, "tap head (schedule, addresses)")):

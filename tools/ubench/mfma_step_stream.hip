@@ -10,6 +10,8 @@
 //   5  stream 2 + the weight prefetch of the kernel every 7 steps (4 global_load_dwordx4 into the other W set, vmcnt(4))
 //   6  stream 5 where the second wave of each SIMD owns 6 row tiles (6 steps per chunk), like row group 1
 //   7  stream 5 without the liveness tests
+//   8-11  the kernel's partly-live step (requests first, ONE test, wait only in a live step, weight prefetch as in 5) with
+//         7 / 5 / 3 / 1 of the wave's 7 row tiles live
 // Standalone: hipcc --offload-arch=gfx950 -O3 -o mfma_step_stream mfma_step_stream.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -82,6 +84,22 @@ __global__ __launch_bounds__(512) void stream_kernel(float* out, unsigned long l
     if (l_ & (1 << (R))) { MF(WS[2], U[0], acc[R][1]); MF(WS[1], U[0], acc[R][0]); MF(WS[3], U[0], acc[R][1]); MF(WS[0], U[1], acc[R][0]); MF(WS[2], U[1], acc[R][1]); } \
   }                                                                                           \
   FENCE
+#define STEPL(R, U, WS, LOADNEXT)                                                             \
+  FENCE LOADNEXT FENCE                                                                        \
+  { int l_ = lv; asm volatile("" : "+s"(l_));                                                 \
+    if (l_ & (1 << (R))) { __builtin_amdgcn_s_waitcnt(0xC27F);                                \
+      MF(WS[0], U[0], acc[R][0]); MF(WS[2], U[0], acc[R][1]); MF(WS[1], U[0], acc[R][0]); MF(WS[3], U[0], acc[R][1]); MF(WS[0], U[1], acc[R][0]); MF(WS[2], U[1], acc[R][1]); } } \
+  FENCE
+    if constexpr (STREAM >= 8) {
+      for (int it = 0; it < iters; ++it) {
+        WPF(WB)
+        STEPL(0, ua, W, XLOAD(1, ub)) STEPL(1, ub, W, XLOAD(2, ua)) STEPL(2, ua, W, XLOAD(3, ub)) STEPL(3, ub, W, XLOAD(4, ua))
+        STEPL(4, ua, W, XLOAD(5, ub)) STEPL(5, ub, W, XLOAD(6, ua)) STEPL(6, ua, W, XLOAD(0, ub))
+        WPF(W)
+        STEPL(0, ub, WB, XLOAD(1, ua)) STEPL(1, ua, WB, XLOAD(2, ub)) STEPL(2, ub, WB, XLOAD(3, ua)) STEPL(3, ua, WB, XLOAD(4, ub))
+        STEPL(4, ub, WB, XLOAD(5, ua)) STEPL(5, ua, WB, XLOAD(6, ub)) STEPL(6, ub, WB, XLOAD(0, ua))
+      }
+    } else {
     const bool six = STREAM == 6 && w >= 4;
     for (int it = 0; it < iters; ++it) {
       if (!six) {
@@ -99,6 +117,7 @@ __global__ __launch_bounds__(512) void stream_kernel(float* out, unsigned long l
         STEPW(0, ua, WB, XLOAD(1, ub)) STEPW(1, ub, WB, XLOAD(2, ua)) STEPW(2, ua, WB, XLOAD(3, ub)) STEPW(3, ub, WB, XLOAD(4, ua))
         STEPW(4, ua, WB, XLOAD(5, ub)) STEPW(5, ub, WB, XLOAD(0, ua))
       }
+    }
     }
   } else
   for (int it = 0; it < iters; ++it) {
@@ -135,15 +154,15 @@ __global__ __launch_bounds__(512) void stream_kernel(float* out, unsigned long l
 }
 
 template <int STREAM>
-void run(const char* name, int threads) {
+void run(const char* name, int threads, int live = 0x7f) {
   float* out; unsigned long long* cyc; h8* wts;
   CK(hipMalloc(&wts, 720 * 1024 * sizeof(h8))); CK(hipMemset(wts, 0, 720 * 1024 * sizeof(h8)));
   const int iters = 4000, nw = threads / 64;
   CK(hipMalloc(&out, 256 * 512 * 4)); CK(hipMalloc(&cyc, 256 * 8 * 8));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  stream_kernel<STREAM><<<256, threads>>>(out, cyc, iters, 0x7f, wts);
+  stream_kernel<STREAM><<<256, threads>>>(out, cyc, iters, live, wts);
   CK(hipEventRecord(e0));
-  stream_kernel<STREAM><<<256, threads>>>(out, cyc, iters, 0x7f, wts);
+  stream_kernel<STREAM><<<256, threads>>>(out, cyc, iters, live, wts);
   CK(hipEventRecord(e1));
   CK(hipDeviceSynchronize());
   float ms; CK(hipEventElapsedTime(&ms, e0, e1));
@@ -152,7 +171,8 @@ void run(const char* name, int threads) {
   double mean = 0.0, m0 = 0.0, m1 = 0.0;
   for (int i = 0; i < 256 * nw; ++i) { mean += (double)h[i]; if (i % nw < 4) m0 += (double)h[i]; else m1 += (double)h[i]; }
   mean /= 256 * nw; m0 /= 256 * 4; m1 /= 256 * 4;
-  const double mfma_per_wave = (double)iters * (STREAM == 4 ? 72 : STREAM == 6 ? 78 : 84);
+  const double mfma_per_wave = (double)iters * (STREAM == 4 ? 72 : STREAM == 6 ? 78 : 12 * __builtin_popcount(live));
+  if (STREAM >= 8) printf("    %.1f ticks per 7-step chunk (older waves), %.1f (younger)\n", m0 / (2.0 * iters), m1 / (2.0 * iters));
   if (nw == 8) printf("    waves 0-3 %.0f ticks, waves 4-7 %.0f ticks\n", m0, m1);
   printf("%-58s %d wave(s)/SIMD: %6.1f ticks per MFMA of the wave, %5.1f per MFMA of the SIMD ; launch %.3f ms = %.2f ns per MFMA of the SIMD, tick rate %.2f GHz\n",
          name, nw / 4, mean / mfma_per_wave, mean / mfma_per_wave / (nw / 4), ms, ms * 1e6 / (mfma_per_wave * (nw / 4)), mean / (ms * 1e6));
@@ -169,6 +189,10 @@ int main() {
     run<5>("5 stream 2 + weight prefetch per 7 steps", threads);
     run<6>("6 stream 5, waves 4-7 with 6 steps per chunk", threads);
     run<7>("7 stream 5 without liveness tests", threads);
+    run<8>("8 partly-live step, 7 of 7 live", threads, 0x7f);
+    run<8>("9 partly-live step, 5 of 7 live", threads, 0x1f);
+    run<8>("10 partly-live step, 3 of 7 live", threads, 0x07);
+    run<8>("11 partly-live step, 1 of 7 live", threads, 0x01);
   }
   return 0;
 }
