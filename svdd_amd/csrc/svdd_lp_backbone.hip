@@ -363,6 +363,20 @@ __global__ __launch_bounds__(512, 2) void backbone_lp_kernel(BackboneLpArgs a) {
 // One sequence per tile only (104 < L <= 208); shorter sequences keep the kernel above.
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 
+// v + (v of lane ^ X), X = 16 or 32, on the VALU: gfx950's v_permlane16_swap / v_permlane32_swap exchange the odd 16-lane rows
+// (the upper 32 lanes) of one register with the even rows (the lower lanes) of another, so after swapping two copies of v each
+// lane holds its own value in one and its partner's in the other. __shfl_xor compiles to ds_bpermute_b32 (an LDS round trip
+// per exchange, four in a row per row tile of the LayerNorm statistics); the builtin of the swap returns its first result
+// twice with this compiler (tools/ubench/permlane_swap_check.hip), hence the asm with the two wait states it needs.
+template <int X>
+__device__ __forceinline__ float xor_sum(float v) {
+  static_assert(X == 16 || X == 32, "row or half-wave exchange");
+  unsigned a = __builtin_bit_cast(unsigned, v), b = a;
+  if constexpr (X == 16) asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  else asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  return __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
+}
+
 // bits RG r, r < n: the row tiles a wave that owns n of them sees in the schedule's live mask (shifted by its row group)
 constexpr int lpt_own_mask(int n, int rgs) { int m = 0; for (int r = 0; r < n; ++r) m |= 1 << (rgs * r); return m; }
 
@@ -674,8 +688,8 @@ __device__ __forceinline__ void backbone_lp_t_body(const BackboneLpArgs& a, char
         const f32x4 d0 = f[r][0] + tb0 - K, d1 = f[r][1] + tb1 - K;
         const f32x4 s = d0 + d1, q = d0 * d0 + d1 * d1;
         float s1 = (s[0] + s[1]) + (s[2] + s[3]), s2 = (q[0] + q[1]) + (q[2] + q[3]);
-        s1 += __shfl_xor(s1, 16, WAVE_SZ); s2 += __shfl_xor(s2, 16, WAVE_SZ);
-        s1 += __shfl_xor(s1, 32, WAVE_SZ); s2 += __shfl_xor(s2, 32, WAVE_SZ);
+        s1 = xor_sum<16>(s1); s2 = xor_sum<16>(s2);       // + the lanes g ^ 1, then g ^ 2: the position's 32 channels of this wave
+        s1 = xor_sum<32>(s1); s2 = xor_sum<32>(s2);
         if (cbo == 32 * cg && p < TW_ROWS) { psum[cg * TW_ROWS + p] = s1; psum[(4 + cg) * TW_ROWS + p] = s2; }
         if (r & 1) __builtin_amdgcn_sched_barrier(0);       // two tiles' worth of loads in flight, not seven (VGPR pressure)
       }
@@ -786,9 +800,14 @@ __device__ __forceinline__ void backbone_lp_t_body(const BackboneLpArgs& a, char
       __builtin_amdgcn_sched_barrier(0);
       // a tap with at most one dead tile takes the all-live path: the dead tile's fragments are the zero rows, its MFMAs add
       // +0 to accumulators that are never -0 — the same bits, and six MFMAs are cheaper than a test in each of the tap's steps
+      // (a tap that is dead for ALL of this wave's tiles — the outermost taps of the dilation-64 layers for the odd row group —
+      // only requests the next tap's first weight tile: the weight stream of those layers is what bounds them, 1 KB per wave
+      // instruction through the vector memory pipe, twice per column group because both row groups need every tile)
 #define LPT_TAP(N)                                                                                           \
       { constexpr int all_ = lpt_own_mask(N, RG);                                                            \
-        if (__builtin_popcount(all_ & ~live) <= 1) { LPT_TAP##N(LPT_STEP_ALL) } else { LPT_TAP##N(LPT_STEP_LIVE) } }
+        if (__builtin_popcount(all_ & ~live) <= 1) { LPT_TAP##N(LPT_STEP_ALL) }                              \
+        else if ((live & all_) != 0) { LPT_TAP##N(LPT_STEP_LIVE) }                                           \
+        else { LPT_WLD0(wA, t1) LPT_WLD(wA, 1) LPT_WLD(wA, 2) LPT_WLD(wA, 3) } }
       V8 ua[2], ub[2];                                    // activation fragments, one (chunk, row tile) step ahead of the MFMAs
       static_assert(TW_RT == 13, "the generated listings are for 13 row tiles");
       if constexpr (NR == 13) LPT_TAP(13)                 // one wave per SIMD: all 13 row tiles
