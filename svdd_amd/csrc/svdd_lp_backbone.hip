@@ -640,6 +640,8 @@ __device__ __forceinline__ void backbone_lp_t_body(const BackboneLpArgs& a, char
 
   constexpr int TILE_V8 = 4 * 64 * 2 * NPARTS;
   const V8* wsrc = reinterpret_cast<const V8*>(a.tiles) + (cg * 64 + lane) * (2 * NPARTS);
+  const char* wbase = reinterpret_cast<const char*>(a.tiles);
+  const unsigned woff = (unsigned)((cg * 64 + lane) * (2 * NPARTS) * sizeof(V8));
   // weight tile of (entry k = 9 layer + tap, chunk c): the host's order is [layer][chunk][tap], then the 4 chunks of the 1x1 conv
   auto tile_of = [&](int k, int c) { const int ly = k / 9; return ly < nl ? ly * 36 + c * 9 + (k - 9 * ly) : nl * 36 + c; };
   int it = 0;
@@ -739,14 +741,15 @@ __device__ __forceinline__ void backbone_lp_t_body(const BackboneLpArgs& a, char
       // requested and never used — a request behind a branch makes the compiler's counter model merge "requested" with "not
       // requested", and it then waits for vmcnt(0), the request just made, in every step of the chunk)
       const int t0 = tile_of(it, 0), tstep = it < nl * 9 ? 9 : 1, t1 = tile_of(nxt < it_end ? nxt : it, 0);
-      const V8* wn_;
+      const char* wn_;
       // the chunk's 64-byte step is an immediate offset of the LDS read
 #define LPT_XLOAD(C, R, V)                                                                                   \
       { V[0] = *reinterpret_cast<const V8*>(plane + xa[R] + 64 * (C));                                       \
         if constexpr (NP == 3) V[1] = *reinterpret_cast<const V8*>(plane + PLANE_B + xa[R] + 64 * (C)); }
       // the next chunk's weight tile, one 16-byte piece per step into the idle set (no wait here: the compiler counts them)
-#define LPT_WLD0(WN, TILE) { wn_ = wsrc + (size_t)(TILE) * TILE_V8; WN[0] = wn_[0]; }
-#define LPT_WLD(WN, Q) { if constexpr ((Q) < 2 * NPARTS) WN[Q] = wn_[Q]; }
+      // (uniform tile base + the lane's 32-bit byte offset: one address VGPR per request instead of a 64-bit pair built per tile)
+#define LPT_WLD0(WN, TILE) { wn_ = wbase + (size_t)(TILE) * (TILE_V8 * sizeof(V8)); WN[0] = *reinterpret_cast<const V8*>(wn_ + woff); }
+#define LPT_WLD(WN, Q) { if constexpr ((Q) < 2 * NPARTS) WN[Q] = *reinterpret_cast<const V8*>(wn_ + woff + 16 * (Q)); }
       // One step = the 6 (2) MFMAs of one (chunk, row tile) on fragments requested during the step before it. What is not an
       // MFMA sits BETWEEN the MFMAs, where it issues while the matrix pipe is busy: the request for the next step's fragments
       // after the first, the piece of the next weight tile after the third. A wave alone on its SIMD then issues an MFMA every
