@@ -240,7 +240,25 @@ def _stamps(layer, tap):
 _T["stamps_d1"] = [_T["timing"][0], _T["timing"][-1]] + _stamps(2, 4)
 _T["stamps_d64"] = [_T["timing"][0], _T["timing"][-1]] + _stamps(17, 5)
 _T["stamps_d64b"] = [_T["timing"][0], _T["timing"][-1]] + _stamps(17, 6)
-SETS = {"bb_lpt_timing": BB_LPT_TIMING, "bb_lpt": BB_LPT, "gru_pc": GRU_PC, "gru_lp": GRU_LP, "tower_lp": TOWER_LP, "bb_lp": BB_LP, "k1": K1, "tower2": TOWER2}
+# the same boundaries in the exact-fp32 backbone_kernel (svdd_nets.hip): [0] LayerNorm (two passes, four barriers) + image write +
+# "image complete" barrier, [1] the (chunk, tap) loop, [2] the barrier after it, [3] epilogue, first layer, last conv
+BB_F32_TIMING = {
+    "file": "svdd_nets.hip",
+    "bench": ["python", "tools/lpt_phase_timing.py", "f32"],
+    "variants": {"timing": [
+        ("struct BackboneArgs {", "__device__ unsigned long long g_lpt_dbg[256 * 8 * 32];\nstruct BackboneArgs {"),
+        ("  for (int layer = 0; layer <= nl; ++layer) {             // layer == nl: the first 1x1 conv of final_conv\n    const float* vl = a.vec + (size_t)(layer + 1) * 4 * BB_C;\n    if (layer < nl) {\n      const float tb0 = vl[BB_C + col0], tb1 = vl[BB_C + col0 + 16];",
+         "  unsigned long long tacc[4] = {0, 0, 0, 0}, tprev = __builtin_readcyclecounter();\n  for (int layer = 0; layer <= nl; ++layer) {             // layer == nl: the first 1x1 conv of final_conv\n    " + _TICK % 3 + "\n    const float* vl = a.vec + (size_t)(layer + 1) * 4 * BB_C;\n    if (layer < nl) {\n      const float tb0 = vl[BB_C + col0], tb1 = vl[BB_C + col0 + 16];"),
+        ("    __syncthreads();                                      // the image is complete\n    // A fragments of row tiles 0 and 1 of an entry are requested during the LAST MFMA groups",
+         "    __syncthreads();                                      // the image is complete\n    " + _TICK % 0 + "\n    const unsigned long long tl0 = tprev;\n    // A fragments of row tiles 0 and 1 of an entry are requested during the LAST MFMA groups"),
+        ("#undef B2_ALOAD\n    __syncthreads();                                      // every wave is done reading the image\n",
+         "#undef B2_ALOAD\n    " + _TICK % 1 + "\n    if (lane == 0 && blockIdx.x < 256) g_lpt_dbg[(blockIdx.x * 8 + w) * 32 + 8 + layer] = tprev - tl0;\n    __syncthreads();                                      // every wave is done reading the image\n    " + _TICK % 2 + "\n"),
+        ("  __syncthreads();\n  // ---- last 1x1 conv 128 -> 5: one (row, class) dot product per thread iteration\n  for (int e = tid; e < tile_rows * 5; e += 512) {",
+         "  __syncthreads();\n  " + _TICK % 3 + "\n  if (lane == 0 && blockIdx.x < 256) for (int k = 0; k < 4; ++k) g_lpt_dbg[(blockIdx.x * 8 + w) * 32 + k] = tacc[k];\n  // ---- last 1x1 conv 128 -> 5: one (row, class) dot product per thread iteration\n  for (int e = tid; e < tile_rows * 5; e += 512) {"),
+        ("extern \"C\" int svdd_backbone_cnn_f32(", "extern \"C\" int svdd_internal_lpt_dbg(void* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_lpt_dbg), sizeof(g_lpt_dbg)); }\n\nextern \"C\" int svdd_backbone_cnn_f32("),
+    ]},
+}
+SETS = {"bb_f32_timing": BB_F32_TIMING, "bb_lpt_timing": BB_LPT_TIMING, "bb_lpt": BB_LPT, "gru_pc": GRU_PC, "gru_lp": GRU_LP, "tower_lp": TOWER_LP, "bb_lp": BB_LP, "k1": K1, "tower2": TOWER2}
 
 
 def build_variant(setname, name, spec):

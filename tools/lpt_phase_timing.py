@@ -21,14 +21,15 @@ if os.environ.get("SVDD_BB_LP_VERSION"):               # 21 / 22 / 23: waves per
 torch.manual_seed(0)
 cnn = backbone.CNNModel(config.dna_config().model, alphabet_size=5).to(dev).eval()
 x = torch.randint(0, 5, (B, L), device=dev, dtype=torch.uint8)
-pk = fused.pack_backbone_lp(cnn, mode)
+pk = fused.pack_backbone(cnn) if mode == "f32" else fused.pack_backbone_lp(cnn, mode)
+fwd = fused.backbone_cnn if mode == "f32" else fused.backbone_cnn_lp
 for _ in range(30):                                    # clocks ramp for tens of ms after idle
-    fused.backbone_cnn_lp(x, pk)
+    fwd(x, pk)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(20):
-    fused.backbone_cnn_lp(x, pk)
+    fwd(x, pk)
 e1.record(); torch.cuda.synchronize()
 buf = np.zeros(256 * 8 * 32, dtype=np.uint64)
 rc = _lib.lib().svdd_internal_lpt_dbg(ctypes.c_void_p(buf.ctypes.data))
@@ -61,5 +62,5 @@ for ly in range(nl + 1):
     if ly == nl:
         live = [7, 6]
     npass = 3 if mode.endswith("x3") else 1
-    floor = (live[0] + live[1]) * 4 * 2 * npass * 16
+    floor = (live[0] + live[1]) * 4 * 2 * (8 * 32 if mode == "f32" else npass * 16)       # f32: 8 v_mfma_f32_16x16x4_f32 of 32 cycles per (tile, column tile, chunk, tap)
     print(f"  {ly:5d}  {dl:8d}  {d[:, :4, 8 + ly].mean():9.0f} / {d[:, 4:, 8 + ly].mean():9.0f}   {floor:9d}   {floor / d[:, :4, 8 + ly].mean():.2f}")
