@@ -1528,13 +1528,16 @@ __global__ __launch_bounds__(512, 2) void backbone_kernel(BackboneArgs a) {
   while (it < it_end && sched[it] == 0) ++it;
   it = __builtin_amdgcn_readfirstlane(it);
   int en = __builtin_amdgcn_readfirstlane(sched[it]);
-  float4 bn[4];
+  // two weight-fragment sets that trade roles from entry to entry (round 4d: with ONE set refilled in place the current tile
+  // had to be copied out first, 8 v_mov_b64 at each end of an entry, and VALU work does not run under fp32 MFMAs on this SIMD)
+  float4 bA[4], bB[4];
   {
     const float* src = wsrc + (size_t)tile_of(it) * BB_C * CH;
-    bn[0] = *reinterpret_cast<const float4*>(src);
-    bn[1] = *reinterpret_cast<const float4*>(src + 4);
-    bn[2] = *reinterpret_cast<const float4*>(src + 16 * CH);
-    bn[3] = *reinterpret_cast<const float4*>(src + 16 * CH + 4);
+    bA[0] = *reinterpret_cast<const float4*>(src);
+    bA[1] = *reinterpret_cast<const float4*>(src + 4);
+    bA[2] = *reinterpret_cast<const float4*>(src + 16 * CH);
+    bA[3] = *reinterpret_cast<const float4*>(src + 16 * CH + 4);
+    bB[0] = bA[0]; bB[1] = bA[1]; bB[2] = bA[2]; bB[3] = bA[3];
   }
 
   for (int layer = 0; layer <= nl; ++layer) {             // layer == nl: the first 1x1 conv of final_conv
@@ -1646,17 +1649,18 @@ __global__ __launch_bounds__(512, 2) void backbone_kernel(BackboneArgs a) {
       const int COFF = (((EN) >> 13) & 3) * (CH * 4);                                                        \
       const int DBYTES = DELTA * (BB_AP * 4) + COFF;
     // one (chunk, tap) entry; UA holds (or is receiving) row tile 0, UB row tile 1
-#define B2_ENTRY(UA, UB)                                                                                     \
+#define B2_ENTRY(UA, UB, BC, BN)                                                                             \
     { const int nxt = en >> 19;                                                                              \
       const int en_next_v = sched[nxt < it_end ? nxt : it];                                                  \
-      const float bf0[8] = {bn[0].x, bn[0].y, bn[0].z, bn[0].w, bn[1].x, bn[1].y, bn[1].z, bn[1].w};         \
-      const float bf1[8] = {bn[2].x, bn[2].y, bn[2].z, bn[2].w, bn[3].x, bn[3].y, bn[3].z, bn[3].w};         \
-      if (nxt < it_end) {                                                                                    \
-        const float* src = wsrc + (size_t)tile_of(nxt) * BB_C * CH;                                          \
-        bn[0] = *reinterpret_cast<const float4*>(src);                                                       \
-        bn[1] = *reinterpret_cast<const float4*>(src + 4);                                                   \
-        bn[2] = *reinterpret_cast<const float4*>(src + 16 * CH);                                             \
-        bn[3] = *reinterpret_cast<const float4*>(src + 16 * CH + 4);                                         \
+      const float bf0[8] = {BC[0].x, BC[0].y, BC[0].z, BC[0].w, BC[1].x, BC[1].y, BC[1].z, BC[1].w};         \
+      const float bf1[8] = {BC[2].x, BC[2].y, BC[2].z, BC[2].w, BC[3].x, BC[3].y, BC[3].z, BC[3].w};         \
+      { /* the next entry's tile into the idle set; after the last entry: this entry's again (never used) — unconditional, \
+           so that the compiler's vmcnt model has one path */                                                \
+        const float* src = wsrc + (size_t)tile_of(nxt < it_end ? nxt : it) * BB_C * CH;                      \
+        BN[0] = *reinterpret_cast<const float4*>(src);                                                       \
+        BN[1] = *reinterpret_cast<const float4*>(src + 4);                                                   \
+        BN[2] = *reinterpret_cast<const float4*>(src + 16 * CH);                                             \
+        BN[3] = *reinterpret_cast<const float4*>(src + 16 * CH + 4);                                         \
       }                                                                                                      \
       B2_PARAMS(en, delta, coff, dbytes)                                                                     \
       const int live = en >> rh;                          /* bit 2 r = owned tile r */                       \
@@ -1692,15 +1696,23 @@ __global__ __launch_bounds__(512, 2) void backbone_kernel(BackboneArgs a) {
       B2_ALOAD(0, ua, delta0, coff0, dbytes0)
       B2_ALOAD(1, ub, delta0, coff0, dbytes0)
     }
+    // entries come in fours (the chunks of a tap), so a layer always ends on the second body and the sets keep their roles
+    // from layer to layer; the odd exit is there for the bookkeeping only
+    bool odd = false;
     if (rh == 0) {
       while (it < layer_end) {
-        B2_ENTRY(ua, ub)
-        if (it >= layer_end) break;
-        B2_ENTRY(ub, ua)
+        B2_ENTRY(ua, ub, bA, bB)
+        if (it >= layer_end) { odd = true; break; }
+        B2_ENTRY(ub, ua, bB, bA)
       }
     } else {
-      while (it < layer_end) B2_ENTRY(ua, ub)
+      while (it < layer_end) {
+        B2_ENTRY(ua, ub, bA, bB)
+        if (it >= layer_end) { odd = true; break; }
+        B2_ENTRY(ua, ub, bB, bA)
+      }
     }
+    if (odd) { bA[0] = bB[0]; bA[1] = bB[1]; bA[2] = bB[2]; bA[3] = bB[3]; }
 #undef B2_ENTRY
 #undef B2_PARAMS
 #undef B2_MM

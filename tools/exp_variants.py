@@ -258,6 +258,22 @@ BB_F32_TIMING = {
         ("extern \"C\" int svdd_backbone_cnn_f32(", "extern \"C\" int svdd_internal_lpt_dbg(void* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_lpt_dbg), sizeof(g_lpt_dbg)); }\n\nextern \"C\" int svdd_backbone_cnn_f32("),
     ]},
 }
+_SKIPLOOP = "while (it < layer_end) { const int nxt_ = en >> 19; en = __builtin_amdgcn_readfirstlane(sched[nxt_ < it_end ? nxt_ : it]); it = nxt_; }"
+_F = BB_F32_TIMING["variants"]
+_F["timing_solo0"] = _F["timing"] + [("    } else {\n      while (it < layer_end) B2_ENTRY(ua, ub)\n    }", "    } else {\n      if (a.n == 12345) { while (it < layer_end) B2_ENTRY(ua, ub) } else { " + _SKIPLOOP + " }\n    }")]
+_F["timing_solo1"] = _F["timing"] + [("    if (rh == 0) {\n      while (it < layer_end) {\n        B2_ENTRY(ua, ub)\n        if (it >= layer_end) break;\n        B2_ENTRY(ub, ua)\n      }\n    } else {",
+                                       "    if (rh == 0) {\n      if (a.n == 12345) { while (it < layer_end) {\n        B2_ENTRY(ua, ub)\n        if (it >= layer_end) break;\n        B2_ENTRY(ub, ua)\n      } } else { " + _SKIPLOOP + " }\n    } else {")]
+_F["timing_nobranch"] = _F["timing"] + [("      if (live & (1 << (2 * (R)))) {                                                                         \\\n        _Pragma(\"unroll\") for (int q = 0; q < 2; ++q) {                                                      \\\n          acc[R][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(U[q].x, bf0[4 * q], acc[R][0], 0, 0, 0);          \\",
+                                          "      {                                                                         \\\n        _Pragma(\"unroll\") for (int q = 0; q < 2; ++q) {                                                      \\\n          acc[R][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(U[q].x, bf0[4 * q], acc[R][0], 0, 0, 0);          \\")]
+_FSTAMP = "if (dbg_on) { const unsigned long long t_ = __builtin_readcyclecounter(); if (lane == 0 && cnt < 62) g_lpt_dbg[8192 + (blockIdx.x * 8 + w) * 64 + cnt] = t_; ++cnt; }"
+_F["stamps"] = [_F["timing"][0], _F["timing"][-1],
+    ("#define B2_MM(R, U, NOUT)                                                                                    \\\n      __builtin_amdgcn_sched_barrier(0);                                                                     \\\n      B2_WAIT(NOUT)                                                                                          \\\n",
+     "#define B2_MM(R, U, NOUT)                                                                                    \\\n      __builtin_amdgcn_sched_barrier(0);                                                                     \\\n      B2_WAIT(NOUT)                                                                                          \\\n      " + _FSTAMP + " \\\n"),
+    ("    float4 ua[2], ub[2];\n    if (it < layer_end) {\n      B2_PARAMS(en, delta0, coff0, dbytes0)", "    const bool dbg_on = blockIdx.x < 2 && layer == 2;\n    int cnt = 0;\n    float4 ua[2], ub[2];\n    if (it < layer_end) {\n      B2_PARAMS(en, delta0, coff0, dbytes0)")]
+_F["stamps_solo0"] = _F["stamps"] + _F["timing_solo0"][-1:]
+_F["timing_solo0_noX"] = _F["timing_solo0"] + [("        V[0] = ap_[0]; V[1] = ap_[1]; }\n#define B2_WAIT", "        if (a.n == 12345) { V[0] = ap_[0]; V[1] = ap_[1]; } }\n#define B2_WAIT")]
+_F["timing_solo0_nobranch"] = _F["timing_solo0"] + _F["timing_nobranch"][-1:]
+_F["timing_solo0_noW"] = _F["timing_solo0"] + [("      if (nxt < it_end) {                                                                                    \\\n        const float* src = wsrc + (size_t)tile_of(nxt) * BB_C * CH;", "      if (nxt < it_end && a.n == 12345) {                                                                                    \\\n        const float* src = wsrc + (size_t)tile_of(nxt) * BB_C * CH;")]
 SETS = {"bb_f32_timing": BB_F32_TIMING, "bb_lpt_timing": BB_LPT_TIMING, "bb_lpt": BB_LPT, "gru_pc": GRU_PC, "gru_lp": GRU_LP, "tower_lp": TOWER_LP, "bb_lp": BB_LP, "k1": K1, "tower2": TOWER2}
 
 

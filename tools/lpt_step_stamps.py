@@ -14,9 +14,9 @@ dev = "cuda:0"
 torch.manual_seed(0)
 cnn = backbone.CNNModel(config.dna_config().model, alphabet_size=5).to(dev).eval()
 x = torch.randint(0, 5, (256, 200), device=dev, dtype=torch.uint8)
-pk = fused.pack_backbone_lp(cnn, mode)
+pk = fused.pack_backbone(cnn) if mode == "f32" else fused.pack_backbone_lp(cnn, mode)
 for _ in range(3):
-    fused.backbone_cnn_lp(x, pk)
+    (fused.backbone_cnn if mode == "f32" else fused.backbone_cnn_lp)(x, pk)
 torch.cuda.synchronize()
 buf = np.zeros(256 * 8 * 32, dtype=np.uint64)
 assert _lib.lib().svdd_internal_lpt_dbg(ctypes.c_void_p(buf.ctypes.data)) == 0

@@ -10,6 +10,9 @@
 //   5  stream 2 + the weight prefetch of the kernel every 7 steps (4 global_load_dwordx4 into the other W set, vmcnt(4))
 //   6  stream 5 where the second wave of each SIMD owns 6 row tiles (6 steps per chunk), like row group 1
 //   7  stream 5 without the liveness tests
+//   12-15 the exact-fp32 backbone's step (14: the fragment address clamped per step as in the kernel, requests after the group;
+//         15: the same requests after the FIRST MFMA of the group): 16 v_mfma_f32_16x16x4_f32 (two accumulators x 8 k-steps) bare / with its wait,
+//         liveness test and two ds_read_b128 of the next row tile's fragment
 //   8-11  the kernel's partly-live step (requests first, ONE test, wait only in a live step, weight prefetch as in 5) with
 //         7 / 5 / 3 / 1 of the wave's 7 row tiles live
 // Standalone: hipcc --offload-arch=gfx950 -O3 -o mfma_step_stream mfma_step_stream.hip
@@ -154,6 +157,108 @@ __global__ __launch_bounds__(512) void stream_kernel(float* out, unsigned long l
 }
 
 template <int STREAM>
+__global__ __launch_bounds__(512) void stream_f32_kernel(float* out, unsigned long long* cyc, int iters, int live) {
+  __shared__ __attribute__((aligned(16))) float lds[210 * 132];
+  for (int e = threadIdx.x; e < 210 * 132; e += blockDim.x) lds[e] = 0.001f * (e & 255);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+  const float* xa = lds + j * 132 + 8 * g;
+  float bf0[8], bf1[8];
+  for (int e = 0; e < 8; ++e) { bf0[e] = 0.01f * e + 0.0001f * lane; bf1[e] = 0.02f * e + 0.0002f * lane; }
+  f4 acc[7][2];
+  for (int r = 0; r < 7; ++r) { acc[r][0] = f4{0, 0, 0, 0}; acc[r][1] = f4{0, 0, 0, 0}; }
+  float4 ua[2], ub[2];
+  ua[0] = *reinterpret_cast<const float4*>(xa); ua[1] = *reinterpret_cast<const float4*>(xa + 4); ub[0] = ua[0]; ub[1] = ua[1];
+  int lv = __builtin_amdgcn_readfirstlane(live);
+  const unsigned long long t0 = __builtin_readcyclecounter();
+#define XLF(R, V) { V[0] = *reinterpret_cast<const float4*>(xa + (R) * 32 * 132); V[1] = *reinterpret_cast<const float4*>(xa + (R) * 32 * 132 + 4); }
+#define MF4(A, B, C) C = __builtin_amdgcn_mfma_f32_16x16x4f32(A, B, C, 0, 0, 0)
+#define GROUP16(R, U)                                                                         \
+  _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                             \
+    MF4(U[q].x, bf0[4 * q], acc[R][0]); MF4(U[q].x, bf1[4 * q], acc[R][1]);                   \
+    MF4(U[q].y, bf0[4 * q + 1], acc[R][0]); MF4(U[q].y, bf1[4 * q + 1], acc[R][1]);           \
+    MF4(U[q].z, bf0[4 * q + 2], acc[R][0]); MF4(U[q].z, bf1[4 * q + 2], acc[R][1]);           \
+    MF4(U[q].w, bf0[4 * q + 3], acc[R][0]); MF4(U[q].w, bf1[4 * q + 3], acc[R][1]); }
+#define XLC(R, V) { const int o_ = min(max(arow + dby + (R) * (32 * 132 * 4), alo), ahi);                       \
+                    const float4* ap_ = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(lds) + o_); V[0] = ap_[0]; V[1] = ap_[1]; }
+#define STEPF(R, U, LOADNEXT)                                                                 \
+  FENCE                                                                                       \
+  if constexpr (STREAM == 15) {                                                               \
+    __builtin_amdgcn_s_waitcnt(0xC07F);                                                       \
+    MF4(U[0].x, bf0[0], acc[R][0]);                                                           \
+    FENCE LOADNEXT FENCE                                                                      \
+    MF4(U[0].x, bf1[0], acc[R][1]);                                                           \
+    MF4(U[0].y, bf0[1], acc[R][0]); MF4(U[0].y, bf1[1], acc[R][1]);                           \
+    MF4(U[0].z, bf0[2], acc[R][0]); MF4(U[0].z, bf1[2], acc[R][1]);                           \
+    MF4(U[0].w, bf0[3], acc[R][0]); MF4(U[0].w, bf1[3], acc[R][1]);                           \
+    MF4(U[1].x, bf0[4], acc[R][0]); MF4(U[1].x, bf1[4], acc[R][1]);                           \
+    MF4(U[1].y, bf0[5], acc[R][0]); MF4(U[1].y, bf1[5], acc[R][1]);                           \
+    MF4(U[1].z, bf0[6], acc[R][0]); MF4(U[1].z, bf1[6], acc[R][1]);                           \
+    MF4(U[1].w, bf0[7], acc[R][0]); MF4(U[1].w, bf1[7], acc[R][1]);                           \
+  } else if constexpr (STREAM >= 13) {                                                               \
+    __builtin_amdgcn_s_waitcnt(0xC07F | (2 << 8));                                            \
+    int l_ = lv; asm volatile("" : "+s"(l_));                                                 \
+    if (l_ & (1 << (R))) { GROUP16(R, U) }                                                    \
+    FENCE LOADNEXT                                                                            \
+  } else { GROUP16(R, U) }                                                                    \
+  FENCE
+  const int arow = (j * 132 + 8 * g) * 4, alo = arow - (j + 1) * 132 * 4, ahi = arow + (208 - j) * 132 * 4;
+  int dby = __builtin_amdgcn_readfirstlane(live) & 0x1000 ? 132 * 4 : 0;
+  asm volatile("" : "+s"(dby));
+  if constexpr (STREAM == 13 || STREAM == 14) { XLF(1, ub) }
+  if constexpr (STREAM == 14) {
+    for (int it = 0; it < iters; ++it) {
+      STEPF(0, ua, XLC(2, ua)) STEPF(1, ub, XLC(3, ub)) STEPF(2, ua, XLC(4, ua)) STEPF(3, ub, XLC(5, ub))
+      STEPF(4, ua, XLC(6, ua)) STEPF(5, ub, XLC(0, ub)) STEPF(6, ua, XLC(1, ua))
+      STEPF(0, ub, XLC(2, ub)) STEPF(1, ua, XLC(3, ua)) STEPF(2, ub, XLC(4, ub)) STEPF(3, ua, XLC(5, ua))
+      STEPF(4, ub, XLC(6, ub)) STEPF(5, ua, XLC(0, ua)) STEPF(6, ub, XLC(1, ub))
+    }
+  } else if constexpr (STREAM == 15) {
+    for (int it = 0; it < iters; ++it) {
+      STEPF(0, ua, XLC(1, ub)) STEPF(1, ub, XLC(2, ua)) STEPF(2, ua, XLC(3, ub)) STEPF(3, ub, XLC(4, ua))
+      STEPF(4, ua, XLC(5, ub)) STEPF(5, ub, XLC(6, ua)) STEPF(6, ua, XLC(0, ub))
+      STEPF(0, ub, XLC(1, ua)) STEPF(1, ua, XLC(2, ub)) STEPF(2, ub, XLC(3, ua)) STEPF(3, ua, XLC(4, ub))
+      STEPF(4, ub, XLC(5, ua)) STEPF(5, ua, XLC(6, ub)) STEPF(6, ub, XLC(0, ua))
+    }
+  } else
+  for (int it = 0; it < iters; ++it) {
+    STEPF(0, ua, XLF(2, ua)) STEPF(1, ub, XLF(3, ub)) STEPF(2, ua, XLF(4, ua)) STEPF(3, ub, XLF(5, ub))
+    STEPF(4, ua, XLF(6, ua)) STEPF(5, ub, XLF(0, ub)) STEPF(6, ua, XLF(1, ua))
+    STEPF(0, ub, XLF(2, ub)) STEPF(1, ua, XLF(3, ua)) STEPF(2, ub, XLF(4, ub)) STEPF(3, ua, XLF(5, ua))
+    STEPF(4, ub, XLF(6, ub)) STEPF(5, ua, XLF(0, ua)) STEPF(6, ub, XLF(1, ub))
+  }
+  const unsigned long long t1 = __builtin_readcyclecounter();
+  float sres = 0.0f;
+  for (int r = 0; r < 7; ++r) sres += acc[r][0][0] + acc[r][1][1] + acc[r][0][2] + acc[r][1][3];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = sres;
+  if (lane == 0) cyc[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;
+}
+
+template <int STREAM>
+void run_f32(const char* name, int threads) {
+  float* out; unsigned long long* cyc;
+  const int iters = 1000, nw = threads / 64;
+  CK(hipMalloc(&out, 256 * 512 * 4)); CK(hipMalloc(&cyc, 256 * 8 * 8));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  stream_f32_kernel<STREAM><<<256, threads>>>(out, cyc, iters, 0x7f);
+  CK(hipEventRecord(e0));
+  stream_f32_kernel<STREAM><<<256, threads>>>(out, cyc, iters, 0x7f);
+  CK(hipEventRecord(e1));
+  CK(hipDeviceSynchronize());
+  float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+  unsigned long long h[256 * 8];
+  CK(hipMemcpy(h, cyc, 256 * nw * 8, hipMemcpyDeviceToHost));
+  double m0 = 0.0, m1 = 0.0;
+  for (int i = 0; i < 256 * nw; ++i) { if (i % nw < 4) m0 += (double)h[i]; else m1 += (double)h[i]; }
+  m0 /= 256 * 4; m1 /= 256 * 4;
+  const double mfma_per_wave = (double)iters * 14 * 16, last = nw == 8 ? (m0 > m1 ? m0 : m1) : m0;
+  printf("%-58s %d wave(s)/SIMD: %5.1f ticks per MFMA of the SIMD ; launch %.3f ms, tick rate %.2f GHz", name, nw / 4, last / (mfma_per_wave * (nw / 4)), ms, last / (ms * 1e6));
+  if (nw == 8) printf(" ; older waves done after %.0f %% of it", 100.0 * (m0 < m1 ? m0 : m1) / last);
+  printf("\n");
+  CK(hipFree(out)); CK(hipFree(cyc));
+}
+
+template <int STREAM>
 void run(const char* name, int threads, int live = 0x7f) {
   float* out; unsigned long long* cyc; h8* wts;
   CK(hipMalloc(&wts, 720 * 1024 * sizeof(h8))); CK(hipMemset(wts, 0, 720 * 1024 * sizeof(h8)));
@@ -198,6 +303,10 @@ int main() {
     run<8>("9 partly-live step, 5 of 7 live", threads, 0x1f);
     run<8>("10 partly-live step, 3 of 7 live", threads, 0x07);
     run<8>("11 partly-live step, 1 of 7 live", threads, 0x01);
+    run_f32<12>("12 fp32: bare 16-MFMA steps (16x16x4), 14 accumulators", threads);
+    run_f32<13>("13 fp32: + wait, liveness test, 2 ds_read_b128", threads);
+    run_f32<14>("14 fp32: 13 with the clamped address computed per step", threads);
+    run_f32<15>("15 fp32: requests (clamped) after the first MFMA, no test", threads);
   }
   return 0;
 }
