@@ -395,3 +395,20 @@ def test_torch_generator_state_conversion_for_the_device_mt19937():
         ops.mt_state_to_torch(np.concatenate([x[:624], [0]]), st)
     with pytest.raises(ops.SvddError):
         ops.mt_state_from_torch(torch.zeros(100, dtype=torch.uint8))
+
+
+def test_generated_step_listings_are_in_sync_with_their_generator():
+    """The unrolled (chunk, row tile) listings of backbone_lp_t_kernel are generated text inside svdd_lp_backbone.hip: the block
+    between the markers must be exactly what tools/gen_lpt_taps.py prints (edit the generator, then --write)."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gen_lpt_taps", os.path.join(root, "tools", "gen_lpt_taps.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    src = open(gen.SRC).read()
+    block = gen.block()
+    assert block in src
+    for n in (13, 7, 6, 5, 4):                       # 4 chunks x n steps, each chunk requests the next weight tile exactly once
+        body = block.split(f"#define LPT_TAP{n}(S)")[1].split("#define")[0]
+        assert body.count("S(") == 4 * n and body.count("LPT_WLD0(") == 4

@@ -61,6 +61,55 @@ def test_backbone_lp_vs_f32_and_fp64(mode, B, L):
         assert e64 <= 2.0 * (f32[:nb] - ref64).abs().max().item() + 1e-6
 
 
+@pytest.mark.parametrize("mode", ["f16x3", "bf16"])
+@pytest.mark.parametrize("L", [200, 128, 105])
+def test_backbone_lp_transposed_variants_same_bits(mode, L):
+    """backbone_lp_t_kernel with one, two (default) and three waves per SIMD — 13 / 7 + 6 / 5 + 4 + 4 row tiles per wave, each a
+    generated step listing (tools/gen_lpt_taps.py) in an all-live and a partly-live form — accumulates every output in the same
+    order: the three must agree bit for bit, at lengths that leave 0, 5 and 7 whole row tiles in the zero padding."""
+    from svdd_amd import _lib, fused
+    cnn = _perturbed_cnn(L)
+    x = torch.randint(0, 5, (19, L), device=DEV, dtype=torch.uint8)
+    pk = fused.pack_backbone_lp(cnn, mode)
+    outs = {}
+    try:
+        for v in (22, 21, 23):
+            _lib.check(_lib.lib().svdd_set_option(3, v), "svdd_set_option")
+            outs[v] = fused.backbone_cnn_lp(x, pk).clone()
+    finally:
+        _lib.check(_lib.lib().svdd_set_option(3, 22), "svdd_set_option")
+    torch.cuda.synchronize()
+    assert torch.isfinite(outs[22]).all()
+    assert torch.equal(outs[21], outs[22]) and torch.equal(outs[23], outs[22])
+
+
+@pytest.mark.parametrize("dils", [(4, 1, 64, 16, 1), (1, 64, 4, 1, 16), (64, 16, 4, 1, 1)])
+def test_backbone_lp_other_dilation_orders(dils, monkeypatch):
+    """The kernels take the dilation of every layer as data. With the reference's order the last conv layer has dilation 64, a
+    shift by four row tiles — which hides any read / write overlap between the two row groups of a SIMD at the one layer
+    boundary without a LayerNorm (the 1x1 stage) behind the tile parity. Other orders do not: every variant must still match the
+    fp32 kernel, and each other bit for bit."""
+    from svdd_amd import _lib, backbone, fused
+    monkeypatch.setattr(backbone, "DILATIONS", dils)
+    cnn = _perturbed_cnn(200)
+    assert [c.dilation[0] for c in cnn.convs][-1] == dils[-1]
+    x = torch.randint(0, 5, (40, 200), device=DEV, dtype=torch.uint8)
+    f32 = fused.backbone_cnn(x, fused.pack_backbone(cnn))
+    for mode in ("f16x3", "bf16"):
+        pk = fused.pack_backbone_lp(cnn, mode)
+        outs = {}
+        try:
+            for v in (22, 21, 23):
+                _lib.check(_lib.lib().svdd_set_option(3, v), "svdd_set_option")
+                outs[v] = torch.stack([fused.backbone_cnn_lp(x, pk) for _ in range(3)])     # three launches each: a race is timing
+        finally:
+            _lib.check(_lib.lib().svdd_set_option(3, 22), "svdd_set_option")
+        torch.cuda.synchronize()
+        assert (outs[22][0] - f32).abs().max().item() <= TOL_LOGITS[mode], (mode, dils)
+        for v in (22, 21, 23):
+            assert torch.equal(outs[v], outs[22][:1].expand_as(outs[v])), (mode, dils, v)
+
+
 def test_backbone_lp_row_placement_independent():
     """A sequence's logits do not depend on which tile / batch position it lands in (needed by the exact work-skipping
     paths, which re-pack rows)."""
