@@ -1510,7 +1510,9 @@ __global__ __launch_bounds__(512, 2) void backbone_kernel(BackboneArgs a) {
   __syncthreads();                                        // sched is visible
 
   // A operand addressing: this lane feeds row 16 (rh + 2 r) + j of its tiles, channels 32 c + 8 g .. + 8
-  const int arow0 = ((16 * rh + j) * BB_AP + 8 * g) * 4;  // byte offset of (row 16 rh + j, col 8 g) inside img
+  typedef __attribute__((address_space(3))) f32x4 LdsF4;
+  const int img_lds = (int)(unsigned)(size_t)(const __attribute__((address_space(3))) float*)img;              // LDS byte address of img
+  const int arow0 = img_lds + ((16 * rh + j) * BB_AP + 8 * g) * 4;  // LDS byte address of (row 16 rh + j, col 8 g) of img
   const int a_lo = arow0 - (16 * rh + j + 1) * BB_AP * 4; // row -1
   const int a_hi = arow0 + (TW_ROWS - 16 * rh - j) * BB_AP * 4;     // row TW_ROWS
   int apos[SPT1 ? 1 : NR];
@@ -1518,7 +1520,6 @@ __global__ __launch_bounds__(512, 2) void backbone_kernel(BackboneArgs a) {
 #pragma unroll
     for (int r = 0; r < NR; ++r) apos[r] = 16 * (rh + 2 * r) + j < TW_ROWS ? rpos[16 * (rh + 2 * r) + j] : -(1 << 20);
   }
-  const char* imgb = reinterpret_cast<const char*>(img);
 
   // Weight stream: each lane reads W[col0][8 g ..] and W[col0 + 16][8 g ..] of the (layer, chunk, tap) tile straight
   // from L2 into the B-operand registers, one tile ahead (no LDS staging, no barrier inside a layer).
@@ -1619,13 +1620,17 @@ __global__ __launch_bounds__(512, 2) void backbone_kernel(BackboneArgs a) {
     // entry of a layer: right here), so that the matrix pipe does not run dry at every (chunk, tap) boundary while both waves
     // of a SIMD wait for their first LDS reads (round 3; same bits: only the loads move). A wave with 7 row tiles ends an
     // entry on the fragment set it began with, so its two sets trade roles from entry to entry (two copies of the body).
+    // (VALU work does not run under fp32 MFMAs on this SIMD: the clamp is ONE v_med3_i32, and the fragment is read through an
+    //  LDS address kept as an integer that already contains the image's base — as "imgb + o_" every request carried a
+    //  v_add_u32 of the dynamic-LDS symbol, which is 0)
 #define B2_ALOAD(R, V, DELTA, COFF, DBYTES)                                                                  \
       { int o_;                                                                                              \
-        if (SPT1) o_ = min(max(arow0 + (DBYTES) + (R) * (32 * BB_AP * 4), a_lo + (COFF)), a_hi + (COFF));    \
+        if (SPT1) asm("v_med3_i32 %0, %1, %2, %3" : "=v"(o_) : "v"(arow0 + (DBYTES) + (R) * (32 * BB_AP * 4)), "v"(a_lo + (COFF)), "v"(a_hi + (COFF))); \
         else o_ = ((unsigned)(apos[SPT1 ? 0 : (R)] + (DELTA)) < (unsigned)L ? arow0 + (DBYTES) + (R) * (32 * BB_AP * 4) \
                                                                              : a_hi + (COFF));               \
-        const float4* ap_ = reinterpret_cast<const float4*>(imgb + o_);                                      \
-        V[0] = ap_[0]; V[1] = ap_[1]; }
+        const LdsF4* ap_ = reinterpret_cast<const LdsF4*>(o_);                                               \
+        const f32x4 t0_ = ap_[0], t1_ = ap_[1];                                                              \
+        V[0] = make_float4(t0_[0], t0_[1], t0_[2], t0_[3]); V[1] = make_float4(t1_[0], t1_[1], t1_[2], t1_[3]); }
 #define B2_WAIT(NOUT) __builtin_amdgcn_s_waitcnt(0xC07F | ((NOUT) << 8));
 #define B2_MM(R, U, NOUT)                                                                                    \
       __builtin_amdgcn_sched_barrier(0);                                                                     \
