@@ -405,7 +405,8 @@ enum { SVDD_OPT_FORCE_EXACT = 0,
        SVDD_OPT_SELECT_ONE_ROW = 2 /* A/B: 1 = svdd_select as one wave per row for every M (default 0: several rows per wave for M <= 64,
                                       4 row groups per wave from 2^21 (row, candidate) slots on); 2 / 3 = force 4 / 1 row groups per wave */,
        SVDD_OPT_BACKBONE_LP_VERSION = 3 /* A/B: 1 = svdd_backbone_cnn_lp runs the round-2 kernel for every shape; 2 (default) = the
-                                            transposed-accumulator kernel where one sequence fills a tile (104 < L <= 208) */,
+                                            transposed-accumulator kernel where one sequence fills a tile (104 < L <= 208);
+                                            21 / 22 (= 2) / 23: that kernel with one / two / three waves per SIMD (same bits) */,
        SVDD_OPT_TRUNK_GEMM_VERSION = 4 /* A/B: svdd_trunk_gemm kernel: 1 = 128 x 128 tiles everywhere, 2 (default) = 256 x 256 LDS-DMA
                                            tiles from 128 tiles up, 3 = 256 x 256 everywhere (13 .. 16: timing experiments with
                                            wrong results: no epilogue / one K block / no DMA / no fragment reads); 40 / 41 / 42: the

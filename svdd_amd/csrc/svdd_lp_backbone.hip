@@ -7,8 +7,9 @@ extern "C" int svdd_internal_num_cus();      // svdd_nets.hip
 extern "C" int svdd_internal_fixed_spt();    // svdd_nets.hip (svdd_set_backbone_packing)
 
 static int g_bb_lp_version = 2;     // svdd_set_option(SVDD_OPT_BACKBONE_LP_VERSION, 1): the round-2 kernel for every shape (A/B)
-static int g_bb_lp_rg = 2;          // ... 22 / 23 / 24: the transposed kernel with 2 / 3 / 4 row groups (waves per SIMD); measured
-                                    // (f16x3 / bf16, B = 256, L = 200): 2: 0.718 / 0.384 ms ; 3: 0.886 / 0.381 ms (x3 spills at 168 VGPRs) ; 4: spills
+static int g_bb_lp_rg = 2;          // ... 21 / 22 / 23: the transposed kernel with 1 / 2 / 3 row groups (waves per SIMD); measured
+                                    // (f16x3 / bf16, B = 256, L = 200, round 4d): 2: 0.652 / 0.339 ms ; 1: 0.74 / 0.51 ms (512 registers, but
+                                    // nothing hides its own stalls) ; 3: spills at 168 VGPRs. All three produce the same bits (tests/test_lp_gpu.py)
 extern "C" void svdd_internal_set_bb_lp_version(int v) {
   if (v >= 21 && v <= 23) { g_bb_lp_version = 2; g_bb_lp_rg = v - 20; }
   else g_bb_lp_version = v == 1 ? 1 : 2;
