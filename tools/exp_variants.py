@@ -4,6 +4,8 @@ wrong by construction) so that the component's cost shows up as a time differenc
     python tools/exp_variants.py build <set>     here (no GPU needed): patched COPIES of svdd_amd/csrc are compiled into
                                                  build/exp/<set>/<variant>/libsvdd_hip.so (git-ignored, travels with gpurun)
     python tools/exp_variants.py run <set>       on the GPU box: the set's microbenchmark once per variant (SVDD_HIP_LIB)
+    python tools/exp_variants.py check <set>     which variants' patches still match the sources (older experiments go stale when
+                                                 a kernel is restructured; their numbers stay in profiles/)
 
 The tracked sources are never edited in place."""
 import os
@@ -204,7 +206,7 @@ _T = BB_LPT_TIMING["variants"]
 _T["timing_noX"] = _T["timing"] + [("      { V[0] = *reinterpret_cast<const V8*>(plane + xa[R] + 64 * (C));", "      if (a.n == 12345) { V[0] = *reinterpret_cast<const V8*>(plane + xa[R] + 64 * (C));")]
 _T["timing_noW"] = _T["timing"] + [("      if (COND) { const V8* src_ = wsrc + (size_t)(TILE) * TILE_V8;", "      if ((COND) && a.n == 12345) { const V8* src_ = wsrc + (size_t)(TILE) * TILE_V8;")]
 _T["timing_noX_noW"] = _T["timing_noX"] + _T["timing_noW"][-1:]
-_T["timing_solo0"] = _T["timing"] + [("        } else if (rg == 1) {                          // 6 row tiles", "        } else if (rg == 1 && a.n == 12345) {                          // 6 row tiles")]
+_T["timing_solo0"] = _T["timing"] + [("      if constexpr (NR == 6) LPT_TAP(6)", "      if constexpr (NR == 6) { if (a.n == 12345) LPT_TAP(6) }")]
 _T["timing_solo1"] = _T["timing"] + [("        if (rg == 0) {                          // 7 row tiles", "        if (rg == 0 && a.n == 12345) {                          // 7 row tiles"),
                                       ("        } else if (rg == 1) {                          // 6 row tiles", "        } else if (rg == 1) { if (a.n != 12345) {                         // 6 row tiles"),
                                       ("          LPT_STEP(5, ub, wB, )\n        }\n      }\n      if constexpr (RG == 3) {", "          LPT_STEP(5, ub, wB, )\n        } }\n      }\n      if constexpr (RG == 3) {")]
@@ -260,9 +262,8 @@ BB_F32_TIMING = {
 }
 _SKIPLOOP = "while (it < layer_end) { const int nxt_ = en >> 19; en = __builtin_amdgcn_readfirstlane(sched[nxt_ < it_end ? nxt_ : it]); it = nxt_; }"
 _F = BB_F32_TIMING["variants"]
-_F["timing_solo0"] = _F["timing"] + [("    } else {\n      while (it < layer_end) B2_ENTRY(ua, ub)\n    }", "    } else {\n      if (a.n == 12345) { while (it < layer_end) B2_ENTRY(ua, ub) } else { " + _SKIPLOOP + " }\n    }")]
-_F["timing_solo1"] = _F["timing"] + [("    if (rh == 0) {\n      while (it < layer_end) {\n        B2_ENTRY(ua, ub)\n        if (it >= layer_end) break;\n        B2_ENTRY(ub, ua)\n      }\n    } else {",
-                                       "    if (rh == 0) {\n      if (a.n == 12345) { while (it < layer_end) {\n        B2_ENTRY(ua, ub)\n        if (it >= layer_end) break;\n        B2_ENTRY(ub, ua)\n      } } else { " + _SKIPLOOP + " }\n    } else {")]
+_F["timing_solo0"] = _F["timing"] + [("    } else {\n      while (it < layer_end) {\n        B2_ENTRY(ua, ub, bA, bB)", "    } else {\n      if (a.n != 12345) { " + _SKIPLOOP + " }\n      while (it < layer_end) {\n        B2_ENTRY(ua, ub, bA, bB)")]
+_F["timing_solo1"] = _F["timing"] + [("    if (rh == 0) {\n      while (it < layer_end) {\n        B2_ENTRY(ua, ub, bA, bB)", "    if (rh == 0) {\n      if (a.n != 12345) { " + _SKIPLOOP + " }\n      while (it < layer_end) {\n        B2_ENTRY(ua, ub, bA, bB)")]
 _F["timing_nobranch"] = _F["timing"] + [("      if (live & (1 << (2 * (R)))) {                                                                         \\\n        _Pragma(\"unroll\") for (int q = 0; q < 2; ++q) {                                                      \\\n          acc[R][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(U[q].x, bf0[4 * q], acc[R][0], 0, 0, 0);          \\",
                                           "      {                                                                         \\\n        _Pragma(\"unroll\") for (int q = 0; q < 2; ++q) {                                                      \\\n          acc[R][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(U[q].x, bf0[4 * q], acc[R][0], 0, 0, 0);          \\")]
 _FSTAMP = "if (dbg_on) { const unsigned long long t_ = __builtin_readcyclecounter(); if (lane == 0 && cnt < 62) g_lpt_dbg[8192 + (blockIdx.x * 8 + w) * 64 + cnt] = t_; ++cnt; }"
@@ -274,6 +275,8 @@ _F["stamps_solo0"] = _F["stamps"] + _F["timing_solo0"][-1:]
 _F["timing_solo0_noX"] = _F["timing_solo0"] + [("        V[0] = ap_[0]; V[1] = ap_[1]; }\n#define B2_WAIT", "        if (a.n == 12345) { V[0] = ap_[0]; V[1] = ap_[1]; } }\n#define B2_WAIT")]
 _F["timing_solo0_nobranch"] = _F["timing_solo0"] + _F["timing_nobranch"][-1:]
 _F["timing_solo0_noW"] = _F["timing_solo0"] + [("      if (nxt < it_end) {                                                                                    \\\n        const float* src = wsrc + (size_t)tile_of(nxt) * BB_C * CH;", "      if (nxt < it_end && a.n == 12345) {                                                                                    \\\n        const float* src = wsrc + (size_t)tile_of(nxt) * BB_C * CH;")]
+_F["timing_noW"] = _F["timing"] + [("        const float* src = wsrc + (size_t)tile_of(nxt < it_end ? nxt : it) * BB_C * CH;                      \\\n", "        const float* src = wsrc + (size_t)(a.n == 12345 ? tile_of(nxt < it_end ? nxt : it) : 0) * BB_C * CH;                      \\\n")]
+_F["timing_noX"] = _F["timing"] + [("        V[0] = make_float4(t0_[0], t0_[1], t0_[2], t0_[3]); V[1] = make_float4(t1_[0], t1_[1], t1_[2], t1_[3]); }", "        if (a.n == 12345) { V[0] = make_float4(t0_[0], t0_[1], t0_[2], t0_[3]); V[1] = make_float4(t1_[0], t1_[1], t1_[2], t1_[3]); } }")]
 SETS = {"bb_f32_timing": BB_F32_TIMING, "bb_lpt_timing": BB_LPT_TIMING, "bb_lpt": BB_LPT, "gru_pc": GRU_PC, "gru_lp": GRU_LP, "tower_lp": TOWER_LP, "bb_lp": BB_LP, "k1": K1, "tower2": TOWER2}
 
 
@@ -291,7 +294,9 @@ def build_variant(setname, name, spec):
     p = os.path.join(work, spec["file"])
     s = open(p).read()
     for old, new in spec["variants"][name]:
-        assert old in s, (name, old)
+        if old not in s:                                  # the variant was written against an earlier revision of the kernel
+            shutil.rmtree(work, ignore_errors=True)
+            return name, False, "STALE: its patch no longer matches the source (the experiment's numbers are in profiles/; `check` lists these)"
         s = s.replace(old, new)
     open(p, "w").write(s)
     r = subprocess.run(["make", "-C", work, "INC=" + os.path.join(ROOT, "include")], capture_output=True, text=True)
@@ -307,6 +312,15 @@ def main():
     spec = SETS[setname]
     only = sys.argv[3:]
     names = [n for n in spec["variants"] if not only or n in only]
+    if cmd == "check":                                   # which variants still apply to the current sources
+        src = open(os.path.join(CSRC, spec["file"])).read()
+        for n in names:
+            t, ok = src, True
+            for old, new in spec["variants"][n]:
+                ok = ok and old in t
+                t = t.replace(old, new)
+            print(f"{n:32s} {'applies' if ok else 'STALE'}")
+        return
     if cmd == "build":
         with ThreadPoolExecutor(4) as ex:
             for name, ok, err in ex.map(lambda n: build_variant(setname, n, spec), names):

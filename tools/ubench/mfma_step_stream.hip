@@ -10,6 +10,8 @@
 //   5  stream 2 + the weight prefetch of the kernel every 7 steps (4 global_load_dwordx4 into the other W set, vmcnt(4))
 //   6  stream 5 where the second wave of each SIMD owns 6 row tiles (6 steps per chunk), like row group 1
 //   7  stream 5 without the liveness tests
+//   16    stream 14 + the kernel's entry head every 7 steps: the next weight tile requested from global memory into the idle
+//         register set (the MFMAs' B operands alternate between the two sets), a schedule word read from LDS
 //   12-15 the exact-fp32 backbone's step (14: the fragment address clamped per step as in the kernel, requests after the group;
 //         15: the same requests after the FIRST MFMA of the group): 16 v_mfma_f32_16x16x4_f32 (two accumulators x 8 k-steps) bare / with its wait,
 //         liveness test and two ds_read_b128 of the next row tile's fragment
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(512) void stream_kernel(float* out, unsigned long l
 }
 
 template <int STREAM>
-__global__ __launch_bounds__(512) void stream_f32_kernel(float* out, unsigned long long* cyc, int iters, int live) {
+__global__ __launch_bounds__(512) void stream_f32_kernel(float* out, unsigned long long* cyc, int iters, int live, const float* wts) {
   __shared__ __attribute__((aligned(16))) float lds[210 * 132];
   for (int e = threadIdx.x; e < 210 * 132; e += blockDim.x) lds[e] = 0.001f * (e & 255);
   __syncthreads();
@@ -213,6 +215,37 @@ __global__ __launch_bounds__(512) void stream_f32_kernel(float* out, unsigned lo
       STEPF(0, ub, XLC(2, ub)) STEPF(1, ua, XLC(3, ua)) STEPF(2, ub, XLC(4, ub)) STEPF(3, ua, XLC(5, ua))
       STEPF(4, ub, XLC(6, ub)) STEPF(5, ua, XLC(0, ua)) STEPF(6, ub, XLC(1, ub))
     }
+  } else if constexpr (STREAM == 16) {
+    __shared__ int sch[64];
+    if (threadIdx.x < 64) sch[threadIdx.x] = (threadIdx.x * 37 + 11) & 63;
+    __syncthreads();
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const float* wsrc = wts + ((wv & 3) * 32 + j) * 32 + 8 * g;
+    float4 bA[4], bB[4];
+    for (int q = 0; q < 4; ++q) { bA[q] = make_float4(bf0[0], bf0[1], bf0[2], bf0[3]); bB[q] = bA[q]; }
+    int en = 1, tile = 0;
+#define GROUP16W(R, U, BC)                                                                    \
+  _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                             \
+    const float w0_[4] = {BC[q].x, BC[q].y, BC[q].z, BC[q].w}, w1_[4] = {BC[2 + q].x, BC[2 + q].y, BC[2 + q].z, BC[2 + q].w}; \
+    MF4(U[q].x, w0_[0], acc[R][0]); MF4(U[q].x, w1_[0], acc[R][1]);                           \
+    MF4(U[q].y, w0_[1], acc[R][0]); MF4(U[q].y, w1_[1], acc[R][1]);                           \
+    MF4(U[q].z, w0_[2], acc[R][0]); MF4(U[q].z, w1_[2], acc[R][1]);                           \
+    MF4(U[q].w, w0_[3], acc[R][0]); MF4(U[q].w, w1_[3], acc[R][1]); }
+#define STEPW16(R, U, BC, LOADNEXT)                                                           \
+  FENCE __builtin_amdgcn_s_waitcnt(0xC07F | (2 << 8));                                        \
+  { int l_ = lv; asm volatile("" : "+s"(l_)); if (l_ & (1 << (R))) { GROUP16W(R, U, BC) } }   \
+  FENCE LOADNEXT FENCE
+#define ENTRY16(UA, UB, BC, BN)                                                               \
+  { const int nxt_ = en & 63; const int env_ = sch[nxt_];                                     \
+    { const float* src_ = wsrc + (size_t)tile * 4096; tile = tile + 9 < 700 ? tile + 9 : tile - 690;                \
+      BN[0] = *reinterpret_cast<const float4*>(src_); BN[1] = *reinterpret_cast<const float4*>(src_ + 4);           \
+      BN[2] = *reinterpret_cast<const float4*>(src_ + 512); BN[3] = *reinterpret_cast<const float4*>(src_ + 516); } \
+    STEPW16(0, UA, BC, XLC(2, UA)) STEPW16(1, UB, BC, XLC(3, UB))                             \
+    en = __builtin_amdgcn_readfirstlane(env_);                                                \
+    STEPW16(2, UA, BC, XLC(4, UA)) STEPW16(3, UB, BC, XLC(5, UB)) STEPW16(4, UA, BC, XLC(6, UA)) \
+    STEPW16(5, UB, BC, XLC(0, UB)) STEPW16(6, UA, BC, XLC(1, UA)) }
+    XLF(1, ub)
+    for (int it = 0; it < iters; ++it) { ENTRY16(ua, ub, bA, bB) ENTRY16(ub, ua, bB, bA) }
   } else if constexpr (STREAM == 15) {
     for (int it = 0; it < iters; ++it) {
       STEPF(0, ua, XLC(1, ub)) STEPF(1, ub, XLC(2, ua)) STEPF(2, ua, XLC(3, ub)) STEPF(3, ub, XLC(4, ua))
@@ -240,9 +273,10 @@ void run_f32(const char* name, int threads) {
   const int iters = 1000, nw = threads / 64;
   CK(hipMalloc(&out, 256 * 512 * 4)); CK(hipMalloc(&cyc, 256 * 8 * 8));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  stream_f32_kernel<STREAM><<<256, threads>>>(out, cyc, iters, 0x7f);
+  float* wts; CK(hipMalloc(&wts, 720 * 4096 * 4)); CK(hipMemset(wts, 0, 720 * 4096 * 4));
+  stream_f32_kernel<STREAM><<<256, threads>>>(out, cyc, iters, 0x7f, wts);
   CK(hipEventRecord(e0));
-  stream_f32_kernel<STREAM><<<256, threads>>>(out, cyc, iters, 0x7f);
+  stream_f32_kernel<STREAM><<<256, threads>>>(out, cyc, iters, 0x7f, wts);
   CK(hipEventRecord(e1));
   CK(hipDeviceSynchronize());
   float ms; CK(hipEventElapsedTime(&ms, e0, e1));
@@ -307,6 +341,7 @@ int main() {
     run_f32<13>("13 fp32: + wait, liveness test, 2 ds_read_b128", threads);
     run_f32<14>("14 fp32: 13 with the clamped address computed per step", threads);
     run_f32<15>("15 fp32: requests (clamped) after the first MFMA, no test", threads);
+    run_f32<16>("16 fp32: 14 + entry head (weight tile from global, schedule word)", threads);
   }
   return 0;
 }
