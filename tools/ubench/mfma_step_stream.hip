@@ -215,7 +215,7 @@ __global__ __launch_bounds__(512) void stream_f32_kernel(float* out, unsigned lo
       STEPF(0, ub, XLC(2, ub)) STEPF(1, ua, XLC(3, ua)) STEPF(2, ub, XLC(4, ub)) STEPF(3, ua, XLC(5, ua))
       STEPF(4, ub, XLC(6, ub)) STEPF(5, ua, XLC(0, ua)) STEPF(6, ub, XLC(1, ub))
     }
-  } else if constexpr (STREAM == 16) {
+  } else if constexpr (STREAM == 16 || STREAM == 17) {
     __shared__ int sch[64];
     if (threadIdx.x < 64) sch[threadIdx.x] = (threadIdx.x * 37 + 11) & 63;
     __syncthreads();
@@ -223,6 +223,8 @@ __global__ __launch_bounds__(512) void stream_f32_kernel(float* out, unsigned lo
     const float* wsrc = wts + ((wv & 3) * 32 + j) * 32 + 8 * g;
     float4 bA[4], bB[4];
     for (int q = 0; q < 4; ++q) { bA[q] = make_float4(bf0[0], bf0[1], bf0[2], bf0[3]); bB[q] = bA[q]; }
+    f4 dummy[28];
+    if constexpr (STREAM == 17) { for (int i = 0; i < 28; ++i) { dummy[i] = f4{bf0[i & 7], bf1[i & 7], (float)i, 1.0f}; asm volatile("" : "+v"(dummy[i])); } }
     int en = 1, tile = 0;
 #define GROUP16W(R, U, BC)                                                                    \
   _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                             \
@@ -246,6 +248,7 @@ __global__ __launch_bounds__(512) void stream_f32_kernel(float* out, unsigned lo
     STEPW16(5, UB, BC, XLC(0, UB)) STEPW16(6, UA, BC, XLC(1, UA)) }
     XLF(1, ub)
     for (int it = 0; it < iters; ++it) { ENTRY16(ua, ub, bA, bB) ENTRY16(ub, ua, bB, bA) }
+    if constexpr (STREAM == 17) { for (int i = 0; i < 28; ++i) { asm volatile("" : "+v"(dummy[i])); acc[i % 7][0] += dummy[i]; } }
   } else if constexpr (STREAM == 15) {
     for (int it = 0; it < iters; ++it) {
       STEPF(0, ua, XLC(1, ub)) STEPF(1, ub, XLC(2, ua)) STEPF(2, ua, XLC(3, ub)) STEPF(3, ub, XLC(4, ua))
@@ -342,6 +345,7 @@ int main() {
     run_f32<14>("14 fp32: 13 with the clamped address computed per step", threads);
     run_f32<15>("15 fp32: requests (clamped) after the first MFMA, no test", threads);
     run_f32<16>("16 fp32: 14 + entry head (weight tile from global, schedule word)", threads);
+    run_f32<17>("17 fp32: 16 with 112 more live VGPRs", threads);
   }
   return 0;
 }
