@@ -838,6 +838,22 @@ def main():
             line["roofline_tds_resample"] = tds_saturated(dev, L=L)
             line["roofline_value_net"] = value_net_roofline(model, emb, head, dev, B, L, M, S, tower_total_ms, tower_launches,
                                                             gru_total_ms, gru_launches)
+            # the same two kernels of the split-precision decodes (tower_lp_kernel, gru_lp_kernel) against the 16-bit MFMA peak, on the
+            # rows the fp32 decode of the same Philox stream executed (a split-precision decode selects differently on a handful
+            # of steps; its counts differ by well under 1 %): issued = useful x MFMA passes
+            ex = (line["roofline_value_net"] or {}).get("executed")
+            for mode, leg in (alt or {}).items():
+                if not ex or "own_kernels_ms_per_decode" not in leg:
+                    continue
+                passes = 3 if mode.endswith("x3") else 1
+                rv = {}
+                for key, kern, flops, ms in (("conv_tower", "tower_lp_kernel", ex["flops_per_tower_row"] * ex["tower_rows"], leg["own_kernels_ms_per_decode"]["conv_tower"]),
+                                             ("gru", "gru_lp_kernel", ex["flops_per_gru_row"] * ex["gru_rows"], leg["own_kernels_ms_per_decode"]["gru"])):
+                    tf = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+                    rv[key] = {"bound": "mfma", "kernel": kern, "achieved": round(tf, 2), "peak": LP_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(tf / LP_PEAK_TFLOPS, 5), "issued_frac": round(tf * passes / LP_PEAK_TFLOPS, 5),
+                               "executed_flops_per_decode": round(flops), "kernel_ms_per_decode": ms}
+                leg["roofline_value_net"] = rv
         if args.value_net != "convgru":
             line["config"]["workload"] += " [value net: Enformer-shaped trunk, 230M params — BASELINE configs[3] shape]"
             line["e2e_fp32_frac"] = None
