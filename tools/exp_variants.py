@@ -277,7 +277,31 @@ _F["timing_solo0_nobranch"] = _F["timing_solo0"] + _F["timing_nobranch"][-1:]
 _F["timing_solo0_noW"] = _F["timing_solo0"] + [("      if (nxt < it_end) {                                                                                    \\\n        const float* src = wsrc + (size_t)tile_of(nxt) * BB_C * CH;", "      if (nxt < it_end && a.n == 12345) {                                                                                    \\\n        const float* src = wsrc + (size_t)tile_of(nxt) * BB_C * CH;")]
 _F["timing_noW"] = _F["timing"] + [("        const float* src = wsrc + (size_t)tile_of(nxt < it_end ? nxt : it) * BB_C * CH;                      \\\n", "        const float* src = wsrc + (size_t)(a.n == 12345 ? tile_of(nxt < it_end ? nxt : it) : 0) * BB_C * CH;                      \\\n")]
 _F["timing_noX"] = _F["timing"] + [("        V[0] = make_float4(t0_[0], t0_[1], t0_[2], t0_[3]); V[1] = make_float4(t1_[0], t1_[1], t1_[2], t1_[3]); }", "        if (a.n == 12345) { V[0] = make_float4(t0_[0], t0_[1], t0_[2], t0_[3]); V[1] = make_float4(t1_[0], t1_[1], t1_[2], t1_[3]); } }")]
-SETS = {"bb_f32_timing": BB_F32_TIMING, "bb_lpt_timing": BB_LPT_TIMING, "bb_lpt": BB_LPT, "gru_pc": GRU_PC, "gru_lp": GRU_LP, "tower_lp": TOWER_LP, "bb_lp": BB_LP, "k1": K1, "tower2": TOWER2}
+# cycle stamps in tower_lp_kernel (window kernel): per wave [0] prologue (parent rows copied, one-hot, planes zeroed), [1] MFMA loops,
+# [2] the barrier after a layer's loop, [3] epilogues + "image complete" barriers, [4] output copy
+_TT = "{ const unsigned long long t_ = __builtin_readcyclecounter(); tacc[%d] += t_ - tprev; tprev = t_; }"
+TOWER_LP_TIMING = {
+    "file": "svdd_lp_tower.hip",
+    "bench": ["python", "tools/tower_lp_timing.py"],
+    "variants": {"timing": [
+        ("constexpr int TW_C = 64;", "__device__ unsigned long long g_tw_dbg[4096 * 8 * 8];\n__device__ unsigned long long g_tw_acc[8];\nconstexpr int TW_C = 64;"),
+        ("  int it = 0;\n  f32x4 acc[NL > 0 ? NL : 1][2];\n", "  int it = 0;\n  f32x4 acc[NL > 0 ? NL : 1][2];\n  unsigned long long tacc[4] = {0, 0, 0, 0}, tprev = __builtin_readcyclecounter();\n"),
+        ("    // every wave must be done reading the image before its owners overwrite it (the stem reads xs, not the image)\n    if (layer >= 0) __syncthreads();\n",
+         "    " + _TT % 1 + "\n    if (layer >= 0) __syncthreads();\n    " + _TT % 2 + "\n"),
+        ("    __syncthreads();                                             // the image is complete\n  }\n}",
+         "    __syncthreads();                                             // the image is complete\n    " + _TT % 3 + "\n  }\n  if ((threadIdx.x & 63) == 0) for (int k = 1; k < 4; ++k) g_tw_dbg[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + k] = tacc[k];\n}"),
+        ("  const int nlive = WIN ? (nt - c.rq + 3) >> 2 : (c.rq == 0 ? 4 : 3);    // owned live tiles rq + 4 r, r < nlive\n  __syncthreads();",
+         "  const int nlive = WIN ? (nt - c.rq + 3) >> 2 : (c.rq == 0 ? 4 : 3);    // owned live tiles rq + 4 r, r < nlive\n  __syncthreads();\n  const unsigned long long tp1 = __builtin_readcyclecounter();\n  if (lane == 0) g_tw_dbg[(blockIdx.x * 8 + w) * 8 + 0] = tp1 - tp0;"),
+        ("  const int tid = threadIdx.x, lane = tid & 63;\n  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);\n  const int L = a.L;\n\n  int cand = blockIdx.x;",
+         "  const unsigned long long tp0 = __builtin_readcyclecounter();\n  const int tid = threadIdx.x, lane = tid & 63;\n  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);\n  const int L = a.L;\n\n  int cand = blockIdx.x;"),
+        ("  // the last image IS the output: rows [hi 128 B | lo 128 B], 16 bytes per thread\n  if (WIN) {",
+         "  const unsigned long long tp2 = __builtin_readcyclecounter();\n  // the last image IS the output: rows [hi 128 B | lo 128 B], 16 bytes per thread\n  if (WIN) {"),
+        ("        outc[(row0 + row) * ROW16 + q] = *reinterpret_cast<const uint4*>(plane + (q >> 3) * TPLANE_B + row * TLSB + 16 * (q & 7));\n    }\n  }\n}",
+         "        outc[(row0 + row) * ROW16 + q] = *reinterpret_cast<const uint4*>(plane + (q >> 3) * TPLANE_B + row * TLSB + 16 * (q & 7));\n    }\n  }\n  if (lane == 0) { const unsigned long long te = __builtin_readcyclecounter(); g_tw_dbg[(blockIdx.x * 8 + w) * 8 + 4] = te - tp2; g_tw_dbg[(blockIdx.x * 8 + w) * 8 + 5] = te - tp0; g_tw_dbg[(blockIdx.x * 8 + w) * 8 + 6] = 1; }\n}"),
+        ("}  // namespace\n", "}  // namespace\n\nextern \"C\" int svdd_internal_tw_dbg(void* dst, int reset) { if (reset) return (int)hipMemset((void*)((char*)0 + 0), 0, 0) * 0 + (int)hipMemcpyToSymbol(HIP_SYMBOL(g_tw_dbg), dst, sizeof(g_tw_dbg)); return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_tw_dbg), sizeof(g_tw_dbg)); }\n"),
+    ]},
+}
+SETS = {"tower_lp_timing": TOWER_LP_TIMING, "bb_f32_timing": BB_F32_TIMING, "bb_lpt_timing": BB_LPT_TIMING, "bb_lpt": BB_LPT, "gru_pc": GRU_PC, "gru_lp": GRU_LP, "tower_lp": TOWER_LP, "bb_lp": BB_LP, "k1": K1, "tower2": TOWER2}
 
 
 def build_variant(setname, name, spec):
