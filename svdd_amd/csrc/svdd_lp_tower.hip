@@ -10,9 +10,12 @@ namespace {
 // the A operand directly. What differs from the fp32 kernels (measured: profiles/r02_exp_ablations.txt, tower_lp):
 //   * the input is the TOKEN row (u8), not the fp32 one-hot: the one-hot is built in LDS (exact in 16 bits, so the stem
 //     needs only A * Bhi + A * Blo); one MFMA covers a whole (tap, 32-channel chunk);
-//   * wave w owns 32 output channels (column pair w & 1; a lane's two channels are ADJACENT, 32 cp + 2 j, + 1, so both
-//     go to LDS in one packed store) of the row tiles rq + 4 r, rq = w >> 1: an A fragment feeds two column tiles, which
-//     halves the LDS read traffic — the largest single cost once the MFMAs are 16x cheaper;
+//   * wave w owns 32 output channels (column pair w & 1) of the row tiles rq + 4 r, rq = w >> 1: an activation fragment feeds
+//     two column tiles, which halves the LDS read traffic — the largest single cost once the MFMAs are 16x cheaper. The
+//     accumulators are TRANSPOSED (round 4d: weights as the A operand, activations as B, like backbone_lp_t_kernel): with the
+//     host's weight order (tile row m of column tile ct = channel 32 cp + 2 m + ct) a lane holds eight ADJACENT channels of
+//     one position per row tile, and a layer's epilogue is one 16-byte LDS load and store per plane and tile instead of four
+//     4-byte ones per row (same bits; windows 364 -> 338 us in f16x3, profiles/r04_bb_lpt_phase_timing.txt section 9);
 //   * the number of live row tiles of a wave (4 / 3 for whole sequences, 0..4 for a window) is a TEMPLATE parameter of
 //     the layer loop, chosen once per wave: straight-line code, no per-tile predicates (the first version, with runtime
 //     predicates, ran the 66 %-live windows SLOWER than whole sequences);
@@ -58,7 +61,6 @@ struct TowerCtx {
 template <typename T, int NP, bool CLAMP, int NL>
 __device__ __forceinline__ void tower_layers(const TowerCtx<T>& c) {
   typedef typename Lp<T>::V8 V8;
-  typedef typename Lp<T>::V2 V2;
   typedef T T4 __attribute__((ext_vector_type(4)));
   constexpr int NPARTS = NP == 3 ? 2 : 1;
   constexpr int TILE_V8 = 2 * 64 * 2 * NPARTS;
@@ -67,7 +69,6 @@ __device__ __forceinline__ void tower_layers(const TowerCtx<T>& c) {
   const int abase = arow0 * TLSB + 16 * g;                       // byte offset of (row arow0, channel 8 g)
   const int a_lo = abase - (arow0 + 1) * TLSB;                   // row -1
   const int a_hi = abase + (TW_ROWS - arow0) * TLSB;             // row TW_ROWS
-  const int c0 = 32 * c.cp + 2 * j;                              // this lane's output channels c0, c0 + 1
   const int nit = 2 + 10 * c.nlayers;
   V8 bn[2 * NPARTS];
 #pragma unroll
@@ -109,11 +110,11 @@ __device__ __forceinline__ void tower_layers(const TowerCtx<T>& c) {
         }
 #pragma unroll
         for (int r = 0; r < NL; ++r) {                           // the one-hot has no lo part
-          acc[r][0] = Lp<T>::mfma(ah[r], bc[0], acc[r][0]);
-          acc[r][1] = Lp<T>::mfma(ah[r], bc[NPARTS], acc[r][1]);
+          acc[r][0] = Lp<T>::mfma(bc[0], ah[r], acc[r][0]);
+          acc[r][1] = Lp<T>::mfma(bc[NPARTS], ah[r], acc[r][1]);
           if constexpr (NP == 3) {
-            acc[r][0] = Lp<T>::mfma(ah[r], bc[1], acc[r][0]);
-            acc[r][1] = Lp<T>::mfma(ah[r], bc[NPARTS + 1], acc[r][1]);
+            acc[r][0] = Lp<T>::mfma(bc[1], ah[r], acc[r][0]);
+            acc[r][1] = Lp<T>::mfma(bc[NPARTS + 1], ah[r], acc[r][1]);
           }
         }
       } else {
@@ -129,13 +130,13 @@ __device__ __forceinline__ void tower_layers(const TowerCtx<T>& c) {
         }
 #pragma unroll
         for (int r = 0; r < NL; ++r) {
-          acc[r][0] = Lp<T>::mfma(ah[r], bc[0], acc[r][0]);
-          acc[r][1] = Lp<T>::mfma(ah[r], bc[NPARTS], acc[r][1]);
+          acc[r][0] = Lp<T>::mfma(bc[0], ah[r], acc[r][0]);
+          acc[r][1] = Lp<T>::mfma(bc[NPARTS], ah[r], acc[r][1]);
           if constexpr (NP == 3) {
-            acc[r][0] = Lp<T>::mfma(ah[r], bc[1], acc[r][0]);
-            acc[r][1] = Lp<T>::mfma(ah[r], bc[NPARTS + 1], acc[r][1]);
-            acc[r][0] = Lp<T>::mfma(al[r], bc[0], acc[r][0]);
-            acc[r][1] = Lp<T>::mfma(al[r], bc[NPARTS], acc[r][1]);
+            acc[r][0] = Lp<T>::mfma(bc[1], ah[r], acc[r][0]);
+            acc[r][1] = Lp<T>::mfma(bc[NPARTS + 1], ah[r], acc[r][1]);
+            acc[r][0] = Lp<T>::mfma(bc[0], al[r], acc[r][0]);
+            acc[r][1] = Lp<T>::mfma(bc[NPARTS], al[r], acc[r][1]);
           }
         }
       }
@@ -143,27 +144,40 @@ __device__ __forceinline__ void tower_layers(const TowerCtx<T>& c) {
     // every wave must be done reading the image before its owners overwrite it (the stem reads xs, not the image)
     if (layer >= 0) __syncthreads();
     const bool rs = layer >= 0 && ((c.residual_mask >> layer) & 1);
-    const float bl0 = c.bias[(layer + 1) * TW_C + c0], bl1 = c.bias[(layer + 1) * TW_C + c0 + 1];
+    // TRANSPOSED accumulators (round 4d; A = weight fragment, B = activation fragment — the same registers either way, the same
+    // products in the same order, as in backbone_lp_t_kernel): lane (j, g) register e of column tile ct holds channel
+    // cb + 2 e + ct, cb = 32 cp + 8 g, of ONE position per row tile, so a layer's epilogue reads the residual and writes the
+    // new image as one 16-byte LDS access per plane and tile (position-major it was four 4-byte loads and stores each).
+    const int cb = 32 * c.cp + 8 * g;
+    const f32x4 b_lo = *reinterpret_cast<const f32x4*>(c.bias + (layer + 1) * TW_C + cb);
+    const f32x4 b_hi = *reinterpret_cast<const f32x4*>(c.bias + (layer + 1) * TW_C + cb + 4);
+    const float bl[8] = {b_lo[0], b_lo[1], b_lo[2], b_lo[3], b_hi[0], b_hi[1], b_hi[2], b_hi[3]};
     const float inv = c.inv[layer + 1];
 #pragma unroll
-    for (int r = 0; r < NL; ++r)
+    for (int r = 0; r < NL; ++r) {
+      const int row = 16 * (c.rq + 4 * r) + j;
+      char* dst = c.plane + row * TLSB + 2 * cb;
+      float res[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+      if (rs) {                                                  // residual = the layer's own input: hi + lo
+        const V8 ph = *reinterpret_cast<const V8*>(dst);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {                              // C/D layout: reg e -> row 4 g + e, column j
-        const int row = 16 * (c.rq + 4 * r) + 4 * g + e;
-        char* dst = c.plane + row * TLSB + 2 * c0;
-        float r0 = 0.0f, r1 = 0.0f;
-        if (rs) {                                                // residual = the layer's own input: hi + lo
-          const V2 ph = *reinterpret_cast<const V2*>(dst);
-          r0 = (float)ph[0]; r1 = (float)ph[1];
-          if constexpr (NP == 3) { const V2 pl = *reinterpret_cast<const V2*>(dst + TPLANE_B); r0 += (float)pl[0]; r1 += (float)pl[1]; }
+        for (int k = 0; k < 8; ++k) res[k] = (float)ph[k];
+        if constexpr (NP == 3) {
+          const V8 pl = *reinterpret_cast<const V8*>(dst + TPLANE_B);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) res[k] += (float)pl[k];
         }
-        const float v0 = row < c.tile_rows ? fmaxf(acc[r][0][e] * inv + bl0 + r0, 0.0f) : 0.0f;
-        const float v1 = row < c.tile_rows ? fmaxf(acc[r][1][e] * inv + bl1 + r1, 0.0f) : 0.0f;
-        V2 hi, lo;
-        split2<T>(v0, v1, hi, lo);
-        *reinterpret_cast<V2*>(dst) = hi;
-        if constexpr (NP == 3) *reinterpret_cast<V2*>(dst + TPLANE_B) = lo;
       }
+      V8 hi, lo;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {                              // channel cb + k = (ct, e) = (k & 1, k >> 1)
+        const float v = row < c.tile_rows ? fmaxf(acc[r][k & 1][k >> 1] * inv + bl[k] + res[k], 0.0f) : 0.0f;
+        const T h = (T)v;
+        hi[k] = h; lo[k] = (T)(v - (float)h);
+      }
+      *reinterpret_cast<V8*>(dst) = hi;
+      if constexpr (NP == 3) *reinterpret_cast<V8*>(dst + TPLANE_B) = lo;
+    }
     __syncthreads();                                             // the image is complete
   }
 }
