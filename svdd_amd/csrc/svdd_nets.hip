@@ -1146,7 +1146,7 @@ __device__ __forceinline__ void tower2_layers(const TowerCtx2& c) {
   const int a_lo = abase - (arow0 + 1) * TW_AP * 4;              // row -1
   const int a_hi = abase + (TW_ROWS - arow0) * TW_AP * 4;        // row TW_ROWS
   const char* actb = reinterpret_cast<const char*>(c.act);
-  const int ch0 = 16 * CT * c.cp + j;                            // this lane's output channels: ch0 + 16 ct
+  const int cb = 16 * CT * c.cp + 4 * g;                         // this lane's OUTPUT channels: cb + 16 ct + e (transposed tiles)
   const int nit = 2 + 10 * c.nlayers;
   float4 bn[2 * CT];                                             // [ct][half]: W[ch0 + 16 ct][8 g .. 8 g + 8] of the next tile
 #pragma unroll
@@ -1158,11 +1158,15 @@ __device__ __forceinline__ void tower2_layers(const TowerCtx2& c) {
   f32x4 acc[NA][CT];
 
   for (int layer = -1; layer < c.nlayers; ++layer) {
+    // TRANSPOSED accumulators (round 4d, as in the 16-bit twin): the weight fragment is the A operand, the activation fragment
+    // the B operand — the same registers either way and the same products in the same order — so lane (j, g) register e of
+    // column tile ct holds channel cb + 16 ct + e, cb = 16 CT cp + 4 g, of ONE position (row 16 (rq + RS r) + j): the
+    // epilogue is one 16-byte LDS load and store per (row tile, column tile) instead of four 4-byte ones
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
-      const float bl = c.bias[(layer + 1) * TW_C + ch0 + 16 * ct];
+      const f32x4 bl = *reinterpret_cast<const f32x4*>(c.bias + (layer + 1) * TW_C + cb + 16 * ct);
 #pragma unroll
-      for (int r = 0; r < NL; ++r) acc[r][ct] = f32x4{bl, bl, bl, bl};
+      for (int r = 0; r < NL; ++r) acc[r][ct] = bl;
     }
     const int niter = layer < 0 ? 2 : 10;
     for (int ci = 0; ci < niter; ++ci, ++it) {
@@ -1214,23 +1218,22 @@ __device__ __forceinline__ void tower2_layers(const TowerCtx2& c) {
           for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct)
-              acc[r][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s4], b[ct][4 * q + s4], acc[r][ct], 0, 0, 0);
+              acc[r][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[ct][4 * q + s4], av[s4], acc[r][ct], 0, 0, 0);
         }
     }
     if (layer >= 0) __syncthreads();                     // every wave is done reading the image (the stem reads xs)
     const bool res = layer >= 0 && ((c.residual_mask >> layer) & 1);
 #pragma unroll
-    for (int r = 0; r < NL; ++r)
+    for (int r = 0; r < NL; ++r) {
+      const int row = 16 * (c.rq + RS * r) + j;          // C/D layout, transposed: reg e -> channel cb + 16 ct + e at position j
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {                      // C/D layout: reg e -> row 4 g + e, column j
-        const int row = 16 * (c.rq + RS * r) + 4 * g + e;
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-          const int o = row * TW_AP + ch0 + 16 * ct;
-          const float v = acc[r][ct][e] + (res ? c.act[o] : 0.0f);
-          c.act[o] = row < c.tile_rows ? fmaxf(v, 0.0f) : 0.0f;
-        }
+      for (int ct = 0; ct < CT; ++ct) {
+        f32x4* dst = reinterpret_cast<f32x4*>(c.act + row * TW_AP + cb + 16 * ct);
+        const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+        const f32x4 v = acc[r][ct] + (res ? *dst : z);
+        *dst = row < c.tile_rows ? __builtin_elementwise_max(v, z) : z;
       }
+    }
     __syncthreads();                                     // the image is complete
   }
 }
