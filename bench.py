@@ -32,7 +32,11 @@ Prints ONE JSON line (rank 0). Extra objects:
   alt_precision the SAME workload with the nets' matrix products on the 16-bit matrix cores (Diffusion.precision,
                 csrc/svdd_lp_*.hip), one object per mode, each with its own timed decodes and the roofline of its
                 dominant kernel against the dense bf16/f16 MFMA peak. Never the headline: `value` / `dtype` above are
-                the exact-fp32 path. Token agreement with the fp32 decode: profiles/r02_precision_agreement.json.
+                the exact-fp32 path. Token agreement with the fp32 decode and the error of every mode against an fp64 forward:
+                profiles/r05_precision_agreement.json (tools/precision_agreement.py), summarised in `precision_evidence`.
+  config3_pm / config5_*  BASELINE.json configs[2] (SVDD-PM, L = 50) and configs[4] (TDS shard + one 2048 population, DPS) as extra
+                objects: whole-decode wall clock + the roofline of the dominant kernel on EXECUTED work.
+  roofline.also every other kernel fraction of the run as a compact list (the driver's record keeps `roofline` in full).
   per_rank      (N > 1) every rank's decode time and the time of the one all-gather, so that a scaling run is diagnosable.
 """
 import argparse
@@ -55,6 +59,11 @@ FP32_PEAK_TFLOPS = 157.3
 LP_PEAK_TFLOPS = 2500.0    # dense bf16 / f16 MFMA peak (MI355X_MICROARCH.md; the 5 PF headline figure is 2:1 sparse)
 
 
+def _digest(tokens):
+    import hashlib
+    return hashlib.sha1(tokens.to(torch.uint8).cpu().numpy().tobytes()).hexdigest()[:16]
+
+
 def host_cpu():
     """(model name, logical cores) of the box the CPU baseline ran on (stated next to every CPU number)."""
     model = "unknown"
@@ -67,6 +76,206 @@ def host_cpu():
     except OSError:
         pass
     return model, os.cpu_count()
+
+
+def backbone_flops(n, L, H=128):
+    """Useful FLOPs of the dilated-CNN backbone forward on n sequences of length L (models/dnaconv.py:176-210): the 20 dilated
+    9-tap 128->128 convs without the multiplications with zero padding, + the 9-tap first conv on the one-hot + the two 1x1 convs."""
+    conv = sum(2.0 * n * H * H * sum(max(0, L - abs(t - 4) * d) for t in range(9)) for d in (1, 1, 4, 16, 64) for _ in range(4))
+    return conv + 2.0 * n * L * (5 * H * 9 + H * H + H * 5)
+
+
+PROFILE_SLOTS = {"propose": 0, "select": 1, "conv1d": 2, "gru": 3, "epilogue_ln": 4, "conv_tower": 5, "backbone_cnn": 6,
+                 "value_tail": 7, "tds_resample": 8}
+
+
+def timed_decodes(run, steps, check):
+    """One warm-up decode, then `steps` timed ones (wall clock, device synchronised on both sides); the LAST one with the
+    per-dispatch HIP events on. -> (seconds per decode, {kernel: (total ms, launches)} of the last decode)."""
+    from svdd_amd import _lib
+    run()
+    torch.cuda.synchronize()
+    for k in PROFILE_SLOTS.values():
+        _lib.profile_collect(k)
+    t0 = time.perf_counter()
+    for k in range(steps):
+        if k == steps - 1:
+            _lib.profile_enable(True)
+        out = run()
+    torch.cuda.synchronize()
+    el = (time.perf_counter() - t0) / steps
+    _lib.profile_enable(False)
+    check(out)
+    return el, {name: _lib.profile_collect(k) for name, k in PROFILE_SLOTS.items()}
+
+
+def _mfma_roofline(kernel, flops, ms, launches, peak=FP32_PEAK_TFLOPS, passes=1, **extra):
+    tf = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    r = {"bound": "mfma", "kernel": kernel, "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 5),
+         "executed_flops_per_decode": round(flops), "kernel_ms_per_decode": round(ms, 3), "launches": launches, "traffic": None}
+    if passes > 1:
+        r["mfma_passes"], r["issued_frac"] = passes, round(tf * passes / peak, 5)
+    r.update(extra)
+    return r
+
+
+def config3_leg(dev, steps=1, alt="f16x3", B=256, L=50, M=10, S=128):
+    """BASELINE.json configs[2]: 5'UTR RNA SVDD-PM (controlled_sample_tweedie, diffusion_gosai.py:1105-1145, 1373-1460), batch 256,
+    L = 50, M = 10, ConvGRU reward, 128 steps, fp32, Philox. `value` = wall clock of whole decodes. `roofline`: its dominant
+    kernel, backbone_kernel on the LIVE candidates (exact work-skipping: a candidate that unmasked nothing is its parent), useful
+    FLOPs of the sequences actually forwarded — counted on the device in one extra untimed decode of the same Philox stream
+    (Diffusion.skip_stats) — over the kernel's summed HIP-event time in the timed decode, against the fp32-MFMA peak."""
+    try:
+        from svdd_amd import synthetic
+        model, _, _, rew = synthetic.build("rna", dev)
+        model.rng_mode, model.philox_seed = "philox", 0
+        run = lambda: model.controlled_sample_tweedie(rew, num_steps=S, eval_sp_size=B, sample_M=M, options="True")   # noqa: E731
+
+        def check(out):
+            assert out.shape == (B, L) and int(out.max()) <= 3
+        el, prof = timed_decodes(run, steps, check)
+        model.skip_stats = {}
+        run()
+        torch.cuda.synchronize()
+        st, model.skip_stats = model.skip_stats, None
+        seqs_fwd = st["live_candidates"] + B                      # + the one forward on the all-MASK parents
+        bb_ms, bb_n = prof["backbone_cnn"]
+        res = {"workload": f"5'UTR RNA SVDD-PM (tweedie), batch={B}, L={L}, M={M}, {S} steps, ConvGRU reward (BASELINE.json configs[2])",
+               "value": round(B / el, 3), "unit": "sequences/s", "n_gpus": 1, "steps": steps, "ms_per_step": round(el * 1e3, 3),
+               "dtype": "f32", "data": "synthetic (random-init nets, all-MASK prior)",
+               "roofline": _mfma_roofline("backbone_kernel (svdd_backbone_cnn_f32 on the compacted live candidates; several L=50 sequences per tile)",
+                                          backbone_flops(seqs_fwd, L), bb_ms, bb_n,
+                                          sequences_forwarded=int(seqs_fwd), nominal_sequences=B * (M + 1) * S + B),
+               "executed": {"live_candidates": st["live_candidates"], "candidates": st["candidates"],
+                            "changed_row_steps": st["changed_row_steps"], "row_steps": st["row_steps"]},
+               "own_kernels_ms_per_decode": {k: round(v[0], 3) for k, v in prof.items() if v[1]}}
+        if alt:
+            model.precision = alt
+            el2, prof2 = timed_decodes(run, 1, check)
+            passes = 3 if alt.endswith("x3") else 1
+            res["alt_precision"] = {alt: {"value": round(B / el2, 3), "unit": "sequences/s", "ms_per_step": round(el2 * 1e3, 3), "steps": 1,
+                                          "roofline": _mfma_roofline("backbone_lp kernel on the compacted live candidates",
+                                                                     backbone_flops(seqs_fwd, L), prof2["backbone_cnn"][0], prof2["backbone_cnn"][1],
+                                                                     peak=LP_PEAK_TFLOPS, passes=passes)}}
+            model.precision = "f32"
+        del model, rew
+        torch.cuda.empty_cache()
+        return res
+    except Exception as e:                                     # noqa: BLE001
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
+def config5_leg(dev, steps=1, alt="f16x3", B=256, L=200, S=128, population=2048, dps_steps=1):
+    """BASELINE.json configs[4]: the TDS / DPS baselines at L = 200 (diffusion_gosai.py:938-978, 1230-1284; 980-1019, 1286-1330).
+      tds_shard       one rank's 256-particle population of the 2048 (per-shard populations), alpha 0.5
+      tds_population  ONE 2048-particle population on one GPU (the exact algorithm at the config's batch)
+      dps             gradient guidance at B = 256, guidance scale 10 (forward + backward through backbone and reward net per step)
+    Each with wall-clock `value` and the roofline of its dominant kernel on executed work: TDS = backbone_kernel (with the exact
+    reuse of _tds_step one forward per step); DPS = the dilated-conv kernel of the differentiable pass (both directions)."""
+    out = {}
+    try:
+        from svdd_amd import synthetic
+        model, _, _, rew = synthetic.build("dna", dev)
+        model.rng_mode, model.philox_seed = "philox", 0
+
+        def tds(b, name, n_steps, alt_mode):
+            def run():
+                np.random.seed(0)
+                return model.controlled_sample_TDS(rew, 0.5, num_steps=S, eval_sp_size=b)
+
+            def check(o):
+                assert o.shape == (b, L) and int(o.max()) <= 3
+            el, prof = timed_decodes(run, n_steps, check)
+            bb_ms, bb_n = prof["backbone_cnn"]
+            leg = {"workload": f"DNA enhancer TDS / SMC, {b} particles, L={L}, {S} steps, alpha=0.5, ConvGRU reward (BASELINE.json configs[4])",
+                   "value": round(b / el, 3), "unit": "sequences/s", "n_gpus": 1, "steps": n_steps, "ms_per_step": round(el * 1e3, 3),
+                   "dtype": "f32",
+                   "roofline": _mfma_roofline(f"backbone_kernel (svdd_backbone_cnn_f32, {b} sequences per launch)",
+                                              backbone_flops(b, L) * bb_n, bb_ms, bb_n, avg_launch_us=round(bb_ms / max(bb_n, 1) * 1e3, 2)),
+                   "own_kernels_ms_per_decode": {k: round(v[0], 3) for k, v in prof.items() if v[1]}}
+            if alt_mode:
+                model.precision = alt_mode
+                el2, _ = timed_decodes(run, 1, check)
+                leg["alt_precision"] = {alt_mode: {"value": round(b / el2, 3), "unit": "sequences/s", "ms_per_step": round(el2 * 1e3, 3), "steps": 1}}
+                model.precision = "f32"
+            out[name] = leg
+        tds(B, "tds_shard", steps, alt)
+        tds(population, "tds_population", 1, alt)
+
+        # DPS: not under no_grad (it back-propagates); Philox for the categorical draw
+        def run_dps():
+            return model.controlled_sample_DPS(rew, 10.0, num_steps=S, eval_sp_size=B)
+
+        def check(o):
+            assert o.shape == (B, L) and int(o.max()) <= 3
+        el, prof = timed_decodes(run_dps, dps_steps, check)
+        H = 128
+        conv_ms, conv_n = prof["conv1d"]
+        conv_flops = backbone_flops(B, L) - 2.0 * B * L * (5 * H * 9 + H * H + H * 5)          # the 20 dilated convs of one pass
+        out["dps"] = {"workload": f"DNA enhancer DPS (gradient guidance), batch={B}, L={L}, {S} steps, guidance scale 10, ConvGRU reward (BASELINE.json configs[4])",
+                      "value": round(B / el, 3), "unit": "sequences/s", "n_gpus": 1, "steps": dps_steps, "ms_per_step": round(el * 1e3, 3),
+                      "dtype": "f32", "own_kernels_ms_per_decode": {k: round(v[0], 3) for k, v in prof.items() if v[1]}}
+        if conv_n:
+            out["dps"]["roofline"] = _mfma_roofline(
+                "conv1d_cl_static_kernel<128,128,9,dil,200> (the 20 dilated convs of the differentiable backbone pass, forward and backward-data)",
+                conv_flops / 20.0 * conv_n, conv_ms, conv_n, avg_launch_us=round(conv_ms / conv_n * 1e3, 2))
+        dps_extra = globals().get("dps_kernel_rooflines")
+        if dps_extra is not None:
+            out["dps"].update(dps_extra(prof, B, L, S))
+        del model, rew
+        torch.cuda.empty_cache()
+    except Exception as e:                                     # noqa: BLE001
+        out["error"] = f"{type(e).__name__}: {e}"
+    return out
+
+
+def roofline_also(line):
+    """Every other kernel fraction of this run in one compact list INSIDE `roofline` (the driver's record keeps `roofline` in full
+    and only the names of the other objects): {kernel, where, bound, frac[, issued_frac], us | ms_per_decode}. Each entry is
+    recomputable from the object of the line it names (`from`)."""
+    also = []
+
+    def add(src, kernel, where, r, ms_key="kernel_ms_per_decode"):
+        if not isinstance(r, dict) or "frac" not in r:
+            return
+        e = {"kernel": kernel, "where": where, "bound": r.get("bound"), "frac": r["frac"], "from": src}
+        if "issued_frac" in r:
+            e["issued_frac"] = r["issued_frac"]
+        if r.get(ms_key) is not None:
+            e["ms_per_decode"] = r[ms_key]
+        elif r.get("avg_launch_us") is not None:
+            e["avg_launch_us"] = r["avg_launch_us"]
+        elif r.get("gemm_ms_per_forward") is not None:
+            e["ms_per_forward"] = r["gemm_ms_per_forward"]
+        also.append(e)
+    rv = line.get("roofline_value_net") or {}
+    for key, name in (("conv_tower", "conv_tower2_kernel"), ("gru", "gru_pc_kernel")):
+        if key in rv:
+            add(f"roofline_value_net.{key}.decode", name, "C2 decode, executed rows", rv[key].get("decode"))
+            add(f"roofline_value_net.{key}.dense", name, "2560 whole sequences", rv[key].get("dense"))
+    add("roofline_sampler", "propose_kernel (K1)", "C2 decode (launch-bound size)", line.get("roofline_sampler"))
+    add("roofline_sampler_saturated", "propose_kernel (K1)", "saturated, B=16384", line.get("roofline_sampler_saturated"))
+    for i, r in enumerate(line.get("roofline_select_saturated") or []):
+        add(f"roofline_select_saturated[{i}]", "select_rows_kernel (K2)", r.get("workload"), r)
+    for i, r in enumerate(line.get("roofline_tds_resample") or []):
+        add(f"roofline_tds_resample[{i}]", "tds_cdf + tds_gather (K4)", r.get("workload"), r)
+    for mode, leg in (line.get("alt_precision") or {}).items():
+        add(f"alt_precision.{mode}.roofline", "backbone_lp_t_kernel", f"C2 decode, {mode}", leg.get("roofline"))
+        for key, name in (("conv_tower", "tower_lp_kernel"), ("gru", "gru_lp_kernel")):
+            add(f"alt_precision.{mode}.roofline_value_net.{key}", name, f"C2 decode, {mode}", (leg.get("roofline_value_net") or {}).get(key))
+    c4 = line.get("config4_enformer") or {}
+    add("config4_enformer.roofline_trunk_gemm", "trunk_gemm256_kernel", "C4 shard, bf16x3", c4.get("roofline_trunk_gemm"))
+    add("config4_enformer.f32.roofline_trunk_gemm", "trunk_gemm256_kernel", "C4 shard, f32", (c4.get("f32") or {}).get("roofline_trunk_gemm"))
+    c3 = line.get("config3_pm") or {}
+    add("config3_pm.roofline", "backbone_kernel", "C3 SVDD-PM decode, live candidates", c3.get("roofline"))
+    for mode, leg in (c3.get("alt_precision") or {}).items():
+        add(f"config3_pm.alt_precision.{mode}.roofline", "backbone_lp kernel", f"C3 SVDD-PM decode, {mode}", leg.get("roofline"))
+    for name in ("tds_shard", "tds_population", "dps"):
+        leg = line.get("config5_" + name) or {}
+        add(f"config5_{name}.roofline", (leg.get("roofline") or {}).get("kernel", "").split(" ")[0], f"C5 {name}", leg.get("roofline"))
+        for k, r in (leg.get("rooflines") or {}).items():
+            add(f"config5_{name}.rooflines.{k}", r.get("kernel", k).split(" ")[0], f"C5 {name}", r)
+    return also
 
 
 def sampler_saturated(dev, L=200, M=10, B=16384, masked_frac=0.5, iters=100):
@@ -271,18 +480,38 @@ def config4_f32(model, emb, head, dev, steps, B, L, M, S):
         return {"error": f"{type(e).__name__}: {e}"}
 
 
-def cpu_baseline(B, L, M, S, sample_steps, seed=44, threads=16, states=None, passes=3):
+def cpu_thread_sweep(model, B, L, candidates=(8, 16, 32, 64, 128)):
+    """Seconds per backbone forward at full batch for each torch thread count that fits this host (one warm-up + one timed forward
+    each): the CPU baseline then runs at the fastest. Recorded inside `cpu_baseline` so that `cores` is justified in the same record
+    (on the GPU box's 2 x EPYC 9575F more threads than 16 are slower: the 3.3 M-parameter convs are small per core)."""
+    ncpu = os.cpu_count() or 1
+    x = torch.full((B, L), 4, dtype=torch.int64)
+    sweep = {}
+    for t in sorted({min(c, ncpu) for c in candidates}):
+        torch.set_num_threads(t)
+        with torch.no_grad():
+            model.backbone(x, torch.zeros(B))
+            t0 = time.perf_counter()
+            model.backbone(x, torch.zeros(B))
+        sweep[t] = round(time.perf_counter() - t0, 4)
+    return sweep
+
+
+def cpu_baseline(B, L, M, S, sample_steps, seed=44, threads=None, states=None, passes=3):
     """Oracle (CPU port of the reference path: M value-net calls of batch B per step, like
     diffusion_gosai.py:1207-1209) on `sample_steps` diffusion steps of the same workload. `states`: the x_t of every
     step of a GPU decode of this very workload — the sampled steps then run on the real states of the trajectory
     (real masked fractions, real tokens) rather than on synthetic ones.
-    16 torch threads: the fastest setting on the GPU box's host (2 x EPYC 9575F; 8/16/32/64/128 threads
-    measured 0.63/0.36/0.53/0.73/1.68 s per backbone forward, tools/exp_cpu_threads.py)."""
+    threads = None: the fastest torch thread count of a sweep on this host (cpu_thread_sweep), recorded as `thread_sweep`."""
     from oracle import svdd_oracle as orc
     from svdd_amd import synthetic
+    model, emb, head, _ = synthetic.build("dna" if L == 200 else "rna", "cpu", seed=seed)
+    sweep = None
+    if threads is None:
+        sweep = cpu_thread_sweep(model, B, L)
+        threads = min(sweep, key=sweep.get)
     threads = max(1, min(threads, os.cpu_count() or 1))
     torch.set_num_threads(threads)
-    model, emb, head, _ = synthetic.build("dna" if L == 200 else "rna", "cpu", seed=seed)
     sched = model._schedule(S, 1e-5)[0]
     bb = lambda x: model.backbone(x, torch.zeros(x.shape[0]))                               # noqa: E731
     val = lambda oh: head(emb(oh)).reshape(-1)                                              # noqa: E731
@@ -319,6 +548,8 @@ def cpu_baseline(B, L, M, S, sample_steps, seed=44, threads=16, states=None, pas
     return {
         "value": round(B / per_decode, 4), "unit": "sequences/s", "cores": threads,
         "cpu_model": cpu_model, "cores_total": cpu_total,
+        "thread_sweep": None if sweep is None else {"s_per_backbone_forward_by_threads": sweep, "chosen": threads,
+                                                    "note": "torch.set_num_threads(t), one backbone forward at full batch after a warm-up; the baseline runs at the fastest"},
         "kind": "port", "passes": len(per_pass), "seq_per_s_each_pass": [round(B / t, 4) for t in per_pass],
         "sample": f"median of {len(per_pass)} passes over {sample_steps} of {S} diffusion steps (evenly spaced, on the {'states of a GPU decode of this workload' if states is not None else 'synthetic states'}) "
                   f"at full batch (B={B}, L={L}, M={M}) + the noise-removal forward, scaled by {S}/{sample_steps} to one decode; "
@@ -603,6 +834,8 @@ def main():
     ap.add_argument("--value-net", default="convgru", choices=["convgru", "enformer"],
                     help="enformer: the 230M-parameter Enformer-shaped value trunk of BASELINE config 4 (not the headline config)")
     ap.add_argument("--c4-steps", type=int, default=1, help="decodes timed for the config4_enformer object of the default line (0 = skip)")
+    ap.add_argument("--c3-steps", type=int, default=1, help="decodes timed for the config3_pm object (BASELINE configs[2], SVDD-PM; 0 = skip)")
+    ap.add_argument("--c5-steps", type=int, default=1, help="decodes timed for the config5 objects (BASELINE configs[4], TDS / DPS; 0 = skip)")
     ap.add_argument("--extra-legs", type=int, default=1,
                     help="0: skip the legs that launch the headline's kernels under other conditions (replay_rng: the backbone with the "
                          "mt19937 workgroup beside it; config1_b4: 4-sequence launches) — used for the rocprofv3 --stats pass, whose "
@@ -709,7 +942,7 @@ def main():
     bb_flops = conv_flops_fwd + 2.0 * B * L * (5 * H * 9 + H * H + H * 5)
     alt = {}
     pmc_lp, pmc_lp_src = {}, None                # HBM bytes per backbone_lp_kernel launch, from separate --pmc passes
-    for name in ("r04_pmc.json", "r03_pmc.json"):
+    for name in ("r05_pmc.json", "r04_pmc.json", "r03_pmc.json"):
         pth = os.path.join(ROOT, "profiles", name)
         if pmc_lp:
             break
@@ -727,7 +960,7 @@ def main():
         for k in range(args.alt_steps):
             if k == args.alt_steps - 1:
                 _lib.profile_enable(True)
-            one_decode()
+            out_alt = one_decode()
         fence()
         el = time.perf_counter() - t1
         _lib.profile_enable(False)
@@ -741,7 +974,7 @@ def main():
         tf = bb_flops / (bb_ms_lp * 1e-3) / 1e12 if prof[6][1] else 0.0
         alt[mode] = {
             "value": round(B * world * args.alt_steps / el, 3), "unit": "sequences/s", "ms_per_step": round(el / args.alt_steps * 1e3, 3),
-            "steps": args.alt_steps, "dtype": mode,
+            "steps": args.alt_steps, "dtype": mode, "x0_sha1": _digest(out_alt),
             "arithmetic": ("fp32 operands split hi+lo in %s, a*b = ahi*bhi + ahi*blo + alo*bhi on the 16-bit MFMA, fp32 accumulate"
                            % mode[:-2]) if passes == 3 else "operands rounded to %s, one MFMA pass, fp32 accumulate" % mode,
             "roofline": {"bound": "mfma", "kernel": "backbone_lp_kernel (svdd_backbone_cnn_lp, one launch per forward)",
@@ -766,7 +999,7 @@ def main():
         conv_ms = conv_total_ms / max(conv_launches, 1)
         conv_tf = (conv_flops_fwd / 20.0) / (conv_ms * 1e-3) / 1e12 if conv_launches else 0.0
         pmc, pmc_src = {}, None
-        for name in ("r04_pmc.json", "r03_pmc.json", "r02_pmc.json", "r01_pmc.json"):   # separate --pmc passes of this workload, see the file
+        for name in ("r05_pmc.json", "r04_pmc.json", "r03_pmc.json", "r02_pmc.json", "r01_pmc.json"):   # separate --pmc passes of this workload, see the file
             pmc_path = os.path.join(ROOT, "profiles", name)
             if os.path.exists(pmc_path) and (B, L, M) == (256, 200, 10):
                 pmc = json.load(open(pmc_path))
@@ -801,6 +1034,7 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic (random-init nets, all-MASK prior)",
+            "x0_sha1": _digest(out),       # of the gathered batch of the last timed decode: equal for any number of ranks (Philox is keyed by the global row)
             "config": {"workload": f"DNA enhancer SVDD-MC, batch={B}/GPU, L={L}, M={M}, {S} steps "
                                    f"(BASELINE.json configs[1]); dilated-CNN backbone 3.3M params + ConvGRU value net",
                        "global_batch": B * world, "rng": args.rng, "sharding": f"rows x{world}, 1 all-gather"},
@@ -862,6 +1096,14 @@ def main():
             line["roofline_trunk_gemm_bf16x3"] = trunk_gemm_roofline(model, emb, head, dev, int(0.75 * B * M), L)
         if args.c4_steps > 0 and world == 1 and args.value_net == "convgru" and (B, L, M) == (256, 200, 10):
             line["config4_enformer"] = config4_leg(dev, args.c4_steps, f32_steps=args.c4_f32_steps)
+        if world == 1 and args.value_net == "convgru" and (B, L, M) == (256, 200, 10):
+            if args.c3_steps > 0:
+                line["config3_pm"] = config3_leg(dev, args.c3_steps, S=S)
+            if args.c5_steps > 0:
+                c5 = config5_leg(dev, args.c5_steps, S=S)
+                for k, v in c5.items():
+                    line["config5_" + k] = v
+        line["roofline"]["also"] = roofline_also(line)
         if args.cpu_steps > 0 and world == 1 and args.value_net == "convgru":
             model.state_trace = []                                  # one extra (untimed) decode: the trajectory's states
             model.controlled_sample(emb, head, num_steps=S, eval_sp_size=B, sample_M=M)

@@ -413,7 +413,9 @@ enum { SVDD_OPT_FORCE_EXACT = 0,
                                            LDS-DMA kernel's tile height by cost (default) / 256 rows / 192 rows; 51 .. 54: how many
                                            chains of GEMMs share the chip (the cost model prices a launch against CUs / that) */,
        SVDD_OPT_CAND_ROW_STRIDE = 5 /* layout experiment (round 4): bytes between two candidate rows of `cand` as svdd_select /
-                                        svdd_select_compact read it (0 = L, the default): rows padded to whole 128-byte lines */,
+                                        svdd_select_compact read it (0 = L, the default): rows padded to whole 128-byte lines. The library cannot
+                                        check the caller's padding: a non-zero value is refused (SVDD_E_ARG) unless the process has
+                                        SVDD_EXPERIMENTS set in its environment */,
        SVDD_OPT_TRUNK_PLANES_F32 = 6 /* the svdd_trunk_* entry points take ONE fp32 operand plane (the *_hi pointers are float*, the
                                          *_lo pointers NULL) and svdd_trunk_gemm multiplies on v_mfma_f32_16x16x4_f32: the Enformer-shaped
                                          trunk at the reference's precision (weights packed by fused_trunk.pack_gemm_weight_f32) */,

@@ -150,6 +150,34 @@ def device_info():
     return buf.value.decode().split(":")[0], ncu.value
 
 
+_OPTIONS = {}          # (key, sub) -> the value this process last set through set_option (absent: the library default)
+_OPTION_DEFAULTS = {(4, "version"): 2, (4, "height"): 40, (4, "concurrency"): 51}
+
+
+def _option_slot(key, value):
+    """SVDD_OPT_TRUNK_GEMM_VERSION multiplexes three settings on one key (include/svdd_hip.h): kernel version, tile height (40 - 42),
+    chains sharing the chip (51 - 54). Each is remembered separately."""
+    if key == 4:
+        return (4, "height" if 40 <= value <= 42 else "concurrency" if 51 <= value <= 54 else "version")
+    return (key, None)
+
+
+def current_option(key, like=0):
+    """The value last set for `key` (for key 4: for the setting `like` belongs to)."""
+    slot = _option_slot(key, like)
+    return _OPTIONS.get(slot, _OPTION_DEFAULTS.get(slot, 0))
+
+
+def set_option(key, value):
+    """svdd_set_option through one door that remembers what was set -> the PREVIOUS value of that setting, so that a scoped change
+    can put back what its caller had chosen instead of a constant."""
+    key, value = int(key), int(value)
+    prev = current_option(key, value)
+    check(lib().svdd_set_option(key, value), f"svdd_set_option({key}, {value})")
+    _OPTIONS[_option_slot(key, value)] = value
+    return prev
+
+
 def set_force_exact(on):
     """A/B switch: K1 evaluates every draw in the exact arithmetic (same results, slower)."""
     check(lib().svdd_set_option(OPT_FORCE_EXACT, int(bool(on))), "svdd_set_option")

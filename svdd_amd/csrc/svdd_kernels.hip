@@ -44,6 +44,11 @@ __device__ __forceinline__ float expf_cr_small(float x) {
   p = __builtin_fma(p, d, 0.5);
   p = __builtin_fma(p, d, 1.0);
   p = __builtin_fma(p, d, 1.0);
+  // The series and ocml's exp are each within an ulp of double of the true value, so they round to the same fp32 unless the
+  // 29 discarded bits sit within a few double-ulps of the fp32 rounding midpoint (2^-26 of the arguments): there, defer to
+  // ocml itself — expf_cr_small(x) == expf_cr(x) for every x, not just with overwhelming probability.
+  const long long low = __double_as_longlong(p) & 0x1FFFFFFFll;
+  if (low - 0x0FFFFFF8ll <= 16ll && low >= 0x0FFFFFF8ll) return expf_cr(x);
   return (float)p;
 }
 __device__ __forceinline__ float expf_cr_nonpos(float x) { return x > -0.0078125f ? expf_cr_small(x) : expf_cr(x); }
@@ -1164,7 +1169,12 @@ int svdd_set_option(int key, int value) {
   if (key == SVDD_OPT_FORCE_EXACT) { g_force_exact = value ? 1 : 0; return SVDD_OK; }
   if (key == SVDD_OPT_MSPLIT && value >= 0 && value <= 64) { g_msplit = value; return SVDD_OK; }
   if (key == SVDD_OPT_SELECT_ONE_ROW && value >= 0 && value <= 3) { g_select_one_row_per_wave = value; return SVDD_OK; }
-  if (key == SVDD_OPT_CAND_ROW_STRIDE && value >= 0) { g_cand_ld = value; return SVDD_OK; }
+  if (key == SVDD_OPT_CAND_ROW_STRIDE && value >= 0) {
+    // a layout EXPERIMENT: svdd_select* would stride `cand` by `value` bytes without any way to check that the caller's buffer is
+    // padded that way (out-of-bounds reads otherwise) — honoured only in a process that opted in (tools/resample_microbench.py does)
+    if (value != 0 && !getenv("SVDD_EXPERIMENTS")) return SVDD_E_ARG;
+    g_cand_ld = value; return SVDD_OK;
+  }
   if (key == SVDD_OPT_TRUNK_PLANES_F32) { svdd_internal_set_trunk_planes_f32(value); return SVDD_OK; }
   if (key == SVDD_OPT_BACKBONE_SPLIT) { svdd_internal_set_bb_split(value); return SVDD_OK; }
   if (key == SVDD_OPT_BACKBONE_LP_VERSION) { svdd_internal_set_bb_lp_version(value); return SVDD_OK; }

@@ -1956,9 +1956,12 @@ __global__ __launch_bounds__(512, 2) void backbone_split_kernel(BackboneArgs a, 
         __hip_atomic_fetch_add(gcnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int target = R * (layer + 1);
         int spins = 0;
+        // (once a barrier of this launch has timed out the launch's results are void — svdd_backbone_split_status reports it, the
+        //  samplers raise — and the remaining layers do not wait again)
         while (__hip_atomic_load(gcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
           __builtin_amdgcn_s_sleep(1);
-          if (++spins > (1 << 24)) { *ws.err = 1; break; }  // a member is not resident (a launcher bug): give up, never hang
+          if ((++spins & 0xFFF) == 0 && __hip_atomic_load(ws.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+          if (spins > (1 << 24)) { __hip_atomic_store(ws.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }  // a member is not resident: give up, never hang
         }
       }
       __syncthreads();
@@ -2355,7 +2358,9 @@ extern "C" int svdd_backbone_split_status(int* err_out) {
   if (!err_out) return SVDD_E_ARG;
   *err_out = 0;
   if (!g_bb_ws.err) return SVDD_OK;
-  return hipMemcpy(err_out, g_bb_ws.err, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
+  if (hipMemcpy(err_out, g_bb_ws.err, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return SVDD_E_LAUNCH;
+  if (*err_out && hipMemset(g_bb_ws.err, 0, sizeof(int)) != hipSuccess) return SVDD_E_LAUNCH;   // reported once, then cleared
+  return SVDD_OK;
 }
 
 extern "C" int svdd_backbone_cnn_f32(const uint8_t* x, const float* table0, const float* tiles, const float* vec,

@@ -60,6 +60,7 @@ Engine knobs (attributes; defaults reproduce the reference's observable behaviou
                    first decode pays for every new live-batch size, rounded to 256 rows here), hence opt-in. The one-pass modes "bf16" / "f16" run an
                    opaque value / reward net under torch.autocast; the x3 modes leave it in fp32.
 """
+import warnings
 import weakref
 
 import numpy as np
@@ -122,6 +123,9 @@ def _decode_scope(fn):
             if self._scope_depth == 0 and self._replay_stream is not None:
                 st, self._replay_stream = self._replay_stream, None
                 st.close()                 # the advanced mt19937 state goes back into torch's global CPU generator
+            if self._scope_depth == 0 and not _capturing():
+                from .fused import check_backbone_split
+                check_backbone_split()     # a small-batch backbone launch whose workgroups could not all be resident: raise, never return its tokens
     return wrapped
 
 
@@ -177,6 +181,7 @@ class Diffusion(nn.Module):
         self.fuse_trunk_f32 = True       # precision "f32" + Enformer-shaped value trunk: the hand-written fp32 trunk kernels (False: the PyTorch modules)
         self.replay_rng = "device"       # rng_mode "replay": "device" = torch's CPU mt19937 stream continued by K8 on the GPU for
         self._replay_stream = None       # the span of a sampler call; "host" = torch.rand on the host + upload (round 1-3)
+        self._replay_checked = None      # scope id of the sharded replay decode whose generator state was compared across ranks
 
     # ------------------------------------------------------------------ plumbing ----
     @property
@@ -280,12 +285,15 @@ class Diffusion(nn.Module):
                     from .fused_trunk import FusedEnformerValueNet
                     for k in [k for k, v in self._fused.items() if k != "backbone" and (v[0]() is None or v[1]() is None)]:
                         del self._fused[k]
-                    try:
+                    # a trunk whose GEMM shapes the kernels do not take (output channels must come in 128s, input channels in
+                    # 32s: a 384-channel toy trunk has a 192-channel stem) stays on the PyTorch modules — said once, and ONLY
+                    # for that documented reason: an assertion while packing a supported trunk is a bug and propagates
+                    ok, why = FusedEnformerValueNet.supports(embedding, head)
+                    if ok:
                         fused_net = FusedEnformerValueNet(embedding, head, tp)
-                    except AssertionError:
-                        # a trunk whose GEMM shapes the kernels do not take (output channels must come in 128s, input channels
-                        # in 32s: a 384-channel toy trunk has a 192-channel stem) stays on the PyTorch modules
+                    else:
                         fused_net = None
+                        warnings.warn(f"Enformer-shaped value trunk stays on the PyTorch modules: {why}", stacklevel=2)
                     ent = (weakref.ref(embedding), weakref.ref(head), fp, fused_net, self._scope_id)
                 else:
                     ent = ent[:4] + (self._scope_id,)
@@ -353,6 +361,15 @@ class Diffusion(nn.Module):
             rows = shard[2] if shard else B
             shape = (M, rows, L, 5) if ul == ops.LAYOUT_BLV else (M, rows, 5, L)
             extra = dict(row_offset=shard[0], uniforms_rows=rows) if shard else {}
+            if shard and not (self._scope_depth > 0 and self._replay_checked == self._scope_id):
+                # every rank replays the whole batch's stream and slices its rows: only the reference's run if all ranks start from
+                # the same generator state (a rank seeded per rank, or one that drew anything extra, would silently decode other tokens)
+                import hashlib
+                from . import distributed
+                digest = hashlib.sha1(torch.get_rng_state().numpy().tobytes()).digest()
+                distributed.assert_same_on_all_ranks(int.from_bytes(digest[:8], "little", signed=True),
+                                                     "sharded replay decode: torch's CPU generator state (seed every rank identically)")
+                self._replay_checked = self._scope_id
             if self.replay_rng == "device" and self._scope_depth > 0 and logits.is_cuda and not _capturing():
                 # the same stream, generated on the device (svdd_mt19937_uniform_f32): the generator's state is uploaded at the
                 # first draw of a sampler call and written back into torch's global generator when the call returns

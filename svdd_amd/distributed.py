@@ -9,7 +9,13 @@ unsharded replay decode, i.e. the reference's run at the total batch size.
 The SMC/TDS baseline is the one sampler whose step couples rows (the resample draws ancestors from the WHOLE batch,
 reference diffusion_gosai.py:1279-1284): `tds_exchange` all-gathers each rank's proposals, both reward vectors and its
 slice of the uniforms in ONE small collective per step ((L + 16) bytes per row), every rank runs the same K4 resample on
-the whole batch and keeps its rows — token-exact against the unsharded decode."""
+the whole batch and keeps its rows — token-exact against the unsharded decode.
+
+Cost of the sharded replay mode, stated: every rank generates M * total_rows * L * 5 uniforms per step on the one-workgroup
+mt19937 kernel (the stream is serial by definition), so the replay cost does NOT shrink with more ranks — it is the parity mode,
+not the throughput mode. It is only correct when every rank's torch CPU generator is in the same state when the sampler starts
+(seed every rank identically, NOT per rank): Diffusion verifies that with one 8-byte all-gather at the first draw of a sharded
+replay decode and raises on a mismatch."""
 import os
 
 import torch
@@ -32,7 +38,26 @@ def init_from_env(backend=None):
             shared = torch.cuda.is_available() and torch.cuda.device_count() < local_world
             backend = os.environ.get("SVDD_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() and not shared else "gloo")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        if torch.cuda.is_available() and torch.cuda.device_count() < int(os.environ.get("LOCAL_WORLD_SIZE", str(world))):
+            # several ranks on one device: the small-batch backbone (2 / 4 workgroups per sequence that WAIT for each other,
+            # svdd_backbone_cnn_f32) may only be launched when all members of a group are resident at once — which another
+            # process's kernels on the same CUs can prevent. One workgroup per sequence then (same bits, no inter-workgroup wait).
+            from . import _lib
+            _lib.set_option(7, 1)
     return rank, world, local
+
+
+def assert_same_on_all_ranks(value, what):
+    """Collective: every rank contributes one int64; raises on every rank when they are not all equal."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor([int(value)], dtype=torch.int64, device=dev)
+    parts = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, t)
+    vals = [int(p.item()) for p in parts]
+    if len(set(vals)) > 1:
+        raise RuntimeError(f"{what} differs between ranks: {vals}")
 
 
 def shard_rows(total_rows, rank, world):

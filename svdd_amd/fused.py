@@ -320,6 +320,20 @@ def _backbone_split_workspace(dev):
     return _BB_SPLIT_WS[key]
 
 
+def check_backbone_split():
+    """Raises if a group barrier of a small-batch backbone launch (several workgroups per sequence) timed out since the last
+    check: its logits were computed from a partly exchanged image. Reads one int from the device (synchronises) — only after a
+    split launch may have happened; the samplers call it at the end of every decode (Diffusion._decode_scope)."""
+    if not _BB_SPLIT_WS.pop("used", False):
+        return
+    err = ctypes.c_int(0)
+    _lib.check(_lib.lib().svdd_backbone_split_status(ctypes.byref(err)), "svdd_backbone_split_status")
+    if err.value:
+        raise _lib.SvddError("svdd_backbone_cnn_f32: a workgroup of a small-batch (several workgroups per sequence) launch waited in vain "
+                             "for its partners — something else occupied the CUs (another process or stream on this GPU). The logits "
+                             "of that launch are invalid. Run with svdd_set_option(SVDD_OPT_BACKBONE_SPLIT, 1) when the GPU is shared.")
+
+
 def backbone_cnn(tokens, pk, count=None, out=None, row_idx=None, scatter=False):
     """tokens [n, L] uint8 -> raw logits fp32 [n, L, 5]: the whole backbone forward in ONE launch
     (HIP kernel svdd_backbone_cnn_f32)."""
@@ -327,6 +341,7 @@ def backbone_cnn(tokens, pk, count=None, out=None, row_idx=None, scatter=False):
     n, L = tokens.shape
     if 104 < L <= 208 and count is None and row_idx is None and (n <= BB_SPLIT_MAX_SEQ or 0 < n % 256 <= BB_SPLIT_MAX_SEQ):
         _backbone_split_workspace(tokens.device)       # small batches, and the tail round of a batch that is not a multiple of the CUs
+        _BB_SPLIT_WS["used"] = True                    # -> check_backbone_split() at the end of the decode
     if out is None:
         out = torch.empty((n, L, 5), dtype=torch.float32, device=tokens.device)
     dil = (ctypes.c_int * len(pk["dil"]))(*pk["dil"])

@@ -19,6 +19,7 @@ of the SVDD-MC loop needs no host round trip.
 The module takes TOKENS ([n, L] uint8, 4 = MASK): the engine's one-hot rows are exact, and the stem's k = 15 convolution
 over a one-hot input is a K = 60 GEMM whose A operand is exactly representable in bf16."""
 import ctypes
+import threading
 import os
 
 import torch
@@ -108,7 +109,49 @@ class _PlanesAt:
         return [b[_Planes.FRONT:] for b in self.buf]
 
 
+_OPTION_LOCK = threading.RLock()     # the plane format / concurrency hint are process-wide switches of the library: one forward at a time sets them
+
+
 class FusedEnformerValueNet(nn.Module):
+    @staticmethod
+    def supports(trunk, head):
+        """(ok, why): whether svdd_trunk_gemm takes every GEMM of this trunk — output channels in 128s, input channels in 32s
+        (a 384-channel toy trunk has a 192-channel stem) — and the block structure is the one the kernels were written for.
+        Diffusion.value_callable falls back to the PyTorch modules ONLY on a False here; any assertion raised while packing a
+        supported trunk is a bug and propagates."""
+        try:
+            blocks = trunk.conv_tower.blocks
+            stem = blocks[0][0]
+            if tuple(stem.weight.shape[1:]) != (4, 15):
+                return False, f"stem weight {tuple(stem.weight.shape)} is not [*, 4, 15]"
+            shapes = [("stem", stem.weight.shape[0], 64)]
+            for i, blk in enumerate(blocks):
+                if i > 0:
+                    a = blk[0]
+                    if a.conv.kernel_size[0] != 5 or a.residual or not isinstance(a.pool, nn.Identity):
+                        return False, f"conv block {i}a is not a plain 5-tap block"
+                    shapes.append((f"conv{i}a", a.conv.out_channels, a.conv.in_channels))
+                b = blk[1]
+                if b.conv.kernel_size[0] != 1 or not b.residual:
+                    return False, f"conv block {i}b is not a residual 1x1 block"
+                shapes.append((f"conv{i}b", b.conv.out_channels, b.conv.in_channels))
+                shapes.append((f"pool{i}", *b.pool.to_attn_logits.weight.shape[:2]))
+            for k, tb in enumerate(trunk.transformer_tower):
+                m = tb.mha
+                shapes += [(f"qkv{k}", 2 * m.to_q.weight.shape[0] + m.to_v.weight.shape[0], m.to_q.weight.shape[1]),
+                           (f"out{k}", *m.to_out.weight.shape), (f"ffn1_{k}", *tb.ffn1.weight.shape), (f"ffn2_{k}", *tb.ffn2.weight.shape)]
+            pw = trunk.pointwise_conv
+            if pw.conv.kernel_size[0] != 1 or pw.residual:
+                return False, "pointwise block is not a plain 1x1 block"
+            shapes.append(("pointwise", pw.conv.out_channels, pw.conv.in_channels))
+            head.channel_transform.conv.layer.weight                # noqa: B018  (the ConvHead layout the tail reads)
+        except AttributeError as e:
+            return False, f"not the EnformerTrunk / ConvHead layout ({e})"
+        for name, N, Cin in shapes:
+            if N % 128 or Cin % 32:
+                return False, f"GEMM {name}: {N} output / {Cin} input channels (need multiples of 128 / 32)"
+        return True, ""
+
     def __init__(self, trunk: EnformerTrunk, head: ConvHead, precision="bf16x3"):
         super().__init__()
         assert precision in ("bf16x3", "bf16", "f32")
@@ -398,13 +441,14 @@ class FusedEnformerValueNet(nn.Module):
     def forward_tokens(self, tok, count=None, shared=None):
         """See _forward_tokens. The plane format is a host-side switch of the library (svdd_set_option): set for the span of the
         call (every launch of the call is enqueued inside it), restored on the way out."""
-        lib = _lib.lib()
-        _lib.check(lib.svdd_set_option(6, 1 if self.f32 else 0), "svdd_set_option(SVDD_OPT_TRUNK_PLANES_F32)")
-        try:
-            return self._forward_tokens(tok, count, shared)
-        finally:
-            lib.svdd_set_option(6, 0)
-            lib.svdd_set_option(4, 51)
+        with _OPTION_LOCK:                       # (two value nets of different precision on two host threads must not interleave)
+            prev_planes = _lib.set_option(6, 1 if self.f32 else 0)
+            prev_conc = _lib.current_option(4, 51)
+            try:
+                return self._forward_tokens(tok, count, shared)
+            finally:                             # what the caller had set, not constants
+                _lib.set_option(6, prev_planes)
+                _lib.set_option(4, prev_conc)
 
     def _forward_tokens(self, tok, count=None, shared=None):
         """tok [n, L] u8 -> scores [n, n_tasks, 1]; count: int32 device scalar = live rows (rows beyond it are undefined).
@@ -432,7 +476,7 @@ class FusedEnformerValueNet(nn.Module):
         if S > 1 and not (n * T >= 2048 and need_f <= reg_f and need_p + 2 * 4096 <= reg_p):
             S = 1
         self.last_streams = S
-        _lib.lib().svdd_set_option(4, 50 + (S if self.gemm_conc_hint else 1))   # the GEMMs' tile-height choice prices a launch against CUs / S
+        _lib.set_option(4, 50 + (S if self.gemm_conc_hint else 1))   # the GEMMs' tile-height choice prices a launch against CUs / S
         if S == 1:
             self.last_window_rows = self._candidates(ws, st, tok, count, shared, depth, zs, 0)
         else:

@@ -224,19 +224,33 @@ def _assert_teacher_forced_lean(rep):
     assert rep["selection_agreement"] >= 0.99, rep
 
 
-def _assert_free_running_lean(run, pm=False):
-    if pm:      # a candidate's x0-hat may differ at a last-bit argmax tie -> a different (legitimate) reward; see e2e_parity
-        assert run["frac_scores_within_1e-4"] >= 0.995, run
+# Free-running bounds = what the last full run recorded (profiles/r04_e2e_parity.json, re-collected as r05) + 1: a regression of a
+# few rows turns these red. (min rows following the reference to the end, max proposal flips, max x0-hat flips) per precision.
+# The residue at f32 is the reference CPU's own rounding (selections at reference score gaps <= 1.9e-8, one categorical draw at a
+# 4e-7 race margin, diffusion_gosai.py:1219-1225, :30-34): recorded, not chased.
+FREE_RUN_BOUNDS = {
+    "c2": {"f32": (252, 2, 2), "f16x3": (252, 2, 2), "bf16x3": (251, 2, 2)},      # observed 253 / 254 / 253 rows
+    "c3": {"f32": (254, 2, 2), "f16x3": (254, 2, 2), "bf16x3": (253, 2, 2)},      # observed 255 / 255 / 254 rows
+    "m20": {"f32": (256, 0, 0), "f16x3": (255, 1, 1), "bf16x3": (255, 1, 1)},     # observed 256 everywhere (f32: x_0 exact, asserted)
+}
+
+
+def _assert_free_running_lean(run, pm=False, bounds=None):
+    precision = run["precision"]
+    if pm or precision == "bf16x3":      # a candidate's x0-hat may differ at a last-bit argmax tie -> a different (legitimate) reward; see e2e_parity
+        assert run["frac_scores_within_1e-4"] >= (0.995 if pm else 0.9999), run
     else:
         assert run["max_abs_score_err_on_undiverged_rows"] <= TOL, run
     assert run["divergences_unexplained"] == [], run                     # every divergence is a near-tie (<= 2e-4) or a proposal flip
-    assert run["divergences_by_proposal_flip"] <= max(2, run["B"] // 50), run
-    assert run["divergences_by_x0hat_flip"] <= (max(2, run["B"] // 50) if pm else 0), run
+    rows_min, prop_max, x0hat_max = bounds[precision] if bounds else (0, max(2, run["B"] // 50), max(2, run["B"] // 50) if pm else 0)
+    assert run["divergences_by_proposal_flip"] <= prop_max, run
+    assert run["divergences_by_x0hat_flip"] <= x0hat_max, run
+    assert run["rows_following_the_reference_to_the_end"] >= rows_min, run
     if run["first_divergence_step"] is None:
         assert run["x0_exact"], run
 
 
-@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+@pytest.mark.parametrize("precision", ["f32", "f16x3", "bf16x3"])
 def test_headline_config_c2_against_the_reference_run(golden, full_nets, precision):
     """g21 (C2 = BASELINE configs[1], the config `metric` is quoted on): the reference's controlled_sample at B = 256, L = 200,
     M = 10, 128 steps with the full-size seed-44 nets. Teacher-forced on all 128 x 256 row-steps (backbone at full occupancy ->
@@ -254,10 +268,10 @@ def test_headline_config_c2_against_the_reference_run(golden, full_nets, precisi
     run = e2e_parity.free_running_lean_report(
         g, model, lambda m: m.controlled_sample(emb, head, num_steps=S, eval_sp_size=B, sample_M=M), precision)
     print("g21 c2 free-running", run)
-    _assert_free_running_lean(run)
+    _assert_free_running_lean(run, bounds=FREE_RUN_BOUNDS["c2"])
 
 
-@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+@pytest.mark.parametrize("precision", ["f32", "f16x3", "bf16x3"])
 def test_headline_config_c3_against_the_reference_run(golden, rna_nets, precision):
     """g21 (C3 = BASELINE configs[2]): the reference's controlled_sample_tweedie(options="True") at B = 256, L = 50, M = 10,
     128 steps, full-size nets + reward model (reference diffusion_gosai.py:1105-1145, 1373-1460): teacher-forced (candidates,
@@ -279,10 +293,10 @@ def test_headline_config_c3_against_the_reference_run(golden, rna_nets, precisio
     run = e2e_parity.free_running_lean_report(
         g, model, lambda m: m.controlled_sample_tweedie(reward, num_steps=S, eval_sp_size=B, sample_M=M, options="True"), precision)
     print("g21 c3 free-running", run)
-    _assert_free_running_lean(run, pm=True)
+    _assert_free_running_lean(run, pm=True, bounds=FREE_RUN_BOUNDS["c3"])
 
 
-@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+@pytest.mark.parametrize("precision", ["f32", "f16x3", "bf16x3"])
 def test_tds_baseline_at_the_c5_shard_size_against_the_reference_run(golden, full_nets, precision):
     """g23: BASELINE configs[4]'s SMC / TDS baseline as the reference ran it at the per-GPU shard size (256 particles, L = 200,
     128 steps, full-size nets + reward model): proposals re-drawn from the replayed stream, x0-hat rows, numerator rewards
@@ -298,21 +312,25 @@ def test_tds_baseline_at_the_c5_shard_size_against_the_reference_run(golden, ful
     assert rep["hand_written_net_kernels"]
     assert rep["max_abs_logit_err_kept_calls"] <= TOL, rep
     assert rep["max_abs_reward_num_err"] <= TOL, rep
-    assert rep["reward_den_within_1e-4"] >= 0.999, rep
+    # (bf16x3's logits are ~4e-5 from the reference's instead of ~4e-6: 107 of 32,768 x0-hat rows sit at a closer argmax tie than
+    #  that — each within 2e-4, asserted below — and their denominators move with them; recorded: 32661 rows, 0.9888)
+    assert rep["reward_den_within_1e-4"] >= (0.98 if precision == "bf16x3" else 0.999), rep
     assert rep["proposals_identical"] >= S * B - 4, rep
     if rep["proposal_tokens_differing"]:
         assert rep["max_race_margin_where_proposals_differ"] <= TOL, rep
-    assert rep["x0hat_rows_identical"] >= S * B - 8, rep
+    assert rep["x0hat_rows_identical"] >= S * B - (160 if precision == "bf16x3" else 8), rep
     if rep["x0hat_tokens_differing"]:
         assert rep["max_logit_top2_gap_where_x0hat_differs"] <= 2 * TOL, rep
     assert rep["resample_indices_identical"] == S * B and rep["resample_next_rows_identical"] == S * B, rep      # K4: exact
     fr = rep["free_running"]
     assert fr["states_recorded"] >= S
-    if fr["first_divergence_step"] is None:
-        assert fr["x0_exact"], rep
+    if precision in ("f32", "f16x3"):      # recorded: every state of the reference's run reproduced, x_0 exact — a diverging run is a regression
+        assert fr["first_divergence_step"] is None and fr["x0_exact"], rep
+    else:                                  # bf16x3 recorded: intermediate states differ from step 1 on (resampled duplicates), x_0 exact
+        assert fr["x0_rows_identical"] >= 0.99, rep
 
 
-@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+@pytest.mark.parametrize("precision", ["f32", "f16x3", "bf16x3"])
 def test_unguided_decode_at_the_headline_batch_against_the_reference_run(golden, full_nets, precision):
     """g24: `decode_sample` (the harness's baseline loop, reference diffusion_gosai.py:888-936) as the reference ran it at B = 256,
     L = 200, 128 steps with the full-size backbone: every transition re-drawn from the replayed stream, the noise-removal argmax,
@@ -331,10 +349,12 @@ def test_unguided_decode_at_the_headline_batch_against_the_reference_run(golden,
     assert rep["noise_removal_rows_identical"] >= int(g["B"]) - 2, rep
     if rep["max_logit_top2_gap_where_x0_differs"] is not None:
         assert rep["max_logit_top2_gap_where_x0_differs"] <= 2 * TOL, rep
-    assert rep["free_running"]["x0_rows_identical"] >= 0.97, rep          # a flipped draw changes that row's later states
+    if precision == "f32":                 # recorded (all three modes): every transition and x_0 identical to the reference's run
+        assert rep["next_states_identical"] == rep["row_steps"] and rep["free_running"]["x0_exact"], rep
+    assert rep["free_running"]["x0_rows_identical"] >= 0.99, rep          # a flipped draw changes that row's later states
 
 
-@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+@pytest.mark.parametrize("precision", ["f32", "f16x3", "bf16x3"])
 def test_mc_with_20_candidates_at_the_shard_batch_against_the_reference_run(golden, full_nets, precision):
     """g25: BASELINE configs[3]'s sampler shape (M = 20) at the shard batch B = 256 with the ConvGRU value net, 48 steps, run by
     the reference: K1 / K2 with 20 candidates per row (the select kernel's 32-lane groups) on 245,760 reference candidates,
@@ -350,4 +370,35 @@ def test_mc_with_20_candidates_at_the_shard_batch_against_the_reference_run(gold
     run = e2e_parity.free_running_lean_report(
         g, model, lambda m: m.controlled_sample(emb, head, num_steps=S, eval_sp_size=B, sample_M=M), precision)
     print("g25 m20 free-running", run)
-    _assert_free_running_lean(run)
+    _assert_free_running_lean(run, bounds=FREE_RUN_BOUNDS["m20"])
+    if precision == "f32":
+        assert run["first_divergence_step"] is None and run["x0_exact"], run
+
+
+def test_headline_decode_digests_per_precision_mode(full_nets):
+    """The whole Philox decode at the headline config (B = 256, L = 200, M = 10, 128 steps), three times per precision mode
+    (tools/decode_repeat_soak.py as a test): ONE digest per mode (a race in any one-launch kernel, or a kernel whose result depends
+    on where a row sits, shows up as a run that differs), and the x3 decodes select what the exact-fp32 one does up to near-ties."""
+    import hashlib
+    model, emb, head, _ = full_nets
+    keep = (model.rng_mode, model.philox_seed, model.precision)
+    model.rng_mode, model.philox_seed = "philox", 12345
+    digests, tokens = {}, {}
+    try:
+        for mode in ("f32", "f16x3", "bf16x3", "bf16"):
+            model.precision = mode
+            seen = set()
+            for _ in range(3):
+                x = model.controlled_sample(emb, head, num_steps=128, eval_sp_size=256, sample_M=10)
+                seen.add(hashlib.sha1(x.cpu().numpy().tobytes()).hexdigest()[:16])
+            assert len(seen) == 1, (mode, sorted(seen))
+            digests[mode], tokens[mode] = seen.pop(), x.cpu()
+    finally:
+        model.rng_mode, model.philox_seed, model.precision = keep
+    same = {m: int((tokens[m] == tokens["f32"]).all(dim=1).sum()) for m in tokens}
+    print("decode digests", digests, "rows identical to the f32 decode", same)
+    # f16x3: token for token the exact-fp32 decode at this key in rounds 3 and 4 (digest 82b920b9...); one near-tie may legitimately
+    # flip when a split kernel's summation order changes, a few rows may not. bf16x3: fp32-class error, ~1.5 % of the rows differ at
+    # near-ties (profiles/r03_precision_agreement.json: 252 / 256 at seed 0). bf16 (one pass) only has to repeat itself.
+    assert same["f16x3"] >= 255, (digests, same)
+    assert same["bf16x3"] >= 246, (digests, same)

@@ -372,3 +372,44 @@ def test_rccl_collectives_of_the_bench_on_one_rank(tmp_path):
     env.pop("SVDD_DIST_BACKEND", None)
     r = subprocess.run([sys.executable, str(script), root], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "RCCL_PROBE_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+@pytest.mark.parametrize("rng", ["philox", "replay"])
+def test_bench_real_two_rank_branch_equals_the_unsharded_decode(rng):
+    """bench.py's REAL multi-rank branch (not --dry-run): `python bench.py --gpus 2 ...` starts two ranks that share this box's one GPU
+    (gloo through the host, chosen by the launcher), each decodes its 64 rows (Philox keyed by the global row / the whole batch's
+    mt19937 stream replayed per rank), max-over-ranks timing, per-rank times, the one all-gather, and one split-precision leg. The
+    digest of the gathered batch in the line must equal the digest of the SAME decode done unsharded in this process (128 rows)."""
+    import hashlib
+    import json
+    import os
+    import subprocess
+    import sys
+    from svdd_amd import synthetic
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    B, S = 64, 16
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", str(B),
+           "--diffusion-steps", str(S), "--cpu-steps", "0", "--c4-steps", "0", "--c3-steps", "0", "--c5-steps", "0",
+           "--alt-precision", "f16x3", "--alt-steps", "1", "--rng", rng]
+    env = dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.lstrip().startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["backend"] == "gloo"
+    assert line["config"]["global_batch"] == 2 * B and line["config"]["rng"] == rng
+    assert line["value"] > 0 and len(line["per_rank"]["decode_ms"]) == 2 and len(line["per_rank"]["allgather_ms"]) == 2
+    assert line["alt_precision"]["f16x3"]["value"] > 0
+    # the same decode unsharded, here
+    model, emb, head, _ = synthetic.build("dna", "cuda:0")
+    model.rng_mode, model.philox_seed, model.row_offset = rng, 0, 0
+    digest = {}
+    for mode in ("f32", "f16x3"):
+        model.precision = mode
+        torch.manual_seed(0)
+        x = model.controlled_sample(emb, head, num_steps=S, eval_sp_size=2 * B, sample_M=10)
+        digest[mode] = hashlib.sha1(x.to(torch.uint8).cpu().numpy().tobytes()).hexdigest()[:16]
+    assert line["x0_sha1"] == digest["f32"], (line["x0_sha1"], digest)
+    assert line["alt_precision"]["f16x3"]["x0_sha1"] == digest["f16x3"], (line["alt_precision"]["f16x3"]["x0_sha1"], digest)

@@ -2,20 +2,20 @@
 # Collects the judged evidence of a round on the GPU box into gpurun_out/<tag>_*:
 #   bench JSON line, rocprofv3 --kernel-trace --stats summary of the same command, per-kernel trace summary of our
 #   kernels, and FETCH_SIZE / WRITE_SIZE PMC passes (separate runs, --kernel-trace only) for the roofline kernels.
-TAG=${1:-r04}
+TAG=${1:-r05}
 OUT=/root/repo/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 OURS="backbone_kernel backbone_lp_kernel backbone_lp_t_kernel conv_tower tower_lp gru_bidir gru_pc gru_lp value_tail tail_lp candidate_windows compact_flags propose_kernel select_kernel select_rows_kernel tds_cdf tds_gather transform advance_rows gather_rows x0hat epilogue_ln conv1d_cl"
 python3 /root/repo/bench.py --steps 3 --warmup 1 2>/dev/null | tail -1 > $OUT/${TAG}_bench.json
 rm -rf /tmp/prof_$TAG
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o $TAG -- python3 /root/repo/bench.py --steps 2 --warmup 1 --cpu-steps 0 --c4-steps 0 --extra-legs 0 > /tmp/prof_$TAG.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o $TAG -- python3 /root/repo/bench.py --steps 2 --warmup 1 --cpu-steps 0 --c4-steps 0 --c3-steps 0 --c5-steps 0 --extra-legs 0 > /tmp/prof_$TAG.log 2>&1
 cp $(find /tmp/prof_$TAG -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_bench_kernel_stats.csv
 python3 /root/repo/tools/trace_summary.py $(find /tmp/prof_$TAG -name "*kernel_trace.csv" | head -1) $OURS > $OUT/${TAG}_own_kernels_trace_summary.txt
 : > $OUT/${TAG}_pmc.txt
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -- python3 /root/repo/bench.py --steps 1 --warmup 0 --cpu-steps 0 --c4-steps 0 --extra-legs 0 --alt-precision f16x3,bf16x3,bf16 --alt-steps 1 > /tmp/pmc_$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -- python3 /root/repo/bench.py --steps 1 --warmup 0 --cpu-steps 0 --c4-steps 0 --c3-steps 0 --c5-steps 0 --extra-legs 0 --alt-precision f16x3,bf16x3,bf16 --alt-steps 1 > /tmp/pmc_$c.log 2>&1
   python3 - $(find /tmp/pmc_$c -name "*counter_collection.csv" | head -1) $c >> $OUT/${TAG}_pmc.txt <<'PY'
 import csv, sys, collections
 agg = collections.defaultdict(list)
@@ -42,7 +42,7 @@ def traffic(pat, use_min=False, use_max=False):
             return int(2 * d["FETCH_SIZE"][k] * 1024 + d["WRITE_SIZE"][k] * 1024), name, d
     return None, None, None
 out = {"how": "two separate passes per counter (tools/collect_round_profile.sh %s): rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace "
-              "--output-format csv -- python3 bench.py --steps 1 --warmup 0 --cpu-steps 0 --c4-steps 0 --extra-legs 0 --alt-precision f16x3,bf16x3,bf16 --alt-steps 1 ; "
+              "--output-format csv -- python3 bench.py --steps 1 --warmup 0 --cpu-steps 0 --c4-steps 0 --c3-steps 0 --c5-steps 0 --extra-legs 0 --alt-precision f16x3,bf16x3,bf16 --alt-steps 1 ; "
               "per-dispatch means in profiles/%s_pmc.txt (rocprofv3 reports KB)" % (sys.argv[3], sys.argv[3]),
        "fetch_correction": "x2: on gfx950 FETCH_SIZE tallies 128-B requests as 64 B for wide coalesced streams (MI355X_MICROARCH.md, HBM section)"}
 t, name, d = traffic(r"backbone_kernel<true>")

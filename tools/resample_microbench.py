@@ -4,6 +4,8 @@ Algorithmic bytes: K2 B*(4M + 2L + 4) (scores + winning row in, x_next + idx out
 import os
 import sys
 
+os.environ.setdefault("SVDD_EXPERIMENTS", "1")   # SVDD_OPT_CAND_ROW_STRIDE is honoured only in an opted-in process
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from svdd_amd import ops
