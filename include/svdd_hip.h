@@ -161,6 +161,9 @@ int svdd_subs_logp(const float* logits, const uint8_t* x, int B, int L, int layo
  *
  * svdd_compact_flags — stable compaction of n flags (one workgroup): flags[i] != 0 -> live_idx[k] = i, slot[i] = k with
  *   k = number of live items before i; else slot[i] = -1; count[0] = number of live items.
+ * svdd_compact_by_key — the same compaction ORDERED by key, largest first (stable inside a key; keys clamp to 15, key <= 0 = not
+ *   live): live_idx lists the live items by descending key, slot[i] = position of item i in it or -1. With key = row tiles of a
+ *   candidate's window (the flags svdd_candidate_windows writes) the windowed tower's long workgroups are dispatched first.
  * svdd_gather_rows   — dst[i,:] = src[idx[i],:] for i < count[0] (count may be NULL = n); rows of row_bytes bytes.
  * svdd_advance_rows  — the selected candidate becomes the next parent: for every b, if slot[b*M + sel[b]] >= 0 then
  *   dst[b,:] = src[slot[...],:], else dst[b] is left untouched; rows of row_bytes (multiple of 4).
@@ -169,6 +172,7 @@ int svdd_subs_logp(const float* logits, const uint8_t* x, int B, int L, int layo
  *   parent score) and changed[b] (1 iff x_next[b] differs from x[b]). slot == NULL: exactly svdd_select.
  */
 int svdd_compact_flags(const int32_t* flags, int n, int32_t* live_idx, int32_t* slot, int32_t* count, void* stream);
+int svdd_compact_by_key(const int32_t* key, int n, int32_t* live_idx, int32_t* slot, int32_t* count, void* stream);
 int svdd_gather_rows(const void* src, const int32_t* idx, const int32_t* count, int n, int row_bytes, void* dst, void* stream);
 int svdd_advance_rows(const void* src, const int32_t* slot, const int32_t* sel, int B, int M, int row_bytes, void* dst,
                       void* stream);
@@ -309,8 +313,8 @@ int svdd_set_tower_version(int v);
  *     positions where the candidate differs from its parent +- margin (27 for the 5-layer tower); (0, 0) if none.
  *   svdd_conv_tower_windows_f32: onehot [n = B*M, L, 4] (row b*M + m), win from above, parent_out [B, L, 64] =
  *     svdd_conv_tower_f32 of the parents' one-hot; out [n, L, 64]. 104 < L <= 208, nlayers = 5.
- *   flags [B*M] (may be NULL): 1 if the candidate differs from its parent, 0 for an exact copy (input of
- *     svdd_compact_flags). live_idx / count (may be NULL): process only the listed candidates; workgroup i handles
+ *   flags [B*M] (may be NULL): the number of row tiles of the window ((w1 - w0) / 16 >= 1) if the candidate differs from its
+ *     parent, 0 for an exact copy (input of svdd_compact_flags / key of svdd_compact_by_key). live_idx / count (may be NULL): process only the listed candidates; workgroup i handles
  *     candidate live_idx[i] and writes rows [i*L, (i+1)*L) of out (a compacted batch). */
 int svdd_candidate_windows(const uint8_t* cand, const uint8_t* x, int B, int L, int M, int margin, int32_t* win,
                            int32_t* flags, void* stream);
@@ -448,7 +452,7 @@ int svdd_device_info(char* arch, int arch_len, int* num_cu);
 
 /* ABI version of this header: bumped on any signature change. */
 int svdd_abi_version(void);
-#define SVDD_ABI_VERSION 8
+#define SVDD_ABI_VERSION 9
 
 /*
  * Enformer-shaped value trunk (BASELINE.json configs[3]; reference decode.py:78-80, Enformer.py:1271-1334 trunk, :1807-1884

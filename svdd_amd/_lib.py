@@ -13,7 +13,7 @@ CSRC = os.path.join(_HERE, "csrc")
 # SVDD_HIP_LIB: load another build of the library instead (the timing-experiment scripts under tools/ build patched
 # copies of the kernels in a scratch directory; the tracked sources are never edited in place)
 SO_PATH = os.environ.get("SVDD_HIP_LIB") or os.path.join(CSRC, "libsvdd_hip.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 OK, E_ARG, E_LAUNCH, E_NODEVICE = 0, -1, -2, -3
 LAYOUT_BLV, LAYOUT_BVL = 0, 1
@@ -30,7 +30,7 @@ EXPORTS = (
     "svdd_conv1d_set_dynamic", "svdd_gru_set_mode", "svdd_conv_tower_f32", "svdd_backbone_cnn_f32", "svdd_value_tail_f32",
     "svdd_candidate_windows", "svdd_conv_tower_windows_f32", "svdd_k1_stats",
     "svdd_backbone_cnn_lp", "svdd_conv_tower_lp", "svdd_conv_tower_windows_lp", "svdd_gru_bidir_lp", "svdd_value_tail_lp",
-    "svdd_compact_flags", "svdd_gather_rows", "svdd_advance_rows", "svdd_select_compact", "svdd_set_tower_version", "svdd_set_backbone_packing",
+    "svdd_compact_flags", "svdd_compact_by_key", "svdd_gather_rows", "svdd_advance_rows", "svdd_select_compact", "svdd_set_tower_version", "svdd_set_backbone_packing",
     "svdd_trunk_gemm", "svdd_trunk_act_split", "svdd_trunk_layernorm_split", "svdd_trunk_attn_pool", "svdd_trunk_stem_unfold", "svdd_trunk_attn_small",
     "svdd_trunk_windows", "svdd_trunk_stem_unfold_win", "svdd_trunk_attn_pool_win",
     "svdd_bb_layer_fwd_f32", "svdd_bb_layer_bwd_f32", "svdd_mt19937_uniform_f32",
@@ -112,6 +112,7 @@ def lib():
     L.svdd_set_tower_version.argtypes = [i32]
     L.svdd_set_backbone_packing.argtypes = [i32]
     L.svdd_compact_flags.argtypes = [vp, i32, vp, vp, vp, vp]
+    L.svdd_compact_by_key.argtypes = [vp, i32, vp, vp, vp, vp]
     L.svdd_gather_rows.argtypes = [vp, vp, vp, i32, i32, vp, vp]
     L.svdd_advance_rows.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp]
     L.svdd_select_compact.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, ctypes.POINTER(SvddRng), vp, vp, vp, vp, vp, vp]

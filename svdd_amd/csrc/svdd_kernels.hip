@@ -995,6 +995,61 @@ __global__ __launch_bounds__(1024) void compact_flags_kernel(const int32_t* __re
   if (threadIdx.x == 0) count[0] = base_s;
 }
 
+// Compaction ORDERED BY KEY, largest first, stable inside a key (counting sort; one workgroup): key[i] > 0 (clamped to 15) marks a
+// live item. The windowed conv tower's workgroups take as many row tiles as their candidate's window has (key = that number); two
+// share a CU and the dispatcher hands them out in grid order — with the long windows first the launch does not end on a few CUs
+// that started a 13-tile window last (profiles/r05_tower_order_probe.txt: 487 -> 395 us per launch on the states of a C2 decode).
+__global__ __launch_bounds__(1024) void compact_by_key_kernel(const int32_t* __restrict__ key, int n, int32_t* __restrict__ live_idx,
+                                                              int32_t* __restrict__ slot, int32_t* __restrict__ count) {
+  __shared__ int hist[16], base[16];
+  __shared__ int wave_cnt[16][16];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (threadIdx.x < 16) hist[threadIdx.x] = 0;
+  __syncthreads();
+  for (int i0 = 0; i0 < n; i0 += 1024) {
+    const int i = i0 + threadIdx.x;
+    const int k = i < n ? min(max(key[i], 0), 15) : 0;
+#pragma unroll
+    for (int kk = 1; kk < 16; ++kk) {
+      const unsigned long long m = __ballot(k == kk);
+      if (lane == 0 && m) atomicAdd(&hist[kk], __popcll(m));
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int kk = 15; kk >= 1; --kk) { base[kk] = run; run += hist[kk]; }
+    count[0] = run;
+  }
+  __syncthreads();
+  for (int i0 = 0; i0 < n; i0 += 1024) {
+    const int i = i0 + threadIdx.x;
+    const int k = i < n ? min(max(key[i], 0), 15) : 0;
+    int rank = 0;
+#pragma unroll
+    for (int kk = 1; kk < 16; ++kk) {
+      const unsigned long long m = __ballot(k == kk);
+      if (k == kk) rank = __popcll(m & ((1ull << lane) - 1ull));
+      if (lane == 0) wave_cnt[w][kk] = __popcll(m);
+    }
+    __syncthreads();
+    if (i < n) {
+      if (k > 0) {
+        int off = base[k] + rank;
+        for (int ww = 0; ww < w; ++ww) off += wave_cnt[ww][k];
+        live_idx[off] = i; slot[i] = off;
+      } else slot[i] = -1;
+    }
+    __syncthreads();
+    if (threadIdx.x >= 1 && threadIdx.x < 16) {
+      int t = 0;
+      for (int ww = 0; ww < 16; ++ww) t += wave_cnt[ww][threadIdx.x];
+      base[threadIdx.x] += t;
+    }
+    __syncthreads();
+  }
+}
+
 // dst[i, :] = src[idx[i], :] for i < count : rows of `row_bytes` bytes, one wave per row
 __global__ __launch_bounds__(256) void gather_rows_kernel(const uint8_t* __restrict__ src, const int32_t* __restrict__ idx,
                                                           const int32_t* __restrict__ count, int n, int row_bytes,
@@ -1372,6 +1427,12 @@ int svdd_select_compact(const float* scores, const int32_t* slot, const float* p
 int svdd_compact_flags(const int32_t* flags, int n, int32_t* live_idx, int32_t* slot, int32_t* count, void* stream) {
   if (!flags || !live_idx || !slot || !count || n <= 0) return SVDD_E_ARG;
   hipLaunchKernelGGL(compact_flags_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, flags, n, live_idx, slot, count);
+  return check_launch();
+}
+
+int svdd_compact_by_key(const int32_t* key, int n, int32_t* live_idx, int32_t* slot, int32_t* count, void* stream) {
+  if (!key || !live_idx || !slot || !count || n <= 0) return SVDD_E_ARG;
+  hipLaunchKernelGGL(compact_by_key_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, key, n, live_idx, slot, count);
   return check_launch();
 }
 

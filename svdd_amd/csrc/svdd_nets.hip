@@ -1358,7 +1358,7 @@ __global__ __launch_bounds__(256) void candidate_windows_kernel(const uint8_t* _
       w1 = min((L + 15) & ~15, (hi + margin + 1 + 15) & ~15);
     }
     win[2 * c] = w0; win[2 * c + 1] = w1;
-    if (flags) flags[c] = hi >= 0 ? 1 : 0;             // 0: the candidate is a copy of its parent
+    if (flags) flags[c] = (w1 - w0) >> 4;              // row tiles of the window (>= 1) ; 0: the candidate is a copy of its parent
   }
 }
 

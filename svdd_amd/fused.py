@@ -646,6 +646,7 @@ class FusedValueNet(nn.Module):
             self.b1f = nn.Parameter(bf, requires_grad=False)
         self.use_fused_tail = True
         self.share_parent_tower = True
+        self.sort_live_by_window = True      # candidate_scores_compact: live candidates ordered by window size, largest first (A/B knob; same bits)
         # "f32" (exact, default) or one of LP_DTYPES: the conv tower, GRU and tail on the 16-bit matrix cores
         # (csrc/svdd_lp_*.hip). Needs the reference-shaped net (tower_ok, tail_ok).
         self.precision = "f32"
@@ -694,7 +695,11 @@ class FusedValueNet(nn.Module):
         from . import ops
         B, M, L = cand.shape
         win = candidate_windows(cand, x, flags=ws.flags)
-        ops.compact_flags(ws.flags, ws.live_idx, ws.slot, ws.count)
+        # the live candidates by DESCENDING window size: a windowed-tower workgroup takes as many row tiles as its window has, and
+        # with the long ones dispatched first the launch does not end on a few CUs that began a 13-tile window last (fp32 tower
+        # 487 -> 395 us per launch on a C2 decode's states, tools/tower_order_probe.py). A row's result does not depend on its
+        # place in the compacted batch: same bits, same tokens.
+        (ops.compact_by_key if self.sort_live_by_window else ops.compact_flags)(ws.flags, ws.live_idx, ws.slot, ws.count)
         if getattr(ws, "n_win_rows", None) is not None:                     # Diffusion.skip_stats: rows the tower computes this step
             ws.n_win_rows += (win[:, 1] - win[:, 0]).sum()
         # The parents' tower output is carried from step to step: the next parent IS the selected candidate, whose tower

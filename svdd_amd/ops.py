@@ -156,6 +156,12 @@ def compact_flags(flags, live_idx, slot, count):
     _lib.check(rc, "svdd_compact_flags")
 
 
+def compact_by_key(key, live_idx, slot, count):
+    """The same compaction ordered by key, largest first, stable inside a key (svdd_compact_by_key): key[i] > 0 = live."""
+    rc = _lib.lib().svdd_compact_by_key(key.data_ptr(), key.numel(), live_idx.data_ptr(), slot.data_ptr(), count.data_ptr(), _stream())
+    _lib.check(rc, "svdd_compact_by_key")
+
+
 def gather_rows(src, idx, count, dst):
     """dst[i] = src[idx[i]] for i < count[0] (row tensors of equal row size, contiguous)."""
     n = src.shape[0]

@@ -34,6 +34,53 @@ def test_compact_flags_vs_torch(n, p):
     assert torch.equal(slot, exp_slot)
 
 
+@pytest.mark.parametrize("n", [1, 63, 64, 1023, 1024, 1025, 2560, 40960])
+@pytest.mark.parametrize("p", [0.0, 0.3, 1.0])
+def test_compact_by_key_vs_torch(n, p):
+    """The compaction ordered by key (window size in row tiles), largest first, stable inside a key: against torch's stable sort."""
+    from svdd_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(n + 1)
+    key = torch.randint(1, 21, (n,), device=DEV, generator=g, dtype=torch.int32)          # keys above 15 clamp to 15
+    key = torch.where(torch.rand(n, device=DEV, generator=g) < p, key, torch.zeros_like(key))
+    if n > 3:
+        key[1] = -2                                                                        # negative = not live
+    live_idx = torch.full((n,), -5, dtype=torch.int32, device=DEV)
+    slot = torch.full((n,), -5, dtype=torch.int32, device=DEV)
+    count = torch.full((1,), -5, dtype=torch.int32, device=DEV)
+    ops.compact_by_key(key, live_idx, slot, count)
+    kc = key.clamp(0, 15)
+    live = torch.nonzero(kc).flatten()
+    order = torch.sort(kc[live], descending=True, stable=True).indices
+    ref = live[order].to(torch.int32)
+    k = int(count)
+    assert k == ref.numel()
+    assert torch.equal(live_idx[:k], ref)
+    exp_slot = torch.full((n,), -1, dtype=torch.int32, device=DEV)
+    exp_slot[ref.long()] = torch.arange(k, dtype=torch.int32, device=DEV)
+    assert torch.equal(slot, exp_slot)
+
+
+def test_mc_decode_same_tokens_whatever_the_order_of_the_live_candidates():
+    """FusedValueNet.sort_live_by_window (the live candidates handed to the windowed tower by descending window size) must not
+    change a token or a traced score: a row's result does not depend on its place in the compacted batch."""
+    from svdd_amd import synthetic
+    model, emb, head, _ = synthetic.build("dna", DEV)
+    model.rng_mode, model.philox_seed = "philox", 11
+    fn = model.value_callable(emb, head)
+    outs = []
+    for srt in (True, False):
+        fn.sort_live_by_window = srt
+        model.trace = []
+        x0 = model.controlled_sample(emb, head, num_steps=24, eval_sp_size=64, sample_M=10)
+        outs.append((x0, [sc for _, sc in model.trace if sc is not None]))
+        model.trace = None
+    fn.sort_live_by_window = True
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert len(outs[0][1]) == len(outs[1][1]) == 24
+    for a, b in zip(outs[0][1], outs[1][1]):
+        assert torch.equal(a, b)
+
+
 def test_gather_and_advance_rows():
     from svdd_amd import ops
     g = torch.Generator(device=DEV).manual_seed(0)
