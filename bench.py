@@ -278,6 +278,50 @@ def roofline_also(line):
     return also
 
 
+def precision_evidence(model, emb, head, states, sched, modes, B, L, M, picks=(32, 96)):
+    """Measured in THIS run, on states of this run's own fp32 decode: how far each precision mode's backbone logits and value scores
+    are from the PyTorch modules evaluated in fp64 (the function itself, not one particular fp32 rounding of it), beside the same
+    figure for the exact-fp32 kernels — so that "f16x3 is fp32-class" is a measurement in the driver's record, not a label.
+    Two states (diffusion steps `picks`), B x L x 5 logits and B x M scores each. tools/precision_agreement.py is the long form."""
+    import copy
+    from svdd_amd import ops
+    dev = states[0].device
+    keep = model.precision
+    out = {}
+    try:
+        with torch.no_grad(), torch.backends.cudnn.flags(enabled=False):
+            bb64 = copy.deepcopy(model.backbone).double()
+            bb64.clear_time_bias_cache()
+            emb64, head64 = copy.deepcopy(emb).double(), copy.deepcopy(head).double()
+            ref = []
+            model.precision = "f32"
+            for i in picks:
+                x = states[i]
+                lg64 = bb64(x.long(), torch.zeros(B, device=dev, dtype=torch.float64))
+                lg32 = model._backbone_logits(x)
+                cand, onehot, _ = ops.propose(lg32, x, sched[i, 2], sched[i, 1], M, ops.Rng(seed=0, row_offset=0, step=int(i)))
+                sc64 = head64(emb64(onehot.double())).reshape(B, M)
+                ref.append((x, lg64, cand, onehot, sc64))
+            del bb64, emb64, head64
+            for mode in ["f32"] + list(modes):
+                model.precision = mode
+                el, es, agree = 0.0, 0.0, []
+                for x, lg64, cand, onehot, sc64 in ref:
+                    el = max(el, float((model._backbone_logits(x).double() - lg64).abs().max()))
+                    sc = model._value_scores(emb, head, onehot, B, M, cand, x)
+                    es = max(es, float((sc.double() - sc64).abs().max()))
+                    agree.append(float((sc.argmax(1) == sc64.argmax(1)).float().mean()))
+                out[mode] = {"vs_fp64_logit_err": el, "vs_fp64_score_err": es, "selection_agreement_with_fp64": round(sum(agree) / len(agree), 5)}
+        out["how"] = (f"max |error| against the PyTorch modules in fp64 on the states of diffusion steps {list(picks)} of this run's fp32 decode "
+                      f"({B} x {L} x 5 logits, {B} x {M} scores per state; logits are O(1), scores O(0.01))")
+    except Exception as e:                                     # noqa: BLE001
+        out["error"] = f"{type(e).__name__}: {e}"
+    finally:
+        model.precision = keep
+        torch.cuda.empty_cache()
+    return out
+
+
 def sampler_saturated(dev, L=200, M=10, B=16384, masked_frac=0.5, iters=100):
     """K1 (propose) at a size that leaves launch latency behind (B*M*L = 32.8 M candidate tokens, 626 MB per launch):
     the HBM fraction the north star quotes for the resample kernel is only measurable there (SURVEY.md section 7
@@ -975,6 +1019,7 @@ def main():
         alt[mode] = {
             "value": round(B * world * args.alt_steps / el, 3), "unit": "sequences/s", "ms_per_step": round(el / args.alt_steps * 1e3, 3),
             "steps": args.alt_steps, "dtype": mode, "x0_sha1": _digest(out_alt),
+            "x0_rows_identical_vs_f32": round(float((out_alt == out).all(dim=1).float().mean()), 5),
             "arithmetic": ("fp32 operands split hi+lo in %s, a*b = ahi*bhi + ahi*blo + alo*bhi on the 16-bit MFMA, fp32 accumulate"
                            % mode[:-2]) if passes == 3 else "operands rounded to %s, one MFMA pass, fp32 accumulate" % mode,
             "roofline": {"bound": "mfma", "kernel": "backbone_lp_kernel (svdd_backbone_cnn_lp, one launch per forward)",
@@ -1109,6 +1154,13 @@ def main():
             model.controlled_sample(emb, head, num_steps=S, eval_sp_size=B, sample_M=M)
             torch.cuda.synchronize()
             states = [x.cpu().numpy() for x in model.state_trace]
+            if (B, L, M) == (256, 200, 10) and S == 128:
+                ev = precision_evidence(model, emb, head, model.state_trace, model._schedule(S, 1e-5)[0], list((alt or {}).keys()), B, L, M)
+                line["roofline"]["vs_fp64"] = ev.get("f32")           # the headline's own arithmetic against fp64, beside its roofline
+                for mode in (alt or {}):
+                    if mode in ev:
+                        alt[mode].update(ev[mode])
+                line["precision_evidence"] = ev
             model.state_trace = None
             line["cpu_baseline"] = cpu_baseline(B, L, M, S, args.cpu_steps, states=states, passes=args.cpu_passes)
             line["cpu_baseline_c1"] = cpu_baseline_c1(passes=args.cpu_passes)

@@ -338,6 +338,23 @@ int svdd_conv_tower_windows_f32(const float* onehot, const float* tiles, const f
 int svdd_backbone_cnn_f32(const uint8_t* x, const float* table0, const float* tiles, const float* vec,
                           const float* w2, float* out, int n, int L, int nlayers, const int* dilations,
                           const int32_t* count, const int32_t* row_idx, int out_scatter, void* stream);
+/* svdd_backbone_cnn_save_f32 + svdd_backbone_cnn_grad_f32 — the backbone's input gradient, one launch each way (the gradient-
+ *   guidance baseline DPS: reference diffusion_gosai.py:1321-1330 differentiates reward(softmax(E[x0 | x_t])) with respect to
+ *   onehot(x_t) through models/dnaconv.py:212-247; the weights are frozen). 104 < L <= 208 (one sequence per workgroup).
+ *   svdd_backbone_cnn_save_f32: svdd_backbone_cnn_f32 on the tokens x (the SAME BITS in `out`) that also writes, in the kernel's
+ *     lane-private layout, xhat [n][nlayers][56][512] f32 (LayerNorm'd value before the affine map), rstd [n][nlayers][208] f32
+ *     and mask [n][nlayers + 2][512] u64 (ReLU decisions of the first layer, every conv layer and final_conv's first 1x1).
+ *   svdd_backbone_cnn_grad_f32: dlogits [n,L,5] = d loss / d `out` -> dx [n,L,5] = d loss / d onehot(x), through the transposed
+ *     1x1 convs, 20 x [ReLU', transposed dilated conv (the same implicit GEMM on tiles_bwd), LayerNorm backward from xhat / rstd,
+ *     residual] and the first conv's transpose. tiles_bwd: W_f1^T as [4][128][32], then layers nlayers-1 .. 0 as [4][9][128][32] of
+ *     W'[ci][32c+k][t] = W[32c+k][ci][8-t] ; gamma [nlayers][128] ; w2, table0 as in svdd_backbone_cnn_f32.
+ *     Packing: svdd_amd/fused.py:pack_backbone_grad. */
+int svdd_backbone_cnn_save_f32(const uint8_t* x, const float* table0, const float* tiles, const float* vec, const float* w2,
+                               float* out, int n, int L, int nlayers, const int* dilations, float* xhat, float* rstd,
+                               unsigned long long* mask, void* stream);
+int svdd_backbone_cnn_grad_f32(const float* dlogits, const float* tiles_bwd, const float* gamma, const float* w2,
+                               const float* table0, const float* xhat, const float* rstd, const unsigned long long* mask,
+                               float* dx, int n, int L, int nlayers, const int* dilations, void* stream);
 /* svdd_backbone_set_workspace — caller-owned scratch for the small-batch form of svdd_backbone_cnn_f32 (several workgroups per
  * sequence exchange the LayerNorm'd image of every layer through it): ws = device memory of `bytes` >= n_max * (2 * 208 * 128 * 4
  * + 4) + 4 bytes for batches of up to n_max sequences (n_max = 128 covers every case the split is used for); NULL: none (one
@@ -434,7 +451,7 @@ int svdd_set_option(int key, int value);
 int svdd_k1_stats(unsigned long long* device_counters2);
 
 /* Per-launch kernel timing (host). While enabled, svdd_propose (kernel 0), svdd_select (1), svdd_conv1d_cl_f32 (2),
- * svdd_gru_bidir_f32 (3), svdd_epilogue_ln_f32 (4), svdd_conv_tower_f32 (5), svdd_backbone_cnn_f32 (6) and svdd_value_tail_f32 (7) are dispatched
+ * svdd_gru_bidir_f32 (3), svdd_epilogue_ln_f32 (4), svdd_conv_tower_f32 (5), svdd_backbone_cnn_f32 / _save_f32 (6), svdd_value_tail_f32 (7), svdd_tds_resample (8), svdd_mt19937_uniform_f32 (9) and svdd_backbone_cnn_grad_f32 (10) are dispatched
  * with HIP start/stop events bound to the dispatch on its launch stream
  * (hipExtLaunchKernelGGL); svdd_profile_collect waits for the recorded launches, returns the summed
  * hipEventElapsedTime and their count, and clears the record. Not for use during graph capture. */

@@ -34,7 +34,7 @@ EXPORTS = (
     "svdd_trunk_gemm", "svdd_trunk_act_split", "svdd_trunk_layernorm_split", "svdd_trunk_attn_pool", "svdd_trunk_stem_unfold", "svdd_trunk_attn_small",
     "svdd_trunk_windows", "svdd_trunk_stem_unfold_win", "svdd_trunk_attn_pool_win",
     "svdd_bb_layer_fwd_f32", "svdd_bb_layer_bwd_f32", "svdd_mt19937_uniform_f32",
-    "svdd_backbone_set_workspace", "svdd_backbone_split_status",
+    "svdd_backbone_set_workspace", "svdd_backbone_split_status", "svdd_backbone_cnn_save_f32", "svdd_backbone_cnn_grad_f32",
 )
 OPT_FORCE_EXACT = 0
 
@@ -106,6 +106,8 @@ def lib():
     L.svdd_candidate_windows.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp]
     L.svdd_conv_tower_windows_f32.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]
     L.svdd_backbone_cnn_f32.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, ctypes.POINTER(ctypes.c_int), vp, vp, i32, vp]
+    L.svdd_backbone_cnn_save_f32.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, ctypes.POINTER(ctypes.c_int), vp, vp, vp, vp]
+    L.svdd_backbone_cnn_grad_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, ctypes.POINTER(ctypes.c_int), vp]
     L.svdd_conv1d_cl_f32.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp]
     L.svdd_epilogue_ln_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_int64, i32, i32, vp]
     L.svdd_k1_stats.argtypes = [vp]

@@ -1179,7 +1179,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(16))) void mt19
 // hipExtLaunchKernelGGL start/stop events, i.e. HIP events bound to the dispatch itself on the launch
 // stream; svdd_profile_collect() sums hipEventElapsedTime over the recorded launches.
 struct TimedLaunch { hipEvent_t start, stop; };
-constexpr int PROFILE_KERNELS = 10;           // 0 propose (K1), 1 select (K2), 2 conv1d, 3 gru, 4 epilogue_ln, 5 conv_tower, 6 backbone_cnn, 7 value_tail, 8 tds_resample (K4, both phases), 9 mt19937 (K8)
+constexpr int PROFILE_KERNELS = 11;           // 0 propose (K1), 1 select (K2), 2 conv1d, 3 gru, 4 epilogue_ln, 5 conv_tower, 6 backbone_cnn, 7 value_tail, 8 tds_resample (K4, both phases), 9 mt19937 (K8), 10 backbone gradient
 bool g_profile = false;
 TimedLaunch* g_timed[PROFILE_KERNELS] = {};
 int g_timed_n[PROFILE_KERNELS] = {}, g_timed_cap[PROFILE_KERNELS] = {};

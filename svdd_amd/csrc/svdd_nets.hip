@@ -1397,6 +1397,19 @@ struct BackboneArgs {
   int auto_spt, ncu;       // auto_spt: the workgroups pick the sequences per tile from the device-side row count (svdd_spt.h)
 };
 
+// What the gradient kernel (backbone_grad_kernel, DPS) needs from a forward, all in the forward kernel's LANE-PRIVATE layout — lane
+// `tid` of workgroup `wg` owns element q = (r * 2 + ct) * 4 + e, q < 56: row 16 (rh + 2 r) + 4 g + e, column 32 cg + j + 16 ct —
+// so every store / load of the pair of kernels is one fully coalesced 256-byte access per wave:
+//   xhat [n][nl][56][512]  the LayerNorm'd value before the affine map, (h - mean) rstd, of every layer's input
+//   rstd [n][nl][208]      1 / sqrt(var + eps) per row
+//   mask [n][nl + 2][512]  bit q of a lane's 64-bit word: ReLU decision of the first layer (word 0), of layer i's conv (1 + i), of
+//                          final_conv's first 1x1 (nl + 1)
+struct BackboneSave {
+  float* xhat;
+  float* rstd;
+  unsigned long long* mask;
+};
+
 template <int N>
 __device__ __forceinline__ float row_ror(float v) {            // rotate right by N inside each 16-lane DPP row
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + N, 0xf, 0xf, false));
@@ -1415,8 +1428,9 @@ __device__ __forceinline__ float group16_sum(float v) {        // sum over the 1
 // (A first version gave each wave 16 channels of all 13 row tiles and skipped tiles in pairs: twice the LDS reads and
 //  address VALU per MFMA, 6 % more MFMAs; 2.31 vs 2.17 ms.)
 // LDS image rows: row -1 and rows >= L of a one-sequence tile are zero, so a tap is a clamped row offset.
-template <bool SPT1>
-__global__ __launch_bounds__(512, 2) void backbone_kernel(BackboneArgs a) {
+template <bool SPT1, bool SAVE = false>
+__global__ __launch_bounds__(512, 2) void backbone_kernel(BackboneArgs a, BackboneSave sv) {
+  static_assert(SPT1 || !SAVE, "the saving forward is the one-sequence-per-tile form");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* img = smem + BB_AP;                              // rows -1 .. TW_ROWS ; [-1] and [TW_ROWS] stay zero
   float* Bs = smem + (TW_ROWS + 2) * BB_AP;               // [9][5][128] the first layer's lookup table
@@ -1488,6 +1502,7 @@ __global__ __launch_bounds__(512, 2) void backbone_kernel(BackboneArgs a) {
 
   // ---- first layer: f[row][col] = relu(b + sum_t table[t][tok[row + t - 4]][col])   (dnaconv.py:177,184)
   f32x4 f[NR][2], acc[NR][2];
+  unsigned long long relu_bits = 0ull;                    // SAVE: this lane's ReLU decisions of the current layer
 #pragma unroll
   for (int ct = 0; ct < 2; ++ct) {
     const int col = col0 + 16 * ct;
@@ -1508,8 +1523,10 @@ __global__ __launch_bounds__(512, 2) void backbone_kernel(BackboneArgs a) {
           }
         }
         f[r][ct][e] = row < tile_rows ? fmaxf(v, 0.0f) : 0.0f;
+        if (SAVE && row < tile_rows && v > 0.0f) relu_bits |= 1ull << ((r * 2 + ct) * 4 + e);
       }
   }
+  if (SAVE) sv.mask[(size_t)blockIdx.x * (nl + 2) * 512 + tid] = relu_bits;
   __syncthreads();                                        // sched is visible
 
   // A operand addressing: this lane feeds row 16 (rh + 2 r) + j of its tiles, channels 32 c + 8 g .. + 8
@@ -1600,9 +1617,15 @@ __global__ __launch_bounds__(512, 2) void backbone_kernel(BackboneArgs a) {
             const float rs = rs4[e];
             img[row * BB_AP + col0] = row < tile_rows ? acc[r][0][e] * rs * gm0 + bt0 : 0.0f;
             img[row * BB_AP + col0 + 16] = row < tile_rows ? acc[r][1][e] * rs * gm1 + bt1 : 0.0f;
+            if (SAVE) {
+              float* xh = sv.xhat + (((size_t)blockIdx.x * nl + layer) * 56 + (r * 2) * 4 + e) * 512 + tid;
+              xh[0] = acc[r][0][e] * rs;
+              xh[4 * 512] = acc[r][1][e] * rs;
+            }
           }
         }
       }
+      if (SAVE && tid < TW_ROWS) sv.rstd[((size_t)blockIdx.x * nl + layer) * TW_ROWS + tid] = rstat[tid];
     } else {
 #pragma unroll
       for (int r = 0; r < NR; ++r)
@@ -1727,6 +1750,17 @@ __global__ __launch_bounds__(512, 2) void backbone_kernel(BackboneArgs a) {
 #undef B2_WAIT
 #undef B2_ALOAD
     __syncthreads();                                      // every wave is done reading the image
+    if (SAVE) {
+      relu_bits = 0ull;
+#pragma unroll
+      for (int r = 0; r < NR; ++r)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (acc[r][ct][e] > 0.0f) relu_bits |= 1ull << ((r * 2 + ct) * 4 + e);
+      sv.mask[((size_t)blockIdx.x * (nl + 2) + 1 + layer) * 512 + tid] = relu_bits;
+    }
     if (layer < nl) {
 #pragma unroll
       for (int r = 0; r < NR; ++r)
@@ -1759,6 +1793,314 @@ __global__ __launch_bounds__(512, 2) void backbone_kernel(BackboneArgs a) {
     for (int k = 0; k < BB_C; ++k) sm += hr[k] * wv[k];
     if (a.row_idx && a.out_scatter) { const int sq = row / L; a.out[((int64_t)a.row_idx[blockIdx.x * spt + sq] * L + (row - sq * L)) * 5 + v] = sm; }
     else a.out[(row0 + row) * 5 + v] = sm;
+  }
+}
+
+// ------------------------------------------- gradient of the backbone with respect to its one-hot input, ONE launch (round 5) ----
+// The gradient-guidance baseline (DPS, reference diffusion_gosai.py:1321-1330 through models/dnaconv.py:212-247) needs
+// d loss / d onehot(x_t) through the whole backbone; the weights are frozen. backbone_kernel<true, true> is the forward (the
+// inference kernel's bits) that also leaves, per layer, x-hat, 1 / sigma and the ReLU decisions in its lane-private layout
+// (BackboneSave); this kernel walks the layers in reverse with the SAME work split — wave (cg, rh) owns columns 32 cg .. + 32 of
+// the row tiles rh + 2 r, the residual GRADIENT stream G lives in the registers the forward kept f in — so that every saved value
+// comes back to the lane that wrote it in one coalesced load:
+//     G1 = (dlogits W2) * relu'(final 1x1)                                    VALU, 5 MACs per element
+//     G  = G1 W1                                                              1x1 conv with W1^T: the MFMA loop, taps = {4}
+//     for i = nl - 1 .. 0:   dhn = conv9_dil_i^T (G * relu'_i)                the SAME implicit-GEMM loop on W_i with flipped taps and
+//                                                                             swapped channel axes (packed by the host)
+//                            G  += LayerNorm'(dhn ; xhat_i, rstd_i, gamma_i)   rstd (t - mean(t) - xhat mean(t xhat)), t = gamma dhn
+//     dx[p][c] = sum_t sum_co W_first[co][c][t] (G * relu'_first)[p - (t - 4)][co]
+// Tiles arrive in PROCESSING order: [4][128][32] of W1^T, then layer nl - 1, nl - 2, ... 0 as [4 chunks][9 taps][128][32].
+struct BackboneGradArgs {
+  const float* dlogits;    // [n][L][5]
+  const float* tiles;      // see above
+  const float* gamma;      // [nl][128], layer order
+  const float* w2;         // [5][128]
+  const float* table0;     // [9][5][128] = W_first[co][c][t] -> [t][c][co]
+  float* dx;               // [n][L][5]
+  int n, L, nl;
+  int dil[BB_MAXL];        // layer order
+};
+
+__global__ __launch_bounds__(512, 2) void backbone_grad_kernel(BackboneGradArgs a, BackboneSave sv) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* img = smem + BB_AP;                              // rows -1 .. TW_ROWS ; [-1] and [TW_ROWS] stay zero
+  float* Bs = smem + (TW_ROWS + 2) * BB_AP;               // [9][5][128]
+  float* psum = Bs + 9 * 5 * BB_C;                        // [8][TW_ROWS]: partial sums of t (0..3) and of t xhat (4..7); first: dlogits
+  float* rstat = psum + 8 * TW_ROWS;                      // [2][TW_ROWS]
+  int* sdil = reinterpret_cast<int*>(rstat + 2 * TW_ROWS);  // [BB_MAXL + 1] dilation of processing step s (step 0 = the 1x1)
+  int* sched = sdil + BB_MAXL + 1;                        // [(nl + 1) * 36]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cg = w & 3, rh = w >> 2;
+  const int j = lane & 15, g = lane >> 4;
+  const int col0 = 32 * cg + j;
+  const int L = a.L, nl = a.nl;
+  const int tile_rows = L;
+  const int64_t row0 = (int64_t)blockIdx.x * L;
+  const int it_end = (nl + 1) * 36;
+  constexpr int NR = 7;
+
+  for (int e = tid; e < BB_AP; e += 512) { smem[e] = 0.0f; img[TW_ROWS * BB_AP + e] = 0.0f; }
+  if (tid <= nl) sdil[tid] = tid == 0 ? 1 : a.dil[nl - tid];
+  for (int e = tid; e < 9 * 5 * BB_C; e += 512) Bs[e] = a.table0[e];
+  for (int e = tid; e < TW_ROWS * 5; e += 512) psum[e] = e < L * 5 ? a.dlogits[row0 * 5 + e] : 0.0f;
+  __syncthreads();
+  // Schedule: index k = (step*4 + chunk)*9 + tap ; the same word format as backbone_kernel's
+  for (int k = tid; k < it_end; k += 512) {
+    auto entry = [&](int kk) {
+      const int step = kk / 36, t = kk % 9;
+      if (step == 0) return t == 4 ? 0x1fff : 0;
+      const int d = (t - 4) * sdil[step];
+      const int lo = d < 0 ? -d : 0, hi = d > 0 ? L - d : L;
+      if (lo >= hi) return 0;
+      int m = 0;
+      for (int r = 0; r < TW_RT; ++r) if (lo < 16 * r + 16 && hi > 16 * r) m |= 1 << r;
+      return m;
+    };
+    const int m = entry(k);
+    int nx = k + 1;
+    while (nx < it_end && entry(nx) == 0) ++nx;
+    sched[k] = m ? (m | ((k % 36) / 9) << 13 | (k % 9) << 15 | nx << 19) : 0;
+  }
+
+  // ---- G1 = (dlogits W2) * relu'(final 1x1) -> the image
+  f32x4 G[NR][2], acc[NR][2];
+  {
+    const unsigned long long mk = sv.mask[((size_t)blockIdx.x * (nl + 2) + nl + 1) * 512 + tid];
+    float w2a[5], w2b[5];
+#pragma unroll
+    for (int v = 0; v < 5; ++v) { w2a[v] = a.w2[v * BB_C + col0]; w2b[v] = a.w2[v * BB_C + col0 + 16]; }
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int row = 16 * (rh + 2 * r) + 4 * g + e;
+        if (row < TW_ROWS) {
+          float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+          for (int v = 0; v < 5; ++v) { const float dl = psum[row * 5 + v]; s0 += dl * w2a[v]; s1 += dl * w2b[v]; }
+          img[row * BB_AP + col0] = ((mk >> ((r * 2) * 4 + e)) & 1ull) && row < tile_rows ? s0 : 0.0f;
+          img[row * BB_AP + col0 + 16] = ((mk >> ((r * 2 + 1) * 4 + e)) & 1ull) && row < tile_rows ? s1 : 0.0f;
+        }
+      }
+  }
+  __syncthreads();                                        // sched and the image are visible
+
+  typedef __attribute__((address_space(3))) f32x4 LdsF4;
+  const int img_lds = (int)(unsigned)(size_t)(const __attribute__((address_space(3))) float*)img;
+  const int arow0 = img_lds + ((16 * rh + j) * BB_AP + 8 * g) * 4;
+  const int a_lo = arow0 - (16 * rh + j + 1) * BB_AP * 4;
+  const int a_hi = arow0 + (TW_ROWS - 16 * rh - j) * BB_AP * 4;
+
+  const float* wsrc = a.tiles + col0 * CH + 8 * g;
+  auto tile_of = [&](int k) { return k < 36 ? k / 9 : 4 + (k - 36); };
+  int it = 0;
+  while (it < it_end && sched[it] == 0) ++it;
+  it = __builtin_amdgcn_readfirstlane(it);
+  int en = __builtin_amdgcn_readfirstlane(sched[it]);
+  float4 bA[4], bB[4];
+  {
+    const float* src = wsrc + (size_t)tile_of(it) * BB_C * CH;
+    bA[0] = *reinterpret_cast<const float4*>(src);
+    bA[1] = *reinterpret_cast<const float4*>(src + 4);
+    bA[2] = *reinterpret_cast<const float4*>(src + 16 * CH);
+    bA[3] = *reinterpret_cast<const float4*>(src + 16 * CH + 4);
+    bB[0] = bA[0]; bB[1] = bA[1]; bB[2] = bA[2]; bB[3] = bA[3];
+  }
+
+  for (int step = 0; step <= nl; ++step) {
+    const int layer = nl - step;                          // step >= 1: the conv layer whose transpose this step applies
+    if (step > 0) {
+      // the image of this step: G * relu'(conv_layer), rows beyond the sequence zero
+      const unsigned long long mk = sv.mask[((size_t)blockIdx.x * (nl + 2) + 1 + layer) * 512 + tid];
+#pragma unroll
+      for (int r = 0; r < NR; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int row = 16 * (rh + 2 * r) + 4 * g + e;
+          if (row < TW_ROWS) {
+            img[row * BB_AP + col0] = ((mk >> ((r * 2) * 4 + e)) & 1ull) && row < tile_rows ? G[r][0][e] : 0.0f;
+            img[row * BB_AP + col0 + 16] = ((mk >> ((r * 2 + 1) * 4 + e)) & 1ull) && row < tile_rows ? G[r][1][e] : 0.0f;
+          }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < NR; ++r) { acc[r][0] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; acc[r][1] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
+    const int dil = __builtin_amdgcn_readfirstlane(sdil[step]);
+    const int layer_end = (step + 1) * 36;
+    __syncthreads();                                      // the image is complete
+#define B2_ALOAD(R, V, DELTA, COFF, DBYTES)                                                                  \
+      { int o_;                                                                                              \
+        asm("v_med3_i32 %0, %1, %2, %3" : "=v"(o_) : "v"(arow0 + (DBYTES) + (R) * (32 * BB_AP * 4)), "v"(a_lo + (COFF)), "v"(a_hi + (COFF))); \
+        const LdsF4* ap_ = reinterpret_cast<const LdsF4*>(o_);                                               \
+        const f32x4 t0_ = ap_[0], t1_ = ap_[1];                                                              \
+        V[0] = make_float4(t0_[0], t0_[1], t0_[2], t0_[3]); V[1] = make_float4(t1_[0], t1_[1], t1_[2], t1_[3]); }
+#define B2_WAIT(NOUT) __builtin_amdgcn_s_waitcnt(0xC07F | ((NOUT) << 8));
+#define B2_MM(R, U, NOUT)                                                                                    \
+      __builtin_amdgcn_sched_barrier(0);                                                                     \
+      B2_WAIT(NOUT)                                                                                          \
+      if (live & (1 << (2 * (R)))) {                                                                         \
+        _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                      \
+          acc[R][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(U[q].x, bf0[4 * q], acc[R][0], 0, 0, 0);          \
+          acc[R][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(U[q].x, bf1[4 * q], acc[R][1], 0, 0, 0);          \
+          acc[R][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(U[q].y, bf0[4 * q + 1], acc[R][0], 0, 0, 0);      \
+          acc[R][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(U[q].y, bf1[4 * q + 1], acc[R][1], 0, 0, 0);      \
+          acc[R][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(U[q].z, bf0[4 * q + 2], acc[R][0], 0, 0, 0);      \
+          acc[R][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(U[q].z, bf1[4 * q + 2], acc[R][1], 0, 0, 0);      \
+          acc[R][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(U[q].w, bf0[4 * q + 3], acc[R][0], 0, 0, 0);      \
+          acc[R][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(U[q].w, bf1[4 * q + 3], acc[R][1], 0, 0, 0);      \
+        }                                                                                                    \
+      }                                                                                                      \
+      __builtin_amdgcn_sched_barrier(0);
+#define B2_PARAMS(EN, DELTA, COFF, DBYTES)                                                                   \
+      const int DELTA = ((((EN) >> 15) & 15) - 4) * dil;                                                     \
+      const int COFF = (((EN) >> 13) & 3) * (CH * 4);                                                        \
+      const int DBYTES = DELTA * (BB_AP * 4) + COFF;
+#define B2_ENTRY(UA, UB, BC, BN)                                                                             \
+    { const int nxt = en >> 19;                                                                              \
+      const int en_next_v = sched[nxt < it_end ? nxt : it];                                                  \
+      const float bf0[8] = {BC[0].x, BC[0].y, BC[0].z, BC[0].w, BC[1].x, BC[1].y, BC[1].z, BC[1].w};         \
+      const float bf1[8] = {BC[2].x, BC[2].y, BC[2].z, BC[2].w, BC[3].x, BC[3].y, BC[3].z, BC[3].w};         \
+      { const float* src = wsrc + (size_t)tile_of(nxt < it_end ? nxt : it) * BB_C * CH;                      \
+        BN[0] = *reinterpret_cast<const float4*>(src);                                                       \
+        BN[1] = *reinterpret_cast<const float4*>(src + 4);                                                   \
+        BN[2] = *reinterpret_cast<const float4*>(src + 16 * CH);                                             \
+        BN[3] = *reinterpret_cast<const float4*>(src + 16 * CH + 4);                                         \
+      }                                                                                                      \
+      B2_PARAMS(en, delta, coff, dbytes)                                                                     \
+      const int live = en >> rh;                                                                             \
+      B2_MM(0, UA, 3)                                                                                        \
+      B2_ALOAD(2, UA, delta, coff, dbytes)                                                                   \
+      B2_MM(1, UB, 2)                                                                                        \
+      const int en2 = __builtin_amdgcn_readfirstlane(en_next_v);                                             \
+      B2_PARAMS(en2, delta2, coff2, dbytes2)                                                                 \
+      B2_ALOAD(3, UB, delta, coff, dbytes)                                                                   \
+      B2_MM(2, UA, 2)                                                                                        \
+      B2_ALOAD(4, UA, delta, coff, dbytes)                                                                   \
+      B2_MM(3, UB, 2)                                                                                        \
+      B2_ALOAD(5, UB, delta, coff, dbytes)                                                                   \
+      B2_MM(4, UA, 2)                                                                                        \
+      if (rh == 0) {                                                                                         \
+        B2_ALOAD(6, UA, delta, coff, dbytes)                                                                 \
+        B2_MM(5, UB, 2)                                                                                      \
+        B2_ALOAD(0, UB, delta2, coff2, dbytes2)                                                              \
+        B2_MM(6, UA, 2)                                                                                      \
+        B2_ALOAD(1, UA, delta2, coff2, dbytes2)                                                              \
+      } else {                                                                                               \
+        B2_ALOAD(0, UA, delta2, coff2, dbytes2)                                                              \
+        B2_MM(5, UB, 2)                                                                                      \
+        B2_ALOAD(1, UB, delta2, coff2, dbytes2)                                                              \
+      }                                                                                                      \
+      it = nxt;                                                                                              \
+      en = en2; }
+    float4 ua[2], ub[2];
+    if (it < layer_end) {
+      B2_PARAMS(en, delta0, coff0, dbytes0)
+      B2_ALOAD(0, ua, delta0, coff0, dbytes0)
+      B2_ALOAD(1, ub, delta0, coff0, dbytes0)
+    }
+    bool odd = false;
+    if (rh == 0) {
+      while (it < layer_end) {
+        B2_ENTRY(ua, ub, bA, bB)
+        if (it >= layer_end) { odd = true; break; }
+        B2_ENTRY(ub, ua, bB, bA)
+      }
+    } else {
+      while (it < layer_end) {
+        B2_ENTRY(ua, ub, bA, bB)
+        if (it >= layer_end) { odd = true; break; }
+        B2_ENTRY(ua, ub, bB, bA)
+      }
+    }
+    if (odd) { bA[0] = bB[0]; bA[1] = bB[1]; bA[2] = bB[2]; bA[3] = bB[3]; }
+#undef B2_ENTRY
+#undef B2_PARAMS
+#undef B2_MM
+#undef B2_WAIT
+#undef B2_ALOAD
+    __syncthreads();                                      // every wave is done reading the image
+    if (step == 0) {
+#pragma unroll
+      for (int r = 0; r < NR; ++r) { G[r][0] = acc[r][0]; G[r][1] = acc[r][1]; }
+    } else {
+      // LayerNorm backward: t = gamma dhn ; dh = rstd (t - mean(t) - xhat mean(t xhat)) ; both row sums in ONE exchange.
+      // The saved x-hat comes back here, after the loop (56 coalesced loads in flight at once): held across the MFMA loop it
+      // would not fit beside G and the accumulators (256 VGPRs at two waves per SIMD).
+      float xh[NR][2][4];
+#pragma unroll
+      for (int r = 0; r < NR; ++r)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            xh[r][ct][e] = (16 * (rh + 2 * r) < TW_ROWS) ? sv.xhat[(((size_t)blockIdx.x * nl + layer) * 56 + (r * 2 + ct) * 4 + e) * 512 + tid] : 0.0f;
+      const float gm0 = a.gamma[layer * BB_C + col0], gm1 = a.gamma[layer * BB_C + col0 + 16];
+#pragma unroll
+      for (int r = 0; r < NR; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int row = 16 * (rh + 2 * r) + 4 * g + e;
+          const float t0 = acc[r][0][e] * gm0, t1 = acc[r][1][e] * gm1;
+          acc[r][0][e] = t0; acc[r][1][e] = t1;
+          const float s1 = group16_sum(t0 + t1);
+          const float s2 = group16_sum(t0 * xh[r][0][e] + t1 * xh[r][1][e]);
+          if (j == 0 && row < TW_ROWS) { psum[cg * TW_ROWS + row] = s1; psum[(4 + cg) * TW_ROWS + row] = s2; }
+        }
+      __syncthreads();
+      if (tid < 2 * TW_ROWS) {
+        const float* ps = psum + (tid < TW_ROWS ? 0 : 4 * TW_ROWS) + (tid < TW_ROWS ? tid : tid - TW_ROWS);
+        rstat[tid] = ((ps[0] + ps[TW_ROWS]) + (ps[2 * TW_ROWS] + ps[3 * TW_ROWS])) * (1.0f / BB_C);
+      }
+      const float* rsd = sv.rstd + ((size_t)blockIdx.x * nl + layer) * TW_ROWS;
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        const int rb = min(16 * (rh + 2 * r) + 4 * g, TW_ROWS - 4);
+        const float4 m1 = *reinterpret_cast<const float4*>(rstat + rb);
+        const float4 m2 = *reinterpret_cast<const float4*>(rstat + TW_ROWS + rb);
+        const float4 rs = *reinterpret_cast<const float4*>(rsd + rb);
+        const float m1v[4] = {m1.x, m1.y, m1.z, m1.w}, m2v[4] = {m2.x, m2.y, m2.z, m2.w}, rsv[4] = {rs.x, rs.y, rs.z, rs.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          G[r][0][e] += rsv[e] * (acc[r][0][e] - m1v[e] - xh[r][0][e] * m2v[e]);
+          G[r][1][e] += rsv[e] * (acc[r][1][e] - m1v[e] - xh[r][1][e] * m2v[e]);
+        }
+      }
+    }
+  }
+  // ---- the first layer's transpose: (G * relu'_first) -> image -> dx[p][c] = sum_t sum_co W_first[co][c][t] g0[p - (t - 4)][co]
+  {
+    const unsigned long long mk = sv.mask[(size_t)blockIdx.x * (nl + 2) * 512 + tid];
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int row = 16 * (rh + 2 * r) + 4 * g + e;
+        if (row < TW_ROWS) {
+          img[row * BB_AP + col0] = ((mk >> ((r * 2) * 4 + e)) & 1ull) && row < tile_rows ? G[r][0][e] : 0.0f;
+          img[row * BB_AP + col0 + 16] = ((mk >> ((r * 2 + 1) * 4 + e)) & 1ull) && row < tile_rows ? G[r][1][e] : 0.0f;
+        }
+      }
+  }
+  __syncthreads();
+  for (int e = tid; e < L * 5; e += 512) {
+    const int p = e / 5, c = e - 5 * p;
+    float sm = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int q = p - (t - 4);
+      if (q < 0 || q >= L) continue;
+      const float4* hr = reinterpret_cast<const float4*>(img + q * BB_AP);
+      const float4* wv = reinterpret_cast<const float4*>(Bs + (t * 5 + c) * BB_C);
+#pragma unroll 8
+      for (int k = 0; k < BB_C / 4; ++k) {
+        const float4 h4 = hr[k], w4 = wv[k];
+        sm += h4.x * w4.x + h4.y * w4.y + h4.z * w4.z + h4.w * w4.w;
+      }
+    }
+    a.dx[row0 * 5 + e] = sm;
   }
 }
 
@@ -2363,6 +2705,50 @@ extern "C" int svdd_backbone_split_status(int* err_out) {
   return SVDD_OK;
 }
 
+// DPS: the forward that also saves what the gradient kernel needs, and the gradient kernel (one launch each way)
+extern "C" int svdd_backbone_cnn_save_f32(const uint8_t* x, const float* table0, const float* tiles, const float* vec,
+                                          const float* w2, float* out, int n, int L, int nlayers, const int* dilations,
+                                          float* xhat, float* rstd, unsigned long long* mask, void* stream) {
+  if (!x || !table0 || !tiles || !vec || !w2 || !out || !dilations || !xhat || !rstd || !mask || n <= 0 || L <= TW_ROWS / 2 ||
+      L > TW_ROWS || nlayers <= 0 || nlayers > BB_MAXL)
+    return SVDD_E_ARG;
+  BackboneArgs a;
+  a.x = x; a.table0 = table0; a.tiles = tiles; a.vec = vec; a.w2 = w2; a.out = out;
+  a.n = n; a.L = L; a.spt = 1; a.nl = nlayers; a.count = nullptr; a.row_idx = nullptr; a.out_scatter = 0;
+  a.auto_spt = 0; a.ncu = svdd_internal_num_cus();
+  for (int i = 0; i < BB_MAXL; ++i) a.dil[i] = i < nlayers ? dilations[i] : 1;
+  for (int i = 0; i < nlayers; ++i) if (dilations[i] <= 0) return SVDD_E_ARG;
+  const size_t lds = sizeof(float) * ((size_t)(TW_ROWS + 2) * BB_AP + 9 * 5 * (size_t)BB_C + 8 * (size_t)TW_ROWS +
+                                      3 * (size_t)TW_ROWS + BB_MAXL + 1 + (size_t)(nlayers + 1) * 36);
+  hipEvent_t e0, e1;
+  svdd_internal_timed_events(6, &e0, &e1);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(backbone_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipExtLaunchKernelGGL((backbone_kernel<true, true>), dim3((unsigned)n), dim3(512), lds, (hipStream_t)stream, e0, e1, 0, a,
+                        BackboneSave{xhat, rstd, mask});
+  return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
+}
+
+extern "C" int svdd_backbone_cnn_grad_f32(const float* dlogits, const float* tiles_bwd, const float* gamma, const float* w2,
+                                          const float* table0, const float* xhat, const float* rstd, const unsigned long long* mask,
+                                          float* dx, int n, int L, int nlayers, const int* dilations, void* stream) {
+  if (!dlogits || !tiles_bwd || !gamma || !w2 || !table0 || !xhat || !rstd || !mask || !dx || !dilations || n <= 0 ||
+      L <= TW_ROWS / 2 || L > TW_ROWS || nlayers <= 0 || nlayers > BB_MAXL)
+    return SVDD_E_ARG;
+  BackboneGradArgs a;
+  a.dlogits = dlogits; a.tiles = tiles_bwd; a.gamma = gamma; a.w2 = w2; a.table0 = table0; a.dx = dx;
+  a.n = n; a.L = L; a.nl = nlayers;
+  for (int i = 0; i < BB_MAXL; ++i) a.dil[i] = i < nlayers ? dilations[i] : 1;
+  for (int i = 0; i < nlayers; ++i) if (dilations[i] <= 0) return SVDD_E_ARG;
+  const size_t lds = sizeof(float) * ((size_t)(TW_ROWS + 2) * BB_AP + 9 * 5 * (size_t)BB_C + 8 * (size_t)TW_ROWS +
+                                      2 * (size_t)TW_ROWS + BB_MAXL + 1 + (size_t)(nlayers + 1) * 36);
+  hipEvent_t e0, e1;
+  svdd_internal_timed_events(10, &e0, &e1);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(backbone_grad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipExtLaunchKernelGGL(backbone_grad_kernel, dim3((unsigned)n), dim3(512), lds, (hipStream_t)stream, e0, e1, 0, a,
+                        BackboneSave{const_cast<float*>(xhat), const_cast<float*>(rstd), const_cast<unsigned long long*>(mask)});
+  return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
+}
+
 extern "C" int svdd_backbone_cnn_f32(const uint8_t* x, const float* table0, const float* tiles, const float* vec,
                                      const float* w2, float* out, int n, int L, int nlayers, const int* dilations,
                                      const int32_t* count, const int32_t* row_idx, int out_scatter, void* stream) {
@@ -2399,7 +2785,7 @@ extern "C" int svdd_backbone_cnn_f32(const uint8_t* x, const float* table0, cons
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(backbone_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         BackboneArgs am = a;
         am.n = n_main;
-        hipExtLaunchKernelGGL(backbone_kernel<true>, dim3((unsigned)n_main), dim3(512), lds, (hipStream_t)stream, e0, nullptr, 0, am);
+        hipExtLaunchKernelGGL(backbone_kernel<true>, dim3((unsigned)n_main), dim3(512), lds, (hipStream_t)stream, e0, nullptr, 0, am, BackboneSave{});
         if (hipGetLastError() != hipSuccess) return SVDD_E_LAUNCH;
         a.x += (size_t)n_main * L; a.out += (size_t)n_main * L * 5; a.n = ns;
         e0 = nullptr;                                     // one timed span over both launches
@@ -2419,10 +2805,10 @@ extern "C" int svdd_backbone_cnn_f32(const uint8_t* x, const float* table0, cons
   const dim3 grid(nwg);
   if (a.spt == 1 && !a.auto_spt) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(backbone_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipExtLaunchKernelGGL(backbone_kernel<true>, grid, dim3(512), lds, (hipStream_t)stream, e0, e1, 0, a);
+    hipExtLaunchKernelGGL(backbone_kernel<true>, grid, dim3(512), lds, (hipStream_t)stream, e0, e1, 0, a, BackboneSave{});
   } else {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(backbone_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipExtLaunchKernelGGL(backbone_kernel<false>, grid, dim3(512), lds, (hipStream_t)stream, e0, e1, 0, a);
+    hipExtLaunchKernelGGL(backbone_kernel<false>, grid, dim3(512), lds, (hipStream_t)stream, e0, e1, 0, a, BackboneSave{});
   }
   return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
 }

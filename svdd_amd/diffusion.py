@@ -47,7 +47,11 @@ Engine knobs (attributes; defaults reproduce the reference's observable behaviou
   logits_cache     "auto" (default): SVDD-MC keeps a per-row logits cache when several sequences share a backbone tile
                    (L <= 104; at L = 200 one workgroup owns one sequence and skipping rows frees CUs but saves no
                    time); "on" / "off". (SVDD-PM always carries the selected candidate's logits forward.)
-  dps_single_forward  False (default): a DPS step runs the no-grad forward for q_xs AND the differentiable pass for the gradient,
+  dps_one_launch   True (default): the differentiable backbone pass of a DPS step (forward2 on one_hot(x_t) + its input gradient) is ONE
+                   launch each way (fp32, CNN backbone, 104 < L <= 208): the forward is the inference kernel bit for bit, so its logits
+                   also give q_xs and the reference's second, identical forward (:1306 vs :1324) is not run. False: the layer-wise
+                   autograd path of round 3 (20 + 20 convolution launches and a pass per layer each way).
+  dps_single_forward  (only where the one-launch pair does not apply) False (default): a DPS step runs the no-grad forward for q_xs AND the differentiable pass for the gradient,
                    like the reference (:1306 and :1324 evaluate one function twice). True (opt-in): the differentiable pass
                    (forward2) also supplies the log-probs of q_xs — equal to round-off (~1e-6), so zero guidance is no longer
                    bit-for-bit the un-guided decode at near-ties.
@@ -169,6 +173,8 @@ class Diffusion(nn.Module):
         self.fuse_nets = True
         self.precision = "f32"
         self.skip_unchanged = True
+        self.dps_one_launch = True       # DPS: the differentiable backbone pass as one launch each way (svdd_backbone_cnn_save_f32 / _grad_f32) where it applies
+        self._dps_hard_onehot, self._dps_raw_logits = False, None
         self.dps_single_forward = False  # DPS opt-in: q_xs from the differentiable pass's log-probs, not from a second backbone forward per step
         self.logits_cache = "auto"
         self.skip_stats = None
@@ -448,7 +454,13 @@ class Diffusion(nn.Module):
         """Differentiable log score on a one-hot input (:359-377), used by the DPS baseline. Autograd
         must see every op, so the SUBS step is expressed in torch here."""
         sigma = self._process_sigma(sigma)
-        if isinstance(self.backbone, CNNModel):
+        fb = self._dps_one_launch(x_onehot) if self._dps_hard_onehot else None
+        if fb is not None:
+            # DPS: x_onehot IS one_hot(x) (:1308) — the whole backbone as ONE launch each way (forward = the inference kernel's
+            # bits + saved statistics, backward = svdd_backbone_cnn_grad_f32): no layer-wise launches, no saved activations rows
+            logits = fb.forward_with_grad(x_onehot, self._tokens_u8(x))
+            self._dps_raw_logits = logits.detach()
+        elif isinstance(self.backbone, CNNModel):
             # dilated convs on the hand-written kernel, both directions — for this call only (the flag does not outlive it:
             # a later backbone.forward2 by the user gets plain autograd unless asked otherwise)
             was = self.backbone.hip_convs
@@ -468,6 +480,14 @@ class Diffusion(nn.Module):
         unmasked = (x != self.mask_index)
         fixed = torch.full_like(logits, self.neg_infinity).scatter(-1, x.clamp(max=self.vocab_size - 1)[..., None], 0.0)
         return torch.where(unmasked[..., None], fixed, logits)
+
+    def _dps_one_launch(self, x_onehot):
+        """The fused backbone when the differentiable pass of a DPS step can run as one launch each way, else None."""
+        if not (self.fuse_nets and self.dps_one_launch and x_onehot.is_cuda and self.precision == "f32" and not self.time_conditioning
+                and isinstance(self.backbone, CNNModel) and not self.backbone.training):
+            return None
+        fb = self._fused_backbone_or_none(x_onehot.shape[1])
+        return fb if fb is not None and fb.grad_ok(x_onehot.shape[1]) else None
 
     def _sample_prior(self, *batch_dims):
         return self.mask_index * torch.ones(*batch_dims, dtype=torch.int64)          # :751-753
@@ -665,17 +685,29 @@ class Diffusion(nn.Module):
     def _dps_guided_q(self, x_u8, mcs, dm, reward_model, guidance_scale):
         """The guided transition weights q_xs of one DPS step (:1306-1314) -> fp32 [B, L, 5]."""
         B, L = x_u8.shape
-        if not self.dps_single_forward:
-            with torch.no_grad():
-                q_xs = torch.exp(ops.subs_logp(self._backbone_logits(x_u8), x_u8)) * float(dm)   # :1306-1307
         x = x_u8.long()
         copy_flag = (x != self.mask_index).to(x.dtype)
         x_onehot = F.one_hot(x, num_classes=self.vocab_size).float()                          # :1308
+        # The reference evaluates the backbone twice per step on the same x_t (forward() for q_xs, :1306 ; forward2() inside the
+        # gradient, :1324). With the one-launch pair the differentiable forward IS the inference kernel, bit for bit (same kernel
+        # template, plus stores): its raw logits serve both, through the same SUBS kernel — zero guidance stays bit-for-bit the
+        # un-guided decode (tests/test_configs_gpu.py), and the second, identical forward is not run.
+        one_launch = self._dps_one_launch(x_onehot) is not None
+        if not self.dps_single_forward and not one_launch:
+            with torch.no_grad():
+                q_xs = torch.exp(ops.subs_logp(self._backbone_logits(x_u8), x_u8)) * float(dm)   # :1306-1307
         sigma = torch.zeros(B, device=x.device)
-        with torch.enable_grad():
-            x_grad = self.compute_gradient_DPS(x_onehot, x, reward_model, sigma, copy_flag)   # :1310
+        self._dps_hard_onehot = True
+        try:
+            with torch.enable_grad():
+                x_grad = self.compute_gradient_DPS(x_onehot, x, reward_model, sigma, copy_flag)   # :1310
+        finally:
+            self._dps_hard_onehot = False
         with torch.no_grad():
-            if self.dps_single_forward:
+            if one_launch:
+                q_xs = torch.exp(ops.subs_logp(self._dps_raw_logits, x_u8)) * float(dm)       # :1306-1307 on the very same logits
+                self._dps_raw_logits = self._dps_logp = None
+            elif self.dps_single_forward:
                 # The reference evaluates the backbone twice per step on the same x_t with the same (zeroed) sigma: forward() for
                 # q_xs (:1306) and forward2() inside the gradient (:1324). They are one function; the differentiable pass's log-probs
                 # are taken for both (round-off apart: ~1e-6, far inside the 1e-3 .. 1e-2 that the gradient's own ReLU decisions

@@ -320,6 +320,94 @@ def _backbone_split_workspace(dev):
     return _BB_SPLIT_WS[key]
 
 
+def pack_backbone_grad(cnn):
+    """CNNModel -> the operand images of svdd_backbone_cnn_grad_f32 (the input gradient of the whole backbone in one launch, DPS):
+    dict(tiles_bwd, gamma). The backward-data pass of a 'same'-padded stride-1 dilated convolution is the same convolution with the
+    taps flipped and the channel axes swapped, so the tiles are pack_backbone's layout of W'[ci][co][t] = W[co][ci][8 - t] — in
+    PROCESSING order: W_f1^T (the first 1x1 of final_conv) as [4][128][32], then layer nl - 1 down to 0 as [4][9][128][32]."""
+    H = cnn.args.hidden_dim
+    assert H == 128 and cnn.alphabet_size == 5 and cnn.linear.kernel_size[0] == 9
+    with torch.no_grad():
+        wf1t = cnn.final_conv[0].weight.detach().float()[:, :, 0].t().contiguous()        # [ci][co]: output channel of the transpose first
+        parts = [wf1t.view(H, 4, 32).permute(1, 0, 2).reshape(-1)]
+        for conv in reversed(list(cnn.convs)):
+            wt = conv.weight.detach().float().flip(2).transpose(0, 1).contiguous()         # [ci][co][t']
+            parts.append(wt.view(H, 4, 32, 9).permute(1, 3, 0, 2).reshape(-1))            # [c][t][ci][k]
+        gamma = torch.stack([n.weight.detach().float() for n in cnn.norms]).contiguous()
+    return dict(tiles_bwd=torch.cat(parts).contiguous(), gamma=gamma)
+
+
+def backbone_cnn_save(tokens, pk):
+    """The one-launch forward (the inference kernel's bits) that also leaves what the gradient kernel needs, in its lane-private
+    layout (svdd_backbone_cnn_save_f32): tokens [n, L] u8, 104 < L <= 208 -> (logits [n, L, 5], (xhat, rstd, mask))."""
+    assert tokens.is_cuda and tokens.dtype == torch.uint8 and tokens.is_contiguous()
+    n, L = tokens.shape
+    nl = len(pk["dil"])
+    dev = tokens.device
+    out = torch.empty((n, L, 5), dtype=torch.float32, device=dev)
+    xhat = torch.empty((n, nl, 56, 512), dtype=torch.float32, device=dev)
+    rstd = torch.empty((n, nl, 208), dtype=torch.float32, device=dev)
+    mask = torch.empty((n, nl + 2, 512), dtype=torch.int64, device=dev)
+    dil = (ctypes.c_int * nl)(*pk["dil"])
+    rc = _lib.lib().svdd_backbone_cnn_save_f32(tokens.data_ptr(), pk["table0"].data_ptr(), pk["tiles"].data_ptr(), pk["vec"].data_ptr(),
+                                               pk["w2"].data_ptr(), out.data_ptr(), n, L, nl, dil, xhat.data_ptr(), rstd.data_ptr(),
+                                               mask.data_ptr(), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    _lib.check(rc, "svdd_backbone_cnn_save_f32")
+    return out, (xhat, rstd, mask)
+
+
+def backbone_cnn_grad(dlogits, pk, pkg, saved):
+    """d loss / d onehot(x) [n, L, 5] from d loss / d logits [n, L, 5] through the whole backbone, one launch
+    (svdd_backbone_cnn_grad_f32); `saved` from backbone_cnn_save of the same tokens."""
+    xhat, rstd, mask = saved
+    n, L, _ = dlogits.shape
+    nl = len(pk["dil"])
+    g = dlogits.contiguous().float()
+    dx = torch.empty((n, L, 5), dtype=torch.float32, device=g.device)
+    dil = (ctypes.c_int * nl)(*pk["dil"])
+    rc = _lib.lib().svdd_backbone_cnn_grad_f32(g.data_ptr(), pkg["tiles_bwd"].data_ptr(), pkg["gamma"].data_ptr(), pk["w2"].data_ptr(),
+                                               pk["table0"].data_ptr(), xhat.data_ptr(), rstd.data_ptr(), mask.data_ptr(), dx.data_ptr(),
+                                               n, L, nl, dil, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    _lib.check(rc, "svdd_backbone_cnn_grad_f32")
+    return dx
+
+
+def decode_backbone_masks(mask, L):
+    """The ReLU decisions backbone_cnn_save left (int64 [n, nl + 2, 512], lane-private bits) as bool [n, nl + 2, L, 128] (tests)."""
+    n, K, _ = mask.shape
+    tid = torch.arange(512, device=mask.device)
+    w, lane = tid >> 6, tid & 63
+    cg, rh, j, g = w & 3, w >> 2, lane & 15, lane >> 4
+    out = torch.zeros((n, K, 208, 128), dtype=torch.bool, device=mask.device)
+    for r in range(7):
+        for ct in range(2):
+            for e in range(4):
+                row = 16 * (rh + 2 * r) + 4 * g + e
+                col = 32 * cg + j + 16 * ct
+                ok = row < 208
+                bit = ((mask >> ((r * 2 + ct) * 4 + e)) & 1).bool()                     # [n, K, 512]
+                out[:, :, row[ok], col[ok]] = bit[:, :, ok]
+    return out[:, :, :L]
+
+
+class BackboneOneLaunchFunction(torch.autograd.Function):
+    """CNNModel.forward2 on a HARD one-hot input (the DPS case: x_onehot = one_hot(x_t), diffusion_gosai.py:1308) as one launch
+    each way: forward = the inference kernel's bits + saved x-hat / rstd / ReLU decisions, backward = the input gradient through all
+    20 layers (svdd_backbone_cnn_grad_f32). Weights frozen: the only gradient is the one with respect to `x_onehot`."""
+
+    @staticmethod
+    def forward(ctx, x_onehot, tokens, pk, pkg):
+        logits, saved = backbone_cnn_save(tokens, pk)
+        ctx.pk, ctx.pkg, ctx.saved = pk, pkg, saved
+        return logits
+
+    @staticmethod
+    def backward(ctx, g):
+        dx = backbone_cnn_grad(g, ctx.pk, ctx.pkg, ctx.saved)
+        ctx.saved = None
+        return dx, None, None, None
+
+
 def check_backbone_split():
     """Raises if a group barrier of a small-batch backbone launch (several workgroups per sequence) timed out since the last
     check: its logits were computed from a partly exchanged image. Reads one int from the device (synchronises) — only after a
@@ -826,11 +914,25 @@ class FusedBackbone(nn.Module):
         self.precision = "f32"          # or one of LP_DTYPES: the one-launch kernel on the 16-bit matrix cores
         self._cnn = (cnn,)
         self._lp = {}
+        self._grad_pack = None
         if self.one_launch:
             pk = pack_backbone(cnn)
             self.ol_dil = pk.pop("dil")
             for k, v in pk.items():
                 self.register_buffer("ol_" + k, v, persistent=False)
+
+    def ol_pack(self):
+        return dict(table0=self.ol_table0, tiles=self.ol_tiles, vec=self.ol_vec, w2=self.ol_w2, dil=self.ol_dil)
+
+    def grad_ok(self, L):
+        """True when the differentiable pass (DPS) can run as one launch each way: the one-launch kernel, one sequence per tile."""
+        return self.one_launch and self.use_one_launch and self.precision == "f32" and 104 < L <= 208
+
+    def forward_with_grad(self, x_onehot, tokens):
+        """Raw logits [n, L, 5] with autograd to `x_onehot` [n, L, 5], which must be the hard one-hot of `tokens` [n, L] u8."""
+        if self._grad_pack is None:
+            self._grad_pack = {k: v.to(self.ol_tiles.device) for k, v in pack_backbone_grad(self._cnn[0]).items()}
+        return BackboneOneLaunchFunction.apply(x_onehot, tokens.contiguous(), self.ol_pack(), self._grad_pack)
 
     def kernel_ok(self, L):
         """True when a forward of length-L sequences is the one-launch kernel (the work-skipping paths need it: they

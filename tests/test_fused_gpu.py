@@ -505,3 +505,57 @@ def test_backbone_forward2_on_the_hip_conv_kernel_both_directions(B, L):
     # ... and with free ReLU decisions the three gradients agree wherever no decision differs: the typical element is at round-off
     for k in ((True, False), (True, True)):
         assert float((res[k][1] - res[False, False][1]).abs().median()) <= 2e-6 * scale, k
+
+
+@pytest.mark.parametrize("B", [3, 37])
+def test_backbone_one_launch_forward_with_saved_statistics_and_its_gradient_kernel(B):
+    """The DPS pair of round 5 (reference diffusion_gosai.py:1321-1330 through models/dnaconv.py:212-247 on one_hot(x_t)):
+    svdd_backbone_cnn_save_f32 must give the inference kernel's logits BIT FOR BIT (it is the same kernel plus stores), and
+    svdd_backbone_cnn_grad_f32 the gradient with respect to the one-hot input — against torch autograd in fp64 over the plain
+    modules with the ReLU decisions pinned to the ones the forward kernel took (decoded from its saved masks; a gradient through
+    20 ReLU layers is discontinuous in the pre-activations, see the test above)."""
+    from svdd_amd import backbone, config, fused
+    import torch.nn.functional as F
+    L = 200
+    torch.manual_seed(B)
+    cnn = backbone.CNNModel(config.dna_config().model, alphabet_size=5).to(DEV).eval()
+    with torch.no_grad():
+        for nm in cnn.norms:
+            nm.weight.uniform_(0.5, 1.5)
+            nm.bias.uniform_(-0.3, 0.3)
+    for p in cnn.parameters():
+        p.requires_grad_(False)
+    fb = fused.FusedBackbone(cnn).to(DEV).eval()
+    assert fb.grad_ok(L)
+    tok = torch.randint(0, 5, (B, L), device=DEV, dtype=torch.uint8)
+    tok[0] = 4                                                                    # an all-MASK row
+    pk = fb.ol_pack()
+    ref = fused.backbone_cnn(tok, pk)
+    logits, saved = fused.backbone_cnn_save(tok, pk)
+    assert torch.equal(logits, ref)
+    g = torch.randn(B, L, 5, device=DEV)
+    onehot = F.one_hot(tok.long(), 5).float().requires_grad_(True)
+    out = fb.forward_with_grad(onehot, tok)
+    assert torch.equal(out.detach(), ref)
+    (out * g).sum().backward()
+    got = onehot.grad.clone()
+    # fp64 reference with pinned ReLU decisions
+    masks = fused.decode_backbone_masks(saved[2], L).double()                     # [B, nl + 2, L, 128]
+    c64 = __import__("copy").deepcopy(cnn).double()
+    c64.clear_time_bias_cache()
+    xi = F.one_hot(tok.long(), 5).double().requires_grad_(True)
+    with torch.backends.cudnn.flags(enabled=False):
+        tbs = c64._time_biases(torch.zeros(B, device=DEV, dtype=torch.float64))
+        feat = c64.linear(xi.permute(0, 2, 1)).permute(0, 2, 1) * masks[:, 0]
+        nl = c64.num_layers
+        for i in range(nl):
+            h = F.layer_norm(feat + tbs[i].transpose(1, 2), (128,), c64.norms[i].weight, c64.norms[i].bias, c64.norms[i].eps)
+            feat = c64.convs[i](h.permute(0, 2, 1)).permute(0, 2, 1) * masks[:, 1 + i] + feat
+        h1 = c64.final_conv[0](feat.permute(0, 2, 1)).permute(0, 2, 1) * masks[:, nl + 1]
+        out64 = c64.final_conv[2](h1.permute(0, 2, 1)).permute(0, 2, 1)
+    assert float((out64.detach() - ref.double()).abs().max()) <= 2e-5             # the pinned fp64 forward is the kernel's function
+    (out64 * g.double()).sum().backward()
+    want = xi.grad
+    scale = max(1.0, float(want.abs().max()))
+    err = float((got.double() - want).abs().max())
+    assert err <= 5e-5 * scale, (err, scale)

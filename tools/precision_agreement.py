@@ -10,6 +10,9 @@ Per mode ("f16x3", "bf16x3", "f16", "bf16") two measurements:
                  how often the fp32 kernels' and each mode's argmax-over-M selection equals the fp64 one, and the max
                  score error against fp64. (Agreement WITH the fp32 kernels measures closeness to one particular
                  rounding; agreement with fp64 measures closeness to the function itself.)
+  logits vs fp64 (round 5) the BACKBONE's raw logits on the same states against the PyTorch backbone evaluated in fp64 (B x L x 5 values per
+                 state): max |error| of the exact-fp32 kernel and of every mode — whether f16x3 is "narrower than the reference's fp32"
+                 is then a measurement, not a label. Plus the PyTorch fp32 modules (the reference's own arithmetic on this GPU).
 Random-init nets give near-tied scores (the worst case for exactness), so a trajectory that
 diverges at one row keeps diverging there; rows are independent, so the row-level numbers are the informative ones.
 Usage: python tools/precision_agreement.py [B] > profiles/rNN_precision_agreement.json"""
@@ -47,18 +50,28 @@ with torch.no_grad():
     # fp64 yardstick on the fp32 trajectory's states (every 16th step)
     import copy
     emb64, head64 = copy.deepcopy(emb).double(), copy.deepcopy(head).double()
+    bb64 = copy.deepcopy(model.backbone).double()
+    bb64.clear_time_bias_cache()
     model.precision = "f32"
-    tf = {}
+    tf, lg64 = {}, {}
+    err_torch32 = 0.0
     for i in range(0, S, 16):
         x = st_ref[i]
         lg_ref, sc_ref = tr_ref[i]
         cand, onehot, _ = ops.propose(lg_ref, x, sched[i, 2], sched[i, 1], M, model._rng(i, M, B, L, lg_ref))
         with torch.backends.cudnn.flags(enabled=False):
             sc64 = head64(emb64(onehot.double())).reshape(B, M)
+            lg64[i] = bb64(x.long(), torch.zeros(B, device=dev, dtype=torch.float64))          # fp64 backbone forward on the fp32 trajectory's state
+        err_torch32 = max(err_torch32, float((model.backbone(x.long(), torch.zeros(B, device=dev)).double() - lg64[i]).abs().max()))
         tf[i] = (cand.clone(), onehot.clone(), sc64)
+    report["logits_scale"] = {"max_abs_logit": max(float(v.abs().max()) for v in lg64.values()),
+                              "states": len(lg64), "values_per_state": B * L * 5}
+    report["pytorch_fp32_modules_vs_fp64"] = {"max_abs_logit_err": err_torch32,
+                                              "note": "the plain PyTorch-ROCm fp32 modules (MIOpen convs) on the same states: the reference's own arithmetic on this GPU"}
     report["fp32_vs_fp64"] = {
         "max_abs_score_err": max(float((tr_ref[i][1].double() - tf[i][2]).abs().max()) for i in tf),
-        "selection_agreement_mean": sum(float((tr_ref[i][1].argmax(1) == tf[i][2].argmax(1)).float().mean()) for i in tf) / len(tf)}
+        "selection_agreement_mean": sum(float((tr_ref[i][1].argmax(1) == tf[i][2].argmax(1)).float().mean()) for i in tf) / len(tf),
+        "max_abs_logit_err": max(float((tr_ref[i][0].double() - lg64[i]).abs().max()) for i in lg64)}
     for mode in ("f16x3", "bf16x3", "f16", "bf16"):
         x0, st, tr = decode(mode)
         rows_same = [float((a == b).all(dim=1).float().mean()) for a, b in zip(st, st_ref)]
@@ -88,7 +101,14 @@ with torch.no_grad():
             sc = model._value_scores(emb, head, onehot, B, M, cand, st_ref[i])
             e64 = max(e64, float((sc.double() - sc64).abs().max()))
             a64.append(float((sc.argmax(1) == sc64.argmax(1)).float().mean()))
+        report["modes"][mode]["vs_fp64_max_abs_logit_err"] = max(float((model._backbone_logits(st_ref[i]).double() - lg64[i]).abs().max()) for i in lg64)
         report["modes"][mode]["vs_fp64_max_abs_score_err"] = e64
         report["modes"][mode]["vs_fp64_selection_agreement_mean"] = sum(a64) / len(a64)
     model.precision = "f32"
+    # the compact form bench.py carries in its line (`precision_evidence`)
+    report["summary"] = {"f32": {"vs_fp64_logit_err": report["fp32_vs_fp64"]["max_abs_logit_err"],
+                                 "vs_fp64_score_err": report["fp32_vs_fp64"]["max_abs_score_err"], "x0_rows_identical_vs_f32": 1.0}}
+    for mode, r in report["modes"].items():
+        report["summary"][mode] = {"vs_fp64_logit_err": r["vs_fp64_max_abs_logit_err"], "vs_fp64_score_err": r["vs_fp64_max_abs_score_err"],
+                                   "x0_rows_identical_vs_f32": r["final_x0_rows_identical"]}
 print(json.dumps(report, indent=1))
