@@ -86,7 +86,7 @@ def backbone_flops(n, L, H=128):
 
 
 PROFILE_SLOTS = {"propose": 0, "select": 1, "conv1d": 2, "gru": 3, "epilogue_ln": 4, "conv_tower": 5, "backbone_cnn": 6,
-                 "value_tail": 7, "tds_resample": 8}
+                 "value_tail": 7, "tds_resample": 8, "backbone_grad": 10}
 
 
 def timed_decodes(run, steps, check):
@@ -215,13 +215,22 @@ def config5_leg(dev, steps=1, alt="f16x3", B=256, L=200, S=128, population=2048,
         out["dps"] = {"workload": f"DNA enhancer DPS (gradient guidance), batch={B}, L={L}, {S} steps, guidance scale 10, ConvGRU reward (BASELINE.json configs[4])",
                       "value": round(B / el, 3), "unit": "sequences/s", "n_gpus": 1, "steps": dps_steps, "ms_per_step": round(el * 1e3, 3),
                       "dtype": "f32", "own_kernels_ms_per_decode": {k: round(v[0], 3) for k, v in prof.items() if v[1]}}
-        if conv_n:
+        g_ms, g_n = prof["backbone_grad"]
+        f_ms, f_n = prof["backbone_cnn"]
+        if g_n:
+            # one launch each way (round 5): the gradient kernel is the dominant one; its useful FLOPs are the forward's (every
+            # product of the forward has one transposed twin: 20 dilated convs, the 1x1 128 -> 128, the 128 -> 5 and the first conv)
+            out["dps"]["roofline"] = _mfma_roofline(
+                "backbone_grad_kernel (svdd_backbone_cnn_grad_f32: d loss / d onehot(x_t) through 2 x 1x1 + 20 x [ReLU', transposed dilated "
+                "conv, LayerNorm backward, residual] + the first conv's transpose, one launch)",
+                backbone_flops(B, L) * g_n, g_ms, g_n, avg_launch_us=round(g_ms / g_n * 1e3, 2))
+            out["dps"]["rooflines"] = {"forward_save": _mfma_roofline(
+                "backbone_kernel<save> (svdd_backbone_cnn_save_f32: the inference kernel's bits + x-hat / rstd / ReLU decisions saved; also serves q_xs)",
+                backbone_flops(B, L) * f_n, f_ms, f_n, avg_launch_us=round(f_ms / max(f_n, 1) * 1e3, 2))}
+        elif conv_n:
             out["dps"]["roofline"] = _mfma_roofline(
                 "conv1d_cl_static_kernel<128,128,9,dil,200> (the 20 dilated convs of the differentiable backbone pass, forward and backward-data)",
                 conv_flops / 20.0 * conv_n, conv_ms, conv_n, avg_launch_us=round(conv_ms / conv_n * 1e3, 2))
-        dps_extra = globals().get("dps_kernel_rooflines")
-        if dps_extra is not None:
-            out["dps"].update(dps_extra(prof, B, L, S))
         del model, rew
         torch.cuda.empty_cache()
     except Exception as e:                                     # noqa: BLE001
@@ -238,7 +247,7 @@ def roofline_also(line):
     def add(src, kernel, where, r, ms_key="kernel_ms_per_decode"):
         if not isinstance(r, dict) or "frac" not in r:
             return
-        e = {"kernel": kernel, "where": where, "bound": r.get("bound"), "frac": r["frac"], "from": src}
+        e = {"kernel": kernel, "where": where, "bound": r.get("bound") or ("hbm" if r.get("unit") == "GB/s" else "mfma"), "frac": r["frac"], "from": src}
         if "issued_frac" in r:
             e["issued_frac"] = r["issued_frac"]
         if r.get(ms_key) is not None:
@@ -524,20 +533,26 @@ def config4_f32(model, emb, head, dev, steps, B, L, M, S):
         return {"error": f"{type(e).__name__}: {e}"}
 
 
-def cpu_thread_sweep(model, B, L, candidates=(8, 16, 32, 64, 128)):
-    """Seconds per backbone forward at full batch for each torch thread count that fits this host (one warm-up + one timed forward
-    each): the CPU baseline then runs at the fastest. Recorded inside `cpu_baseline` so that `cores` is justified in the same record
-    (on the GPU box's 2 x EPYC 9575F more threads than 16 are slower: the 3.3 M-parameter convs are small per core)."""
+def cpu_thread_sweep(model, emb, head, B, L, M, candidates=(8, 16, 32, 64)):
+    """Seconds per diffusion step of the CPU port's nets at full batch (one backbone forward + M value-net calls of batch B, the
+    99 % of a reference step) for each torch thread count that fits this host — one warm-up (backbone + one value call) and one
+    timed step each: the CPU baseline then runs at the fastest. Recorded inside `cpu_baseline` so that `cores` is justified in the
+    same record (on the GPU box's 2 x EPYC 9575F more threads than 16 are slower: these nets are small per core)."""
     ncpu = os.cpu_count() or 1
     x = torch.full((B, L), 4, dtype=torch.int64)
+    oh = torch.zeros(B, L, 4)
+    oh[:, ::2, 1] = 1.0
     sweep = {}
-    for t in sorted({min(c, ncpu) for c in candidates}):
-        torch.set_num_threads(t)
-        with torch.no_grad():
+    with torch.no_grad():
+        for t in sorted({min(c, ncpu) for c in candidates}):
+            torch.set_num_threads(t)
             model.backbone(x, torch.zeros(B))
+            head(emb(oh))
             t0 = time.perf_counter()
             model.backbone(x, torch.zeros(B))
-        sweep[t] = round(time.perf_counter() - t0, 4)
+            for _ in range(M):
+                head(emb(oh))
+            sweep[t] = round(time.perf_counter() - t0, 4)
     return sweep
 
 
@@ -552,7 +567,7 @@ def cpu_baseline(B, L, M, S, sample_steps, seed=44, threads=None, states=None, p
     model, emb, head, _ = synthetic.build("dna" if L == 200 else "rna", "cpu", seed=seed)
     sweep = None
     if threads is None:
-        sweep = cpu_thread_sweep(model, B, L)
+        sweep = cpu_thread_sweep(model, emb, head, B, L, M)
         threads = min(sweep, key=sweep.get)
     threads = max(1, min(threads, os.cpu_count() or 1))
     torch.set_num_threads(threads)
@@ -592,8 +607,8 @@ def cpu_baseline(B, L, M, S, sample_steps, seed=44, threads=None, states=None, p
     return {
         "value": round(B / per_decode, 4), "unit": "sequences/s", "cores": threads,
         "cpu_model": cpu_model, "cores_total": cpu_total,
-        "thread_sweep": None if sweep is None else {"s_per_backbone_forward_by_threads": sweep, "chosen": threads,
-                                                    "note": "torch.set_num_threads(t), one backbone forward at full batch after a warm-up; the baseline runs at the fastest"},
+        "thread_sweep": None if sweep is None else {"s_per_step_of_the_nets_by_threads": sweep, "chosen": threads,
+                                                    "note": "torch.set_num_threads(t): one backbone forward + M value-net calls at full batch after a warm-up; the baseline runs at the fastest"},
         "kind": "port", "passes": len(per_pass), "seq_per_s_each_pass": [round(B / t, 4) for t in per_pass],
         "sample": f"median of {len(per_pass)} passes over {sample_steps} of {S} diffusion steps (evenly spaced, on the {'states of a GPU decode of this workload' if states is not None else 'synthetic states'}) "
                   f"at full batch (B={B}, L={L}, M={M}) + the noise-removal forward, scaled by {S}/{sample_steps} to one decode; "

@@ -638,6 +638,13 @@ class Diffusion(nn.Module):
         # recurrent module falls back to the native cells.
         # ... and where the GRU is the reward net's 64-unit bidirectional one, neither is used: the recurrence runs on the
         # hand-written forward + BPTT kernels (csrc/svdd_gru_train.hip; 35.9 -> ~1 ms of the gradient at B = 256).
+        fn = self.reward_callable(reward_model) if (self.fuse_nets and self.dps_one_launch and x_onehot.is_cuda) else None
+        from .fused import FusedValueNet
+        if isinstance(fn, FusedValueNet) and fn.grad_ok(x_onehot.shape[1]):
+            # the reward net without MIOpen (round 5): convolutions on svdd_conv1d_cl_f32 both ways, GRU on the BPTT kernels
+            scores = fn.forward_grad(probs[:, :, 0:4].contiguous())[:, 0]
+            scores.mean().backward()
+            return x_onehot.grad.clone()
         hip = self._hip_gru_blocks(reward_model) if (self.fuse_nets and x_onehot.is_cuda) else []
         taken = {id(b.gru) for b in hip}
         rnns = [m for m in reward_model.modules() if isinstance(m, torch.nn.RNNBase) and id(m) not in taken]

@@ -742,6 +742,8 @@ class FusedValueNet(nn.Module):
         self._stem_w_raw = stem.weight.detach()
         self._folded_ws = [w.detach() for w in folded_ws]
         self._lp = {}
+        self._grad_packs = None
+        self._ln_eps = d1.norm.layer.eps
 
     def lp_ok(self, L):
         return self.precision != "f32" and self.tower_ok and self.tail_ok and L <= 208
@@ -770,6 +772,37 @@ class FusedValueNet(nn.Module):
             return self._after_tower_lp(seq, pk, count)
         seq = conv_tower(ops.transform_samples(tok.contiguous()), self.tw_tiles, self.tw_bias, self.tw_resmask, count)
         return self._after_tower(seq, tok.shape[0], tok.shape[1], count)
+
+    def grad_ok(self, L):
+        """True when forward_grad applies: the reference-shaped net in fp32 at a length the static 64 -> 64 conv kernel has."""
+        return (self.tower_ok and self.tail_ok and self.precision == "f32" and L in (200, 50) and
+                all(p.numel() for p in self.wpacks))
+
+    def forward_grad(self, x):
+        """Scores [n, n_tasks, 1] of a RELAXED input x [n, L, 4] (fp32, e.g. softmax probabilities) WITH autograd to x — the reward
+        call of the DPS baseline (reference diffusion_gosai.py:1326-1329: reward_model(softmax(E[x0 | x_t]))) without MIOpen: the
+        stem as unfold + matmul, every 64 -> 64 x 5 convolution on svdd_conv1d_cl_f32 in both directions (DilatedConvFunction;
+        eval-mode BatchNorm folded), the GRU on the hand-written forward + BPTT kernels (GruBidirFunction), the element-wise ops
+        and the tail left to torch autograd on channels-last rows. MIOpen served these small convolutions' backward passes as
+        im2col + one GEMM per sample (2.7 ms of a 8.3 ms DPS step at B = 256). Weights frozen: input gradient only."""
+        n, L, _ = x.shape
+        if self._grad_packs is None:
+            dev = self.tw_bias.device
+            w_stem = self._stem_w_raw.to(dev).float().permute(2, 1, 0).reshape(-1, self._stem_w_raw.shape[0]).contiguous()   # [4 t + c][co]
+            packs_t = [pack_conv(w.to(dev).float().flip(2).transpose(0, 1).contiguous()) for w in self._folded_ws]
+            self._grad_packs = (w_stem, packs_t, pack_gru_bwd(self._gru_mod[0]).to(dev))
+        w_stem, packs_t, gru_bwd = self._grad_packs
+        T = self._stem_w_raw.shape[2]
+        xp = F.pad(x, (0, 0, T // 2, T // 2))
+        cols = torch.cat([xp[:, k:k + L] for k in range(T)], dim=2)                          # [n, L, 4 T], tap-major
+        f = F.relu(cols @ w_stem + self.stem_b)
+        for wp, wpt, b, res in zip(self.wpacks, packs_t, self.bs, self.residual):
+            c = DilatedConvFunction.apply(f, wp, wpt, 64, 64, 5, 1) + b
+            f = F.relu(c + f) if res else F.relu(c)
+        y2 = GruBidirFunction.apply(f, self.wpack, self.bpack, gru_bwd)
+        hn = F.layer_norm(y2[0] + y2[1], (64,), self.ln_w, self.ln_b, self._ln_eps)
+        z = F.relu(F.linear(hn, self.w1, self.b1))
+        return ((z @ self.w_eff).mean(dim=1) + self.b_eff)[:, :, None]
 
     def kernels_ok(self, L):
         """True when the whole net runs on the hand-written kernels (tower, GRU, tail) for sequences of length L."""

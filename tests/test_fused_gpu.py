@@ -559,3 +559,30 @@ def test_backbone_one_launch_forward_with_saved_statistics_and_its_gradient_kern
     scale = max(1.0, float(want.abs().max()))
     err = float((got.double() - want).abs().max())
     assert err <= 5e-5 * scale, (err, scale)
+
+
+@pytest.mark.parametrize("B,task", [(6, "dna"), (5, "rna")])
+def test_value_net_forward_grad_vs_torch_autograd(B, task):
+    """FusedValueNet.forward_grad — the DPS reward call on a RELAXED input (reference diffusion_gosai.py:1326-1329) with the convolutions
+    on svdd_conv1d_cl_f32 in both directions and the GRU on the BPTT kernels — against torch autograd through the plain modules
+    (native GRU cells): scores and the gradient with respect to the input."""
+    from svdd_amd import synthetic
+    model, _, _, reward = synthetic.build(task, DEV)
+    L = model.config.model.length
+    fn = model.reward_callable(reward)
+    assert fn.grad_ok(L)
+    torch.manual_seed(B)
+    x = torch.softmax(2.0 * torch.randn(B, L, 5, device=DEV), dim=-1)[:, :, :4].contiguous()
+    xa = x.clone().requires_grad_(True)
+    sa = fn.forward_grad(xa)
+    sa[:, 0].mean().backward()
+    xb = x.clone().requires_grad_(True)
+    with torch.backends.cudnn.flags(enabled=False):
+        sb = reward(xb.transpose(1, 2))
+    sb[:, 0].mean().backward()
+    assert sa.shape == sb.shape
+    assert float((sa - sb).abs().max()) <= 2e-5, float((sa - sb).abs().max())
+    scale = float(xb.grad.abs().max())
+    err = float((xa.grad - xb.grad).abs().max())
+    assert err <= 5e-4 * scale, (err, scale)
+    assert float((xa.grad - xb.grad).abs().median()) <= 2e-5 * scale
