@@ -1395,6 +1395,7 @@ struct BackboneArgs {
   const int* row_idx;      // [count] (NULL: identity): compact row r reads the tokens of sequence row_idx[r] of x ...
   int out_scatter;         // ... and writes its logits to row row_idx[r] of out (1) or to row r (0)
   int auto_spt, ncu;       // auto_spt: the workgroups pick the sequences per tile from the device-side row count (svdd_spt.h)
+  SvddTilePlan plan;       // several sequences per tile, row count known on the host: which tile takes how many (svdd_spt.h)
 };
 
 // What the gradient kernel (backbone_grad_kernel, DPS) needs from a forward, all in the forward kernel's LANE-PRIVATE layout — lane
@@ -1448,9 +1449,16 @@ __global__ __launch_bounds__(512, 2) void backbone_kernel(BackboneArgs a, Backbo
   const int col0 = 32 * cg + j;                           // this lane's columns: col0 and col0 + 16
   const int L = a.L;
   const int nvalid = a.count ? __builtin_amdgcn_readfirstlane(*a.count) : a.n;
-  const int spt = (!SPT1 && a.auto_spt) ? __builtin_amdgcn_readfirstlane(svdd_choose_spt(nvalid, L, a.ncu, 3)) : a.spt;
+  int seq0 = blockIdx.x, spt = 1;                         // this tile's first sequence and how many it takes
+  if (!SPT1) {
+    SvddTilePlan pl = a.plan;
+    if (a.auto_spt) pl = svdd_plan_tiles(nvalid, L, a.ncu, 3);
+    svdd_plan_tile(pl, (int)blockIdx.x, seq0, spt);
+    seq0 = __builtin_amdgcn_readfirstlane(seq0);
+    spt = __builtin_amdgcn_readfirstlane(spt);
+  }
   const int tile_rows = spt * L;
-  const int64_t row0 = (int64_t)blockIdx.x * tile_rows;
+  const int64_t row0 = (int64_t)seq0 * L;
   const int64_t total_rows = (int64_t)nvalid * L;
   if (row0 >= total_rows) return;
   const int nl = a.nl;
@@ -1460,7 +1468,7 @@ __global__ __launch_bounds__(512, 2) void backbone_kernel(BackboneArgs a, Backbo
   for (int e = tid; e < TW_ROWS; e += 512) {
     int tk = -1;
     if (e < tile_rows && row0 + e < total_rows) {
-      if (a.row_idx) { const int sq = e / L; tk = a.x[(int64_t)a.row_idx[blockIdx.x * spt + sq] * L + (e - sq * L)]; }
+      if (a.row_idx) { const int sq = e / L; tk = a.x[(int64_t)a.row_idx[seq0 + sq] * L + (e - sq * L)]; }
       else tk = a.x[row0 + e];
     }
     toks[e] = tk;
@@ -1791,7 +1799,7 @@ __global__ __launch_bounds__(512, 2) void backbone_kernel(BackboneArgs a, Backbo
     float sm = a.w2[5 * BB_C + v];
 #pragma unroll 8
     for (int k = 0; k < BB_C; ++k) sm += hr[k] * wv[k];
-    if (a.row_idx && a.out_scatter) { const int sq = row / L; a.out[((int64_t)a.row_idx[blockIdx.x * spt + sq] * L + (row - sq * L)) * 5 + v] = sm; }
+    if (a.row_idx && a.out_scatter) { const int sq = row / L; a.out[((int64_t)a.row_idx[seq0 + sq] * L + (row - sq * L)) * 5 + v] = sm; }
     else a.out[(row0 + row) * 5 + v] = sm;
   }
 }
@@ -2715,7 +2723,7 @@ extern "C" int svdd_backbone_cnn_save_f32(const uint8_t* x, const float* table0,
   BackboneArgs a;
   a.x = x; a.table0 = table0; a.tiles = tiles; a.vec = vec; a.w2 = w2; a.out = out;
   a.n = n; a.L = L; a.spt = 1; a.nl = nlayers; a.count = nullptr; a.row_idx = nullptr; a.out_scatter = 0;
-  a.auto_spt = 0; a.ncu = svdd_internal_num_cus();
+  a.auto_spt = 0; a.ncu = svdd_internal_num_cus(); a.plan = SvddTilePlan{1, 0, 1};
   for (int i = 0; i < BB_MAXL; ++i) a.dil[i] = i < nlayers ? dilations[i] : 1;
   for (int i = 0; i < nlayers; ++i) if (dilations[i] <= 0) return SVDD_E_ARG;
   const size_t lds = sizeof(float) * ((size_t)(TW_ROWS + 2) * BB_AP + 9 * 5 * (size_t)BB_C + 8 * (size_t)TW_ROWS +
@@ -2760,10 +2768,11 @@ extern "C" int svdd_backbone_cnn_f32(const uint8_t* x, const float* table0, cons
   a.n = n; a.L = L; a.spt = TW_ROWS / L; a.nl = nlayers; a.count = count; a.row_idx = row_idx; a.out_scatter = out_scatter;
   a.auto_spt = 0; a.ncu = svdd_internal_num_cus();
   unsigned nwg = (unsigned)((n + a.spt - 1) / a.spt);
-  if (a.spt > 1 && g_fixed_spt <= 0) {                   // several sequences fit a tile: how many to take (svdd_spt.h)
-    if (g_fixed_spt < 0) { a.spt = -g_fixed_spt < a.spt ? -g_fixed_spt : a.spt; nwg = (unsigned)((n + a.spt - 1) / a.spt); }
+  a.plan = SvddTilePlan{a.spt, 0, a.spt};                // every tile full (one sequence per tile: never read)
+  if (a.spt > 1 && g_fixed_spt <= 0) {                   // several sequences fit a tile: which tile takes how many (svdd_spt.h)
+    if (g_fixed_spt < 0) { a.spt = -g_fixed_spt < a.spt ? -g_fixed_spt : a.spt; a.plan = SvddTilePlan{a.spt, 0, a.spt}; nwg = (unsigned)((n + a.spt - 1) / a.spt); }
     else if (count) { a.auto_spt = 1; nwg = (unsigned)n; }   // decided on the device from *count; grid for one sequence per tile
-    else { a.spt = svdd_choose_spt(n, L, a.ncu, 3); nwg = (unsigned)((n + a.spt - 1) / a.spt); }
+    else { a.plan = svdd_plan_tiles(n, L, a.ncu, 3); a.spt = a.plan.s2; nwg = (unsigned)svdd_plan_num_tiles(a.plan, n); }
   }
   for (int i = 0; i < BB_MAXL; ++i) a.dil[i] = i < nlayers ? dilations[i] : 1;
   for (int i = 0; i < nlayers; ++i) if (dilations[i] <= 0) return SVDD_E_ARG;
@@ -2803,7 +2812,7 @@ extern "C" int svdd_backbone_cnn_f32(const uint8_t* x, const float* table0, cons
     }
   }
   const dim3 grid(nwg);
-  if (a.spt == 1 && !a.auto_spt) {
+  if (!a.auto_spt && a.plan.s2 == 1 && (a.plan.n1 == 0 || a.plan.s1 == 1)) {   // every tile holds one sequence
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(backbone_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipExtLaunchKernelGGL(backbone_kernel<true>, grid, dim3(512), lds, (hipStream_t)stream, e0, e1, 0, a, BackboneSave{});
   } else {

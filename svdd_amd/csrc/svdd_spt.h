@@ -27,3 +27,48 @@ __host__ __device__ inline int svdd_choose_spt(int n, int L, int ncu, int fixed)
   }
   return best;
 }
+
+// Round 5: TWO tile sizes per launch. With one size the launch costs whole rounds of it — 1100 live candidates of L = 50 are 367
+// tiles of three = 2 rounds x 13 units although the second round is 43 % full. A plan is k FULL rounds (k x CUs tiles) of s1
+// sequences followed by the remainder tiled at s2: 1100 = 256 tiles of four (16 units) + 76 single-sequence tiles (7 units) = 23.
+// The single size is the k = 0 plan, so a plan never costs more than svdd_choose_spt's choice under the same model. The workgroups
+// are dispatched in grid order, the large tiles first. A row's result does not depend on the plan.
+struct SvddTilePlan { int s1, n1, s2; };          // tiles 0 .. n1 - 1 take s1 sequences each, the tiles after them s2
+
+__host__ __device__ inline SvddTilePlan svdd_plan_tiles(int n, int L, int ncu, int fixed) {
+  const int smax = SVDD_TILE_ROWS / L;
+  SvddTilePlan best = {smax, 0, svdd_choose_spt(n, L, ncu, fixed)};
+  long long best_cost;
+  {
+    const long long tiles = (n + best.s2 - 1) / best.s2;
+    best_cost = ((tiles + ncu - 1) / ncu) * ((best.s2 * L + 15) / 16 + fixed);
+  }
+  for (int s1 = smax; s1 >= 1; --s1) {
+    const long long c1 = (s1 * L + 15) / 16 + fixed;
+    const long long per_round = (long long)s1 * ncu;
+    for (long long k = 1; k * per_round <= n; ++k) {
+      const long long r = n - k * per_round;
+      if (r == 0) {
+        if (k * c1 < best_cost) { best_cost = k * c1; best = {s1, (int)(k * ncu), s1}; }
+        continue;
+      }
+      for (int s2 = smax; s2 >= 1; --s2) {
+        const long long tiles2 = (r + s2 - 1) / s2;
+        const long long cost = k * c1 + ((tiles2 + ncu - 1) / ncu) * ((s2 * L + 15) / 16 + fixed);
+        if (cost < best_cost) { best_cost = cost; best = {s1, (int)(k * ncu), s2}; }
+      }
+    }
+  }
+  return best;
+}
+
+__host__ __device__ inline int svdd_plan_num_tiles(const SvddTilePlan& p, int n) {
+  const int rest = n - p.n1 * p.s1;
+  return p.n1 + (rest > 0 ? (rest + p.s2 - 1) / p.s2 : 0);
+}
+
+// first sequence and sequences of tile t
+__host__ __device__ inline void svdd_plan_tile(const SvddTilePlan& p, int t, int& seq0, int& ns) {
+  if (t < p.n1) { seq0 = t * p.s1; ns = p.s1; }
+  else { seq0 = p.n1 * p.s1 + (t - p.n1) * p.s2; ns = p.s2; }
+}

@@ -387,12 +387,13 @@ def test_tower_generations_bit_identical(nets, n, L):
     assert torch.equal(outs[1][0], outs[1][1])
 
 
-@pytest.mark.parametrize("n,L", [(256, 50), (1408, 50), (2560, 50), (37, 33), (700, 9), (3, 104)])
+@pytest.mark.parametrize("n,L", [(256, 50), (1100, 50), (1408, 50), (1650, 50), (2560, 50), (37, 33), (700, 9), (3, 104)])
 @pytest.mark.parametrize("mode", ["f32", "f16x3"])
 def test_backbone_sequences_per_tile_choice_same_bits(n, L, mode):
     """Short sequences (several fit a 208-row tile): the number a workgroup takes is chosen to minimise rounds x tile cost
     (csrc/svdd_spt.h) — on the host for a known row count, by the workgroups for a device-side count, with or without a
-    row index list. Every variant gives the bits of the always-full tiles of round 1."""
+    row index list; since round 5 the fp32 kernel may mix TWO tile sizes in one launch (full rounds of one size, the remainder at
+    another: 1100 sequences of L = 50 = 256 tiles of four + 76 of one). Every variant gives the bits of the always-full tiles of round 1."""
     from svdd_amd import _lib, backbone, config, fused
     torch.manual_seed(L)
     cnn = backbone.CNNModel(config.rna_config().model, alphabet_size=5).to(DEV).eval()

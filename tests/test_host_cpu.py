@@ -412,3 +412,41 @@ def test_generated_step_listings_are_in_sync_with_their_generator():
     for n in (13, 7, 6, 5, 4):                       # 4 chunks x n steps, each chunk requests the next weight tile exactly once
         body = block.split(f"#define LPT_TAP{n}(S)")[1].split("#define")[0]
         assert body.count("S(") == 4 * n and body.count("LPT_WLD0(") == 4
+
+
+def test_tile_plan_never_costs_more_than_one_tile_size(tmp_path):
+    """csrc/svdd_spt.h (host + device code): the two-size tile plan of the fp32 backbone covers every sequence exactly once, in
+    order, and under the header's own cost model never costs more than the best single tile size."""
+    import subprocess
+    src = tmp_path / "plan.cpp"
+    src.write_text(r'''
+#define __host__
+#define __device__
+#include <cstdio>
+#include <initializer_list>
+#include "svdd_spt.h"
+int main() {
+  long long worse = 0, cases = 0, better = 0;
+  for (int L : {9, 33, 50, 100, 104}) for (int ncu : {8, 256}) for (int fixed : {3, 13}) for (int n = 1; n <= 3000; n += (n < 600 ? 1 : 7)) {
+    const SvddTilePlan p = svdd_plan_tiles(n, L, ncu, fixed);
+    const int tiles = svdd_plan_num_tiles(p, n);
+    int next = 0;
+    for (int t = 0; t < tiles; ++t) { int s0, ns; svdd_plan_tile(p, t, s0, ns); if (s0 != next || ns < 1 || ns > 208 / L) return 2; next = s0 + ns; }
+    if (next < n || next - n >= (p.n1 < tiles ? p.s2 : p.s1)) return 3;
+    auto cost1 = [&](int s) { long long tl = (n + s - 1) / s; return ((tl + ncu - 1) / ncu) * ((s * L + 15) / 16 + fixed); };
+    const long long single = cost1(svdd_choose_spt(n, L, ncu, fixed));
+    const long long r = n - (long long)p.n1 * p.s1;
+    long long mixed = (long long)(p.n1 / ncu) * ((p.s1 * L + 15) / 16 + fixed);
+    if (r > 0) { long long tl = (r + p.s2 - 1) / p.s2; mixed += ((tl + ncu - 1) / ncu) * ((p.s2 * L + 15) / 16 + fixed); }
+    if (p.n1 % ncu) return 4;
+    worse += mixed > single; better += mixed < single; ++cases;
+  }
+  std::printf("%lld %lld %lld\n", cases, worse, better);
+  return worse ? 1 : 0;
+}''')
+    exe = tmp_path / "plan"
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "svdd_amd", "csrc"), "-o", str(exe), str(src)])
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0, (out.returncode, out.stdout)
+    cases, worse, better = map(int, out.stdout.split())
+    assert worse == 0 and better > 0 and cases > 10000
