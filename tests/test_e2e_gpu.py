@@ -20,7 +20,7 @@
      baseline at its 256-particle shard; g24: the un-guided decode at B = 256; g25: M = 20 at B = 256): teacher-forced on every
      row-step with the candidates RE-PROPOSED from the replayed mt19937 stream (device generator), scores within 1e-4, then the
      free-running replay decode; every divergence from the reference's trajectory must be a near-tie the report identifies
-     (tests/e2e_parity.py, numbers of the last run in profiles/r04_e2e_parity.json)."""
+     (tests/e2e_parity.py, numbers of the last run in profiles/r05_e2e_parity.json)."""
 import numpy as np
 import pytest
 import torch
@@ -224,7 +224,7 @@ def _assert_teacher_forced_lean(rep):
     assert rep["selection_agreement"] >= 0.99, rep
 
 
-# Free-running bounds = what the last full run recorded (profiles/r04_e2e_parity.json, re-collected as r05) + 1: a regression of a
+# Free-running bounds = what the last full run recorded (profiles/r05_e2e_parity.json, re-collected as r05) + 1: a regression of a
 # few rows turns these red. (min rows following the reference to the end, max proposal flips, max x0-hat flips) per precision.
 # The residue at f32 is the reference CPU's own rounding (selections at reference score gaps <= 1.9e-8, one categorical draw at a
 # 4e-7 race margin, diffusion_gosai.py:1219-1225, :30-34): recorded, not chased.
@@ -256,7 +256,7 @@ def test_headline_config_c2_against_the_reference_run(golden, full_nets, precisi
     M = 10, 128 steps with the full-size seed-44 nets. Teacher-forced on all 128 x 256 row-steps (backbone at full occupancy ->
     K1 with the replayed uniforms -> candidates == the reference's; value kernels on all 327,680 candidates -> scores within
     1e-4; K2 -> the reference's next state), then the free-running replay decode (reference diffusion_gosai.py:1021-1061,
-    1174-1228). Numbers of the last run: profiles/r04_e2e_parity.json."""
+    1174-1228). Numbers of the last run: profiles/r05_e2e_parity.json."""
     from tests import e2e_parity
     g = golden("g21_traj_mc_c2.npz")
     model, emb, head, _ = full_nets

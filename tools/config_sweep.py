@@ -46,3 +46,4 @@ run(f"C3 RNA SVDD-PM (tweedie) B=256 L=50 M=10 S={S}", lambda: rna.controlled_sa
 run(f"RNA SVDD-MC B=256 L=50 M=10 S={S}", lambda: rna.controlled_sample(emb_r, head_r, num_steps=S, eval_sp_size=256, sample_M=10), 256)
 S2 = 4 if quick else 16
 run(f"DPS DNA B=64 L=200 S={S2} (autograd baseline)", lambda: dna.controlled_sample_DPS(rew, 10.0, num_steps=S2, eval_sp_size=64), 64, reps=1)
+run(f"C5 DPS DNA B=256 L=200 S={S} (gradient guidance, scale 10)", lambda: dna.controlled_sample_DPS(rew, 10.0, num_steps=S, eval_sp_size=256), 256, reps=1)

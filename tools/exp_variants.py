@@ -4,6 +4,7 @@ wrong by construction) so that the component's cost shows up as a time differenc
     python tools/exp_variants.py build <set>     here (no GPU needed): patched COPIES of svdd_amd/csrc are compiled into
                                                  build/exp/<set>/<variant>/libsvdd_hip.so (git-ignored, travels with gpurun)
     python tools/exp_variants.py run <set>       on the GPU box: the set's microbenchmark once per variant (SVDD_HIP_LIB)
+    python tools/exp_variants.py check all       one line per set: VALID / PARTLY STALE / STALE against the current kernels
     python tools/exp_variants.py check <set>     which variants' patches still match the sources (older experiments go stale when
                                                  a kernel is restructured; their numbers stay in profiles/)
 
@@ -331,8 +332,26 @@ def build_variant(setname, name, spec):
     return name, ok, r.stderr[-400:] if not ok else ""
 
 
+def _applies(src, patches):
+    t = src
+    for old, new in patches:
+        if old not in t:
+            return False
+        t = t.replace(old, new)
+    return True
+
+
 def main():
     cmd, setname = sys.argv[1], sys.argv[2]
+    if cmd == "check" and setname == "all":              # every set: how many of its variants still apply to today's kernels
+        for sn, sp in SETS.items():
+            src = open(os.path.join(CSRC, sp["file"])).read()
+            ok = [n for n, patches in sp["variants"].items() if _applies(src, patches)]
+            stale = [n for n in sp["variants"] if n not in ok]
+            state = "VALID (every variant applies)" if not stale else ("STALE (none applies: numbers in profiles/ only)" if not ok else
+                                                                       f"PARTLY STALE ({len(ok)} of {len(sp['variants'])} apply)")
+            print(f"{sn:20s} {sp['file']:24s} {state}" + (f"   stale: {', '.join(stale)}" if stale and ok else ""))
+        return
     spec = SETS[setname]
     only = sys.argv[3:]
     names = [n for n in spec["variants"] if not only or n in only]
