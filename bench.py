@@ -390,8 +390,8 @@ def select_saturated(dev, L=200, M=10, B=1 << 18, iters=50, near_uniform=False):
     # rocprofv3 reports KB = 1024 B; MI355X_MICROARCH.md HBM section): the 200-byte rows gathered at arbitrary offsets over-fetch
     traffic, src = None, None
     if (B, L, M) == (1 << 18, 200, 10):
-        traffic = (2 * 46149.5 + 52275.1) * 1024
-        src = ("profiles/r04_pmc_k2_raw.txt, row stride 200 (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+        traffic = (2 * 46138.3 + 52279.8) * 1024
+        src = ("profiles/r05_pmc_k2_raw.txt, row stride 200 (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
                "tools/resample_microbench.py one 10 0, not measured in this run)")
     return {"bound": "hbm", "kernel": "select_rows_kernel (K2: softmax over M, argmax, index-gather compaction), saturated",
             "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5),

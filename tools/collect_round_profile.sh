@@ -45,7 +45,7 @@ out = {"how": "two separate passes per counter (tools/collect_round_profile.sh %
               "--output-format csv -- python3 bench.py --steps 1 --warmup 0 --cpu-steps 0 --c4-steps 0 --c3-steps 0 --c5-steps 0 --extra-legs 0 --alt-precision f16x3,bf16x3,bf16 --alt-steps 1 ; "
               "per-dispatch means in profiles/%s_pmc.txt (rocprofv3 reports KB)" % (sys.argv[3], sys.argv[3]),
        "fetch_correction": "x2: on gfx950 FETCH_SIZE tallies 128-B requests as 64 B for wide coalesced streams (MI355X_MICROARCH.md, HBM section)"}
-t, name, d = traffic(r"backbone_kernel<true>")
+t, name, d = traffic(r"backbone_kernel<true(, false)?>")
 if t: out["backbone_traffic_bytes_per_launch"] = t; out["backbone"] = {"kernel": name, "FETCH_SIZE_KB": d["FETCH_SIZE"][0], "WRITE_SIZE_KB": d["WRITE_SIZE"][0], "algorithmic_bytes_per_launch": 14405104}
 t, name, d = traffic(r"propose_kernel<false, false>", use_min=True)
 if t: out["k1_traffic_bytes_per_launch"] = t; out["k1"] = {"kernel": name + " (min over the dispatches: the list also holds bench.py's saturated launches)", "FETCH_SIZE_KB": d["FETCH_SIZE"][1], "WRITE_SIZE_KB": d["WRITE_SIZE"][1], "algorithmic_bytes_per_launch": 9779200}
