@@ -450,3 +450,40 @@ int main() {
     assert out.returncode == 0, (out.returncode, out.stdout)
     cases, worse, better = map(int, out.stdout.split())
     assert worse == 0 and better > 0 and cases > 10000
+
+
+_SAME_STATE_WORKER = r"""
+import os, sys, hashlib, torch
+sys.path.insert(0, {root!r})
+import torch.distributed as dist
+from svdd_amd import distributed
+rank, world, local = distributed.init_from_env("gloo")
+assert world == 2
+def state_hash():
+    return int.from_bytes(hashlib.sha1(torch.get_rng_state().numpy().tobytes()).digest()[:8], "little", signed=True)
+torch.manual_seed(0)
+distributed.assert_same_on_all_ranks(state_hash(), "generator state")          # equal seeds: passes on both ranks
+torch.manual_seed(rank)                                                         # the common torchrun habit: a seed per rank
+try:
+    distributed.assert_same_on_all_ranks(state_hash(), "generator state")
+    raised = False
+except RuntimeError as e:
+    raised = "differs between ranks" in str(e)
+assert raised, "a per-rank seed must be refused"
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_sharded_replay_refuses_ranks_with_different_generator_states(tmp_path):
+    """distributed.assert_same_on_all_ranks — the check a sharded replay decode makes at its first draw (every rank replays the WHOLE
+    batch's mt19937 stream and slices its rows, which is only the reference's run if all ranks start from the same generator state):
+    equal seeds pass, a seed per rank raises on every rank. Two gloo ranks on the CPU."""
+    script = tmp_path / "same_state.py"
+    script.write_text(_SAME_STATE_WORKER.format(root=ROOT))
+    port = 31500 + os.getpid() % 2000
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=dict(os.environ, OMP_NUM_THREADS="1"))
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    assert res.stdout.count("ok") == 2
