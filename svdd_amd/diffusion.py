@@ -120,16 +120,19 @@ def _decode_scope(fn):
         if self._scope_depth == 0:
             self._scope_id += 1
         self._scope_depth += 1
+        ok = False
         try:
-            return fn(self, *a, **k)
+            out = fn(self, *a, **k)
+            ok = True
         finally:
             self._scope_depth -= 1
             if self._scope_depth == 0 and self._replay_stream is not None:
                 st, self._replay_stream = self._replay_stream, None
                 st.close()                 # the advanced mt19937 state goes back into torch's global CPU generator
-            if self._scope_depth == 0 and not _capturing():
-                from .fused import check_backbone_split
-                check_backbone_split()     # a small-batch backbone launch whose workgroups could not all be resident: raise, never return its tokens
+        if ok and self._scope_depth == 0 and not _capturing():
+            from .fused import check_backbone_split
+            check_backbone_split()         # a small-batch backbone launch whose workgroups could not all be resident: raise, never return its tokens
+        return out
     return wrapped
 
 

@@ -54,6 +54,9 @@ outputs are stored. Fixtures:
                               np.random.choice's ancestor indices)
   g24_decode_sample_c2.npz    decode_sample (un-guided) at B=256, L=200, S=128
   g25_traj_mc_m20.npz         controlled_sample with M=20 (configs[3]'s sampler shape, ConvGRU value net) at B=256, L=200, S=48
+  -- round 5 (`python make_golden.py g26`, 8 torch threads, ~10 min) --
+  g26_traj_dps_c5.npz         controlled_sample_DPS at configs[4]'s per-GPU shard: B=256, L=200, S=128, guidance scale 25600 (= g20's 300 at a
+                              batch-mean reward): every state, x_0, the guided q_xs of 32 rows at 5 steps, per-row sums of q at every step
   g12_fullsize_probe.npz      FULL-SIZE reference nets (CNNModel hidden 128 x 4 stacks; ConvGRUTrunk 64 ch, n_conv 6 +
                               ConvHead) built at torch.manual_seed(44) in the order svdd_amd/synthetic.py builds them,
                               evaluated on 4 probe rows: logits, value scores, a checksum of every parameter tensor
@@ -926,6 +929,49 @@ def g23_traj_tds_c5(seed=0, np_seed=1, alpha=0.5, B=256, L=200, S=128):
          alpha=alpha, seed=seed, np_seed=np_seed, net_seed=44, B=B, L=L, S=S, threads=torch.get_num_threads(), sched=sched_rows(d, S), **arrs)
 
 
+def g26_traj_dps_c5(seed=0, scale=25600.0, B=256, L=200, S=128, keep_q=(0, 32, 64, 96, 127), q_rows=32):
+    """BASELINE.json configs[4]'s gradient-guidance baseline AT its per-GPU shard size, run by the reference: controlled_sample_DPS
+    (diffusion_gosai.py:980-1019, 1286-1330) with the full-size seed-44 nets + reward model, B = 256, L = 200, 128 steps (a forward and
+    a forward + backward through the backbone and the reward net per step; ~10 min on the 8 build cores). The reward is the MEAN over
+    the batch (:1329), so a sample's gradient is 1 / B of its own: guidance scale 25600 = 300 * 256 / 3 gives the factors of g20 (up to
+    ~1.06) and keeps scale * (fp32 autograd noise) ~ 3e-5, comparable at 1e-4. Lean: every state x_t, x_0, the guided q_xs of the first
+    `q_rows` rows at the steps `keep_q`, the per-step max of q (a checksum over all rows); the uniforms are NOT stored — the test replays
+    the mt19937 stream (one rand_like(q) per step, in q's memory order [b][v][l])."""
+    d, emb_v, head_v = full_nets(length=L, steps=S)
+    emb_m, head_m = full_reward()
+    reward = RewardWrap(emb_m, head_m).eval()
+    rec = {"q": {}, "x": [], "qmax": [], "qsum": []}
+    orig_sc, orig_grad = dg._sample_categorical, d.compute_gradient_DPS
+
+    def sc(q):
+        i = len(rec["qmax"])
+        if i in keep_q:
+            rec["q"][i] = q[:q_rows].detach().clone()
+        rec["qmax"].append(float(q.max()))
+        rec["qsum"].append(q.detach().double().sum(dim=(1, 2)).float().clone())   # [B]: a per-row checksum of the guided weights (detached:
+                                                                                  # q carries the autograd graph of a whole backbone forward)
+        assert q.stride()[1] == 1                                             # [b][v][l] memory order (the CNN's permuted output)
+        return orig_sc(q)
+
+    def grad(x_onehot, x, reward_model, sigma_s, copy_flag):
+        rec["x"].append(x.to(torch.uint8).clone())
+        return orig_grad(x_onehot, x, reward_model, sigma_s, copy_flag)
+
+    dg._sample_categorical, d.compute_gradient_DPS = sc, grad
+    try:
+        torch.manual_seed(seed)
+        x0 = d.controlled_sample_DPS(reward, scale, eval_sp_size=B)
+    finally:
+        dg._sample_categorical, d.compute_gradient_DPS = orig_sc, orig_grad
+    assert len(rec["x"]) == S and len(rec["qmax"]) == S
+    arrs = {n_ + "_param_sums": np.array([float(p.double().sum()) for p in mod.state_dict().values()])
+            for n_, mod in (("backbone", d.backbone), ("reward_embedding", emb_m), ("reward_head", head_m))}
+    save("g26_traj_dps_c5.npz", xs=torch.stack(rec["x"]), x0=x0.to(torch.uint8), q_steps=np.array(sorted(rec["q"])),
+         q=torch.stack([rec["q"][i] for i in sorted(rec["q"])]), q_rows=q_rows, qmax=np.array(rec["qmax"], np.float32),
+         qsum=torch.stack(rec["qsum"]), seed=seed, net_seed=44, scale=scale, B=B, L=L, S=S, threads=torch.get_num_threads(),
+         sched=sched_rows(d, S), **arrs)
+
+
 def g24_decode_sample_c2(seed=0, B=256, L=200, S=128):
     """The un-guided ancestral decode (`decode_sample`, diffusion_gosai.py:888-936, 1147-1172: what the harness's baseline loop
     runs gen_batch_num * sample_M times) by the reference at the headline batch: B = 256, L = 200, 128 steps, full-size seed-44
@@ -1056,6 +1102,10 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "g18":
         g18()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "g26":
+        torch.set_num_threads(int(os.environ.get("SVDD_GOLDEN_THREADS", "8")))
+        g26_traj_dps_c5()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] in ("g24", "g25"):
         torch.set_num_threads(int(os.environ.get("SVDD_GOLDEN_THREADS", "8")))
