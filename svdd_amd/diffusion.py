@@ -486,7 +486,7 @@ class Diffusion(nn.Module):
 
     def _dps_one_launch(self, x_onehot):
         """The fused backbone when the differentiable pass of a DPS step can run as one launch each way, else None."""
-        if not (self.fuse_nets and self.dps_one_launch and x_onehot.is_cuda and self.precision == "f32" and not self.time_conditioning
+        if not (self.fuse_nets and self.dps_one_launch and x_onehot.is_cuda and not self.time_conditioning
                 and isinstance(self.backbone, CNNModel) and not self.backbone.training):
             return None
         fb = self._fused_backbone_or_none(x_onehot.shape[1])
@@ -702,8 +702,12 @@ class Diffusion(nn.Module):
         # gradient, :1324). With the one-launch pair the differentiable forward IS the inference kernel, bit for bit (same kernel
         # template, plus stores): its raw logits serve both, through the same SUBS kernel — zero guidance stays bit-for-bit the
         # un-guided decode (tests/test_configs_gpu.py), and the second, identical forward is not run.
-        one_launch = self._dps_one_launch(x_onehot) is not None
-        if not self.dps_single_forward and not one_launch:
+        # (a split-precision mode keeps its own sampling forward for q_xs — the mode's bits — and takes only the gradient from the
+        #  fp32 pair: the differentiable pass has always been fp32)
+        pair = self._dps_one_launch(x_onehot) is not None            # the gradient comes from the one-launch fp32 pair ...
+        reuse = pair and self.precision == "f32"                     # ... whose forward logits also give q_xs
+        legacy_single = self.dps_single_forward and not pair         # round 4's opt-in, layer-wise path only
+        if not reuse and not legacy_single:
             with torch.no_grad():
                 q_xs = torch.exp(ops.subs_logp(self._backbone_logits(x_u8), x_u8)) * float(dm)   # :1306-1307
         sigma = torch.zeros(B, device=x.device)
@@ -714,16 +718,15 @@ class Diffusion(nn.Module):
         finally:
             self._dps_hard_onehot = False
         with torch.no_grad():
-            if one_launch:
+            if reuse:
                 q_xs = torch.exp(ops.subs_logp(self._dps_raw_logits, x_u8)) * float(dm)       # :1306-1307 on the very same logits
-                self._dps_raw_logits = self._dps_logp = None
-            elif self.dps_single_forward:
+            elif legacy_single:
                 # The reference evaluates the backbone twice per step on the same x_t with the same (zeroed) sigma: forward() for
                 # q_xs (:1306) and forward2() inside the gradient (:1324). They are one function; the differentiable pass's log-probs
                 # are taken for both (round-off apart: ~1e-6, far inside the 1e-3 .. 1e-2 that the gradient's own ReLU decisions
                 # move it by). dps_single_forward = False (the default) runs the second forward like the reference.
                 q_xs = torch.exp(self._dps_logp) * float(dm)
-                self._dps_logp = None
+            self._dps_raw_logits = self._dps_logp = None
             guidance = guidance_scale * (x_grad - x_grad[:, :, self.mask_index][:, :, None])   # :1311
             q_xs[:, :, self.mask_index] = float(mcs)                                          # :1312
             return q_xs * guidance.exp()                                                      # :1314

@@ -775,8 +775,7 @@ class FusedValueNet(nn.Module):
 
     def grad_ok(self, L):
         """True when forward_grad applies: the reference-shaped net in fp32 at a length the static 64 -> 64 conv kernel has."""
-        return (self.tower_ok and self.tail_ok and self.precision == "f32" and L in (200, 50) and
-                all(p.numel() for p in self.wpacks))
+        return self.tower_ok and self.tail_ok and L in (200, 50) and all(p.numel() for p in self.wpacks)   # (fp32 whatever self.precision)
 
     def forward_grad(self, x):
         """Scores [n, n_tasks, 1] of a RELAXED input x [n, L, 4] (fp32, e.g. softmax probabilities) WITH autograd to x — the reward
@@ -959,7 +958,7 @@ class FusedBackbone(nn.Module):
 
     def grad_ok(self, L):
         """True when the differentiable pass (DPS) can run as one launch each way: the one-launch kernel, one sequence per tile."""
-        return self.one_launch and self.use_one_launch and self.precision == "f32" and 104 < L <= 208
+        return self.one_launch and self.use_one_launch and 104 < L <= 208      # (always the fp32 kernels, whatever self.precision)
 
     def forward_with_grad(self, x_onehot, tokens):
         """Raw logits [n, L, 5] with autograd to `x_onehot` [n, L, 5], which must be the hard one-hot of `tokens` [n, L] u8."""

@@ -266,6 +266,33 @@ def test_dps_at_config5_shape_full_size_nets(full_nets):
     assert q.shape == (B, 200, 5)
 
 
+def test_dps_in_a_split_precision_mode_takes_its_gradient_from_the_fp32_pair(full_nets):
+    """precision = "f16x3": the sampling forward (q_xs) runs in the mode's arithmetic, the gradient comes from the fp32 one-launch pair
+    (the differentiable pass has always been fp32). Zero guidance is then bit-for-bit the mode's own un-guided decode; guidance
+    changes the outcome; the gradient kernel really ran."""
+    from svdd_amd import _lib
+    model, _, _, reward = full_nets
+    keep = (model.rng_mode, model.philox_seed, model.precision)
+    model.rng_mode, model.philox_seed, model.precision = "philox", 23, "f16x3"
+    B, S = 16, 5
+    try:
+        _lib.profile_collect(10)
+        _lib.profile_enable(True)
+        a = model.controlled_sample_DPS(reward, 0.0, num_steps=S, eval_sp_size=B)
+        torch.cuda.synchronize()
+        _lib.profile_enable(False)
+        grad_launches = _lib.profile_collect(10)[1]
+        for k in (0, 1, 2, 3, 5, 6, 7):
+            _lib.profile_collect(k)
+        d = model.decode_sample(num_steps=S, eval_sp_size=B)
+        c = model.controlled_sample_DPS(reward, 2000.0, num_steps=S, eval_sp_size=B)
+    finally:
+        model.rng_mode, model.philox_seed, model.precision = keep
+    assert grad_launches == S
+    assert torch.equal(a, d)
+    assert int(c.max()) <= 3 and not torch.equal(c, d)
+
+
 # ------------------------------------------------------------------------------------------ C4 in its stated form
 @pytest.mark.parametrize("skip_generic", [False, True])
 def test_c4_full_enformer_trunk_slice_vs_oracle(skip_generic):
