@@ -47,6 +47,10 @@ Engine knobs (attributes; defaults reproduce the reference's observable behaviou
   logits_cache     "auto" (default): SVDD-MC keeps a per-row logits cache when several sequences share a backbone tile
                    (L <= 104; at L = 200 one workgroup owns one sequence and skipping rows frees CUs but saves no
                    time); "on" / "off". (SVDD-PM always carries the selected candidate's logits forward.)
+  dedup_prior      True (default): every row of the prior x_T is the same all-MASK row (_sample_prior, :751-753), and with the hand-written
+                   kernels a row's net output does not depend on the batch around it — so the FIRST backbone forward of a decode, the
+                   parents' first value / reward score and their first tower pass run on one row and are broadcast. Bit-identical to
+                   forwarding all B rows (tests/test_skip_gpu.py); one backbone launch of 129 and a value-net pass less per decode.
   dps_one_launch   True (default): the differentiable backbone pass of a DPS step (forward2 on one_hot(x_t) + its input gradient) is ONE
                    launch each way (fp32, CNN backbone, 104 < L <= 208): the forward is the inference kernel bit for bit, so its logits
                    also give q_xs and the reference's second, identical forward (:1306 vs :1324) is not run. False: the layer-wise
@@ -176,6 +180,7 @@ class Diffusion(nn.Module):
         self.fuse_nets = True
         self.precision = "f32"
         self.skip_unchanged = True
+        self.dedup_prior = True          # the prior's rows are identical (all MASK): its net evaluations run on ONE row (exact; see _prior_logits)
         self.dps_one_launch = True       # DPS: the differentiable backbone pass as one launch each way (svdd_backbone_cnn_save_f32 / _grad_f32) where it applies
         self._dps_hard_onehot, self._dps_raw_logits = False, None
         self.dps_single_forward = False  # DPS opt-in: q_xs from the differentiable pass's log-probs, not from a second backbone forward per step
@@ -335,6 +340,19 @@ class Diffusion(nn.Module):
             return self.backbone(x_u8, None, zero_sigma=True)
         sigma = torch.zeros(x_u8.shape[0], device=x_u8.device)
         return self.backbone(x_u8.long(), sigma).float()
+
+    def _prior_dedup_ok(self, x_u8):
+        """True when the net evaluations of the prior state x_u8 (every row all-MASK by construction) may run on one row: more than
+        one row, and the one-launch backbone kernel (a row's logits are then the same bits wherever and with whomever it is evaluated)."""
+        return (self.dedup_prior and x_u8.shape[0] > 1 and x_u8.is_cuda and not _capturing() and
+                self._fused_backbone_or_none(x_u8.shape[1]) is not None)
+
+    def _prior_logits(self, x_u8):
+        """Backbone logits of the PRIOR state (the first forward of every sampler loop): one row forwarded, broadcast to all B."""
+        if self._prior_dedup_ok(x_u8):
+            B, L = x_u8.shape
+            return self._backbone_logits(x_u8[:1].contiguous()).expand(B, L, self.vocab_size).contiguous()
+        return self._backbone_logits(x_u8)
 
     def _step_scalars(self, t, dt):
         """(mct, mcs, mct - mcs) for an explicit (t, dt) as the per-step API receives them
@@ -576,7 +594,8 @@ class Diffusion(nn.Module):
         kernels' output for a row does not depend on where the row sits in the batch)."""
         B, L = x_u8.shape
         have = carry is not None and "logits" in carry
-        logits = carry["logits"] if have else self._backbone_logits(x_u8)
+        prior = carry is not None and carry.pop("prior", False)           # first step of a decode: x is the all-MASK prior
+        logits = carry["logits"] if have else (self._prior_logits(x_u8) if prior else self._backbone_logits(x_u8))
         cand, _, _ = ops.propose(logits, x_u8, dm, mcs, 1, self._rng(step, 1, B, L, logits))
         sample = cand[:, 0].contiguous()
         logits_s = self._backbone_logits(sample)
@@ -768,7 +787,7 @@ class Diffusion(nn.Module):
         sched, _, _ = self._schedule(S, eps)
         x = torch.full((B, L), self.mask_index, dtype=torch.uint8, device=self.device)
         for i in range(S):
-            logits = self._backbone_logits(x)
+            logits = self._prior_logits(x) if i == 0 else self._backbone_logits(x)
             cand, _, _ = ops.propose(logits, x, sched[i, 2], sched[i, 1], 1, self._rng(i, 1, B, L, logits))
             x = cand.view(B, L)
         return self._noise_removal(x)
@@ -785,7 +804,7 @@ class Diffusion(nn.Module):
         x = torch.full((B, L), self.mask_index, dtype=torch.uint8, device=self.device)
         mid_x = []
         for i in range(S):
-            logits = self._backbone_logits(x)
+            logits = self._prior_logits(x) if i == 0 else self._backbone_logits(x)
             cand, _, _ = ops.propose(logits, x, sched[i, 2], sched[i, 1], 1, self._rng(i, 1, B, L, logits))
             x = cand.view(B, L)
             if i != S - 1:
@@ -810,7 +829,7 @@ class Diffusion(nn.Module):
                 self.select_mode in ("argmax", "multinomial")):
             return self._controlled_sample_generic_skipping(fn, x, cand, onehot, sched, B, L, S, M)
         for i in range(S):
-            logits = self._backbone_logits(x)
+            logits = self._prior_logits(x) if i == 0 else self._backbone_logits(x)
             ops.propose(logits, x, sched[i, 2], sched[i, 1], M, self._rng(i, M, B, L, logits), cand=cand, onehot=onehot)
             scores = self._value_scores(pre_scorer_embedding, pre_scorer_head, onehot, B, M, cand, x)
             self._record(logits, scores, x)
@@ -848,6 +867,7 @@ class Diffusion(nn.Module):
             self.M = M
             self.n_live = torch.zeros(1, dtype=torch.int64, device=dev)
             self.n_changed = torch.zeros(1, dtype=torch.int64, device=dev)
+            self.prior_rows_identical = False   # set by the sampler when x is the prior: the parents' first tower pass runs on one row
             self.n_win_rows = None          # with skip_stats: rows the value net's tower computed (the candidates' row windows)
 
     def _select_compact(self, sc, ws, cand, step):
@@ -891,14 +911,18 @@ class Diffusion(nn.Module):
         ws = self._SkipWorkspace(B, M, self.device)
         if self.skip_stats is not None:
             ws.n_win_rows = torch.zeros(1, dtype=torch.int64, device=self.device)
-        ws.parent_score.copy_(fn.forward_tokens(x).reshape(B))               # scores of the all-MASK parents
+        from .fused import FusedValueNet
+        dedup = self._prior_dedup_ok(x) and isinstance(fn, FusedValueNet)   # the parents are B copies of the all-MASK row
+        ws.parent_score.copy_(fn.forward_tokens(x[:1].contiguous()).reshape(1).expand(B) if dedup
+                              else fn.forward_tokens(x).reshape(B))          # scores of the all-MASK parents
+        ws.prior_rows_identical = dedup                                      # -> the parents' first tower pass too (FusedValueNet)
         fb = self._fused_backbone_or_none(L) if self._use_logits_cache(L) else None
         share = hasattr(fn, "candidates_ok") and fn.candidates_ok(L, M)
         toks_c = None if share else torch.empty((B * M, L), dtype=torch.uint8, device=self.device)
         logits = None
         for i in range(S):
             if fb is None or logits is None:
-                logits = self._backbone_logits(x)
+                logits = self._prior_logits(x) if i == 0 else self._backbone_logits(x)
             else:                                                             # only the rows the last select changed
                 ops.compact_flags(ws.changed, ws.row_idx, ws.row_slot, ws.row_count)
                 fb.forward_rows(x, count=ws.row_count, out=logits, row_idx=ws.row_idx, scatter=True)
@@ -931,7 +955,7 @@ class Diffusion(nn.Module):
         ws.parent_score.copy_(first.reshape(B).float())
         sc = torch.zeros(B * M, device=self.device)
         for i in range(S):
-            logits = self._backbone_logits(x)
+            logits = self._prior_logits(x) if i == 0 else self._backbone_logits(x)
             ops.propose(logits, x, sched[i, 2], sched[i, 1], M, self._rng(i, M, B, L, logits), cand=cand, onehot=onehot)
             candidate_windows(cand, x, margin=0, flags=ws.flags)
             ops.compact_flags(ws.flags, ws.live_idx, ws.slot, ws.count)
@@ -958,9 +982,13 @@ class Diffusion(nn.Module):
         cand = torch.empty((B, M, L), dtype=torch.uint8, device=dev)
         toks_c = torch.empty((n, L), dtype=torch.uint8, device=dev)
         lg_c = torch.empty((n, L, 5), dtype=torch.float32, device=dev)
-        logits = fb.forward_rows(x)                                           # parents' logits; advanced, never recomputed
+        from .fused import FusedValueNet
+        dedup = self._prior_dedup_ok(x) and isinstance(rf, FusedValueNet)     # the parents are B copies of the all-MASK row
+        logits = (fb.forward_rows(x[:1].contiguous()).expand(B, L, self.vocab_size).contiguous() if dedup
+                  else fb.forward_rows(x))                                    # parents' logits; advanced, never recomputed
         _, xh = ops.x0hat(logits, x, want_tokens=True, want_onehot=False)
-        ws.parent_score.copy_(rf.forward_tokens(xh).reshape(B))               # reward of the parents' x0-hat
+        ws.parent_score.copy_(rf.forward_tokens(xh[:1].contiguous()).reshape(1).expand(B) if dedup
+                              else rf.forward_tokens(xh).reshape(B))          # reward of the parents' x0-hat
         for i in range(S):
             ops.propose(logits, x, sched[i, 2], sched[i, 1], M, self._rng(i, M, B, L, logits), cand=cand)
             from .fused import candidate_windows
@@ -993,7 +1021,7 @@ class Diffusion(nn.Module):
         if options == "True" and task != "rna_saluki" and fb is not None and self._can_skip(rf, L, M):
             return self._tweedie_sample_skipping(rf, x, sched, B, L, S, M, fb)
         for i in range(S):
-            logits = self._backbone_logits(x)
+            logits = self._prior_logits(x) if i == 0 else self._backbone_logits(x)
             cand, _, _ = ops.propose(logits, x, sched[i, 2], sched[i, 1], M, self._rng(i, M, B, L, logits))
             scores = self._tweedie_scores(cand, reward_model, options, task)
             self._record(logits, scores, x)
@@ -1009,6 +1037,8 @@ class Diffusion(nn.Module):
         sched, _, _ = self._schedule(S, eps)
         x = torch.full((B, L), self.mask_index, dtype=torch.uint8, device=self.device)
         carry = self._tds_carry(reward_model, L)
+        if carry is not None:
+            carry["prior"] = True
         for i in range(S):
             if self.state_trace is not None:
                 self.state_trace.append(x.detach().clone())

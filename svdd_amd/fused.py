@@ -827,11 +827,16 @@ class FusedValueNet(nn.Module):
         # the select. Only the first step runs the tower on the parents.
         lp = self.precision != "f32"
         if ws.parent_out is None or ws.parent_out_lp != self.precision:
+            # (the parents of the first step are B copies of the all-MASK row: one row through the tower, broadcast — a row's output
+            #  does not depend on the batch around it; Diffusion.dedup_prior)
+            xp = x[:1].contiguous() if getattr(ws, "prior_rows_identical", False) else x
             if lp:
                 pk = self._lp_pack()
-                ws.parent_out = conv_tower_lp(x, pk["tiles"], self.tw_bias, pk["tinv"], self.tw_resmask, pk["prec"])
+                po = conv_tower_lp(xp, pk["tiles"], self.tw_bias, pk["tinv"], self.tw_resmask, pk["prec"])
             else:
-                ws.parent_out = conv_tower(ops.transform_samples(x), self.tw_tiles, self.tw_bias, self.tw_resmask)
+                po = conv_tower(ops.transform_samples(xp), self.tw_tiles, self.tw_bias, self.tw_resmask)
+            ws.parent_out = po if xp is x else po.expand(B, *po.shape[1:]).contiguous()
+            ws.prior_rows_identical = False
             ws.parent_out_lp = self.precision
         if lp:
             pk = self._lp_pack()

@@ -309,3 +309,37 @@ def test_tds_carry_is_bit_identical(B, L, task):
     assert model._tds_carry(reward, L) == {"keep_logits": True, "keep_den": True}
     assert torch.equal(outs[0], outs[1])
     assert len(torch.unique(outs[0], dim=0)) < B                    # the resample did duplicate particles
+
+
+@pytest.mark.parametrize("kind,precision", [("mc", "f32"), ("mc", "f16x3"), ("pm", "f32"), ("tds", "f32"), ("plain", "f32"), ("mc_rna", "f32")])
+def test_prior_rows_run_once_bit_identical(kind, precision):
+    """Diffusion.dedup_prior: the rows of the prior x_T are B copies of the all-MASK row, so the first backbone forward of a decode
+    (and the parents' first value score / tower pass) runs on ONE row and is broadcast. Tokens and every traced logit / score
+    must equal the decode that forwards all B rows."""
+    from svdd_amd import synthetic
+    task = "rna" if kind in ("pm", "mc_rna") else "dna"
+    model, emb, head, reward = synthetic.build(task, DEV)
+    model.rng_mode, model.philox_seed, model.precision = "philox", 5, precision
+    B, M, S = 48, 6, 12
+    outs = []
+    for on in (True, False):
+        model.dedup_prior = on
+        model.trace = []
+        np.random.seed(0)
+        if kind in ("mc", "mc_rna"):
+            x0 = model.controlled_sample(emb, head, num_steps=S, eval_sp_size=B, sample_M=M)
+        elif kind == "pm":
+            x0 = model.controlled_sample_tweedie(reward, num_steps=S, eval_sp_size=B, sample_M=M, options="True", task="rna")
+        elif kind == "tds":
+            x0 = model.controlled_sample_TDS(reward, 0.5, num_steps=S, eval_sp_size=B)
+        else:
+            x0 = model.decode_sample(num_steps=S, eval_sp_size=B)
+        torch.cuda.synchronize()
+        outs.append((x0, model.trace))
+        model.trace = None
+    model.dedup_prior, model.precision = True, "f32"
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert len(outs[0][1]) == len(outs[1][1])
+    for (la, sa), (lb, sb) in zip(outs[0][1], outs[1][1]):
+        assert torch.equal(la, lb)
+        assert (sa is None) == (sb is None) and (sa is None or torch.equal(sa, sb))
