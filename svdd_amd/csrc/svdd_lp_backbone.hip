@@ -1,7 +1,6 @@
 // svdd_lp_backbone.hip — the one-launch dilated-CNN backbone, split precision
 // (split-precision net kernels on the 16-bit matrix cores: see svdd_lp_common.h for the arithmetic)
 #include "svdd_lp_common.h"
-#include "svdd_spt.h"
 
 extern "C" int svdd_internal_num_cus();      // svdd_nets.hip
 extern "C" int svdd_internal_fixed_spt();    // svdd_nets.hip (svdd_set_backbone_packing)
@@ -54,7 +53,7 @@ __global__ __launch_bounds__(512, 2) void backbone_lp_kernel(BackboneLpArgs a) {
   const int c0 = 32 * cg + 2 * j;                            // this lane's output channels: c0 and c0 + 1
   const int L = a.L;
   const int nvalid = a.count ? __builtin_amdgcn_readfirstlane(*a.count) : a.n;
-  const int spt = (!SPT1 && a.auto_spt) ? __builtin_amdgcn_readfirstlane(svdd_choose_spt(nvalid, L, a.ncu, NP == 3 ? 13 : 20)) : a.spt;
+  const int spt = (!SPT1 && a.auto_spt) ? __builtin_amdgcn_readfirstlane(svdd_choose_spt(nvalid, L, a.ncu, NP == 3 ? 26 : 40)) : a.spt;
   const int tile_rows = spt * L;
   const int64_t row0 = (int64_t)blockIdx.x * tile_rows;
   const int64_t total_rows = (int64_t)nvalid * L;
@@ -540,7 +539,12 @@ constexpr int lpt_own_mask(int n, int rgs) { int m = 0; for (int r = 0; r < n; +
 // "if (rg == 0) 7 tiles else 6 tiles" blocks in the tap loop, times the all-live / partly-live variants of a tap, the
 // register allocator gave the 14 accumulators different registers in different blocks (52 v_mov_b64 per tap to reconcile
 // them) and spilled a quarter of the residual stream around the loop.
-template <typename T, int NP, int RG, int MYRG>
+// IL (round 5): several whole sequences of L <= 104 positions per tile, INTERLEAVED position-major (tile row = position * il + q is
+// position `row / il` of the tile's sequence q): a dilated tap is then a row offset of il * (t - 4) * dil that leaves the tile
+// exactly when the position leaves the sequence, i.e. the tile behaves like ONE sequence of il * L rows with every dilation
+// multiplied by il — and the short sequences run on this kernel (clamped addressing, tile-granular liveness) instead of the
+// round-2 kernel with a position test per fragment row.
+template <typename T, int NP, int RG, int MYRG, bool IL>
 __device__ __forceinline__ void backbone_lp_t_body(const BackboneLpArgs& a, char* smem_b) {
   constexpr int NTH = 256 * RG;
   typedef typename Lp<T>::V8 V8;
@@ -564,14 +568,28 @@ __device__ __forceinline__ void backbone_lp_t_body(const BackboneLpArgs& a, char
   const int cb = 32 * cg + 8 * g;                            // this lane's channels cb .. cb + 7: (ct, e) <-> cb + 2 e + ct
   const int L = a.L;
   const int nvalid = a.count ? __builtin_amdgcn_readfirstlane(*a.count) : a.n;
-  if ((int)blockIdx.x >= nvalid) return;
-  const int64_t seq = a.row_idx ? a.row_idx[blockIdx.x] : (int64_t)blockIdx.x;
+  int seq0 = blockIdx.x, il = 1;                             // this tile's first (compact) sequence and how many it interleaves
+  if (IL) {
+    SvddTilePlan pl = a.plan;
+    if (a.auto_spt) pl = svdd_plan_tiles(nvalid, L, a.ncu, a.fixed_half);
+    svdd_plan_tile(pl, (int)blockIdx.x, seq0, il);
+    seq0 = __builtin_amdgcn_readfirstlane(seq0);
+    il = __builtin_amdgcn_readfirstlane(il);
+  }
+  if (seq0 >= nvalid) return;
+  const int R = il * L;                                      // rows of the tile
   const int nl = a.nl;
   const int it_end = (nl + 1) * 9;                           // (layer, tap) entries
   constexpr int NR = (TW_RT - MYRG + RG - 1) / RG;           // row tiles of this row group: MYRG, MYRG + RG, ...
 
   for (int e = tid; e < TW_ROWS; e += NTH) {
-    toks[e] = e < L ? (int)a.x[seq * L + e] : -1;
+    int tk = -1;
+    const int q = IL ? e % il : 0, pos = IL ? e / il : e;
+    if (e < R && seq0 + q < nvalid) {
+      const int64_t sq = a.row_idx ? (int64_t)a.row_idx[seq0 + q] : (int64_t)(seq0 + q);
+      tk = (int)a.x[sq * L + pos];
+    }
+    toks[e] = tk;
     rmean[e] = 0.0f;
   }
   for (int e = tid; e < LPSB / 4; e += NTH) {                // zero rows -1 and TW_ROWS of both planes
@@ -594,8 +612,8 @@ __device__ __forceinline__ void backbone_lp_t_body(const BackboneLpArgs& a, char
     auto entry = [&](int kk) {
       const int layer = kk / 9, t = kk % 9;
       if (layer >= nl) return t == 4 ? 0x1fff : 0;
-      const int d = (t - 4) * sdil[layer];
-      const int lo = d < 0 ? -d : 0, hi = d > 0 ? L - d : L;
+      const int d = (t - 4) * sdil[layer] * il;              // in tile rows
+      const int lo = d < 0 ? -d : 0, hi = d > 0 ? R - d : R;
       if (lo >= hi) return 0;
       int m = 0;
       for (int r = 0; r < TW_RT; ++r) if (lo < 16 * r + 16 && hi > 16 * r) m |= 1 << r;
@@ -618,8 +636,8 @@ __device__ __forceinline__ void backbone_lp_t_body(const BackboneLpArgs& a, char
       if (rg + RG * r < TW_RT) {
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-          const int q = p + t - 4;
-          const int tk = (q >= 0 && q < L) ? toks[q < 0 ? 0 : (q < TW_ROWS ? q : TW_ROWS - 1)] : -1;
+          const int q = p + (t - 4) * il;                  // the row of position + t - 4 of the same sequence
+          const int tk = (q >= 0 && q < R) ? toks[q < 0 ? 0 : (q < TW_ROWS ? q : TW_ROWS - 1)] : -1;
           const float* row = Bs + (t * 5 + (tk < 0 ? 0 : tk)) * BB_C + cb;
           const f32x4 ta = *reinterpret_cast<const f32x4*>(row), tb = *reinterpret_cast<const f32x4*>(row + 4);
           const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -627,7 +645,7 @@ __device__ __forceinline__ void backbone_lp_t_body(const BackboneLpArgs& a, char
           vb += tk >= 0 ? tb : z;
         }
       }
-      const bool in = p < L;
+      const bool in = p < R;
       f[r][0] = f32x4{in ? fmaxf(va[0], 0.0f) : 0.0f, in ? fmaxf(va[2], 0.0f) : 0.0f, in ? fmaxf(vb[0], 0.0f) : 0.0f, in ? fmaxf(vb[2], 0.0f) : 0.0f};
       f[r][1] = f32x4{in ? fmaxf(va[1], 0.0f) : 0.0f, in ? fmaxf(va[3], 0.0f) : 0.0f, in ? fmaxf(vb[1], 0.0f) : 0.0f, in ? fmaxf(vb[3], 0.0f) : 0.0f};
     }
@@ -713,8 +731,8 @@ __device__ __forceinline__ void backbone_lp_t_body(const BackboneLpArgs& a, char
         if (rg + RG * r < TW_RT) {
           const float rs = rstat[p], mean = rmean[p];
           const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
-          const f32x4 v0 = p < L ? (f[r][0] + tb0 - mean) * rs * gm0 + bt0 : z;
-          const f32x4 v1 = p < L ? (f[r][1] + tb1 - mean) * rs * gm1 + bt1 : z;
+          const f32x4 v0 = p < R ? (f[r][0] + tb0 - mean) * rs * gm0 + bt0 : z;
+          const f32x4 v1 = p < R ? (f[r][1] + tb1 - mean) * rs * gm1 + bt1 : z;
           store_image(wrow, r, v0, v1);
         }
         if (r & 1) __builtin_amdgcn_sched_barrier(0);
@@ -727,7 +745,7 @@ __device__ __forceinline__ void backbone_lp_t_body(const BackboneLpArgs& a, char
     // ---- implicit GEMM over (chunk, live tap): acc^T[channel, position] += W[channel, k] X^T[k, position]
 #pragma unroll
     for (int r = 0; r < NR; ++r) { acc[r][0] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; acc[r][1] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
-    const int dil = __builtin_amdgcn_readfirstlane(sdil[layer < nl ? layer : BB_MAXL]);
+    const int dil = __builtin_amdgcn_readfirstlane(sdil[layer < nl ? layer : BB_MAXL]) * il;   // in tile rows
     const int layer_end = (layer + 1) * 9;
     __syncthreads();                                      // the image is complete
     while (it < layer_end) {                              // one live tap: 4 chunks x the wave's row tiles
@@ -860,29 +878,31 @@ __device__ __forceinline__ void backbone_lp_t_body(const BackboneLpArgs& a, char
   }
   __syncthreads();
   // ---- last 1x1 conv 128 -> 5 in fp32
-  for (int e = tid; e < L * 5; e += NTH) {
+  for (int e = tid; e < R * 5; e += NTH) {
     const int row = e / 5, v = e - 5 * row;
+    const int q = IL ? row % il : 0, pos = IL ? row / il : row;   // tile row -> (sequence seq0 + q, position)
+    if (seq0 + q >= nvalid) continue;
     const float* hr = img32 + row * BB_AP;
     const float* wv = a.w2 + v * BB_C;
     float sm = a.w2[5 * BB_C + v];
 #pragma unroll 8
     for (int k = 0; k < BB_C; ++k) sm += hr[k] * wv[k];
-    if (a.row_idx && !a.out_scatter) a.out[((int64_t)blockIdx.x * L + row) * 5 + v] = sm;
-    else a.out[(seq * L + row) * 5 + v] = sm;
+    const int64_t sq = (a.row_idx && a.out_scatter) ? (int64_t)a.row_idx[seq0 + q] : (int64_t)(seq0 + q);
+    a.out[(sq * L + pos) * 5 + v] = sm;
   }
 }
 
-template <typename T, int NP, int RG>
+template <typename T, int NP, int RG, bool IL = false>
 __global__ __launch_bounds__(256 * RG, RG) void backbone_lp_t_kernel(BackboneLpArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_b[];
   const int rg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);     // wave w = (column group w & 3, row group w >> 2)
   // every row group executes the same sequence of workgroup barriers (the bodies differ in tile counts only)
-  if constexpr (RG == 1) backbone_lp_t_body<T, NP, RG, 0>(a, smem_b);
-  if constexpr (RG == 2) { if (rg == 0) backbone_lp_t_body<T, NP, RG, 0>(a, smem_b); else backbone_lp_t_body<T, NP, RG, 1>(a, smem_b); }
+  if constexpr (RG == 1) backbone_lp_t_body<T, NP, RG, 0, IL>(a, smem_b);
+  if constexpr (RG == 2) { if (rg == 0) backbone_lp_t_body<T, NP, RG, 0, IL>(a, smem_b); else backbone_lp_t_body<T, NP, RG, 1, IL>(a, smem_b); }
   if constexpr (RG == 3) {
-    if (rg == 0) backbone_lp_t_body<T, NP, RG, 0>(a, smem_b);
-    else if (rg == 1) backbone_lp_t_body<T, NP, RG, 1>(a, smem_b);
-    else backbone_lp_t_body<T, NP, RG, 2>(a, smem_b);
+    if (rg == 0) backbone_lp_t_body<T, NP, RG, 0, IL>(a, smem_b);
+    else if (rg == 1) backbone_lp_t_body<T, NP, RG, 1, IL>(a, smem_b);
+    else backbone_lp_t_body<T, NP, RG, 2, IL>(a, smem_b);
   }
 }
 
@@ -905,17 +925,22 @@ extern "C" int svdd_backbone_cnn_lp(const uint8_t* x, const float* table0, const
   hipEvent_t e0, e1;
   svdd_internal_timed_events(6, &e0, &e1);
   a.auto_spt = 0; a.ncu = svdd_internal_num_cus();
+  a.fixed_half = (prec == SVDD_PREC_F16X3 || prec == SVDD_PREC_BF16X3) ? 58 : 90;   // svdd_spt.h: calibrated on the interleaved kernel
   unsigned nwg = (unsigned)((n + a.spt - 1) / a.spt);
+  a.plan = SvddTilePlan{a.spt, 0, a.spt};
   const int fixed = svdd_internal_fixed_spt();
-  if (a.spt > 1 && fixed <= 0) {                         // several sequences fit a tile: how many to take (svdd_spt.h)
-    if (fixed < 0) { a.spt = -fixed < a.spt ? -fixed : a.spt; nwg = (unsigned)((n + a.spt - 1) / a.spt); }
+  // Short sequences (several fit a tile) run INTERLEAVED on the transposed-accumulator kernel (round 5; version 1 = the round-2
+  // kernel with the sequences stacked, for A/B). Every packing gives a row the same bits (exact work-skipping needs that).
+  const bool interleaved = TW_ROWS / L > 1 && g_bb_lp_version != 1;
+  if (a.spt > 1 && fixed <= 0) {                         // several sequences fit a tile: which tile takes how many (svdd_spt.h)
+    if (fixed < 0) { a.spt = -fixed < a.spt ? -fixed : a.spt; a.plan = SvddTilePlan{a.spt, 0, a.spt}; nwg = (unsigned)((n + a.spt - 1) / a.spt); }
     else if (count) { a.auto_spt = 1; nwg = (unsigned)n; }   // decided on the device from *count; grid for one sequence per tile
-    else { a.spt = svdd_choose_spt(n, L, a.ncu, (prec == SVDD_PREC_F16X3 || prec == SVDD_PREC_BF16X3) ? 13 : 20); nwg = (unsigned)((n + a.spt - 1) / a.spt); }
+    else if (interleaved) { a.plan = svdd_plan_tiles(n, L, a.ncu, a.fixed_half); a.spt = a.plan.s2; nwg = (unsigned)svdd_plan_num_tiles(a.plan, n); }
+    else { a.spt = svdd_choose_spt(n, L, a.ncu, a.fixed_half); nwg = (unsigned)((n + a.spt - 1) / a.spt); }
   }
   const dim3 grid(nwg);
-  const bool spt1 = a.spt == 1 && !a.auto_spt;
-  // the transposed-accumulator kernel (round 3) where one sequence per tile is the ONLY packing (104 < L <= 208): for
-  // shorter sequences every packing must give a row the same bits (exact work-skipping), so they all stay on one kernel
+  const bool spt1 = a.spt == 1 && !a.auto_spt && (a.plan.n1 == 0 || a.plan.s1 == 1);
+  // the transposed-accumulator kernel (round 3) where one sequence per tile is the ONLY packing (104 < L <= 208)
   const bool transposed = spt1 && TW_ROWS / L == 1 && g_bb_lp_version != 1;
 #define LPT_LAUNCH_ONE(TT, NPP, RGG)                                                                                \
   { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(backbone_lp_t_kernel<TT, NPP, RGG>),                    \
@@ -927,6 +952,10 @@ extern "C" int svdd_backbone_cnn_lp(const uint8_t* x, const float* table0, const
   do {                                                                                                               \
     if (transposed) {                                                                                                \
       LPT_LAUNCH_RG(TT, NPP)                                                                                         \
+    } else if (interleaved) {                                                                                        \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(backbone_lp_t_kernel<TT, NPP, 2, true>),               \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                               \
+      hipExtLaunchKernelGGL((backbone_lp_t_kernel<TT, NPP, 2, true>), grid, dim3(512), lds, (hipStream_t)stream, e0, e1, 0, a); \
     } else if (spt1) {                                                                                               \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(backbone_lp_kernel<TT, NPP, true>),                    \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                               \

@@ -22,6 +22,7 @@
 #include <stdint.h>
 
 #include "svdd_hip.h"
+#include "svdd_spt.h"
 
 extern "C" void svdd_internal_timed_events(int k, hipEvent_t* e0, hipEvent_t* e1);   // svdd_kernels.hip (profiling)
 
@@ -85,6 +86,8 @@ struct BackboneLpArgs {
   const int* row_idx;      // [count] (NULL: identity): compact row r reads the tokens of sequence row_idx[r] of x ...
   int out_scatter;         // ... and writes its logits to row row_idx[r] of out (1) or to row r (0)
   int auto_spt, ncu;       // auto_spt: the workgroups pick the sequences per tile from the device-side row count (svdd_spt.h)
+  SvddTilePlan plan;       // several sequences per tile (interleaved, backbone_lp_t_kernel<.., IL = true>): which tile takes how many
+  int fixed_half;          // ... and the cost model's fixed part for a plan made on the device
 };
 
 }  // namespace

@@ -1452,27 +1452,33 @@ __global__ __launch_bounds__(512, 2) void backbone_kernel(BackboneArgs a, Backbo
   int seq0 = blockIdx.x, spt = 1;                         // this tile's first sequence and how many it takes
   if (!SPT1) {
     SvddTilePlan pl = a.plan;
-    if (a.auto_spt) pl = svdd_plan_tiles(nvalid, L, a.ncu, 3);
+    if (a.auto_spt) pl = svdd_plan_tiles(nvalid, L, a.ncu, 9);
     svdd_plan_tile(pl, (int)blockIdx.x, seq0, spt);
     seq0 = __builtin_amdgcn_readfirstlane(seq0);
     spt = __builtin_amdgcn_readfirstlane(spt);
   }
   const int tile_rows = spt * L;
-  const int64_t row0 = (int64_t)seq0 * L;
-  const int64_t total_rows = (int64_t)nvalid * L;
-  if (row0 >= total_rows) return;
+  if (seq0 >= nvalid) return;
   const int nl = a.nl;
   const int it_end = (nl + 1) * 36;
   constexpr int NR = 7;                                   // owned row tiles rh + 2 r (r = 6 only for rh = 0)
 
+  // Several sequences per tile (!SPT1, L <= 104; round 5): the `spt` sequences are INTERLEAVED position-major — tile row
+  // e = position * spt + q holds position e / spt of sequence seq0 + q. A dilated tap then is a row offset of spt * (t - 4) * dil that
+  // leaves the tile exactly when the position leaves the sequence: the tile behaves like ONE sequence of spt * L rows with every
+  // dilation multiplied by spt — clamped addressing and tile-granular liveness as for L = 200, instead of a position test per
+  // fragment row and row tiles kept live by a few rows of each stacked sequence (the stacked layout issued 425 tile-taps per five
+  // layers for 372 useful ones). Same products in the same order per output element: same bits.
+  const int il = SPT1 ? 1 : spt;
   for (int e = tid; e < TW_ROWS; e += 512) {
     int tk = -1;
-    if (e < tile_rows && row0 + e < total_rows) {
-      if (a.row_idx) { const int sq = e / L; tk = a.x[(int64_t)a.row_idx[seq0 + sq] * L + (e - sq * L)]; }
-      else tk = a.x[row0 + e];
+    const int q = SPT1 ? 0 : e % il, pos = SPT1 ? e : e / il;
+    if (e < tile_rows && seq0 + q < nvalid) {
+      const int64_t sq = a.row_idx ? (int64_t)a.row_idx[seq0 + q] : (int64_t)(seq0 + q);
+      tk = a.x[sq * L + pos];
     }
     toks[e] = tk;
-    rpos[e] = e < tile_rows ? e % L : -(1 << 20);
+    rpos[e] = e < tile_rows ? pos : -(1 << 20);
   }
   for (int e = tid; e < BB_AP; e += 512) { smem[e] = 0.0f; img[TW_ROWS * BB_AP + e] = 0.0f; }
   if (tid == 0) {
@@ -1488,18 +1494,11 @@ __global__ __launch_bounds__(512, 2) void backbone_kernel(BackboneArgs a, Backbo
     auto entry = [&](int kk) {
       const int layer = kk / 36, t = kk % 9;
       if (layer >= nl) return t == 4 ? 0x1fff : 0;
-      const int d = (t - 4) * sdil[layer];
-      const int lo = d < 0 ? -d : 0, hi = d > 0 ? L - d : L;
+      const int d = (t - 4) * sdil[layer] * il;           // in tile rows (interleaved sequences: il rows per position)
+      const int lo = d < 0 ? -d : 0, hi = d > 0 ? tile_rows - d : tile_rows;
       if (lo >= hi) return 0;
       int m = 0;
-      if (SPT1) {
-        for (int r = 0; r < TW_RT; ++r) if (lo < 16 * r + 16 && hi > 16 * r) m |= 1 << r;
-      } else {                                            // several sequences per tile: a row tile is live if any of its rows is
-        for (int row = 0; row < TW_ROWS; ++row) {
-          const int pp = rpos[row];
-          if (pp >= lo && pp < hi) m |= 1 << (row >> 4);
-        }
-      }
+      for (int r = 0; r < TW_RT; ++r) if (lo < 16 * r + 16 && hi > 16 * r) m |= 1 << r;
       return m;
     };
     const int m = entry(k);
@@ -1526,7 +1525,7 @@ __global__ __launch_bounds__(512, 2) void backbone_kernel(BackboneArgs a, Backbo
 #pragma unroll
           for (int t = 0; t < 9; ++t) {
             const int p = pos + t - 4;
-            const int tk = (p >= 0 && p < L) ? toks[row + t - 4] : -1;
+            const int tk = (p >= 0 && p < L) ? toks[row + (t - 4) * il] : -1;
             if (tk >= 0) v += Bs[(t * 5 + tk) * BB_C + col];
           }
         }
@@ -1543,11 +1542,6 @@ __global__ __launch_bounds__(512, 2) void backbone_kernel(BackboneArgs a, Backbo
   const int arow0 = img_lds + ((16 * rh + j) * BB_AP + 8 * g) * 4;  // LDS byte address of (row 16 rh + j, col 8 g) of img
   const int a_lo = arow0 - (16 * rh + j + 1) * BB_AP * 4; // row -1
   const int a_hi = arow0 + (TW_ROWS - 16 * rh - j) * BB_AP * 4;     // row TW_ROWS
-  int apos[SPT1 ? 1 : NR];
-  if (!SPT1) {
-#pragma unroll
-    for (int r = 0; r < NR; ++r) apos[r] = 16 * (rh + 2 * r) + j < TW_ROWS ? rpos[16 * (rh + 2 * r) + j] : -(1 << 20);
-  }
 
   // Weight stream: each lane reads W[col0][8 g ..] and W[col0 + 16][8 g ..] of the (layer, chunk, tap) tile straight
   // from L2 into the B-operand registers, one tile ahead (no LDS staging, no barrier inside a layer).
@@ -1647,7 +1641,7 @@ __global__ __launch_bounds__(512, 2) void backbone_kernel(BackboneArgs a, Backbo
     const float bl0 = vl[col0], bl1 = vl[col0 + 16];
 #pragma unroll
     for (int r = 0; r < NR; ++r) { acc[r][0] = f32x4{bl0, bl0, bl0, bl0}; acc[r][1] = f32x4{bl1, bl1, bl1, bl1}; }
-    const int dil = __builtin_amdgcn_readfirstlane(sdil[layer < nl ? layer : BB_MAXL]);
+    const int dil = __builtin_amdgcn_readfirstlane(sdil[layer < nl ? layer : BB_MAXL]) * il;   // in tile rows
     const int layer_end = (layer + 1) * 36;
     __syncthreads();                                      // the image is complete
     // A fragments of row tiles 0 and 1 of an entry are requested during the LAST MFMA groups of the entry before it (first
@@ -1659,9 +1653,7 @@ __global__ __launch_bounds__(512, 2) void backbone_kernel(BackboneArgs a, Backbo
     //  v_add_u32 of the dynamic-LDS symbol, which is 0)
 #define B2_ALOAD(R, V, DELTA, COFF, DBYTES)                                                                  \
       { int o_;                                                                                              \
-        if (SPT1) asm("v_med3_i32 %0, %1, %2, %3" : "=v"(o_) : "v"(arow0 + (DBYTES) + (R) * (32 * BB_AP * 4)), "v"(a_lo + (COFF)), "v"(a_hi + (COFF))); \
-        else o_ = ((unsigned)(apos[SPT1 ? 0 : (R)] + (DELTA)) < (unsigned)L ? arow0 + (DBYTES) + (R) * (32 * BB_AP * 4) \
-                                                                             : a_hi + (COFF));               \
+        asm("v_med3_i32 %0, %1, %2, %3" : "=v"(o_) : "v"(arow0 + (DBYTES) + (R) * (32 * BB_AP * 4)), "v"(a_lo + (COFF)), "v"(a_hi + (COFF))); \
         const LdsF4* ap_ = reinterpret_cast<const LdsF4*>(o_);                                               \
         const f32x4 t0_ = ap_[0], t1_ = ap_[1];                                                              \
         V[0] = make_float4(t0_[0], t0_[1], t0_[2], t0_[3]); V[1] = make_float4(t1_[0], t1_[1], t1_[2], t1_[3]); }
@@ -1793,14 +1785,15 @@ __global__ __launch_bounds__(512, 2) void backbone_kernel(BackboneArgs a, Backbo
   // ---- last 1x1 conv 128 -> 5: one (row, class) dot product per thread iteration
   for (int e = tid; e < tile_rows * 5; e += 512) {
     const int row = e / 5, v = e - 5 * row;
-    if (row0 + row >= total_rows) continue;
+    const int q = SPT1 ? 0 : row % il, pos = SPT1 ? row : row / il;   // tile row -> (sequence seq0 + q, position)
+    if (seq0 + q >= nvalid) continue;
     const float* hr = img + row * BB_AP;
     const float* wv = a.w2 + v * BB_C;
     float sm = a.w2[5 * BB_C + v];
 #pragma unroll 8
     for (int k = 0; k < BB_C; ++k) sm += hr[k] * wv[k];
-    if (a.row_idx && a.out_scatter) { const int sq = row / L; a.out[((int64_t)a.row_idx[seq0 + sq] * L + (row - sq * L)) * 5 + v] = sm; }
-    else a.out[(row0 + row) * 5 + v] = sm;
+    const int64_t sq = (a.row_idx && a.out_scatter) ? (int64_t)a.row_idx[seq0 + q] : (int64_t)(seq0 + q);
+    a.out[(sq * L + pos) * 5 + v] = sm;
   }
 }
 
@@ -2772,7 +2765,7 @@ extern "C" int svdd_backbone_cnn_f32(const uint8_t* x, const float* table0, cons
   if (a.spt > 1 && g_fixed_spt <= 0) {                   // several sequences fit a tile: which tile takes how many (svdd_spt.h)
     if (g_fixed_spt < 0) { a.spt = -g_fixed_spt < a.spt ? -g_fixed_spt : a.spt; a.plan = SvddTilePlan{a.spt, 0, a.spt}; nwg = (unsigned)((n + a.spt - 1) / a.spt); }
     else if (count) { a.auto_spt = 1; nwg = (unsigned)n; }   // decided on the device from *count; grid for one sequence per tile
-    else { a.plan = svdd_plan_tiles(n, L, a.ncu, 3); a.spt = a.plan.s2; nwg = (unsigned)svdd_plan_num_tiles(a.plan, n); }
+    else { a.plan = svdd_plan_tiles(n, L, a.ncu, 9); a.spt = a.plan.s2; nwg = (unsigned)svdd_plan_num_tiles(a.plan, n); }
   }
   for (int i = 0; i < BB_MAXL; ++i) a.dil[i] = i < nlayers ? dilations[i] : 1;
   for (int i = 0; i < nlayers; ++i) if (dilations[i] <= 0) return SVDD_E_ARG;

@@ -1,8 +1,10 @@
 // svdd_spt.h — how many whole sequences a backbone workgroup takes when several fit its 208-row tile (L <= 104).
 // A tile costs its row tiles of 16 plus a fixed part (the loop skeleton of the 756 (layer, chunk, tap) iterations, LayerNorm
 // phases, barriers, the first-layer lookup): measured with 256 x s sequences of L = 50 / 33 (tools/backbone_spt_calib.py,
-// one full round): fp32 865 / 1240 / 1582 / 1941 us at 4 / 7 / 10 / 13 row tiles = 120 us per row tile + 3 row tiles' worth
-// fixed; f16x3 483 / 585 / 655 / 733 us = 28 us per row tile + 13 row tiles' worth fixed (`fixed`, passed by the caller).
+// one full round): fp32 (round 5, interleaved sequences) 806 / 1058 / 1359 / 1659 us at 4 / 7 / 10 / 13 row tiles = 95 us per row tile +
+// 4.5 row tiles' worth fixed (rounds 2-4, stacked sequences: 865 / 1240 / 1582 / 1941 = 120 us + 3); f16x3 (interleaved, on the
+// transposed-accumulator kernel) 421 / 442 / 481 / 536 us = 13 us per row tile + 29 row tiles' worth fixed (stacked, round-2 kernel:
+// 478 / 575 / 644 / 726 = 28 us + 13). The caller passes the fixed part in HALF row tiles (`fixed_half`: 9 fp32, 58 x3 modes, 90 one-pass).
 // The launch costs rounds x tile cost, rounds = ceil(tiles / CUs) (one workgroup per CU). Packing the tile full is only
 // best when the tiles then fill whole rounds: 256 RNA sequences (L = 50) packed four to a tile are 64 workgroups on 256
 // CUs, one to a tile they are 256 workgroups of a quarter of the work; 1408 live candidates are 352 full tiles = 2
@@ -15,14 +17,14 @@
 #define SVDD_TILE_ROWS 208
 #endif
 
-__host__ __device__ inline int svdd_choose_spt(int n, int L, int ncu, int fixed) {
+__host__ __device__ inline int svdd_choose_spt(int n, int L, int ncu, int fixed_half) {   // fixed_half: the fixed part in HALF row tiles
   const int smax = SVDD_TILE_ROWS / L;
   int best = smax;
   long long best_cost = -1;
   for (int s = smax; s >= 1; --s) {                   // ties: the fuller tile (fewer workgroups)
     const long long tiles = (n + s - 1) / s;
     const long long rounds = (tiles + ncu - 1) / ncu;
-    const long long cost = rounds * ((s * L + 15) / 16 + fixed);
+    const long long cost = rounds * (2 * ((s * L + 15) / 16) + fixed_half);
     if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = s; }
   }
   return best;
@@ -35,16 +37,16 @@ __host__ __device__ inline int svdd_choose_spt(int n, int L, int ncu, int fixed)
 // are dispatched in grid order, the large tiles first. A row's result does not depend on the plan.
 struct SvddTilePlan { int s1, n1, s2; };          // tiles 0 .. n1 - 1 take s1 sequences each, the tiles after them s2
 
-__host__ __device__ inline SvddTilePlan svdd_plan_tiles(int n, int L, int ncu, int fixed) {
+__host__ __device__ inline SvddTilePlan svdd_plan_tiles(int n, int L, int ncu, int fixed_half) {
   const int smax = SVDD_TILE_ROWS / L;
-  SvddTilePlan best = {smax, 0, svdd_choose_spt(n, L, ncu, fixed)};
+  SvddTilePlan best = {smax, 0, svdd_choose_spt(n, L, ncu, fixed_half)};
   long long best_cost;
   {
     const long long tiles = (n + best.s2 - 1) / best.s2;
-    best_cost = ((tiles + ncu - 1) / ncu) * ((best.s2 * L + 15) / 16 + fixed);
+    best_cost = ((tiles + ncu - 1) / ncu) * (2 * ((best.s2 * L + 15) / 16) + fixed_half);
   }
   for (int s1 = smax; s1 >= 1; --s1) {
-    const long long c1 = (s1 * L + 15) / 16 + fixed;
+    const long long c1 = 2 * ((s1 * L + 15) / 16) + fixed_half;
     const long long per_round = (long long)s1 * ncu;
     for (long long k = 1; k * per_round <= n; ++k) {
       const long long r = n - k * per_round;
@@ -54,7 +56,7 @@ __host__ __device__ inline SvddTilePlan svdd_plan_tiles(int n, int L, int ncu, i
       }
       for (int s2 = smax; s2 >= 1; --s2) {
         const long long tiles2 = (r + s2 - 1) / s2;
-        const long long cost = k * c1 + ((tiles2 + ncu - 1) / ncu) * ((s2 * L + 15) / 16 + fixed);
+        const long long cost = k * c1 + ((tiles2 + ncu - 1) / ncu) * (2 * ((s2 * L + 15) / 16) + fixed_half);
         if (cost < best_cost) { best_cost = cost; best = {s1, (int)(k * ncu), s2}; }
       }
     }

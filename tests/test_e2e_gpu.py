@@ -230,7 +230,9 @@ def _assert_teacher_forced_lean(rep):
 # 4e-7 race margin, diffusion_gosai.py:1219-1225, :30-34): recorded, not chased.
 FREE_RUN_BOUNDS = {
     "c2": {"f32": (252, 2, 2), "f16x3": (252, 2, 2), "bf16x3": (251, 2, 2)},      # observed 253 / 254 / 253 rows
-    "c3": {"f32": (254, 2, 2), "f16x3": (254, 2, 2), "bf16x3": (253, 2, 2)},      # observed 255 / 255 / 254 rows
+    "c3": {"f32": (254, 2, 2), "f16x3": (254, 2, 2), "bf16x3": (251, 2, 3)},      # observed 255 / 255 / 252 rows (bf16x3: 254 on the stacked-
+                                                                                  # sequence kernel of rounds 2-4, 252 with 2 x0-hat flips on round 5's
+                                                                                  # interleaved kernel: another summation order, logits 4e-5 from fp64)
     "m20": {"f32": (256, 0, 0), "f16x3": (255, 1, 1), "bf16x3": (255, 1, 1)},     # observed 256 everywhere (f32: x_0 exact, asserted)
 }
 
