@@ -164,6 +164,8 @@ int svdd_subs_logp(const float* logits, const uint8_t* x, int B, int L, int layo
  * svdd_compact_by_key — the same compaction ORDERED by key, largest first (stable inside a key; keys clamp to 15, key <= 0 = not
  *   live): live_idx lists the live items by descending key, slot[i] = position of item i in it or -1. With key = row tiles of a
  *   candidate's window (the flags svdd_candidate_windows writes) the windowed tower's long workgroups are dispatched first.
+ *   split > 0: count must hold 3 ints; count[1] = min(count[0], split), count[2] = max(count[0] - split, 0) — the lengths of the
+ *   list's two parts [0, split) and [split, ...), for callers that run the parts as separate launches (fused.py: the GRU's second round).
  * svdd_gather_rows   — dst[i,:] = src[idx[i],:] for i < count[0] (count may be NULL = n); rows of row_bytes bytes.
  * svdd_advance_rows  — the selected candidate becomes the next parent: for every b, if slot[b*M + sel[b]] >= 0 then
  *   dst[b,:] = src[slot[...],:], else dst[b] is left untouched; rows of row_bytes (multiple of 4).
@@ -172,7 +174,7 @@ int svdd_subs_logp(const float* logits, const uint8_t* x, int B, int L, int layo
  *   parent score) and changed[b] (1 iff x_next[b] differs from x[b]). slot == NULL: exactly svdd_select.
  */
 int svdd_compact_flags(const int32_t* flags, int n, int32_t* live_idx, int32_t* slot, int32_t* count, void* stream);
-int svdd_compact_by_key(const int32_t* key, int n, int32_t* live_idx, int32_t* slot, int32_t* count, void* stream);
+int svdd_compact_by_key(const int32_t* key, int n, int32_t* live_idx, int32_t* slot, int32_t* count, int split, void* stream);
 int svdd_gather_rows(const void* src, const int32_t* idx, const int32_t* count, int n, int row_bytes, void* dst, void* stream);
 int svdd_advance_rows(const void* src, const int32_t* slot, const int32_t* sel, int B, int M, int row_bytes, void* dst,
                       void* stream);
@@ -469,7 +471,7 @@ int svdd_device_info(char* arch, int arch_len, int* num_cu);
 
 /* ABI version of this header: bumped on any signature change. */
 int svdd_abi_version(void);
-#define SVDD_ABI_VERSION 9
+#define SVDD_ABI_VERSION 10
 
 /*
  * Enformer-shaped value trunk (BASELINE.json configs[3]; reference decode.py:78-80, Enformer.py:1271-1334 trunk, :1807-1884

@@ -13,7 +13,7 @@ CSRC = os.path.join(_HERE, "csrc")
 # SVDD_HIP_LIB: load another build of the library instead (the timing-experiment scripts under tools/ build patched
 # copies of the kernels in a scratch directory; the tracked sources are never edited in place)
 SO_PATH = os.environ.get("SVDD_HIP_LIB") or os.path.join(CSRC, "libsvdd_hip.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 OK, E_ARG, E_LAUNCH, E_NODEVICE = 0, -1, -2, -3
 LAYOUT_BLV, LAYOUT_BVL = 0, 1
@@ -114,7 +114,7 @@ def lib():
     L.svdd_set_tower_version.argtypes = [i32]
     L.svdd_set_backbone_packing.argtypes = [i32]
     L.svdd_compact_flags.argtypes = [vp, i32, vp, vp, vp, vp]
-    L.svdd_compact_by_key.argtypes = [vp, i32, vp, vp, vp, vp]
+    L.svdd_compact_by_key.argtypes = [vp, i32, vp, vp, vp, i32, vp]
     L.svdd_gather_rows.argtypes = [vp, vp, vp, i32, i32, vp, vp]
     L.svdd_advance_rows.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp]
     L.svdd_select_compact.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, ctypes.POINTER(SvddRng), vp, vp, vp, vp, vp, vp]

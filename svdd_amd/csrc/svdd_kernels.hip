@@ -1000,7 +1000,7 @@ __global__ __launch_bounds__(1024) void compact_flags_kernel(const int32_t* __re
 // share a CU and the dispatcher hands them out in grid order — with the long windows first the launch does not end on a few CUs
 // that started a 13-tile window last (profiles/r05_tower_order_probe.txt: 487 -> 395 us per launch on the states of a C2 decode).
 __global__ __launch_bounds__(1024) void compact_by_key_kernel(const int32_t* __restrict__ key, int n, int32_t* __restrict__ live_idx,
-                                                              int32_t* __restrict__ slot, int32_t* __restrict__ count) {
+                                                              int32_t* __restrict__ slot, int32_t* __restrict__ count, int split) {
   __shared__ int hist[16], base[16];
   __shared__ int wave_cnt[16][16];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -1020,6 +1020,7 @@ __global__ __launch_bounds__(1024) void compact_by_key_kernel(const int32_t* __r
     int run = 0;
     for (int kk = 15; kk >= 1; --kk) { base[kk] = run; run += hist[kk]; }
     count[0] = run;
+    if (split > 0) { count[1] = min(run, split); count[2] = max(run - split, 0); }   // the list as two parts: [0, split) and the rest
   }
   __syncthreads();
   for (int i0 = 0; i0 < n; i0 += 1024) {
@@ -1430,9 +1431,9 @@ int svdd_compact_flags(const int32_t* flags, int n, int32_t* live_idx, int32_t* 
   return check_launch();
 }
 
-int svdd_compact_by_key(const int32_t* key, int n, int32_t* live_idx, int32_t* slot, int32_t* count, void* stream) {
-  if (!key || !live_idx || !slot || !count || n <= 0) return SVDD_E_ARG;
-  hipLaunchKernelGGL(compact_by_key_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, key, n, live_idx, slot, count);
+int svdd_compact_by_key(const int32_t* key, int n, int32_t* live_idx, int32_t* slot, int32_t* count, int split, void* stream) {
+  if (!key || !live_idx || !slot || !count || n <= 0 || split < 0) return SVDD_E_ARG;
+  hipLaunchKernelGGL(compact_by_key_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, key, n, live_idx, slot, count, split);
   return check_launch();
 }
 

@@ -2848,9 +2848,10 @@ extern "C" int svdd_candidate_windows(const uint8_t* cand, const uint8_t* x, int
 extern "C" int svdd_conv_tower_windows_f32(const float* onehot, const float* tiles, const float* bias, const int32_t* win,
                                            const float* parent_out, float* out, int n, int L, int M, int nlayers,
                                            int residual_mask, const int32_t* live_idx, const int32_t* count, void* stream) {
-  if (!onehot || !tiles || !bias || !win || !parent_out || !out || n <= 0 || M <= 0 || n % M || L <= TW_ROWS / 2 ||
+  if (!onehot || !tiles || !bias || !win || !parent_out || !out || n <= 0 || M <= 0 || (n % M && !live_idx) || L <= TW_ROWS / 2 ||
       L > TW_ROWS || nlayers != 5)
     return SVDD_E_ARG;                                   // one sequence per tile; margins below assume the 5-layer tower
+  // (with an index list, n is only the number of list entries this launch may take: a launch over PART of a compacted list)
   TowerWinArgs wa{TowerArgs{onehot, tiles, bias, out, n, L, 1, nlayers, residual_mask, nullptr}, win, parent_out, M, live_idx, count};
   const size_t lds = sizeof(float) * ((size_t)(TW_ROWS + 2) * TW_AP + (size_t)(TW_ROWS + 16) * 4);
   hipEvent_t e0, e1;

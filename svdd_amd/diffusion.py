@@ -180,6 +180,7 @@ class Diffusion(nn.Module):
         self.fuse_nets = True
         self.precision = "f32"
         self.skip_unchanged = True
+        self.late_steps_from = 0.8       # from this fraction of the steps on, FusedValueNet may run the live candidates as two parts (split_gru_rounds)
         self.dedup_prior = True          # the prior's rows are identical (all MASK): its net evaluations run on ONE row (exact; see _prior_logits)
         self.dps_one_launch = True       # DPS: the differentiable backbone pass as one launch each way (svdd_backbone_cnn_save_f32 / _grad_f32) where it applies
         self._dps_hard_onehot, self._dps_raw_logits = False, None
@@ -858,7 +859,8 @@ class Diffusion(nn.Module):
         def __init__(self, B, M, dev):
             i32 = dict(dtype=torch.int32, device=dev)
             self.flags, self.live_idx, self.slot = (torch.empty(B * M, **i32) for _ in range(3))
-            self.count = torch.zeros(1, **i32)
+            self.count3 = torch.zeros(3, **i32)           # [live candidates, of them in the list's first part, in its second] (svdd_compact_by_key split)
+            self.count = self.count3[0:1]
             self.row_idx, self.row_slot = torch.empty(B, **i32), torch.empty(B, **i32)
             self.row_count = torch.zeros(1, **i32)
             self.parent_score, self.sel_score = torch.empty(B, device=dev), torch.empty(B, device=dev)
@@ -867,6 +869,8 @@ class Diffusion(nn.Module):
             self.M = M
             self.n_live = torch.zeros(1, dtype=torch.int64, device=dev)
             self.n_changed = torch.zeros(1, dtype=torch.int64, device=dev)
+            self.late = False                   # set by the sampler per step: the live candidates may exceed one GRU round (FusedValueNet.split_gru_rounds)
+            self.split_bufs = None              # persistent buffers + side stream of that path
             self.prior_rows_identical = False   # set by the sampler when x is the prior: the parents' first tower pass runs on one row
             self.n_win_rows = None          # with skip_stats: rows the value net's tower computed (the candidates' row windows)
 
@@ -928,6 +932,7 @@ class Diffusion(nn.Module):
                 fb.forward_rows(x, count=ws.row_count, out=logits, row_idx=ws.row_idx, scatter=True)
             ops.propose(logits, x, sched[i, 2], sched[i, 1], M, self._rng(i, M, B, L, logits), cand=cand, onehot=onehot)
             if share:
+                ws.late = i >= int(self.late_steps_from * S)                 # late steps: (almost) every candidate is live
                 sc = fn.candidate_scores_compact(onehot, cand, x, ws).reshape(-1)
             else:
                 candidate_windows(cand, x, margin=0, flags=ws.flags)

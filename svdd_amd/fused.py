@@ -259,13 +259,15 @@ def pack_tail(w1, b1, gamma, beta):
     return w.permute(3, 1, 0, 2, 4).reshape(64, 128).contiguous(), bf
 
 
-def value_tail(h, w1pack, b1f, w_eff, b_eff, count=None):
+def value_tail(h, w1pack, b1f, w_eff, b_eff, count=None, out=None):
     """h [2, n, L, 64] (GRU output, both directions) -> scores [n, n_tasks]: direction sum + LayerNorm + dense1 + ReLU +
     collapsed (dense2, head) + mean over length in one pass (HIP kernel svdd_value_tail_f32); (w1pack, b1f) from pack_tail."""
     assert h.is_cuda and h.dtype == torch.float32 and h.is_contiguous() and h.shape[0] == 2 and h.shape[3] == 64
     _, n, L, _ = h.shape
     T = w_eff.shape[1]
-    out = torch.empty((n, T), dtype=torch.float32, device=h.device)
+    if out is None:
+        out = torch.empty((n, T), dtype=torch.float32, device=h.device)
+    assert out.is_contiguous() and out.shape == (n, T)
     rc = _lib.lib().svdd_value_tail_f32(h[0].data_ptr(), h[1].data_ptr(), w1pack.data_ptr(), b1f.data_ptr(),
                                         w_eff.data_ptr(), b_eff.data_ptr(), out.data_ptr(), n, L, T, _ptr(count),
                                         ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
@@ -636,13 +638,19 @@ def candidate_windows(cand, x, margin=TOWER_WINDOW_MARGIN, flags=None):
     return win
 
 
-def conv_tower_windows(onehot, win, parent_out, M, tiles, bias, residual_mask, live_idx=None, count=None):
+def conv_tower_windows(onehot, win, parent_out, M, tiles, bias, residual_mask, live_idx=None, count=None, out=None):
     """Tower output [n, L, 64] of the candidates' one-hot [n = B*M, L, 4], computing only the row windows `win` and
-    copying the rest from the parents' tower output [B, L, 64] (HIP kernel svdd_conv_tower_windows_f32)."""
+    copying the rest from the parents' tower output [B, L, 64] (HIP kernel svdd_conv_tower_windows_f32).
+    out: a [k, L, 64] buffer for a launch over PART of a compacted list — live_idx is then a slice of the list, count the
+    device-side length of that part, and the launch takes at most k entries."""
     assert onehot.is_cuda and onehot.dtype == torch.float32 and onehot.is_contiguous() and onehot.shape[2] == 4
     n, L, _ = onehot.shape
     assert parent_out.is_contiguous() and parent_out.shape == (n // M, L, 64) and win.shape == (n, 2)
-    out = torch.empty((n, L, 64), dtype=torch.float32, device=onehot.device)
+    if out is None:
+        out = torch.empty((n, L, 64), dtype=torch.float32, device=onehot.device)
+    else:
+        assert live_idx is not None and count is not None and out.is_contiguous() and out.shape[1:] == (L, 64)
+        n = out.shape[0]
     rc = _lib.lib().svdd_conv_tower_windows_f32(onehot.data_ptr(), tiles.data_ptr(), bias.data_ptr(), win.data_ptr(),
                                                 parent_out.data_ptr(), out.data_ptr(), n, L, M, bias.shape[0] - 1,
                                                 int(residual_mask), _ptr(live_idx), _ptr(count),
@@ -734,6 +742,8 @@ class FusedValueNet(nn.Module):
             self.b1f = nn.Parameter(bf, requires_grad=False)
         self.use_fused_tail = True
         self.share_parent_tower = True
+        self.split_gru_rounds = True         # candidate_scores_compact, late steps: the live candidates as two parts so that the GRU's second round
+                                             # hides under the first part's tower (same bits; _windows_gru_tail_split)
         self.sort_live_by_window = True      # candidate_scores_compact: live candidates ordered by window size, largest first (A/B knob; same bits)
         # "f32" (exact, default) or one of LP_DTYPES: the conv tower, GRU and tail on the 16-bit matrix cores
         # (csrc/svdd_lp_*.hip). Needs the reference-shaped net (tower_ok, tail_ok).
@@ -819,7 +829,11 @@ class FusedValueNet(nn.Module):
         # with the long ones dispatched first the launch does not end on a few CUs that began a 13-tile window last (fp32 tower
         # 487 -> 395 us per launch on a C2 decode's states, tools/tower_order_probe.py). A row's result does not depend on its
         # place in the compacted batch: same bits, same tokens.
-        (ops.compact_by_key if self.sort_live_by_window else ops.compact_flags)(ws.flags, ws.live_idx, ws.slot, ws.count)
+        split = self._gru_split(B * M) if (self.precision == "f32" and getattr(ws, "late", False)) else 0
+        if split:
+            ops.compact_by_key(ws.flags, ws.live_idx, ws.slot, ws.count3, split=split)
+        else:
+            (ops.compact_by_key if self.sort_live_by_window else ops.compact_flags)(ws.flags, ws.live_idx, ws.slot, ws.count)
         if getattr(ws, "n_win_rows", None) is not None:                     # Diffusion.skip_stats: rows the tower computes this step
             ws.n_win_rows += (win[:, 1] - win[:, 0]).sum()
         # The parents' tower output is carried from step to step: the next parent IS the selected candidate, whose tower
@@ -843,9 +857,51 @@ class FusedValueNet(nn.Module):
             ws.seq = conv_tower_windows_lp(cand, win, ws.parent_out, pk["tiles"], self.tw_bias, pk["tinv"], self.tw_resmask,
                                            pk["prec"], live_idx=ws.live_idx, count=ws.count)
             return self._after_tower_lp(ws.seq, pk, ws.count)[:, :, 0]
+        if split:
+            return self._windows_gru_tail_split(onehot, win, ws, B * M, L, M, split)
         ws.seq = conv_tower_windows(onehot, win, ws.parent_out, M, self.tw_tiles, self.tw_bias, self.tw_resmask,
                                     live_idx=ws.live_idx, count=ws.count)
         return self._after_tower(ws.seq, B * M, L, ws.count)[:, :, 0]
+
+    GRU_ROUND_ROWS = 2048        # 128 tiles of 16 sequences x 2 directions = 256 units: exactly one GRU round on 256 CUs
+
+    def _gru_split(self, n):
+        """Rows of the first part when n compacted candidates are to run as two parts (0: do not split): only where the second
+        part is at most a quarter of a round (n = B * M = 2560 at config 2)."""
+        return self.GRU_ROUND_ROWS if (self.split_gru_rounds and self.GRU_ROUND_ROWS < n <= self.GRU_ROUND_ROWS + 640
+                                       and self.use_fused_tail and self.tail_ok) else 0
+
+    def _windows_gru_tail_split(self, onehot, win, ws, n, L, M, split):
+        """The late steps of a decode have more live candidates than ONE round of the GRU's (tile, direction) units on the chip's
+        CUs (2048 rows on 256): the launch then takes two rounds, the second with 3/4 of the chip idle (0.67 instead of 0.36 ms).
+        Here the compacted list runs as two parts: B = the entries from `split` on (the smallest windows, the list being sorted),
+        A = the first `split`:   tower(B) -> [GRU(B), tail(B) on a side stream || tower(A)] -> GRU(A) -> tail(A).
+        B's GRU hides under A's tower (a GRU workgroup and a tower workgroup share a CU: 33 + 57 KB of LDS, 108 + 104 VGPRs).
+        Same kernels on the same rows: same bits per candidate (tools/gru_split_probe.py: 1270 -> 1060 us per late step)."""
+        dev = onehot.device
+        sb = ws.split_bufs
+        if sb is None or sb["n"] != n or sb["L"] != L:
+            sb = ws.split_bufs = dict(n=n, L=L, side=torch.cuda.Stream(device=dev), ev_b=torch.cuda.Event(), ev_done=torch.cuda.Event(),
+                                      seq=torch.empty((n, L, 64), device=dev), h_a=torch.empty((2, split, L, 64), device=dev),
+                                      h_b=torch.empty((2, n - split, L, 64), device=dev), sc=torch.empty((n, self.w_eff.shape[1]), device=dev))
+        seq, sc, side = sb["seq"], sb["sc"], sb["side"]
+        c_a, c_b = ws.count3[1:2], ws.count3[2:3]
+        main = torch.cuda.current_stream()
+        conv_tower_windows(onehot, win, ws.parent_out, M, self.tw_tiles, self.tw_bias, self.tw_resmask,
+                           live_idx=ws.live_idx[split:], count=c_b, out=seq[split:])
+        sb["ev_b"].record(main)
+        with torch.cuda.stream(side):
+            side.wait_event(sb["ev_b"])
+            gru_bidir(seq[split:], self.wpack, self.bpack, c_b, out=sb["h_b"])
+            value_tail(sb["h_b"], self.w1pack, self.b1f, self.w_eff, self.b_eff, c_b, out=sc[split:])
+            sb["ev_done"].record(side)
+        conv_tower_windows(onehot, win, ws.parent_out, M, self.tw_tiles, self.tw_bias, self.tw_resmask,
+                           live_idx=ws.live_idx, count=c_a, out=seq[:split])
+        gru_bidir(seq[:split], self.wpack, self.bpack, c_a, out=sb["h_a"])
+        value_tail(sb["h_a"], self.w1pack, self.b1f, self.w_eff, self.b_eff, c_a, out=sc[:split])
+        main.wait_event(sb["ev_done"])
+        ws.seq = seq
+        return sc[:, 0]
 
     def _after_tower_lp(self, seq, pk, count=None):
         h = gru_bidir_lp(seq, pk["gw"], pk["gb"], pk["ginv"], pk["prec"], count=count)

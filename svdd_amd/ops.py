@@ -156,9 +156,12 @@ def compact_flags(flags, live_idx, slot, count):
     _lib.check(rc, "svdd_compact_flags")
 
 
-def compact_by_key(key, live_idx, slot, count):
-    """The same compaction ordered by key, largest first, stable inside a key (svdd_compact_by_key): key[i] > 0 = live."""
-    rc = _lib.lib().svdd_compact_by_key(key.data_ptr(), key.numel(), live_idx.data_ptr(), slot.data_ptr(), count.data_ptr(), _stream())
+def compact_by_key(key, live_idx, slot, count, split=0):
+    """The same compaction ordered by key, largest first, stable inside a key (svdd_compact_by_key): key[i] > 0 = live.
+    split > 0: count has 3 entries and also receives the lengths of the list's parts [0, split) and [split, ...)."""
+    assert split == 0 or count.numel() >= 3
+    rc = _lib.lib().svdd_compact_by_key(key.data_ptr(), key.numel(), live_idx.data_ptr(), slot.data_ptr(), count.data_ptr(), int(split),
+                                        _stream())
     _lib.check(rc, "svdd_compact_by_key")
 
 

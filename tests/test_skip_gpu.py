@@ -343,3 +343,29 @@ def test_prior_rows_run_once_bit_identical(kind, precision):
     for (la, sa), (lb, sb) in zip(outs[0][1], outs[1][1]):
         assert torch.equal(la, lb)
         assert (sa is None) == (sb is None) and (sa is None or torch.equal(sa, sb))
+
+
+def test_mc_decode_two_part_value_net_is_bit_identical():
+    """FusedValueNet.split_gru_rounds: in the late steps of a C2 decode (more live candidates than one round of GRU units) the
+    compacted list runs as two parts on two streams (tower(B) -> [GRU(B), tail(B) || tower(A)] -> GRU(A) -> tail(A)). Forced on
+    for EVERY step here (late_steps_from = 0: the second part is then often empty), against the one-part decode: tokens and every
+    traced score identical, and the skip statistics too."""
+    from svdd_amd import synthetic
+    model, emb, head, _ = synthetic.build("dna", DEV)
+    model.rng_mode, model.philox_seed = "philox", 3
+    fn = model.value_callable(emb, head)
+    outs = []
+    for on, frm in ((True, 0.0), (True, 0.8), (False, 0.8)):
+        fn.split_gru_rounds, model.late_steps_from = on, frm
+        model.trace, model.skip_stats = [], {}
+        x0 = model.controlled_sample(emb, head, num_steps=128, eval_sp_size=256, sample_M=10)
+        torch.cuda.synchronize()
+        outs.append((x0, [sc for _, sc in model.trace if sc is not None], dict(model.skip_stats)))
+        model.trace, model.skip_stats = None, None
+    fn.split_gru_rounds, model.late_steps_from = True, 0.8
+    for o in outs[:2]:
+        assert torch.equal(o[0], outs[2][0])
+        assert len(o[1]) == len(outs[2][1]) == 128
+        for a, b in zip(o[1], outs[2][1]):
+            assert torch.equal(a, b)
+        assert o[2]["live_candidates"] == outs[2][2]["live_candidates"]
