@@ -869,7 +869,8 @@ class FusedValueNet(nn.Module):
         """Rows of the first part when n compacted candidates are to run as two parts (0: do not split): only where the second
         part is at most a quarter of a round (n = B * M = 2560 at config 2)."""
         return self.GRU_ROUND_ROWS if (self.split_gru_rounds and self.GRU_ROUND_ROWS < n <= self.GRU_ROUND_ROWS + 640
-                                       and self.use_fused_tail and self.tail_ok) else 0
+                                       and self.use_fused_tail and self.tail_ok
+                                       and not torch.cuda.is_current_stream_capturing()) else 0
 
     def _windows_gru_tail_split(self, onehot, win, ws, n, L, M, split):
         """The late steps of a decode have more live candidates than ONE round of the GRU's (tile, direction) units on the chip's
