@@ -649,11 +649,24 @@ def value_net_roofline(model, emb, head, dev, B, L, M, S, tower_ms, tower_launch
     C = 64
     tower_row = 2.0 * (4 * C * 15 + 5 * C * C * 5)             # stem 4->64 x 15 taps + five 64->64 x 5-tap blocks, per sequence row
     gru_row = 2.0 * 2 * 3 * (C * C + C * C)                    # 2 directions x 3 gates x (W_ih + W_hh), per row
+    # kernel times of THIS decode, with the late steps' two-part pipeline off: there the second part's GRU co-runs with the first
+    # part's tower on two streams (FusedValueNet.split_gru_rounds), and per-dispatch durations of co-running kernels add up to more
+    # than the wall time they take — the fractions below are kernel-exclusive
+    split_was, fn.split_gru_rounds = fn.split_gru_rounds, False
+    for k in (3, 5):
+        _lib.profile_collect(k)
     model.skip_stats = {}
+    _lib.profile_enable(True)
     model.controlled_sample(emb, head, num_steps=S, eval_sp_size=B, sample_M=M)
     torch.cuda.synchronize()
+    _lib.profile_enable(False)
+    fn.split_gru_rounds = split_was
     st, model.skip_stats = model.skip_stats, None
-    out = {}
+    (tower_ms, tower_launches), (gru_ms, gru_launches) = _lib.profile_collect(5), _lib.profile_collect(3)
+    for k in (0, 1, 6, 7):
+        _lib.profile_collect(k)
+    out = {"timing": "per-dispatch HIP events of one extra decode of the same Philox stream with the value net as ONE part per step "
+                     "(kernel-exclusive; the timed decodes run the late steps as two parts on two streams, DESIGN section 4b)"}
     rows_t = (st.get("tower_window_rows") or 0) + B * L        # + the one whole-sequence pass on the all-MASK parents
     rows_g = (st["live_candidates"] + B) * L                   # + the parents' pass
     for key, kern, flops, ms, n in (("conv_tower", "conv_tower2_kernel (value net: stem + 5 residual conv blocks; candidates' row windows)",
@@ -1133,6 +1146,8 @@ def main():
                                           "conv1d": round(conv_total_ms, 2), "gru": round(gru_total_ms, 2),
                                           "epilogue_ln": round(epi_total_ms, 2),
                                           "propose": round(k1_total_ms, 3), "select": round(k2_total_ms, 3)},
+            "own_kernels_note": "summed per-dispatch durations of the last timed decode; in its late steps the second part's GRU / tail co-run with the "
+                                "first part's tower on a side stream, so the sum can exceed the wall time those kernels take (roofline_value_net is kernel-exclusive)",
             # reference-equivalent FLOPs (every candidate through every net) per second over the fp32 peak:
             # a throughput normalisation, not a utilisation — exact work-skipping executes fewer FLOPs than that
             "e2e_fp32_frac": round(flops_seq * seqs / elapsed / 1e12 / (FP32_PEAK_TFLOPS * world), 5),
