@@ -183,7 +183,7 @@ def set_option(key, value):
 
 def set_force_exact(on):
     """A/B switch: K1 evaluates every draw in the exact arithmetic (same results, slower)."""
-    check(lib().svdd_set_option(OPT_FORCE_EXACT, int(bool(on))), "svdd_set_option")
+    set_option(OPT_FORCE_EXACT, int(bool(on)))
 
 
 def profile_enable(on=True):

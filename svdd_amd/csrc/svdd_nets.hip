@@ -2701,6 +2701,9 @@ extern "C" int svdd_backbone_split_status(int* err_out) {
   if (!err_out) return SVDD_E_ARG;
   *err_out = 0;
   if (!g_bb_ws.err) return SVDD_OK;
+  // the split launches may sit on ANY stream (the caller passes its own): a blocking hipMemcpy orders only against the null stream
+  // and blocking streams, so a launch on a non-blocking stream could still be running — and its time-out would surface one decode late
+  if (hipDeviceSynchronize() != hipSuccess) return SVDD_E_LAUNCH;
   if (hipMemcpy(err_out, g_bb_ws.err, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return SVDD_E_LAUNCH;
   if (*err_out && hipMemset(g_bb_ws.err, 0, sizeof(int)) != hipSuccess) return SVDD_E_LAUNCH;   // reported once, then cleared
   return SVDD_OK;

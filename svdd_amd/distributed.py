@@ -38,12 +38,13 @@ def init_from_env(backend=None):
             shared = torch.cuda.is_available() and torch.cuda.device_count() < local_world
             backend = os.environ.get("SVDD_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() and not shared else "gloo")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
-        if torch.cuda.is_available() and torch.cuda.device_count() < int(os.environ.get("LOCAL_WORLD_SIZE", str(world))):
-            # several ranks on one device: the small-batch backbone (2 / 4 workgroups per sequence that WAIT for each other,
-            # svdd_backbone_cnn_f32) may only be launched when all members of a group are resident at once — which another
-            # process's kernels on the same CUs can prevent. One workgroup per sequence then (same bits, no inter-workgroup wait).
-            from . import _lib
-            _lib.set_option(7, 1)
+    if world > 1 and torch.cuda.is_available() and torch.cuda.device_count() < int(os.environ.get("LOCAL_WORLD_SIZE", str(world))):
+        # several ranks on one device (whoever initialised the process group): the small-batch backbone (2 / 4 workgroups per
+        # sequence that WAIT for each other, svdd_backbone_cnn_f32) may only be launched when all members of a group are resident at
+        # once — which another process's kernels on the same CUs can prevent. One workgroup per sequence then (same bits, no
+        # inter-workgroup wait).
+        from . import _lib
+        _lib.set_option(7, 1)
     return rank, world, local
 
 

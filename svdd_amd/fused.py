@@ -863,14 +863,25 @@ class FusedValueNet(nn.Module):
                                     live_idx=ws.live_idx, count=ws.count)
         return self._after_tower(ws.seq, B * M, L, ws.count)[:, :, 0]
 
-    GRU_ROUND_ROWS = 2048        # 128 tiles of 16 sequences x 2 directions = 256 units: exactly one GRU round on 256 CUs
+    GRU_ROUND_ROWS = None        # rows of ONE round of the GRU's (tile of 16 sequences, direction) units on this chip's CUs; None: from
+                                 # the device (gru_round_rows: 8 x CUs = 2048 on MI355X's 256), an int: override (tests, A/B)
+
+    def gru_round_rows(self):
+        """One workgroup = 16 sequences in one direction, one workgroup per CU per round: a round covers CUs / 2 tiles = 8 x CUs rows."""
+        if self.GRU_ROUND_ROWS is not None:
+            return int(self.GRU_ROUND_ROWS)
+        r = self.__dict__.get("_round_rows")
+        if r is None:
+            r = self.__dict__["_round_rows"] = 8 * _lib.device_info()[1]     # asked once per net (one process drives one GPU)
+        return r
 
     def _gru_split(self, n):
         """Rows of the first part when n compacted candidates are to run as two parts (0: do not split): only where the second
-        part is at most a quarter of a round (n = B * M = 2560 at config 2)."""
-        return self.GRU_ROUND_ROWS if (self.split_gru_rounds and self.GRU_ROUND_ROWS < n <= self.GRU_ROUND_ROWS + 640
-                                       and self.use_fused_tail and self.tail_ok
-                                       and not torch.cuda.is_current_stream_capturing()) else 0
+        part is at most 5/16 of a round (n = B * M = 2560 at config 2 on 256 CUs: 2048 + 512)."""
+        if not (self.split_gru_rounds and self.use_fused_tail and self.tail_ok) or torch.cuda.is_current_stream_capturing():
+            return 0
+        r = self.gru_round_rows()
+        return r if r < n <= r + (5 * r) // 16 else 0
 
     def _windows_gru_tail_split(self, onehot, win, ws, n, L, M, split):
         """The late steps of a decode have more live candidates than ONE round of the GRU's (tile, direction) units on the chip's
@@ -880,11 +891,17 @@ class FusedValueNet(nn.Module):
         B's GRU hides under A's tower (a GRU workgroup and a tower workgroup share a CU: 33 + 57 KB of LDS, 108 + 104 VGPRs).
         Same kernels on the same rows: same bits per candidate (tools/gru_split_probe.py: 1270 -> 1060 us per late step)."""
         dev = onehot.device
-        sb = ws.split_bufs
-        if sb is None or sb["n"] != n or sb["L"] != L:
-            sb = ws.split_bufs = dict(n=n, L=L, side=torch.cuda.Stream(device=dev), ev_b=torch.cuda.Event(), ev_done=torch.cuda.Event(),
-                                      seq=torch.empty((n, L, 64), device=dev), h_a=torch.empty((2, split, L, 64), device=dev),
-                                      h_b=torch.empty((2, n - split, L, 64), device=dev), sc=torch.empty((n, self.w_eff.shape[1]), device=dev))
+        # persistent buffers + the side stream: kept on the NET (one set per (n, L, split, device)), not on the per-decode workspace —
+        # every decode used to allocate ~400 MB and a new stream; decodes on one stream follow each other, so the set is never shared
+        key = (n, L, split, str(dev))
+        cache = self.__dict__.setdefault("_split_bufs", {})
+        sb = cache.get(key)
+        if sb is None:
+            cache.clear()
+            sb = cache[key] = dict(n=n, L=L, side=torch.cuda.Stream(device=dev), ev_b=torch.cuda.Event(), ev_done=torch.cuda.Event(),
+                                   seq=torch.empty((n, L, 64), device=dev), h_a=torch.empty((2, split, L, 64), device=dev),
+                                   h_b=torch.empty((2, n - split, L, 64), device=dev), sc=torch.empty((n, self.w_eff.shape[1]), device=dev))
+        ws.split_bufs = sb
         seq, sc, side = sb["seq"], sb["sc"], sb["side"]
         c_a, c_b = ws.count3[1:2], ws.count3[2:3]
         main = torch.cuda.current_stream()

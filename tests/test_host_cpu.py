@@ -331,6 +331,77 @@ def test_bench_starts_its_own_ranks_from_a_bare_shell():
     assert bad.returncode != 0
 
 
+def _import_bench():
+    import importlib
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    return importlib.import_module("bench")
+
+
+def test_bench_compact_line_fits_the_drivers_record():
+    """Round 5's final stdout line was 24.9 KB and the driver's record (the last ~8 KB of stdout) could not be parsed. The line the
+    driver reads is now bench.compact_line(full): built here from round 5's own long record (profiles/r05_bench_driver_cmd.json),
+    it must be < 6144 bytes, parse, and keep every key of the bench contract with `roofline` and `cpu_baseline` intact."""
+    import json
+    bench = _import_bench()
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_driver_cmd.json")))
+    s = bench.compact_line(full, "bench_full.json")
+    assert "\n" not in s and len(s.encode()) < 6144, len(s)
+    line = json.loads(s)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert line["value"] == full["value"] and line["ms_per_step"] == full["ms_per_step"] and line["config"] == full["config"]
+    r, rf = line["roofline"], full["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "flops_per_launch", "avg_launch_us", "launches"):
+        assert r[k] == rf[k], k
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert len(r["also"]) == len(rf["also"]) and "also_truncated" not in r
+    assert all(set(e) <= {"k", "w", "frac", "issued", "us", "ms"} and len(json.dumps(e)) < 110 for e in r["also"])
+    cb = line["cpu_baseline"]
+    assert cb["value"] == full["cpu_baseline"]["value"] and cb["cores"] == 16 and cb["kind"] == "port" and cb["unit"] and cb["sample"]
+    assert set(line["configs"]) >= {"c1_b4", "c3_pm", "c4_f32", "c4_bf16x3", "c5_tds_shard", "c5_tds_pop", "c5_dps"}
+    assert line["configs"]["c3_pm"]["value"] == round(full["config3_pm"]["value"], 2)
+    assert line["alt"]["f16x3"]["rows_vs_f32"] == full["alt_precision"]["f16x3"]["x0_rows_identical_vs_f32"]
+    # a record that outgrows the limit sheds `also` entries / detail objects, never the contract keys
+    fat = json.loads(json.dumps(full))
+    fat["roofline"]["also"] = fat["roofline"]["also"] * 12
+    s2 = bench.compact_line(fat, "bench_full.json")
+    l2 = json.loads(s2)
+    assert len(s2.encode()) <= 6144 and l2["roofline"]["also_truncated"] and l2["cpu_baseline"]["value"] == cb["value"] and l2["value"] == line["value"]
+    # a leg that failed shows its error, a leg that was skipped is absent
+    broken = json.loads(json.dumps(full))
+    broken["config3_pm"] = {"error": "RuntimeError: boom"}
+    del broken["config4_enformer"]
+    l3 = json.loads(bench.compact_line(broken))
+    assert "boom" in l3["configs"]["c3_pm"]["error"] and "c4_f32" not in l3["configs"] and "full_json" not in l3
+
+
+def test_bench_cpu_thread_choice_is_a_rule_not_a_race():
+    """cpu_baseline's thread count: fastest per-count minimum; counts within 5 % tie and ties go to the count nearest 16 (round 5's
+    driver run chose 8 over 16 on 1.3459 s vs 1.3648 s, the builder's run 16: the GPU / CPU ratio moved 1.7 x between records)."""
+    bench = _import_bench()
+    assert bench.choose_threads({8: 1.3459, 16: 1.3648, 32: 2.7}) == 16
+    assert bench.choose_threads({8: 1.5608, 16: 1.0628, 32: 2.6963}) == 16
+    assert bench.choose_threads({8: 1.00, 16: 1.20, 32: 2.0}) == 8
+    assert bench.choose_threads({8: 1.2, 16: 1.1, 32: 1.0}) == 32
+    assert bench.choose_threads({8: 1.0, 32: 1.01}) == 8
+    assert bench.choose_threads({4: 1.0}) == 4
+
+
+def test_bench_emit_prints_the_compact_line_last(tmp_path, capsys):
+    import json
+    bench = _import_bench()
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_driver_cmd.json")))
+    path = tmp_path / "full.json"
+    bench.emit(full, str(path))
+    cap = capsys.readouterr()
+    out_lines = [ln for ln in cap.out.splitlines() if ln.strip()]
+    assert len(out_lines) == 1 and len(out_lines[0]) < 6144 and json.loads(out_lines[0])["value"] == full["value"]
+    assert cap.err.startswith("BENCH_FULL {") and json.loads(cap.err[len("BENCH_FULL "):])["roofline"] == full["roofline"]
+    assert json.load(open(path))["cpu_baseline"] == full["cpu_baseline"]
+
+
 def test_dps_gradient_matches_reference_full_size(golden):
     """g20: compute_gradient_DPS of the PyTorch mirrors (CNNModel.forward2 + ConvGRU reward model, seed 44 in synthetic.build's
     order) against the gradients of the reference's own full-size controlled_sample_DPS run, on the CPU: same framework, same

@@ -14,11 +14,11 @@ dev = "cuda"
 if "--rg" in sys.argv:                            # A/B: row groups (waves per SIMD) of the transposed kernel: 2, 3 or 4
     from svdd_amd import _lib
     k = sys.argv.index("--rg")
-    _lib.check(_lib.lib().svdd_set_option(3, 20 + int(sys.argv[k + 1])), "backbone lp row groups")
+    _lib.set_option(3, 20 + int(sys.argv[k + 1]))
     del sys.argv[k:k + 2]
 if "--v1" in sys.argv:                            # A/B: the round-2 kernel (svdd_set_option SVDD_OPT_BACKBONE_LP_VERSION = 1)
     from svdd_amd import _lib
-    _lib.check(_lib.lib().svdd_set_option(3, 1), "backbone lp version")
+    _lib.set_option(3, 1)
     sys.argv.remove("--v1")
 if "--time-only" in sys.argv:                    # ablation experiments: time of one mode, nothing else
     import time as _t

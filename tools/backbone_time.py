@@ -10,7 +10,7 @@ import torch
 from svdd_amd import _lib, backbone, config, fused
 
 if os.environ.get("SVDD_BB_LP_VERSION"):               # A/B of the split-precision backbone kernels (SVDD_OPT_BACKBONE_LP_VERSION)
-    _lib.check(_lib.lib().svdd_set_option(3, int(os.environ["SVDD_BB_LP_VERSION"])), "svdd_set_option")
+    _lib.set_option(3, int(os.environ["SVDD_BB_LP_VERSION"]))
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 L = int(sys.argv[2]) if len(sys.argv) > 2 else 200

@@ -16,7 +16,7 @@ args = ap.parse_args()
 dev = "cuda:0"
 torch.manual_seed(0)
 _lib.set_force_exact(args.exact)
-_lib.check(_lib.lib().svdd_set_option(1, args.msplit), 'msplit')
+_lib.set_option(1, args.msplit)
 for (B, L, M) in [(256, 200, 10), (2048, 200, 10), (16384, 200, 10), (2048, 200, 20)]:
     logits = torch.randn(B, 5, L, device=dev).transpose(1, 2)
     x = torch.where(torch.rand(B, L, device=dev) < args.masked_frac, torch.full((B, L), 4, device=dev), torch.randint(0, 4, (B, L), device=dev)).to(torch.uint8)

@@ -14,7 +14,7 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else 300
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 256
 L = int(sys.argv[4]) if len(sys.argv) > 4 else 200
 if os.environ.get("SVDD_BB_LP_VERSION"):
-    _lib.check(_lib.lib().svdd_set_option(3, int(os.environ["SVDD_BB_LP_VERSION"])), "svdd_set_option")
+    _lib.set_option(3, int(os.environ["SVDD_BB_LP_VERSION"]))
 dev = "cuda:0"
 torch.manual_seed(11)
 cnn = backbone.CNNModel((config.dna_config() if L > 104 else config.rna_config()).model, alphabet_size=5).to(dev).eval()

@@ -17,7 +17,7 @@ B = int(args[1]) if len(args) > 1 else 256
 L = 200
 dev = "cuda:0"
 if os.environ.get("SVDD_BB_LP_VERSION"):               # 21 / 22 / 23: waves per SIMD of the transposed kernel
-    _lib.check(_lib.lib().svdd_set_option(3, int(os.environ["SVDD_BB_LP_VERSION"])), "svdd_set_option")
+    _lib.set_option(3, int(os.environ["SVDD_BB_LP_VERSION"]))
 torch.manual_seed(0)
 cnn = backbone.CNNModel(config.dna_config().model, alphabet_size=5).to(dev).eval()
 x = torch.randint(0, 5, (B, L), device=dev, dtype=torch.uint8)

@@ -40,7 +40,7 @@ def k2(B, M, L=200, compact=False, ld=0, scale=1e-3):
         wide = torch.zeros(B, M, ld, dtype=torch.uint8, device=DEV)
         wide[:, :, :L] = cand
         cand_dense, cand = cand, wide
-        assert _lib.lib().svdd_set_option(5, ld) == 0
+        _lib.set_option(5, ld)
 
     if compact:
         live = torch.rand(B * M, device=DEV, generator=g) < 0.77
@@ -64,7 +64,7 @@ def k2(B, M, L=200, compact=False, ld=0, scale=1e-3):
         torch.cuda.synchronize()
         if not compact:
             assert torch.equal(x_next, ref), "padded-row select differs from the dense one"
-        assert _lib.lib().svdd_set_option(5, 0) == 0
+        _lib.set_option(5, 0)
     gbs = nbytes / us / 1e3
     print(f"K2 select{'_compact' if compact else ''} B={B} M={M} L={L} ld={ld or L} scores~{scale:g}: {us:9.1f} us  {gbs:8.1f} GB/s  frac {gbs / PEAK:.3f}  ({nbytes / 1e6:.1f} MB)")
 

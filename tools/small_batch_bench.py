@@ -29,7 +29,7 @@ for B, M in ((4, 2), (4, 10), (32, 10), (64, 10), (128, 10), (256, 10)):
     x = torch.randint(0, 5, (B, 200), device=DEV, dtype=torch.uint8)
     res = {}
     for name, opt in (("one workgroup / sequence", 1), ("split (auto)", 0)):
-        lib.svdd_set_option(7, opt)
+        _lib.set_option(7, opt)
         with torch.no_grad():
             fwd = timed(lambda: model._backbone_logits(x), 20)
             dec = timed(lambda: model.controlled_sample(emb, head, num_steps=128, eval_sp_size=B, sample_M=M), 2)
@@ -37,4 +37,4 @@ for B, M in ((4, 2), (4, 10), (32, 10), (64, 10), (128, 10), (256, 10)):
         print(f"B={B:4d} M={M:2d} {name:26s}: backbone forward {fwd:6.3f} ms   decode {dec:7.1f} ms = {B / dec * 1e3:7.1f} seq/s")
     a, b = res["one workgroup / sequence"], res["split (auto)"]
     print(f"          speed-up: forward x{a[0] / b[0]:.2f}  decode x{a[1] / b[1]:.2f}")
-lib.svdd_set_option(7, 0)
+_lib.set_option(7, 0)

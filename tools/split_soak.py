@@ -24,18 +24,18 @@ bad = 0
 launches = 0
 for n, L in ((4, 200), (17, 200), (32, 200), (64, 200), (64, 187), (100, 200), (128, 200), (300, 200)):
     x = torch.randint(0, 5, (n, L), device=DEV, dtype=torch.uint8)
-    lib.svdd_set_option(7, 1)
+    _lib.set_option(7, 1)
     ref = fused.backbone_cnn(x, pk).clone()
-    lib.svdd_set_option(7, 0)
+    _lib.set_option(7, 0)
     for it in range(args.iters):
         if it % 3 == 0:
             with torch.cuda.stream(side):                      # something else hammering the memory system meanwhile
                 noise.add_(1.0)
         if it % 50 == 25:
             x = torch.randint(0, 5, (n, L), device=DEV, dtype=torch.uint8)
-            lib.svdd_set_option(7, 1)
+            _lib.set_option(7, 1)
             ref = fused.backbone_cnn(x, pk).clone()
-            lib.svdd_set_option(7, 0)
+            _lib.set_option(7, 0)
         out = fused.backbone_cnn(x, pk)
         launches += 1
         if not torch.equal(out, ref):

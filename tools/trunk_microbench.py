@@ -20,7 +20,7 @@ tok = torch.randint(0, 5, (n, 200), device=dev, dtype=torch.uint8)
 fn = FusedEnformerValueNet(emb, head, prec)
 if os.environ.get("SVDD_TRUNK_GEMM"):                  # A/B: 1 = 128 x 128 tiles everywhere, 3 = 256 x 256 everywhere
     from svdd_amd import _lib
-    _lib.check(_lib.lib().svdd_set_option(4, int(os.environ["SVDD_TRUNK_GEMM"])), "svdd_set_option")
+    _lib.set_option(4, int(os.environ["SVDD_TRUNK_GEMM"]))
 
 
 def bench(f, it=3):

@@ -12,10 +12,10 @@ for prec in ("f32", "bf16x3"):
     fn = model.value_callable(emb, head)
     model.controlled_sample(emb, head, num_steps=S, eval_sp_size=B, sample_M=M); torch.cuda.synchronize()
     for name, bm, hint in (("256-row tiles only", 41, True), ("by cost, no concurrency hint", 40, False), ("by cost, with hint", 40, True), ("256-row tiles only", 41, True), ("by cost, with hint", 40, True)):
-        lib.svdd_set_option(4, bm); fn.gemm_conc_hint = hint
+        _lib.set_option(4, bm); fn.gemm_conc_hint = hint
         t0 = time.perf_counter()
         model.controlled_sample(emb, head, num_steps=S, eval_sp_size=B, sample_M=M)
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
         print(f"{prec:7s} {name:32s}: {el:6.2f} s = {B / el:6.2f} seq/s")
-lib.svdd_set_option(4, 40)
+_lib.set_option(4, 40)
