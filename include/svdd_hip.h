@@ -453,7 +453,7 @@ int svdd_set_option(int key, int value);
 int svdd_k1_stats(unsigned long long* device_counters2);
 
 /* Per-launch kernel timing (host). While enabled, svdd_propose (kernel 0), svdd_select (1), svdd_conv1d_cl_f32 (2),
- * svdd_gru_bidir_f32 (3), svdd_epilogue_ln_f32 (4), svdd_conv_tower_f32 (5), svdd_backbone_cnn_f32 / _save_f32 (6), svdd_value_tail_f32 (7), svdd_tds_resample (8), svdd_mt19937_uniform_f32 (9) and svdd_backbone_cnn_grad_f32 (10) are dispatched
+ * svdd_gru_bidir_f32 (3), svdd_epilogue_ln_f32 (4), svdd_conv_tower_f32 (5), svdd_backbone_cnn_f32 / _save_f32 (6), svdd_value_tail_f32 (7), svdd_tds_resample (8), svdd_mt19937_uniform_f32 (9), svdd_backbone_cnn_grad_f32 (10), svdd_gru_bidir_train_f32 (11) and svdd_gru_bidir_bwd_f32 (12) are dispatched
  * with HIP start/stop events bound to the dispatch on its launch stream
  * (hipExtLaunchKernelGGL); svdd_profile_collect waits for the recorded launches, returns the summed
  * hipEventElapsedTime and their count, and clears the record. Not for use during graph capture. */
@@ -471,7 +471,7 @@ int svdd_device_info(char* arch, int arch_len, int* num_cu);
 
 /* ABI version of this header: bumped on any signature change. */
 int svdd_abi_version(void);
-#define SVDD_ABI_VERSION 10
+#define SVDD_ABI_VERSION 11
 
 /*
  * Enformer-shaped value trunk (BASELINE.json configs[3]; reference decode.py:78-80, Enformer.py:1271-1334 trunk, :1807-1884
@@ -539,6 +539,39 @@ int svdd_trunk_attn_pool_win(const float* x, const float* logits, int n, int L, 
                              const void* parent_lo, const int32_t* count, void* out_hi, void* out_lo, const float* post_scale,
                              const float* post_shift, int post_act, const int32_t* v0, const int32_t* vlen, const int32_t* off2,
                              void* stream);
+
+/* --------------------------------------------------------------------------------------------------------------------------
+ * DPS (gradient guidance, BASELINE configs[4]) without autograd — ABI 11. The reference's step (diffusion_gosai.py:1286-1330):
+ *   x_grad = d mean(reward(softmax(E)[:, 0:4])) / d onehot(x_t),  E = keep onehot(x_t) + (1 - keep) log p(x0 | x_t)      (:1321-1330)
+ *   q_xs   = exp(log p) (mct - mcs), q_xs[MASK] = mcs, times exp(scale (x_grad - x_grad[MASK]))                        (:1306-1314)
+ * Per-position pieces (logits = the one-launch backbone's raw output [B][L][5] contiguous, x = tokens u8 [B][L]):
+ *   svdd_dps_probs       -> probs4 [B][L][4] = softmax(E)[..., 0:4], the reward net's input
+ *   svdd_dps_probs_bwd   dprobs4 [B][L][4] -> dlogits [B][L][5] (input of svdd_backbone_cnn_grad_f32; zero at unmasked positions) and
+ *                        direct [B][L][5] = keep dE (the term through `keep * x_onehot`; zero at masked positions)
+ *   svdd_dps_guided_q    grad_backbone + grad_direct = x_grad -> the guided q_xs [B][L][5]
+ * The reward net's gradient pass (ConvGRUTrunk + ConvHead, Enformer.py:1411-1426, 2166-2173; eval-mode BatchNorm folded):
+ *   svdd_reward_stem_f32 / _bwd_f32   the 4 -> 64 x 15-tap stem on REAL-valued rows x [n][L][4] (w as [15][4][64]): relu(conv + b) /
+ *                                     its transpose applied to the gradient at the stem's pre-activation
+ *   svdd_conv1d_cl_f32 (act = 1)      a tower layer forwards: relu(conv + b + f_prev)
+ *   svdd_conv1d_cl_gated_f32          a tower layer backwards: gate > 0 ? conv^T(g) + f_prev : 0 (wpack = flipped, transposed taps)
+ *   svdd_gru_bidir_train_f32 / _bwd_f32   the GRU (above)
+ *   svdd_reward_tail_grad_f32         h_fwd, h_bwd [n][L][64] -> d mean_n(mean_l(score)) / d (h_fwd + h_bwd), written to g_fwd AND g_bwd
+ *                                     (w1 [128][64], b1 [128]: dense1; gamma / beta [64]: its LayerNorm; w_eff [128]: dense2 and the
+ *                                     head collapsed, task 0)
+ *   svdd_sum_gate_f32                 g = f > 0 ? a + b : 0 over `count` floats (count % 4 == 0)
+ * All: caller-owned device buffers, launched on `stream`, no allocation, no synchronisation. */
+int svdd_dps_probs(const float* logits, const uint8_t* x, int B, int L, float* probs4, void* stream);
+int svdd_dps_probs_bwd(const float* logits, const uint8_t* x, const float* dprobs4, int B, int L, float* dlogits, float* direct,
+                       void* stream);
+int svdd_dps_guided_q(const float* logits, const uint8_t* x, const float* grad_backbone, const float* grad_direct, float dm, float mcs,
+                      float scale, int B, int L, float* q, void* stream);
+int svdd_reward_stem_f32(const float* x, const float* w, const float* b, float* out, int n, int L, int taps, void* stream);
+int svdd_reward_stem_bwd_f32(const float* g, const float* w, float* dx, int n, int L, int taps, void* stream);
+int svdd_conv1d_cl_gated_f32(const float* x, const float* wpack, float* y, int n, int L, int cin, int cout, int taps, int dilation,
+                             const float* f_prev, const float* gate, void* stream);
+int svdd_reward_tail_grad_f32(const float* h_fwd, const float* h_bwd, const float* w1, const float* b1, const float* gamma,
+                              const float* beta, const float* w_eff, float eps, int n, int L, float* g_fwd, float* g_bwd, void* stream);
+int svdd_sum_gate_f32(const float* a, const float* b, const float* f, float* g, int64_t count, void* stream);
 
 #ifdef __cplusplus
 }

@@ -13,7 +13,7 @@ CSRC = os.path.join(_HERE, "csrc")
 # SVDD_HIP_LIB: load another build of the library instead (the timing-experiment scripts under tools/ build patched
 # copies of the kernels in a scratch directory; the tracked sources are never edited in place)
 SO_PATH = os.environ.get("SVDD_HIP_LIB") or os.path.join(CSRC, "libsvdd_hip.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 OK, E_ARG, E_LAUNCH, E_NODEVICE = 0, -1, -2, -3
 LAYOUT_BLV, LAYOUT_BVL = 0, 1
@@ -35,6 +35,8 @@ EXPORTS = (
     "svdd_trunk_windows", "svdd_trunk_stem_unfold_win", "svdd_trunk_attn_pool_win",
     "svdd_bb_layer_fwd_f32", "svdd_bb_layer_bwd_f32", "svdd_mt19937_uniform_f32",
     "svdd_backbone_set_workspace", "svdd_backbone_split_status", "svdd_backbone_cnn_save_f32", "svdd_backbone_cnn_grad_f32",
+    "svdd_dps_probs", "svdd_dps_probs_bwd", "svdd_dps_guided_q", "svdd_reward_stem_f32", "svdd_reward_stem_bwd_f32",
+    "svdd_conv1d_cl_gated_f32", "svdd_reward_tail_grad_f32", "svdd_sum_gate_f32",
 )
 OPT_FORCE_EXACT = 0
 
@@ -135,6 +137,14 @@ def lib():
     L.svdd_trunk_stem_unfold_win.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]
     L.svdd_trunk_attn_pool_win.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp]
     L.svdd_trunk_attn_small.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp]
+    L.svdd_dps_probs.argtypes = [vp, vp, i32, i32, vp, vp]
+    L.svdd_dps_probs_bwd.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp]
+    L.svdd_dps_guided_q.argtypes = [vp, vp, vp, vp, f32, f32, f32, i32, i32, vp, vp]
+    L.svdd_reward_stem_f32.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp]
+    L.svdd_reward_stem_bwd_f32.argtypes = [vp, vp, vp, i32, i32, i32, vp]
+    L.svdd_conv1d_cl_gated_f32.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp]
+    L.svdd_reward_tail_grad_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, f32, i32, i32, vp, vp, vp]
+    L.svdd_sum_gate_f32.argtypes = [vp, vp, vp, vp, i64, vp]
     L.svdd_profile_enable.argtypes = [i32]
     L.svdd_profile_collect.argtypes = [i32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]
     L.svdd_device_info.argtypes = [ctypes.c_char_p, i32, ctypes.POINTER(ctypes.c_int)]

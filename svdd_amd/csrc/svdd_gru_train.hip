@@ -22,6 +22,7 @@
 //   dn = dh' (1 - z) ; dz = dh' (h - n) ; da_n = dn (1 - n^2) ; da_r = da_n (W_hn h + b_hn) r (1 - r) ; da_z = dz z (1 - z)
 //   dx = W_ir^T da_r + W_iz^T da_z + W_in^T da_n ; dh = dh' z + W_hr^T da_r + W_hz^T da_z + W_hn^T (da_n r)
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include "svdd_hip.h"
@@ -295,7 +296,131 @@ __global__ __launch_bounds__(256) void bb_layer_bwd_kernel(BbBwdArgs a) {
   }
 }
 
+// ---------------------------------------------- the rest of the reward net's gradient pass without autograd (round 6) ----
+// DPS needs d mean(score) / d input of the ConvGRU reward net (reference Enformer.py:1411-1426, 2166-2173 under
+// diffusion_gosai.py:1326-1329). Round 5 ran the convolutions and the GRU on hand-written kernels but left the stem, every bias /
+// residual / ReLU, the tail and all their autograd twins to ~110 torch element-wise launches per step. With the kernels below (and
+// svdd_conv1d_cl_f32's fused epilogue forwards, svdd_conv1d_cl_gated_f32 backwards) the whole pass is 16 launches, no autograd.
+
+
+// stem: f0[p][co] = relu(b[co] + sum_t sum_c x[p + t - T/2][c] W[t][c][co]), x [n][L][4] (any real values: softmax probabilities),
+// W as [T][4][64]. One wave per position (lane = co), positions in a grid-stride loop; the lane's 4 T weights live in registers.
+template <int T>
+__global__ __launch_bounds__(256) void reward_stem_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                                                              float* __restrict__ out, int64_t rows, int L) {
+  const int lane = threadIdx.x & 63;
+  float wr[T][4];
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) wr[t][c] = w[(t * 4 + c) * 64 + lane];
+  const float bias = b[lane];
+  const int64_t nw = (int64_t)gridDim.x * 4;
+  for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += nw) {
+    const int pos = (int)(r % L);
+    float acc = bias;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const int q = pos + t - T / 2;
+      if (q < 0 || q >= L) continue;                           // wave-uniform
+      const float4 xv = *reinterpret_cast<const float4*>(x + (r + t - T / 2) * 4);
+      acc += xv.x * wr[t][0] + xv.y * wr[t][1] + xv.z * wr[t][2] + xv.w * wr[t][3];
+    }
+    out[r * 64 + lane] = fmaxf(acc, 0.0f);
+  }
+}
+
+// transpose of the stem: dx[p][c] = sum_t sum_co W[t][c][co] g[p - (t - T/2)][co], g [n][L][64] = the gradient at the stem's
+// pre-activation (already gated by its ReLU). One wave per position, lane = co, four wave reductions.
+template <int T>
+__global__ __launch_bounds__(256) void reward_stem_bwd_kernel(const float* __restrict__ g, const float* __restrict__ w, float* __restrict__ dx,
+                                                              int64_t rows, int L) {
+  const int lane = threadIdx.x & 63;
+  float wr[T][4];
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) wr[t][c] = w[(t * 4 + c) * 64 + lane];
+  const int64_t nw = (int64_t)gridDim.x * 4;
+  for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += nw) {
+    const int pos = (int)(r % L);
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const int q = pos - (t - T / 2);
+      if (q < 0 || q >= L) continue;
+      const float gv = g[(r - (t - T / 2)) * 64 + lane];
+      a0 += gv * wr[t][0]; a1 += gv * wr[t][1]; a2 += gv * wr[t][2]; a3 += gv * wr[t][3];
+    }
+    a0 = wave_sum64(a0); a1 = wave_sum64(a1); a2 = wave_sum64(a2); a3 = wave_sum64(a3);
+    if (lane == 0) *reinterpret_cast<float4*>(dx + r * 4) = make_float4(a0, a1, a2, a3);
+  }
+}
+
+// g = (a + b) where f > 0, else 0: the two directions' input gradients of the GRU summed and gated by the last tower layer's ReLU
+__global__ __launch_bounds__(256) void sum_gate_kernel(const float4* __restrict__ a, const float4* __restrict__ b, const float4* __restrict__ f,
+                                                       float4* __restrict__ g, int64_t n4) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const float4 av = a[i], bv = b[i], fv = f[i];
+    g[i] = make_float4(fv.x > 0.0f ? av.x + bv.x : 0.0f, fv.y > 0.0f ? av.y + bv.y : 0.0f, fv.z > 0.0f ? av.z + bv.z : 0.0f,
+                       fv.w > 0.0f ? av.w + bv.w : 0.0f);
+  }
+}
+
+// The tail's forward AND backward in one pass (GRUBlock's direction sum + FFN + ConvHead + mean over length and batch, Enformer.py:
+// 1617, 2010-2047, 2166-2173): the loss is mean_n(mean_l(w_eff . relu(W1 LN(h_f + h_b) + b1)) + b_eff), so its gradient with respect
+// to h_f + h_b needs nothing from outside the row:  dz = [z > 0] w_eff / (n L) ; dhn = W1^T dz ; ds = LN'(gamma dhn).
+// One wave per row (lane = channel); W1 sits in LDS both ways ([c][k] for z, [k][c] for dhn: both conflict-free).
+__global__ __launch_bounds__(256) void reward_tail_grad_kernel(const float* __restrict__ h0, const float* __restrict__ h1, const float* __restrict__ w1 /*[128][64]*/,
+                                                               const float* __restrict__ b1, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               const float* __restrict__ w_eff /*[128]*/, float eps, float inv_count,
+                                                               float* __restrict__ g0, float* __restrict__ g1, int64_t rows) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* w1kc = sm;                    // [128][64]
+  float* w1ck = sm + 128 * 64;         // [64][128]
+  float* buf = w1ck + 64 * 128;        // per wave: hn [64] + dz [128]
+  for (int e = threadIdx.x; e < 128 * 64; e += 256) {
+    const float v = w1[e];
+    w1kc[e] = v;
+    w1ck[(e & 63) * 128 + (e >> 6)] = v;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float* hn_s = buf + wv * 192;
+  float* dz_s = hn_s + 64;
+  const float gm = gamma[lane], bt = beta[lane];
+  const float b1a = b1[lane], b1b = b1[lane + 64], wea = w_eff[lane] * inv_count, web = w_eff[lane + 64] * inv_count;
+  const int64_t nw = (int64_t)gridDim.x * 4;
+  for (int64_t r = (int64_t)blockIdx.x * 4 + wv; r < rows; r += nw) {
+    const float s = h0[r * 64 + lane] + h1[r * 64 + lane];
+    const float mean = wave_sum64(s) * (1.0f / 64);
+    const float d = s - mean;
+    const float rstd = rsqrtf(wave_sum64(d * d) * (1.0f / 64) + eps);
+    const float xh = d * rstd;
+    hn_s[lane] = xh * gm + bt;
+    float za = b1a, zb = b1b;                                  // z[lane], z[lane + 64]
+#pragma unroll 8
+    for (int c = 0; c < 64; ++c) {
+      const float hv = hn_s[c];                                // broadcast (same wave wrote it: no barrier needed across waves)
+      za += hv * w1ck[c * 128 + lane];
+      zb += hv * w1ck[c * 128 + 64 + lane];
+    }
+    dz_s[lane] = za > 0.0f ? wea : 0.0f;
+    dz_s[lane + 64] = zb > 0.0f ? web : 0.0f;
+    float dh = 0.0f;
+#pragma unroll 8
+    for (int k = 0; k < 128; ++k) dh += dz_s[k] * w1kc[k * 64 + lane];
+    const float t = dh * gm;
+    const float m1 = wave_sum64(t) * (1.0f / 64), m2 = wave_sum64(t * xh) * (1.0f / 64);
+    const float ds = rstd * (t - m1 - xh * m2);
+    g0[r * 64 + lane] = ds;
+    g1[r * 64 + lane] = ds;
+  }
+}
+
 }  // namespace
+
+extern "C" void svdd_internal_timed_events(int k, hipEvent_t* e0, hipEvent_t* e1);   // svdd_kernels.hip (profiling)
 
 extern "C" {
 
@@ -337,16 +462,57 @@ int svdd_bb_layer_bwd_f32(const float* g_hn, const float* f_in, const float* tb,
 int svdd_gru_bidir_train_f32(const float* x, const float* wpack, const float* bpack, float* out, float* save, int n, int L,
                              void* stream) {
   if (!x || !wpack || !bpack || !out || !save || n <= 0 || L <= 0) return SVDD_E_ARG;
-  hipLaunchKernelGGL(gru_train_fwd_kernel, dim3(2 * (unsigned)((n + TS - 1) / TS)), dim3(256), 0, (hipStream_t)stream, x, wpack,
-                     bpack, out, save, n, L);
+  hipEvent_t e0, e1;
+  svdd_internal_timed_events(11, &e0, &e1);
+  hipExtLaunchKernelGGL(gru_train_fwd_kernel, dim3(2 * (unsigned)((n + TS - 1) / TS)), dim3(256), 0, (hipStream_t)stream, e0, e1, 0,
+                        x, wpack, bpack, out, save, n, L);
   return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
 }
 
 int svdd_gru_bidir_bwd_f32(const float* grad_out, const float* out, const float* save, const float* wpack_bwd, float* dx, int n,
                            int L, void* stream) {
   if (!grad_out || !out || !save || !wpack_bwd || !dx || n <= 0 || L <= 0) return SVDD_E_ARG;
-  hipLaunchKernelGGL(gru_bwd_kernel, dim3(2 * (unsigned)((n + TS - 1) / TS)), dim3(256), 0, (hipStream_t)stream, grad_out, out,
-                     save, wpack_bwd, dx, n, L);
+  hipEvent_t e0, e1;
+  svdd_internal_timed_events(12, &e0, &e1);
+  hipExtLaunchKernelGGL(gru_bwd_kernel, dim3(2 * (unsigned)((n + TS - 1) / TS)), dim3(256), 0, (hipStream_t)stream, e0, e1, 0,
+                        grad_out, out, save, wpack_bwd, dx, n, L);
+  return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
+}
+
+int svdd_reward_stem_f32(const float* x, const float* w, const float* b, float* out, int n, int L, int taps, void* stream) {
+  if (!x || !w || !b || !out || n <= 0 || L <= 0 || taps != 15) return SVDD_E_ARG;
+  const int64_t rows = (int64_t)n * L;
+  const unsigned grid = (unsigned)((rows + 3) / 4 < 2048 ? (rows + 3) / 4 : 2048);
+  hipLaunchKernelGGL(reward_stem_fwd_kernel<15>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, w, b, out, rows, L);
+  return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
+}
+
+int svdd_reward_stem_bwd_f32(const float* g, const float* w, float* dx, int n, int L, int taps, void* stream) {
+  if (!g || !w || !dx || n <= 0 || L <= 0 || taps != 15) return SVDD_E_ARG;
+  const int64_t rows = (int64_t)n * L;
+  const unsigned grid = (unsigned)((rows + 3) / 4 < 2048 ? (rows + 3) / 4 : 2048);
+  hipLaunchKernelGGL(reward_stem_bwd_kernel<15>, dim3(grid), dim3(256), 0, (hipStream_t)stream, g, w, dx, rows, L);
+  return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
+}
+
+int svdd_sum_gate_f32(const float* a, const float* b, const float* f, float* g, int64_t count, void* stream) {
+  if (!a || !b || !f || !g || count <= 0 || (count & 3)) return SVDD_E_ARG;
+  const int64_t n4 = count / 4;
+  const unsigned grid = (unsigned)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+  hipLaunchKernelGGL(sum_gate_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float4*>(a),
+                     reinterpret_cast<const float4*>(b), reinterpret_cast<const float4*>(f), reinterpret_cast<float4*>(g), n4);
+  return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
+}
+
+int svdd_reward_tail_grad_f32(const float* h_fwd, const float* h_bwd, const float* w1, const float* b1, const float* gamma,
+                              const float* beta, const float* w_eff, float eps, int n, int L, float* g_fwd, float* g_bwd, void* stream) {
+  if (!h_fwd || !h_bwd || !w1 || !b1 || !gamma || !beta || !w_eff || !g_fwd || !g_bwd || n <= 0 || L <= 0) return SVDD_E_ARG;
+  const int64_t rows = (int64_t)n * L;
+  const size_t lds = sizeof(float) * (2 * 128 * 64 + 4 * 192);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(reward_tail_grad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const unsigned grid = (unsigned)((rows + 3) / 4 < 1024 ? (rows + 3) / 4 : 1024);
+  hipLaunchKernelGGL(reward_tail_grad_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, h_fwd, h_bwd, w1, b1, gamma, beta, w_eff,
+                     eps, 1.0f / ((float)n * (float)L), g_fwd, g_bwd, rows);
   return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
 }
 

@@ -807,6 +807,87 @@ __global__ __launch_bounds__(256) void subs_logp_kernel(PosArgs a) {
   for (int v = 0; v < V; ++v) a.out_f[at(a.layout, r, l, v, a.L)] = lp[v];
 }
 
+// ------------------------------------------------- DPS: the per-position pieces around the two net passes (round 6) ----
+// Gradient guidance (reference diffusion_gosai.py:1286-1330) differentiates mean(reward(softmax(E))) with respect to the one-hot
+// input, E = keep * onehot(x_t) + (1 - keep) * log p(x0 | x_t) (:1325). Between the backbone and the reward net that is per-position
+// arithmetic on 5 values; rounds 4-5 left it to ~40 torch element-wise kernels and their autograd twins per step. Three kernels:
+//   dps_probs_kernel      logits, x -> softmax(E)[..., 0:4]                            (the reward net's input, :1326-1328)
+//   dps_probs_bwd_kernel  d loss / d probs4 -> d loss / d logits (masked rows; the gradient kernel's input) and the DIRECT term
+//                         keep * dE (the path through `keep * x_onehot`, unmasked rows)
+//   dps_guided_q_kernel   q_xs * exp(scale * (grad - grad[MASK]))                      (:1306-1314; grad = backbone term + direct term)
+// logits: the one-launch backbone's raw output, [B][L][5] contiguous. log p is subs_logp_1 (K7's arithmetic) in all three.
+struct DpsArgs {
+  const float* logits; const uint8_t* x; const float* g_in; const float* g_in2;
+  float* out; float* out2; int B, L; float dm, mcs, scale;
+};
+
+__device__ __forceinline__ void dps_expected_probs(const float (&z)[V], int xt, float (&lp)[V], float (&pr)[V]) {
+  subs_logp_1(z, xt, lp);
+  float E[V];
+#pragma unroll
+  for (int v = 0; v < V; ++v) E[v] = (xt != MASK) ? (v == xt ? 1.0f : 0.0f) : lp[v];   // keep * onehot + (1 - keep) * logp
+  float mx = E[0];
+#pragma unroll
+  for (int v = 1; v < V; ++v) mx = E[v] > mx ? E[v] : mx;
+  float e[V], sm = 0.0f;
+#pragma unroll
+  for (int v = 0; v < V; ++v) { e[v] = expf(E[v] - mx); sm += e[v]; }
+#pragma unroll
+  for (int v = 0; v < V; ++v) pr[v] = e[v] / sm;
+}
+
+__global__ __launch_bounds__(256) void dps_probs_kernel(DpsArgs a) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= (int64_t)a.B * a.L) return;
+  float z[V], lp[V], pr[V];
+#pragma unroll
+  for (int v = 0; v < V; ++v) z[v] = a.logits[n * V + v];
+  dps_expected_probs(z, a.x[n], lp, pr);
+  reinterpret_cast<float4*>(a.out)[n] = make_float4(pr[0], pr[1], pr[2], pr[3]);
+}
+
+__global__ __launch_bounds__(256) void dps_probs_bwd_kernel(DpsArgs a) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= (int64_t)a.B * a.L) return;
+  const int xt = a.x[n];
+  float z[V], lp[V], pr[V];
+#pragma unroll
+  for (int v = 0; v < V; ++v) z[v] = a.logits[n * V + v];
+  dps_expected_probs(z, xt, lp, pr);
+  const float4 g4 = reinterpret_cast<const float4*>(a.g_in)[n];
+  const float dp[V] = {g4.x, g4.y, g4.z, g4.w, 0.0f};            // probs[..., 4] is not an input of the reward net
+  float s = 0.0f;
+#pragma unroll
+  for (int v = 0; v < V; ++v) s += pr[v] * dp[v];
+  float dE[V];
+#pragma unroll
+  for (int v = 0; v < V; ++v) dE[v] = pr[v] * (dp[v] - s);       // softmax backward
+  if (xt != MASK) {                                               // keep = 1: E does not depend on the logits
+#pragma unroll
+    for (int v = 0; v < V; ++v) { a.out[n * V + v] = 0.0f; a.out2[n * V + v] = dE[v]; }
+  } else {                                                        // keep = 0: log p = z' - logsumexp(z')
+    float gs = 0.0f;
+#pragma unroll
+    for (int v = 0; v < V; ++v) gs += dE[v];
+#pragma unroll
+    for (int v = 0; v < V; ++v) { a.out[n * V + v] = dE[v] - expf(lp[v]) * gs; a.out2[n * V + v] = 0.0f; }
+  }
+}
+
+__global__ __launch_bounds__(256) void dps_guided_q_kernel(DpsArgs a) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= (int64_t)a.B * a.L) return;
+  float z[V], lp[V], g[V];
+#pragma unroll
+  for (int v = 0; v < V; ++v) { z[v] = a.logits[n * V + v]; g[v] = a.g_in[n * V + v] + a.g_in2[n * V + v]; }
+  subs_logp_1(z, a.x[n], lp);
+#pragma unroll
+  for (int v = 0; v < V; ++v) {
+    const float q = v == MASK ? a.mcs : expf(lp[v]) * a.dm;      // :1306-1307, :1312 (torch.exp, not the sampler's correctly rounded one)
+    a.out[n * V + v] = q * expf(a.scale * (g[v] - g[MASK]));      // :1311, :1314
+  }
+}
+
 // -------------------------------------------------------------------- K4 TDS resample ----
 // numpy's pairwise float32 sum (np.add.reduce), the order `ratio.sum()` uses at :1282: the array is halved (left half
 // rounded down to a multiple of 8) until a block has <= 128 elements; a block is summed with 8 running accumulators.
@@ -1180,7 +1261,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(16))) void mt19
 // hipExtLaunchKernelGGL start/stop events, i.e. HIP events bound to the dispatch itself on the launch
 // stream; svdd_profile_collect() sums hipEventElapsedTime over the recorded launches.
 struct TimedLaunch { hipEvent_t start, stop; };
-constexpr int PROFILE_KERNELS = 11;           // 0 propose (K1), 1 select (K2), 2 conv1d, 3 gru, 4 epilogue_ln, 5 conv_tower, 6 backbone_cnn, 7 value_tail, 8 tds_resample (K4, both phases), 9 mt19937 (K8), 10 backbone gradient
+constexpr int PROFILE_KERNELS = 13;           // 0 propose (K1), 1 select (K2), 2 conv1d, 3 gru, 4 epilogue_ln, 5 conv_tower, 6 backbone_cnn, 7 value_tail, 8 tds_resample (K4, both phases), 9 mt19937 (K8), 10 backbone gradient, 11 GRU forward that saves its gates (DPS), 12 GRU BPTT (DPS)
 bool g_profile = false;
 TimedLaunch* g_timed[PROFILE_KERNELS] = {};
 int g_timed_n[PROFILE_KERNELS] = {}, g_timed_cap[PROFILE_KERNELS] = {};
@@ -1478,6 +1559,32 @@ int svdd_transform_samples(const uint8_t* tok, int R, int L, int transposed, flo
 int svdd_subs_logp(const float* logits, const uint8_t* x, int B, int L, int layout, float* logp, void* stream) {
   if (!logits || !x || !logp || B <= 0 || L <= 0 || bad_layout(layout)) return SVDD_E_ARG;
   return launch_pos(subs_logp_kernel, PosArgs{logits, x, B, L, layout, logp, nullptr, nullptr, 0}, stream);
+}
+
+int svdd_dps_probs(const float* logits, const uint8_t* x, int B, int L, float* probs4, void* stream) {
+  if (!logits || !x || !probs4 || B <= 0 || L <= 0) return SVDD_E_ARG;
+  const int64_t N = (int64_t)B * L;
+  hipLaunchKernelGGL(dps_probs_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     DpsArgs{logits, x, nullptr, nullptr, probs4, nullptr, B, L, 0.0f, 0.0f, 0.0f});
+  return check_launch();
+}
+
+int svdd_dps_probs_bwd(const float* logits, const uint8_t* x, const float* dprobs4, int B, int L, float* dlogits, float* direct,
+                       void* stream) {
+  if (!logits || !x || !dprobs4 || !dlogits || !direct || B <= 0 || L <= 0) return SVDD_E_ARG;
+  const int64_t N = (int64_t)B * L;
+  hipLaunchKernelGGL(dps_probs_bwd_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     DpsArgs{logits, x, dprobs4, nullptr, dlogits, direct, B, L, 0.0f, 0.0f, 0.0f});
+  return check_launch();
+}
+
+int svdd_dps_guided_q(const float* logits, const uint8_t* x, const float* grad_backbone, const float* grad_direct, float dm, float mcs,
+                      float scale, int B, int L, float* q, void* stream) {
+  if (!logits || !x || !grad_backbone || !grad_direct || !q || B <= 0 || L <= 0) return SVDD_E_ARG;
+  const int64_t N = (int64_t)B * L;
+  hipLaunchKernelGGL(dps_guided_q_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     DpsArgs{logits, x, grad_backbone, grad_direct, q, nullptr, B, L, dm, mcs, scale});
+  return check_launch();
 }
 
 int svdd_tds_resample(const float* reward_num, const float* reward_den, double alpha, const uint8_t* sample,

@@ -734,14 +734,18 @@ __global__ __launch_bounds__(256) void conv1d_cl_static_kernel(ConvArgs a) {
     const int nrows = min(128, TILE_ROWS - 128 * half);
     constexpr int RB = 8;                                 // rows in flight per wave: the residual loads are issued together
     for (int base = 0; base < nrows; base += 4 * RB) {
-      float p[RB][VPL];
+      float p[RB][VPL], gt[RB][VPL];
 #pragma unroll
       for (int j = 0; j < RB; ++j) {
         const int lr = base + 4 * j + w;
         const int64_t gr = row0 + 128 * half + lr;
 #pragma unroll
-        for (int k = 0; k < VPL; ++k)
+        for (int k = 0; k < VPL; ++k) {
           p[j][k] = (a.f_prev && lr < nrows && gr < total_rows) ? a.f_prev[gr * COUT + lane * VPL + k] : 0.0f;
+          // act 3 (svdd_conv1d_cl_gated_f32, the backward pass of a ReLU layer): a.tb is a ROW tensor [rows][COUT], the forward
+          // activation whose sign gates this gradient
+          gt[j][k] = (a.act == 3 && lr < nrows && gr < total_rows) ? a.tb[gr * COUT + lane * VPL + k] : 1.0f;
+        }
       }
 #pragma unroll
       for (int j = 0; j < RB; ++j) {
@@ -754,7 +758,8 @@ __global__ __launch_bounds__(256) void conv1d_cl_static_kernel(ConvArgs a) {
 #pragma unroll
         for (int k = 0; k < VPL; ++k) {
           const float t = Es[lr * EP + lane * VPL + k];
-          v[k] = a.act == 0 ? fmaxf(t, 0.0f) + p[j][k] : a.act == 1 ? fmaxf(t + p[j][k], 0.0f) : t + p[j][k];
+          v[k] = a.act == 0 ? fmaxf(t, 0.0f) + p[j][k] : a.act == 1 ? fmaxf(t + p[j][k], 0.0f) :
+                 a.act == 3 ? (gt[j][k] > 0.0f ? t + p[j][k] : 0.0f) : t + p[j][k];
           a.y[o + k] = v[k];
           v[k] += tbv[k];
           sum += v[k];
@@ -2646,6 +2651,28 @@ extern "C" int svdd_conv1d_cl_f32(const float* x, const float* wpack, float* y, 
   else if (cin == 64 && cout == 128) launch(conv1d_cl_kernel<64, 128>, 128);
   else if (cin == 128 && cout == 64) launch(conv1d_cl_kernel<128, 64>, 64);
   else return SVDD_E_ARG;
+  return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
+}
+
+// y = gate > 0 ? conv(x) + f_prev : 0 — one layer of the reward tower's BACKWARD pass (DPS): x = the gradient at this layer's
+// pre-activation, wpack = the transposed / flipped taps, f_prev = the residual branch's gradient (NULL: none), gate = the forward
+// activation of the layer BELOW (its ReLU decides where the gradient passes; NULL: no gating). 64 -> 64 x 5 taps, L = 200 / 50 only.
+extern "C" int svdd_conv1d_cl_gated_f32(const float* x, const float* wpack, float* y, int n, int L, int cin, int cout, int taps,
+                                        int dilation, const float* f_prev, const float* gate, void* stream) {
+  if (!x || !wpack || !y || n <= 0 || cin != 64 || cout != 64 || taps != 5 || dilation != 1 || (L != 200 && L != 50)) return SVDD_E_ARG;
+  const int spt = CONV_ROWS / L;
+  ConvArgs a{x, wpack, y, n, L, spt, taps, dilation, nullptr, f_prev, gate ? 3 : 2, gate, nullptr, nullptr, nullptr};
+  const unsigned grid = (unsigned)((n + spt - 1) / spt);
+  const size_t lds = sizeof(float) * ((size_t)(CONV_ROWS + 1) * CHP + 2 * (size_t)64 * CHP);
+  hipEvent_t e0, e1;
+  svdd_internal_timed_events(2, &e0, &e1);
+  if (L == 200) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv1d_cl_static_kernel<64, 64, 5, 1, 200>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipExtLaunchKernelGGL((conv1d_cl_static_kernel<64, 64, 5, 1, 200>), dim3(grid), dim3(256), lds, (hipStream_t)stream, e0, e1, 0, a);
+  } else {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv1d_cl_static_kernel<64, 64, 5, 1, 50>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipExtLaunchKernelGGL((conv1d_cl_static_kernel<64, 64, 5, 1, 50>), dim3(grid), dim3(256), lds, (hipStream_t)stream, e0, e1, 0, a);
+  }
   return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
 }
 

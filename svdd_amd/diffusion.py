@@ -182,6 +182,8 @@ class Diffusion(nn.Module):
         self.skip_unchanged = True
         self.late_steps_from = 0.8       # from this fraction of the steps on, FusedValueNet may run the live candidates as two parts (split_gru_rounds)
         self.dedup_prior = True          # the prior's rows are identical (all MASK): its net evaluations run on ONE row (exact; see _prior_logits)
+        self.pm_two_part = True          # SVDD-PM skipping loop: the live candidates as whole backbone rounds + remainder, the first part's reward net under the remainder (_pm_split_rows)
+        self.dps_fused = True            # DPS: the whole step on hand-written kernels, no autograd (_dps_fused_nets); False: round 5's autograd path between the same big kernels
         self.dps_one_launch = True       # DPS: the differentiable backbone pass as one launch each way (svdd_backbone_cnn_save_f32 / _grad_f32) where it applies
         self._dps_hard_onehot, self._dps_raw_logits = False, None
         self.dps_single_forward = False  # DPS opt-in: q_xs from the differentiable pass's log-probs, not from a second backbone forward per step
@@ -715,6 +717,20 @@ class Diffusion(nn.Module):
     def _dps_guided_q(self, x_u8, mcs, dm, reward_model, guidance_scale):
         """The guided transition weights q_xs of one DPS step (:1306-1314) -> fp32 [B, L, 5]."""
         B, L = x_u8.shape
+        fused = self._dps_fused_nets(x_u8, reward_model)
+        if fused is not None:
+            # round 6: the whole step without autograd — the one-launch backbone pair, the per-position pieces (K9: svdd_dps_probs /
+            # _probs_bwd / _guided_q) and the reward net's gradient pass on hand-written kernels (FusedValueNet.mean_score_input_grad):
+            # 22 launches where rounds 4-5 issued ~200 (torch element-wise ops and their autograd twins between the kernels)
+            from .fused import backbone_cnn_grad, backbone_cnn_save
+            fb, fn = fused
+            with torch.no_grad():
+                pk = fb.ol_pack()
+                logits, saved = backbone_cnn_save(x_u8.contiguous(), pk)              # the inference kernel's bits + saved statistics
+                dprobs = fn.mean_score_input_grad(ops.dps_probs(logits, x_u8))        # :1325-1329
+                dlogits, direct = ops.dps_probs_bwd(logits, x_u8, dprobs)
+                dx_bb = backbone_cnn_grad(dlogits, pk, fb.grad_pack(), saved)
+                return ops.dps_guided_q(logits, x_u8, dx_bb, direct, dm, mcs, guidance_scale)     # :1306-1314
         x = x_u8.long()
         copy_flag = (x != self.mask_index).to(x.dtype)
         x_onehot = F.one_hot(x, num_classes=self.vocab_size).float()                          # :1308
@@ -750,6 +766,23 @@ class Diffusion(nn.Module):
             guidance = guidance_scale * (x_grad - x_grad[:, :, self.mask_index][:, :, None])   # :1311
             q_xs[:, :, self.mask_index] = float(mcs)                                          # :1312
             return q_xs * guidance.exp()                                                      # :1314
+
+    def _dps_fused_nets(self, x_u8, reward_model):
+        """(fused backbone, fused reward net) when a DPS step can run without autograd, else None: the one-launch fp32 backbone pair at
+        this length, the reference-shaped ConvGRU reward net on the hand-written kernels, exact-fp32 mode (a split-precision mode keeps
+        its own sampling forward for q_xs: the autograd path), dps_fused on."""
+        if not (self.dps_fused and self.dps_one_launch and self.fuse_nets and self.precision == "f32" and x_u8.is_cuda
+                and not self.time_conditioning and isinstance(self.backbone, CNNModel) and not self.backbone.training):
+            return None
+        L = x_u8.shape[1]
+        fb = self._fused_backbone_or_none(L)
+        if fb is None or not fb.grad_ok(L):
+            return None
+        from .fused import FusedValueNet
+        fn = self.reward_callable(reward_model)
+        if not (isinstance(fn, FusedValueNet) and fn.grad_ok(L)):
+            return None
+        return fb, fn
 
     def _dps_step(self, x_u8, mct, mcs, dm, reward_model, guidance_scale, step):
         B, L = x_u8.shape
@@ -979,6 +1012,16 @@ class Diffusion(nn.Module):
         self._finish_stats(ws, B, M, S, "mc-generic")
         return self._noise_removal(x)
 
+    def _pm_split_rows(self, fb, rf, n, L):
+        """Entries of part A of a two-part SVDD-PM step (0: one part): one full round of full backbone tiles — CUs x (208 // L)
+        sequences — when several sequences share a tile, the candidates can exceed it and the reward net takes an output buffer."""
+        from .fused import FusedValueNet
+        if not (self.pm_two_part and isinstance(rf, FusedValueNet) and rf.w_eff.shape[1] == 1 and 208 // L >= 2) or _capturing():
+            return 0
+        from . import _lib
+        n_a = _lib.device_info()[1] * (208 // L)
+        return n_a if n_a < n else 0
+
     def _tweedie_sample_skipping(self, rf, x, sched, B, L, S, M, fb):
         """SVDD-PM with exact work-skipping: per step ONE backbone forward, on the live candidates only."""
         dev = self.device
@@ -994,15 +1037,43 @@ class Diffusion(nn.Module):
         _, xh = ops.x0hat(logits, x, want_tokens=True, want_onehot=False)
         ws.parent_score.copy_(rf.forward_tokens(xh[:1].contiguous()).reshape(1).expand(B) if dedup
                               else rf.forward_tokens(xh).reshape(B))          # reward of the parents' x0-hat
+        from .fused import candidate_windows
+        # Two-part steps (round 6): the live candidates of a step are rarely a whole number of rounds of backbone tiles (1400 of L = 50
+        # are one full round of four-sequence tiles + a remainder round with a third of the chip idle). The compacted list runs as
+        # A = its first `n_a` entries (whole rounds) and B = the rest: backbone(A), then backbone(B) with A's x0-hat + reward net on a
+        # side stream filling the CUs B leaves idle. Same kernels on the same rows (a row's result does not depend on its batch or
+        # tile): same bits (tests/test_skip_gpu.py).
+        n_a = self._pm_split_rows(fb, rf, n, L)
+        if n_a:
+            side, ev_a, ev_done = torch.cuda.Stream(device=dev), torch.cuda.Event(), torch.cuda.Event()
+            sc_buf = torch.empty((n, rf.w_eff.shape[1]), dtype=torch.float32, device=dev)
+            c_a, c_b = ws.count3[1:2], ws.count3[2:3]
+            cand_rows = cand.view(n, L)
         for i in range(S):
             ops.propose(logits, x, sched[i, 2], sched[i, 1], M, self._rng(i, M, B, L, logits), cand=cand)
-            from .fused import candidate_windows
             candidate_windows(cand, x, margin=0, flags=ws.flags)
-            ops.compact_flags(ws.flags, ws.live_idx, ws.slot, ws.count)
-            fb.forward_rows(cand.view(n, L), count=ws.count, out=lg_c, row_idx=ws.live_idx, scatter=False)
-            ops.gather_rows(cand.view(n, L), ws.live_idx, ws.count, toks_c)
-            _, xh = ops.x0hat(lg_c, toks_c, want_tokens=True, want_onehot=False)   # :1415-1419 on the compacted rows
-            sc = rf.forward_tokens(xh, count=ws.count).reshape(-1)                 # :1430
+            if n_a:
+                main = torch.cuda.current_stream()
+                ops.compact_by_key(ws.flags, ws.live_idx, ws.slot, ws.count3, split=n_a)     # keys are 0 / 1: the order of compact_flags
+                ops.gather_rows(cand_rows, ws.live_idx, ws.count, toks_c)
+                fb.forward_rows(cand_rows, count=c_a, out=lg_c[:n_a], row_idx=ws.live_idx, scatter=False)
+                ev_a.record(main)
+                fb.forward_rows(cand_rows, count=c_b, out=lg_c[n_a:], row_idx=ws.live_idx[n_a:], scatter=False)
+                with torch.cuda.stream(side):
+                    side.wait_event(ev_a)
+                    _, xh_a = ops.x0hat(lg_c[:n_a], toks_c[:n_a], want_tokens=True, want_onehot=False)
+                    rf.forward_tokens(xh_a, count=c_a, out=sc_buf[:n_a])
+                    ev_done.record(side)
+                _, xh_b = ops.x0hat(lg_c[n_a:], toks_c[n_a:], want_tokens=True, want_onehot=False)
+                rf.forward_tokens(xh_b, count=c_b, out=sc_buf[n_a:])
+                main.wait_event(ev_done)
+                sc = sc_buf.reshape(-1)
+            else:
+                ops.compact_flags(ws.flags, ws.live_idx, ws.slot, ws.count)
+                fb.forward_rows(cand.view(n, L), count=ws.count, out=lg_c, row_idx=ws.live_idx, scatter=False)
+                ops.gather_rows(cand.view(n, L), ws.live_idx, ws.count, toks_c)
+                _, xh = ops.x0hat(lg_c, toks_c, want_tokens=True, want_onehot=False)   # :1415-1419 on the compacted rows
+                sc = rf.forward_tokens(xh, count=ws.count).reshape(-1)                 # :1430
             if self.trace is not None or self.state_trace is not None:
                 self._record(logits, self._dense_scores(sc, ws, B, M), x)
             x_next = self._select_compact(sc, ws, cand, i)

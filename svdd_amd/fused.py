@@ -611,11 +611,13 @@ def gru_bidir_lp(x_nlc, wpack, bpack, inv, prec, count=None, out=None):
     return out
 
 
-def value_tail_lp(h, w1pack, b1f, w_eff, b_eff, inv, prec, count=None):
+def value_tail_lp(h, w1pack, b1f, w_eff, b_eff, inv, prec, count=None, out=None):
     """h [2, n, L, 64] -> scores [n, n_tasks] (svdd_value_tail_lp)."""
     _, n, L, _ = h.shape
     T = w_eff.shape[1]
-    out = torch.empty((n, T), dtype=torch.float32, device=h.device)
+    if out is None:
+        out = torch.empty((n, T), dtype=torch.float32, device=h.device)
+    assert out.is_contiguous() and out.shape == (n, T) and out.dtype == torch.float32
     rc = _lib.lib().svdd_value_tail_lp(h[0].data_ptr(), h[1].data_ptr(), w1pack.data_ptr(), b1f.data_ptr(),
                                        w_eff.data_ptr(), b_eff.data_ptr(), float(inv), out.data_ptr(), n, L, T,
                                        _ptr(count), prec, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
@@ -771,17 +773,18 @@ class FusedValueNet(nn.Module):
             self._lp[self.precision] = pk
         return pk
 
-    def forward_tokens(self, tok, count=None):
+    def forward_tokens(self, tok, count=None, out=None):
         """Scores [n, n_tasks, 1] of the token rows tok [n, L] u8 (4 = MASK) through the hand-written kernels, in the
         module's precision. count: int32 device scalar = number of valid rows of a compacted batch (rows beyond it are
-        neither computed nor defined)."""
+        neither computed nor defined). out: fp32 [n, n_tasks] buffer for the scores (a caller that runs parts of a batch on
+        several streams owns the result buffer)."""
         from . import ops
         if self.precision != "f32":
             pk = self._lp_pack()
             seq = conv_tower_lp(tok.contiguous(), pk["tiles"], self.tw_bias, pk["tinv"], self.tw_resmask, pk["prec"], count)
-            return self._after_tower_lp(seq, pk, count)
+            return self._after_tower_lp(seq, pk, count, out)
         seq = conv_tower(ops.transform_samples(tok.contiguous()), self.tw_tiles, self.tw_bias, self.tw_resmask, count)
-        return self._after_tower(seq, tok.shape[0], tok.shape[1], count)
+        return self._after_tower(seq, tok.shape[0], tok.shape[1], count, out)
 
     def grad_ok(self, L):
         """True when forward_grad applies: the reference-shaped net in fp32 at a length the static 64 -> 64 conv kernel has."""
@@ -812,6 +815,52 @@ class FusedValueNet(nn.Module):
         hn = F.layer_norm(y2[0] + y2[1], (64,), self.ln_w, self.ln_b, self._ln_eps)
         z = F.relu(F.linear(hn, self.w1, self.b1))
         return ((z @ self.w_eff).mean(dim=1) + self.b_eff)[:, :, None]
+
+    def mean_score_input_grad(self, x):
+        """d mean_n(score_n[task 0]) / d x for a RELAXED input x [n, L, 4] (fp32) — the gradient the DPS baseline needs of its reward
+        call (reference diffusion_gosai.py:1326-1329: reward_model(softmax(E)).mean().backward()) — WITHOUT autograd: 16 launches of
+        hand-written kernels (stem, 5 x conv + fused epilogue, GRU with saved gates | tail forward + backward in one pass, BPTT,
+        direction sum + ReLU gate, 5 x transposed conv + gate, stem transpose). forward_grad is the autograd form of the same function
+        (tests/test_fused_gpu.py compares the two). Only where grad_ok(L)."""
+        x = x.contiguous().float()
+        n, L, _ = x.shape
+        lib, st = _lib.lib(), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        if self._grad_packs is None:
+            self.forward_grad(torch.zeros(1, L, 4, device=x.device))                 # packs the transposed weights
+        w_stem, packs_t, gru_bwd = self._grad_packs
+        dev = x.device
+        f = torch.empty((n, L, 64), dtype=torch.float32, device=dev)
+        _lib.check(lib.svdd_reward_stem_f32(x.data_ptr(), w_stem.data_ptr(), self.stem_b.data_ptr(), f.data_ptr(), n, L,
+                                            self._stem_w_raw.shape[2], st), "svdd_reward_stem_f32")
+        fs = [f]
+        for wp, b, res in zip(self.wpacks, self.bs, self.residual):
+            fs.append(conv1d_cl(fs[-1], wp, 64, 5, 1, bias=b, f_prev=fs[-1] if res else None, act=ACT_ADD_THEN_RELU))
+        out = torch.empty((2, n, L, 64), dtype=torch.float32, device=dev)
+        save = torch.empty((2, n, L, 4, 64), dtype=torch.float32, device=dev)
+        _lib.check(lib.svdd_gru_bidir_train_f32(fs[-1].data_ptr(), self.wpack.data_ptr(), self.bpack.data_ptr(), out.data_ptr(),
+                                                save.data_ptr(), n, L, st), "svdd_gru_bidir_train_f32")
+        gout = torch.empty_like(out)
+        w_eff0 = self.w_eff[:, 0].contiguous()
+        _lib.check(lib.svdd_reward_tail_grad_f32(out[0].data_ptr(), out[1].data_ptr(), self.w1.data_ptr(), self.b1.data_ptr(),
+                                                 self.ln_w.data_ptr(), self.ln_b.data_ptr(), w_eff0.data_ptr(), float(self._ln_eps), n, L,
+                                                 gout[0].data_ptr(), gout[1].data_ptr(), st), "svdd_reward_tail_grad_f32")
+        dxg = torch.empty_like(out)
+        _lib.check(lib.svdd_gru_bidir_bwd_f32(gout.data_ptr(), out.data_ptr(), save.data_ptr(), gru_bwd.data_ptr(), dxg.data_ptr(), n, L, st),
+                   "svdd_gru_bidir_bwd_f32")
+        g = gout[0]                                                                  # reuse: the gradient at the last layer's pre-activation
+        _lib.check(lib.svdd_sum_gate_f32(dxg[0].data_ptr(), dxg[1].data_ptr(), fs[-1].data_ptr(), g.data_ptr(), n * L * 64, st),
+                   "svdd_sum_gate_f32")
+        bufs = [gout[1], dxg[0]]
+        for k in range(len(packs_t) - 1, -1, -1):                                    # block k + 1: fs[k + 1] = relu(conv_k(fs[k]) + b (+ fs[k]))
+            y = bufs[k & 1]
+            _lib.check(lib.svdd_conv1d_cl_gated_f32(g.data_ptr(), packs_t[k].data_ptr(), y.data_ptr(), n, L, 64, 64, 5, 1,
+                                                    g.data_ptr() if self.residual[k] else None, fs[k].data_ptr(), st),
+                       "svdd_conv1d_cl_gated_f32")
+            g = y
+        dx = torch.empty((n, L, 4), dtype=torch.float32, device=dev)
+        _lib.check(lib.svdd_reward_stem_bwd_f32(g.data_ptr(), w_stem.data_ptr(), dx.data_ptr(), n, L, self._stem_w_raw.shape[2], st),
+                   "svdd_reward_stem_bwd_f32")
+        return dx
 
     def kernels_ok(self, L):
         """True when the whole net runs on the hand-written kernels (tower, GRU, tail) for sequences of length L."""
@@ -921,9 +970,9 @@ class FusedValueNet(nn.Module):
         ws.seq = seq
         return sc[:, 0]
 
-    def _after_tower_lp(self, seq, pk, count=None):
+    def _after_tower_lp(self, seq, pk, count=None, out=None):
         h = gru_bidir_lp(seq, pk["gw"], pk["gb"], pk["ginv"], pk["prec"], count=count)
-        return value_tail_lp(h, pk["tw"], pk["tb1"], self.w_eff, self.b_eff, pk["tail_inv"], pk["prec"], count=count)[:, :, None]
+        return value_tail_lp(h, pk["tw"], pk["tb1"], self.w_eff, self.b_eff, pk["tail_inv"], pk["prec"], count=count, out=out)[:, :, None]
 
     def forward(self, x):
         if x.shape[1] == self.in_channels and x.shape[2] != self.in_channels:
@@ -975,11 +1024,11 @@ class FusedValueNet(nn.Module):
         seq = conv_tower_windows(onehot, win, parent_out, M, self.tw_tiles, self.tw_bias, self.tw_resmask)
         return self._after_tower(seq, B * M, L)
 
-    def _after_tower(self, seq, n, L, count=None):
+    def _after_tower(self, seq, n, L, count=None, out=None):
         h = gru_bidir(seq, self.wpack, self.bpack, count)
         if self.use_fused_tail and self.tail_ok:
-            return value_tail(h, self.w1pack, self.b1f, self.w_eff, self.b_eff, count)[:, :, None]
-        assert count is None, "compacted batches need the fused tail kernel"
+            return value_tail(h, self.w1pack, self.b1f, self.w_eff, self.b_eff, count, out=out)[:, :, None]
+        assert count is None and out is None, "compacted batches need the fused tail kernel"
         # LayerNorm(h_fwd + h_bwd) in one pass (the direction sum of Enformer.py:1617 + dense1.norm)
         _, hn = epilogue_ln(h[0], None, h[1], None, self.ln_w, self.ln_b, act=ACT_NONE, want_sum=False)
         z = F.relu(F.linear(hn, self.w1, self.b1))                  # [n,L,128]
@@ -1039,11 +1088,15 @@ class FusedBackbone(nn.Module):
         """True when the differentiable pass (DPS) can run as one launch each way: the one-launch kernel, one sequence per tile."""
         return self.one_launch and self.use_one_launch and 104 < L <= 208      # (always the fp32 kernels, whatever self.precision)
 
-    def forward_with_grad(self, x_onehot, tokens):
-        """Raw logits [n, L, 5] with autograd to `x_onehot` [n, L, 5], which must be the hard one-hot of `tokens` [n, L] u8."""
+    def grad_pack(self):
+        """Operand images of svdd_backbone_cnn_grad_f32 (packed on first use)."""
         if self._grad_pack is None:
             self._grad_pack = {k: v.to(self.ol_tiles.device) for k, v in pack_backbone_grad(self._cnn[0]).items()}
-        return BackboneOneLaunchFunction.apply(x_onehot, tokens.contiguous(), self.ol_pack(), self._grad_pack)
+        return self._grad_pack
+
+    def forward_with_grad(self, x_onehot, tokens):
+        """Raw logits [n, L, 5] with autograd to `x_onehot` [n, L, 5], which must be the hard one-hot of `tokens` [n, L] u8."""
+        return BackboneOneLaunchFunction.apply(x_onehot, tokens.contiguous(), self.ol_pack(), self.grad_pack())
 
     def kernel_ok(self, L):
         """True when a forward of length-L sequences is the one-launch kernel (the work-skipping paths need it: they

@@ -232,6 +232,45 @@ def subs_logp(logits, x):
     return out
 
 
+def dps_probs(logits, x):
+    """softmax(E)[..., 0:4] of a DPS step, E = keep * onehot(x) + (1 - keep) * log p(x0 | x) (reference diffusion_gosai.py:1325-1328):
+    logits fp32 [B, L, 5] contiguous (the backbone's raw output), x u8 [B, L] -> fp32 [B, L, 4], the reward net's input."""
+    logits = _need(logits, torch.float32, "logits")
+    x = _need(x, torch.uint8, "x").contiguous()
+    assert logits.is_contiguous() and logits.shape == (*x.shape, 5)
+    B, L = x.shape
+    out = torch.empty((B, L, 4), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().svdd_dps_probs(logits.data_ptr(), x.data_ptr(), B, L, out.data_ptr(), _stream()), "svdd_dps_probs")
+    return out
+
+
+def dps_probs_bwd(logits, x, dprobs4):
+    """d loss / d probs4 [B, L, 4] -> (d loss / d logits [B, L, 5] — what the backbone's gradient kernel takes; zero at unmasked
+    positions — , direct [B, L, 5] = the gradient through `keep * x_onehot`, zero at masked positions)."""
+    x = _need(x, torch.uint8, "x").contiguous()
+    B, L = x.shape
+    g = dprobs4.contiguous().float()
+    assert logits.is_contiguous() and logits.shape == (B, L, 5) and g.shape == (B, L, 4)
+    dlogits = torch.empty((B, L, 5), dtype=torch.float32, device=x.device)
+    direct = torch.empty_like(dlogits)
+    _lib.check(_lib.lib().svdd_dps_probs_bwd(logits.data_ptr(), x.data_ptr(), g.data_ptr(), B, L, dlogits.data_ptr(), direct.data_ptr(),
+                                             _stream()), "svdd_dps_probs_bwd")
+    return dlogits, direct
+
+
+def dps_guided_q(logits, x, grad_backbone, grad_direct, dm, mcs, scale):
+    """The guided transition weights of a DPS step (reference :1306-1314): exp(log p) * dm with q[MASK] = mcs, times
+    exp(scale * (x_grad - x_grad[MASK])), x_grad = grad_backbone + grad_direct -> fp32 [B, L, 5]."""
+    x = _need(x, torch.uint8, "x").contiguous()
+    B, L = x.shape
+    gb, gd = grad_backbone.contiguous().float(), grad_direct.contiguous().float()
+    assert logits.is_contiguous() and logits.shape == (B, L, 5) and gb.shape == (B, L, 5) and gd.shape == (B, L, 5)
+    q = torch.empty((B, L, 5), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().svdd_dps_guided_q(logits.data_ptr(), x.data_ptr(), gb.data_ptr(), gd.data_ptr(), float(dm), float(mcs),
+                                            float(scale), B, L, q.data_ptr(), _stream()), "svdd_dps_guided_q")
+    return q
+
+
 def tds_resample(reward_num, reward_den, alpha, sample, u):
     """-> (x_next u8 [B,L], idx i32 [B]); u = the B float64 uniforms np.random.choice consumes."""
     num = _need(reward_num, torch.float32, "reward_num").contiguous()

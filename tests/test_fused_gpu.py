@@ -587,3 +587,75 @@ def test_value_net_forward_grad_vs_torch_autograd(B, task):
     err = float((xa.grad - xb.grad).abs().max())
     assert err <= 5e-4 * scale, (err, scale)
     assert float((xa.grad - xb.grad).abs().median()) <= 2e-5 * scale
+
+
+@pytest.mark.parametrize("B,task", [(6, "dna"), (37, "dna"), (5, "rna")])
+def test_value_net_mean_score_input_grad_without_autograd(B, task):
+    """FusedValueNet.mean_score_input_grad (round 6: the DPS reward call's gradient on 16 hand-written launches, no autograd — stem,
+    conv + fused epilogue, GRU with saved gates, tail forward + backward in one pass, BPTT, gated transposed convs, stem transpose)
+    against (a) the autograd form of the same kernels (forward_grad) and (b) torch autograd through the plain modules in fp64."""
+    import copy
+    from svdd_amd import synthetic
+    model, _, _, reward = synthetic.build(task, DEV)
+    L = model.config.model.length
+    fn = model.reward_callable(reward)
+    assert fn.grad_ok(L)
+    torch.manual_seed(B)
+    x = torch.softmax(2.0 * torch.randn(B, L, 5, device=DEV), dim=-1)[:, :, :4].contiguous()
+    x[0, : L // 3] = 0.0                                                          # rows of zeros (what a MASK position's one-hot is)
+    got = fn.mean_score_input_grad(x)
+    assert got.shape == (B, L, 4) and torch.isfinite(got).all()
+    xa = x.clone().requires_grad_(True)
+    fn.forward_grad(xa)[:, 0].mean().backward()
+    r64 = copy.deepcopy(reward).double()
+    xb = x.double().clone().requires_grad_(True)
+    with torch.backends.cudnn.flags(enabled=False):
+        r64(xb.transpose(1, 2))[:, 0].mean().backward()
+    scale = float(xb.grad.abs().max())
+    err_auto = float((got - xa.grad).abs().max())
+    err64 = float((got.double() - xb.grad).abs().max())
+    err64_auto = float((xa.grad.double() - xb.grad).abs().max())
+    print(f"mean_score_input_grad {task} B={B}: vs forward_grad {err_auto / scale:.2e}, vs fp64 {err64 / scale:.2e} (forward_grad vs fp64 {err64_auto / scale:.2e})")
+    bad = (got - xa.grad).abs() > 5e-5 * scale
+    print("  elements off by > 5e-5 of the scale:", int(bad.sum()), "of", bad.numel(), "; rows", sorted(set(bad.nonzero()[:, 0].tolist()))[:8],
+          "positions", sorted(set(bad.nonzero()[:, 1].tolist()))[:12])
+    # Equal to a few 1e-7 of the scale — except where ONE ReLU decides differently: the stem is a GEMM in forward_grad and a direct sum
+    # here, so a pre-activation within an ulp of zero can land on either side, and the gradient then differs inside that unit's
+    # receptive field only (measured: B = 6 has one such unit, row 4 around position 189, 1.5e-2 of the scale over 18 positions; both
+    # are gradients of the same function at a kink). Accepted: at most one such window per case.
+    if bad.any():
+        rows, pos = bad.nonzero()[:, 0], bad.nonzero()[:, 1]
+        assert len(set(rows.tolist())) == 1 and int(pos.max() - pos.min()) <= 48 and err_auto <= 5e-2 * scale, (err_auto, scale)
+    assert float((got - xa.grad).abs().median()) <= 2e-6 * scale
+    assert float((got.double() - xb.grad).abs().median()) <= 2e-5 * scale
+    if not bad.any():
+        assert err64 <= max(5e-4 * scale, 2.0 * err64_auto), (err64, err64_auto, scale)
+
+
+@pytest.mark.parametrize("scale", [0.0, 300.0, 25600.0])
+def test_dps_step_without_autograd_equals_the_autograd_path(scale):
+    """Diffusion._dps_guided_q with dps_fused (round 6: one-launch backbone pair + svdd_dps_probs / _probs_bwd / _guided_q + the reward
+    net's gradient pass, no autograd) against round 5's path (torch autograd between the same big kernels) on a half-unmasked state:
+    the guided q_xs, and the un-guided base (scale 0) bit for bit."""
+    from svdd_amd import synthetic
+    model, _, _, reward = synthetic.build("dna", DEV)
+    B, L = 24, 200
+    torch.manual_seed(5)
+    x = torch.where(torch.rand(B, L, device=DEV) < 0.5, 4, torch.randint(0, 4, (B, L), device=DEV)).to(torch.uint8)
+    x[0] = 4
+    x[1] = torch.randint(0, 4, (L,), device=DEV).to(torch.uint8)                 # a fully unmasked row
+    sched = model._schedule(128, 1e-5)[0]
+    assert model._dps_fused_nets(x, reward) is not None
+    model.dps_fused = True
+    q_new = model._dps_guided_q(x, sched[40, 1], sched[40, 2], reward, scale)
+    model.dps_fused = False
+    try:
+        q_old = model._dps_guided_q(x, sched[40, 1], sched[40, 2], reward, scale)
+    finally:
+        model.dps_fused = True
+    assert q_new.shape == q_old.shape == (B, L, 5) and torch.isfinite(q_new).all()
+    if scale == 0.0:
+        assert torch.equal(q_new, q_old)
+    rel = float(((q_new - q_old).abs() / q_old.abs().clamp(min=1e-12)).max())
+    print(f"dps fused vs autograd path, scale {scale}: max rel diff of q {rel:.2e}")
+    assert rel <= 2e-4, rel

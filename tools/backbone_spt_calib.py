@@ -1,5 +1,5 @@
 """Calibration of csrc/svdd_spt.h: time of one backbone launch with exactly s sequences per tile and 256 x s sequences (one
-full round of workgroups), L = 50 and L = 33, fp32 and f16x3.  Usage: python tools/backbone_spt_calib.py"""
+full round of workgroups), L = 50 and L = 33, fp32 and f16x3.  Usage: python tools/backbone_spt_calib.py [mode ...]"""
 import os
 import sys
 
@@ -9,7 +9,7 @@ from svdd_amd import _lib, backbone, config, fused
 
 dev = "cuda:0"
 cnn = backbone.CNNModel(config.rna_config().model, alphabet_size=5).to(dev).eval()
-for mode in ("f32", "f16x3"):
+for mode in (sys.argv[1:] or ["f32", "f16x3"]):
     pk = fused.pack_backbone(cnn) if mode == "f32" else fused.pack_backbone_lp(cnn, mode)
     fwd = fused.backbone_cnn if mode == "f32" else fused.backbone_cnn_lp
     for L in (50, 33):

@@ -247,6 +247,7 @@ _T["stamps_d64b"] = [_T["timing"][0], _T["timing"][-1]] + _stamps(17, 6)
 # "image complete" barrier, [1] the (chunk, tap) loop, [2] the barrier after it, [3] epilogue, first layer, last conv
 BB_F32_TIMING = {
     "file": "svdd_nets.hip",
+    "first_only": True,      # backbone_grad_kernel (round 5) repeats backbone_kernel's loop text further down: patch the first occurrence only
     "bench": ["python", "tools/lpt_phase_timing.py", "f32"],
     "variants": {"timing": [
         ("struct BackboneArgs {", "__device__ unsigned long long g_lpt_dbg[256 * 8 * 32];\nstruct BackboneArgs {"),
@@ -302,7 +303,15 @@ TOWER_LP_TIMING = {
         ("}  // namespace\n", "}  // namespace\n\nextern \"C\" int svdd_internal_tw_dbg(void* dst, int reset) { if (reset) return (int)hipMemset((void*)((char*)0 + 0), 0, 0) * 0 + (int)hipMemcpyToSymbol(HIP_SYMBOL(g_tw_dbg), dst, sizeof(g_tw_dbg)); return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_tw_dbg), sizeof(g_tw_dbg)); }\n"),
     ]},
 }
-SETS = {"tower_lp_timing": TOWER_LP_TIMING, "bb_f32_timing": BB_F32_TIMING, "bb_lpt_timing": BB_LPT_TIMING, "bb_lpt": BB_LPT, "gru_pc": GRU_PC, "gru_lp": GRU_LP, "tower_lp": TOWER_LP, "bb_lp": BB_LP, "k1": K1, "tower2": TOWER2}
+# round 6: is the per-tile FIXED cost of the fp32 backbone on short sequences (4.5 row tiles' worth, csrc/svdd_spt.h) the latency of the
+# weight stream (one tile requested one entry ahead; an entry of a 4-row-tile workgroup is ~1300 cycles of MFMA work)? "noW": every entry
+# reads weight tile 0 (cache-hot); "base": the tracked kernel. Timing only (noW computes garbage). Bench: the calibration launches.
+BB_F32_SMALL = {
+    "file": "svdd_nets.hip",
+    "bench": ["python", "tools/backbone_spt_calib.py", "f32"],
+    "variants": {"base": [], "noW": _F["timing_noW"][-1:]},
+}
+SETS = {"bb_f32_small": BB_F32_SMALL, "tower_lp_timing": TOWER_LP_TIMING, "bb_f32_timing": BB_F32_TIMING, "bb_lpt_timing": BB_LPT_TIMING, "bb_lpt": BB_LPT, "gru_pc": GRU_PC, "gru_lp": GRU_LP, "tower_lp": TOWER_LP, "bb_lp": BB_LP, "k1": K1, "tower2": TOWER2}
 
 
 def build_variant(setname, name, spec):
@@ -322,7 +331,7 @@ def build_variant(setname, name, spec):
         if old not in s:                                  # the variant was written against an earlier revision of the kernel
             shutil.rmtree(work, ignore_errors=True)
             return name, False, "STALE: its patch no longer matches the source (the experiment's numbers are in profiles/; `check` lists these)"
-        s = s.replace(old, new)
+        s = s.replace(old, new, 1) if spec.get("first_only") else s.replace(old, new)
     open(p, "w").write(s)
     r = subprocess.run(["make", "-C", work, "INC=" + os.path.join(ROOT, "include")], capture_output=True, text=True)
     ok = os.path.exists(os.path.join(work, "libsvdd_hip.so"))
