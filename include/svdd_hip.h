@@ -453,7 +453,7 @@ int svdd_set_option(int key, int value);
 int svdd_k1_stats(unsigned long long* device_counters2);
 
 /* Per-launch kernel timing (host). While enabled, svdd_propose (kernel 0), svdd_select (1), svdd_conv1d_cl_f32 (2),
- * svdd_gru_bidir_f32 (3), svdd_epilogue_ln_f32 (4), svdd_conv_tower_f32 (5), svdd_backbone_cnn_f32 / _save_f32 (6), svdd_value_tail_f32 (7), svdd_tds_resample (8), svdd_mt19937_uniform_f32 (9), svdd_backbone_cnn_grad_f32 (10), svdd_gru_bidir_train_f32 (11) and svdd_gru_bidir_bwd_f32 (12) are dispatched
+ * svdd_gru_bidir_f32 (3), svdd_epilogue_ln_f32 (4), svdd_conv_tower_f32 (5), svdd_backbone_cnn_f32 / _save_f32 (6), svdd_value_tail_f32 (7), svdd_tds_resample (8), svdd_mt19937_uniform_f32 (9), svdd_backbone_cnn_grad_f32 (10), svdd_gru_bidir_train[2]_f32 (11) and svdd_gru_bidir_bwd[2]_f32 (12; the *2 forms as one span over their two launches) are dispatched (the reward net's DPS kernels share slots: svdd_reward_stem*_f32 5, svdd_reward_tail_grad_f32 7, svdd_conv1d_cl_gated_f32 2)
  * with HIP start/stop events bound to the dispatch on its launch stream
  * (hipExtLaunchKernelGGL); svdd_profile_collect waits for the recorded launches, returns the summed
  * hipEventElapsedTime and their count, and clears the record. Not for use during graph capture. */
@@ -572,6 +572,17 @@ int svdd_conv1d_cl_gated_f32(const float* x, const float* wpack, float* y, int n
 int svdd_reward_tail_grad_f32(const float* h_fwd, const float* h_bwd, const float* w1, const float* b1, const float* gamma,
                               const float* beta, const float* w_eff, float eps, int n, int L, float* g_fwd, float* g_bwd, void* stream);
 int svdd_sum_gate_f32(const float* a, const float* b, const float* f, float* g, int64_t count, void* stream);
+/* The GRU pair with the non-recurrent halves off the serial chain (at the DPS batch the chains are latency: 32 workgroups, 200 dependent
+ * steps). Same results as svdd_gru_bidir_train_f32 (out / save: same bits) and as dx_fwd + dx_bwd of svdd_gru_bidir_bwd_f32 (to rounding:
+ * the two directions accumulate in one chain):
+ *   svdd_gru_bidir_train2_f32: gi = caller scratch [2][n L][192] fp32 (receives b + W_i x of every step: one launch on the whole chip),
+ *                              then the chain with W_h h only; out [2][n][L][64], save [2][n][L][4][64] as above.
+ *   svdd_gru_bidir_bwd2_f32:   da = caller scratch [2][n L][192] (receives the gate derivatives), then
+ *                              g [n][L][64] = gate > 0 ? da_fwd W_i,fwd + da_bwd W_i,bwd : 0 (gate [n][L][64] or NULL: no gate). */
+int svdd_gru_bidir_train2_f32(const float* x, const float* wpack, const float* bpack, float* gi, float* out, float* save, int n, int L,
+                              void* stream);
+int svdd_gru_bidir_bwd2_f32(const float* grad_out, const float* out, const float* save, const float* wpack_bwd, float* da, const float* gate,
+                            float* g, int n, int L, void* stream);
 
 #ifdef __cplusplus
 }

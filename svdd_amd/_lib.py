@@ -36,7 +36,7 @@ EXPORTS = (
     "svdd_bb_layer_fwd_f32", "svdd_bb_layer_bwd_f32", "svdd_mt19937_uniform_f32",
     "svdd_backbone_set_workspace", "svdd_backbone_split_status", "svdd_backbone_cnn_save_f32", "svdd_backbone_cnn_grad_f32",
     "svdd_dps_probs", "svdd_dps_probs_bwd", "svdd_dps_guided_q", "svdd_reward_stem_f32", "svdd_reward_stem_bwd_f32",
-    "svdd_conv1d_cl_gated_f32", "svdd_reward_tail_grad_f32", "svdd_sum_gate_f32",
+    "svdd_conv1d_cl_gated_f32", "svdd_reward_tail_grad_f32", "svdd_sum_gate_f32", "svdd_gru_bidir_train2_f32", "svdd_gru_bidir_bwd2_f32",
 )
 OPT_FORCE_EXACT = 0
 
@@ -145,6 +145,8 @@ def lib():
     L.svdd_conv1d_cl_gated_f32.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp]
     L.svdd_reward_tail_grad_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, f32, i32, i32, vp, vp, vp]
     L.svdd_sum_gate_f32.argtypes = [vp, vp, vp, vp, i64, vp]
+    L.svdd_gru_bidir_train2_f32.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, vp]
+    L.svdd_gru_bidir_bwd2_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]
     L.svdd_profile_enable.argtypes = [i32]
     L.svdd_profile_collect.argtypes = [i32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]
     L.svdd_device_info.argtypes = [ctypes.c_char_p, i32, ctypes.POINTER(ctypes.c_int)]

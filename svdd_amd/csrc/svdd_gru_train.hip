@@ -418,6 +418,253 @@ __global__ __launch_bounds__(256) void reward_tail_grad_kernel(const float* __re
   }
 }
 
+// ------------------------------------------------ round 6: the GRU pair with the non-recurrent halves OFF the serial chain ----
+// At the DPS batch (256 sequences = 16 tiles x 2 directions = 32 workgroups on 256 CUs) the two kernels above are pure latency:
+// 200 dependent steps of 96 fp32 MFMAs per wave (48 for W_h h, 48 for W_i x) forwards — 386 us — and, backwards, 96 more plus 24
+// global loads per lane that were requested in the step that needs them — 788 us — with 7/8 of the chip idle. Neither W_i x_t nor
+// dx_t = W_i^T da_t depends on the recurrence:
+//   gru_xproj_kernel     gi[dir][row][3][64] = b + W_i x for every (sequence, step) at once, on the whole chip (the SAME accumulator
+//                        sequence as the in-chain version: bias, then the 16 k-steps — the chain continues it with W_h h: same bits)
+//   gru_train_fwd2_kernel  the chain with 48 MFMAs per step; the next step's gi requested a step ahead
+//   gru_bwd2_kernel      the chain with 48 MFMAs per step (dh only); every saved value of step - 1 requested during step; the gate
+//                        derivatives da = [da_r | da_z | da_n] go to global memory ...
+//   gru_dx_gate_kernel   ... and dx = da_fwd W_i,fwd + da_bwd W_i,bwd for all rows at once, gated by the ReLU of the layer below
+//                        (replaces the per-direction dx tensors, their sum and the separate gate pass)
+__global__ __launch_bounds__(256) void gru_xproj_kernel(const float* __restrict__ x, const float* __restrict__ wpack, const float* __restrict__ bpack,
+                                                        float* __restrict__ gi, int64_t rows) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int dir = (int)blockIdx.y;
+  const int j = lane & 15, g = lane >> 4;
+  float wx[48];
+  {
+    const float4* wp = reinterpret_cast<const float4*>(wpack + (((size_t)dir * 4 + w) * 64 + lane) * 96);
+#pragma unroll
+    for (int gate = 0; gate < 3; ++gate)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { const float4 v = wp[8 * gate + i]; wx[16 * gate + 4 * i] = v.x; wx[16 * gate + 4 * i + 1] = v.y; wx[16 * gate + 4 * i + 2] = v.z; wx[16 * gate + 4 * i + 3] = v.w; }
+  }
+  const int u = 16 * w + j;
+  const float b_r = bpack[(dir * 4 + 0) * H + u], b_z = bpack[(dir * 4 + 1) * H + u], b_nx = bpack[(dir * 4 + 2) * H + u];
+  const int64_t ntiles = (rows + 15) / 16;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t r0 = tile * 16;
+    const int64_t arow = r0 + j < rows ? r0 + j : rows - 1;
+    float xa[16];
+    const float4* xp = reinterpret_cast<const float4*>(x + arow * H + 16 * g);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const float4 v = xp[i]; xa[4 * i] = v.x; xa[4 * i + 1] = v.y; xa[4 * i + 2] = v.z; xa[4 * i + 3] = v.w; }
+    f32x4 acc_r = {b_r, b_r, b_r, b_r}, acc_z = {b_z, b_z, b_z, b_z}, acc_nx = {b_nx, b_nx, b_nx, b_nx};
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      acc_r = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[s], wx[s], acc_r, 0, 0, 0);
+      acc_z = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[s], wx[16 + s], acc_z, 0, 0, 0);
+      acc_nx = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[s], wx[32 + s], acc_nx, 0, 0, 0);
+    }
+#pragma unroll
+    for (int rho = 0; rho < 4; ++rho) {
+      const int64_t row = r0 + 4 * g + rho;
+      if (row < rows) {
+        float* o = gi + ((size_t)dir * rows + row) * (3 * H) + u;
+        o[0] = acc_r[rho]; o[H] = acc_z[rho]; o[2 * H] = acc_nx[rho];
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void gru_train_fwd2_kernel(const float* __restrict__ gi, const float* __restrict__ wpack, const float* __restrict__ bpack,
+                                                             float* __restrict__ out, float* __restrict__ save, int n, int L) {
+  __shared__ __attribute__((aligned(16))) float hbuf[2][TS][HPAD];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int dir = (int)(blockIdx.x & 1);
+  const int j = lane & 15, g = lane >> 4;
+  const int seq0 = (int)(blockIdx.x >> 1) * TS;
+  if (seq0 >= n) return;
+  float wh[48];                                                     // the recurrent halves: W_hr, W_hz, W_hn
+  {
+    const float4* wp = reinterpret_cast<const float4*>(wpack + (((size_t)dir * 4 + w) * 64 + lane) * 96);
+#pragma unroll
+    for (int gate = 0; gate < 3; ++gate)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { const float4 v = wp[8 * gate + 4 + i]; wh[16 * gate + 4 * i] = v.x; wh[16 * gate + 4 * i + 1] = v.y; wh[16 * gate + 4 * i + 2] = v.z; wh[16 * gate + 4 * i + 3] = v.w; }
+  }
+  const int u = 16 * w + j;
+  const float b_nh = bpack[(dir * 4 + 3) * H + u];
+  const size_t rows = (size_t)n * L;
+  float hprev[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  for (int i = threadIdx.x; i < TS * HPAD; i += 256) (&hbuf[0][0][0])[i] = 0.0f;
+  const int t0 = dir == 0 ? 0 : L - 1, dt = dir == 0 ? 1 : -1;
+  const float* gbase[4];
+#pragma unroll
+  for (int rho = 0; rho < 4; ++rho) gbase[rho] = gi + ((size_t)dir * rows + (size_t)min(seq0 + 4 * g + rho, n - 1) * L) * (3 * H) + u;
+  float cr[4], cz[4], cn[4], nr[4], nz[4], nn_[4];
+#pragma unroll
+  for (int rho = 0; rho < 4; ++rho) { const float* p = gbase[rho] + (size_t)t0 * (3 * H); cr[rho] = p[0]; cz[rho] = p[H]; cn[rho] = p[2 * H]; }
+  __syncthreads();
+  for (int step = 0; step < L; ++step) {
+    const int t = t0 + dt * step;
+    const int cur = step & 1;
+    if (step + 1 < L) {
+#pragma unroll
+      for (int rho = 0; rho < 4; ++rho) { const float* p = gbase[rho] + (size_t)(t + dt) * (3 * H); nr[rho] = p[0]; nz[rho] = p[H]; nn_[rho] = p[2 * H]; }
+    }
+    float ha[16];
+    {
+      const float4* hp = reinterpret_cast<const float4*>(&hbuf[cur][j][16 * g]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { const float4 v = hp[i]; ha[4 * i] = v.x; ha[4 * i + 1] = v.y; ha[4 * i + 2] = v.z; ha[4 * i + 3] = v.w; }
+    }
+    f32x4 acc_nh = {b_nh, b_nh, b_nh, b_nh}, acc_r = {cr[0], cr[1], cr[2], cr[3]}, acc_z = {cz[0], cz[1], cz[2], cz[3]};
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      acc_nh = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[s], wh[32 + s], acc_nh, 0, 0, 0);
+      acc_r = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[s], wh[s], acc_r, 0, 0, 0);
+      acc_z = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[s], wh[16 + s], acc_z, 0, 0, 0);
+    }
+#pragma unroll
+    for (int rho = 0; rho < 4; ++rho) {
+      const float r = sigmoid_fast(acc_r[rho]);
+      const float z = sigmoid_fast(acc_z[rho]);
+      const float nn = tanh_fast(cn[rho] + r * acc_nh[rho]);
+      const float hn = (1.0f - z) * nn + z * hprev[rho];
+      hprev[rho] = hn;
+      const int srow = 4 * g + rho;
+      hbuf[cur ^ 1][srow][u] = hn;
+      if (seq0 + srow < n) {
+        const size_t at = ((size_t)dir * n + seq0 + srow) * L + t;
+        out[at * H + u] = hn;
+        float* sv = save + at * (4 * H) + u;
+        sv[0] = r; sv[H] = z; sv[2 * H] = nn; sv[3 * H] = acc_nh[rho];
+      }
+    }
+#pragma unroll
+    for (int rho = 0; rho < 4; ++rho) { cr[rho] = nr[rho]; cz[rho] = nz[rho]; cn[rho] = nn_[rho]; }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void gru_bwd2_kernel(const float* __restrict__ gout, const float* __restrict__ out, const float* __restrict__ save,
+                                                       const float* __restrict__ wpack_bwd, float* __restrict__ di, int n, int L) {
+  __shared__ __attribute__((aligned(16))) float dh_m[2][TS][DP];      // [da_r | da_z | da_n r]  -> dh
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int dir = (int)(blockIdx.x & 1);
+  const int j = lane & 15, g = lane >> 4;
+  const int seq0 = (int)(blockIdx.x >> 1) * TS;
+  if (seq0 >= n) return;
+  float wh[48];
+  {
+    const float4* wp = reinterpret_cast<const float4*>(wpack_bwd + (((size_t)dir * 4 + w) * 64 + lane) * 96);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) { const float4 a = wp[i]; wh[4 * i] = a.x; wh[4 * i + 1] = a.y; wh[4 * i + 2] = a.z; wh[4 * i + 3] = a.w; }
+  }
+  const int u = 16 * w + j;
+  const int t0 = dir == 0 ? 0 : L - 1, dt = dir == 0 ? 1 : -1;        // the FORWARD walk; this kernel walks it backwards
+  size_t base[4];                                                      // (dir, sequence) row base; rows beyond n read the last sequence, never stored
+  bool ok[4];
+#pragma unroll
+  for (int rho = 0; rho < 4; ++rho) { ok[rho] = seq0 + 4 * g + rho < n; base[rho] = ((size_t)dir * n + min(seq0 + 4 * g + rho, n - 1)) * L; }
+  float dh_rec[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  // the saved values of the step in hand (c*) and of the one after it in walking order (p*), requested a step ahead
+  float cg[4], c_r[4], c_z[4], c_n[4], c_l[4], c_h[4], pg[4], p_r[4], p_z[4], p_n[4], p_l[4], p_h[4];
+#define GRU_BWD_FETCH(G, R, Z, N, LL, HP, STEP)                                                       \
+  _Pragma("unroll") for (int rho = 0; rho < 4; ++rho) {                                               \
+    const size_t at = base[rho] + (size_t)(t0 + dt * (STEP));                                         \
+    G[rho] = gout[at * H + u];                                                                        \
+    const float* sv = save + at * (4 * H) + u;                                                        \
+    R[rho] = sv[0]; Z[rho] = sv[H]; N[rho] = sv[2 * H]; LL[rho] = sv[3 * H];                          \
+    HP[rho] = (STEP) > 0 ? out[(at - dt) * H + u] : 0.0f;                                             \
+  }
+  GRU_BWD_FETCH(cg, c_r, c_z, c_n, c_l, c_h, L - 1)
+  for (int step = L - 1; step >= 0; --step) {
+    const int t = t0 + dt * step;
+    const int cur = step & 1;
+    if (step > 0) { GRU_BWD_FETCH(pg, p_r, p_z, p_n, p_l, p_h, step - 1) }
+#pragma unroll
+    for (int rho = 0; rho < 4; ++rho) {
+      const int srow = 4 * g + rho;
+      float da_r = 0.0f, da_z = 0.0f, da_n = 0.0f, da_hn = 0.0f, keep = 0.0f;
+      if (ok[rho]) {
+        const float dh = cg[rho] + dh_rec[rho];
+        const float r = c_r[rho], z = c_z[rho], nn = c_n[rho];
+        const float dn = dh * (1.0f - z);
+        da_n = dn * (1.0f - nn * nn);
+        da_r = da_n * c_l[rho] * r * (1.0f - r);
+        da_z = dh * (c_h[rho] - nn) * z * (1.0f - z);
+        da_hn = da_n * r;
+        keep = dh * z;
+        float* o = di + (base[rho] + t) * (3 * H) + u;
+        o[0] = da_r; o[H] = da_z; o[2 * H] = da_n;
+      }
+      dh_rec[rho] = keep;
+      dh_m[cur][srow][u] = da_r; dh_m[cur][srow][H + u] = da_z; dh_m[cur][srow][2 * H + u] = da_hn;
+    }
+    __syncthreads();                                                  // (two buffers: one barrier per step)
+    f32x4 acc_h = {0.0f, 0.0f, 0.0f, 0.0f};
+    {
+      const float4* ph = reinterpret_cast<const float4*>(&dh_m[cur][j][48 * g]);
+#pragma unroll
+      for (int i = 0; i < 12; ++i) {
+        const float4 a = ph[i];
+        acc_h = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, wh[4 * i], acc_h, 0, 0, 0);
+        acc_h = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, wh[4 * i + 1], acc_h, 0, 0, 0);
+        acc_h = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, wh[4 * i + 2], acc_h, 0, 0, 0);
+        acc_h = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, wh[4 * i + 3], acc_h, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int rho = 0; rho < 4; ++rho) {
+      dh_rec[rho] += acc_h[rho];
+      cg[rho] = pg[rho]; c_r[rho] = p_r[rho]; c_z[rho] = p_z[rho]; c_n[rho] = p_n[rho]; c_l[rho] = p_l[rho]; c_h[rho] = p_h[rho];
+    }
+  }
+#undef GRU_BWD_FETCH
+}
+
+// dx[row][c] = sum_dir sum_k' da[dir][row][k'] W_ih,dir[k'][c], gated: g = gate[row][c] > 0 ? dx : 0 (gate == NULL: no gate).
+// da [2][rows][192]; the B operands are the [48:96) halves of pack_gru_bwd's images. One wave = 16 rows x 16 columns.
+__global__ __launch_bounds__(256) void gru_dx_gate_kernel(const float* __restrict__ di, const float* __restrict__ wpack_bwd, const float* __restrict__ gate,
+                                                          float* __restrict__ gout, int64_t rows) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  float wi[2][48];
+#pragma unroll
+  for (int dir = 0; dir < 2; ++dir) {
+    const float4* wp = reinterpret_cast<const float4*>(wpack_bwd + (((size_t)dir * 4 + w) * 64 + lane) * 96 + 48);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) { const float4 b = wp[i]; wi[dir][4 * i] = b.x; wi[dir][4 * i + 1] = b.y; wi[dir][4 * i + 2] = b.z; wi[dir][4 * i + 3] = b.w; }
+  }
+  const int u = 16 * w + j;
+  const int64_t ntiles = (rows + 15) / 16;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t r0 = tile * 16;
+    const int64_t arow = r0 + j < rows ? r0 + j : rows - 1;
+    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int dir = 0; dir < 2; ++dir) {
+      const float4* pa = reinterpret_cast<const float4*>(di + ((size_t)dir * rows + arow) * (3 * H) + 48 * g);
+#pragma unroll
+      for (int i = 0; i < 12; ++i) {
+        const float4 a = pa[i];
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, wi[dir][4 * i], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, wi[dir][4 * i + 1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, wi[dir][4 * i + 2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, wi[dir][4 * i + 3], acc, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int rho = 0; rho < 4; ++rho) {
+      const int64_t row = r0 + 4 * g + rho;
+      if (row < rows) {
+        // (the value is moved out of the accumulator first: with `cond ? acc[rho] : 0.0f` hipcc 7.2 zeroes the AGPR that still holds
+        //  acc[rho] before the compare and stores that — every gated element came out 0)
+        float v = acc[rho];
+        asm volatile("" : "+v"(v));
+        const float gv = gate ? gate[row * H + u] : 1.0f;
+        gout[row * H + u] = gv > 0.0f ? v : 0.0f;
+      }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" void svdd_internal_timed_events(int k, hipEvent_t* e0, hipEvent_t* e1);   // svdd_kernels.hip (profiling)
@@ -483,7 +730,9 @@ int svdd_reward_stem_f32(const float* x, const float* w, const float* b, float* 
   if (!x || !w || !b || !out || n <= 0 || L <= 0 || taps != 15) return SVDD_E_ARG;
   const int64_t rows = (int64_t)n * L;
   const unsigned grid = (unsigned)((rows + 3) / 4 < 2048 ? (rows + 3) / 4 : 2048);
-  hipLaunchKernelGGL(reward_stem_fwd_kernel<15>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, w, b, out, rows, L);
+  hipEvent_t e0, e1;
+  svdd_internal_timed_events(5, &e0, &e1);
+  hipExtLaunchKernelGGL(reward_stem_fwd_kernel<15>, dim3(grid), dim3(256), 0, (hipStream_t)stream, e0, e1, 0, x, w, b, out, rows, L);
   return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
 }
 
@@ -491,7 +740,9 @@ int svdd_reward_stem_bwd_f32(const float* g, const float* w, float* dx, int n, i
   if (!g || !w || !dx || n <= 0 || L <= 0 || taps != 15) return SVDD_E_ARG;
   const int64_t rows = (int64_t)n * L;
   const unsigned grid = (unsigned)((rows + 3) / 4 < 2048 ? (rows + 3) / 4 : 2048);
-  hipLaunchKernelGGL(reward_stem_bwd_kernel<15>, dim3(grid), dim3(256), 0, (hipStream_t)stream, g, w, dx, rows, L);
+  hipEvent_t e0, e1;
+  svdd_internal_timed_events(5, &e0, &e1);
+  hipExtLaunchKernelGGL(reward_stem_bwd_kernel<15>, dim3(grid), dim3(256), 0, (hipStream_t)stream, e0, e1, 0, g, w, dx, rows, L);
   return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
 }
 
@@ -511,8 +762,40 @@ int svdd_reward_tail_grad_f32(const float* h_fwd, const float* h_bwd, const floa
   const size_t lds = sizeof(float) * (2 * 128 * 64 + 4 * 192);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(reward_tail_grad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const unsigned grid = (unsigned)((rows + 3) / 4 < 1024 ? (rows + 3) / 4 : 1024);
-  hipLaunchKernelGGL(reward_tail_grad_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, h_fwd, h_bwd, w1, b1, gamma, beta, w_eff,
-                     eps, 1.0f / ((float)n * (float)L), g_fwd, g_bwd, rows);
+  hipEvent_t e0, e1;
+  svdd_internal_timed_events(7, &e0, &e1);
+  hipExtLaunchKernelGGL(reward_tail_grad_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, e0, e1, 0, h_fwd, h_bwd, w1, b1, gamma, beta,
+                        w_eff, eps, 1.0f / ((float)n * (float)L), g_fwd, g_bwd, rows);
+  return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
+}
+
+int svdd_gru_bidir_train2_f32(const float* x, const float* wpack, const float* bpack, float* gi, float* out, float* save, int n, int L,
+                              void* stream) {
+  if (!x || !wpack || !bpack || !gi || !out || !save || n <= 0 || L <= 0) return SVDD_E_ARG;
+  const int64_t rows = (int64_t)n * L;
+  const int64_t tiles = (rows + 15) / 16;
+  hipEvent_t e0, e1;
+  svdd_internal_timed_events(11, &e0, &e1);                          // one timed span over both launches
+  hipExtLaunchKernelGGL(gru_xproj_kernel, dim3((unsigned)(tiles < 2048 ? tiles : 2048), 2), dim3(256), 0, (hipStream_t)stream, e0, nullptr, 0,
+                        x, wpack, bpack, gi, rows);
+  if (hipGetLastError() != hipSuccess) return SVDD_E_LAUNCH;
+  hipExtLaunchKernelGGL(gru_train_fwd2_kernel, dim3(2 * (unsigned)((n + TS - 1) / TS)), dim3(256), 0, (hipStream_t)stream, nullptr, e1, 0,
+                        (const float*)gi, wpack, bpack, out, save, n, L);
+  return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
+}
+
+int svdd_gru_bidir_bwd2_f32(const float* grad_out, const float* out, const float* save, const float* wpack_bwd, float* da, const float* gate,
+                            float* g, int n, int L, void* stream) {
+  if (!grad_out || !out || !save || !wpack_bwd || !da || !g || n <= 0 || L <= 0) return SVDD_E_ARG;
+  hipEvent_t e0, e1;
+  svdd_internal_timed_events(12, &e0, &e1);
+  hipExtLaunchKernelGGL(gru_bwd2_kernel, dim3(2 * (unsigned)((n + TS - 1) / TS)), dim3(256), 0, (hipStream_t)stream, e0, nullptr, 0,
+                        grad_out, out, save, wpack_bwd, da, n, L);
+  if (hipGetLastError() != hipSuccess) return SVDD_E_LAUNCH;
+  const int64_t rows = (int64_t)n * L;
+  const int64_t tiles = (rows + 15) / 16;
+  hipExtLaunchKernelGGL(gru_dx_gate_kernel, dim3((unsigned)(tiles < 2048 ? tiles : 2048)), dim3(256), 0, (hipStream_t)stream, nullptr, e1, 0,
+                        (const float*)da, wpack_bwd, gate, g, rows);
   return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
 }
 

@@ -182,7 +182,7 @@ class Diffusion(nn.Module):
         self.skip_unchanged = True
         self.late_steps_from = 0.8       # from this fraction of the steps on, FusedValueNet may run the live candidates as two parts (split_gru_rounds)
         self.dedup_prior = True          # the prior's rows are identical (all MASK): its net evaluations run on ONE row (exact; see _prior_logits)
-        self.pm_two_part = True          # SVDD-PM skipping loop: the live candidates as whole backbone rounds + remainder, the first part's reward net under the remainder (_pm_split_rows)
+        self.pm_two_part = False         # SVDD-PM skipping loop: the live candidates as whole backbone rounds + remainder, the first part's reward net under the remainder (_pm_split_rows)
         self.dps_fused = True            # DPS: the whole step on hand-written kernels, no autograd (_dps_fused_nets); False: round 5's autograd path between the same big kernels
         self.dps_one_launch = True       # DPS: the differentiable backbone pass as one launch each way (svdd_backbone_cnn_save_f32 / _grad_f32) where it applies
         self._dps_hard_onehot, self._dps_raw_logits = False, None

@@ -755,6 +755,7 @@ class FusedValueNet(nn.Module):
         self._folded_ws = [w.detach() for w in folded_ws]
         self._lp = {}
         self._grad_packs = None
+        self.gru_off_chain = True            # mean_score_input_grad: W_i x and W_i^T da as whole-chip launches beside the GRU's serial chains (A/B knob)
         self._ln_eps = d1.norm.layer.eps
 
     def lp_ok(self, L):
@@ -837,19 +838,30 @@ class FusedValueNet(nn.Module):
             fs.append(conv1d_cl(fs[-1], wp, 64, 5, 1, bias=b, f_prev=fs[-1] if res else None, act=ACT_ADD_THEN_RELU))
         out = torch.empty((2, n, L, 64), dtype=torch.float32, device=dev)
         save = torch.empty((2, n, L, 4, 64), dtype=torch.float32, device=dev)
-        _lib.check(lib.svdd_gru_bidir_train_f32(fs[-1].data_ptr(), self.wpack.data_ptr(), self.bpack.data_ptr(), out.data_ptr(),
-                                                save.data_ptr(), n, L, st), "svdd_gru_bidir_train_f32")
+        gates = torch.empty((2, n * L, 192), dtype=torch.float32, device=dev)         # b + W_i x, then reused for the gate derivatives
         gout = torch.empty_like(out)
         w_eff0 = self.w_eff[:, 0].contiguous()
+        dxg = torch.empty((2, n, L, 64), dtype=torch.float32, device=dev)             # work buffers of the tower's backward pass
+        if self.gru_off_chain:
+            # the non-recurrent halves (W_i x forwards, W_i^T da backwards) as whole-chip launches beside the serial chains
+            _lib.check(lib.svdd_gru_bidir_train2_f32(fs[-1].data_ptr(), self.wpack.data_ptr(), self.bpack.data_ptr(), gates.data_ptr(),
+                                                     out.data_ptr(), save.data_ptr(), n, L, st), "svdd_gru_bidir_train2_f32")
+        else:
+            _lib.check(lib.svdd_gru_bidir_train_f32(fs[-1].data_ptr(), self.wpack.data_ptr(), self.bpack.data_ptr(), out.data_ptr(),
+                                                    save.data_ptr(), n, L, st), "svdd_gru_bidir_train_f32")
         _lib.check(lib.svdd_reward_tail_grad_f32(out[0].data_ptr(), out[1].data_ptr(), self.w1.data_ptr(), self.b1.data_ptr(),
                                                  self.ln_w.data_ptr(), self.ln_b.data_ptr(), w_eff0.data_ptr(), float(self._ln_eps), n, L,
                                                  gout[0].data_ptr(), gout[1].data_ptr(), st), "svdd_reward_tail_grad_f32")
-        dxg = torch.empty_like(out)
-        _lib.check(lib.svdd_gru_bidir_bwd_f32(gout.data_ptr(), out.data_ptr(), save.data_ptr(), gru_bwd.data_ptr(), dxg.data_ptr(), n, L, st),
-                   "svdd_gru_bidir_bwd_f32")
-        g = gout[0]                                                                  # reuse: the gradient at the last layer's pre-activation
-        _lib.check(lib.svdd_sum_gate_f32(dxg[0].data_ptr(), dxg[1].data_ptr(), fs[-1].data_ptr(), g.data_ptr(), n * L * 64, st),
-                   "svdd_sum_gate_f32")
+        g = dxg[1]                                                                   # the gradient at the last layer's pre-activation
+        if self.gru_off_chain:
+            _lib.check(lib.svdd_gru_bidir_bwd2_f32(gout.data_ptr(), out.data_ptr(), save.data_ptr(), gru_bwd.data_ptr(), gates.data_ptr(),
+                                                   fs[-1].data_ptr(), g.data_ptr(), n, L, st), "svdd_gru_bidir_bwd2_f32")
+        else:
+            dxd = torch.empty_like(out)
+            _lib.check(lib.svdd_gru_bidir_bwd_f32(gout.data_ptr(), out.data_ptr(), save.data_ptr(), gru_bwd.data_ptr(), dxd.data_ptr(), n, L, st),
+                       "svdd_gru_bidir_bwd_f32")
+            _lib.check(lib.svdd_sum_gate_f32(dxd[0].data_ptr(), dxd[1].data_ptr(), fs[-1].data_ptr(), g.data_ptr(), n * L * 64, st),
+                       "svdd_sum_gate_f32")
         bufs = [gout[1], dxg[0]]
         for k in range(len(packs_t) - 1, -1, -1):                                    # block k + 1: fs[k + 1] = relu(conv_k(fs[k]) + b (+ fs[k]))
             y = bufs[k & 1]

@@ -605,6 +605,12 @@ def test_value_net_mean_score_input_grad_without_autograd(B, task):
     x[0, : L // 3] = 0.0                                                          # rows of zeros (what a MASK position's one-hot is)
     got = fn.mean_score_input_grad(x)
     assert got.shape == (B, L, 4) and torch.isfinite(got).all()
+    fn.gru_off_chain = False                                                      # A/B: the GRU's non-recurrent halves inside the chains (round 5's kernels)
+    try:
+        got_in = fn.mean_score_input_grad(x)
+    finally:
+        fn.gru_off_chain = True
+    assert float((got - got_in).abs().max()) <= 2e-6 * float(got_in.abs().max())
     xa = x.clone().requires_grad_(True)
     fn.forward_grad(xa)[:, 0].mean().backward()
     r64 = copy.deepcopy(reward).double()
@@ -659,3 +665,41 @@ def test_dps_step_without_autograd_equals_the_autograd_path(scale):
     rel = float(((q_new - q_old).abs() / q_old.abs().clamp(min=1e-12)).max())
     print(f"dps fused vs autograd path, scale {scale}: max rel diff of q {rel:.2e}")
     assert rel <= 2e-4, rel
+
+
+@pytest.mark.parametrize("n,L", [(5, 50), (37, 200), (256, 200)])
+def test_gru_pair_off_the_chain_equals_the_in_chain_kernels(n, L):
+    """svdd_gru_bidir_train2_f32 / _bwd2_f32 (round 6: W_i x of every step and W_i^T da of every step as whole-chip launches, the serial
+    chains keep only the recurrent 48 MFMAs per step) against the in-chain kernels of round 5: hidden states and saved gates bit for bit
+    (the accumulators see the same operations in the same order), the gated input gradient to fp32 rounding."""
+    import ctypes
+    from svdd_amd import _lib, synthetic
+    from svdd_amd.fused import pack_gru, pack_gru_bwd
+    _, _, _, reward = synthetic.build("dna" if L == 200 else "rna", DEV)
+    gru = reward.embedding.gru_tower.gru
+    wpack, bpack = (t.to(DEV) for t in pack_gru(gru))
+    wbwd = pack_gru_bwd(gru).to(DEV)
+    lib, st = _lib.lib(), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    torch.manual_seed(n)
+    x = torch.relu(torch.randn(n, L, 64, device=DEV))
+    gout = torch.randn(2, n, L, 64, device=DEV) * 1e-3
+    out1, out2 = torch.empty(2, n, L, 64, device=DEV), torch.empty(2, n, L, 64, device=DEV)
+    save1, save2 = torch.empty(2, n, L, 4, 64, device=DEV), torch.empty(2, n, L, 4, 64, device=DEV)
+    scratch = torch.empty(2, n * L, 192, device=DEV)
+    _lib.check(lib.svdd_gru_bidir_train_f32(x.data_ptr(), wpack.data_ptr(), bpack.data_ptr(), out1.data_ptr(), save1.data_ptr(), n, L, st), "train")
+    _lib.check(lib.svdd_gru_bidir_train2_f32(x.data_ptr(), wpack.data_ptr(), bpack.data_ptr(), scratch.data_ptr(), out2.data_ptr(),
+                                             save2.data_ptr(), n, L, st), "train2")
+    assert torch.equal(out1, out2) and torch.equal(save1, save2)
+    dx = torch.empty(2, n, L, 64, device=DEV)
+    _lib.check(lib.svdd_gru_bidir_bwd_f32(gout.data_ptr(), out1.data_ptr(), save1.data_ptr(), wbwd.data_ptr(), dx.data_ptr(), n, L, st), "bwd")
+    want = torch.where(x > 0, dx[0] + dx[1], torch.zeros_like(x))
+    got = torch.empty(n, L, 64, device=DEV)
+    _lib.check(lib.svdd_gru_bidir_bwd2_f32(gout.data_ptr(), out1.data_ptr(), save1.data_ptr(), wbwd.data_ptr(), scratch.data_ptr(), x.data_ptr(),
+                                           got.data_ptr(), n, L, st), "bwd2")
+    scale = float(want.abs().max())
+    assert float((got - want).abs().max()) <= 2e-6 * scale, (float((got - want).abs().max()), scale)
+    assert torch.equal(got == 0, want == 0) or float(((got == 0) != (want == 0)).float().mean()) < 1e-6
+    nogate = torch.empty(n, L, 64, device=DEV)
+    _lib.check(lib.svdd_gru_bidir_bwd2_f32(gout.data_ptr(), out1.data_ptr(), save1.data_ptr(), wbwd.data_ptr(), scratch.data_ptr(), None,
+                                           nogate.data_ptr(), n, L, st), "bwd2 no gate")
+    assert float((nogate - (dx[0] + dx[1])).abs().max()) <= 2e-6 * float((dx[0] + dx[1]).abs().max())
