@@ -492,7 +492,7 @@ def trunk_gemm_roofline(model, emb, head, dev, n, L, precision="bf16x3"):
 def config4_leg(dev, steps, B=256, L=200, M=20, S=128, f32_steps=1):
     """BASELINE.json configs[3] at its per-GPU shard size (B = 256 of the 2048, M = 20, the Enformer-shaped 230 M-parameter
     value trunk) as an extra object of the default line: one warm-up decode + `steps` timed decodes in bf16x3 (split bf16
-    operands, fp32-class error) and, beside it (`f32`), at the reference's own precision on the fp32-plane form of the same kernels (round 4).
+    operands: a 16-bit operand, 1e-5-class error — not fp32-class) and, beside it (`f32`), at the reference's own precision on the fp32-plane form of the same kernels (round 4).
     Reported beside the headline, never in it; a failure here is recorded, not raised."""
     try:
         from svdd_amd import synthetic
@@ -512,8 +512,8 @@ def config4_leg(dev, steps, B=256, L=200, M=20, S=128, f32_steps=1):
         res = {"workload": f"DNA enhancer SVDD-MC, batch={B}/GPU, L={L}, M={M}, {S} steps, Enformer-shaped value trunk "
                            "(230M params) — BASELINE.json configs[3] per-GPU shard", "value": round(B * steps / el, 3),
                "unit": "sequences/s", "n_gpus": 1, "steps": steps, "ms_per_step": round(el / steps * 1e3, 3), "dtype": "bf16x3",
-               "arithmetic": "value trunk: fp32 operands split hi+lo in bf16, 3 MFMA passes, fp32 accumulate; backbone: the same split "
-                             "(backbone_lp_t_kernel)", "data": "synthetic (random-init nets, all-MASK prior)"}
+               "arithmetic": "value trunk: fp32 operands split hi+lo in bf16 (16-bit operand: 1e-5-class error, not fp32-class), 3 MFMA passes, "
+                             "fp32 accumulate; backbone: the same split (backbone_lp_t_kernel)", "data": "synthetic (random-init nets, all-MASK prior)"}
         try:                                                   # the dominant kernel of THIS workload, measured in this run
             res["roofline_trunk_gemm"] = trunk_gemm_roofline(model, emb, head, dev, int(0.75 * B * M), L)
         except Exception as e:                                 # noqa: BLE001
@@ -1273,8 +1273,9 @@ def main():
             "value": round(B * world * args.alt_steps / el, 3), "unit": "sequences/s", "ms_per_step": round(el / args.alt_steps * 1e3, 3),
             "steps": args.alt_steps, "dtype": mode, "x0_sha1": _digest(out_alt),
             "x0_rows_identical_vs_f32": round(float((out_alt == out).all(dim=1).float().mean()), 5),
-            "arithmetic": ("fp32 operands split hi+lo in %s, a*b = ahi*bhi + ahi*blo + alo*bhi on the 16-bit MFMA, fp32 accumulate"
-                           % mode[:-2]) if passes == 3 else "operands rounded to %s, one MFMA pass, fp32 accumulate" % mode,
+            "arithmetic": ("fp32 operands split hi+lo in %s, a*b = ahi*bhi + ahi*blo + alo*bhi on the 16-bit MFMA, fp32 accumulate; %s"
+                           % (mode[:-2], "22-bit operand: fp32-class" if mode == "f16x3" else "16-bit operand: 1e-5-class, NOT fp32-class"))
+                          if passes == 3 else "operands rounded to %s, one MFMA pass, fp32 accumulate" % mode,
             "roofline": {"bound": "mfma", "kernel": "backbone_lp_kernel (svdd_backbone_cnn_lp, one launch per forward)",
                          "achieved": round(tf, 2), "peak": LP_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / LP_PEAK_TFLOPS, 5),
                          "flops_per_launch": round(bb_flops), "mfma_passes": passes,

@@ -112,6 +112,7 @@ int svdd_sample_categorical(const float* q, const uint8_t* x, int B, int L, int 
  *
  *  scores [B,M] fp32 (row b, candidate m) ; cand [B,M,L] u8
  *  x_next [B,L] u8 out ; soft [B,M] fp32 out (softmax, may be NULL) ; idx [B] i32 out (may be NULL)
+ *  (x_next == NULL with idx != NULL, M <= 64: the decision only, no row gather — round 6's measurement of what the gather costs)
  *  rng is read only for SVDD_SELECT_MULTINOMIAL (must be PHILOX).
  */
 int svdd_select(const float* scores, const uint8_t* cand, int B, int L, int M, int mode,
@@ -370,7 +371,8 @@ int svdd_backbone_split_status(int* err);
  * with the matrix products on the 16-bit matrix cores (fp32 accumulate). An explicit opt-in of the caller
  * (Diffusion.precision); the exact-fp32 kernels remain the default and the parity reference.
  *   SVDD_PREC_F16X3 / BF16X3: fp32 operands split hi + lo on the fly, a*b = ahi*bhi + ahi*blo + alo*bhi (3 MFMAs):
- *     fp32-class error (measured 1.5e-7 / 5.3e-7 of sum|a b| at K = 1152 vs 1.8e-7 for the fp32 MFMA chain);
+ *     f16x3 is fp32-class (a 22-bit operand: 1.5e-7 of sum|a b| at K = 1152 vs 1.8e-7 for the fp32 MFMA chain); bf16x3 is NOT — its
+ *     operand keeps 16 bits (5.3e-7 of sum|a b| per product, backbone logits 4.5e-5 from an fp64 forward: 10 x fp32's 4.5e-6);
  *   SVDD_PREC_F16 / BF16: one pass on the 16-bit roundings of the operands (~3e-5 / ~3e-4 of sum|a b|).
  * Everything that is not a matrix product stays fp32. */
 enum { SVDD_PREC_F32 = 0, SVDD_PREC_F16X3 = 1, SVDD_PREC_BF16X3 = 2, SVDD_PREC_F16 = 3, SVDD_PREC_BF16 = 4 };

@@ -43,7 +43,7 @@ def build_parser(method="mc"):
                         "reference's decode.py:78-80 builds for --model enformer (BASELINE configs[3])")                   # decode.py:149
     p.add_argument("--precision", default="f32", choices=["f32", "f16x3", "bf16x3", "f16", "bf16"],
                    help="f32: exact fp32 net kernels (default, the parity reference); x3: fp32 operands split hi + lo on the 16-bit "
-                        "matrix cores (fp32-class error); f16 / bf16: one pass. With --model enformer any non-f32 mode runs the "
+                        "matrix cores (f16x3: fp32-class error; bf16x3: a 16-bit operand, 1e-5-class); f16 / bf16: one pass. With --model enformer any non-f32 mode runs the "
                         "hand-written trunk kernels (bf16x3 / bf16); f32 runs the PyTorch module")
     p.add_argument("--rng", default="replay", choices=["replay", "philox"],
                    help="replay: the reference's torch-CPU RNG stream; philox: in-kernel counter RNG")

@@ -685,6 +685,7 @@ __global__ __launch_bounds__(256) void select_rows_kernel(SelectArgs a) {
   const int bq = __shfl(best, (q >= 0 && q < G ? q : 0) * MP, WAVE);
   wbest = (q >= 0 && q < G) ? bq : wbest;
   }
+  if (!a.x_next) return;                                    // decision only (idx / sel_score / changed): round 6's gather-free experiment
   // index-gather compaction (diffusion_gosai.py:1226-1227): the R * G winning rows, in units of ub bytes spread over the wave
   const uintptr_t al = (uintptr_t)(a.L | a.ld) | reinterpret_cast<uintptr_t>(a.cand) | reinterpret_cast<uintptr_t>(a.x_next);
   const int ub = (al & 7) == 0 ? 8 : (al & 3) == 0 ? 4 : (al & 1) == 0 ? 2 : 1;
@@ -1458,7 +1459,8 @@ int svdd_select(const float* scores, const uint8_t* cand, int B, int L, int M, i
 int svdd_select_compact(const float* scores, const int32_t* slot, const float* parent_score, const uint8_t* cand, int B,
                         int L, int M, int mode, const svdd_rng_t* rng, uint8_t* x_next, float* soft, int32_t* idx,
                         float* sel_score, int32_t* changed, void* stream) {
-  if (!scores || !cand || !x_next || B <= 0 || L <= 0 || M <= 0 || M > SVDD_MAX_M) return SVDD_E_ARG;
+  if (!scores || !cand || (!x_next && !idx) || B <= 0 || L <= 0 || M <= 0 || M > SVDD_MAX_M) return SVDD_E_ARG;
+  if (!x_next && !(M <= WAVE && g_select_one_row_per_wave != 1)) return SVDD_E_ARG;   // the decision-only form exists in select_rows_kernel only
   if (mode != SVDD_SELECT_ARGMAX && mode != SVDD_SELECT_MULTINOMIAL) return SVDD_E_ARG;
   if (mode == SVDD_SELECT_MULTINOMIAL && (!rng || rng->kind != SVDD_RNG_PHILOX)) return SVDD_E_ARG;
   if (slot && !parent_score) return SVDD_E_ARG;

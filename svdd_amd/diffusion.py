@@ -33,8 +33,9 @@ Engine knobs (attributes; defaults reproduce the reference's observable behaviou
                    False: call the modules as given.
   precision        "f32" (default): the fused nets compute in exact fp32 — the parity path and what bench.py's
                    headline measures. "f16x3" / "bf16x3": matrix products on the 16-bit matrix cores with operands
-                   split hi + lo (3 MFMAs per product, fp32 accumulate): fp32-class error (logits / scores within
-                   ~3e-6 / ~3e-5 of the fp32 kernels) at ~2.5x the speed. "f16" / "bf16": one 16-bit pass.
+                   split hi + lo (3 MFMAs per product, fp32 accumulate) at ~2.5x the speed. ONLY f16x3 is fp32-class (a 22-bit
+                   operand: logits 3e-6 from an fp64 forward, the fp32 kernels 4.5e-6); bf16x3 carries a 16-bit operand —
+                   logits 4.5e-5 from fp64, ten times fp32's error, 1e-5-class. "f16" / "bf16": one 16-bit pass.
                    Tokens can differ from the fp32 decode at near-ties; tools/precision_agreement.py reports it.
   skip_unchanged   True (default): exact work-skipping. A candidate that unmasked nothing is a copy of
                    its parent x_t (:1203) and, time_conditioning being off (:334-335), every net output for it is the

@@ -5,7 +5,7 @@
 Enformer.py:1271-1334, :1807-1884 conv tower, :1887-2007 transformer tower, :2176-2292 ConvBlock "NACDR"), with every
 matrix product on the 16-bit matrix cores in split precision:
 
-    precision "bf16x3"  operands split hi + lo in bf16, 3 MFMAs per product, fp32 accumulate (fp32-class error);
+    precision "bf16x3"  operands split hi + lo in bf16 (a 16-bit operand: 1e-5-class error, NOT fp32-class), 3 MFMAs per product, fp32 accumulate;
               "bf16"    one pass on hi.
 
 Layout and kernels (see the header of svdd_trunk.hip): channels-last rows with two zero rows behind every sequence (and two

@@ -400,7 +400,7 @@ def test_headline_decode_digests_per_precision_mode(full_nets):
     same = {m: int((tokens[m] == tokens["f32"]).all(dim=1).sum()) for m in tokens}
     print("decode digests", digests, "rows identical to the f32 decode", same)
     # f16x3: token for token the exact-fp32 decode at this key in rounds 3 and 4 (digest 82b920b9...); one near-tie may legitimately
-    # flip when a split kernel's summation order changes, a few rows may not. bf16x3: fp32-class error, ~1.5 % of the rows differ at
+    # flip when a split kernel's summation order changes, a few rows may not. bf16x3: a 16-bit operand (1e-5-class error, not fp32-class), ~1.5 % of the rows differ at
     # near-ties (profiles/r03_precision_agreement.json: 252 / 256 at seed 0). bf16 (one pass) only has to repeat itself.
     assert same["f16x3"] >= 255, (digests, same)
     assert same["bf16x3"] >= 246, (digests, same)

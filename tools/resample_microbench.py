@@ -80,7 +80,44 @@ def k4(B, L=200):
     print(f"K4 tds_resample B={B} L={L}: {us:9.1f} us  {gbs:8.1f} GB/s  frac {gbs / PEAK:.4f}  ({nbytes / 1e6:.2f} MB)")
 
 
+def k2_gather_split(B=1 << 18, M=10, L=200, scale=1e-2):
+    """VERDICT r05 #8, one experiment: K2 WITHOUT the row gather (x_next = NULL: idx only), beside the fused kernel and beside the gather as a
+    launch of its own (svdd_gather_rows through the flat index b * M + idx[b]) — what a consumer that reads cand[b, idx[b]] itself would
+    pay per pass. Bytes: decision B (4M + 4); gather B 2L (+ 4 for the index)."""
+    import ctypes
+    from svdd_amd import _lib
+    g = torch.Generator(device=DEV).manual_seed(0)
+    scores = torch.randn(B, M, device=DEV, generator=g) * scale
+    cand = torch.randint(0, 5, (B, M, L), device=DEV, generator=g, dtype=torch.uint8)
+    x_next, x2 = torch.empty(B, L, dtype=torch.uint8, device=DEV), torch.empty(B, L, dtype=torch.uint8, device=DEV)
+    idx = torch.empty(B, dtype=torch.int32, device=DEV)
+    st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)   # noqa: E731
+
+    def fused():
+        assert _lib.lib().svdd_select(scores.data_ptr(), cand.data_ptr(), B, L, M, ops.SELECT_ARGMAX, None, x_next.data_ptr(), None, idx.data_ptr(), st()) == 0
+
+    def decide():
+        assert _lib.lib().svdd_select(scores.data_ptr(), cand.data_ptr(), B, L, M, ops.SELECT_ARGMAX, None, None, None, idx.data_ptr(), st()) == 0
+    fused()
+    flat = (torch.arange(B, device=DEV, dtype=torch.int32) * M + idx).contiguous()
+    count = torch.tensor([B], dtype=torch.int32, device=DEV)
+    gather = lambda: ops.gather_rows(cand.view(B * M, L), flat, count, x2)   # noqa: E731
+    gather()
+    torch.cuda.synchronize()
+    assert torch.equal(x2, x_next)
+    for name, fn, nbytes in (("fused select + gather (the shipped K2)", fused, B * (4 * M + 2 * L + 4)),
+                             ("decision only (x_next = NULL)", decide, B * (4 * M + 4)),
+                             ("gather alone (svdd_gather_rows via idx)", gather, B * (2 * L + 4))):
+        us = timed(fn)
+        print(f"K2 split B={B} M={M} L={L} scores~{scale:g}  {name:42s} {us:8.1f} us  {nbytes / us / 1e3:8.1f} GB/s  frac {nbytes / us / 1e3 / PEAK:.3f}  ({nbytes / 1e6:.1f} MB)")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "split":
+        for scale in (1e-7, 1e-2):
+            k2_gather_split(scale=scale)
+        k2_gather_split(M=20)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "ld":        # the padded-row layout experiment (VERDICT r03 #7): near-tied leg first
         for scale in (1e-7, 1e-2):
             for M in (10, 20):
