@@ -444,6 +444,9 @@ enum { SVDD_OPT_FORCE_EXACT = 0,
        SVDD_OPT_TRUNK_PLANES_F32 = 6 /* the svdd_trunk_* entry points take ONE fp32 operand plane (the *_hi pointers are float*, the
                                          *_lo pointers NULL) and svdd_trunk_gemm multiplies on v_mfma_f32_16x16x4_f32: the Enformer-shaped
                                          trunk at the reference's precision (weights packed by fused_trunk.pack_gemm_weight_f32) */,
+       SVDD_OPT_SELECT_BATCHES = 8 /* A/B (round 6): batches of row groups a wave of a SATURATED svdd_select launch (>= 2^21 (row, candidate)
+                                      slots, M = 10 / 20) takes: 0 / 1 = one (default), 2 / 4 = the next batch decided under the row
+                                      gathers of the one before — measured slower, kept for the record */,
        SVDD_OPT_BACKBONE_SPLIT = 7 /* svdd_backbone_cnn_f32 on several workgroups per sequence (small batches; same bits): 0 = automatic
                                        (4 workgroups per sequence while 4 n <= CUs, 2 while 2 n <= CUs; needs
                                        svdd_backbone_set_workspace), 1 = never, 2 / 4 = that many wherever n R <= CUs */ };

@@ -608,18 +608,12 @@ struct OrderedSum<MP, 0> {
 
 // MS = how many lanes of the group the ordered sum visits: MP in general (lanes beyond M hold +0), exactly M for the widths
 // the BASELINE configs run (M = 10, 20): 6 / 12 fewer broadcast + add pairs on the exact path.
-template <int MP, int R, int MS = MP>
-__global__ __launch_bounds__(256) void select_rows_kernel(SelectArgs a) {
-  // R row GROUPS per wave (round 4): with one group a wave had one 512-byte gather in flight at a time, 8192 waves on the chip
-  // = 4 MB in flight against the ~12 MB that 5.8 TB/s x 2 us of latency need (the padded-row layout experiment showed the
-  // kernel is not traffic-bound: 151 -> 131 MB moved, 26.7 -> 25.6 us). A wave now loads the scores of its R groups back to
-  // back, decides them, and issues the row gathers of all R * G winners in batches of four loads before the first store.
+// The decision of the G * R rows row0 .. of one wave (scores -> first-index argmax | exact softmax argmax | Philox multinomial; writes
+// soft / idx / sel_score / changed) -> lane q < R * G holds the winning candidate of row row0 + q.
+template <int MP, int R, int MS>
+__device__ __forceinline__ int select_decide(const SelectArgs& a, const int64_t row0, const int lane) {
   constexpr int G = WAVE / MP;
-  static_assert(R * G <= WAVE, "one lane per winning row");
-  const int lane = threadIdx.x & (WAVE - 1);
   const int g = lane / MP, m = lane % MP, base = lane & ~(MP - 1);
-  const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * (G * R);
-  if (row0 >= a.B) return;
   float svr[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
@@ -685,49 +679,95 @@ __global__ __launch_bounds__(256) void select_rows_kernel(SelectArgs a) {
   const int bq = __shfl(best, (q >= 0 && q < G ? q : 0) * MP, WAVE);
   wbest = (q >= 0 && q < G) ? bq : wbest;
   }
-  if (!a.x_next) return;                                    // decision only (idx / sel_score / changed): round 6's gather-free experiment
-  // index-gather compaction (diffusion_gosai.py:1226-1227): the R * G winning rows, in units of ub bytes spread over the wave
+  return wbest;
+}
+
+// index-gather compaction (diffusion_gosai.py:1226-1227) of the R * G winning rows of a wave in units of 8 bytes: four gathers per
+// lane are REQUESTED (select_gather_issue) and stored later (select_gather_store), so that the caller can put other work — the next
+// batch's decision — under their latency.
+struct SelectGather { uint2 v[4]; uint8_t* dst[4]; bool ok[4]; };
+
+template <int RG>
+__device__ __forceinline__ void select_gather_issue(const SelectArgs& a, const int64_t row0, const int wbest, const int lane, const int i0,
+                                                    const int U, const int total, const float inv_u, SelectGather& s) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int i = i0 + k * WAVE + lane;
+    int gq = (int)(((float)i + 0.5f) * inv_u);            // i / U (i < 2^22: exact after the half-unit offset)
+    gq = gq < RG ? gq : RG - 1;
+    const int bq = __shfl(wbest, gq, WAVE);
+    const int64_t rq = row0 + gq;
+    s.ok[k] = i < total && rq < a.B;
+    const int c = i - gq * U;
+    s.dst[k] = a.x_next + rq * a.L + (int64_t)c * 8;
+    s.v[k] = uint2{0u, 0u};
+    if (s.ok[k]) s.v[k] = *reinterpret_cast<const uint2*>(a.cand + (rq * a.M + bq) * a.ld + (int64_t)c * 8);
+  }
+}
+__device__ __forceinline__ void select_gather_store(const SelectGather& s) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (s.ok[k]) *reinterpret_cast<uint2*>(s.dst[k]) = s.v[k];
+}
+
+// NB = batches of G * R rows per wave (round 6 experiment, SVDD_OPT_SELECT_BATCHES): with one batch every wave of a saturated launch
+// decides, then gathers — the decision's arithmetic (9 - 15 us of the 26 - 30 at 2^18 rows, profiles/r06_k2_gather_split.txt) and the
+// gather's traffic (the rest: at the memory system's speed) add up. A wave with NB > 1 batches requests the row gathers of batch b and
+// decides batch b + 1 while they are in flight: same decisions, same bytes — and SLOWER (35.8 / 41.5 us at NB = 2 / 4 against 27.4):
+// fewer waves, fewer loads in flight. NB = 1 is what runs.
+template <int MP, int R, int MS = MP, int NB = 1>
+__global__ __launch_bounds__(256) void select_rows_kernel(SelectArgs a) {
+  // R row GROUPS per wave (round 4): with one group a wave had one 512-byte gather in flight at a time, 8192 waves on the chip
+  // = 4 MB in flight against the ~12 MB that 5.8 TB/s x 2 us of latency need. A wave loads the scores of its R groups back to
+  // back, decides them, and issues the row gathers of all R * G winners in batches of four loads before the first store.
+  constexpr int G = WAVE / MP;
+  static_assert(R * G <= WAVE, "one lane per winning row");
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int64_t row_first = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * (G * R) * NB;
+  if (row_first >= a.B) return;
   const uintptr_t al = (uintptr_t)(a.L | a.ld) | reinterpret_cast<uintptr_t>(a.cand) | reinterpret_cast<uintptr_t>(a.x_next);
   const int ub = (al & 7) == 0 ? 8 : (al & 3) == 0 ? 4 : (al & 1) == 0 ? 2 : 1;
   const int U = a.L / ub, total = R * G * U;
   const float inv_u = 1.0f / (float)U;
-  if (ub == 8) {
-    // four gathers in flight per lane before the first store
-    for (int i0 = 0; i0 < total; i0 += 4 * WAVE) {
-      uint2 v[4]; uint8_t* dst[4]; bool ok[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int i = i0 + k * WAVE + lane;
-        int gq = (int)(((float)i + 0.5f) * inv_u);          // i / U (i < 2^22: exact after the half-unit offset)
-        gq = gq < R * G ? gq : R * G - 1;
-        const int bq = __shfl(wbest, gq, WAVE);
-        const int64_t rq = row0 + gq;
-        ok[k] = i < total && rq < a.B;
-        const int c = i - gq * U;
-        dst[k] = a.x_next + rq * a.L + (int64_t)c * 8;
-        v[k] = uint2{0u, 0u};
-        if (ok[k]) v[k] = *reinterpret_cast<const uint2*>(a.cand + (rq * a.M + bq) * a.ld + (int64_t)c * 8);
+  int wbest = select_decide<MP, R, MS>(a, row_first, lane);
+#pragma unroll 1
+  for (int b = 0; b < NB; ++b) {
+    const int64_t row0 = row_first + (int64_t)b * (G * R);
+    if (row0 >= a.B) return;
+    const bool more = b + 1 < NB && row0 + G * R < a.B;
+    if (!a.x_next) {                                        // decision only (idx / sel_score / changed): round 6's gather-free experiment
+      if (more) wbest = select_decide<MP, R, MS>(a, row0 + G * R, lane);
+      continue;
+    }
+    if (ub == 8) {
+      SelectGather sg;
+      select_gather_issue<R * G>(a, row0, wbest, lane, 0, U, total, inv_u, sg);
+      int wnext = 0;
+      if (more) wnext = select_decide<MP, R, MS>(a, row0 + G * R, lane);     // under the gathers' latency
+      select_gather_store(sg);
+      for (int i0 = 4 * WAVE; i0 < total; i0 += 4 * WAVE) {
+        select_gather_issue<R * G>(a, row0, wbest, lane, i0, U, total, inv_u, sg);
+        select_gather_store(sg);
       }
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-        if (ok[k]) *reinterpret_cast<uint2*>(dst[k]) = v[k];
+      wbest = wnext;
+      continue;
     }
-    return;
-  }
-  for (int i0 = 0; i0 < total; i0 += WAVE) {
-    const int i = i0 + lane;
-    int gq = (int)(((float)i + 0.5f) * inv_u);
-    gq = gq < R * G ? gq : R * G - 1;
-    const int bq = __shfl(wbest, gq, WAVE);
-    const int64_t rq = row0 + gq;
-    if (i < total && rq < a.B) {
-      const int c = i - gq * U;
-      const uint8_t* src = a.cand + (rq * a.M + bq) * a.ld + (int64_t)c * ub;
-      uint8_t* dst = a.x_next + rq * a.L + (int64_t)c * ub;
-      if (ub == 4) *reinterpret_cast<uint32_t*>(dst) = *reinterpret_cast<const uint32_t*>(src);
-      else if (ub == 2) *reinterpret_cast<uint16_t*>(dst) = *reinterpret_cast<const uint16_t*>(src);
-      else *dst = *src;
+    for (int i0 = 0; i0 < total; i0 += WAVE) {
+      const int i = i0 + lane;
+      int gq = (int)(((float)i + 0.5f) * inv_u);
+      gq = gq < R * G ? gq : R * G - 1;
+      const int bq = __shfl(wbest, gq, WAVE);
+      const int64_t rq = row0 + gq;
+      if (i < total && rq < a.B) {
+        const int c = i - gq * U;
+        const uint8_t* src = a.cand + (rq * a.M + bq) * a.ld + (int64_t)c * ub;
+        uint8_t* dst = a.x_next + rq * a.L + (int64_t)c * ub;
+        if (ub == 4) *reinterpret_cast<uint32_t*>(dst) = *reinterpret_cast<const uint32_t*>(src);
+        else if (ub == 2) *reinterpret_cast<uint16_t*>(dst) = *reinterpret_cast<const uint16_t*>(src);
+        else *dst = *src;
+      }
     }
+    if (more) wbest = select_decide<MP, R, MS>(a, row0 + G * R, lane);
   }
 }
 
@@ -1285,6 +1325,7 @@ TimedLaunch* timed_slot(int k) {
 int g_msplit = 0;        // svdd_set_option(SVDD_OPT_MSPLIT, k): override K1's candidate split (0 = auto)
 int g_force_exact = 0;   // svdd_set_option(SVDD_OPT_FORCE_EXACT, 1): K1 takes the exact path for every draw
 int g_cand_ld = 0;        // svdd_set_option(SVDD_OPT_CAND_ROW_STRIDE, bytes): row stride of `cand` in svdd_select* (0 = L)
+int g_select_batches = 0;   // svdd_set_option(SVDD_OPT_SELECT_BATCHES, n): batches of row groups per wave in saturated svdd_select launches (0 / 1 = one, the default; 2, 4: the round-6 experiment)
 int g_select_one_row_per_wave = 0;   // svdd_set_option(SVDD_OPT_SELECT_ONE_ROW, v): 1 = K2 as one wave per row for every M (A/B); 2 / 3 = the rows-per-wave kernel with 4 / 1 row groups per wave whatever the batch (0: by size)
 unsigned long long* g_k1_stats = nullptr;   // svdd_k1_stats: device counters K1 adds to
 
@@ -1313,6 +1354,7 @@ int svdd_set_option(int key, int value) {
     if (value != 0 && !getenv("SVDD_EXPERIMENTS")) return SVDD_E_ARG;
     g_cand_ld = value; return SVDD_OK;
   }
+  if (key == SVDD_OPT_SELECT_BATCHES && (value == 0 || value == 1 || value == 2 || value == 4)) { g_select_batches = value; return SVDD_OK; }
   if (key == SVDD_OPT_TRUNK_PLANES_F32) { svdd_internal_set_trunk_planes_f32(value); return SVDD_OK; }
   if (key == SVDD_OPT_BACKBONE_SPLIT) { svdd_internal_set_bb_split(value); return SVDD_OK; }
   if (key == SVDD_OPT_BACKBONE_LP_VERSION) { svdd_internal_set_bb_lp_version(value); return SVDD_OK; }
@@ -1483,11 +1525,21 @@ int svdd_select_compact(const float* scores, const int32_t* slot, const float* p
     if (R > 1) hipExtLaunchKernelGGL((select_rows_kernel<MP_, (MP_ >= 4 ? 4 : MP_)>), grid, dim3(256), 0, (hipStream_t)stream, e0, e1, 0, a); \
     else hipExtLaunchKernelGGL((select_rows_kernel<MP_, 1>), grid, dim3(256), 0, (hipStream_t)stream, e0, e1, 0, a);
     if (M == 10 || M == 20) {                               // the BASELINE widths: the ordered sum stops at M
+      // saturated launches (R > 1), EXPERIMENT (svdd_set_option(SVDD_OPT_SELECT_BATCHES, 2 | 4)): NB batches per wave, the next batch's
+      // decision under the row gathers of the one before. Measured slower (profiles/r06_k2_gather_split.txt: 27.4 -> 35.8 / 41.5 us at
+      // 2^18 rows, M = 10): a quarter of the waves means a quarter of the loads in flight — the kernel lives on memory-level
+      // parallelism, not on overlap inside a wave. Default: one batch per wave (round 5's launch).
+      const int nb = R > 1 ? (g_select_batches == 2 ? 2 : g_select_batches == 4 ? 4 : 1) : 1;
+      const dim3 gridb((unsigned)(((waves + nb - 1) / nb + 3) / 4));
       if (M == 10) {
-        if (R > 1) hipExtLaunchKernelGGL((select_rows_kernel<16, 4, 10>), grid, dim3(256), 0, (hipStream_t)stream, e0, e1, 0, a);
+        if (nb == 4) hipExtLaunchKernelGGL((select_rows_kernel<16, 4, 10, 4>), gridb, dim3(256), 0, (hipStream_t)stream, e0, e1, 0, a);
+        else if (nb == 2) hipExtLaunchKernelGGL((select_rows_kernel<16, 4, 10, 2>), gridb, dim3(256), 0, (hipStream_t)stream, e0, e1, 0, a);
+        else if (R > 1) hipExtLaunchKernelGGL((select_rows_kernel<16, 4, 10>), grid, dim3(256), 0, (hipStream_t)stream, e0, e1, 0, a);
         else hipExtLaunchKernelGGL((select_rows_kernel<16, 1, 10>), grid, dim3(256), 0, (hipStream_t)stream, e0, e1, 0, a);
       } else {
-        if (R > 1) hipExtLaunchKernelGGL((select_rows_kernel<32, 4, 20>), grid, dim3(256), 0, (hipStream_t)stream, e0, e1, 0, a);
+        if (nb == 4) hipExtLaunchKernelGGL((select_rows_kernel<32, 4, 20, 4>), gridb, dim3(256), 0, (hipStream_t)stream, e0, e1, 0, a);
+        else if (nb == 2) hipExtLaunchKernelGGL((select_rows_kernel<32, 4, 20, 2>), gridb, dim3(256), 0, (hipStream_t)stream, e0, e1, 0, a);
+        else if (R > 1) hipExtLaunchKernelGGL((select_rows_kernel<32, 4, 20>), grid, dim3(256), 0, (hipStream_t)stream, e0, e1, 0, a);
         else hipExtLaunchKernelGGL((select_rows_kernel<32, 1, 20>), grid, dim3(256), 0, (hipStream_t)stream, e0, e1, 0, a);
       }
       return check_launch();

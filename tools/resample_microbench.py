@@ -105,6 +105,15 @@ def k2_gather_split(B=1 << 18, M=10, L=200, scale=1e-2):
     gather()
     torch.cuda.synchronize()
     assert torch.equal(x2, x_next)
+    for nb in (1, 2, 4):                                   # SVDD_OPT_SELECT_BATCHES: batches of row groups per wave (1 = the default; 2 / 4: the round-6 experiment)
+        _lib.set_option(8, nb)
+        x_next.zero_()
+        us = timed(fused)
+        torch.cuda.synchronize()
+        assert torch.equal(x_next, x2), f"batches {nb}: other tokens"
+        nbytes = B * (4 * M + 2 * L + 4)
+        print(f"K2 split B={B} M={M} L={L} scores~{scale:g}  fused, {nb} batch(es) per wave{'':19s} {us:8.1f} us  {nbytes / us / 1e3:8.1f} GB/s  frac {nbytes / us / 1e3 / PEAK:.3f}")
+    _lib.set_option(8, 0)
     for name, fn, nbytes in (("fused select + gather (the shipped K2)", fused, B * (4 * M + 2 * L + 4)),
                              ("decision only (x_next = NULL)", decide, B * (4 * M + 4)),
                              ("gather alone (svdd_gather_rows via idx)", gather, B * (2 * L + 4))):
