@@ -570,6 +570,7 @@ __device__ __forceinline__ void backbone_lp_t_body(const BackboneLpArgs& a, char
   const int nvalid = a.count ? __builtin_amdgcn_readfirstlane(*a.count) : a.n;
   int seq0 = blockIdx.x, il = 1;                             // this tile's first (compact) sequence and how many it interleaves
   if (IL) {
+    if ((int)blockIdx.x >= nvalid) return;                   // a tile takes at least one sequence: no plan needed to know this one is empty
     SvddTilePlan pl = a.plan;
     if (a.auto_spt) pl = svdd_plan_tiles(nvalid, L, a.ncu, a.fixed_half);
     svdd_plan_tile(pl, (int)blockIdx.x, seq0, il);

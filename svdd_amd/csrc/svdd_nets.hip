@@ -1456,6 +1456,7 @@ __global__ __launch_bounds__(512, 2) void backbone_kernel(BackboneArgs a, Backbo
   const int nvalid = a.count ? __builtin_amdgcn_readfirstlane(*a.count) : a.n;
   int seq0 = blockIdx.x, spt = 1;                         // this tile's first sequence and how many it takes
   if (!SPT1) {
+    if ((int)blockIdx.x >= nvalid) return;                // a tile takes at least one sequence: no plan needed to know this one is empty
     SvddTilePlan pl = a.plan;
     if (a.auto_spt) pl = svdd_plan_tiles(nvalid, L, a.ncu, 9);
     svdd_plan_tile(pl, (int)blockIdx.x, seq0, spt);
@@ -1464,6 +1465,15 @@ __global__ __launch_bounds__(512, 2) void backbone_kernel(BackboneArgs a, Backbo
   }
   const int tile_rows = spt * L;
   if (seq0 >= nvalid) return;
+  // Short tiles (round 6): a tile of nt < 13 row tiles leaves some of a wave's 7 / 6 row-tile slots dead — and a dead slot still cost
+  // its fragment request, liveness test and wait in every (chunk, tap) entry, and its rows their LayerNorm passes (a 4-row-tile
+  // workgroup: 10 dead slots per entry, 0.73 pipe occupancy in the loop, 14 % of its time in LayerNorm code for rows that do not exist;
+  // profiles/r06_bb_small_tile_phases.txt). nro = the row-tile slots this wave really owns; the entry bodies come in three lengths
+  // (7 / 4 / 2 slots) and the LayerNorm passes skip the slots beyond nro. Same operations on every live row: same bits.
+  const int nt = SPT1 ? TW_RT : (tile_rows + 15) >> 4;
+  const int nro = SPT1 ? 7 : __builtin_amdgcn_readfirstlane((nt - rh + 1) >> 1);
+  const int body = SPT1 ? 7 : (nt <= 4 ? 2 : nt <= 8 ? 4 : 7);
+#define BB_OWN(R) (SPT1 || (R) < nro)
   const int nl = a.nl;
   const int it_end = (nl + 1) * 36;
   constexpr int NR = 7;                                   // owned row tiles rh + 2 r (r = 6 only for rh = 0)
@@ -1486,6 +1496,8 @@ __global__ __launch_bounds__(512, 2) void backbone_kernel(BackboneArgs a, Backbo
     rpos[e] = e < tile_rows ? pos : -(1 << 20);
   }
   for (int e = tid; e < BB_AP; e += 512) { smem[e] = 0.0f; img[TW_ROWS * BB_AP + e] = 0.0f; }
+  if (!SPT1)                                              // rows of the slots nobody owns: zero once, never written again (taps read them as padding)
+    for (int e = 16 * nt * BB_AP + tid; e < TW_ROWS * BB_AP; e += 512) img[e] = 0.0f;
   if (tid == 0) {
 #pragma unroll
     for (int i = 0; i < BB_MAXL; ++i) sdil[i] = a.dil[i];
@@ -1574,13 +1586,15 @@ __global__ __launch_bounds__(512, 2) void backbone_kernel(BackboneArgs a, Backbo
       const float tb0 = vl[BB_C + col0], tb1 = vl[BB_C + col0 + 16];
       // pass 1: row means (this lane's two values of a row first, then the 16 lanes of the DPP row)
 #pragma unroll
-      for (int r = 0; r < NR; ++r)
+      for (int r = 0; r < NR; ++r) {
+        if (!BB_OWN(r)) continue;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int row = 16 * (rh + 2 * r) + 4 * g + e;
           const float sm = group16_sum((f[r][0][e] + tb0) + (f[r][1][e] + tb1));
           if (j == 0 && row < TW_ROWS) psum[cg * TW_ROWS + row] = sm;
         }
+      }
       __syncthreads();
       if (tid < TW_ROWS)
         rstat[tid] = ((psum[tid] + psum[TW_ROWS + tid]) + (psum[2 * TW_ROWS + tid] + psum[3 * TW_ROWS + tid])) * (1.0f / BB_C);
@@ -1594,6 +1608,7 @@ __global__ __launch_bounds__(512, 2) void backbone_kernel(BackboneArgs a, Backbo
         const float4 cur4 = st4;
         if (r + 1 < NR) st4 = *reinterpret_cast<const float4*>(rstat + min(16 * (rh + 2 * r + 2) + 4 * g, TW_ROWS - 4));
         const float mean4[4] = {cur4.x, cur4.y, cur4.z, cur4.w};
+        if (!BB_OWN(r)) continue;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int row = 16 * (rh + 2 * r) + 4 * g + e;
@@ -1617,6 +1632,7 @@ __global__ __launch_bounds__(512, 2) void backbone_kernel(BackboneArgs a, Backbo
         const float4 cur4 = st4;
         if (r + 1 < NR) st4 = *reinterpret_cast<const float4*>(rstat + min(16 * (rh + 2 * r + 2) + 4 * g, TW_ROWS - 4));
         const float rs4[4] = {cur4.x, cur4.y, cur4.z, cur4.w};
+        if (!BB_OWN(r)) continue;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int row = 16 * (rh + 2 * r) + 4 * g + e;
@@ -1635,12 +1651,14 @@ __global__ __launch_bounds__(512, 2) void backbone_kernel(BackboneArgs a, Backbo
       if (SAVE && tid < TW_ROWS) sv.rstd[((size_t)blockIdx.x * nl + layer) * TW_ROWS + tid] = rstat[tid];
     } else {
 #pragma unroll
-      for (int r = 0; r < NR; ++r)
+      for (int r = 0; r < NR; ++r) {
+        if (!BB_OWN(r)) continue;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int row = 16 * (rh + 2 * r) + 4 * g + e;
           if (row < TW_ROWS) { img[row * BB_AP + col0] = f[r][0][e]; img[row * BB_AP + col0 + 16] = f[r][1][e]; }
         }
+      }
     }
     // ---- implicit GEMM over (chunk, live tap)
     const float bl0 = vl[col0], bl1 = vl[col0 + 16];
@@ -1726,6 +1744,45 @@ __global__ __launch_bounds__(512, 2) void backbone_kernel(BackboneArgs a, Backbo
       }                                                                                                      \
       it = nxt;                                                                                              \
       en = en2; }
+    // the same entry for a wave with at most FOUR / TWO owned row tiles (tiles of <= 8 / <= 4 row tiles): both waves of a SIMD take the
+    // same even number of slots, so the fragment sets keep their roles from entry to entry
+#define B2_ENTRY_HEAD(BC, BN)                                                                                \
+      const int nxt = en >> 19;                                                                              \
+      const int en_next_v = sched[nxt < it_end ? nxt : it];                                                  \
+      const float bf0[8] = {BC[0].x, BC[0].y, BC[0].z, BC[0].w, BC[1].x, BC[1].y, BC[1].z, BC[1].w};         \
+      const float bf1[8] = {BC[2].x, BC[2].y, BC[2].z, BC[2].w, BC[3].x, BC[3].y, BC[3].z, BC[3].w};         \
+      { const float* src = wsrc + (size_t)tile_of(nxt < it_end ? nxt : it) * BB_C * CH;                      \
+        BN[0] = *reinterpret_cast<const float4*>(src);                                                       \
+        BN[1] = *reinterpret_cast<const float4*>(src + 4);                                                   \
+        BN[2] = *reinterpret_cast<const float4*>(src + 16 * CH);                                             \
+        BN[3] = *reinterpret_cast<const float4*>(src + 16 * CH + 4);                                         \
+      }                                                                                                      \
+      B2_PARAMS(en, delta, coff, dbytes)                                                                     \
+      const int live = en >> rh;
+#define B2_ENTRY4(UA, UB, BC, BN)                                                                            \
+    { B2_ENTRY_HEAD(BC, BN)                                                                                  \
+      B2_MM(0, UA, 3)                                                                                        \
+      B2_ALOAD(2, UA, delta, coff, dbytes)                                                                   \
+      B2_MM(1, UB, 2)                                                                                        \
+      const int en2 = __builtin_amdgcn_readfirstlane(en_next_v);                                             \
+      B2_PARAMS(en2, delta2, coff2, dbytes2)                                                                 \
+      B2_ALOAD(3, UB, delta, coff, dbytes)                                                                   \
+      B2_MM(2, UA, 2)                                                                                        \
+      B2_ALOAD(0, UA, delta2, coff2, dbytes2)                                                                \
+      B2_MM(3, UB, 2)                                                                                        \
+      B2_ALOAD(1, UB, delta2, coff2, dbytes2)                                                                \
+      it = nxt;                                                                                              \
+      en = en2; }
+#define B2_ENTRY2(UA, UB, BC, BN)                                                                            \
+    { B2_ENTRY_HEAD(BC, BN)                                                                                  \
+      B2_MM(0, UA, 3)                                                                                        \
+      const int en2 = __builtin_amdgcn_readfirstlane(en_next_v);                                             \
+      B2_PARAMS(en2, delta2, coff2, dbytes2)                                                                 \
+      B2_ALOAD(0, UA, delta2, coff2, dbytes2)                                                                \
+      B2_MM(1, UB, 2)                                                                                        \
+      B2_ALOAD(1, UB, delta2, coff2, dbytes2)                                                                \
+      it = nxt;                                                                                              \
+      en = en2; }
     float4 ua[2], ub[2];
     if (it < layer_end) {
       B2_PARAMS(en, delta0, coff0, dbytes0)
@@ -1735,7 +1792,19 @@ __global__ __launch_bounds__(512, 2) void backbone_kernel(BackboneArgs a, Backbo
     // entries come in fours (the chunks of a tap), so a layer always ends on the second body and the sets keep their roles
     // from layer to layer; the odd exit is there for the bookkeeping only
     bool odd = false;
-    if (rh == 0) {
+    if (!SPT1 && body == 4) {
+      while (it < layer_end) {
+        B2_ENTRY4(ua, ub, bA, bB)
+        if (it >= layer_end) { odd = true; break; }
+        B2_ENTRY4(ua, ub, bB, bA)
+      }
+    } else if (!SPT1 && body == 2) {
+      while (it < layer_end) {
+        B2_ENTRY2(ua, ub, bA, bB)
+        if (it >= layer_end) { odd = true; break; }
+        B2_ENTRY2(ua, ub, bB, bA)
+      }
+    } else if (rh == 0) {
       while (it < layer_end) {
         B2_ENTRY(ua, ub, bA, bB)
         if (it >= layer_end) { odd = true; break; }
@@ -1750,6 +1819,9 @@ __global__ __launch_bounds__(512, 2) void backbone_kernel(BackboneArgs a, Backbo
     }
     if (odd) { bA[0] = bB[0]; bA[1] = bB[1]; bA[2] = bB[2]; bA[3] = bB[3]; }
 #undef B2_ENTRY
+#undef B2_ENTRY4
+#undef B2_ENTRY2
+#undef B2_ENTRY_HEAD
 #undef B2_PARAMS
 #undef B2_MM
 #undef B2_WAIT
@@ -1768,14 +1840,17 @@ __global__ __launch_bounds__(512, 2) void backbone_kernel(BackboneArgs a, Backbo
     }
     if (layer < nl) {
 #pragma unroll
-      for (int r = 0; r < NR; ++r)
+      for (int r = 0; r < NR; ++r) {
+        if (!BB_OWN(r)) continue;
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
           for (int e = 0; e < 4; ++e) f[r][ct][e] = fmaxf(acc[r][ct][e], 0.0f) + f[r][ct][e];   // relu(conv + b) + f
+      }
     } else {
 #pragma unroll
-      for (int r = 0; r < NR; ++r)
+      for (int r = 0; r < NR; ++r) {
+        if (!BB_OWN(r)) continue;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int row = 16 * (rh + 2 * r) + 4 * g + e;
@@ -1784,6 +1859,7 @@ __global__ __launch_bounds__(512, 2) void backbone_kernel(BackboneArgs a, Backbo
             img[row * BB_AP + col0 + 16] = fmaxf(acc[r][1][e], 0.0f);
           }
         }
+      }
     }
   }
   __syncthreads();
@@ -1801,6 +1877,7 @@ __global__ __launch_bounds__(512, 2) void backbone_kernel(BackboneArgs a, Backbo
     a.out[(sq * L + pos) * 5 + v] = sm;
   }
 }
+#undef BB_OWN
 
 // ------------------------------------------- gradient of the backbone with respect to its one-hot input, ONE launch (round 5) ----
 // The gradient-guidance baseline (DPS, reference diffusion_gosai.py:1321-1330 through models/dnaconv.py:212-247) needs

@@ -17,6 +17,15 @@
 #define SVDD_TILE_ROWS 208
 #endif
 
+// Cost of one tile of `rt` row tiles in HALF row tiles. Round 6: the fp32 kernel (fixed_half == 9) runs tiles of 5 .. 8 row tiles on
+// a four-slot entry body and skips the LayerNorm passes of slots nobody owns (backbone_kernel, "Short tiles"): measured 817 / 994 /
+// 1356 / 1667 us at 4 / 7 / 10 / 13 row tiles (L = 50) and 646 / 723 / 919 / 1164 / 1370 / 1559 us at 3 / 5 / 7 / 9 / 11 / 13 (L = 33), i.e.
+// ~95 us per row tile + a fixed part worth 4.5 row tiles on the 7-slot and the 2-slot bodies, ~3 on the 4-slot body.
+__host__ __device__ inline long long svdd_tile_cost(int rt, int fixed_half) {
+  const int fixed = (fixed_half == 9 && rt > 4 && rt <= 8) ? 6 : fixed_half;
+  return 2 * rt + fixed;
+}
+
 __host__ __device__ inline int svdd_choose_spt(int n, int L, int ncu, int fixed_half) {   // fixed_half: the fixed part in HALF row tiles
   const int smax = SVDD_TILE_ROWS / L;
   int best = smax;
@@ -24,7 +33,7 @@ __host__ __device__ inline int svdd_choose_spt(int n, int L, int ncu, int fixed_
   for (int s = smax; s >= 1; --s) {                   // ties: the fuller tile (fewer workgroups)
     const long long tiles = (n + s - 1) / s;
     const long long rounds = (tiles + ncu - 1) / ncu;
-    const long long cost = rounds * (2 * ((s * L + 15) / 16) + fixed_half);
+    const long long cost = rounds * svdd_tile_cost((s * L + 15) / 16, fixed_half);
     if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = s; }
   }
   return best;
@@ -43,10 +52,10 @@ __host__ __device__ inline SvddTilePlan svdd_plan_tiles(int n, int L, int ncu, i
   long long best_cost;
   {
     const long long tiles = (n + best.s2 - 1) / best.s2;
-    best_cost = ((tiles + ncu - 1) / ncu) * (2 * ((best.s2 * L + 15) / 16) + fixed_half);
+    best_cost = ((tiles + ncu - 1) / ncu) * svdd_tile_cost((best.s2 * L + 15) / 16, fixed_half);
   }
   for (int s1 = smax; s1 >= 1; --s1) {
-    const long long c1 = 2 * ((s1 * L + 15) / 16) + fixed_half;
+    const long long c1 = svdd_tile_cost((s1 * L + 15) / 16, fixed_half);
     const long long per_round = (long long)s1 * ncu;
     for (long long k = 1; k * per_round <= n; ++k) {
       const long long r = n - k * per_round;
@@ -56,7 +65,7 @@ __host__ __device__ inline SvddTilePlan svdd_plan_tiles(int n, int L, int ncu, i
       }
       for (int s2 = smax; s2 >= 1; --s2) {
         const long long tiles2 = (r + s2 - 1) / s2;
-        const long long cost = k * c1 + ((tiles2 + ncu - 1) / ncu) * (2 * ((s2 * L + 15) / 16) + fixed_half);
+        const long long cost = k * c1 + ((tiles2 + ncu - 1) / ncu) * svdd_tile_cost((s2 * L + 15) / 16, fixed_half);
         if (cost < best_cost) { best_cost = cost; best = {s1, (int)(k * ncu), s2}; }
       }
     }

@@ -504,11 +504,11 @@ int main() {
     int next = 0;
     for (int t = 0; t < tiles; ++t) { int s0, ns; svdd_plan_tile(p, t, s0, ns); if (s0 != next || ns < 1 || ns > 208 / L) return 2; next = s0 + ns; }
     if (next < n || next - n >= (p.n1 < tiles ? p.s2 : p.s1)) return 3;
-    auto cost1 = [&](int s) { long long tl = (n + s - 1) / s; return ((tl + ncu - 1) / ncu) * (2 * ((s * L + 15) / 16) + fixed); };
+    auto cost1 = [&](int s) { long long tl = (n + s - 1) / s; return ((tl + ncu - 1) / ncu) * svdd_tile_cost((s * L + 15) / 16, fixed); };
     const long long single = cost1(svdd_choose_spt(n, L, ncu, fixed));
     const long long r = n - (long long)p.n1 * p.s1;
-    long long mixed = (long long)(p.n1 / ncu) * (2 * ((p.s1 * L + 15) / 16) + fixed);
-    if (r > 0) { long long tl = (r + p.s2 - 1) / p.s2; mixed += ((tl + ncu - 1) / ncu) * (2 * ((p.s2 * L + 15) / 16) + fixed); }
+    long long mixed = (long long)(p.n1 / ncu) * svdd_tile_cost((p.s1 * L + 15) / 16, fixed);
+    if (r > 0) { long long tl = (r + p.s2 - 1) / p.s2; mixed += ((tl + ncu - 1) / ncu) * svdd_tile_cost((p.s2 * L + 15) / 16, fixed); }
     if (p.n1 % ncu) return 4;
     worse += mixed > single; better += mixed < single; ++cases;
   }
