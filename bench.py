@@ -413,7 +413,7 @@ def select_saturated(dev, L=200, M=10, B=1 << 18, iters=50, near_uniform=False):
     traffic, src = None, None
     if (B, L, M) == (1 << 18, 200, 10):
         traffic = (2 * 46138.3 + 52279.8) * 1024
-        src = ("profiles/r05_pmc_k2_raw.txt, row stride 200 (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+        src = ("profiles/r05_pmc_k2_raw.txt (round 5's passes; the kernel is unchanged), row stride 200 (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
                "tools/resample_microbench.py one 10 0, not measured in this run)")
     return {"bound": "hbm", "kernel": "select_rows_kernel (K2: softmax over M, argmax, index-gather compaction), saturated",
             "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5),
@@ -1239,7 +1239,7 @@ def main():
     bb_flops = conv_flops_fwd + 2.0 * B * L * (5 * H * 9 + H * H + H * 5)
     alt = {}
     pmc_lp, pmc_lp_src = {}, None                # HBM bytes per backbone_lp_kernel launch, from separate --pmc passes
-    for name in ("r05_pmc.json", "r04_pmc.json", "r03_pmc.json"):
+    for name in ("r06_pmc.json", "r05_pmc.json", "r04_pmc.json", "r03_pmc.json"):
         pth = os.path.join(ROOT, "profiles", name)
         if pmc_lp:
             break
@@ -1299,7 +1299,7 @@ def main():
         conv_ms = conv_total_ms / max(conv_launches, 1)
         conv_tf = (conv_flops_fwd / 20.0) / (conv_ms * 1e-3) / 1e12 if conv_launches else 0.0
         pmc, pmc_src = {}, None
-        for name in ("r05_pmc.json", "r04_pmc.json", "r03_pmc.json", "r02_pmc.json", "r01_pmc.json"):   # separate --pmc passes of this workload, see the file
+        for name in ("r06_pmc.json", "r05_pmc.json", "r04_pmc.json", "r03_pmc.json", "r02_pmc.json", "r01_pmc.json"):   # separate --pmc passes of this workload, see the file
             pmc_path = os.path.join(ROOT, "profiles", name)
             if os.path.exists(pmc_path) and (B, L, M) == (256, 200, 10):
                 pmc = json.load(open(pmc_path))

@@ -2,12 +2,12 @@
 # Collects the judged evidence of a round on the GPU box into gpurun_out/<tag>_*:
 #   bench JSON line, rocprofv3 --kernel-trace --stats summary of the same command, per-kernel trace summary of our
 #   kernels, and FETCH_SIZE / WRITE_SIZE PMC passes (separate runs, --kernel-trace only) for the roofline kernels.
-TAG=${1:-r05}
+TAG=${1:-r06}
 OUT=/root/repo/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 OURS="backbone_kernel backbone_lp_kernel backbone_lp_t_kernel conv_tower tower_lp gru_bidir gru_pc gru_lp value_tail tail_lp candidate_windows compact_flags propose_kernel select_kernel select_rows_kernel tds_cdf tds_gather transform advance_rows gather_rows x0hat epilogue_ln conv1d_cl"
-python3 /root/repo/bench.py --steps 3 --warmup 1 2>/dev/null | tail -1 > $OUT/${TAG}_bench.json
+python3 /root/repo/bench.py --steps 3 --warmup 1 --full-json $OUT/${TAG}_bench_full.json 2>/dev/null | tail -1 > $OUT/${TAG}_bench.json   # the compact line (what the driver parses) + the long record
 rm -rf /tmp/prof_$TAG
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o $TAG -- python3 /root/repo/bench.py --steps 2 --warmup 1 --cpu-steps 0 --c4-steps 0 --c3-steps 0 --c5-steps 0 --extra-legs 0 > /tmp/prof_$TAG.log 2>&1
 cp $(find /tmp/prof_$TAG -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_bench_kernel_stats.csv

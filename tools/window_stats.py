@@ -8,8 +8,8 @@ model, emb, head, _ = synthetic.build("dna", dev)
 model.rng_mode, model.philox_seed = "philox", 0
 stats = []
 orig = fused.candidate_windows
-def spy(cand, x, margin=fused.TOWER_WINDOW_MARGIN):
-    win = orig(cand, x, margin)
+def spy(cand, x, margin=fused.TOWER_WINDOW_MARGIN, flags=None):
+    win = orig(cand, x, margin, flags=flags)
     stats.append((float(((win[:, 1] - win[:, 0]) // 16).float().mean()) / 13, float((x == 4).float().mean()),
                   float((cand != x[:, None, :]).float().sum(2).mean())))
     return win
