@@ -1354,7 +1354,7 @@ int svdd_set_option(int key, int value) {
     if (value != 0 && !getenv("SVDD_EXPERIMENTS")) return SVDD_E_ARG;
     g_cand_ld = value; return SVDD_OK;
   }
-  if (key == SVDD_OPT_SELECT_BATCHES && (value == 0 || value == 1 || value == 2 || value == 4)) { g_select_batches = value; return SVDD_OK; }
+  if (key == SVDD_OPT_SELECT_BATCHES && value >= 0 && value <= 5) { g_select_batches = value; return SVDD_OK; }
   if (key == SVDD_OPT_TRUNK_PLANES_F32) { svdd_internal_set_trunk_planes_f32(value); return SVDD_OK; }
   if (key == SVDD_OPT_BACKBONE_SPLIT) { svdd_internal_set_bb_split(value); return SVDD_OK; }
   if (key == SVDD_OPT_BACKBONE_LP_VERSION) { svdd_internal_set_bb_lp_version(value); return SVDD_OK; }
@@ -1531,6 +1531,17 @@ int svdd_select_compact(const float* scores, const int32_t* slot, const float* p
       // parallelism, not on overlap inside a wave. Default: one batch per wave (round 5's launch).
       const int nb = R > 1 ? (g_select_batches == 2 ? 2 : g_select_batches == 4 ? 4 : 1) : 1;
       const dim3 gridb((unsigned)(((waves + nb - 1) / nb + 3) / 4));
+      if (R > 1 && (g_select_batches == 3 || g_select_batches == 5)) {
+        // the same experiment at an UNCHANGED wave count: the wave's 4 row groups as 2 batches of 2 (3) or 4 batches of 1 (5)
+        if (M == 10) {
+          if (g_select_batches == 3) hipExtLaunchKernelGGL((select_rows_kernel<16, 2, 10, 2>), grid, dim3(256), 0, (hipStream_t)stream, e0, e1, 0, a);
+          else hipExtLaunchKernelGGL((select_rows_kernel<16, 1, 10, 4>), grid, dim3(256), 0, (hipStream_t)stream, e0, e1, 0, a);
+        } else {
+          if (g_select_batches == 3) hipExtLaunchKernelGGL((select_rows_kernel<32, 2, 20, 2>), grid, dim3(256), 0, (hipStream_t)stream, e0, e1, 0, a);
+          else hipExtLaunchKernelGGL((select_rows_kernel<32, 1, 20, 4>), grid, dim3(256), 0, (hipStream_t)stream, e0, e1, 0, a);
+        }
+        return check_launch();
+      }
       if (M == 10) {
         if (nb == 4) hipExtLaunchKernelGGL((select_rows_kernel<16, 4, 10, 4>), gridb, dim3(256), 0, (hipStream_t)stream, e0, e1, 0, a);
         else if (nb == 2) hipExtLaunchKernelGGL((select_rows_kernel<16, 4, 10, 2>), gridb, dim3(256), 0, (hipStream_t)stream, e0, e1, 0, a);

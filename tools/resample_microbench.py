@@ -105,14 +105,15 @@ def k2_gather_split(B=1 << 18, M=10, L=200, scale=1e-2):
     gather()
     torch.cuda.synchronize()
     assert torch.equal(x2, x_next)
-    for nb in (1, 2, 4):                                   # SVDD_OPT_SELECT_BATCHES: batches of row groups per wave (1 = the default; 2 / 4: the round-6 experiment)
+    for nb in (1, 2, 4, 3, 5):                                   # SVDD_OPT_SELECT_BATCHES: batches of row groups per wave (1 = the default; 2 / 4: the round-6 experiment)
         _lib.set_option(8, nb)
         x_next.zero_()
         us = timed(fused)
         torch.cuda.synchronize()
         assert torch.equal(x_next, x2), f"batches {nb}: other tokens"
         nbytes = B * (4 * M + 2 * L + 4)
-        print(f"K2 split B={B} M={M} L={L} scores~{scale:g}  fused, {nb} batch(es) per wave{'':19s} {us:8.1f} us  {nbytes / us / 1e3:8.1f} GB/s  frac {nbytes / us / 1e3 / PEAK:.3f}")
+        what = {1: "1 batch of 4 row groups (shipped)", 2: "2 batches of 4 groups", 4: "4 batches of 4 groups", 3: "2 batches of 2 groups (same waves)", 5: "4 batches of 1 group (same waves)"}[nb]
+        print(f"K2 split B={B} M={M} L={L} scores~{scale:g}  fused, {what:36s} {us:8.1f} us  {nbytes / us / 1e3:8.1f} GB/s  frac {nbytes / us / 1e3 / PEAK:.3f}")
     _lib.set_option(8, 0)
     for name, fn, nbytes in (("fused select + gather (the shipped K2)", fused, B * (4 * M + 2 * L + 4)),
                              ("decision only (x_next = NULL)", decide, B * (4 * M + 4)),
