@@ -375,10 +375,11 @@ __global__ __launch_bounds__(256) void reward_tail_grad_kernel(const float* __re
                                                                const float* __restrict__ b1, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                const float* __restrict__ w_eff /*[128]*/, float eps, float inv_count,
                                                                float* __restrict__ g0, float* __restrict__ g1, int64_t rows) {
+  constexpr int RB = 4;                // rows per wave iteration: every weight read from LDS serves RB rows
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* w1kc = sm;                    // [128][64]
   float* w1ck = sm + 128 * 64;         // [64][128]
-  float* buf = w1ck + 64 * 128;        // per wave: hn [64] + dz [128]
+  float* buf = w1ck + 64 * 128;        // per wave: hn [RB][64] + dz [RB][128]
   for (int e = threadIdx.x; e < 128 * 64; e += 256) {
     const float v = w1[e];
     w1kc[e] = v;
@@ -386,35 +387,50 @@ __global__ __launch_bounds__(256) void reward_tail_grad_kernel(const float* __re
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  float* hn_s = buf + wv * 192;
-  float* dz_s = hn_s + 64;
+  float* hn_s = buf + wv * (RB * 192);
+  float* dz_s = hn_s + RB * 64;
   const float gm = gamma[lane], bt = beta[lane];
   const float b1a = b1[lane], b1b = b1[lane + 64], wea = w_eff[lane] * inv_count, web = w_eff[lane + 64] * inv_count;
   const int64_t nw = (int64_t)gridDim.x * 4;
-  for (int64_t r = (int64_t)blockIdx.x * 4 + wv; r < rows; r += nw) {
-    const float s = h0[r * 64 + lane] + h1[r * 64 + lane];
-    const float mean = wave_sum64(s) * (1.0f / 64);
-    const float d = s - mean;
-    const float rstd = rsqrtf(wave_sum64(d * d) * (1.0f / 64) + eps);
-    const float xh = d * rstd;
-    hn_s[lane] = xh * gm + bt;
-    float za = b1a, zb = b1b;                                  // z[lane], z[lane + 64]
-#pragma unroll 8
-    for (int c = 0; c < 64; ++c) {
-      const float hv = hn_s[c];                                // broadcast (same wave wrote it: no barrier needed across waves)
-      za += hv * w1ck[c * 128 + lane];
-      zb += hv * w1ck[c * 128 + 64 + lane];
+  for (int64_t r0 = ((int64_t)blockIdx.x * 4 + wv) * RB; r0 < rows; r0 += nw * RB) {
+    float xh[RB], rstd[RB];
+#pragma unroll
+    for (int q = 0; q < RB; ++q) {
+      const int64_t r = r0 + q < rows ? r0 + q : rows - 1;
+      const float s = h0[r * 64 + lane] + h1[r * 64 + lane];
+      const float mean = wave_sum64(s) * (1.0f / 64);
+      const float d = s - mean;
+      rstd[q] = rsqrtf(wave_sum64(d * d) * (1.0f / 64) + eps);
+      xh[q] = d * rstd[q];
+      hn_s[q * 64 + lane] = xh[q] * gm + bt;
     }
-    dz_s[lane] = za > 0.0f ? wea : 0.0f;
-    dz_s[lane + 64] = zb > 0.0f ? web : 0.0f;
-    float dh = 0.0f;
-#pragma unroll 8
-    for (int k = 0; k < 128; ++k) dh += dz_s[k] * w1kc[k * 64 + lane];
-    const float t = dh * gm;
-    const float m1 = wave_sum64(t) * (1.0f / 64), m2 = wave_sum64(t * xh) * (1.0f / 64);
-    const float ds = rstd * (t - m1 - xh * m2);
-    g0[r * 64 + lane] = ds;
-    g1[r * 64 + lane] = ds;
+    float za[RB], zb[RB];
+#pragma unroll
+    for (int q = 0; q < RB; ++q) { za[q] = b1a; zb[q] = b1b; }
+#pragma unroll 4
+    for (int c = 0; c < 64; ++c) {
+      const float wa = w1ck[c * 128 + lane], wb = w1ck[c * 128 + 64 + lane];
+#pragma unroll
+      for (int q = 0; q < RB; ++q) { const float hv = hn_s[q * 64 + c]; za[q] += hv * wa; zb[q] += hv * wb; }   // hv: a broadcast read
+    }
+#pragma unroll
+    for (int q = 0; q < RB; ++q) { dz_s[q * 128 + lane] = za[q] > 0.0f ? wea : 0.0f; dz_s[q * 128 + lane + 64] = zb[q] > 0.0f ? web : 0.0f; }
+    float dh[RB];
+#pragma unroll
+    for (int q = 0; q < RB; ++q) dh[q] = 0.0f;
+#pragma unroll 4
+    for (int k = 0; k < 128; ++k) {
+      const float wk = w1kc[k * 64 + lane];
+#pragma unroll
+      for (int q = 0; q < RB; ++q) dh[q] += dz_s[q * 128 + k] * wk;
+    }
+#pragma unroll
+    for (int q = 0; q < RB; ++q) {
+      const float t = dh[q] * gm;
+      const float m1 = wave_sum64(t) * (1.0f / 64), m2 = wave_sum64(t * xh[q]) * (1.0f / 64);
+      const float ds = rstd[q] * (t - m1 - xh[q] * m2);
+      if (r0 + q < rows) { g0[(r0 + q) * 64 + lane] = ds; g1[(r0 + q) * 64 + lane] = ds; }
+    }
   }
 }
 
@@ -729,7 +745,7 @@ int svdd_gru_bidir_bwd_f32(const float* grad_out, const float* out, const float*
 int svdd_reward_stem_f32(const float* x, const float* w, const float* b, float* out, int n, int L, int taps, void* stream) {
   if (!x || !w || !b || !out || n <= 0 || L <= 0 || taps != 15) return SVDD_E_ARG;
   const int64_t rows = (int64_t)n * L;
-  const unsigned grid = (unsigned)((rows + 3) / 4 < 2048 ? (rows + 3) / 4 : 2048);
+  const unsigned grid = (unsigned)((rows + 3) / 4 < 4096 ? (rows + 3) / 4 : 4096);   // latency-bound per position: many short-lived waves beat few long-lived ones (512 workgroups: 49 -> 69 us)
   hipEvent_t e0, e1;
   svdd_internal_timed_events(5, &e0, &e1);
   hipExtLaunchKernelGGL(reward_stem_fwd_kernel<15>, dim3(grid), dim3(256), 0, (hipStream_t)stream, e0, e1, 0, x, w, b, out, rows, L);
@@ -739,7 +755,7 @@ int svdd_reward_stem_f32(const float* x, const float* w, const float* b, float* 
 int svdd_reward_stem_bwd_f32(const float* g, const float* w, float* dx, int n, int L, int taps, void* stream) {
   if (!g || !w || !dx || n <= 0 || L <= 0 || taps != 15) return SVDD_E_ARG;
   const int64_t rows = (int64_t)n * L;
-  const unsigned grid = (unsigned)((rows + 3) / 4 < 2048 ? (rows + 3) / 4 : 2048);
+  const unsigned grid = (unsigned)((rows + 3) / 4 < 4096 ? (rows + 3) / 4 : 4096);
   hipEvent_t e0, e1;
   svdd_internal_timed_events(5, &e0, &e1);
   hipExtLaunchKernelGGL(reward_stem_bwd_kernel<15>, dim3(grid), dim3(256), 0, (hipStream_t)stream, e0, e1, 0, g, w, dx, rows, L);
@@ -759,9 +775,9 @@ int svdd_reward_tail_grad_f32(const float* h_fwd, const float* h_bwd, const floa
                               const float* beta, const float* w_eff, float eps, int n, int L, float* g_fwd, float* g_bwd, void* stream) {
   if (!h_fwd || !h_bwd || !w1 || !b1 || !gamma || !beta || !w_eff || !g_fwd || !g_bwd || n <= 0 || L <= 0) return SVDD_E_ARG;
   const int64_t rows = (int64_t)n * L;
-  const size_t lds = sizeof(float) * (2 * 128 * 64 + 4 * 192);
+  const size_t lds = sizeof(float) * (2 * 128 * 64 + 4 * 4 * 192);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(reward_tail_grad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  const unsigned grid = (unsigned)((rows + 3) / 4 < 1024 ? (rows + 3) / 4 : 1024);
+  const unsigned grid = (unsigned)((rows + 15) / 16 < 512 ? (rows + 15) / 16 : 512);   // 4 waves x 4 rows per iteration; 2 workgroups per CU (76 KB of LDS each)
   hipEvent_t e0, e1;
   svdd_internal_timed_events(7, &e0, &e1);
   hipExtLaunchKernelGGL(reward_tail_grad_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, e0, e1, 0, h_fwd, h_bwd, w1, b1, gamma, beta,
@@ -776,7 +792,7 @@ int svdd_gru_bidir_train2_f32(const float* x, const float* wpack, const float* b
   const int64_t tiles = (rows + 15) / 16;
   hipEvent_t e0, e1;
   svdd_internal_timed_events(11, &e0, &e1);                          // one timed span over both launches
-  hipExtLaunchKernelGGL(gru_xproj_kernel, dim3((unsigned)(tiles < 2048 ? tiles : 2048), 2), dim3(256), 0, (hipStream_t)stream, e0, nullptr, 0,
+  hipExtLaunchKernelGGL(gru_xproj_kernel, dim3((unsigned)(tiles < 512 ? tiles : 512), 2), dim3(256), 0, (hipStream_t)stream, e0, nullptr, 0,
                         x, wpack, bpack, gi, rows);
   if (hipGetLastError() != hipSuccess) return SVDD_E_LAUNCH;
   hipExtLaunchKernelGGL(gru_train_fwd2_kernel, dim3(2 * (unsigned)((n + TS - 1) / TS)), dim3(256), 0, (hipStream_t)stream, nullptr, e1, 0,
@@ -794,7 +810,7 @@ int svdd_gru_bidir_bwd2_f32(const float* grad_out, const float* out, const float
   if (hipGetLastError() != hipSuccess) return SVDD_E_LAUNCH;
   const int64_t rows = (int64_t)n * L;
   const int64_t tiles = (rows + 15) / 16;
-  hipExtLaunchKernelGGL(gru_dx_gate_kernel, dim3((unsigned)(tiles < 2048 ? tiles : 2048)), dim3(256), 0, (hipStream_t)stream, nullptr, e1, 0,
+  hipExtLaunchKernelGGL(gru_dx_gate_kernel, dim3((unsigned)(tiles < 1024 ? tiles : 1024)), dim3(256), 0, (hipStream_t)stream, nullptr, e1, 0,
                         (const float*)da, wpack_bwd, gate, g, rows);
   return hipGetLastError() == hipSuccess ? SVDD_OK : SVDD_E_LAUNCH;
 }
