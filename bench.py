@@ -1369,8 +1369,9 @@ def main():
             line["roofline_select_saturated"] = [select_saturated(dev, L=L, M=M, near_uniform=True), select_saturated(dev, L=L, M=M),
                                                  select_saturated(dev, L=L, M=20)]
             legs.mark("saturated")
-            if args.extra_legs:
+            if args.extra_legs in (1, 2):
                 line["replay_rng"] = replay_leg(model, emb, head, B, L, M, S)
+            if args.extra_legs in (1, 3):
                 line["config1_b4"] = small_batch_leg(model, emb, head, L, S)
             legs.mark("replay_c1" if args.extra_legs else "saturated")
             line["roofline_tds_resample"] = tds_saturated(dev, L=L)

@@ -106,6 +106,43 @@ def subs_logp(logits, x, layout=BLV):
     return out
 
 
+# ---- DPS (gradient guidance), the per-position arithmetic around the two net passes (reference diffusion_gosai.py:1306-1314, 1321-1330):
+# numpy restatement of what svdd_dps_probs / svdd_dps_probs_bwd / svdd_dps_guided_q compute (K9). Pinned on the CPU against the
+# reference's recorded guided q_xs (g11: its own controlled_sample_DPS run) and against torch autograd of the reference's expressions
+# (tests/test_oracle_golden.py); the kernels are checked against THIS on the GPU (tests/test_kernels_gpu.py).
+def _dps_expected_probs(logits, x):
+    """log p(x0 | x_t) (SUBS, :286-304), E = copy * onehot(x) + (1 - copy) * log p (:1325), softmax(E, dim=2) (:1326) — all [B, L, 5]."""
+    lp = subs_logp(logits, x).astype(np.float32)
+    keep = (np.asarray(x) != MASK)[..., None]
+    onehot = np.eye(5, dtype=np.float32)[np.asarray(x, dtype=np.int64)]
+    E = np.where(keep, onehot, lp).astype(np.float32)
+    e = np.exp(E - E.max(axis=2, keepdims=True), dtype=np.float32)
+    return lp, keep, (e / e.sum(axis=2, keepdims=True, dtype=np.float32)).astype(np.float32)
+
+
+def dps_probs(logits, x):
+    """-> softmax(E)[..., 0:4] fp32 [B, L, 4]: the reward model's input (:1327, before its transpose)."""
+    return np.ascontiguousarray(_dps_expected_probs(logits, x)[2][..., :4])
+
+
+def dps_probs_bwd(logits, x, dprobs4):
+    """d loss / d probs4 -> (d loss / d logits through forward2's SUBS — zero at unmasked positions —, the direct term copy * dE)."""
+    lp, keep, pr = _dps_expected_probs(logits, x)
+    dp = np.concatenate([np.asarray(dprobs4, np.float32), np.zeros(pr.shape[:2] + (1,), np.float32)], axis=2)
+    dE = pr * (dp - (pr * dp).sum(axis=2, keepdims=True, dtype=np.float32))              # softmax backward
+    dlogits = np.where(keep, 0.0, dE - np.exp(lp, dtype=np.float32) * dE.sum(axis=2, keepdims=True, dtype=np.float32))
+    return dlogits.astype(np.float32), np.where(keep, dE, 0.0).astype(np.float32)
+
+
+def dps_guided_q(logits, x, x_grad, dm, mcs, scale):
+    """q_xs = exp(log p) * (mct - mcs) ; q_xs[MASK] = mcs ; q_xs * exp(scale * (x_grad - x_grad[MASK]))   (:1306-1314) -> fp32 [B, L, 5]."""
+    lp = subs_logp(logits, x).astype(np.float32)
+    q = (np.exp(lp, dtype=np.float32) * np.float32(dm)).astype(np.float32)
+    q[..., MASK] = np.float32(mcs)
+    g = np.asarray(x_grad, np.float32)
+    return (q * np.exp(np.float32(scale) * (g - g[..., MASK:MASK + 1]), dtype=np.float32)).astype(np.float32)
+
+
 def sample_categorical(q, u):
     q = _f32(q); u = _f32(u)
     tok = np.empty(q.shape[:-1], dtype=np.uint8)

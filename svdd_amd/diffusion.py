@@ -1046,7 +1046,7 @@ class Diffusion(nn.Module):
         # tile): same bits (tests/test_skip_gpu.py).
         n_a = self._pm_split_rows(fb, rf, n, L)
         if n_a:
-            side, ev_a, ev_done = torch.cuda.Stream(device=dev), torch.cuda.Event(), torch.cuda.Event()
+            side, ev_a, ev_done = ops.side_stream(dev, 0), torch.cuda.Event(), torch.cuda.Event()
             sc_buf = torch.empty((n, rf.w_eff.shape[1]), dtype=torch.float32, device=dev)
             c_a, c_b = ws.count3[1:2], ws.count3[2:3]
             cand_rows = cand.view(n, L)

@@ -959,7 +959,8 @@ class FusedValueNet(nn.Module):
         sb = cache.get(key)
         if sb is None:
             cache.clear()
-            sb = cache[key] = dict(n=n, L=L, side=torch.cuda.Stream(device=dev), ev_b=torch.cuda.Event(), ev_done=torch.cuda.Event(),
+            from . import ops
+            sb = cache[key] = dict(n=n, L=L, side=ops.side_stream(dev, 0), ev_b=torch.cuda.Event(), ev_done=torch.cuda.Event(),
                                    seq=torch.empty((n, L, 64), device=dev), h_a=torch.empty((2, split, L, 64), device=dev),
                                    h_b=torch.empty((2, n - split, L, 64), device=dev), sc=torch.empty((n, self.w_eff.shape[1]), device=dev))
         ws.split_bufs = sb

@@ -32,8 +32,8 @@ from .value_nets import ConvHead
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 GUARD = 4            # operand-plane rows in front of row 0 (a k = 5 tap reads rows -2 .. of the first tile)
 TAIL = 136           # ... and behind the last row (the last 128-row tile + 2 tap rows)
-_SIDE_STREAMS = {}   # device index -> the side streams of forward_tokens (made once per process: HIP maps streams onto a handful
-                     # of hardware queues, and a second instance with streams of its own ran 20 % slower than with one chain)
+# (side streams: ops.side_stream — process-wide and probed; a second instance with streams of its own once ran 20 % slower than one
+#  chain, and round 6 found why: HIP has four hardware queues and streams that share one do not overlap)
 WIN_K = 4            # window slots per candidate and level of the shared levels (svdd_trunk.hip)
 
 
@@ -497,10 +497,8 @@ class FusedEnformerValueNet(nn.Module):
                         b[_Planes.FRONT - 2 * 4096: _Planes.FRONT].zero_()  # the rows in front of this part's first sequence
                 wss.append(w)
             main = torch.cuda.current_stream()
-            key = torch.device(dev).index or 0
-            while len(_SIDE_STREAMS.setdefault(key, [])) < S:     # shared by every instance: a process has few hardware queues
-                _SIDE_STREAMS[key].append(torch.cuda.Stream(device=dev))
-            self._side = _SIDE_STREAMS[key]
+            from . import ops
+            self._side = [ops.side_stream(dev, k) for k in range(S)]   # process-wide, chosen so that any two run concurrently (ops.side_stream)
             stats = []
             for k in range(S):
                 sd = self._side[k]

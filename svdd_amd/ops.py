@@ -327,6 +327,64 @@ def mt_state_to_torch(words_pos, template_u8):
 _REPLAY_SIDE_STREAMS = {}
 
 
+# ---- side streams, process-wide -----------------------------------------------------------------------------------------------
+# Every component that runs parts of a step concurrently (the C4 trunk's two chains, the late steps' second GRU part, the SVDD-PM
+# two-part step, the device replay generator) takes its side streams from ONE list per device, for the life of the process.
+# Why a list and a test (round 6, tools/c4_stream_probe.py, profiles/r06_c4_stream_probe.txt): HIP maps streams onto FOUR hardware
+# queues, in the order in which they are first used, and two streams on one hardware queue do not run concurrently — nor does a side
+# stream that shares the queue of the stream the decode itself runs on. Which queue a stream got used to depend on how many streams
+# anything in the process had touched before: the C4 trunk's two chains measured 65 instead of 80 seq/s whenever 4 k other streams
+# had been used first, and bench.py's C4 leg lost 20 % in round 6 when an earlier leg stopped creating a stream per decode.
+# side_stream() therefore PROBES its candidates once: a candidate is kept only if a marker on it is not held up by a sleeping kernel
+# on the current stream, nor by one on a candidate already kept (same hardware queue = in-order = the marker waits). ~10 ms, once.
+_SIDE_STREAMS = {}
+SIDE_SLOTS = 3                                        # three other hardware queues exist beside the main stream's
+SIDE_TRUNK_A, SIDE_TRUNK_B, SIDE_REPLAY = 0, 1, 2     # who uses which slot (the split GRU / PM paths share slot 0)
+
+
+def _held_up_by(busy, cand, ms=0.4):
+    """True when a marker on stream `cand` has to wait for a sleeping kernel on stream `busy` (they share a hardware queue)."""
+    e0, e1, ec = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    torch.cuda.synchronize()
+    e0.record(busy)
+    with torch.cuda.stream(busy):
+        torch.cuda._sleep(int(ms * 2.0e6))            # ~ms at 2 GHz
+    e1.record(busy)
+    ec.record(cand)
+    torch.cuda.synchronize()
+    return e0.elapsed_time(ec) > 0.5 * e0.elapsed_time(e1)
+
+
+def _probe_side_streams(dev, want):
+    import os
+    cur = torch.cuda.current_stream(dev)
+    kept, tried = [], 0
+    probe = os.environ.get("SVDD_SIDE_STREAM_PROBE", "1") != "0" and not torch.cuda.is_current_stream_capturing()
+    while len(kept) < want and tried < 12:
+        st = torch.cuda.Stream(device=dev)
+        tried += 1
+        with torch.cuda.stream(st):
+            torch.zeros(1, device=dev)                # first use: this is when HIP binds the stream to a hardware queue
+        try:
+            if probe and (_held_up_by(cur, st) or any(_held_up_by(k, st) for k in kept)):
+                continue
+        except Exception:                             # noqa: BLE001  (no _sleep in this build, ...): take the streams as they come
+            probe = False
+        kept.append(st)
+    while len(kept) < want:                           # fewer free hardware queues than slots: the remaining slots share
+        kept.append(kept[len(kept) % max(len(kept), 1)] if kept else torch.cuda.Stream(device=dev))
+    return kept
+
+
+def side_stream(device, slot=0):
+    """The `slot`-th side stream of `device` (slots 0 .. SIDE_SLOTS - 1; made and probed at the first call, never destroyed)."""
+    dev = torch.device(device)
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = _probe_side_streams(torch.device("cuda", key), SIDE_SLOTS)
+    return _SIDE_STREAMS[key][slot % SIDE_SLOTS]
+
+
 class DeviceReplayStream:
     """torch's global CPU generator continued ON THE DEVICE for the span of one decode (rng_mode = "replay"): the state
     (2.5 KB) is uploaded at open(), `uniforms(n)` returns the next n floats of the stream as a device tensor (K8
@@ -344,9 +402,7 @@ class DeviceReplayStream:
         st = mt_state_from_torch(self.template)
         self.state = torch.from_numpy(st.astype(np.uint32).view(np.int32).copy()).to(self.dev)          # [625] u32 bits
         key = self.dev.index if self.dev.index is not None else torch.cuda.current_device()
-        if key not in _REPLAY_SIDE_STREAMS:        # one side stream per device for the life of the process (a decode opens one of
-            _REPLAY_SIDE_STREAMS[key] = torch.cuda.Stream(device=self.dev)   # these objects per sampler call; HIP has few hardware queues)
-        self.side = _REPLAY_SIDE_STREAMS[key]
+        self.side = side_stream(self.dev, SIDE_REPLAY)      # one side stream per device for the life of the process
         self.side.wait_stream(torch.cuda.current_stream(self.dev))
         self.bufs = {}            # n -> [two device buffers]
         self.flip = 0

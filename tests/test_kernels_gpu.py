@@ -585,3 +585,30 @@ def test_mt19937_device_stream_g9_and_state_write_back(ops, golden):
     torch.manual_seed(123)
     ref = torch.rand(5010)
     assert torch.equal(a.cpu(), ref[:5000]) and torch.equal(after, ref[5000:])
+
+
+@pytest.mark.parametrize("B,L", [(3, 50), (16, 200), (257, 200)])
+def test_dps_kernels_vs_oracle(ops, B, L):
+    """K9 (svdd_dps_probs / _probs_bwd / _guided_q: the per-position arithmetic of a DPS step, reference diffusion_gosai.py:1306-1314,
+    1321-1330) against the numpy oracle, which the CPU suite pins to the reference's g11 run and to autograd of the reference's
+    expressions. fp32 tolerance: exp / log differ in the last ulps (the kernels: ocml, the oracle: numpy)."""
+    from oracle import svdd_oracle as orc
+    rng = np.random.default_rng(B + L)
+    logits = (rng.standard_normal((B, L, 5)) * 2).astype(np.float32)
+    x = rng.integers(0, 5, (B, L)).astype(np.uint8)
+    x[0] = 4
+    if B > 1:
+        x[1] = rng.integers(0, 4, L)
+    tl, tx = torch.from_numpy(logits).cuda(), torch.from_numpy(x).cuda()
+    p = ops.dps_probs(tl, tx)
+    assert np.allclose(p.cpu().numpy(), orc.dps_probs(logits, x), rtol=2e-6, atol=1e-7)
+    dp = (rng.standard_normal((B, L, 4)) * 1e-3).astype(np.float32)
+    dl, dr = ops.dps_probs_bwd(tl, tx, torch.from_numpy(dp).cuda())
+    wl, wr = orc.dps_probs_bwd(logits, x, dp)
+    assert np.allclose(dl.cpu().numpy(), wl, rtol=1e-5, atol=1e-9) and np.allclose(dr.cpu().numpy(), wr, rtol=1e-5, atol=1e-9)
+    assert float(dl[tx != 4].abs().max()) == 0.0 and float(dr[tx == 4].abs().max()) == 0.0      # each position feeds exactly one of the two paths
+    ga, gb = (rng.standard_normal((B, L, 5)) * 1e-4).astype(np.float32), (rng.standard_normal((B, L, 5)) * 1e-4).astype(np.float32)
+    for scale in (0.0, 300.0):
+        q = ops.dps_guided_q(tl, tx, torch.from_numpy(ga).cuda(), torch.from_numpy(gb).cuda(), 0.0078, 0.31, scale)
+        assert np.allclose(q.cpu().numpy(), orc.dps_guided_q(logits, x, ga + gb, 0.0078, 0.31, scale), rtol=2e-6, atol=1e-12)
+    assert float(q[..., 4].min()) > 0 and torch.isfinite(q).all()

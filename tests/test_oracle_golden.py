@@ -262,3 +262,48 @@ def test_select_matches_torch_softmax_argmax_up_to_M20(M, kind):
     tp = torch.softmax(torch.from_numpy(s), dim=1)
     assert np.array_equal(idx, tp.argmax(dim=1).numpy())
     assert np.abs(soft - tp.numpy()).max() <= 1e-6
+
+
+def test_oracle_dps_arithmetic_pinned_by_g11_and_autograd(golden):
+    """oracle.dps_probs / dps_probs_bwd / dps_guided_q (numpy restatement of reference diffusion_gosai.py:1306-1314, 1321-1330, the
+    checker of kernels K9) against (a) the reference's recorded guided q_xs of its own controlled_sample_DPS run — g11: logits from the
+    tiny backbone mirror (pinned against the reference's outputs elsewhere), the reference's recorded x_grad in, its q out — and (b)
+    torch autograd of the reference's expressions on random inputs."""
+    import torch
+    from oracle import svdd_oracle as orc
+    from svdd_amd import noise_schedule
+    from svdd_amd.config import Config, ModelConfig
+    from svdd_amd.diffusion import Diffusion
+    from tests.test_nets_cpu import tiny_nets
+    g = golden("g11_traj_dps.npz")
+    bb, _, _ = tiny_nets(golden("nets_tiny.npz"))
+    S, L, scale = int(g["S"]), int(g["L"]), float(g["scale"])
+    d = Diffusion(Config(model=ModelConfig(hidden_dim=16, num_cnn_stacks=1, length=L)), backbone=bb).eval()
+    sched = d._schedule(S, 1e-5)[0]
+    for i in range(S):
+        x = g["xs"][i]
+        with torch.no_grad():
+            logits = bb(torch.from_numpy(x.astype(np.int64)), torch.zeros(x.shape[0])).contiguous().numpy()
+        q = orc.dps_guided_q(logits, x, g["grad"][i], sched[i, 2], sched[i, 1], scale)
+        ref = g["q"][i] if not int(g["q_is_bvl"]) else np.ascontiguousarray(g["q"][i])
+        assert np.allclose(q, ref, rtol=2e-5, atol=1e-9), (i, np.abs(q - ref).max())
+    # (b) the reference's expressions under autograd (:1325-1327 after forward2's SUBS, :359-377)
+    rng = np.random.default_rng(3)
+    logits = rng.standard_normal((3, 40, 5)).astype(np.float32) * 2
+    x = rng.integers(0, 5, (3, 40)).astype(np.uint8)
+    x[0] = 4
+    tl = torch.from_numpy(logits).requires_grad_(True)
+    xt = torch.from_numpy(x.astype(np.int64))
+    oh = torch.nn.functional.one_hot(xt, 5).float().requires_grad_(True)
+    z = tl + torch.tensor([0, 0, 0, 0, -1000000.0])
+    lp = z - torch.logsumexp(z, dim=-1, keepdim=True)
+    fixed = torch.full_like(lp, -1000000.0).scatter(-1, xt.clamp(max=4)[..., None], 0.0)
+    lp = torch.where((xt != 4)[..., None], fixed, lp)
+    keep = (xt != 4).float()[..., None]
+    probs = torch.softmax(keep * oh + (1 - keep) * lp, dim=2)
+    assert np.allclose(orc.dps_probs(logits, x), probs[..., :4].detach().numpy(), rtol=1e-6, atol=1e-7)
+    w = torch.from_numpy(rng.standard_normal((3, 40, 4)).astype(np.float32))
+    (probs[..., :4] * w).sum().backward()
+    dlogits, direct = orc.dps_probs_bwd(logits, x, w.numpy())
+    assert np.allclose(dlogits, tl.grad.numpy(), rtol=1e-5, atol=1e-7)
+    assert np.allclose(direct, (keep * oh.grad).numpy(), rtol=1e-5, atol=1e-7)
