@@ -324,7 +324,7 @@ def mt_state_to_torch(words_pos, template_u8):
     return torch.from_numpy(a)
 
 
-_REPLAY_SIDE_STREAMS = {}
+
 
 
 # ---- side streams, process-wide -----------------------------------------------------------------------------------------------
