@@ -181,7 +181,9 @@ class Diffusion(nn.Module):
         self.fuse_nets = True
         self.precision = "f32"
         self.skip_unchanged = True
-        self.late_steps_from = 0.8       # from this fraction of the steps on, FusedValueNet may run the live candidates as two parts (split_gru_rounds)
+        self.late_steps_from = "auto"    # when FusedValueNet may run the live candidates as two parts (split_gru_rounds): "auto" = when the LAST
+                                         # step's live count (read back asynchronously, never waited for) came within 3 % of one GRU round;
+                                         # a number = from that fraction of the steps on (rounds 4-5: 0.8, tuned to the random-init benchmark)
         self.dedup_prior = True          # the prior's rows are identical (all MASK): its net evaluations run on ONE row (exact; see _prior_logits)
         self.pm_two_part = False         # SVDD-PM skipping loop: the live candidates as whole backbone rounds + remainder, the first part's reward net under the remainder (_pm_split_rows)
         self.dps_fused = True            # DPS: the whole step on hand-written kernels, no autograd (_dps_fused_nets); False: round 5's autograd path between the same big kernels
@@ -958,6 +960,14 @@ class Diffusion(nn.Module):
         share = hasattr(fn, "candidates_ok") and fn.candidates_ok(L, M)
         toks_c = None if share else torch.empty((B * M, L), dtype=torch.uint8, device=self.device)
         logits = None
+        # the two-part late steps adapt to the decode in hand: the live count of a step is copied to pinned host memory without
+        # waiting; a later step looks at the newest count that has arrived (a trained value net, another M or L, another chip change
+        # when the live candidates outgrow one GRU round — the fixed "last 20 % of the steps" of rounds 4-5 fitted random-init nets)
+        auto_late = share and self.late_steps_from == "auto" and not _capturing() and hasattr(fn, "gru_round_rows")
+        if auto_late:
+            live_host = torch.empty(1, dtype=torch.int32).pin_memory()
+            live_ev, live_pending, live_last = torch.cuda.Event(), False, 0
+            late_thr = 0.97 * fn.gru_round_rows()
         for i in range(S):
             if fb is None or logits is None:
                 logits = self._prior_logits(x) if i == 0 else self._backbone_logits(x)
@@ -966,8 +976,18 @@ class Diffusion(nn.Module):
                 fb.forward_rows(x, count=ws.row_count, out=logits, row_idx=ws.row_idx, scatter=True)
             ops.propose(logits, x, sched[i, 2], sched[i, 1], M, self._rng(i, M, B, L, logits), cand=cand, onehot=onehot)
             if share:
-                ws.late = i >= int(self.late_steps_from * S)                 # late steps: (almost) every candidate is live
+                if auto_late:
+                    if live_pending and live_ev.query():
+                        live_last, live_pending = int(live_host[0]), False
+                    ws.late = live_last > late_thr
+                else:
+                    frac = 0.8 if self.late_steps_from == "auto" else float(self.late_steps_from)
+                    ws.late = i >= int(frac * S)                             # late steps: (almost) every candidate is live
                 sc = fn.candidate_scores_compact(onehot, cand, x, ws).reshape(-1)
+                if auto_late and not live_pending:
+                    live_host.copy_(ws.count, non_blocking=True)
+                    live_ev.record()
+                    live_pending = True
             else:
                 candidate_windows(cand, x, margin=0, flags=ws.flags)
                 ops.compact_flags(ws.flags, ws.live_idx, ws.slot, ws.count)

@@ -355,14 +355,15 @@ def test_mc_decode_two_part_value_net_is_bit_identical():
     model.rng_mode, model.philox_seed = "philox", 3
     fn = model.value_callable(emb, head)
     outs = []
-    for on, frm in ((True, 0.0), (True, 0.8), (False, 0.8)):
+    # ("auto", round 6: two parts whenever the last step's live count — read back asynchronously — came within 3 % of one GRU round)
+    for on, frm in ((True, 0.0), (True, "auto"), (False, 0.8)):
         fn.split_gru_rounds, model.late_steps_from = on, frm
         model.trace, model.skip_stats = [], {}
         x0 = model.controlled_sample(emb, head, num_steps=128, eval_sp_size=256, sample_M=10)
         torch.cuda.synchronize()
         outs.append((x0, [sc for _, sc in model.trace if sc is not None], dict(model.skip_stats)))
         model.trace, model.skip_stats = None, None
-    fn.split_gru_rounds, model.late_steps_from = True, 0.8
+    fn.split_gru_rounds, model.late_steps_from = True, "auto"
     for o in outs[:2]:
         assert torch.equal(o[0], outs[2][0])
         assert len(o[1]) == len(outs[2][1]) == 128

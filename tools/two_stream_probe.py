@@ -17,6 +17,8 @@ model.rng_mode, model.philox_seed, model.precision = "philox", 5, precision
 B, L, M, S = 256, 200, 10, 128
 sched = model._schedule(S, 1e-5)[0]
 fn = model.value_callable(emb, head)
+from svdd_amd import _lib
+_lib.set_option(7, 1)        # halves of 128 rows would each take the small-batch backbone (2 workgroups per sequence that wait for each other): not with two launches in flight
 
 
 def half_decode(rows, row0):
@@ -38,7 +40,7 @@ def half_decode(rows, row0):
 
 
 def split_decode():
-    streams = [torch.cuda.Stream() for _ in range(nsplit)]
+    streams = [ops.side_stream(dev, k) for k in range(nsplit)]      # probed: on hardware queues of their own (round 6)
     rows = B // nsplit
     gens = []
     for k, st in enumerate(streams):
