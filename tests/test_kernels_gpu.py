@@ -612,3 +612,22 @@ def test_dps_kernels_vs_oracle(ops, B, L):
         q = ops.dps_guided_q(tl, tx, torch.from_numpy(ga).cuda(), torch.from_numpy(gb).cuda(), 0.0078, 0.31, scale)
         assert np.allclose(q.cpu().numpy(), orc.dps_guided_q(logits, x, ga + gb, 0.0078, 0.31, scale), rtol=2e-6, atol=1e-12)
     assert float(q[..., 4].min()) > 0 and torch.isfinite(q).all()
+
+
+def test_side_streams_sit_on_hardware_queues_of_their_own():
+    """ops.side_stream (round 6): the engine's three side streams per device are chosen so that a marker on any of them is not held up
+    by a sleeping kernel on the current stream nor on another side stream — HIP has four hardware queues, and streams that share one
+    run in order (the C4 trunk's two chains lost 20 % on such a pair, profiles/r06_c4_stream_probe.txt). Also: the list is process-wide
+    (the same objects on every call) and a stream that IS on the current stream's queue is recognised as such."""
+    from svdd_amd import ops as o
+    dev = torch.device("cuda", 0)
+    s = [o.side_stream(dev, k) for k in range(o.SIDE_SLOTS)]
+    assert [o.side_stream(dev, k) for k in range(o.SIDE_SLOTS)] == s and o.side_stream(dev, o.SIDE_SLOTS) == s[0]
+    cur = torch.cuda.current_stream(dev)
+    assert len({x.cuda_stream for x in s}) == o.SIDE_SLOTS and cur.cuda_stream not in {x.cuda_stream for x in s}
+    for a in s:
+        assert not o._held_up_by(cur, a)
+        for b in s:
+            if a is not b:
+                assert not o._held_up_by(a, b)
+    assert o._held_up_by(cur, cur)                      # the test itself sees a shared queue when there is one
