@@ -703,3 +703,61 @@ def test_gru_pair_off_the_chain_equals_the_in_chain_kernels(n, L):
     _lib.check(lib.svdd_gru_bidir_bwd2_f32(gout.data_ptr(), out1.data_ptr(), save1.data_ptr(), wbwd.data_ptr(), scratch.data_ptr(), None,
                                            nogate.data_ptr(), n, L, st), "bwd2 no gate")
     assert float((nogate - (dx[0] + dx[1])).abs().max()) <= 2e-6 * float((dx[0] + dx[1]).abs().max())
+
+
+def test_reward_gradient_kernels_one_by_one_vs_torch():
+    """The ABI-11 entry points of the reward net's gradient pass, each alone against torch (autograd where it is a backward):
+    svdd_reward_stem_f32 / _bwd_f32 (4 -> 64 x 15 taps on real-valued rows), svdd_conv1d_cl_gated_f32 (transposed 64 -> 64 x 5
+    convolution + residual + ReLU gate), svdd_reward_tail_grad_f32 (direction sum + LayerNorm + FFN + head + means: forward and
+    backward in one pass), svdd_sum_gate_f32."""
+    import ctypes
+    import torch.nn.functional as F
+    from svdd_amd import _lib
+    from svdd_amd.fused import pack_conv
+    lib, st = _lib.lib(), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    torch.manual_seed(0)
+    n, L = 7, 200
+    # stem
+    x = torch.rand(n, L, 4, device=DEV)
+    w = torch.randn(64, 4, 15, device=DEV) * 0.2
+    b = torch.randn(64, device=DEV) * 0.1
+    wk = w.permute(2, 1, 0).reshape(-1, 64).contiguous()                        # [(t, c)][co]
+    f = torch.empty(n, L, 64, device=DEV)
+    _lib.check(lib.svdd_reward_stem_f32(x.data_ptr(), wk.data_ptr(), b.data_ptr(), f.data_ptr(), n, L, 15, st), "stem")
+    xr = x.clone().requires_grad_(True)
+    want = F.relu(F.conv1d(xr.transpose(1, 2), w, b, padding=7)).transpose(1, 2)
+    assert float((f - want.detach()).abs().max()) <= 1e-5
+    g = torch.randn(n, L, 64, device=DEV) * 1e-3
+    gm = torch.where(want > 0, g, torch.zeros_like(g)).contiguous()             # the gradient at the pre-activation
+    want.backward(g)
+    dx = torch.empty(n, L, 4, device=DEV)
+    _lib.check(lib.svdd_reward_stem_bwd_f32(gm.data_ptr(), wk.data_ptr(), dx.data_ptr(), n, L, 15, st), "stem bwd")
+    assert float((dx - xr.grad).abs().max()) <= 1e-6 * max(1.0, float(xr.grad.abs().max()) * 1e3)
+    # gated transposed convolution: y = gate > 0 ? conv^T(g) + g : 0
+    w5 = torch.randn(64, 64, 5, device=DEV) * 0.1
+    wt = pack_conv(w5.flip(2).transpose(0, 1).contiguous())
+    fin = torch.randn(n, L, 64, device=DEV)
+    fr = fin.clone().requires_grad_(True)
+    out = F.conv1d(F.relu(fr).transpose(1, 2), w5, None, padding=2).transpose(1, 2) + F.relu(fr)   # conv(relu(f)) + relu(f): residual block on a gated input
+    out.backward(g)
+    y = torch.empty(n, L, 64, device=DEV)
+    gc = g.contiguous()
+    _lib.check(lib.svdd_conv1d_cl_gated_f32(gc.data_ptr(), wt.data_ptr(), y.data_ptr(), n, L, 64, 64, 5, 1, gc.data_ptr(), fin.data_ptr(), st), "gated conv")
+    assert float((y - fr.grad).abs().max()) <= 2e-6
+    # tail: d mean_n(mean_l(w_eff . relu(W1 LN(h0 + h1) + b1))) / d (h0 + h1)
+    h = torch.randn(2, n, L, 64, device=DEV)
+    w1, b1 = torch.randn(128, 64, device=DEV) * 0.2, torch.randn(128, device=DEV) * 0.1
+    gam, bet, weff = torch.rand(64, device=DEV) + 0.5, torch.randn(64, device=DEV) * 0.1, torch.randn(128, device=DEV)
+    hr = h.clone().requires_grad_(True)
+    z = F.relu(F.linear(F.layer_norm(hr[0] + hr[1], (64,), gam, bet, 1e-5), w1, b1))
+    ((z @ weff).mean(dim=1)).mean().backward()
+    gout = torch.empty_like(h)
+    _lib.check(lib.svdd_reward_tail_grad_f32(h[0].data_ptr(), h[1].data_ptr(), w1.data_ptr(), b1.data_ptr(), gam.data_ptr(), bet.data_ptr(),
+                                             weff.data_ptr(), 1e-5, n, L, gout[0].data_ptr(), gout[1].data_ptr(), st), "tail grad")
+    sc = float(hr.grad.abs().max())
+    assert float((gout[0] - hr.grad[0]).abs().max()) <= 2e-5 * sc and torch.equal(gout[0], gout[1])
+    # sum + gate
+    a_, b_ = torch.randn(n, L, 64, device=DEV), torch.randn(n, L, 64, device=DEV)
+    sg = torch.empty_like(a_)
+    _lib.check(lib.svdd_sum_gate_f32(a_.data_ptr(), b_.data_ptr(), fin.data_ptr(), sg.data_ptr(), a_.numel(), st), "sum gate")
+    assert torch.equal(sg, torch.where(fin > 0, a_ + b_, torch.zeros_like(a_)))

@@ -631,3 +631,23 @@ def test_side_streams_sit_on_hardware_queues_of_their_own():
             if a is not b:
                 assert not o._held_up_by(a, b)
     assert o._held_up_by(cur, cur)                      # the test itself sees a shared queue when there is one
+
+
+@pytest.mark.parametrize("B,M", [(256, 10), (1 << 18, 10), (70000, 20)])
+def test_select_decision_only_form_equals_the_full_kernel(ops, B, M):
+    """svdd_select with x_next = NULL (round 6's measurement of what the index gather costs): the decision alone — idx — must be the
+    full kernel's, at the decode's size and at the saturated sizes (the 4-row-group launch), near-tied scores included."""
+    import ctypes
+    from svdd_amd import _lib
+    L = 200
+    g = torch.Generator(device="cuda").manual_seed(B + M)
+    scores = torch.randn(B, M, device="cuda", generator=g) * 1e-7 + 0.01
+    scores[::7] = torch.randn((B + 6) // 7, M, device="cuda", generator=g)
+    cand = torch.randint(0, 5, (B, M, L), device="cuda", generator=g, dtype=torch.uint8)
+    _, _, idx = ops.select(scores, cand, want_soft=False)
+    idx2 = torch.full((B,), -1, dtype=torch.int32, device="cuda")
+    rc = _lib.lib().svdd_select(scores.data_ptr(), cand.data_ptr(), B, L, M, ops.SELECT_ARGMAX, None, None, None, idx2.data_ptr(),
+                                ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0 and torch.equal(idx, idx2)
+    assert _lib.lib().svdd_select(scores.data_ptr(), cand.data_ptr(), B, L, M, ops.SELECT_ARGMAX, None, None, None, None,
+                                  ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)) == _lib.E_ARG      # neither output: refused
