@@ -2542,8 +2542,17 @@ __global__ __launch_bounds__(256, 2) void value_tail_kernel(const float* __restr
                                                             const float* __restrict__ weff, const float* __restrict__ beff,
                                                             float* __restrict__ out, int n_alloc, int L,
                                                             const int* __restrict__ count) {
+  // b1' and w_eff per output column, [j][8 ct | 8 ct x T]: read from LDS every tile (lgkmcnt, not the row prefetch's vmcnt) instead of
+  // living in 8 + 8 T registers — with W1' (128), the accumulators (32) and two row sets the kernel sat at the 256-register limit and
+  // spilled its lane offsets, reloading them from scratch every tile.
+  __shared__ __attribute__((aligned(16))) float colv[16][8 + 8 * T];
+  for (int e = threadIdx.x; e < 16 * (8 + 8 * T); e += 256) {
+    const int jj = e / (8 + 8 * T), r = e - jj * (8 + 8 * T);
+    colv[jj][r] = r < 8 ? b1[16 * r + jj] : weff[(16 * ((r - 8) / T) + jj) * T + (r - 8) % T];
+  }
+  __syncthreads();
   const int lane = threadIdx.x & 63;
-  const int seq = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int seq = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));   // wave-uniform: the row bases stay in SGPRs
   const int n = count ? *count : n_alloc;
   if (seq >= n) return;
   const int j = lane & 15, g = lane >> 4;
@@ -2555,26 +2564,25 @@ __global__ __launch_bounds__(256, 2) void value_tail_kernel(const float* __restr
 #pragma unroll
     for (int i = 0; i < 32; ++i) { const float4 v = wp[i]; wb[4 * i] = v.x; wb[4 * i + 1] = v.y; wb[4 * i + 2] = v.z; wb[4 * i + 3] = v.w; }
   }
-  float bias1[8], we[8][T];
+  // Round 6: the operands above are PINNED here (they must have arrived before the loop). Left pending, their loads share the
+  // in-order vmcnt counter with the row prefetches, and the compiler's conservative waits inside the loop (s_waitcnt vmcnt(3..1) in
+  // the middle of the MFMA block) drained each tile's prefetch a third of the way into the tile it was meant to fly under.
 #pragma unroll
-  for (int ct = 0; ct < 8; ++ct) {
-    bias1[ct] = b1[16 * ct + j];
-#pragma unroll
-    for (int t = 0; t < T; ++t) we[ct][t] = weff[(16 * ct + j) * T + t];
-  }
+  for (int i = 0; i < 128; ++i) asm volatile("" : "+v"(wb[i]));
   float part[T];
 #pragma unroll
   for (int t = 0; t < T; ++t) part[t] = 0.0f;
-  const float* pf = hf + (size_t)seq * L * 64 + 4 * g;
-  const float* pb = hb + (size_t)seq * L * 64 + 4 * g;
+  const float* sf = hf + (size_t)seq * L * 64;             // scalar bases + a 32-bit lane offset (L * 64 floats < 2^31 bytes per sequence)
+  const float* sb = hb + (size_t)seq * L * 64;
   const int ntiles = (L + 15) / 16;
   float4 xa[4], xb[4];
   auto load_rows = [&](int tile) {
-    const int row = min(16 * tile + j, L - 1);            // rows past the end re-read the last row; masked below
-    const float4* a4 = reinterpret_cast<const float4*>(pf + (size_t)row * 64);
-    const float4* b4 = reinterpret_cast<const float4*>(pb + (size_t)row * 64);
+    const int off = min(16 * tile + j, L - 1) * 64 + 4 * g;   // rows past the end re-read the last row; masked below
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { xa[i] = a4[4 * i]; xb[i] = b4[4 * i]; }
+    for (int i = 0; i < 4; ++i) {
+      xa[i] = *reinterpret_cast<const float4*>(sf + off + 16 * i);
+      xb[i] = *reinterpret_cast<const float4*>(sb + off + 16 * i);
+    }
   };
   load_rows(0);
   for (int tile = 0; tile < ntiles; ++tile) {
@@ -2584,7 +2592,11 @@ __global__ __launch_bounds__(256, 2) void value_tail_kernel(const float* __restr
       v[4 * i] = xa[i].x + xb[i].x; v[4 * i + 1] = xa[i].y + xb[i].y;
       v[4 * i + 2] = xa[i].z + xb[i].z; v[4 * i + 3] = xa[i].w + xb[i].w;
     }
-    if (tile + 1 < ntiles) load_rows(tile + 1);           // fly under the LayerNorm and the 128 MFMAs below
+    // the next tile's loads go into the registers the sums above just freed (hoisted above the sums, as the scheduler would, they
+    // need a second set of 32 registers + 32 copies per tile, and that spilled the row pointers into scratch inside the loop)
+    __builtin_amdgcn_sched_barrier(0);
+    load_rows(min(tile + 1, ntiles - 1));                 // fly under the LayerNorm and the 128 MFMAs below (unconditional: a branch
+    __builtin_amdgcn_sched_barrier(0);                    // here becomes a block of its own, placed BEFORE the sums; the last tile re-reads itself)
     // LayerNorm (no affine: folded into W1', b1') over the 64 channels of row 16 tile + j: 16 here, 48 in lanes j + 16 g'
     float sm = 0.0f;
 #pragma unroll
@@ -2598,14 +2610,23 @@ __global__ __launch_bounds__(256, 2) void value_tail_kernel(const float* __restr
     const float rstd = rsqrtf(sq * (1.0f / 64.0f) + 1e-5f);
 #pragma unroll
     for (int i = 0; i < 16; ++i) v[i] *= rstd;
+    int jj = j;
+    asm volatile("" : "+v"(jj));                           // opaque per tile: the LDS reads stay in the loop (the INDEX, not the pointer:
+    const float* cv = colv[jj];                            // a laundered pointer turns generic and its flat loads wait on vmcnt too)
     f32x4 acc[8];
 #pragma unroll
-    for (int ct = 0; ct < 8; ++ct) acc[ct] = f32x4{bias1[ct], bias1[ct], bias1[ct], bias1[ct]};
+    for (int ct = 0; ct < 8; ++ct) { const float b = cv[ct]; acc[ct] = f32x4{b, b, b, b}; }
 #pragma unroll
     for (int sidx = 0; sidx < 16; ++sidx)
 #pragma unroll
       for (int ct = 0; ct < 8; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[sidx], wb[16 * ct + sidx], acc[ct], 0, 0, 0);
     // C/D layout: reg rho -> row 4 g + rho, column 16 ct + j
+    constexpr bool HOIST = T <= 3;                         // w_eff of this lane's columns: one LDS read per tile, not one per row
+    float wl[HOIST ? 8 * T : 1];                           // (T = 4: 32 more registers would spill; read per row there)
+    if constexpr (HOIST) {
+#pragma unroll
+      for (int i = 0; i < 8 * T; ++i) wl[i] = cv[8 + i];
+    }
 #pragma unroll
     for (int rho = 0; rho < 4; ++rho) {
       if (16 * tile + 4 * g + rho < L) {
@@ -2613,7 +2634,7 @@ __global__ __launch_bounds__(256, 2) void value_tail_kernel(const float* __restr
         for (int ct = 0; ct < 8; ++ct) {
           const float z = fmaxf(acc[ct][rho], 0.0f);
 #pragma unroll
-          for (int t = 0; t < T; ++t) part[t] += z * we[ct][t];
+          for (int t = 0; t < T; ++t) part[t] += z * (HOIST ? wl[ct * T + t] : cv[8 + ct * T + t]);
         }
       }
     }

@@ -321,7 +321,23 @@ PERTURB = {
     "bench": ["true"],
     "variants": {name: [(_EPS, _EPS.replace("1e-5f", val))] for name, val in (("eps1.2", "1.2e-5f"), ("eps2", "2e-5f"), ("eps10", "1e-4f"))},
 }
-SETS = {"perturb": PERTURB, "bb_f32_small": BB_F32_SMALL, "tower_lp_timing": TOWER_LP_TIMING, "bb_f32_timing": BB_F32_TIMING, "bb_lpt_timing": BB_LPT_TIMING, "bb_lpt": BB_LPT, "gru_pc": GRU_PC, "gru_lp": GRU_LP, "tower_lp": TOWER_LP, "bb_lp": BB_LP, "k1": K1, "tower2": TOWER2}
+TAIL = {
+    "file": "svdd_nets.hip",
+    "bench": ["python", "tools/tail_microbench.py"],
+    "variants": {
+        "baseline": [],
+        "nomfma": [("      for (int ct = 0; ct < 8; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[sidx], wb[16 * ct + sidx], acc[ct], 0, 0, 0);",
+                    "      for (int ct = 0; ct < 8; ++ct) acc[ct][sidx & 3] += v[sidx] * wb[16 * ct + sidx];")],
+        "noln": [("    sm += __shfl_xor(sm, 16, 64); sm += __shfl_xor(sm, 32, 64);\n    const float mean = sm * (1.0f / 64.0f);", "    const float mean = sm * (1.0f / 64.0f);"),
+                 ("    sq += __shfl_xor(sq, 16, 64); sq += __shfl_xor(sq, 32, 64);\n    const float rstd = rsqrtf(sq * (1.0f / 64.0f) + 1e-5f);", "    const float rstd = sq * (1.0f / 64.0f) + 1e-5f;")],
+        "noload": [("    load_rows(min(tile + 1, ntiles - 1));                 // fly under", "    if (n == 12345) load_rows(min(tile + 1, ntiles - 1));                 // fly under")],
+        "noepi": [("          const float z = fmaxf(acc[ct][rho], 0.0f);\n#pragma unroll\n          for (int t = 0; t < T; ++t) part[t] += z * (HOIST ? wl[ct * T + t] : cv[8 + ct * T + t]);",
+                   "          part[0] += acc[ct][rho];")],      # every accumulator is still read (the MFMAs stay): no max, no multiply
+        "lb1": [("template <int T>\n__global__ __launch_bounds__(256, 2) void value_tail_kernel(", "template <int T>\n__global__ __launch_bounds__(256, 1) void value_tail_kernel(")],
+    },
+}
+TAIL["variants"]["nomfma_noln_noepi"] = TAIL["variants"]["nomfma"] + TAIL["variants"]["noln"] + TAIL["variants"]["noepi"]
+SETS = {"tail": TAIL, "perturb": PERTURB, "bb_f32_small": BB_F32_SMALL, "tower_lp_timing": TOWER_LP_TIMING, "bb_f32_timing": BB_F32_TIMING, "bb_lpt_timing": BB_LPT_TIMING, "bb_lpt": BB_LPT, "gru_pc": GRU_PC, "gru_lp": GRU_LP, "tower_lp": TOWER_LP, "bb_lp": BB_LP, "k1": K1, "tower2": TOWER2}
 
 
 def build_variant(setname, name, spec):
