@@ -280,7 +280,7 @@ def roofline_also(line):
             e["ms_per_forward"] = r["gemm_ms_per_forward"]
         also.append(e)
     rv = line.get("roofline_value_net") or {}
-    for key, name in (("conv_tower", "conv_tower2_kernel"), ("gru", "gru_pc_kernel")):
+    for key, name in (("conv_tower", "conv_tower2_kernel"), ("gru", "gru_pc_kernel"), ("tail", "value_tail_kernel")):
         if key in rv:
             add(f"roofline_value_net.{key}.decode", name, "C2 decode, executed rows", rv[key].get("decode"))
             add(f"roofline_value_net.{key}.dense", name, "2560 whole sequences", rv[key].get("dense"))
@@ -714,7 +714,9 @@ def value_net_roofline(model, emb, head, dev, B, L, M, S, tower_ms, tower_launch
     fn.split_gru_rounds = split_was
     st, model.skip_stats = model.skip_stats, None
     (tower_ms, tower_launches), (gru_ms, gru_launches) = _lib.profile_collect(5), _lib.profile_collect(3)
-    for k in (0, 1, 6, 7):
+    tail_ms, tail_launches = _lib.profile_collect(7)
+    tail_row = 2.0 * C * 2 * C                                  # the 64 -> 128 map of the FFN on the matrix cores, per row
+    for k in (0, 1, 6):
         _lib.profile_collect(k)
     out = {"timing": "per-dispatch HIP events of one extra decode of the same Philox stream with the value net as ONE part per step "
                      "(kernel-exclusive; the timed decodes run the late steps as two parts on two streams, DESIGN section 4b)"}
@@ -725,28 +727,31 @@ def value_net_roofline(model, emb, head, dev, B, L, M, S, tower_ms, tower_launch
     for key, kern, flops, ms, n in (("conv_tower", "conv_tower2_kernel (value net: stem + 5 residual conv blocks; candidates' row windows)",
                                      tower_row * rows_t, tower_ms, tower_launches),
                                     ("gru", "gru_pc_kernel (value net: bidirectional GRU 64 -> 64; live candidates only)",
-                                     gru_row * rows_g, gru_ms, gru_launches)):
+                                     gru_row * rows_g, gru_ms, gru_launches),
+                                    ("tail", "value_tail_kernel (value net after the GRU: direction sum + LayerNorm + FFN 64 -> 128 + ReLU + collapsed head + "
+                                             "mean over length; live candidates only; fp32 MFMA and the vector ALU share one datapath, the non-MFMA third adds on top)",
+                                     tail_row * rows_g, tail_ms, tail_launches)):
         tf = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         out[key] = {"bound": "mfma", "kernel": kern, "decode": {
             "achieved": round(tf, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / FP32_PEAK_TFLOPS, 5),
             "executed_flops_per_decode": round(flops), "kernel_ms_per_decode": round(ms, 3), "launches": n}}
     out["executed"] = {"tower_rows": int(rows_t), "gru_rows": int(rows_g), "nominal_rows": B * M * L * S,
                        "live_candidates": st["live_candidates"], "candidates": st["candidates"],
-                       "flops_per_tower_row": tower_row, "flops_per_gru_row": gru_row}
+                       "flops_per_tower_row": tower_row, "flops_per_gru_row": gru_row, "flops_per_tail_row": tail_row}
     # dense: whole sequences
     n = B * M
     tok = torch.randint(0, 5, (n, L), device=dev, dtype=torch.uint8)
     for _ in range(3):
         fn.forward_tokens(tok)
     torch.cuda.synchronize()
-    for k in (3, 5):
+    for k in (3, 5, 7):
         _lib.profile_collect(k)
     _lib.profile_enable(True)
     for _ in range(10):
         fn.forward_tokens(tok)
     torch.cuda.synchronize()
     _lib.profile_enable(False)
-    for key, slot, per_row in (("conv_tower", 5, tower_row), ("gru", 3, gru_row)):
+    for key, slot, per_row in (("conv_tower", 5, tower_row), ("gru", 3, gru_row), ("tail", 7, tail_row)):
         tot, k = _lib.profile_collect(slot)
         ms = tot / max(k, 1)
         tf = per_row * n * L / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
@@ -772,6 +777,7 @@ def value_net_roofline(model, emb, head, dev, B, L, M, S, tower_ms, tower_launch
                                 "flops_per_launch": round(gru_row * n2 * L), "avg_launch_us": round(ms * 1e3, 2), "launches": k,
                                 "workload": f"{n2} whole sequences of length {L} (one unit per CU)"}
     _lib.profile_collect(5)
+    _lib.profile_collect(7)
     return out
 
 

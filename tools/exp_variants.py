@@ -336,6 +336,9 @@ TAIL = {
         "lb1": [("template <int T>\n__global__ __launch_bounds__(256, 2) void value_tail_kernel(", "template <int T>\n__global__ __launch_bounds__(256, 1) void value_tail_kernel(")],
     },
 }
+for _nm, _cond in (("skew_hi", "((blockIdx.x >> 8) & 1)"), ("skew_lo", "(blockIdx.x & 1)"), ("skew_wave", "((threadIdx.x >> 6) & 1)")):
+    TAIL["variants"][_nm] = [("  load_rows(0);\n  for (int tile = 0; tile < ntiles; ++tile) {\n    float v[16];",
+                              "  load_rows(0);\n  if (" + _cond + ") __builtin_amdgcn_s_sleep(56);\n  for (int tile = 0; tile < ntiles; ++tile) {\n    float v[16];")]
 TAIL["variants"]["nomfma_noln_noepi"] = TAIL["variants"]["nomfma"] + TAIL["variants"]["noln"] + TAIL["variants"]["noepi"]
 SETS = {"tail": TAIL, "perturb": PERTURB, "bb_f32_small": BB_F32_SMALL, "tower_lp_timing": TOWER_LP_TIMING, "bb_f32_timing": BB_F32_TIMING, "bb_lpt_timing": BB_LPT_TIMING, "bb_lpt": BB_LPT, "gru_pc": GRU_PC, "gru_lp": GRU_LP, "tower_lp": TOWER_LP, "bb_lp": BB_LP, "k1": K1, "tower2": TOWER2}
 
