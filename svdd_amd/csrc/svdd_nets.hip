@@ -239,13 +239,15 @@ __global__ __launch_bounds__(512) void gru_pc_kernel(const float* __restrict__ x
     if (L > 2) load_x(t0 + 2 * dt, 0);
     __syncthreads();
     // step s (consumers work on slot s & 1): project x_{s+1} into slot (s + 1) & 1, prefetch x_{s+3}
+    // (the prefetches are unconditional — past the end they re-read the last row: with a load on one path only, the compiler's
+    //  s_waitcnt before a projection became vmcnt(0) and drained the row issued just before it, not only the one it needs)
     for (int s = 0; s < L; s += 2) {
       if (s + 1 < L) project(1, 1);
-      if (s + 3 < L) load_x(t0 + (s + 3) * dt, 1);
+      load_x(t0 + min(s + 3, L - 1) * dt, 1);
       __syncthreads();
       if (s + 1 >= L) break;
       if (s + 2 < L) project(0, 0);
-      if (s + 4 < L) load_x(t0 + (s + 4) * dt, 0);
+      load_x(t0 + min(s + 4, L - 1) * dt, 0);
       __syncthreads();
     }
     return;

@@ -141,8 +141,8 @@ GRU_PC = {
                      "      hbuf[cur ^ 1][srow][u] = hn;\n      if (seq0 + srow < n && hn == 12345.0f) out[(((size_t)dir * n_alloc + seq0 + srow) * L + t) * H + u] = hn;\n    }\n    __syncthreads();\n  }\n}\n\n// ------------------------------------------------------------------ fused conv epilogue")],
         "noprod_mfma": [("      if (s + 1 < L) project(1, 1);", "      if (s + 1 < L && n == 12345) project(1, 1);"),
                         ("      if (s + 2 < L) project(0, 0);", "      if (s + 2 < L && n == 12345) project(0, 0);")],
-        "noprod_load": [("      if (s + 3 < L) load_x(t0 + (s + 3) * dt, 1);", "      if (s + 3 < L && n == 12345) load_x(t0 + (s + 3) * dt, 1);"),
-                        ("      if (s + 4 < L) load_x(t0 + (s + 4) * dt, 0);", "      if (s + 4 < L && n == 12345) load_x(t0 + (s + 4) * dt, 0);")],
+        "noprod_load": [("      load_x(t0 + min(s + 3, L - 1) * dt, 1);", "      if (n == 12345) load_x(t0 + min(s + 3, L - 1) * dt, 1);"),
+                        ("      load_x(t0 + min(s + 4, L - 1) * dt, 0);", "      if (n == 12345) load_x(t0 + min(s + 4, L - 1) * dt, 0);")],
         "norec_mfma": [("    for (int s = 0; s < 16; ++s) {\n      acc_nh = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[s], wr[2][s], acc_nh, 0, 0, 0);",
                         "    for (int s = 0; s < 16 && n == 12345; ++s) {\n      acc_nh = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[s], wr[2][s], acc_nh, 0, 0, 0);")],
     },
